@@ -1,0 +1,183 @@
+/*
+ * pxo.h -- CPU ORACLE for the featuremetric KA/BA hot path of cvg/pixel-perfect-sfm.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load liboracle.so.  The product path
+ * (pixel-perfect-sfm_amd/) never links, imports or calls anything in this directory.
+ *
+ * It is a plain-C restatement (no Eigen / Ceres / COLMAP) of the reference's arithmetic.
+ * Every function cites the reference file:line (relative to /root/reference) it follows;
+ * [upstream] marks formulas that live in un-vendored third-party code (Ceres >= 2.1,
+ * COLMAP 3.8) and are restated from their published algorithms.
+ *
+ * Parity status: the spline + grid arithmetic (A2) is pinned bit-exactly against the
+ * reference's own cubic_hermite_spline_simd.h / grid2d.h compiled in place
+ * (oracle/_ref, see oracle/Makefile) and against the reference's interpolation test
+ * cases.  The residual functors (A7-A10), the LM solvers and the reference extraction
+ * have no golden vectors in the reference and cannot be run here (Ceres/COLMAP absent):
+ * for those rows "parity unpinned" -- they are validated by finite differences and
+ * closed-form properties only.
+ */
+#ifndef PXO_H_
+#define PXO_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { PXO_F16 = 0, PXO_F32 = 1, PXO_F64 = 2 };
+
+/* COLMAP 3.8 camera model ids [upstream colmap/base/camera_models.h] */
+enum {
+  PXO_SIMPLE_PINHOLE = 0,
+  PXO_PINHOLE = 1,
+  PXO_SIMPLE_RADIAL = 2,
+  PXO_RADIAL = 3,
+  PXO_OPENCV = 4,
+  PXO_OPENCV_FISHEYE = 5,
+  PXO_FULL_OPENCV = 6,
+  PXO_SIMPLE_RADIAL_FISHEYE = 8,
+  PXO_RADIAL_FISHEYE = 9
+};
+
+/* Ceres loss functions [upstream ceres/loss_function.h] */
+enum { PXO_LOSS_TRIVIAL = 0, PXO_LOSS_CAUCHY = 1, PXO_LOSS_HUBER = 2, PXO_LOSS_SOFTL1 = 3 };
+
+/* FeaturePatch descriptor: features/src/featurepatch.h:40-156 (HWC, channel fastest). */
+typedef struct {
+  const void* data; /* H*W*C elements of dtype                                 */
+  int32_t dtype;    /* PXO_F16 / PXO_F32 / PXO_F64                             */
+  int32_t H, W, C;
+  int32_t x0, y0;   /* corner_                                                 */
+  double sx, sy;    /* scale_                                                  */
+  double up;        /* upsampling_factor_ (1.0 for feature patches)            */
+} pxo_patch;
+
+/* InterpolationConfig (base/src/interpolation.h:39-51); BICUBIC, N_NODES=1 only. */
+typedef struct {
+  int32_t l2_normalize;
+  int32_t use_float_simd;
+  int32_t check_bounds;
+} pxo_interp_cfg;
+
+typedef struct {
+  int32_t type;  /* PXO_LOSS_*                  */
+  double a;      /* scale parameter             */
+} pxo_loss;
+
+/* ---- fp16 helpers -------------------------------------------------------------- */
+float pxo_half_to_float(uint16_t h);
+uint16_t pxo_float_to_half(float f);
+void pxo_halfs_to_floats(const uint16_t* h, float* f, int64_t n);
+void pxo_floats_to_halfs(const float* f, uint16_t* h, int64_t n);
+
+/* ---- A2: Catmull-Rom spline + bicubic ------------------------------------------- */
+/* cubic_hermite_spline_simd.h:123-192 (IN_T = half/float): fp32 math for channels
+ * [0, C - C%8), scalar fp64 tail beyond; results widened to double. */
+void pxo_spline_lowp(const void* p0, const void* p1, const void* p2, const void* p3,
+                     int dtype, int C, double x, int round_out_to_float, double* f,
+                     double* dfdx);
+/* cubic_hermite_spline_simd.h:56-121 (double input). */
+void pxo_spline_f64(const double* p0, const double* p1, const double* p2, const double* p3,
+                    int C, double x, double* f, double* dfdx);
+/* ceres::CubicHermiteSpline [upstream ceres/cubic_interpolation.h], all-fp64 Horner. */
+void pxo_spline_ceres(const double* p0, const double* p1, const double* p2, const double* p3,
+                      int C, double x, double* f, double* dfdx);
+/* BiCubicInterpolator::Evaluate (interpolation.h:177-274): AVX2 path semantics for
+ * C >= 8, scalar Ceres path for C < 8. (r,c) in patch texel coordinates. */
+void pxo_bicubic(const pxo_patch* p, double r, double c, int use_float_simd, double* f,
+                 double* dfdr, double* dfdc);
+/* ceres::BiCubicInterpolator [upstream] on a border-clamped grid: all-fp64. */
+void pxo_bicubic_ceres(const pxo_patch* p, double r, double c, double* f, double* dfdr,
+                       double* dfdc);
+
+/* ---- A3: PixelInterpolator::Evaluate (interpolation.h:642-677) -------------------- */
+void pxo_pixel_interp(const pxo_patch* p, double r, double c, const pxo_interp_cfg* cfg,
+                      double* f, double* dfdr, double* dfdc);
+
+/* ---- A1/A5: PatchInterpolator::Evaluate (patch_interpolator.h:125-135) ------------
+ * xy in COLMAP image coordinates; returns is_inside (always 1 unless check_bounds).
+ * dfdx/dfdy are derivatives w.r.t. the image coordinates (Jet bridge A4 applied to
+ * featurepatch.h:250-255). Either may be NULL. */
+int pxo_patch_eval(const pxo_patch* p, const double xy[2], const pxo_interp_cfg* cfg,
+                   double* f, double* dfdx, double* dfdy);
+
+/* ---- A6: projection ------------------------------------------------------------- */
+int pxo_camera_num_params(int model);
+/* CameraModel::WorldToImage [upstream COLMAP]; J_uv 2x2 row-major, J_k 2xK row-major. */
+int pxo_world_to_image(int model, const double* params, double u, double v, double* x,
+                       double* y, double* J_uv, double* J_k);
+/* WorldToPixel (base/src/projection.h:60-75). Jacobians row-major 2x4, 2x3, 2x3, 2xK;
+ * J_q is the ambient derivative (includes the normalisation inside
+ * ceres::QuaternionRotatePoint). Any Jacobian pointer may be NULL. */
+int pxo_world_to_pixel(int model, const double* params, const double q[4], const double t[3],
+                       const double X[3], double xy[2], double* J_q, double* J_t, double* J_X,
+                       double* J_k);
+
+/* ---- A7-A10: residual functors ---------------------------------------------------- */
+/* FeatureReferenceCostFunctor (residuals/src/feature_reference.h:98-137).
+ * r[C]; Jacobians row-major C x {4,3,3,K} as ceres::AutoDiffCostFunction emits. */
+int pxo_ba_residual(const pxo_patch* p, const pxo_interp_cfg* cfg, int model,
+                    const double q[4], const double t[3], const double X[3],
+                    const double* params, const double* ref, double* r, double* Jq,
+                    double* Jt, double* JX, double* Jk);
+/* FeatureMetric2DCostFunctor (residuals/src/featuremetric.h:44-63). J1,J2: C x 2. */
+int pxo_ka_residual(const pxo_patch* p1, const pxo_patch* p2, const pxo_interp_cfg* cfg,
+                    const double kp1[2], const double kp2[2], double* r, double* J1,
+                    double* J2);
+/* FeatureReference2DCostFunctor (residuals/src/feature_reference.h:44-60). */
+int pxo_ref2d_residual(const pxo_patch* p, const pxo_interp_cfg* cfg, const double kp[2],
+                       const double* ref, double* r, double* J);
+
+/* ---- A20: robustifier [upstream ceres/loss_function.cc, corrector.cc] ------------- */
+/* rho[0..2] = weight * (rho, rho', rho'') at s. */
+void pxo_loss_eval(const pxo_loss* loss, double weight, double s, double rho[3]);
+/* Corrector: in-place r~ = scale*r, J~ = sqrt(rho')(J - alpha/s r r^T J); J row-major C x n
+ * (may be NULL). */
+void pxo_corrector(double s, const double rho[3], int C, int n, double* r, double* J);
+
+/* ---- A19: reference extraction ---------------------------------------------------- */
+/* RobustMeanIRLS (base/src/irls_optim.h:24-71), N_NODES = 1. descs: n x C row-major.
+ * Returns the index of an observation if the early-return branch (rho <= 0) is taken
+ * (mean then holds that descriptor), else -1. */
+int pxo_robust_mean_irls(const double* descs, int n, int C, const pxo_loss* loss, int iters,
+                         int l2_normalize, double* mean);
+/* ComputeReference (bundle_adjustment/src/reference_extractor.h:238-272): returns the
+ * index of the observation closest to the robust mean; ref_out = that descriptor
+ * (closest_to_robust_mean = true) . */
+int pxo_compute_reference(const double* descs, int n, int C, const pxo_loss* loss, int iters,
+                          int l2_normalize, double* ref_out, double* robust_mean_out);
+
+/* ---- batch helpers (CPU baseline timing + test convenience) ----------------------- */
+typedef struct {
+  int64_t n_obs;
+  const int32_t* obs_image;   /* [n_obs] */
+  const int32_t* obs_point;   /* [n_obs] */
+  const int64_t* obs_patch;   /* [n_obs] index into patches */
+  const int32_t* image_camera;/* [n_images] */
+  const double* qvec;         /* [n_images][4] */
+  const double* tvec;         /* [n_images][3] */
+  const int32_t* cam_model;   /* [n_cams] */
+  const double* cam_params;   /* [n_cams][12] (padded) */
+  const double* xyz;          /* [n_points][3] */
+  const double* refs;         /* [n_points][C] */
+  /* uniform patch arena */
+  const void* arena; int32_t dtype, H, W, C;
+  const int32_t* corners;     /* [n_patches][2] */
+  const double* scales;       /* [n_patches][2] */
+} pxo_ba_batch;
+
+/* Evaluate residual + materialised 128 x n Jacobian blocks for obs [first, first+count),
+ * the way ceres::AutoDiffCostFunction hands them to Ceres; returns sum of 0.5*rho(s).
+ * Optional outputs (may be NULL): r_out [count][C], J_out [count][C][10+Kmax] with
+ * column layout q(4) t(3) X(3) k(Kpad=12).  n_threads <= 1 -> serial. */
+double pxo_ba_eval_batch(const pxo_ba_batch* b, const pxo_interp_cfg* cfg, const pxo_loss* loss,
+                         int64_t first, int64_t count, int n_threads, double* r_out,
+                         double* J_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PXO_H_ */

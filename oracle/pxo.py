@@ -1,0 +1,266 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so, oracle/_ref/libpxo_ref.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+F16, F32, F64 = 0, 1, 2
+KPAD = 12
+CAMERA_MODELS = {"SIMPLE_PINHOLE": 0, "PINHOLE": 1, "SIMPLE_RADIAL": 2, "RADIAL": 3, "OPENCV": 4}
+LOSSES = {"trivial": 0, "cauchy": 1, "huber": 2, "soft_l1": 3}
+_NP2DT = {np.dtype(np.float16): F16, np.dtype(np.float32): F32, np.dtype(np.float64): F64}
+
+c_double_p = C.POINTER(C.c_double)
+
+
+class Patch(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("dtype", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("C", C.c_int32), ("x0", C.c_int32), ("y0", C.c_int32), ("sx", C.c_double),
+                ("sy", C.c_double), ("up", C.c_double)]
+
+
+class InterpCfg(C.Structure):
+    _fields_ = [("l2_normalize", C.c_int32), ("use_float_simd", C.c_int32),
+                ("check_bounds", C.c_int32)]
+
+
+class Loss(C.Structure):
+    _fields_ = [("type", C.c_int32), ("a", C.c_double)]
+
+
+class BaBatch(C.Structure):
+    _fields_ = [("n_obs", C.c_int64), ("obs_image", C.c_void_p), ("obs_point", C.c_void_p),
+                ("obs_patch", C.c_void_p), ("image_camera", C.c_void_p), ("qvec", C.c_void_p),
+                ("tvec", C.c_void_p), ("cam_model", C.c_void_p), ("cam_params", C.c_void_p),
+                ("xyz", C.c_void_p), ("refs", C.c_void_p), ("arena", C.c_void_p),
+                ("dtype", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("corners", C.c_void_p), ("scales", C.c_void_p)]
+
+
+def build(force=False):
+    """Compile liboracle.so (and _ref when /root/reference is present)."""
+    so = os.path.join(HERE, "liboracle.so")
+    srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".c", ".h", ".cc"))]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", HERE, "-s"], stdout=subprocess.DEVNULL)
+    return so
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.pxo_half_to_float.restype = C.c_float
+        _lib.pxo_half_to_float.argtypes = [C.c_uint16]
+        _lib.pxo_float_to_half.restype = C.c_uint16
+        _lib.pxo_float_to_half.argtypes = [C.c_float]
+        _lib.pxo_ba_eval_batch.restype = C.c_double
+        _lib.pxo_ba_eval_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                           C.c_int, C.c_void_p, C.c_void_p]
+    return _lib
+
+
+def ref():
+    """The reference's own spline/grid headers compiled in place (None if not built)."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(HERE, "_ref", "libpxo_ref.so")
+        if not os.path.exists(path):
+            return None
+        _ref = C.CDLL(path)
+        _ref.pxo_ref_bicubic_many_half128.restype = C.c_double
+    return _ref
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def make_patch(data, corner=(0, 0), scale=(1.0, 1.0), up=1.0):
+    """data: HxWxC numpy array (f16/f32/f64), C-contiguous. Keeps a reference alive."""
+    assert data.ndim == 3 and data.flags["C_CONTIGUOUS"]
+    p = Patch(data.ctypes.data, _NP2DT[data.dtype], data.shape[0], data.shape[1], data.shape[2],
+              int(corner[0]), int(corner[1]), float(scale[0]), float(scale[1]), float(up))
+    p._keep = data
+    return p
+
+
+def cfg(l2_normalize=True, use_float_simd=False, check_bounds=False):
+    return InterpCfg(int(l2_normalize), int(use_float_simd), int(check_bounds))
+
+
+def loss(name="cauchy", a=0.25):
+    return Loss(LOSSES[name], float(a))
+
+
+def bicubic(patch, r, c, use_float_simd=False):
+    n = patch.C
+    f, dr, dc = (np.empty(n) for _ in range(3))
+    lib().pxo_bicubic(C.byref(patch), C.c_double(r), C.c_double(c), int(use_float_simd), _p(f), _p(dr), _p(dc))
+    return f, dr, dc
+
+
+def bicubic_ceres(patch, r, c):
+    n = patch.C
+    f, dr, dc = (np.empty(n) for _ in range(3))
+    lib().pxo_bicubic_ceres(C.byref(patch), C.c_double(r), C.c_double(c), _p(f), _p(dr), _p(dc))
+    return f, dr, dc
+
+
+def ref_bicubic(data, r, c, use_float_simd=False):
+    H, W, n = data.shape
+    f, dr, dc = (np.empty(n) for _ in range(3))
+    rc = ref().pxo_ref_bicubic(_p(data), _NP2DT[data.dtype], H, W, n, C.c_double(r), C.c_double(c),
+                               int(use_float_simd), _p(f), _p(dr), _p(dc))
+    if rc != 0:
+        raise ValueError("channel count %d not instantiated in ref_shim.cc" % n)
+    return f, dr, dc
+
+
+def pixel_interp(patch, r, c, config):
+    n = patch.C
+    f, dr, dc = (np.empty(n) for _ in range(3))
+    lib().pxo_pixel_interp(C.byref(patch), C.c_double(r), C.c_double(c), C.byref(config), _p(f), _p(dr), _p(dc))
+    return f, dr, dc
+
+
+def patch_eval(patch, xy, config, want_grad=True):
+    n = patch.C
+    xy = np.ascontiguousarray(xy, dtype=np.float64)
+    f = np.empty(n)
+    gx, gy = (np.empty(n), np.empty(n)) if want_grad else (None, None)
+    inside = lib().pxo_patch_eval(C.byref(patch), _p(xy), C.byref(config), _p(f), _p(gx), _p(gy))
+    return f, gx, gy, inside
+
+
+def world_to_image(model, params, u, v):
+    K = lib().pxo_camera_num_params(model)
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    x, y = C.c_double(), C.c_double()
+    Juv, Jk = np.empty((2, 2)), np.empty((2, K))
+    rc = lib().pxo_world_to_image(model, _p(params), C.c_double(u), C.c_double(v), C.byref(x), C.byref(y), _p(Juv), _p(Jk))
+    assert rc == 0
+    return np.array([x.value, y.value]), Juv, Jk
+
+
+def world_to_pixel(model, params, q, t, X, jac=True):
+    K = lib().pxo_camera_num_params(model)
+    params, q, t, X = (np.ascontiguousarray(a, dtype=np.float64) for a in (params, q, t, X))
+    xy = np.empty(2)
+    if jac:
+        Jq, Jt, JX, Jk = np.empty((2, 4)), np.empty((2, 3)), np.empty((2, 3)), np.empty((2, K))
+    else:
+        Jq = Jt = JX = Jk = None
+    rc = lib().pxo_world_to_pixel(model, _p(params), _p(q), _p(t), _p(X), _p(xy), _p(Jq), _p(Jt), _p(JX), _p(Jk))
+    assert rc == 0
+    return xy, Jq, Jt, JX, Jk
+
+
+def ba_residual(patch, config, model, q, t, X, params, ref_desc, jac=True):
+    n = patch.C
+    K = lib().pxo_camera_num_params(model)
+    params, q, t, X = (np.ascontiguousarray(a, dtype=np.float64) for a in (params, q, t, X))
+    ref_desc = None if ref_desc is None else np.ascontiguousarray(ref_desc, dtype=np.float64)
+    r = np.empty(n)
+    if jac:
+        Jq, Jt, JX, Jk = np.empty((n, 4)), np.empty((n, 3)), np.empty((n, 3)), np.empty((n, K))
+    else:
+        Jq = Jt = JX = Jk = None
+    rc = lib().pxo_ba_residual(C.byref(patch), C.byref(config), model, _p(q), _p(t), _p(X), _p(params),
+                               _p(ref_desc), _p(r), _p(Jq), _p(Jt), _p(JX), _p(Jk))
+    assert rc >= 0
+    return r, Jq, Jt, JX, Jk
+
+
+def ka_residual(p1, p2, config, kp1, kp2, jac=True):
+    n = p1.C
+    kp1, kp2 = (np.ascontiguousarray(a, dtype=np.float64) for a in (kp1, kp2))
+    r = np.empty(n)
+    J1, J2 = (np.empty((n, 2)), np.empty((n, 2))) if jac else (None, None)
+    rc = lib().pxo_ka_residual(C.byref(p1), C.byref(p2), C.byref(config), _p(kp1), _p(kp2), _p(r), _p(J1), _p(J2))
+    assert rc >= 0
+    return r, J1, J2
+
+
+def ref2d_residual(p, config, kp, ref_desc, jac=True):
+    n = p.C
+    kp = np.ascontiguousarray(kp, dtype=np.float64)
+    ref_desc = np.ascontiguousarray(ref_desc, dtype=np.float64)
+    r = np.empty(n)
+    J = np.empty((n, 2)) if jac else None
+    lib().pxo_ref2d_residual(C.byref(p), C.byref(config), _p(kp), _p(ref_desc), _p(r), _p(J))
+    return r, J
+
+
+def loss_eval(ls, s, weight=1.0):
+    rho = np.empty(3)
+    lib().pxo_loss_eval(C.byref(ls), C.c_double(weight), C.c_double(s), _p(rho))
+    return rho
+
+
+def corrector(s, rho, r, J=None):
+    r = np.array(r, dtype=np.float64)
+    rho = np.ascontiguousarray(rho, dtype=np.float64)
+    n = 0
+    if J is not None:
+        J = np.array(J, dtype=np.float64, order="C")
+        n = J.shape[1]
+    lib().pxo_corrector(C.c_double(s), _p(rho), r.shape[0], n, _p(r), _p(J))
+    return r, J
+
+
+def robust_mean_irls(descs, ls, iters=100, l2_normalize=True):
+    descs = np.ascontiguousarray(descs, dtype=np.float64)
+    n, ch = descs.shape
+    mean = np.empty(ch)
+    early = lib().pxo_robust_mean_irls(_p(descs), n, ch, C.byref(ls), iters, int(l2_normalize), _p(mean))
+    return mean, early
+
+
+def compute_reference(descs, ls, iters=100, l2_normalize=True):
+    descs = np.ascontiguousarray(descs, dtype=np.float64)
+    n, ch = descs.shape
+    ref_out, mean = np.empty(ch), np.empty(ch)
+    idx = lib().pxo_compute_reference(_p(descs), n, ch, C.byref(ls), iters, int(l2_normalize), _p(ref_out), _p(mean))
+    return idx, ref_out, mean
+
+
+def ba_batch(problem):
+    """problem: dict of numpy arrays (see tests/synth.py). Returns (BaBatch, keepalive)."""
+    keep = {}
+
+    def arr(name, dt):
+        a = np.ascontiguousarray(problem[name], dtype=dt)
+        keep[name] = a
+        return a.ctypes.data
+
+    arena = np.ascontiguousarray(problem["patches"])
+    keep["patches"] = arena
+    n_p, H, W, ch = arena.shape
+    b = BaBatch(len(problem["obs_image"]), arr("obs_image", np.int32), arr("obs_point", np.int32),
+                arr("obs_patch", np.int64), arr("image_camera", np.int32), arr("qvec", np.float64),
+                arr("tvec", np.float64), arr("cam_model", np.int32), arr("cam_params", np.float64),
+                arr("xyz", np.float64), arr("refs", np.float64), arena.ctypes.data,
+                _NP2DT[arena.dtype], H, W, ch, arr("corners", np.int32), arr("scales", np.float64))
+    return b, keep
+
+
+def ba_eval_batch(problem, config, ls, first=0, count=None, n_threads=1, want_r=False, want_J=False):
+    b, keep = ba_batch(problem)
+    n = b.n_obs if count is None else count
+    ch = b.C
+    r = np.empty((n, ch)) if want_r else None
+    J = np.empty((n, ch, 10 + KPAD)) if want_J else None
+    cost = lib().pxo_ba_eval_batch(C.byref(b), C.byref(config), C.byref(ls), first, n, n_threads, _p(r), _p(J))
+    return cost, r, J

@@ -1,0 +1,150 @@
+/*
+ * pixsfm_hip.h -- C-ABI of the MI355X-native featuremetric refinement engine
+ * (libpixsfm_hip.so).  Drop-in boundary for pixsfm's keypoint-adjustment (KA) and
+ * bundle-adjustment (BA) hot path.
+ *
+ * The reference has no C plugin ABI: its seam is the pybind11 module pixsfm._pixsfm
+ * (pixsfm/_pixsfm/bindings.cc:34-63) and, at the finest grain,
+ * ceres::CostFunction::Evaluate(parameters, residuals, jacobians) [upstream Ceres]
+ * called once per residual block.  This ABI is the batched, flat-array replacement of
+ * that seam: plain pointers and sizes, no torch / pybind / Eigen types.  Each entry
+ * point cites the reference interface it replaces.  INTEGRATION.md shows the binding a
+ * pixsfm maintainer would add on the reference side.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative PXR_E* code on failure;
+ *    pxr_last_error() returns a thread-local message (the reference throws C++
+ *    exceptions mapped to Python, util/src/log_exceptions.h:52-116).
+ *  - pointers prefixed d_ are DEVICE pointers (HBM), h_ are host pointers.
+ *  - all work is enqueued on the context's HIP stream; functions that return host
+ *    values synchronise that stream.
+ *  - parameters are optimised IN PLACE in the caller's (device) arrays, like the
+ *    reference does in caller memory (featuremetric_keypoint_optimizer.h:195-196,
+ *    feature_reference_bundle_optimizer.h:111-114).
+ *  - layouts: patches H x W x C channel-fastest (features/src/featurepatch.cc:160-163);
+ *    qvec w-first (COLMAP); cam_params padded to PXR_KPAD doubles per camera.
+ */
+#ifndef PIXSFM_HIP_H_
+#define PIXSFM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PXR_KPAD 12 /* camera parameter slots per camera (FULL_OPENCV has 12) */
+#define PXR_OBS_REC 8 /* doubles per fused observation record */
+
+enum { PXR_OK = 0, PXR_EINVAL = -1, PXR_EHIP = -2, PXR_ENOMEM = -3, PXR_EUNSUPPORTED = -4,
+       PXR_ENUMERIC = -5 };
+enum { PXR_F16 = 0, PXR_F32 = 1, PXR_F64 = 2 };
+/* COLMAP 3.8 camera model ids (CAMERA_MODEL_SWITCH_CASES, residuals/src/feature_reference.h:232) */
+enum { PXR_SIMPLE_PINHOLE = 0, PXR_PINHOLE = 1, PXR_SIMPLE_RADIAL = 2, PXR_RADIAL = 3,
+       PXR_OPENCV = 4 };
+/* ceres loss functions reachable through options.loss
+ * (keypoint_adjustment_options.h:53, bundle_adjustment_options.h:49) */
+enum { PXR_LOSS_TRIVIAL = 0, PXR_LOSS_CAUCHY = 1, PXR_LOSS_HUBER = 2, PXR_LOSS_SOFTL1 = 3 };
+
+typedef struct pxr_ctx pxr_ctx;
+typedef struct pxr_arena pxr_arena;
+
+/* InterpolationConfig (base/src/interpolation.h:39-51, base/bindings.cc:134-154).
+ * Only mode = BICUBIC with one node is on the hot path; other modes are rejected. */
+typedef struct {
+  int32_t l2_normalize;   /* default 1 */
+  int32_t use_float_simd; /* default 0: fp32 horizontal pass, fp64 vertical pass */
+  int32_t check_bounds;   /* default 0 */
+} pxr_interp_cfg;
+
+typedef struct {
+  int32_t type; /* PXR_LOSS_* */
+  double a;     /* scale (Cauchy(0.25) is the reference default) */
+} pxr_loss;
+
+/* ---- context / errors ------------------------------------------------------------- */
+int pxr_version(void);
+const char* pxr_last_error(void);
+/* device: HIP device ordinal; stream: a hipStream_t (e.g. torch's current stream
+ * handle) or NULL for the device's default stream. */
+int pxr_ctx_create(int device, void* stream, pxr_ctx** out);
+int pxr_ctx_destroy(pxr_ctx* ctx);
+int pxr_ctx_sync(pxr_ctx* ctx);
+/* plain device-memory plumbing so that a host without torch can drive the library */
+int pxr_malloc(pxr_ctx* ctx, size_t bytes, void** d_ptr);
+int pxr_free(pxr_ctx* ctx, void* d_ptr);
+int pxr_memcpy_h2d(pxr_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int pxr_memcpy_d2h(pxr_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+int pxr_memset(pxr_ctx* ctx, void* d_dst, int value, size_t bytes);
+/* HIP-event timer on the context's stream: start/stop bracket enqueued work;
+ * pxr_timer_stop synchronises and returns elapsed milliseconds. */
+int pxr_timer_start(pxr_ctx* ctx);
+int pxr_timer_stop(pxr_ctx* ctx, double* ms);
+
+/* ---- patch arena --------------------------------------------------------------------
+ * Flat HBM-resident replacement of the FeaturePatch/FeatureMap/FeatureSet/FeatureView
+ * container hierarchy (features/src/featurepatch.h:40-156, featureview.cc:44-55): n
+ * patches of identical H x W x C and dtype, patch i at data + i*H*W*C, with per-patch
+ * corner_ (x0,y0) and scale_ (sx,sy) (upsampling_factor_ is 1 for feature patches). */
+int pxr_arena_create(pxr_ctx* ctx, int dtype, int C, int H, int W, int64_t n_patches,
+                     void* d_data_or_null /* adopt caller's device buffer, non-owning */,
+                     pxr_arena** out);
+int pxr_arena_destroy(pxr_arena* a);
+/* copy `count` patches (host, HWC) and their metadata; corners int32[count][2],
+ * scales double[count][2].  h_patches may be NULL to only set metadata. */
+int pxr_arena_upload(pxr_arena* a, int64_t first, int64_t count, const void* h_patches,
+                     const int32_t* h_corners, const double* h_scales);
+void* pxr_arena_data(pxr_arena* a);     /* device pointer of patch 0 */
+int32_t* pxr_arena_corners(pxr_arena* a); /* device int32[n][2] */
+double* pxr_arena_scales(pxr_arena* a);   /* device double[n][2] */
+int64_t pxr_arena_size(pxr_arena* a);
+
+/* ---- BA evaluation -------------------------------------------------------------------
+ * Batched replacement of FeatureReferenceCostFunctor / ...ConstantPoseCostFunctor
+ * ::operator() under ceres::AutoDiffCostFunction
+ * (residuals/src/feature_reference.h:71-148,157-207), one unit = one observation =
+ * one residual block of C residuals.  All arrays are device pointers. */
+typedef struct {
+  int64_t n_obs;
+  const int32_t* d_obs_image; /* [n_obs] index into qvec/tvec/image_camera */
+  const int32_t* d_obs_point; /* [n_obs] index into xyz/refs */
+  const int64_t* d_obs_patch; /* [n_obs] index into the arena */
+  int32_t n_images;
+  const int32_t* d_image_camera; /* [n_images] */
+  const double* d_qvec;          /* [n_images][4] */
+  const double* d_tvec;          /* [n_images][3] */
+  int32_t n_cameras;
+  const int32_t* d_cam_model;    /* [n_cameras] PXR_* model id */
+  const double* d_cam_params;    /* [n_cameras][PXR_KPAD] */
+  int64_t n_points;
+  const double* d_xyz;           /* [n_points][3] */
+  const double* d_refs;          /* [n_points][C]  Reference::descriptor (references.h:65) */
+} pxr_ba_view;
+
+/* Fused evaluation.  Per observation i writes the record d_rec[i][0..7]:
+ *   [0] s = r.r   [1] gx.gx  [2] gx.gy  [3] gy.gy  [4] gx.r  [5] gy.r  [6] x  [7] y
+ * where r = f(x,y) - ref (C residuals), gx = dr/dx, gy = dr/dy (image coordinates) and
+ * (x,y) = WorldToPixel(...) (base/src/projection.h:60-75).  The C x n Jacobian of the
+ * block is J = [gx gy] * d(x,y)/d(params) (Jet bridge, base/src/interpolation.h:130-140),
+ * so J^T J, J^T r and the robustifier's corrector are functions of this record and of
+ * the 2 x n projection Jacobian only; the 128-row Jacobian is never materialised.
+ * with_jacobian = 0 evaluates only s, x, y (trial-point cost evaluation).
+ * Optional materialised outputs for parity checks (NULL to skip):
+ *   d_r [n_obs][C], d_gx [n_obs][C], d_gy [n_obs][C]. */
+int pxr_ba_eval(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view,
+                const pxr_interp_cfg* cfg, int with_jacobian, double* d_rec, double* d_r,
+                double* d_gx, double* d_gy);
+
+/* Projection Jacobians for parity checks: d_P [n_obs][2][10 + PXR_KPAD], columns
+ * q(4, ambient) t(3) X(3) k(PXR_KPAD); row 0 = dx/d., row 1 = dy/d. */
+int pxr_ba_projection_jacobian(pxr_ctx* ctx, const pxr_ba_view* view, double* d_P);
+
+/* Sum of 0.5 * rho(s_i) over the records (ceres cost), robustifier A20. */
+int pxr_ba_cost(pxr_ctx* ctx, const double* d_rec, int64_t n_obs, const pxr_loss* loss,
+                double* h_cost);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIXSFM_HIP_H_ */

@@ -1,0 +1,427 @@
+// pxr_ba_eval.hip -- the featuremetric BA residual kernel for gfx950 (MI355X).
+//
+// One unit of work = one observation = one residual block of C residuals:
+//   (x,y) = WorldToPixel(camera, q, t, X)                         base/src/projection.h:60-75
+//   f     = normalised bicubic descriptor of the obs' patch at (x,y)
+//                                                                 base/src/interpolation.h:177-218,642-677
+//   r     = f - ref_descriptor(point)                             residuals/src/feature_reference.h:132-134
+// The reference materialises a C x (10+K) Jacobian per block through ceres::Jet
+// (interpolation.h:130-140).  Because J = [gx gy] * d(x,y)/dparams, everything
+// C-dimensional collapses to six dot products, which this kernel reduces inside the wave.
+//
+// Mapping (wave64, CDNA4): an observation occupies one DPP row = 16 lanes, each lane owns 8
+// consecutive channels (16 B of fp16 per texel), so
+//   * every texel fetch is one global_load_dwordx4 per lane, 256 B contiguous per row,
+//     and the 4 x 4 stencil = 16 such loads in flight per lane (HBM-latency cover);
+//   * the horizontal / vertical Catmull-Rom passes need no cross-lane traffic at all;
+//   * the channel reductions are 4 DPP steps inside the row (no LDS, no ds_bpermute).
+// A row processes 16 consecutive observations: lane s first computes the projection of
+// observation s (so the fp64 geometry is not replicated 16x), then the row walks the 16
+// observations, broadcasting (u,v,patch,point) from the owning lane.  At the end lane s holds
+// the 64-byte record of observation s and the row stores 1 KiB contiguously.
+//
+// Precision contract = the reference's: fp32 FMA horizontal pass on fp16/fp32 texels, fp64
+// vertical pass, fp64 normalisation (use_float_simd: fp32 vertical pass), identical
+// operation order -> bit-identical h/f values; only the 16-lane reduction order differs.
+#include <hip/hip_runtime.h>
+
+#include "pxr_device.h"
+#include "pxr_internal.h"
+
+namespace pxr {
+
+struct BaEvalArgs {
+  pxr_ba_view v;
+  const void* arena;
+  const int32_t* corners;
+  const double* scales;
+  int H, W;
+  int l2_normalize;
+  double* rec;
+  double* out_r;
+  double* out_gx;
+  double* out_gy;
+};
+
+template <typename ST>
+struct Texel8;  // 8 consecutive channels of one texel, widened for the horizontal pass
+
+template <>
+struct Texel8<_Float16> {
+  typedef float work_t;
+  uint4 raw;
+  __device__ __forceinline__ void load(const _Float16* p) { raw = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void unpack(float out[8]) const {
+    union { uint4 u; half8_t h; } cvt;
+    cvt.u = raw;
+    const float8_t f = __builtin_convertvector(cvt.h, float8_t);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = f[i];
+  }
+};
+template <>
+struct Texel8<float> {
+  typedef float work_t;
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = *reinterpret_cast<const float4*>(p);
+    b = *reinterpret_cast<const float4*>(p + 4);
+  }
+  __device__ __forceinline__ void unpack(float out[8]) const {
+    out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
+    out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+  }
+};
+template <>
+struct Texel8<double> {
+  typedef double work_t;
+  double2 a, b, c, d;
+  __device__ __forceinline__ void load(const double* p) {
+    a = *reinterpret_cast<const double2*>(p);
+    b = *reinterpret_cast<const double2*>(p + 2);
+    c = *reinterpret_cast<const double2*>(p + 4);
+    d = *reinterpret_cast<const double2*>(p + 6);
+  }
+  __device__ __forceinline__ void unpack(double out[8]) const {
+    out[0] = a.x; out[1] = a.y; out[2] = b.x; out[3] = b.y;
+    out[4] = c.x; out[5] = c.y; out[6] = d.x; out[7] = d.y;
+  }
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Normalised descriptor + gradients of 8 channels of one observation, all lanes of the
+// observation's lane group cooperating.  LPO = lanes per observation (C / 8).
+template <typename ST, int LPO, bool WITH_JAC, bool FLOAT_SIMD>
+__device__ __forceinline__ void interp8(const ST* __restrict__ patch, int H, int W, int C, int sub,
+                                        double u, double v, bool l2_normalize, double f[8],
+                                        double fr[8], double fc[8]) {
+  // BiCubicInterpolator::EvaluateSIMD: r = v (row), c = u (column)
+  const double rf = floor(v), cf = floor(u);
+  const int row = (int)rf, col = (int)cf;
+  const double dy = v - rf, dx = u - cf;
+  int ro[4], co[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    ro[j] = clampi(row - 1 + j, 0, H - 1) * W;   // Grid2D::GetPointer clamping, grid2d.h:64-73
+    co[j] = clampi(col - 1 + j, 0, W - 1);
+  }
+  Texel8<ST> tx[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tx[j][i].load(patch + (size_t)(ro[j] + co[i]) * C + sub * 8);
+
+  typedef typename Texel8<ST>::work_t HT;  // horizontal-pass arithmetic type
+  HT h[4][8], hd[4][8];
+  if constexpr (sizeof(HT) == 4) {
+    const SplineCoefF32 kh(dx);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float p0[8], p1[8], p2[8], p3[8];
+      tx[j][0].unpack(p0); tx[j][1].unpack(p1); tx[j][2].unpack(p2); tx[j][3].unpack(p3);
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        float dd = 0.f;
+        spline_f32<WITH_JAC>(p0[ch], p1[ch], p2[ch], p3[ch], kh, h[j][ch], dd);
+        hd[j][ch] = dd;
+      }
+    }
+  } else {
+    const SplineCoefF64 kh(dx);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double p0[8], p1[8], p2[8], p3[8];
+      tx[j][0].unpack(p0); tx[j][1].unpack(p1); tx[j][2].unpack(p2); tx[j][3].unpack(p3);
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        double ff = 0, dd = 0;
+        spline_f64<true, WITH_JAC>(p0[ch], p1[ch], p2[ch], p3[ch], kh, ff, dd);
+        if (FLOAT_SIMD) { ff = (double)(float)ff; dd = (double)(float)dd; }
+        h[j][ch] = ff; hd[j][ch] = dd;
+      }
+    }
+  }
+  // vertical pass
+  if constexpr (FLOAT_SIMD) {
+    const SplineCoefF32 kv(dy);
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+      float ff, dd = 0.f, cc = 0.f, dummy = 0.f;
+      spline_f32<WITH_JAC>((float)h[0][ch], (float)h[1][ch], (float)h[2][ch], (float)h[3][ch], kv, ff, dd);
+      if (WITH_JAC)
+        spline_f32<false>((float)hd[0][ch], (float)hd[1][ch], (float)hd[2][ch], (float)hd[3][ch], kv, cc, dummy);
+      f[ch] = (double)ff; fr[ch] = (double)dd; fc[ch] = (double)cc;
+    }
+  } else {
+    const SplineCoefF64 kv(dy);
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+      double ff = 0, dd = 0, cc = 0, dummy = 0;
+      spline_f64<true, WITH_JAC>((double)h[0][ch], (double)h[1][ch], (double)h[2][ch], (double)h[3][ch], kv, ff, dd);
+      if (WITH_JAC)
+        spline_f64<true, false>((double)hd[0][ch], (double)hd[1][ch], (double)hd[2][ch], (double)hd[3][ch], kv, cc, dummy);
+      f[ch] = ff; fr[ch] = dd; fc[ch] = cc;
+    }
+  }
+  // PixelInterpolator::Evaluate L2 normalisation + chain rule, interpolation.h:648-666
+  if (l2_normalize) {
+    double ss = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) ss = fma(f[ch], f[ch], ss);
+    ss = (LPO == 16) ? row16_sum(ss) : row8_sum(ss);
+    const double ninv = 1.0 / sqrt(ss);
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) f[ch] *= ninv;
+    if (WITH_JAC) {
+      double dc = 0.0, dr = 0.0;
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        fc[ch] *= ninv; fr[ch] *= ninv;
+        dc = fma(f[ch], fc[ch], dc);
+        dr = fma(f[ch], fr[ch], dr);
+      }
+      if (LPO == 16) { dc = row16_sum(dc); dr = row16_sum(dr); }
+      else { dc = row8_sum(dc); dr = row8_sum(dr); }
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        fc[ch] = fma(-dc, f[ch], fc[ch]);
+        fr[ch] = fma(-dr, f[ch], fr[ch]);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+  union { double d; int i[2]; } a;
+  a.d = v;
+  a.i[0] = __shfl(a.i[0], src);
+  a.i[1] = __shfl(a.i[1], src);
+  return a.d;
+}
+__device__ __forceinline__ int64_t shfl_i64(int64_t v, int src) {
+  union { int64_t l; int i[2]; } a;
+  a.l = v;
+  a.i[0] = __shfl(a.i[0], src);
+  a.i[1] = __shfl(a.i[1], src);
+  return a.l;
+}
+
+template <typename ST, int C, bool WITH_JAC, bool FLOAT_SIMD>
+__global__ __launch_bounds__(256) void ba_eval_kernel(const BaEvalArgs a) {
+  constexpr int LPO = C / 8;            // lanes per observation (16 for C = 128)
+  constexpr int GPW = 64 / LPO;         // observation groups per wave
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & (LPO - 1);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t obs0 = (wave * GPW + (lane / LPO)) * LPO;   // first observation of this lane group
+  const int64_t n = a.v.n_obs;
+  if (wave * 64 >= n) return;                               // whole wave out of range (uniform)
+
+  // ---- prologue: lane `sub` owns the geometry of observation obs0 + sub -----------------
+  const int64_t mine = obs0 + sub;
+  const bool mine_valid = mine < n;
+  const int64_t oi = mine_valid ? mine : n - 1;
+  const int img = a.v.d_obs_image[oi];
+  const int pt = a.v.d_obs_point[oi];
+  const int64_t pidx = a.v.d_obs_patch[oi];
+  const int cam = a.v.d_image_camera[img];
+  double q[4], t[3], X[3], k[PXR_KPAD];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = a.v.d_qvec[4 * (size_t)img + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { t[i] = a.v.d_tvec[3 * (size_t)img + i]; X[i] = a.v.d_xyz[3 * (size_t)pt + i]; }
+#pragma unroll
+  for (int i = 0; i < PXR_KPAD; ++i) k[i] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + i];
+  double my_x, my_y;
+  world_to_pixel(a.v.d_cam_model[cam], k, q, t, X, my_x, my_y);
+  // FeaturePatch::ToPixelCoordinates, featurepatch.h:250-255 (upsampling_factor_ = 1)
+  const double sx = a.scales[2 * pidx], sy = a.scales[2 * pidx + 1];
+  const double my_u = (my_x * sx - 0.5 - (double)a.corners[2 * pidx]);
+  const double my_v = (my_y * sy - 0.5 - (double)a.corners[2 * pidx + 1]);
+
+  double rec[PXR_OBS_REC];
+#pragma unroll
+  for (int i = 0; i < PXR_OBS_REC; ++i) rec[i] = 0.0;
+  rec[6] = my_x; rec[7] = my_y;
+
+  const size_t patch_elems = (size_t)a.H * a.W * C;
+  const ST* arena = reinterpret_cast<const ST*>(a.arena);
+  const int row_base = lane & ~(LPO - 1);
+
+  for (int it = 0; it < LPO; ++it) {
+    if (obs0 + it >= n) break;   // uniform within the lane group
+    const int src = row_base | it;
+    const double u = shfl_f64(my_u, src), v = shfl_f64(my_v, src);
+    const int64_t pi = shfl_i64(pidx, src);
+    const int pti = __shfl(pt, src);
+    // reference descriptor slice of this lane: 8 doubles (issued before the texel math)
+    const double* refp = a.v.d_refs + (size_t)pti * C + sub * 8;
+    double2 rf0 = *reinterpret_cast<const double2*>(refp);
+    double2 rf1 = *reinterpret_cast<const double2*>(refp + 2);
+    double2 rf2 = *reinterpret_cast<const double2*>(refp + 4);
+    double2 rf3 = *reinterpret_cast<const double2*>(refp + 6);
+
+    double f[8], fr[8], fc[8];
+    interp8<ST, LPO, WITH_JAC, FLOAT_SIMD>(arena + (size_t)pi * patch_elems, a.H, a.W, C, sub, u, v,
+                                           a.l2_normalize != 0, f, fr, fc);
+    const double ref[8] = {rf0.x, rf0.y, rf1.x, rf1.y, rf2.x, rf2.y, rf3.x, rf3.y};
+    double r[8];
+    double s = 0, gcc = 0, gcr = 0, grr = 0, bc = 0, br = 0;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+      r[ch] = f[ch] - ref[ch];
+      s = fma(r[ch], r[ch], s);
+      if (WITH_JAC) {
+        gcc = fma(fc[ch], fc[ch], gcc);
+        gcr = fma(fc[ch], fr[ch], gcr);
+        grr = fma(fr[ch], fr[ch], grr);
+        bc = fma(fc[ch], r[ch], bc);
+        br = fma(fr[ch], r[ch], br);
+      }
+    }
+    if (LPO == 16) {
+      s = row16_sum(s);
+      if (WITH_JAC) { gcc = row16_sum(gcc); gcr = row16_sum(gcr); grr = row16_sum(grr); bc = row16_sum(bc); br = row16_sum(br); }
+    } else {
+      s = row8_sum(s);
+      if (WITH_JAC) { gcc = row8_sum(gcc); gcr = row8_sum(gcr); grr = row8_sum(grr); bc = row8_sum(bc); br = row8_sum(br); }
+    }
+    if (sub == it) { rec[0] = s; rec[1] = gcc; rec[2] = gcr; rec[3] = grr; rec[4] = bc; rec[5] = br; }
+
+    if (a.out_r) {   // materialise mode (parity checks): r, dr/dx, dr/dy per channel
+      const double ax = shfl_f64(sx, src), ay = shfl_f64(sy, src);
+      const size_t o = (size_t)(obs0 + it) * C + sub * 8;
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        a.out_r[o + ch] = r[ch];
+        if (WITH_JAC && a.out_gx) { a.out_gx[o + ch] = fc[ch] * ax; a.out_gy[o + ch] = fr[ch] * ay; }
+      }
+    }
+  }
+  if (mine_valid) {
+    // Jet bridge: d/dx = dfdc * sx, d/dy = dfdr * sy  (interpolation.h:130-140 + featurepatch.h:250-255)
+    rec[1] *= sx * sx; rec[2] *= sx * sy; rec[3] *= sy * sy; rec[4] *= sx; rec[5] *= sy;
+    double2* o = reinterpret_cast<double2*>(a.rec + (size_t)mine * PXR_OBS_REC);
+    o[0] = make_double2(rec[0], rec[1]);
+    o[1] = make_double2(rec[2], rec[3]);
+    o[2] = make_double2(rec[4], rec[5]);
+    o[3] = make_double2(rec[6], rec[7]);
+  }
+}
+
+// ---- projection Jacobians (parity checks) ------------------------------------------------
+__global__ __launch_bounds__(256) void ba_projjac_kernel(const pxr_ba_view v, double* __restrict__ P) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= v.n_obs) return;
+  const int img = v.d_obs_image[i], pt = v.d_obs_point[i], cam = v.d_image_camera[img];
+  double q[4], t[3], X[3], k[PXR_KPAD];
+  for (int j = 0; j < 4; ++j) q[j] = v.d_qvec[4 * (size_t)img + j];
+  for (int j = 0; j < 3; ++j) { t[j] = v.d_tvec[3 * (size_t)img + j]; X[j] = v.d_xyz[3 * (size_t)pt + j]; }
+  for (int j = 0; j < PXR_KPAD; ++j) k[j] = v.d_cam_params[(size_t)cam * PXR_KPAD + j];
+  double x, y, A[2][3], Pq[2][4], PX[2][3], Pk[2][PXR_KPAD];
+  world_to_pixel_jac(v.d_cam_model[cam], k, q, t, X, x, y, A, Pq, PX, Pk);
+  const int NJ = 10 + PXR_KPAD;
+  double* o = P + (size_t)i * 2 * NJ;
+  for (int r = 0; r < 2; ++r) {
+    for (int j = 0; j < 4; ++j) o[r * NJ + j] = Pq[r][j];
+    for (int j = 0; j < 3; ++j) o[r * NJ + 4 + j] = A[r][j];   // dp/dt = I
+    for (int j = 0; j < 3; ++j) o[r * NJ + 7 + j] = PX[r][j];
+    for (int j = 0; j < PXR_KPAD; ++j) o[r * NJ + 10 + j] = Pk[r][j];
+  }
+}
+
+// ---- cost = sum 0.5 rho(s) ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_cost_kernel(const double* __restrict__ rec, int64_t n,
+                                                      pxr_loss loss, double* __restrict__ out) {
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double rho[3];
+    loss_eval(loss.type, loss.a, 1.0, rec[i * PXR_OBS_REC], rho);
+    acc += 0.5 * rho[0];
+  }
+  // wave reduce then one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) acc += shfl_f64(acc, (threadIdx.x & 63) ^ off);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+template <typename ST, int C>
+static int launch_eval(pxr_ctx* ctx, const BaEvalArgs& a, bool with_jac, bool float_simd) {
+  constexpr int LPO = C / 8;
+  const int64_t obs_per_block = 4 * 64;   // 4 waves x (64/LPO groups x LPO obs)
+  const int64_t blocks = (a.v.n_obs + obs_per_block - 1) / obs_per_block;
+  (void)LPO;
+  if (blocks == 0) return PXR_OK;
+  dim3 grid((unsigned)blocks), block(256);
+  if (with_jac) {
+    if (float_simd) hipLaunchKernelGGL((ba_eval_kernel<ST, C, true, true>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((ba_eval_kernel<ST, C, true, false>), grid, block, 0, ctx->stream, a);
+  } else {
+    if (float_simd) hipLaunchKernelGGL((ba_eval_kernel<ST, C, false, true>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((ba_eval_kernel<ST, C, false, false>), grid, block, 0, ctx->stream, a);
+  }
+  return pxr::hip_check(hipGetLastError(), "ba_eval_kernel launch");
+}
+
+template <typename ST>
+static int launch_eval_c(pxr_ctx* ctx, int C, const BaEvalArgs& a, bool with_jac, bool float_simd) {
+  switch (C) {
+    case 128: return launch_eval<ST, 128>(ctx, a, with_jac, float_simd);
+    case 64: return launch_eval<ST, 64>(ctx, a, with_jac, float_simd);
+    default:
+      return set_error(PXR_EUNSUPPORTED, "pxr_ba_eval: CHANNELS=%d not supported (128, 64)", C);
+  }
+}
+
+}  // namespace pxr
+
+extern "C" {
+
+int pxr_ba_eval(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
+                int with_jacobian, double* d_rec, double* d_r, double* d_gx, double* d_gy) {
+  PXR_REQUIRE(ctx && arena && view && cfg && d_rec, "pxr_ba_eval: NULL argument");
+  PXR_REQUIRE(view->n_obs >= 0, "pxr_ba_eval: negative n_obs");
+  PXR_REQUIRE((d_gx == nullptr) == (d_gy == nullptr), "pxr_ba_eval: d_gx and d_gy must be given together");
+  PXR_REQUIRE(!(d_gx && !d_r), "pxr_ba_eval: d_gx/d_gy require d_r");
+  if (view->n_obs == 0) return PXR_OK;
+  PXR_HIP(hipSetDevice(ctx->device));
+  pxr::BaEvalArgs a;
+  a.v = *view;
+  a.arena = arena->d_data; a.corners = arena->d_corners; a.scales = arena->d_scales;
+  a.H = arena->H; a.W = arena->W; a.l2_normalize = cfg->l2_normalize;
+  a.rec = d_rec; a.out_r = d_r; a.out_gx = d_gx; a.out_gy = d_gy;
+  const bool wj = with_jacobian != 0, fs = cfg->use_float_simd != 0;
+  switch (arena->dtype) {
+    case PXR_F16: return pxr::launch_eval_c<_Float16>(ctx, arena->C, a, wj, fs);
+    case PXR_F32: return pxr::launch_eval_c<float>(ctx, arena->C, a, wj, fs);
+    case PXR_F64: return pxr::launch_eval_c<double>(ctx, arena->C, a, wj, fs);
+  }
+  return pxr::set_error(PXR_EINVAL, "pxr_ba_eval: bad arena dtype");
+}
+
+int pxr_ba_projection_jacobian(pxr_ctx* ctx, const pxr_ba_view* view, double* d_P) {
+  PXR_REQUIRE(ctx && view && d_P, "pxr_ba_projection_jacobian: NULL argument");
+  if (view->n_obs == 0) return PXR_OK;
+  PXR_HIP(hipSetDevice(ctx->device));
+  const unsigned blocks = (unsigned)((view->n_obs + 255) / 256);
+  hipLaunchKernelGGL(pxr::ba_projjac_kernel, dim3(blocks), dim3(256), 0, ctx->stream, *view, d_P);
+  return pxr::hip_check(hipGetLastError(), "ba_projjac_kernel launch");
+}
+
+int pxr_ba_cost(pxr_ctx* ctx, const double* d_rec, int64_t n_obs, const pxr_loss* loss, double* h_cost) {
+  PXR_REQUIRE(ctx && d_rec && loss && h_cost, "pxr_ba_cost: NULL argument");
+  PXR_HIP(hipSetDevice(ctx->device));
+  PXR_HIP(hipMemsetAsync(ctx->d_scratch, 0, sizeof(double), ctx->stream));
+  if (n_obs > 0) {
+    int64_t blocks = (n_obs + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pxr::ba_cost_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_rec, n_obs,
+                       *loss, ctx->d_scratch);
+    PXR_HIP(hipGetLastError());
+  }
+  PXR_HIP(hipMemcpyAsync(h_cost, ctx->d_scratch, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PXR_HIP(hipStreamSynchronize(ctx->stream));
+  return PXR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+// pxr_internal.h -- host-side internals of libpixsfm_hip.so (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "pixsfm_hip.h"
+
+struct pxr_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  double* d_scratch = nullptr;   // small reduction scratch (device)
+  size_t scratch_bytes = 0;
+  int num_cus = 256;
+};
+
+struct pxr_arena {
+  pxr_ctx* ctx = nullptr;
+  int dtype = PXR_F16, C = 0, H = 0, W = 0;
+  int64_t n = 0;
+  void* d_data = nullptr;
+  bool owns_data = false;
+  int32_t* d_corners = nullptr;
+  double* d_scales = nullptr;
+  size_t elem_size() const { return dtype == PXR_F16 ? 2 : (dtype == PXR_F32 ? 4 : 8); }
+  size_t patch_bytes() const { return (size_t)H * W * C * elem_size(); }
+};
+
+namespace pxr {
+int set_error(int code, const char* fmt, ...);
+inline int hip_check(hipError_t e, const char* what) {
+  if (e == hipSuccess) return PXR_OK;
+  return set_error(PXR_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+}  // namespace pxr
+
+#define PXR_HIP(call)                                        \
+  do {                                                       \
+    int _rc = pxr::hip_check((call), #call);                 \
+    if (_rc != PXR_OK) return _rc;                           \
+  } while (0)
+
+#define PXR_REQUIRE(cond, ...)                               \
+  do {                                                       \
+    if (!(cond)) return pxr::set_error(PXR_EINVAL, __VA_ARGS__); \
+  } while (0)

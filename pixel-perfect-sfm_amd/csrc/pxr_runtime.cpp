@@ -1,0 +1,189 @@
+// pxr_runtime.cpp -- context, error reporting, device-memory plumbing and the patch arena.
+#include <cstring>
+#include <vector>
+
+#include "pxr_internal.h"
+
+namespace pxr {
+static thread_local std::string g_error;
+int set_error(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+}  // namespace pxr
+
+extern "C" {
+
+int pxr_version(void) { return 100; }
+
+const char* pxr_last_error(void) { return pxr::g_error.c_str(); }
+
+int pxr_ctx_create(int device, void* stream, pxr_ctx** out) {
+  PXR_REQUIRE(out != nullptr, "pxr_ctx_create: out is NULL");
+  int count = 0;
+  PXR_HIP(hipGetDeviceCount(&count));
+  PXR_REQUIRE(device >= 0 && device < count, "pxr_ctx_create: device %d out of range (%d visible)",
+              device, count);
+  PXR_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  PXR_HIP(hipGetDeviceProperties(&prop, device));
+  pxr_ctx* c = new pxr_ctx();
+  c->device = device;
+  c->stream = (hipStream_t)stream;
+  c->num_cus = prop.multiProcessorCount;
+  PXR_HIP(hipEventCreate(&c->ev_start));
+  PXR_HIP(hipEventCreate(&c->ev_stop));
+  c->scratch_bytes = 1 << 20;
+  PXR_HIP(hipMalloc((void**)&c->d_scratch, c->scratch_bytes));
+  *out = c;
+  return PXR_OK;
+}
+
+int pxr_ctx_destroy(pxr_ctx* ctx) {
+  if (!ctx) return PXR_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  if (ctx->d_scratch) hipFree(ctx->d_scratch);
+  if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_stop) hipEventDestroy(ctx->ev_stop);
+  delete ctx;
+  return PXR_OK;
+}
+
+int pxr_ctx_sync(pxr_ctx* ctx) {
+  PXR_REQUIRE(ctx, "pxr_ctx_sync: ctx is NULL");
+  PXR_HIP(hipStreamSynchronize(ctx->stream));
+  return PXR_OK;
+}
+
+int pxr_malloc(pxr_ctx* ctx, size_t bytes, void** d_ptr) {
+  PXR_REQUIRE(ctx && d_ptr, "pxr_malloc: NULL argument");
+  PXR_HIP(hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
+  if (e == hipErrorOutOfMemory) return pxr::set_error(PXR_ENOMEM, "pxr_malloc: out of device memory (%zu bytes)", bytes);
+  return pxr::hip_check(e, "hipMalloc");
+}
+
+int pxr_free(pxr_ctx* ctx, void* d_ptr) {
+  PXR_REQUIRE(ctx, "pxr_free: ctx is NULL");
+  if (d_ptr) PXR_HIP(hipFree(d_ptr));
+  return PXR_OK;
+}
+
+int pxr_memcpy_h2d(pxr_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+  PXR_REQUIRE(ctx && (bytes == 0 || (d_dst && h_src)), "pxr_memcpy_h2d: NULL argument");
+  if (bytes == 0) return PXR_OK;
+  PXR_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  PXR_HIP(hipStreamSynchronize(ctx->stream));
+  return PXR_OK;
+}
+
+int pxr_memcpy_d2h(pxr_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+  PXR_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), "pxr_memcpy_d2h: NULL argument");
+  if (bytes == 0) return PXR_OK;
+  PXR_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  PXR_HIP(hipStreamSynchronize(ctx->stream));
+  return PXR_OK;
+}
+
+int pxr_memset(pxr_ctx* ctx, void* d_dst, int value, size_t bytes) {
+  PXR_REQUIRE(ctx && (bytes == 0 || d_dst), "pxr_memset: NULL argument");
+  if (bytes == 0) return PXR_OK;
+  PXR_HIP(hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+  return PXR_OK;
+}
+
+int pxr_timer_start(pxr_ctx* ctx) {
+  PXR_REQUIRE(ctx, "pxr_timer_start: ctx is NULL");
+  PXR_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
+  return PXR_OK;
+}
+
+int pxr_timer_stop(pxr_ctx* ctx, double* ms) {
+  PXR_REQUIRE(ctx && ms, "pxr_timer_stop: NULL argument");
+  PXR_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
+  PXR_HIP(hipEventSynchronize(ctx->ev_stop));
+  float f = 0.f;
+  PXR_HIP(hipEventElapsedTime(&f, ctx->ev_start, ctx->ev_stop));
+  *ms = (double)f;
+  return PXR_OK;
+}
+
+// ---- arena ---------------------------------------------------------------------------
+int pxr_arena_create(pxr_ctx* ctx, int dtype, int C, int H, int W, int64_t n_patches,
+                     void* d_data_or_null, pxr_arena** out) {
+  PXR_REQUIRE(ctx && out, "pxr_arena_create: NULL argument");
+  PXR_REQUIRE(dtype == PXR_F16 || dtype == PXR_F32 || dtype == PXR_F64,
+              "pxr_arena_create: unknown dtype %d", dtype);
+  PXR_REQUIRE(C >= 1 && H >= 1 && W >= 1 && n_patches >= 0,
+              "pxr_arena_create: invalid shape C=%d H=%d W=%d n=%lld", C, H, W, (long long)n_patches);
+  PXR_HIP(hipSetDevice(ctx->device));
+  pxr_arena* a = new pxr_arena();
+  a->ctx = ctx; a->dtype = dtype; a->C = C; a->H = H; a->W = W; a->n = n_patches;
+  const size_t bytes = a->patch_bytes() * (size_t)n_patches;
+  if (d_data_or_null) {
+    a->d_data = d_data_or_null;
+    a->owns_data = false;
+  } else {
+    hipError_t e = hipMalloc(&a->d_data, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+      delete a;
+      return pxr::set_error(e == hipErrorOutOfMemory ? PXR_ENOMEM : PXR_EHIP,
+                            "pxr_arena_create: hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    a->owns_data = true;
+  }
+  const size_t n1 = n_patches ? (size_t)n_patches : 1;
+  hipError_t e1 = hipMalloc((void**)&a->d_corners, n1 * 2 * sizeof(int32_t));
+  hipError_t e2 = hipMalloc((void**)&a->d_scales, n1 * 2 * sizeof(double));
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    pxr_arena_destroy(a);
+    return pxr::set_error(PXR_ENOMEM, "pxr_arena_create: metadata allocation failed");
+  }
+  *out = a;
+  return PXR_OK;
+}
+
+int pxr_arena_destroy(pxr_arena* a) {
+  if (!a) return PXR_OK;
+  hipSetDevice(a->ctx->device);
+  hipStreamSynchronize(a->ctx->stream);
+  if (a->owns_data && a->d_data) hipFree(a->d_data);
+  if (a->d_corners) hipFree(a->d_corners);
+  if (a->d_scales) hipFree(a->d_scales);
+  delete a;
+  return PXR_OK;
+}
+
+int pxr_arena_upload(pxr_arena* a, int64_t first, int64_t count, const void* h_patches,
+                     const int32_t* h_corners, const double* h_scales) {
+  PXR_REQUIRE(a, "pxr_arena_upload: arena is NULL");
+  PXR_REQUIRE(first >= 0 && count >= 0 && first + count <= a->n,
+              "pxr_arena_upload: range [%lld, %lld) outside arena of %lld patches", (long long)first,
+              (long long)(first + count), (long long)a->n);
+  if (count == 0) return PXR_OK;
+  hipStream_t s = a->ctx->stream;
+  if (h_patches)
+    PXR_HIP(hipMemcpyAsync((char*)a->d_data + a->patch_bytes() * (size_t)first, h_patches,
+                           a->patch_bytes() * (size_t)count, hipMemcpyHostToDevice, s));
+  if (h_corners)
+    PXR_HIP(hipMemcpyAsync(a->d_corners + 2 * first, h_corners, sizeof(int32_t) * 2 * count,
+                           hipMemcpyHostToDevice, s));
+  if (h_scales)
+    PXR_HIP(hipMemcpyAsync(a->d_scales + 2 * first, h_scales, sizeof(double) * 2 * count,
+                           hipMemcpyHostToDevice, s));
+  PXR_HIP(hipStreamSynchronize(s));
+  return PXR_OK;
+}
+
+void* pxr_arena_data(pxr_arena* a) { return a ? a->d_data : nullptr; }
+int32_t* pxr_arena_corners(pxr_arena* a) { return a ? a->d_corners : nullptr; }
+double* pxr_arena_scales(pxr_arena* a) { return a ? a->d_scales : nullptr; }
+int64_t pxr_arena_size(pxr_arena* a) { return a ? a->n : 0; }
+
+}  // extern "C"

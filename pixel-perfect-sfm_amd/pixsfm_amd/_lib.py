@@ -1,0 +1,95 @@
+"""ctypes loader of libpixsfm_hip.so (the C-ABI declared in include/pixsfm_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, an exception
+is raised.  Nothing under oracle/ is ever imported from the product package.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpixsfm_hip.so")
+
+KPAD = 12
+OBS_REC = 8
+F16, F32, F64 = 0, 1, 2
+CAMERA_MODEL_IDS = {"SIMPLE_PINHOLE": 0, "PINHOLE": 1, "SIMPLE_RADIAL": 2, "RADIAL": 3, "OPENCV": 4}
+LOSS_IDS = {"trivial": 0, "cauchy": 1, "huber": 2, "soft_l1": 3}
+
+
+class PixsfmHipError(RuntimeError):
+    pass
+
+
+class InterpCfg(C.Structure):
+    _fields_ = [("l2_normalize", C.c_int32), ("use_float_simd", C.c_int32), ("check_bounds", C.c_int32)]
+
+
+class Loss(C.Structure):
+    _fields_ = [("type", C.c_int32), ("a", C.c_double)]
+
+
+class BaView(C.Structure):
+    _fields_ = [("n_obs", C.c_int64), ("d_obs_image", C.c_void_p), ("d_obs_point", C.c_void_p),
+                ("d_obs_patch", C.c_void_p), ("n_images", C.c_int32), ("d_image_camera", C.c_void_p),
+                ("d_qvec", C.c_void_p), ("d_tvec", C.c_void_p), ("n_cameras", C.c_int32),
+                ("d_cam_model", C.c_void_p), ("d_cam_params", C.c_void_p), ("n_points", C.c_int64),
+                ("d_xyz", C.c_void_p), ("d_refs", C.c_void_p)]
+
+
+# every symbol include/pixsfm_hip.h declares (checked by tests/test_cabi.py)
+_SIGNATURES = {
+    "pxr_version": (C.c_int, []),
+    "pxr_last_error": (C.c_char_p, []),
+    "pxr_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pxr_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "pxr_ctx_sync": (C.c_int, [C.c_void_p]),
+    "pxr_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pxr_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pxr_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "pxr_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "pxr_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
+    "pxr_timer_start": (C.c_int, [C.c_void_p]),
+    "pxr_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "pxr_arena_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p,
+                                   C.POINTER(C.c_void_p)]),
+    "pxr_arena_destroy": (C.c_int, [C.c_void_p]),
+    "pxr_arena_upload": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pxr_arena_data": (C.c_void_p, [C.c_void_p]),
+    "pxr_arena_corners": (C.c_void_p, [C.c_void_p]),
+    "pxr_arena_scales": (C.c_void_p, [C.c_void_p]),
+    "pxr_arena_size": (C.c_int64, [C.c_void_p]),
+    "pxr_ba_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BaView), C.POINTER(InterpCfg), C.c_int,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pxr_ba_projection_jacobian": (C.c_int, [C.c_void_p, C.POINTER(BaView), C.c_void_p]),
+    "pxr_ba_cost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Loss), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def declared_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """Load libpixsfm_hip.so; raises PixsfmHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PixsfmHipError(
+            "libpixsfm_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().pxr_last_error()
+        raise PixsfmHipError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))

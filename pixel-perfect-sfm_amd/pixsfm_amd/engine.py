@@ -1,0 +1,240 @@
+"""Thin Python host layer over the C-ABI: context, device arrays, patch arena, BA problem.
+
+Everything numerical happens in libpixsfm_hip.so on the GPU.  numpy is used only to stage
+host arrays in and out.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import F16, F32, F64, KPAD, OBS_REC, BaView, InterpCfg, Loss, check
+
+_NP2DT = {np.dtype(np.float16): F16, np.dtype(np.float32): F32, np.dtype(np.float64): F64}
+
+
+class Context:
+    """One HIP device + stream.  `stream` may be a raw hipStream_t handle (int), e.g.
+    torch.cuda.current_stream().cuda_stream, so torch events see the kernels."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.pxr_ctx_create(int(device), C.c_void_p(stream or 0), C.byref(h)), "pxr_ctx_create")
+        self.handle = h
+        self.device = device
+
+    def sync(self):
+        check(self.lib.pxr_ctx_sync(self.handle), "pxr_ctx_sync")
+
+    def timer_start(self):
+        check(self.lib.pxr_timer_start(self.handle), "pxr_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_double()
+        check(self.lib.pxr_timer_stop(self.handle, C.byref(ms)), "pxr_timer_stop")
+        return ms.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.pxr_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- device arrays ------------------------------------------------------------------
+    def empty(self, shape, dtype):
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype):
+        a = DeviceArray(self, shape, dtype)
+        check(self.lib.pxr_memset(self.handle, a.ptr, 0, a.nbytes), "pxr_memset")
+        return a
+
+    def to_device(self, host, dtype=None):
+        host = np.ascontiguousarray(host, dtype=dtype)
+        a = DeviceArray(self, host.shape, host.dtype)
+        a.upload(host)
+        return a
+
+
+class DeviceArray:
+    """A typed HBM buffer owned through pxr_malloc/pxr_free."""
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in (shape if hasattr(shape, "__len__") else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(ctx.lib.pxr_malloc(ctx.handle, self.nbytes, C.byref(p)), "pxr_malloc")
+        self.ptr = p
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        assert host.nbytes == self.nbytes, (host.shape, self.shape)
+        check(self.ctx.lib.pxr_memcpy_h2d(self.ctx.handle, self.ptr, host.ctypes.data, self.nbytes), "pxr_memcpy_h2d")
+
+    def download(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(self.ctx.lib.pxr_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes), "pxr_memcpy_d2h")
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None) and self.ctx.handle:
+            self.ctx.lib.pxr_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PatchArena:
+    """HBM-resident patches (n, H, W, C) channel-fastest + per-patch corner / scale.
+
+    Replaces the FeaturePatch / FeatureMap / FeatureSet / FeatureView containers
+    (pixsfm/features/src/featurepatch.h:40-156, featureview.cc:44-55) on the device.
+    """
+
+    def __init__(self, ctx, n, H, W, channels, dtype=np.float16, device_ptr=None):
+        self.ctx = ctx
+        self.n, self.H, self.W, self.C = int(n), int(H), int(W), int(channels)
+        self.dtype = np.dtype(dtype)
+        h = C.c_void_p()
+        check(ctx.lib.pxr_arena_create(ctx.handle, _NP2DT[self.dtype], self.C, self.H, self.W, self.n,
+                                       C.c_void_p(device_ptr or 0), C.byref(h)), "pxr_arena_create")
+        self.handle = h
+
+    @classmethod
+    def from_numpy(cls, ctx, patches, corners, scales=None):
+        patches = np.ascontiguousarray(patches)
+        n, H, W, ch = patches.shape
+        a = cls(ctx, n, H, W, ch, patches.dtype)
+        a.upload(0, patches, corners, scales)
+        return a
+
+    def upload(self, first, patches=None, corners=None, scales=None):
+        count = len(patches) if patches is not None else len(corners)
+        if patches is not None:
+            patches = np.ascontiguousarray(patches, dtype=self.dtype)
+            assert patches.shape[1:] == (self.H, self.W, self.C)
+        if corners is not None:
+            corners = np.ascontiguousarray(corners, dtype=np.int32).reshape(count, 2)
+        if scales is None and corners is not None:
+            scales = np.ones((count, 2))
+        if scales is not None:
+            scales = np.ascontiguousarray(scales, dtype=np.float64).reshape(count, 2)
+        check(self.ctx.lib.pxr_arena_upload(
+            self.handle, int(first), int(count),
+            None if patches is None else patches.ctypes.data,
+            None if corners is None else corners.ctypes.data,
+            None if scales is None else scales.ctypes.data), "pxr_arena_upload")
+
+    @property
+    def data_ptr(self):
+        return self.ctx.lib.pxr_arena_data(self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None) and self.ctx.handle:
+            self.ctx.lib.pxr_arena_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def interp_cfg(l2_normalize=True, use_float_simd=False, check_bounds=False, mode="BICUBIC", nodes=None,
+               ncc_normalize=False, **_):
+    """InterpolationConfig (pixsfm/base/main.py:1-7).  Only the hot-path configuration is accepted."""
+    if str(mode).upper() != "BICUBIC":
+        raise ValueError("InterpolatorType %r is outside the accelerated path (BICUBIC only)" % (mode,))
+    if nodes is not None and [list(map(float, n)) for n in nodes] != [[0.0, 0.0]]:
+        raise ValueError("only a single interpolation node [[0, 0]] is supported (N_NODES = 1)")
+    if ncc_normalize:
+        raise ValueError("ncc_normalize needs N_NODES > 1, which is outside the accelerated path")
+    return InterpCfg(int(l2_normalize), int(use_float_simd), int(check_bounds))
+
+
+def make_loss(name="cauchy", params=(0.25,)):
+    name = str(name).lower()
+    if name not in _lib.LOSS_IDS:
+        raise ValueError("unsupported loss %r (have %s)" % (name, sorted(_lib.LOSS_IDS)))
+    a = float(params[0]) if (params is not None and len(params)) else 1.0
+    return Loss(_lib.LOSS_IDS[name], a)
+
+
+class BAProblem:
+    """Device-resident flat arrays of a bundle-adjustment problem (pxr_ba_view).
+
+    problem: dict with obs_image, obs_point, obs_patch, image_camera, qvec, tvec,
+    cam_model, cam_params (n_cams x KPAD), xyz, refs (n_points x C).
+    """
+
+    def __init__(self, ctx, arena, problem):
+        self.ctx, self.arena = ctx, arena
+        g = problem
+        self.n_obs = len(g["obs_image"])
+        self.n_images = len(g["image_camera"])
+        self.n_cameras = len(g["cam_model"])
+        self.n_points = len(g["xyz"])
+        cam_params = np.zeros((self.n_cameras, KPAD))
+        cp = np.asarray(g["cam_params"], dtype=np.float64)
+        cam_params[:, :cp.shape[1]] = cp
+        self.d = {
+            "obs_image": ctx.to_device(g["obs_image"], np.int32),
+            "obs_point": ctx.to_device(g["obs_point"], np.int32),
+            "obs_patch": ctx.to_device(g["obs_patch"], np.int64),
+            "image_camera": ctx.to_device(g["image_camera"], np.int32),
+            "qvec": ctx.to_device(g["qvec"], np.float64),
+            "tvec": ctx.to_device(g["tvec"], np.float64),
+            "cam_model": ctx.to_device(g["cam_model"], np.int32),
+            "cam_params": ctx.to_device(cam_params, np.float64),
+            "xyz": ctx.to_device(g["xyz"], np.float64),
+            "refs": ctx.to_device(g["refs"], np.float64),
+        }
+        self.rec = ctx.empty((self.n_obs, OBS_REC), np.float64)
+        self.view = self._view()
+
+    def _view(self):
+        d = self.d
+        return BaView(self.n_obs, d["obs_image"].ptr, d["obs_point"].ptr, d["obs_patch"].ptr,
+                      self.n_images, d["image_camera"].ptr, d["qvec"].ptr, d["tvec"].ptr,
+                      self.n_cameras, d["cam_model"].ptr, d["cam_params"].ptr,
+                      self.n_points, d["xyz"].ptr, d["refs"].ptr)
+
+    def eval(self, cfg, with_jacobian=True, materialize=False):
+        """Launch the fused residual kernel.  Returns device arrays (rec, r, gx, gy)."""
+        ctx = self.ctx
+        r = gx = gy = None
+        if materialize:
+            r = ctx.empty((self.n_obs, self.arena.C), np.float64)
+            if with_jacobian:
+                gx = ctx.empty((self.n_obs, self.arena.C), np.float64)
+                gy = ctx.empty((self.n_obs, self.arena.C), np.float64)
+        check(ctx.lib.pxr_ba_eval(ctx.handle, self.arena.handle, C.byref(self.view), C.byref(cfg),
+                                  int(with_jacobian), self.rec.ptr,
+                                  r.ptr if r else None, gx.ptr if gx else None, gy.ptr if gy else None),
+              "pxr_ba_eval")
+        return self.rec, r, gx, gy
+
+    def projection_jacobian(self):
+        P = self.ctx.empty((self.n_obs, 2, 10 + KPAD), np.float64)
+        check(self.ctx.lib.pxr_ba_projection_jacobian(self.ctx.handle, C.byref(self.view), P.ptr),
+              "pxr_ba_projection_jacobian")
+        return P
+
+    def cost(self, loss):
+        out = C.c_double()
+        check(self.ctx.lib.pxr_ba_cost(self.ctx.handle, self.rec.ptr, self.n_obs, C.byref(loss), C.byref(out)),
+              "pxr_ba_cost")
+        return out.value

@@ -1,0 +1,126 @@
+"""GPU parity: fused BA residual kernel (pxr_ba_eval, through the C-ABI) vs the CPU oracle.
+
+Tolerance: BASELINE.json's north_star asks residuals/Jacobians within 1e-5 relative; the
+kernel keeps the reference's precision contract (fp32 horizontal / fp64 vertical), so we
+assert 1e-10 relative for the default mode and for use_float_simd.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+def _setup(ctx, **kw):
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena
+    prob = synthetic.make_ba_problem(**kw)
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    return prob, arena, BAProblem(ctx, arena, prob)
+
+
+def _oracle_blocks(prob, cfg_kw):
+    import pxo
+    cost, r, J = pxo.ba_eval_batch(prob, pxo.cfg(**cfg_kw), pxo.loss("cauchy", 0.25), want_r=True, want_J=True)
+    return cost, r, J
+
+
+def _relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("model", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("float_simd", [False, True])
+def test_residual_and_jacobian_match_oracle(ctx, model, float_simd):
+    from pixsfm_amd.engine import interp_cfg, make_loss
+    prob, arena, ba = _setup(ctx, n_cams=5, n_points=67, obs_per_point=3, seed=10 + model, model=model)
+    rec, r, gx, gy = ba.eval(interp_cfg(use_float_simd=float_simd), with_jacobian=True, materialize=True)
+    P = ba.projection_jacobian().download()
+    r, gx, gy, rec = r.download(), gx.download(), gy.download(), rec.download()
+    cost_o, r_o, J_o = _oracle_blocks(prob, dict(use_float_simd=float_simd))
+    assert _relerr(r, r_o) < TOL
+    # J = [gx gy] * P  (C x 22)
+    J = gx[:, :, None] * P[:, None, 0, :] + gy[:, :, None] * P[:, None, 1, :]
+    assert _relerr(J, J_o) < TOL
+    # fused record == reductions of the materialised quantities
+    assert _relerr(rec[:, 0], (r_o ** 2).sum(1)) < TOL
+    assert _relerr(rec[:, 1], (gx * gx).sum(1)) < TOL
+    assert _relerr(rec[:, 2], (gx * gy).sum(1)) < 1e-8
+    assert _relerr(rec[:, 3], (gy * gy).sum(1)) < TOL
+    assert np.abs(rec[:, 4] - (gx * r_o).sum(1)).max() < 1e-9 * np.abs(gx).max()
+    assert np.abs(rec[:, 5] - (gy * r_o).sum(1)).max() < 1e-9 * np.abs(gy).max()
+    cost = ba.cost(make_loss("cauchy", [0.25]))
+    assert abs(cost - cost_o) < 1e-10 * abs(cost_o)
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32, np.float64])
+@pytest.mark.parametrize("channels", [128, 64])
+def test_patch_dtypes_and_channels(ctx, dtype, channels):
+    from pixsfm_amd.engine import interp_cfg
+    prob, arena, ba = _setup(ctx, n_cams=4, n_points=33, obs_per_point=3, seed=3, dtype=dtype, channels=channels)
+    rec, r, gx, gy = ba.eval(interp_cfg(), with_jacobian=True, materialize=True)
+    cost_o, r_o, J_o = _oracle_blocks(prob, {})
+    P = ba.projection_jacobian().download()
+    J = gx.download()[:, :, None] * P[:, None, 0, :] + gy.download()[:, :, None] * P[:, None, 1, :]
+    assert _relerr(r.download(), r_o) < TOL
+    assert _relerr(J, J_o) < TOL
+
+
+def test_scaled_patches_border_clamp_and_ragged_tail(ctx):
+    """scale != 1 (featurepatch.h:250-255), projections pushed against / beyond the patch border
+    (Grid2D clamping, grid2d.h:64-73), n_obs not a multiple of the 16-observation lane group."""
+    from pixsfm_amd.engine import interp_cfg
+    prob, arena, ba = _setup(ctx, n_cams=6, n_points=101, obs_per_point=5, seed=5, scale=(0.5, 0.25),
+                             rot_deg=1.5, trans=0.05, pt_sigma=0.05)
+    assert ba.n_obs % 16 != 0
+    rec, r, gx, gy = ba.eval(interp_cfg(), with_jacobian=True, materialize=True)
+    cost_o, r_o, J_o = _oracle_blocks(prob, {})
+    uv = (rec.download()[:, 6:8] * prob["scales"] - 0.5 - prob["corners"])
+    assert (uv.min() < 1.0) or (uv.max() > 14.0), "test should exercise border clamping"
+    assert _relerr(r.download(), r_o) < TOL
+    P = ba.projection_jacobian().download()
+    J = gx.download()[:, :, None] * P[:, None, 0, :] + gy.download()[:, :, None] * P[:, None, 1, :]
+    assert _relerr(J, J_o) < TOL
+
+
+def test_value_only_and_unnormalised(ctx):
+    from pixsfm_amd.engine import interp_cfg
+    prob, arena, ba = _setup(ctx, n_cams=4, n_points=40, obs_per_point=3, seed=8)
+    rec, r, _, _ = ba.eval(interp_cfg(l2_normalize=False), with_jacobian=False, materialize=True)
+    cost_o, r_o, _ = _oracle_blocks(prob, dict(l2_normalize=False))
+    assert _relerr(r.download(), r_o) < TOL
+    assert _relerr(rec.download()[:, 0], (r_o ** 2).sum(1)) < TOL
+
+
+def test_empty_problem_is_a_noop(ctx):
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, make_loss
+    prob = synthetic.make_ba_problem(n_cams=3, n_points=4, obs_per_point=2, seed=1)
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    for k in ("obs_image", "obs_point", "obs_patch"):
+        prob[k] = prob[k][:0]
+    ba = BAProblem(ctx, arena, prob)
+    ba.eval(interp_cfg())
+    assert ba.cost(make_loss()) == 0.0
+
+
+def test_unsupported_channels_raise(ctx):
+    from pixsfm_amd import PixsfmHipError
+    from pixsfm_amd.engine import interp_cfg
+    prob, arena, ba = _setup(ctx, n_cams=3, n_points=5, obs_per_point=2, seed=1, channels=24)
+    with pytest.raises(PixsfmHipError):
+        ba.eval(interp_cfg())
+
+
+def test_linearity_in_reference_full_size_property(ctx):
+    """Size-independent property: r(ref) - r(0) == -ref for every observation."""
+    from pixsfm_amd.engine import interp_cfg
+    prob, arena, ba = _setup(ctx, n_cams=8, n_points=500, obs_per_point=4, seed=21)
+    _, r1, _, _ = ba.eval(interp_cfg(), with_jacobian=False, materialize=True)
+    r1 = r1.download()
+    ba.d["refs"].upload(np.zeros_like(prob["refs"]))
+    rec0, r0, _, _ = ba.eval(interp_cfg(), with_jacobian=False, materialize=True)
+    r0 = r0.download()
+    assert np.abs((r0 - r1) - prob["refs"][prob["obs_point"]]).max() < 1e-15
+    assert np.abs((r0 ** 2).sum(1) - 1.0).max() < 1e-12   # unit-norm descriptors (interpolation_test.cc:187-207)

@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""bench.py -- featuremetric residual+Jacobian throughput on the synthetic 1M-observation BA
+problem (BASELINE.json config 3: 200 cams / 200k points / 1M obs, 128-ch fp16 16x16 patches).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" = one fused residual+Jacobian evaluation (pxr_ba_eval, with_jacobian=1) of every
+observation owned by the rank: projection, bicubic interpolation of the patch stencil,
+L2-normalisation with analytic gradient, reference subtraction and the six-scalar reduction
+that stands in for the 128 x (10+K) Jacobian block.  Inputs are resident in HBM when the
+timed region starts.  N > 1: points (with all their observations and patches) are
+partitioned over the ranks, no data-path collective in the evaluation; the total
+problem size is fixed (strong scaling).
+
+Rank 0 prints ONE JSON line; see DESIGN.md section "Measurement" for the roofline and
+cpu_baseline definitions.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pixel-perfect-sfm_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_obs(C, K=4, elem=2):
+    """stencil 16*C*sizeof(dtype) + reference C*8 + params 8*(10+K) + 4 indices."""
+    return 16 * C * elem + C * 8 + 8 * (10 + K) + 16
+
+
+def cpu_baseline(prob, patches, n_sample, budget_s=12.0):
+    """Oracle (kind 'port') timed on this box's host cores: materialised 128 x n Jacobian blocks
+    + loss per residual block, threaded over blocks like Ceres (bundle_adjustment_options.h:58)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pxo
+    n_sample = int(min(n_sample, len(prob["obs_image"])))
+    sub = dict(prob)
+    for k in ("obs_image", "obs_point", "obs_patch", "corners", "scales"):
+        sub[k] = prob[k][:n_sample]
+    sub["patches"] = patches[:n_sample].cpu().numpy()
+    cores = os.cpu_count() or 1
+    cfg, ls = pxo.cfg(), pxo.loss("cauchy", 0.25)
+    pxo.ba_eval_batch(sub, cfg, ls, count=min(n_sample, 2048), n_threads=cores)       # warm-up / page-in
+    t0 = time.perf_counter()
+    passes = 0
+    while True:
+        pxo.ba_eval_batch(sub, cfg, ls, n_threads=cores)
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or passes >= 2000:
+            break
+    return {"value": n_sample * passes / dt, "unit": "residual_blocks/s", "cores": cores, "kind": "port",
+            "sample": "%d passes over the first %d observations of the same workload (%.1f s), oracle C "
+                      "restatement, materialised 128x(10+K) Jacobians + Cauchy loss, %d pthreads"
+                      % (passes, n_sample, dt, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cams", type=int, default=200)
+    ap.add_argument("--points", type=int, default=200_000)
+    ap.add_argument("--obs-per-point", type=int, default=5)
+    ap.add_argument("--float-simd", action="store_true", help="InterpolationConfig.use_float_simd")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=32768)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from pixsfm_amd import synthetic_gpu
+    from pixsfm_amd.engine import BAProblem, Context, PatchArena, interp_cfg, make_loss
+
+    C, PS = 128, 16
+    per = (args.points + world - 1) // world
+    lo, hi = rank * per, min(args.points, (rank + 1) * per)
+    prob, patches = synthetic_gpu.make_ba_problem_gpu(dev, n_cams=args.cams, n_points=args.points,
+                                                      obs_per_point=args.obs_per_point, channels=C,
+                                                      patch_size=PS, seed=2, point_range=(lo, hi))
+    n_obs_local = len(prob["obs_image"])
+    ctx = Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    arena = PatchArena(ctx, n_obs_local, PS, PS, C, np.float16, device_ptr=patches.data_ptr())
+    arena.upload(0, None, prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    cfg = interp_cfg(use_float_simd=args.float_simd)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ba.eval(cfg, with_jacobian=True)
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        ba.eval(cfg, with_jacobian=True)
+    kernel_ms = ctx.timer_stop() / args.steps            # HIP events on the launch stream
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+        ntot = torch.tensor([n_obs_local], dtype=torch.float64, device=dev)
+        dist.all_reduce(ntot)
+        n_obs_total = int(ntot.item())
+    else:
+        n_obs_total = n_obs_local
+    cost = ba.cost(make_loss("cauchy", [0.25]))
+
+    if rank == 0:
+        bpo = algorithmic_bytes_per_obs(C)
+        # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of
+        # this same command (gpurun refuses/forbids mixing passes) and committed under profiles/.
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r1_ba_eval_pmc.json")
+        if os.path.exists(pmc_path) and world == 1 and n_obs_total == 1_000_000 and not args.float_simd:
+            with open(pmc_path) as fh:
+                traffic = json.load(fh).get("hbm_bytes_per_launch")
+        achieved = bpo * n_obs_local / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "featuremetric residuals+Jacobians evaluated/sec (1M obs)",
+            "value": n_obs_total * args.steps / dt,
+            "unit": "residual_blocks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 horizontal / f64 vertical+normalisation on f16 patches"
+                     if not args.float_simd else "f32 splines / f64 normalisation on f16 patches",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: synthetic %d cams / %d points / %d obs "
+                                   "featuremetric BA residual+Jacobian evaluation, %d-ch fp16 %dx%d patches, "
+                                   "SIMPLE_RADIAL, fused six-scalar Jacobian reduction"
+                                   % (args.cams, args.points, n_obs_total, C, PS, PS),
+                       "n_obs": n_obs_total, "channels": C, "patch": PS,
+                       "arena_GB": n_obs_total * PS * PS * C * 2 / 1e9,
+                       "partition": "points" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_note": "bytes/launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
+                                         "profiles/r1_ba_eval_pmc.json",
+                         "kernel": "ba_eval_kernel<f16,128,jac>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_obs": bpo},
+            "initial_cost": cost,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(prob, patches, args.cpu_sample)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

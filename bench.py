@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--float-simd", action="store_true", help="InterpolationConfig.use_float_simd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32768)
+    ap.add_argument("--lm-iters", type=int, default=10, help="LM iterations for the iters/s figure (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,6 +129,26 @@ def main():
         n_obs_total = n_obs_local
     cost = ba.cost(make_loss("cauchy", [0.25]))
 
+    # ---- second half of the metric: LM iterations / s on the same problem ------------------------
+    # default gauge (bundle_adjustment/main.py:12-18) and refine flags (bundle_adjustment_options.h:66-76);
+    # one iteration = linearise + Schur + Cholesky + back-substitution + evaluation at the trial point.
+    lm = None
+    if args.lm_iters > 0:
+        from pixsfm_amd.engine import lm_options
+        from pixsfm_amd.parallel import make_allreduce
+        n_img = args.cams
+        pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
+        tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
+        cmask = np.full(n_img, 0b0110, np.uint16)          # SIMPLE_RADIAL: refine f and k, keep cx, cy
+        ptc = np.zeros(len(prob["xyz"]), np.uint8)
+        barrier()
+        t1 = time.perf_counter()
+        lm = ba.solve(cfg, make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,
+                      options=lm_options(max_iterations=args.lm_iters),
+                      allreduce=make_allreduce() if world > 1 else None)
+        barrier()
+        lm["wall_s"] = time.perf_counter() - t1
+
     if rank == 0:
         bpo = algorithmic_bytes_per_obs(C)
         # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of
@@ -163,6 +184,12 @@ def main():
                          "algorithmic_bytes_per_obs": bpo},
             "initial_cost": cost,
         }
+        if lm is not None:
+            out["lm"] = {"iters_per_sec": lm["iterations"] / (lm["total_ms"] * 1e-3), "iterations": lm["iterations"],
+                         "successful": lm["num_successful"], "ms_per_iter": lm["total_ms"] / max(1, lm["iterations"]),
+                         "setup_ms": lm["setup_ms"], "initial_cost": lm["initial_cost"], "final_cost": lm["final_cost"],
+                         "reduced_system": lm["num_camera_unknowns"], "linear_solver": "Schur + dense Cholesky (rocSOLVER)",
+                         "inner_iterations": False}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(prob, patches, args.cpu_sample)
         print(json.dumps(out))

@@ -144,6 +144,60 @@ int pxr_ba_projection_jacobian(pxr_ctx* ctx, const pxr_ba_view* view, double* d_
 int pxr_ba_cost(pxr_ctx* ctx, const double* d_rec, int64_t n_obs, const pxr_loss* loss,
                 double* h_cost);
 
+
+/* ---- BA solve -------------------------------------------------------------------------
+ * Replaces BundleOptimizer::SolveProblem -> ceres::Solve
+ * (bundle_adjustment/src/bundle_optimizer.h:172-245) for the feature-reference cost:
+ * trust-region Levenberg-Marquardt [upstream Ceres 2.1 semantics: Jacobi scaling, LM
+ * diagonal clamp, step acceptance, radius update, tolerances] with the point blocks
+ * eliminated (Schur complement, what DENSE_SCHUR / SPARSE_SCHUR do, :181-191) and a dense
+ * Cholesky of the reduced camera system on the GPU. */
+enum { PXR_TERM_CONVERGENCE = 0, PXR_TERM_NO_CONVERGENCE = 1, PXR_TERM_FAILURE = 2 };
+
+typedef struct {
+  int32_t max_iterations;        /* 100 (bundle_adjustment_options.h:54)                */
+  double function_tolerance;     /* 0                                                   */
+  double gradient_tolerance;     /* 0                                                   */
+  double parameter_tolerance;    /* 0                                                   */
+  double initial_radius;         /* 1e4  [upstream ceres::Solver::Options defaults]     */
+  double max_radius;             /* 1e16                                                */
+  double min_radius;             /* 1e-32                                               */
+  double min_relative_decrease;  /* 1e-3                                                */
+  double min_lm_diagonal;        /* 1e-6                                                */
+  double max_lm_diagonal;        /* 1e32                                                */
+  int32_t max_consecutive_invalid_steps; /* 10 (bundle_adjustment_options.h:56)         */
+  int32_t jacobi_scaling;        /* 1                                                   */
+} pxr_lm_options;
+
+typedef struct {
+  int32_t iterations;      /* LM iterations attempted                                   */
+  int32_t num_successful;
+  int32_t termination;     /* PXR_TERM_*                                                */
+  int32_t num_camera_unknowns; /* size of the reduced camera system                     */
+  int64_t num_point_unknowns;
+  double initial_cost, final_cost, final_radius;
+  double total_ms;         /* wall time of the LM loop (set-up excluded)                */
+  double setup_ms;         /* host-side index construction + allocations                */
+} pxr_lm_summary;
+
+/* In-place sum over ranks of `count` doubles at device pointer d_buf, enqueued on / ordered
+ * with the context's stream (RCCL all-reduce over xGMI in the Python host layer).  NULL for a
+ * single GPU.  With N ranks every rank holds ALL images and cameras (replicated) and a
+ * disjoint shard of the points with all their observations. */
+typedef int (*pxr_allreduce_fn)(void* user, double* d_buf, int64_t count);
+
+/* Parameterisation (host arrays, bundle_optimizer.h:335-453):
+ *   h_pose_const[img]      1 = qvec,tvec constant (HasConstantPose / !refine_extrinsics)
+ *   h_tvec_const_mask[img] bit a = tvec[a] constant (SubsetManifold, ConstantTvec)
+ *   h_cam_const_mask[cam]  bit a = camera parameter a constant (SubsetManifold / constant camera)
+ *   h_point_const[pt]      1 = constant point
+ * The qvec / tvec / cam_params / xyz device arrays of `view` are updated IN PLACE. */
+int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
+                 const pxr_loss* loss, const uint8_t* h_pose_const, const uint8_t* h_tvec_const_mask,
+                 const uint16_t* h_cam_const_mask, const uint8_t* h_point_const,
+                 const pxr_lm_options* options, pxr_allreduce_fn allreduce, void* allreduce_user,
+                 pxr_lm_summary* summary);
+
 #ifdef __cplusplus
 }
 #endif

@@ -177,6 +177,44 @@ double pxo_ba_eval_batch(const pxo_ba_batch* b, const pxo_interp_cfg* cfg, const
                          int64_t first, int64_t count, int n_threads, double* r_out,
                          double* J_out);
 
+
+/* ---- LM solvers [upstream Ceres 2.1 trust_region_minimizer.cc restated] -------------- */
+enum { PXO_TERM_CONVERGENCE = 0, PXO_TERM_NO_CONVERGENCE = 1, PXO_TERM_FAILURE = 2 };
+
+typedef struct {
+  int32_t max_iterations;              /* 100 (base/main.py:9-22)                           */
+  double function_tolerance;           /* 0                                                 */
+  double gradient_tolerance;           /* 0                                                 */
+  double parameter_tolerance;          /* 0 for BA, 1e-5 for KA (keypoint_adjustment/main.py:74) */
+  double initial_radius;               /* 1e4  [upstream default]                           */
+  double max_radius;                   /* 1e16                                              */
+  double min_radius;                   /* 1e-32                                             */
+  double min_relative_decrease;        /* 1e-3                                              */
+  double min_lm_diagonal;              /* 1e-6                                              */
+  double max_lm_diagonal;              /* 1e32                                              */
+  int32_t max_consecutive_invalid_steps; /* 10 (bundle_adjustment_options.h:56)             */
+  int32_t jacobi_scaling;              /* 1                                                 */
+} pxo_lm_options;
+
+typedef struct {
+  int32_t iterations;       /* LM iterations attempted (successful + rejected + invalid)   */
+  int32_t num_successful;
+  int32_t termination;      /* PXO_TERM_*                                                  */
+  int32_t num_unknowns;
+  double initial_cost, final_cost, final_radius;
+} pxo_lm_summary;
+
+/* Featuremetric BA on the flat problem (parameters are updated IN PLACE inside b, like the
+ * reference does in the colmap::Reconstruction, feature_reference_bundle_optimizer.h:111-114).
+ *   pose_const[img]        1 = SetParameterBlockConstant(qvec, tvec)   (bundle_optimizer.h:391-394)
+ *   tvec_const_mask[img]   bit a = tvec[a] held by a SubsetManifold     (:385-390)
+ *   cam_const_mask[cam]    bit a = camera param a constant              (:400-442)
+ *   point_const[pt]        1 = constant point                           (:342-363)          */
+int pxo_ba_solve(pxo_ba_batch* b, int n_images, int n_cams, int64_t n_points,
+                 const pxo_interp_cfg* cfg, const pxo_loss* loss, const uint8_t* pose_const,
+                 const uint8_t* tvec_const_mask, const uint16_t* cam_const_mask,
+                 const uint8_t* point_const, const pxo_lm_options* opt, pxo_lm_summary* sum);
+
 #ifdef __cplusplus
 }
 #endif

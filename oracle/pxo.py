@@ -264,3 +264,51 @@ def ba_eval_batch(problem, config, ls, first=0, count=None, n_threads=1, want_r=
     J = np.empty((n, ch, 10 + KPAD)) if want_J else None
     cost = lib().pxo_ba_eval_batch(C.byref(b), C.byref(config), C.byref(ls), first, n, n_threads, _p(r), _p(J))
     return cost, r, J
+
+
+class LMOptions(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("function_tolerance", C.c_double),
+                ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
+                ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
+                ("max_lm_diagonal", C.c_double), ("max_consecutive_invalid_steps", C.c_int32),
+                ("jacobi_scaling", C.c_int32)]
+
+
+class LMSummary(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("num_successful", C.c_int32), ("termination", C.c_int32),
+                ("num_unknowns", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("final_radius", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def lm_options(max_iterations=100, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0,
+               initial_radius=1e4, max_radius=1e16, min_radius=1e-32, min_relative_decrease=1e-3,
+               min_lm_diagonal=1e-6, max_lm_diagonal=1e32, max_consecutive_invalid_steps=10, jacobi_scaling=1):
+    return LMOptions(max_iterations, function_tolerance, gradient_tolerance, parameter_tolerance,
+                     initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal,
+                     max_lm_diagonal, max_consecutive_invalid_steps, jacobi_scaling)
+
+
+def ba_solve(problem, config, ls, pose_const, tvec_const_mask, cam_const_mask, point_const, opts=None):
+    """Runs the oracle LM; returns (summary dict, refined copies of qvec, tvec, cam_params, xyz)."""
+    prob = dict(problem)
+    for k in ("qvec", "tvec", "cam_params", "xyz"):
+        prob[k] = np.array(problem[k], dtype=np.float64, order="C", copy=True)
+    b, keep = ba_batch(prob)
+    # ba_batch made contiguous copies only if needed; make sure we mutate the arrays we return
+    for k in ("qvec", "tvec", "cam_params", "xyz"):
+        assert keep[k] is prob[k] or keep[k].ctypes.data == prob[k].ctypes.data
+    opts = opts or lm_options()
+    s = LMSummary()
+    pc = np.ascontiguousarray(pose_const, dtype=np.uint8)
+    tm = np.ascontiguousarray(tvec_const_mask, dtype=np.uint8)
+    cm = np.ascontiguousarray(cam_const_mask, dtype=np.uint16)
+    ptc = np.ascontiguousarray(point_const, dtype=np.uint8)
+    rc = lib().pxo_ba_solve(C.byref(b), len(prob["image_camera"]), len(prob["cam_model"]),
+                            C.c_int64(len(prob["xyz"])), C.byref(config), C.byref(ls), _p(pc), _p(tm), _p(cm),
+                            _p(ptc), C.byref(opts), C.byref(s))
+    assert rc == 0
+    return s.as_dict(), prob["qvec"], prob["tvec"], prob["cam_params"], prob["xyz"]

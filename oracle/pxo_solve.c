@@ -1,2 +1,400 @@
-/* pxo_solve.c -- ORACLE (test infrastructure only; see pxo.h header).  LM solvers: filled in below. */
+/*
+ * pxo_solve.c -- ORACLE (test infrastructure only; see pxo.h header).
+ *
+ * Dense-matrix restatement of the solves the reference delegates to Ceres:
+ *   BA: BundleOptimizer::SolveProblem (bundle_adjustment/src/bundle_optimizer.h:172-245) with
+ *       the parameterisation of :335-453 (quaternion manifold, subset manifolds, constant
+ *       blocks), residual blocks from feature_reference_bundle_optimizer.h:90-149;
+ *   KA: KeypointOptimizerBase::SolveProblem (keypoint_adjustment/src/keypoint_optimizer.h:77-104)
+ *       with the box bounds of :110-157 and the edges of
+ *       topological_keypoint_optimizer.h:97-175 / featuremetric_keypoint_optimizer.h:158-202.
+ *
+ * [upstream Ceres 2.1] The trust-region Levenberg-Marquardt loop is restated from
+ * trust_region_minimizer.cc / levenberg_marquardt_strategy.cc: Jacobi column scaling
+ * 1/(1+||J_j||) fixed at iteration 0; LM diagonal sqrt(clamp(diag(J^T J), 1e-6, 1e32)/radius);
+ * model_cost_change = -(J d).(r + J d / 2); accept if rho > 1e-3; radius <- radius /
+ * max(1/3, 1 - (2 rho - 1)^3) on success, radius /= decrease_factor (2, 4, 8 ...) on failure;
+ * parameter tolerance |dx| <= tol (|x| + tol); function tolerance |dcost| <= tol * cost.
+ * Unlike the reference's SPARSE_SCHUR / SPARSE_NORMAL_CHOLESKY the oracle factorises the full
+ * damped normal matrix densely -- mathematically the same step, independent code path.
+ * PARITY UNPINNED: Ceres is not available, so trajectories cannot be compared with the real
+ * reference; the GPU solver is compared with THIS restatement.  Inner iterations
+ * (bundle_adjustment/main.py:43) and the bounds line search are restated in simplified
+ * form (see the functions below).
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
 #include "pxo.h"
+
+#define PXO_MAXC 512
+#define PXO_KPAD 12
+
+/* ------------------------------------------------------------------------------------ */
+/* dense symmetric positive definite solve (Cholesky), returns 0 on success              */
+static int chol_solve(int n, double* A /* n x n row-major, overwritten (lower) */, double* b) {
+  for (int j = 0; j < n; ++j) {
+    double d = A[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+    if (!(d > 0.0) || !isfinite(d)) return -1;
+    d = sqrt(d);
+    A[(size_t)j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = A[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+      A[(size_t)i * n + j] = s / d;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= A[(size_t)i * n + k] * b[k];
+    b[i] = s / A[(size_t)i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = b[i];
+    for (int k = i + 1; k < n; ++k) s -= A[(size_t)k * n + i] * b[k];
+    b[i] = s / A[(size_t)i * n + i];
+  }
+  return 0;
+}
+
+/* [upstream Ceres 2.1 manifold.cc] QuaternionManifold::Plus: x+ = [cos|d|, sin|d|/|d| d] * x */
+static void quat_plus(const double* x, const double* d, double* xp) {
+  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (nd == 0.0) { memcpy(xp, x, 32); return; }
+  const double s = sin(nd) / nd;
+  const double q[4] = {cos(nd), s * d[0], s * d[1], s * d[2]};
+  xp[0] = q[0] * x[0] - q[1] * x[1] - q[2] * x[2] - q[3] * x[3];
+  xp[1] = q[0] * x[1] + q[1] * x[0] + q[2] * x[3] - q[3] * x[2];
+  xp[2] = q[0] * x[2] - q[1] * x[3] + q[2] * x[0] + q[3] * x[1];
+  xp[3] = q[0] * x[3] + q[1] * x[2] - q[2] * x[1] + q[3] * x[0];
+}
+/* QuaternionManifold::PlusJacobian (4 x 3 row-major) */
+static void quat_plus_jac(const double* x, double* J) {
+  J[0] = -x[1]; J[1] = -x[2]; J[2] = -x[3];
+  J[3] = x[0];  J[4] = x[3];  J[5] = -x[2];
+  J[6] = -x[3]; J[7] = x[0];  J[8] = x[1];
+  J[9] = x[2];  J[10] = -x[1]; J[11] = x[0];
+}
+
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+  /* unknown layout */
+  int n;                 /* total tangent unknowns */
+  int* pose_off; int* pose_dim; /* per image: offset of [3 rot][free tvec comps] */
+  int* intr_off; int* intr_dim; /* per camera */
+  int* pt_off;                  /* per point: offset or -1 */
+} ba_layout;
+
+typedef struct {
+  pxo_ba_batch* b; const pxo_interp_cfg* cfg; const pxo_loss* loss;
+  const uint8_t* pose_const; const uint8_t* tvec_const_mask; const uint16_t* cam_const_mask;
+  const uint8_t* point_const;
+  int n_images, n_cams; int64_t n_points;
+  ba_layout L;
+} ba_ctx;
+
+static void ba_build_layout(ba_ctx* c) {
+  ba_layout* L = &c->L;
+  L->pose_off = (int*)malloc(sizeof(int) * c->n_images);
+  L->pose_dim = (int*)malloc(sizeof(int) * c->n_images);
+  L->intr_off = (int*)malloc(sizeof(int) * c->n_cams);
+  L->intr_dim = (int*)malloc(sizeof(int) * c->n_cams);
+  L->pt_off = (int*)malloc(sizeof(int) * c->n_points);
+  /* only blocks that appear in at least one residual are part of the program */
+  uint8_t* img_used = (uint8_t*)calloc(c->n_images, 1);
+  uint8_t* cam_used = (uint8_t*)calloc(c->n_cams, 1);
+  uint8_t* pt_used = (uint8_t*)calloc(c->n_points, 1);
+  for (int64_t i = 0; i < c->b->n_obs; ++i) {
+    img_used[c->b->obs_image[i]] = 1;
+    cam_used[c->b->image_camera[c->b->obs_image[i]]] = 1;
+    pt_used[c->b->obs_point[i]] = 1;
+  }
+  int off = 0;
+  for (int i = 0; i < c->n_images; ++i) {
+    int d = 0;
+    if (img_used[i] && !c->pose_const[i]) {
+      d = 3;
+      for (int k = 0; k < 3; ++k) if (!((c->tvec_const_mask[i] >> k) & 1)) ++d;
+    }
+    L->pose_off[i] = off; L->pose_dim[i] = d; off += d;
+  }
+  for (int j = 0; j < c->n_cams; ++j) {
+    int d = 0;
+    if (cam_used[j]) {
+      const int K = pxo_camera_num_params(c->b->cam_model[j]);
+      for (int k = 0; k < K; ++k) if (!((c->cam_const_mask[j] >> k) & 1)) ++d;
+    }
+    L->intr_off[j] = off; L->intr_dim[j] = d; off += d;
+  }
+  for (int64_t p = 0; p < c->n_points; ++p) {
+    if (pt_used[p] && !c->point_const[p]) { L->pt_off[p] = off; off += 3; } else L->pt_off[p] = -1;
+  }
+  L->n = off;
+  free(img_used); free(cam_used); free(pt_used);
+}
+
+static pxo_patch ba_patch(const pxo_ba_batch* b, int64_t pi) {
+  const size_t es = b->dtype == PXO_F16 ? 2 : (b->dtype == PXO_F32 ? 4 : 8);
+  pxo_patch p;
+  p.data = (const char*)b->arena + (size_t)pi * b->H * b->W * b->C * es;
+  p.dtype = b->dtype; p.H = b->H; p.W = b->W; p.C = b->C;
+  p.x0 = b->corners[2 * pi]; p.y0 = b->corners[2 * pi + 1];
+  p.sx = b->scales[2 * pi]; p.sy = b->scales[2 * pi + 1]; p.up = 1.0;
+  return p;
+}
+
+/* cost (and optionally H = J~^T J~ (n x n, full), g = J~^T r~ in UNSCALED tangent space) */
+static double ba_evaluate(ba_ctx* c, const double* qvec, const double* tvec, const double* cams,
+                          const double* xyz, double* H, double* g) {
+  const pxo_ba_batch* b = c->b;
+  const int C = b->C, n = c->L.n;
+  double cost = 0;
+  if (H) { memset(H, 0, sizeof(double) * (size_t)n * n); memset(g, 0, sizeof(double) * n); }
+  double* r = (double*)malloc(sizeof(double) * C);
+  double* Jq = (double*)malloc(sizeof(double) * C * (4 + 3 + 3 + PXO_KPAD));
+  double *Jt = Jq + C * 4, *JX = Jt + C * 3, *Jk = JX + C * 3;
+  double* Jl = (double*)malloc(sizeof(double) * C * 24); /* local tangent Jacobian C x dl */
+  int idx[24];
+  for (int64_t i = 0; i < b->n_obs; ++i) {
+    const int img = b->obs_image[i], cam = b->image_camera[img];
+    const int64_t pt = b->obs_point[i];
+    const int model = b->cam_model[cam], K = pxo_camera_num_params(model);
+    pxo_patch p = ba_patch(b, b->obs_patch[i]);
+    pxo_ba_residual(&p, c->cfg, model, qvec + 4 * img, tvec + 3 * img, xyz + 3 * pt,
+                    cams + PXO_KPAD * cam, b->refs + (size_t)C * pt, r, H ? Jq : NULL, H ? Jt : NULL,
+                    H ? JX : NULL, H ? Jk : NULL);
+    double s = 0;
+    for (int k = 0; k < C; ++k) s += r[k] * r[k];
+    double rho[3];
+    pxo_loss_eval(c->loss, 1.0, s, rho);
+    cost += 0.5 * rho[0];
+    if (!H) continue;
+    /* ambient -> tangent columns + global indices */
+    int dl = 0;
+    if (c->L.pose_dim[img] > 0) {
+      double PJ[12];
+      quat_plus_jac(qvec + 4 * img, PJ);
+      for (int a = 0; a < 3; ++a) {
+        for (int k = 0; k < C; ++k) {
+          double v = 0;
+          for (int m = 0; m < 4; ++m) v += Jq[k * 4 + m] * PJ[m * 3 + a];
+          Jl[k * 24 + dl] = v;
+        }
+        idx[dl] = c->L.pose_off[img] + a; ++dl;
+      }
+      int tc = 0;
+      for (int a = 0; a < 3; ++a) {
+        if ((c->tvec_const_mask[img] >> a) & 1) continue;
+        for (int k = 0; k < C; ++k) Jl[k * 24 + dl] = Jt[k * 3 + a];
+        idx[dl] = c->L.pose_off[img] + 3 + tc; ++tc; ++dl;
+      }
+    }
+    if (c->L.intr_dim[cam] > 0) {
+      int kc = 0;
+      for (int a = 0; a < K; ++a) {
+        if ((c->cam_const_mask[cam] >> a) & 1) continue;
+        for (int k = 0; k < C; ++k) Jl[k * 24 + dl] = Jk[k * K + a];
+        idx[dl] = c->L.intr_off[cam] + kc; ++kc; ++dl;
+      }
+    }
+    if (c->L.pt_off[pt] >= 0) {
+      for (int a = 0; a < 3; ++a) {
+        for (int k = 0; k < C; ++k) Jl[k * 24 + dl] = JX[k * 3 + a];
+        idx[dl] = c->L.pt_off[pt] + a; ++dl;
+      }
+    }
+    /* corrector on (r, Jl) -- Jl has row stride 24; compact to C x dl first */
+    double* Jc = (double*)malloc(sizeof(double) * C * (dl > 0 ? dl : 1));
+    for (int k = 0; k < C; ++k) for (int a = 0; a < dl; ++a) Jc[k * dl + a] = Jl[k * 24 + a];
+    pxo_corrector(s, rho, C, dl, r, Jc);
+    for (int a = 0; a < dl; ++a) {
+      double ga = 0;
+      for (int k = 0; k < C; ++k) ga += Jc[k * dl + a] * r[k];
+      g[idx[a]] += ga;
+      for (int bb = 0; bb < dl; ++bb) {
+        double h = 0;
+        for (int k = 0; k < C; ++k) h += Jc[k * dl + a] * Jc[k * dl + bb];
+        H[(size_t)idx[a] * n + idx[bb]] += h;
+      }
+    }
+    free(Jc);
+  }
+  free(r); free(Jq); free(Jl);
+  return cost;
+}
+
+/* x (+) delta for all blocks (delta in unscaled tangent space) */
+static void ba_plus(ba_ctx* c, const double* q0, const double* t0, const double* k0, const double* X0,
+                    const double* delta, double* q1, double* t1, double* k1, double* X1) {
+  memcpy(q1, q0, sizeof(double) * 4 * c->n_images);
+  memcpy(t1, t0, sizeof(double) * 3 * c->n_images);
+  memcpy(k1, k0, sizeof(double) * PXO_KPAD * c->n_cams);
+  memcpy(X1, X0, sizeof(double) * 3 * c->n_points);
+  for (int i = 0; i < c->n_images; ++i) {
+    if (c->L.pose_dim[i] == 0) continue;
+    const double* d = delta + c->L.pose_off[i];
+    quat_plus(q0 + 4 * i, d, q1 + 4 * i);
+    int tc = 0;
+    for (int a = 0; a < 3; ++a) {
+      if ((c->tvec_const_mask[i] >> a) & 1) continue;
+      t1[3 * i + a] = t0[3 * i + a] + d[3 + tc]; ++tc;
+    }
+  }
+  for (int j = 0; j < c->n_cams; ++j) {
+    if (c->L.intr_dim[j] == 0) continue;
+    const int K = pxo_camera_num_params(c->b->cam_model[j]);
+    int kc = 0;
+    for (int a = 0; a < K; ++a) {
+      if ((c->cam_const_mask[j] >> a) & 1) continue;
+      k1[PXO_KPAD * j + a] = k0[PXO_KPAD * j + a] + delta[c->L.intr_off[j] + kc]; ++kc;
+    }
+  }
+  for (int64_t p = 0; p < c->n_points; ++p) {
+    if (c->L.pt_off[p] < 0) continue;
+    for (int a = 0; a < 3; ++a) X1[3 * p + a] = X0[3 * p + a] + delta[c->L.pt_off[p] + a];
+  }
+}
+
+/* squared ambient norms over the variable blocks (Ceres' x_norm / step_norm) */
+static double ba_ambient_sqnorm(ba_ctx* c, const double* q, const double* t, const double* k,
+                                const double* X, const double* q2, const double* t2,
+                                const double* k2, const double* X2) {
+  double s = 0;
+#define DIFF(a, b, i) ((a)[i] - ((b) ? (b)[i] : 0.0))
+  for (int i = 0; i < c->n_images; ++i) {
+    if (c->L.pose_dim[i] == 0) continue;
+    for (int a = 0; a < 4; ++a) { double d = DIFF(q, q2, 4 * i + a); s += d * d; }
+    /* tvec: SubsetManifold keeps the whole block in the ambient vector */
+    for (int a = 0; a < 3; ++a) { double d = DIFF(t, t2, 3 * i + a); s += d * d; }
+  }
+  for (int j = 0; j < c->n_cams; ++j) {
+    if (c->L.intr_dim[j] == 0) continue;
+    const int K = pxo_camera_num_params(c->b->cam_model[j]);
+    for (int a = 0; a < K; ++a) { double d = DIFF(k, k2, PXO_KPAD * j + a); s += d * d; }
+  }
+  for (int64_t p = 0; p < c->n_points; ++p) {
+    if (c->L.pt_off[p] < 0) continue;
+    for (int a = 0; a < 3; ++a) { double d = DIFF(X, X2, 3 * p + a); s += d * d; }
+  }
+#undef DIFF
+  return s;
+}
+
+int pxo_ba_solve(pxo_ba_batch* b, int n_images, int n_cams, int64_t n_points,
+                 const pxo_interp_cfg* cfg, const pxo_loss* loss, const uint8_t* pose_const,
+                 const uint8_t* tvec_const_mask, const uint16_t* cam_const_mask,
+                 const uint8_t* point_const, const pxo_lm_options* opt, pxo_lm_summary* sum) {
+  ba_ctx c;
+  memset(&c, 0, sizeof(c));
+  c.b = b; c.cfg = cfg; c.loss = loss; c.pose_const = pose_const; c.tvec_const_mask = tvec_const_mask;
+  c.cam_const_mask = cam_const_mask; c.point_const = point_const;
+  c.n_images = n_images; c.n_cams = n_cams; c.n_points = n_points;
+  ba_build_layout(&c);
+  const int n = c.L.n;
+  double* q = (double*)b->qvec; double* t = (double*)b->tvec;
+  double* k = (double*)b->cam_params; double* X = (double*)b->xyz;
+  /* AddImageToProblem normalises the quaternions (bundle_optimizer.h:255) */
+  for (int i = 0; i < n_images; ++i) {
+    double nn = sqrt(q[4 * i] * q[4 * i] + q[4 * i + 1] * q[4 * i + 1] + q[4 * i + 2] * q[4 * i + 2] + q[4 * i + 3] * q[4 * i + 3]);
+    for (int a = 0; a < 4; ++a) q[4 * i + a] /= nn;
+  }
+  double* H = (double*)malloc(sizeof(double) * (size_t)n * n);
+  double* A = (double*)malloc(sizeof(double) * (size_t)n * n);
+  double* g = (double*)malloc(sizeof(double) * n);
+  double* scale = (double*)malloc(sizeof(double) * n);
+  double* step = (double*)malloc(sizeof(double) * n);
+  double* delta = (double*)malloc(sizeof(double) * n);
+  double* diag = (double*)malloc(sizeof(double) * n);
+  double* q1 = (double*)malloc(sizeof(double) * 4 * n_images);
+  double* t1 = (double*)malloc(sizeof(double) * 3 * n_images);
+  double* k1 = (double*)malloc(sizeof(double) * PXO_KPAD * n_cams);
+  double* X1 = (double*)malloc(sizeof(double) * 3 * n_points);
+
+  double cost = ba_evaluate(&c, q, t, k, X, H, g);
+  sum->initial_cost = cost; sum->num_unknowns = n;
+  sum->iterations = 0; sum->num_successful = 0; sum->termination = PXO_TERM_NO_CONVERGENCE;
+  for (int j = 0; j < n; ++j) scale[j] = opt->jacobi_scaling ? 1.0 / (1.0 + sqrt(H[(size_t)j * n + j])) : 1.0;
+  /* scale the system: Hs = S H S, gs = S g */
+#define SCALE_SYSTEM()                                                                   \
+  do {                                                                                   \
+    for (int a = 0; a < n; ++a) {                                                        \
+      g[a] *= scale[a];                                                                  \
+      for (int bb = 0; bb < n; ++bb) H[(size_t)a * n + bb] *= scale[a] * scale[bb];     \
+    }                                                                                    \
+  } while (0)
+  SCALE_SYSTEM();
+  double radius = opt->initial_radius, decrease_factor = 2.0;
+  int invalid = 0;
+  int reuse_diag = 0;
+  while (1) {
+    if (sum->iterations >= opt->max_iterations) { sum->termination = PXO_TERM_NO_CONVERGENCE; break; }
+    if (radius < opt->min_radius) { sum->termination = PXO_TERM_CONVERGENCE; break; }
+    ++sum->iterations;
+    /* LevenbergMarquardtStrategy::ComputeStep */
+    if (!reuse_diag)
+      for (int j = 0; j < n; ++j) {
+        double d = H[(size_t)j * n + j];
+        diag[j] = d < opt->min_lm_diagonal ? opt->min_lm_diagonal : (d > opt->max_lm_diagonal ? opt->max_lm_diagonal : d);
+      }
+    memcpy(A, H, sizeof(double) * (size_t)n * n);
+    for (int j = 0; j < n; ++j) { A[(size_t)j * n + j] += diag[j] / radius; step[j] = -g[j]; }
+    int ok = chol_solve(n, A, step) == 0;
+    double model_cost_change = 0;
+    if (ok) {
+      /* -(J d).(r + J d/2) = -d.g - 0.5 d.H.d */
+      double dg = 0, dHd = 0;
+      for (int a = 0; a < n; ++a) {
+        dg += step[a] * g[a];
+        double hr = 0;
+        for (int bb = 0; bb < n; ++bb) hr += H[(size_t)a * n + bb] * step[bb];
+        dHd += step[a] * hr;
+        if (!isfinite(step[a])) ok = 0;
+      }
+      model_cost_change = -dg - 0.5 * dHd;
+      if (!(model_cost_change > 0.0)) ok = 0;
+    }
+    if (!ok) { /* HandleInvalidStep */
+      if (++invalid >= opt->max_consecutive_invalid_steps) { sum->termination = PXO_TERM_FAILURE; break; }
+      radius *= 0.5; reuse_diag = 1;   /* StepIsInvalid */
+      continue;
+    }
+    invalid = 0;
+    for (int j = 0; j < n; ++j) delta[j] = step[j] * scale[j];
+    ba_plus(&c, q, t, k, X, delta, q1, t1, k1, X1);
+    const double cand = ba_evaluate(&c, q1, t1, k1, X1, NULL, NULL);
+    const double step_norm = sqrt(ba_ambient_sqnorm(&c, q, t, k, X, q1, t1, k1, X1));
+    const double x_norm = sqrt(ba_ambient_sqnorm(&c, q, t, k, X, NULL, NULL, NULL, NULL));
+    if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) {
+      sum->termination = PXO_TERM_CONVERGENCE; break;
+    }
+    const double cost_change = cost - cand;
+    if (fabs(cost_change) <= opt->function_tolerance * cost) { sum->termination = PXO_TERM_CONVERGENCE; break; }
+    const double rel = cost_change / model_cost_change;
+    if (rel > opt->min_relative_decrease) { /* HandleSuccessfulStep */
+      memcpy(q, q1, sizeof(double) * 4 * n_images); memcpy(t, t1, sizeof(double) * 3 * n_images);
+      memcpy(k, k1, sizeof(double) * PXO_KPAD * n_cams); memcpy(X, X1, sizeof(double) * 3 * n_points);
+      cost = ba_evaluate(&c, q, t, k, X, H, g);
+      SCALE_SYSTEM();
+      ++sum->num_successful;
+      double gmax = 0;
+      for (int j = 0; j < n; ++j) { double v = fabs(g[j] / scale[j]); if (v > gmax) gmax = v; }
+      const double tmp = 2.0 * rel - 1.0;
+      double f = 1.0 - tmp * tmp * tmp;
+      if (f < 1.0 / 3.0) f = 1.0 / 3.0;
+      radius = radius / f;
+      if (radius > opt->max_radius) radius = opt->max_radius;
+      decrease_factor = 2.0; reuse_diag = 0;
+      if (gmax <= opt->gradient_tolerance) { sum->termination = PXO_TERM_CONVERGENCE; break; }
+    } else { /* StepRejected */
+      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diag = 1;
+    }
+  }
+  sum->final_cost = cost; sum->final_radius = radius;
+  free(H); free(A); free(g); free(scale); free(step); free(delta); free(diag);
+  free(q1); free(t1); free(k1); free(X1);
+  free(c.L.pose_off); free(c.L.pose_dim); free(c.L.intr_off); free(c.L.intr_dim); free(c.L.pt_off);
+  return 0;
+}

@@ -1,0 +1,791 @@
+// pxr_ba_solve.hip -- featuremetric bundle adjustment: Levenberg-Marquardt with Schur
+// elimination of the point blocks, entirely on the GPU.
+//
+// Replaces BundleOptimizer::SolveProblem -> ceres::Solve
+// (bundle_adjustment/src/bundle_optimizer.h:172-245) and the parameterisation of :335-453.
+// [upstream Ceres 2.1] trust_region_minimizer.cc / levenberg_marquardt_strategy.cc semantics.
+//
+// Because every residual block's Jacobian factors as J = G P (G: C x 2 descriptor gradients,
+// P: 2 x n projection Jacobian), the robustified normal equations of observation i are
+//     J~^T J~ = P^T M~ P ,  J~^T r~ = P^T b~ ,   M~ = rho'(G^T G - kappa b b^T), b~ = rho' G^T r
+// with the 2x2 / 2-vector (M~, b~) coming straight out of the fused record of pxr_ba_eval.
+// The solver therefore never touches C-dimensional data: one pass of the HBM-bound residual
+// kernel per LM iteration, everything else is per-observation 2 x (dc+3) algebra.
+//
+// Pipeline per linearisation (observations sorted by point for K1 locality):
+//   K_jac     thread/obs    M~, b~, E = d(x,y)/dX (2x3), B = d(x,y)/d(pose,intr) tangent (2xdc)
+//   K_point   thread/point  V_p = sum E^T M~ E, g_p = sum E^T b~
+//   K_img     block/(image,chunk)  U (pose/intrinsics blocks, upper) and g_c, LDS-reduced
+// per LM attempt (radius changes on rejection, linearisation is reused):
+//   K_pinv    thread/point  T_p = (V_p + D_p/radius)^-1
+//   K_wy      thread/obs    W_i = B^T M~ E (dc x 3), Y_i = W_i T_p
+//   K_schur   thread/(obs,row)  S -= Y_i W_j^T over the point's observation pairs (upper
+//             triangle only), rhs -= Y_i g_p      [atomics into the dense reduced system]
+//   all-reduce(S | rhs) over ranks (RCCL, multi-GPU), + LM damping, rocSOLVER potrf/potrs
+//   K_backsub thread/point  delta_p = -T_p (g_p + sum W_i^T delta_c)
+//   K_update  x (+) delta (quaternion manifold, subset manifolds), then pxr_ba_eval at the
+//             candidate WITH Jacobians (same HBM traffic as cost-only, saves the second
+//             evaluation Ceres does after an accepted step).
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "pxr_device.h"
+#include "pxr_internal.h"
+
+namespace pxr {
+
+constexpr int DC_CAP = 6 + PXR_KPAD;  // pose tangent (6) + intrinsics
+
+struct SolveDev {          // device-side problem description shared by the kernels
+  pxr_ba_view v;           // parameters being linearised (current or candidate)
+  const int* pose_off; const int* pose_dim; const int* tmask;   // per image
+  const int* intr_off; const int* intr_dim; const int* cmask;   // per camera
+  const int* pt_var;                                             // per point
+  const double* scale_c;   // [n_c]   Jacobi scaling, camera side
+  const double* scale_p;   // [n_points][3]
+  int n_c; int DC; int LS; // reduced system size, max camera-side columns, Lrec stride
+};
+
+// ---- K_jac ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_jac(const SolveDev d, const double* __restrict__ rec,
+                                             pxr_loss loss, double* __restrict__ L) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.v.n_obs) return;
+  const int img = d.v.d_obs_image[i], pt = d.v.d_obs_point[i], cam = d.v.d_image_camera[img];
+  double q[4], t[3], X[3], k[PXR_KPAD];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) q[j] = d.v.d_qvec[4 * (size_t)img + j];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { t[j] = d.v.d_tvec[3 * (size_t)img + j]; X[j] = d.v.d_xyz[3 * (size_t)pt + j]; }
+#pragma unroll
+  for (int j = 0; j < PXR_KPAD; ++j) k[j] = d.v.d_cam_params[(size_t)cam * PXR_KPAD + j];
+  const int model = d.v.d_cam_model[cam];
+  double x, y, A[2][3], Pq[2][4], PX[2][3], Pk[2][PXR_KPAD];
+  world_to_pixel_jac(model, k, q, t, X, x, y, A, Pq, PX, Pk);
+
+  const double* r = rec + (size_t)i * PXR_OBS_REC;
+  const double s = r[0], gxx = r[1], gxy = r[2], gyy = r[3], bx = r[4], by = r[5];
+  double rho[3];
+  loss_eval(loss.type, loss.a, 1.0, s, rho);
+  // corrector [upstream Ceres corrector.cc]: J~^T J~ = rho'(J^T J - kappa (J^T r)(J^T r)^T)
+  double kappa = 0.0;
+  if (s != 0.0 && rho[2] > 0.0) {
+    const double D = 1.0 + 2.0 * s * rho[2] / rho[1];
+    const double alpha = 1.0 - sqrt(D);
+    kappa = (2.0 * alpha - alpha * alpha) / s;
+  }
+  double* Lo = L + (size_t)i * d.LS;
+  Lo[0] = rho[1] * (gxx - kappa * bx * bx);
+  Lo[1] = rho[1] * (gxy - kappa * bx * by);
+  Lo[2] = rho[1] * (gyy - kappa * by * by);
+  Lo[3] = rho[1] * bx;
+  Lo[4] = rho[1] * by;
+  // E = d(x,y)/dX, scaled
+  const bool pvar = d.pt_var[pt] != 0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double sc = pvar ? d.scale_p[3 * (size_t)pt + j] : 0.0;
+    Lo[5 + j] = PX[0][j] * sc;
+    Lo[8 + j] = PX[1][j] * sc;
+  }
+  // B: tangent pose columns then variable intrinsics columns
+  double* B0 = Lo + 11;
+  double* B1 = B0 + d.DC;
+  int col = 0;
+  if (d.pose_dim[img] > 0) {
+    const int po = d.pose_off[img];
+    // QuaternionManifold::PlusJacobian [upstream Ceres manifold.cc], 4x3
+    const double PJ[4][3] = {{-q[1], -q[2], -q[3]}, {q[0], q[3], -q[2]}, {-q[3], q[0], q[1]}, {q[2], -q[1], q[0]}};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double sc = d.scale_c[po + a];
+      B0[col] = (Pq[0][0] * PJ[0][a] + Pq[0][1] * PJ[1][a] + Pq[0][2] * PJ[2][a] + Pq[0][3] * PJ[3][a]) * sc;
+      B1[col] = (Pq[1][0] * PJ[0][a] + Pq[1][1] * PJ[1][a] + Pq[1][2] * PJ[2][a] + Pq[1][3] * PJ[3][a]) * sc;
+      ++col;
+    }
+    const int tm = d.tmask[img];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if ((tm >> a) & 1) continue;
+      const double sc = d.scale_c[po + col];
+      B0[col] = A[0][a] * sc; B1[col] = A[1][a] * sc;
+      ++col;
+    }
+  }
+  if (d.intr_dim[cam] > 0) {
+    const int io = d.intr_off[cam], cm = d.cmask[cam], K = camera_num_params(model);
+    int kc = 0;
+#pragma unroll
+    for (int a = 0; a < PXR_KPAD; ++a) {
+      if (a >= K || ((cm >> a) & 1)) continue;
+      const double sc = d.scale_c[io + kc];
+      B0[col] = Pk[0][a] * sc; B1[col] = Pk[1][a] * sc;
+      ++col; ++kc;
+    }
+  }
+  for (; col < d.DC; ++col) { B0[col] = 0.0; B1[col] = 0.0; }
+}
+
+// global column index of camera-side column `a` of an observation in image img / camera cam
+__device__ __forceinline__ int col_index(const SolveDev& d, int img, int cam, int a) {
+  const int pd = d.pose_dim[img];
+  return a < pd ? d.pose_off[img] + a : d.intr_off[cam] + (a - pd);
+}
+
+// ---- K_point ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_point(const SolveDev d, const int64_t* __restrict__ pt_ptr,
+                                               const int64_t* __restrict__ pt_obs,
+                                               const double* __restrict__ L, double* __restrict__ V,
+                                               double* __restrict__ gp) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.v.n_points) return;
+  double v[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+  for (int64_t o = pt_ptr[p]; o < pt_ptr[p + 1]; ++o) {
+    const double* Lo = L + (size_t)pt_obs[o] * d.LS;
+    const double m00 = Lo[0], m01 = Lo[1], m11 = Lo[2], b0 = Lo[3], b1 = Lo[4];
+    const double e0[3] = {Lo[5], Lo[6], Lo[7]}, e1[3] = {Lo[8], Lo[9], Lo[10]};
+    double me0[3], me1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { me0[j] = m00 * e0[j] + m01 * e1[j]; me1[j] = m01 * e0[j] + m11 * e1[j]; }
+    v[0] += e0[0] * me0[0] + e1[0] * me1[0];
+    v[1] += e0[0] * me0[1] + e1[0] * me1[1];
+    v[2] += e0[0] * me0[2] + e1[0] * me1[2];
+    v[3] += e0[1] * me0[1] + e1[1] * me1[1];
+    v[4] += e0[1] * me0[2] + e1[1] * me1[2];
+    v[5] += e0[2] * me0[2] + e1[2] * me1[2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g[j] += e0[j] * b0 + e1[j] * b1;
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) V[6 * p + j] = v[j];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) gp[3 * p + j] = g[j];
+}
+
+// ---- K_img: U and g_c --------------------------------------------------------------------------
+struct ImgChunk { int img; int64_t begin, end; };
+
+__global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* __restrict__ chunks,
+                                             const int64_t* __restrict__ img_obs,
+                                             const double* __restrict__ L, double* __restrict__ U,
+                                             double* __restrict__ gc) {
+  __shared__ double red[256];
+  const ImgChunk ch = chunks[blockIdx.x];
+  const int img = ch.img, cam = d.v.d_image_camera[img];
+  const int dc = d.pose_dim[img] + d.intr_dim[cam];
+  if (dc == 0) return;
+  const int NP = dc * (dc + 1) / 2, NE = NP + dc;
+  const int slices = 256 / NE;                 // NE <= 189
+  const int e = threadIdx.x % NE, sl = threadIdx.x / NE;
+  int a = 0, b = 0;
+  const bool is_g = e >= NP;
+  if (is_g) { a = e - NP; }
+  else { int rem = e; a = 0; while (rem >= dc - a) { rem -= dc - a; ++a; } b = a + rem; }
+  double acc = 0.0;
+  if (sl < slices) {
+    for (int64_t o = ch.begin + sl; o < ch.end; o += slices) {
+      const double* Lo = L + (size_t)img_obs[o] * d.LS;
+      const double* B0 = Lo + 11; const double* B1 = B0 + d.DC;
+      if (is_g) acc += B0[a] * Lo[3] + B1[a] * Lo[4];
+      else acc += B0[a] * (Lo[0] * B0[b] + Lo[1] * B1[b]) + B1[a] * (Lo[1] * B0[b] + Lo[2] * B1[b]);
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (sl == 0) {
+    for (int s2 = 1; s2 < slices; ++s2) acc += red[s2 * NE + e];
+    const int ra = col_index(d, img, cam, a);
+    if (is_g) atomicAdd(gc + ra, acc);
+    else atomicAdd(U + (size_t)ra * d.n_c + col_index(d, img, cam, b), acc);
+  }
+}
+
+// ---- K_pinv: T_p = (V_p + D_p / radius)^-1 -----------------------------------------------------
+__global__ __launch_bounds__(256) void k_pinv(int64_t n_points, const int* __restrict__ pt_var,
+                                              const double* __restrict__ V,
+                                              const double* __restrict__ Vdiag0 /* clamped diag */,
+                                              double inv_radius, double* __restrict__ T) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_points) return;
+  double* To = T + 6 * p;
+  if (!pt_var[p]) { for (int j = 0; j < 6; ++j) To[j] = 0.0; return; }
+  const double a00 = V[6 * p] + Vdiag0[3 * p] * inv_radius, a01 = V[6 * p + 1], a02 = V[6 * p + 2];
+  const double a11 = V[6 * p + 3] + Vdiag0[3 * p + 1] * inv_radius, a12 = V[6 * p + 4];
+  const double a22 = V[6 * p + 5] + Vdiag0[3 * p + 2] * inv_radius;
+  const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+  const double det = a00 * c00 + a01 * c01 + a02 * c02;
+  const double id = 1.0 / det;
+  To[0] = c00 * id; To[1] = c01 * id; To[2] = c02 * id;
+  To[3] = (a00 * a22 - a02 * a02) * id; To[4] = (a01 * a02 - a00 * a12) * id;
+  To[5] = (a00 * a11 - a01 * a01) * id;
+}
+
+// ---- K_wy: W = B^T M~ E, Y = W T ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wy(const SolveDev d, const double* __restrict__ L,
+                                            const double* __restrict__ T, double* __restrict__ W,
+                                            double* __restrict__ Y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.v.n_obs) return;
+  const double* Lo = L + (size_t)i * d.LS;
+  const int pt = d.v.d_obs_point[i];
+  const double* Tp = T + 6 * (size_t)pt;
+  const double t00 = Tp[0], t01 = Tp[1], t02 = Tp[2], t11 = Tp[3], t12 = Tp[4], t22 = Tp[5];
+  double me0[3], me1[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    me0[j] = Lo[0] * Lo[5 + j] + Lo[1] * Lo[8 + j];
+    me1[j] = Lo[1] * Lo[5 + j] + Lo[2] * Lo[8 + j];
+  }
+  const double* B0 = Lo + 11; const double* B1 = B0 + d.DC;
+  double* Wo = W + (size_t)i * d.DC * 3; double* Yo = Y + (size_t)i * d.DC * 3;
+  for (int a = 0; a < d.DC; ++a) {
+    const double w0 = B0[a] * me0[0] + B1[a] * me1[0];
+    const double w1 = B0[a] * me0[1] + B1[a] * me1[1];
+    const double w2 = B0[a] * me0[2] + B1[a] * me1[2];
+    Wo[3 * a] = w0; Wo[3 * a + 1] = w1; Wo[3 * a + 2] = w2;
+    Yo[3 * a] = w0 * t00 + w1 * t01 + w2 * t02;
+    Yo[3 * a + 1] = w0 * t01 + w1 * t11 + w2 * t12;
+    Yo[3 * a + 2] = w0 * t02 + w1 * t12 + w2 * t22;
+  }
+}
+
+// ---- K_schur: S -= Y_i W_j^T (upper), rhs -= Y_i g_p ----------------------------------------------
+__global__ __launch_bounds__(256) void k_schur(const SolveDev d, const int64_t* __restrict__ pt_ptr,
+                                               const int64_t* __restrict__ pt_obs,
+                                               const double* __restrict__ W, const double* __restrict__ Y,
+                                               const double* __restrict__ gp, double* __restrict__ S,
+                                               double* __restrict__ rhs) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = tid / d.DC;
+  const int a = (int)(tid - i * d.DC);
+  if (i >= d.v.n_obs) return;
+  const int img = d.v.d_obs_image[i], cam = d.v.d_image_camera[img];
+  const int dci = d.pose_dim[img] + d.intr_dim[cam];
+  if (a >= dci) return;
+  const int pt = d.v.d_obs_point[i];
+  if (!d.pt_var[pt]) return;
+  const double* Yi = Y + ((size_t)i * d.DC + a) * 3;
+  const double y0 = Yi[0], y1 = Yi[1], y2 = Yi[2];
+  const int r = col_index(d, img, cam, a);
+  atomicAdd(rhs + r, -(y0 * gp[3 * (size_t)pt] + y1 * gp[3 * (size_t)pt + 1] + y2 * gp[3 * (size_t)pt + 2]));
+  for (int64_t o = pt_ptr[pt]; o < pt_ptr[pt + 1]; ++o) {
+    const int64_t j = pt_obs[o];
+    const int imgj = d.v.d_obs_image[j], camj = d.v.d_image_camera[imgj];
+    const int dcj = d.pose_dim[imgj] + d.intr_dim[camj];
+    const double* Wj = W + (size_t)j * d.DC * 3;
+    for (int b = 0; b < dcj; ++b) {
+      const int c = col_index(d, imgj, camj, b);
+      if (r > c) continue;   // upper triangle only: the mirrored entry comes from the ordered pair (j, i)
+      atomicAdd(S + (size_t)r * d.n_c + c, -(y0 * Wj[3 * b] + y1 * Wj[3 * b + 1] + y2 * Wj[3 * b + 2]));
+    }
+  }
+}
+
+// ---- small vector kernels --------------------------------------------------------------------------
+__global__ void k_copy_upper_add_diag(int n, const double* __restrict__ U, const double* __restrict__ damp,
+                                      double inv_radius, double* __restrict__ S, int add_u) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)n * n) return;
+  const int r = (int)(t / n), c = (int)(t % n);
+  double v = S[t];
+  if (add_u) v = (r <= c) ? U[t] : 0.0;
+  if (damp && r == c) v += damp[r] * inv_radius;
+  S[t] = v;
+}
+
+__global__ void k_extract_diag(int n, const double* __restrict__ U, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = U[(size_t)i * n + i];
+}
+
+__global__ void k_clamp(int64_t n, const double* __restrict__ in, double lo, double hi, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = fmin(fmax(in[i], lo), hi);
+}
+
+__global__ void k_point_diag(int64_t n_points, const double* __restrict__ V, double* __restrict__ out) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_points) return;
+  out[3 * p] = V[6 * p]; out[3 * p + 1] = V[6 * p + 3]; out[3 * p + 2] = V[6 * p + 5];
+}
+
+__global__ void k_jacobi_scale(int64_t n, const double* __restrict__ diag, double* __restrict__ scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) scale[i] = 1.0 / (1.0 + sqrt(diag[i]));
+}
+
+__global__ void k_fill(int64_t n, double v, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = v;
+}
+
+// delta_c = -x ; accumulates replicated scalars: [0] d.D.d - d.g (camera side)  [4] max|g_c/scale|
+__global__ void k_finish_camera_step(int n, const double* __restrict__ x, const double* __restrict__ gc,
+                                     const double* __restrict__ damp, double inv_radius,
+                                     double* __restrict__ delta_c, double* __restrict__ scal_rep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double part = 0.0;
+  if (i < n) {
+    const double dl = -x[i];
+    delta_c[i] = dl;
+    part = dl * (damp[i] * inv_radius * dl - gc[i]);
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  if ((threadIdx.x & 63) == 0) atomicAdd(scal_rep + 0, part);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// ---- K_backsub: delta_p = -T (g_p + sum_i W_i^T delta_c) ---------------------------------------------
+__global__ __launch_bounds__(256) void k_backsub(const SolveDev d, const int64_t* __restrict__ pt_ptr,
+                                                 const int64_t* __restrict__ pt_obs,
+                                                 const double* __restrict__ W, const double* __restrict__ T,
+                                                 const double* __restrict__ gp, const double* __restrict__ delta_c,
+                                                 const double* __restrict__ Vdiag0, double inv_radius,
+                                                 double* __restrict__ delta_p, double* __restrict__ scal_sum) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double part = 0.0;
+  if (p < d.v.n_points) {
+    double dl[3] = {0, 0, 0};
+    if (d.pt_var[p]) {
+      double v[3] = {gp[3 * p], gp[3 * p + 1], gp[3 * p + 2]};
+      for (int64_t o = pt_ptr[p]; o < pt_ptr[p + 1]; ++o) {
+        const int64_t i = pt_obs[o];
+        const int img = d.v.d_obs_image[i], cam = d.v.d_image_camera[img];
+        const int dci = d.pose_dim[img] + d.intr_dim[cam];
+        const double* Wi = W + (size_t)i * d.DC * 3;
+        for (int a = 0; a < dci; ++a) {
+          const double dcv = delta_c[col_index(d, img, cam, a)];
+          v[0] += Wi[3 * a] * dcv; v[1] += Wi[3 * a + 1] * dcv; v[2] += Wi[3 * a + 2] * dcv;
+        }
+      }
+      const double* Tp = T + 6 * p;
+      dl[0] = -(Tp[0] * v[0] + Tp[1] * v[1] + Tp[2] * v[2]);
+      dl[1] = -(Tp[1] * v[0] + Tp[3] * v[1] + Tp[4] * v[2]);
+      dl[2] = -(Tp[2] * v[0] + Tp[4] * v[1] + Tp[5] * v[2]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) part += dl[j] * (Vdiag0[3 * p + j] * inv_radius * dl[j] - gp[3 * p + j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) delta_p[3 * p + j] = dl[j];
+  }
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) atomicAdd(scal_sum + 1, part);
+}
+
+// ---- K_update: candidate = x (+) scale * delta --------------------------------------------------------
+struct ParamPtrs { double* q; double* t; double* k; double* X; };
+
+__global__ __launch_bounds__(256) void k_update(const SolveDev d, const double* __restrict__ delta_c,
+                                                const double* __restrict__ delta_p, ParamPtrs out,
+                                                double* __restrict__ scal_rep, double* __restrict__ scal_sum) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_img = d.v.n_images, n_cam = d.v.n_cameras;
+  double step2_rep = 0, x2_rep = 0, step2_sum = 0, x2_sum = 0;
+  if (tid < n_img) {
+    const int i = (int)tid;
+    double q0[4], t0[3], q1[4], t1[3];
+    for (int j = 0; j < 4; ++j) q1[j] = q0[j] = d.v.d_qvec[4 * i + j];
+    for (int j = 0; j < 3; ++j) t1[j] = t0[j] = d.v.d_tvec[3 * i + j];
+    if (d.pose_dim[i] > 0) {
+      const int po = d.pose_off[i];
+      const double dd[3] = {delta_c[po] * d.scale_c[po], delta_c[po + 1] * d.scale_c[po + 1],
+                            delta_c[po + 2] * d.scale_c[po + 2]};
+      const double nd = sqrt(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]);
+      if (nd != 0.0) {   // QuaternionManifold::Plus [upstream Ceres manifold.cc]
+        const double sn = sin(nd) / nd;
+        const double qd[4] = {cos(nd), sn * dd[0], sn * dd[1], sn * dd[2]};
+        q1[0] = qd[0] * q0[0] - qd[1] * q0[1] - qd[2] * q0[2] - qd[3] * q0[3];
+        q1[1] = qd[0] * q0[1] + qd[1] * q0[0] + qd[2] * q0[3] - qd[3] * q0[2];
+        q1[2] = qd[0] * q0[2] - qd[1] * q0[3] + qd[2] * q0[0] + qd[3] * q0[1];
+        q1[3] = qd[0] * q0[3] + qd[1] * q0[2] - qd[2] * q0[1] + qd[3] * q0[0];
+      }
+      int col = 3;
+      for (int a = 0; a < 3; ++a) {
+        if ((d.tmask[i] >> a) & 1) continue;
+        t1[a] = t0[a] + delta_c[po + col] * d.scale_c[po + col];
+        ++col;
+      }
+      for (int j = 0; j < 4; ++j) { x2_rep += q0[j] * q0[j]; step2_rep += (q1[j] - q0[j]) * (q1[j] - q0[j]); }
+      for (int j = 0; j < 3; ++j) { x2_rep += t0[j] * t0[j]; step2_rep += (t1[j] - t0[j]) * (t1[j] - t0[j]); }
+    }
+    for (int j = 0; j < 4; ++j) out.q[4 * i + j] = q1[j];
+    for (int j = 0; j < 3; ++j) out.t[3 * i + j] = t1[j];
+  } else if (tid < n_img + n_cam) {
+    const int c = (int)(tid - n_img);
+    const int K = camera_num_params(d.v.d_cam_model[c]);
+    int kc = 0;
+    for (int a = 0; a < PXR_KPAD; ++a) {
+      const double k0 = d.v.d_cam_params[(size_t)c * PXR_KPAD + a];
+      double k1 = k0;
+      if (d.intr_dim[c] > 0 && a < K) {
+        if (!((d.cmask[c] >> a) & 1)) {
+          const int io = d.intr_off[c] + kc;
+          k1 = k0 + delta_c[io] * d.scale_c[io];
+          ++kc;
+        }
+        x2_rep += k0 * k0; step2_rep += (k1 - k0) * (k1 - k0);
+      }
+      out.k[(size_t)c * PXR_KPAD + a] = k1;
+    }
+  } else if (tid < n_img + n_cam + d.v.n_points) {
+    const int64_t p = tid - n_img - n_cam;
+    for (int j = 0; j < 3; ++j) {
+      const double x0 = d.v.d_xyz[3 * p + j];
+      double x1 = x0;
+      if (d.pt_var[p]) {
+        x1 = x0 + delta_p[3 * p + j] * d.scale_p[3 * p + j];
+        x2_sum += x0 * x0; step2_sum += (x1 - x0) * (x1 - x0);
+      }
+      out.X[3 * p + j] = x1;
+    }
+  }
+  step2_rep = wave_sum(step2_rep); x2_rep = wave_sum(x2_rep);
+  step2_sum = wave_sum(step2_sum); x2_sum = wave_sum(x2_sum);
+  if ((threadIdx.x & 63) == 0) {
+    if (step2_rep != 0.0 || x2_rep != 0.0) { atomicAdd(scal_rep + 1, step2_rep); atomicAdd(scal_rep + 2, x2_rep); }
+    if (step2_sum != 0.0 || x2_sum != 0.0) { atomicAdd(scal_sum + 2, step2_sum); atomicAdd(scal_sum + 3, x2_sum); }
+  }
+}
+
+__global__ void k_normalize_q(int n, double* __restrict__ q) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double nn = sqrt(q[4 * i] * q[4 * i] + q[4 * i + 1] * q[4 * i + 1] + q[4 * i + 2] * q[4 * i + 2] + q[4 * i + 3] * q[4 * i + 3]);
+  for (int j = 0; j < 4; ++j) q[4 * i + j] /= nn;   // colmap::Image::NormalizeQvec, bundle_optimizer.h:255
+}
+
+// cost accumulation into scal_sum[0] (no host sync)
+__global__ __launch_bounds__(256) void k_cost(const double* __restrict__ rec, int64_t n, pxr_loss loss,
+                                              double* __restrict__ out) {
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double rho[3];
+    loss_eval(loss.type, loss.a, 1.0, rec[i * PXR_OBS_REC], rho);
+    acc += 0.5 * rho[0];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+__global__ void k_absmax_unscaled(int64_t n, const double* __restrict__ g, const double* __restrict__ scale,
+                                  double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double v = (i < n) ? fabs(g[i] / scale[i]) : 0.0;
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  if ((threadIdx.x & 63) == 0) {
+    // non-negative doubles order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(v));
+  }
+}
+
+// ---- host orchestration -----------------------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    n = count;
+    return hip_check(hipMalloc((void**)&p, sizeof(T) * (count ? count : 1)), "hipMalloc(solver buffer)");
+  }
+  int upload(const std::vector<T>& h, hipStream_t s) {
+    int rc = alloc(h.size());
+    if (rc) return rc;
+    if (!h.empty()) return hip_check(hipMemcpyAsync(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice, s), "H2D");
+    return PXR_OK;
+  }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+static inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
+
+#define RC(call) do { int _rc = (call); if (_rc != PXR_OK) return _rc; } while (0)
+#define LAUNCH_CHECK(name) RC(hip_check(hipGetLastError(), name))
+
+}  // namespace pxr
+
+extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
+                            const pxr_loss* loss, const uint8_t* h_pose_const, const uint8_t* h_tvec_const_mask,
+                            const uint16_t* h_cam_const_mask, const uint8_t* h_point_const,
+                            const pxr_lm_options* opt, pxr_allreduce_fn allreduce, void* ar_user,
+                            pxr_lm_summary* sum) {
+  using namespace pxr;
+  PXR_REQUIRE(ctx && arena && view && cfg && loss && opt && sum, "pxr_ba_solve: NULL argument");
+  PXR_REQUIRE(h_pose_const && h_tvec_const_mask && h_cam_const_mask && h_point_const,
+              "pxr_ba_solve: NULL parameterisation array");
+  PXR_REQUIRE(view->n_obs > 0, "pxr_ba_solve: problem has no residuals (bundle_optimizer.h:174-176)");
+  PXR_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const auto t_setup0 = std::chrono::steady_clock::now();
+  const int64_t n_obs = view->n_obs, n_pts = view->n_points;
+  const int n_img = view->n_images, n_cam = view->n_cameras;
+
+  // ---- host-side structure: which blocks are in the program, offsets, CSR lists ------------
+  std::vector<int32_t> obs_image(n_obs), obs_point(n_obs), image_camera(n_img), cam_model(n_cam);
+  PXR_HIP(hipMemcpyAsync(obs_image.data(), view->d_obs_image, 4 * n_obs, hipMemcpyDeviceToHost, st));
+  PXR_HIP(hipMemcpyAsync(obs_point.data(), view->d_obs_point, 4 * n_obs, hipMemcpyDeviceToHost, st));
+  PXR_HIP(hipMemcpyAsync(image_camera.data(), view->d_image_camera, 4 * n_img, hipMemcpyDeviceToHost, st));
+  PXR_HIP(hipMemcpyAsync(cam_model.data(), view->d_cam_model, 4 * n_cam, hipMemcpyDeviceToHost, st));
+  PXR_HIP(hipStreamSynchronize(st));
+  static const int kNumParams[5] = {3, 4, 4, 5, 8};
+  for (int c = 0; c < n_cam; ++c)
+    PXR_REQUIRE(cam_model[c] >= 0 && cam_model[c] <= 4, "pxr_ba_solve: unsupported camera model id %d", cam_model[c]);
+  std::vector<int64_t> img_cnt(n_img + 1, 0), pt_cnt(n_pts + 1, 0);
+  for (int64_t i = 0; i < n_obs; ++i) {
+    PXR_REQUIRE(obs_image[i] >= 0 && obs_image[i] < n_img && obs_point[i] >= 0 && obs_point[i] < n_pts,
+                "pxr_ba_solve: observation %lld references image %d / point %d out of range", (long long)i,
+                obs_image[i], obs_point[i]);
+    ++img_cnt[obs_image[i] + 1]; ++pt_cnt[obs_point[i] + 1];
+  }
+  // With several ranks a camera-side block may have no local observation but still be part of the
+  // (global) program: the caller marks unused blocks constant, we keep every non-constant block.
+  std::vector<int> pose_off(n_img), pose_dim(n_img), tmask(n_img), intr_off(n_cam), intr_dim(n_cam), cmask(n_cam), pt_var(n_pts);
+  int off = 0, dpose_max = 0, dintr_max = 0;
+  for (int i = 0; i < n_img; ++i) {
+    int d = 0;
+    tmask[i] = h_tvec_const_mask[i] & 7;
+    if (!h_pose_const[i]) d = 3 + (3 - __builtin_popcount(tmask[i]));
+    pose_off[i] = off; pose_dim[i] = d; off += d;
+    dpose_max = std::max(dpose_max, d);
+  }
+  for (int c = 0; c < n_cam; ++c) {
+    const int K = kNumParams[cam_model[c]];
+    cmask[c] = h_cam_const_mask[c] & ((1 << K) - 1);
+    const int d = K - __builtin_popcount(cmask[c]);
+    intr_off[c] = off; intr_dim[c] = d; off += d;
+    dintr_max = std::max(dintr_max, d);
+  }
+  const int n_c = off;
+  const int DC = std::max(1, dpose_max + dintr_max);
+  const int LS = 11 + 2 * DC;
+  int64_t n_pvar = 0;
+  for (int64_t p = 0; p < n_pts; ++p) { pt_var[p] = (!h_point_const[p] && pt_cnt[p + 1] > 0) ? 1 : 0; n_pvar += pt_var[p]; }
+  PXR_REQUIRE(n_c > 0 || n_pvar > 0, "pxr_ba_solve: every parameter block is constant");
+  for (int i = 0; i < n_img; ++i) img_cnt[i + 1] += img_cnt[i];
+  for (int64_t p = 0; p < n_pts; ++p) pt_cnt[p + 1] += pt_cnt[p];
+  std::vector<int64_t> img_obs(n_obs), pt_obs(n_obs);
+  {
+    std::vector<int64_t> ic(img_cnt.begin(), img_cnt.end() - 1), pc(pt_cnt.begin(), pt_cnt.end() - 1);
+    for (int64_t i = 0; i < n_obs; ++i) { img_obs[ic[obs_image[i]]++] = i; pt_obs[pc[obs_point[i]]++] = i; }
+  }
+  std::vector<ImgChunk> chunks;
+  const int64_t CH = 2048;
+  for (int i = 0; i < n_img; ++i)
+    for (int64_t b = img_cnt[i]; b < img_cnt[i + 1]; b += CH)
+      chunks.push_back({i, b, std::min(img_cnt[i + 1], b + CH)});
+
+  // ---- device buffers ---------------------------------------------------------------------------
+  DevBuf<int> d_pose_off, d_pose_dim, d_tmask, d_intr_off, d_intr_dim, d_cmask, d_pt_var;
+  DevBuf<int64_t> d_img_obs, d_pt_ptr, d_pt_obs;
+  DevBuf<ImgChunk> d_chunks;
+  RC(d_pose_off.upload(pose_off, st)); RC(d_pose_dim.upload(pose_dim, st)); RC(d_tmask.upload(tmask, st));
+  RC(d_intr_off.upload(intr_off, st)); RC(d_intr_dim.upload(intr_dim, st)); RC(d_cmask.upload(cmask, st));
+  RC(d_pt_var.upload(pt_var, st)); RC(d_img_obs.upload(img_obs, st)); RC(d_pt_ptr.upload(pt_cnt, st));
+  RC(d_pt_obs.upload(pt_obs, st)); RC(d_chunks.upload(chunks, st));
+  const size_t nc1 = n_c ? n_c : 1;
+  DevBuf<double> L, V, gp, Vd0, T, W, Y, U, S /* S | rhs */, gcd /* diagU | g_c */, damp_c, scale_c, scale_p,
+      delta_c, delta_p, rec_a, rec_b, q1, t1, k1, X1, scal;
+  RC(L.alloc((size_t)n_obs * LS)); RC(V.alloc((size_t)n_pts * 6)); RC(gp.alloc((size_t)n_pts * 3));
+  RC(Vd0.alloc((size_t)n_pts * 3)); RC(T.alloc((size_t)n_pts * 6));
+  RC(W.alloc((size_t)n_obs * DC * 3)); RC(Y.alloc((size_t)n_obs * DC * 3));
+  RC(U.alloc(nc1 * nc1)); RC(S.alloc(nc1 * nc1 + nc1)); RC(gcd.alloc(2 * nc1)); RC(damp_c.alloc(nc1));
+  RC(scale_c.alloc(nc1)); RC(scale_p.alloc((size_t)n_pts * 3)); RC(delta_c.alloc(nc1)); RC(delta_p.alloc((size_t)n_pts * 3));
+  RC(rec_a.alloc((size_t)n_obs * PXR_OBS_REC)); RC(rec_b.alloc((size_t)n_obs * PXR_OBS_REC));
+  RC(q1.alloc((size_t)n_img * 4)); RC(t1.alloc((size_t)n_img * 3)); RC(k1.alloc((size_t)n_cam * PXR_KPAD)); RC(X1.alloc((size_t)n_pts * 3));
+  RC(scal.alloc(16));   // [0..7] summed over ranks, [8..15] replicated
+  double* scal_sum = scal.p; double* scal_rep = scal.p + 8;
+  double* rhs = S.p + nc1 * nc1;
+  double* diagU = gcd.p; double* gc = gcd.p + nc1;
+  rocblas_handle blas = nullptr;
+  rocblas_int* d_info = nullptr;
+  if (n_c > 0) {
+    PXR_REQUIRE(rocblas_create_handle(&blas) == rocblas_status_success, "rocblas_create_handle failed");
+    rocblas_set_stream(blas, st);
+    PXR_HIP(hipMalloc((void**)&d_info, sizeof(rocblas_int)));
+  }
+  struct Cleanup { rocblas_handle& h; rocblas_int*& i; ~Cleanup() { if (h) rocblas_destroy_handle(h); if (i) (void)hipFree(i); } } cleanup{blas, d_info};
+
+  double* cur_q = const_cast<double*>(view->d_qvec); double* cur_t = const_cast<double*>(view->d_tvec);
+  double* cur_k = const_cast<double*>(view->d_cam_params); double* cur_X = const_cast<double*>(view->d_xyz);
+  hipLaunchKernelGGL(k_normalize_q, dim3(nblk(n_img)), dim3(256), 0, st, n_img, cur_q);
+
+  SolveDev dv;
+  dv.v = *view;
+  dv.pose_off = d_pose_off.p; dv.pose_dim = d_pose_dim.p; dv.tmask = d_tmask.p;
+  dv.intr_off = d_intr_off.p; dv.intr_dim = d_intr_dim.p; dv.cmask = d_cmask.p; dv.pt_var = d_pt_var.p;
+  dv.scale_c = scale_c.p; dv.scale_p = scale_p.p; dv.n_c = n_c; dv.DC = DC; dv.LS = LS;
+  pxr_ba_view cand_view = *view;
+  cand_view.d_qvec = q1.p; cand_view.d_tvec = t1.p; cand_view.d_cam_params = k1.p; cand_view.d_xyz = X1.p;
+
+  auto ar = [&](double* buf, int64_t count) -> int {
+    if (!allreduce) return PXR_OK;
+    if (allreduce(ar_user, buf, count) != 0) return set_error(PXR_EHIP, "pxr_ba_solve: all-reduce callback failed");
+    return PXR_OK;
+  };
+  auto read_scal = [&](double* h16) -> int {
+    RC(ar(scal_sum, 8));
+    PXR_HIP(hipMemcpyAsync(h16, scal.p, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
+    PXR_HIP(hipStreamSynchronize(st));
+    return PXR_OK;
+  };
+  auto evaluate = [&](const pxr_ba_view& v, double* rec) -> int {   // rec + cost into scal_sum[0]
+    RC(pxr_ba_eval(ctx, arena, &v, cfg, 1, rec, nullptr, nullptr, nullptr));
+    hipLaunchKernelGGL(k_cost, dim3(std::min<unsigned>(2048, nblk(n_obs))), dim3(256), 0, st, rec, n_obs, *loss, scal_sum);
+    LAUNCH_CHECK("k_cost");
+    return PXR_OK;
+  };
+  // linearise at the CURRENT parameters from record buffer `rec`
+  auto linearize = [&](const double* rec) -> int {
+    hipLaunchKernelGGL(k_jac, dim3(nblk(n_obs)), dim3(256), 0, st, dv, rec, *loss, L.p);
+    hipLaunchKernelGGL(k_point, dim3(nblk(n_pts)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, L.p, V.p, gp.p);
+    PXR_HIP(hipMemsetAsync(U.p, 0, sizeof(double) * nc1 * nc1, st));
+    PXR_HIP(hipMemsetAsync(gcd.p, 0, sizeof(double) * 2 * nc1, st));
+    if (n_c > 0 && !chunks.empty()) {
+      hipLaunchKernelGGL(k_img, dim3((unsigned)chunks.size()), dim3(256), 0, st, dv, d_chunks.p, d_img_obs.p, L.p, U.p, gc);
+      hipLaunchKernelGGL(k_extract_diag, dim3(nblk(n_c)), dim3(256), 0, st, n_c, U.p, diagU);
+    }
+    LAUNCH_CHECK("linearize kernels");
+    RC(ar(gcd.p, 2 * (int64_t)nc1));   // global diag(U) and g_c
+    return PXR_OK;
+  };
+  auto refresh_damping = [&]() -> int {  // LevenbergMarquardtStrategy: diagonal clamped to [min, max]
+    if (n_c > 0) hipLaunchKernelGGL(k_clamp, dim3(nblk(n_c)), dim3(256), 0, st, (int64_t)n_c, diagU, opt->min_lm_diagonal, opt->max_lm_diagonal, damp_c.p);
+    hipLaunchKernelGGL(k_point_diag, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, V.p, Vd0.p);
+    hipLaunchKernelGGL(k_clamp, dim3(nblk(n_pts * 3)), dim3(256), 0, st, n_pts * 3, Vd0.p, opt->min_lm_diagonal, opt->max_lm_diagonal, Vd0.p);
+    LAUNCH_CHECK("damping kernels");
+    return PXR_OK;
+  };
+
+  const auto t_loop0 = std::chrono::steady_clock::now();
+  sum->setup_ms = std::chrono::duration<double, std::milli>(t_loop0 - t_setup0).count();
+  sum->num_camera_unknowns = n_c; sum->num_point_unknowns = 3 * n_pvar;
+  sum->iterations = 0; sum->num_successful = 0; sum->termination = PXR_TERM_NO_CONVERGENCE;
+  const bool verbose = std::getenv("PXR_VERBOSE") != nullptr;
+
+  // ---- iteration 0: evaluate, Jacobi scaling, linearise ------------------------------------------------
+  double hs[16];
+  double* rec_cur = rec_a.p; double* rec_cand = rec_b.p;
+  PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * 16, st));
+  RC(evaluate(dv.v, rec_cur));
+  RC(read_scal(hs));
+  double cost = hs[0];
+  sum->initial_cost = cost;
+  hipLaunchKernelGGL(k_fill, dim3(nblk(nc1)), dim3(256), 0, st, (int64_t)nc1, 1.0, scale_c.p);
+  hipLaunchKernelGGL(k_fill, dim3(nblk(n_pts * 3)), dim3(256), 0, st, n_pts * 3, 1.0, scale_p.p);
+  RC(linearize(rec_cur));
+  if (opt->jacobi_scaling) {   // 1 / (1 + sqrt(diag(J~^T J~))), fixed for the whole solve
+    if (n_c > 0) hipLaunchKernelGGL(k_jacobi_scale, dim3(nblk(n_c)), dim3(256), 0, st, (int64_t)n_c, diagU, scale_c.p);
+    hipLaunchKernelGGL(k_point_diag, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, V.p, Vd0.p);
+    hipLaunchKernelGGL(k_jacobi_scale, dim3(nblk(n_pts * 3)), dim3(256), 0, st, n_pts * 3, Vd0.p, scale_p.p);
+    RC(linearize(rec_cur));
+  }
+  double radius = opt->initial_radius, decrease_factor = 2.0;
+  int invalid = 0;
+  bool reuse_diag = false;
+
+  while (true) {
+    if (sum->iterations >= opt->max_iterations) { sum->termination = PXR_TERM_NO_CONVERGENCE; break; }
+    if (radius < opt->min_radius) { sum->termination = PXR_TERM_CONVERGENCE; break; }
+    ++sum->iterations;
+    if (!reuse_diag) RC(refresh_damping());
+    const double inv_radius = 1.0 / radius;
+    // point elimination + reduced camera system
+    hipLaunchKernelGGL(k_pinv, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, d_pt_var.p, V.p, Vd0.p, inv_radius, T.p);
+    PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * 16, st));
+    bool ok = true;
+    if (n_c > 0) {
+      hipLaunchKernelGGL(k_wy, dim3(nblk(n_obs)), dim3(256), 0, st, dv, L.p, T.p, W.p, Y.p);
+      hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * n_c)), dim3(256), 0, st, n_c, U.p, (const double*)nullptr, 0.0, S.p, 1);
+      PXR_HIP(hipMemsetAsync(rhs, 0, sizeof(double) * n_c, st));
+      hipLaunchKernelGGL(k_schur, dim3(nblk(n_obs * DC)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, W.p, Y.p, gp.p, S.p, rhs);
+      LAUNCH_CHECK("schur kernels");
+      RC(ar(S.p, (int64_t)nc1 * nc1 + n_c));          // sum of U_local - Schur_local and of -Y g_p
+      // rhs += g_c (global), S += D_c / radius
+      hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * n_c)), dim3(256), 0, st, n_c, U.p, damp_c.p, inv_radius, S.p, 0);
+      rocblas_status bs;
+      {
+        const double one = 1.0;
+        bs = rocblas_daxpy(blas, n_c, &one, gc, 1, rhs, 1);
+        PXR_REQUIRE(bs == rocblas_status_success, "rocblas_daxpy failed (%d)", (int)bs);
+      }
+      // row-major upper == column-major lower
+      bs = rocsolver_dpotrf(blas, rocblas_fill_lower, n_c, S.p, n_c, d_info);
+      PXR_REQUIRE(bs == rocblas_status_success, "rocsolver_dpotrf failed (%d)", (int)bs);
+      rocblas_int info = 0;
+      PXR_HIP(hipMemcpyAsync(&info, d_info, sizeof(info), hipMemcpyDeviceToHost, st));
+      PXR_HIP(hipStreamSynchronize(st));
+      if (info != 0) ok = false;
+      if (ok) {
+        bs = rocsolver_dpotrs(blas, rocblas_fill_lower, n_c, 1, S.p, n_c, rhs, n_c);
+        PXR_REQUIRE(bs == rocblas_status_success, "rocsolver_dpotrs failed (%d)", (int)bs);
+        hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, rhs, gc, damp_c.p, inv_radius, delta_c.p, scal_rep);
+      }
+    }
+    double model_cost_change = 0, cand_cost = 0, step_norm = 0, x_norm = 0;
+    if (ok) {
+      hipLaunchKernelGGL(k_backsub, dim3(nblk(n_pts)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, W.p, T.p, gp.p, delta_c.p, Vd0.p, inv_radius, delta_p.p, scal_sum);
+      ParamPtrs out{q1.p, t1.p, k1.p, X1.p};
+      hipLaunchKernelGGL(k_update, dim3(nblk((int64_t)n_img + n_cam + n_pts)), dim3(256), 0, st, dv, delta_c.p, delta_p.p, out, scal_rep, scal_sum);
+      LAUNCH_CHECK("step kernels");
+      RC(evaluate(cand_view, rec_cand));
+      RC(read_scal(hs));
+      cand_cost = hs[0];
+      model_cost_change = 0.5 * (hs[1] + hs[8]);     // 0.5 * delta.(D^2 delta - g) == -(J d).(r + J d / 2)
+      step_norm = std::sqrt(hs[2] + hs[9]);
+      x_norm = std::sqrt(hs[3] + hs[10]);
+      if (!(model_cost_change > 0.0) || !std::isfinite(model_cost_change) || !std::isfinite(cand_cost)) ok = false;
+    }
+    if (verbose)
+      fprintf(stderr, "[pxr_ba_solve] it %3d cost %.9e cand %.9e mcc %.3e radius %.3e |dx| %.3e %s\n", sum->iterations,
+              cost, cand_cost, model_cost_change, radius, step_norm, ok ? "" : "INVALID");
+    if (!ok) {   // HandleInvalidStep
+      if (++invalid >= opt->max_consecutive_invalid_steps) { sum->termination = PXR_TERM_FAILURE; break; }
+      radius *= 0.5; reuse_diag = true;
+      continue;
+    }
+    invalid = 0;
+    if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) { sum->termination = PXR_TERM_CONVERGENCE; break; }
+    const double cost_change = cost - cand_cost;
+    if (std::fabs(cost_change) <= opt->function_tolerance * cost) { sum->termination = PXR_TERM_CONVERGENCE; break; }
+    const double rel = cost_change / model_cost_change;
+    if (rel > opt->min_relative_decrease) {   // HandleSuccessfulStep
+      PXR_HIP(hipMemcpyAsync(cur_q, q1.p, sizeof(double) * 4 * n_img, hipMemcpyDeviceToDevice, st));
+      PXR_HIP(hipMemcpyAsync(cur_t, t1.p, sizeof(double) * 3 * n_img, hipMemcpyDeviceToDevice, st));
+      PXR_HIP(hipMemcpyAsync(cur_k, k1.p, sizeof(double) * PXR_KPAD * n_cam, hipMemcpyDeviceToDevice, st));
+      PXR_HIP(hipMemcpyAsync(cur_X, X1.p, sizeof(double) * 3 * n_pts, hipMemcpyDeviceToDevice, st));
+      std::swap(rec_cur, rec_cand);
+      cost = cand_cost;
+      RC(linearize(rec_cur));
+      ++sum->num_successful;
+      const double tmp = 2.0 * rel - 1.0;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - tmp * tmp * tmp);
+      radius = std::min(opt->max_radius, radius);
+      decrease_factor = 2.0; reuse_diag = false;
+      if (opt->gradient_tolerance > 0.0) {
+        PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * 16, st));
+        if (n_c > 0) hipLaunchKernelGGL(k_absmax_unscaled, dim3(nblk(n_c)), dim3(256), 0, st, (int64_t)n_c, gc, scale_c.p, scal_rep + 4);
+        hipLaunchKernelGGL(k_absmax_unscaled, dim3(nblk(n_pts * 3)), dim3(256), 0, st, n_pts * 3, gp.p, scale_p.p, scal_rep + 5);
+        PXR_HIP(hipMemcpyAsync(hs, scal.p, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
+        PXR_HIP(hipStreamSynchronize(st));
+        if (std::max(hs[12], hs[13]) <= opt->gradient_tolerance) { sum->termination = PXR_TERM_CONVERGENCE; break; }
+      }
+    } else {   // StepRejected
+      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diag = true;
+    }
+  }
+  PXR_HIP(hipStreamSynchronize(st));
+  sum->final_cost = cost; sum->final_radius = radius;
+  sum->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop0).count();
+  return PXR_OK;
+}

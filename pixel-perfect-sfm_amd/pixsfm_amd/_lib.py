@@ -36,6 +36,27 @@ class BaView(C.Structure):
                 ("d_xyz", C.c_void_p), ("d_refs", C.c_void_p)]
 
 
+class LMOptions(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("function_tolerance", C.c_double),
+                ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
+                ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
+                ("max_lm_diagonal", C.c_double), ("max_consecutive_invalid_steps", C.c_int32),
+                ("jacobi_scaling", C.c_int32)]
+
+
+class LMSummary(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("num_successful", C.c_int32), ("termination", C.c_int32),
+                ("num_camera_unknowns", C.c_int32), ("num_point_unknowns", C.c_int64),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double),
+                ("total_ms", C.c_double), ("setup_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+
 # every symbol include/pixsfm_hip.h declares (checked by tests/test_cabi.py)
 _SIGNATURES = {
     "pxr_version": (C.c_int, []),
@@ -61,6 +82,9 @@ _SIGNATURES = {
     "pxr_ba_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BaView), C.POINTER(InterpCfg), C.c_int,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pxr_ba_projection_jacobian": (C.c_int, [C.c_void_p, C.POINTER(BaView), C.c_void_p]),
+    "pxr_ba_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BaView), C.POINTER(InterpCfg), C.POINTER(Loss),
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(LMOptions),
+                               C.c_void_p, C.c_void_p, C.POINTER(LMSummary)]),
     "pxr_ba_cost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Loss), C.POINTER(C.c_double)]),
 }
 

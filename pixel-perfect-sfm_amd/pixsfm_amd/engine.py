@@ -173,6 +173,19 @@ def make_loss(name="cauchy", params=(0.25,)):
     return Loss(_lib.LOSS_IDS[name], a)
 
 
+def lm_options(max_iterations=100, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0,
+               initial_radius=1e4, max_radius=1e16, min_radius=1e-32, min_relative_decrease=1e-3,
+               min_lm_diagonal=1e-6, max_lm_diagonal=1e32, max_consecutive_invalid_steps=10, jacobi_scaling=1,
+               **ignored):
+    """Subset of ceres::Solver::Options the engine honours (pixsfm/base/main.py:9-22 +
+    bundle_adjustment_options.h:48-64); unknown keys are ignored like pyceres ignores nothing --
+    callers should pass only what they need."""
+    return _lib.LMOptions(int(max_iterations), float(function_tolerance), float(gradient_tolerance),
+                          float(parameter_tolerance), float(initial_radius), float(max_radius), float(min_radius),
+                          float(min_relative_decrease), float(min_lm_diagonal), float(max_lm_diagonal),
+                          int(max_consecutive_invalid_steps), int(jacobi_scaling))
+
+
 class BAProblem:
     """Device-resident flat arrays of a bundle-adjustment problem (pxr_ba_view).
 
@@ -232,6 +245,46 @@ class BAProblem:
         check(self.ctx.lib.pxr_ba_projection_jacobian(self.ctx.handle, C.byref(self.view), P.ptr),
               "pxr_ba_projection_jacobian")
         return P
+
+    def solve(self, cfg, loss, pose_const, tvec_const_mask, cam_const_mask, point_const, options=None,
+              allreduce=None):
+        """Run the GPU LM (pxr_ba_solve); parameters are refined in place on the device.
+
+        allreduce: optional callable(device_ptr:int, count:int) summing `count` doubles in place
+        over the ranks (see parallel.make_allreduce); None for one GPU.
+        Returns the summary dict; use params() to fetch the refined parameters.
+        """
+        ctx = self.ctx
+        pc = np.ascontiguousarray(pose_const, dtype=np.uint8)
+        tm = np.ascontiguousarray(tvec_const_mask, dtype=np.uint8)
+        cm = np.ascontiguousarray(cam_const_mask, dtype=np.uint16)
+        ptc = np.ascontiguousarray(point_const, dtype=np.uint8)
+        if len(pc) != self.n_images or len(tm) != self.n_images or len(cm) != self.n_cameras \
+                or len(ptc) != self.n_points:
+            raise ValueError("parameterisation arrays do not match the problem dimensions")
+        opts = options or lm_options()
+        summ = _lib.LMSummary()
+        cb = None
+        if allreduce is not None:
+            def _cb(user, ptr, count):
+                try:
+                    allreduce(ptr, count)
+                    return 0
+                except Exception as e:  # noqa: BLE001 -- must not unwind through C
+                    import sys
+                    print("all-reduce callback failed: %r" % (e,), file=sys.stderr)
+                    return 1
+            cb = _lib.ALLREDUCE_FN(_cb)
+        check(ctx.lib.pxr_ba_solve(ctx.handle, self.arena.handle, C.byref(self.view), C.byref(cfg), C.byref(loss),
+                                   pc.ctypes.data, tm.ctypes.data, cm.ctypes.data, ptc.ctypes.data,
+                                   C.byref(opts), C.cast(cb, C.c_void_p) if cb else None, None, C.byref(summ)),
+              "pxr_ba_solve")
+        return summ.as_dict()
+
+    def params(self):
+        """Download (qvec, tvec, cam_params, xyz)."""
+        d = self.d
+        return d["qvec"].download(), d["tvec"].download(), d["cam_params"].download(), d["xyz"].download()
 
     def cost(self, loss):
         out = C.c_double()

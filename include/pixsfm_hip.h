@@ -198,6 +198,14 @@ int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const 
                  const pxr_lm_options* options, pxr_allreduce_fn allreduce, void* allreduce_user,
                  pxr_lm_summary* summary);
 
+
+/* Dense SPD solve used for the reduced camera system (what Ceres' DENSE_SCHUR / SPARSE_SCHUR
+ * Cholesky does on the CPU, bundle_optimizer.h:181-191): blocked right-looking Cholesky +
+ * substitution in hand-written HIP.  d_a: n x n row-major, UPPER triangle filled (overwritten
+ * by the factor); d_b: right-hand side -> solution.  *h_info = 0 or the 1-based index of the
+ * first non-positive pivot. */
+int pxr_dense_spd_solve(pxr_ctx* ctx, double* d_a, int n, double* d_b, int* h_info);
+
 #ifdef __cplusplus
 }
 #endif

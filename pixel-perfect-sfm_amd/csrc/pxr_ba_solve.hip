@@ -27,8 +27,6 @@
 //             candidate WITH Jacobians (same HBM traffic as cost-only, saves the second
 //             evaluation Ceres does after an accepted step).
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
-#include <rocsolver/rocsolver.h>
 
 #include <algorithm>
 #include <chrono>
@@ -322,6 +320,11 @@ __global__ void k_jacobi_scale(int64_t n, const double* __restrict__ diag, doubl
   if (i < n) scale[i] = 1.0 / (1.0 + sqrt(diag[i]));
 }
 
+__global__ void k_axpy1(int n, const double* __restrict__ x, double* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += x[i];
+}
+
 __global__ void k_fill(int64_t n, double v, double* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = v;
@@ -508,6 +511,9 @@ struct DevBuf {
   ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
+int chol_factor(hipStream_t st, double* a, int n, int lda, int* d_info);   // pxr_chol.hip
+int chol_solve(hipStream_t st, const double* a, int n, int lda, double* b);
+
 static inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 
 #define RC(call) do { int _rc = (call); if (_rc != PXR_OK) return _rc; } while (0)
@@ -607,14 +613,9 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   double* scal_sum = scal.p; double* scal_rep = scal.p + 8;
   double* rhs = S.p + nc1 * nc1;
   double* diagU = gcd.p; double* gc = gcd.p + nc1;
-  rocblas_handle blas = nullptr;
-  rocblas_int* d_info = nullptr;
-  if (n_c > 0) {
-    PXR_REQUIRE(rocblas_create_handle(&blas) == rocblas_status_success, "rocblas_create_handle failed");
-    rocblas_set_stream(blas, st);
-    PXR_HIP(hipMalloc((void**)&d_info, sizeof(rocblas_int)));
-  }
-  struct Cleanup { rocblas_handle& h; rocblas_int*& i; ~Cleanup() { if (h) rocblas_destroy_handle(h); if (i) (void)hipFree(i); } } cleanup{blas, d_info};
+  DevBuf<int> info_buf;
+  RC(info_buf.alloc(1));
+  int* d_info = info_buf.p;
 
   double* cur_q = const_cast<double*>(view->d_qvec); double* cur_t = const_cast<double*>(view->d_tvec);
   double* cur_k = const_cast<double*>(view->d_cam_params); double* cur_X = const_cast<double*>(view->d_xyz);
@@ -672,6 +673,16 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   sum->num_camera_unknowns = n_c; sum->num_point_unknowns = 3 * n_pvar;
   sum->iterations = 0; sum->num_successful = 0; sum->termination = PXR_TERM_NO_CONVERGENCE;
   const bool verbose = std::getenv("PXR_VERBOSE") != nullptr;
+  const bool phase_timing = std::getenv("PXR_PHASE_TIMING") != nullptr;   // adds a stream sync per phase
+  double ph_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto ph_t0 = std::chrono::steady_clock::now();
+  auto phase = [&](int k) {
+    if (!phase_timing) return;
+    (void)hipStreamSynchronize(st);
+    const auto now = std::chrono::steady_clock::now();
+    ph_ms[k] += std::chrono::duration<double, std::milli>(now - ph_t0).count();
+    ph_t0 = now;
+  };
 
   // ---- iteration 0: evaluate, Jacobi scaling, linearise ------------------------------------------------
   double hs[16];
@@ -698,6 +709,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     if (sum->iterations >= opt->max_iterations) { sum->termination = PXR_TERM_NO_CONVERGENCE; break; }
     if (radius < opt->min_radius) { sum->termination = PXR_TERM_CONVERGENCE; break; }
     ++sum->iterations;
+    phase(7);
     if (!reuse_diag) RC(refresh_damping());
     const double inv_radius = 1.0 / radius;
     // point elimination + reduced camera system
@@ -710,36 +722,33 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       PXR_HIP(hipMemsetAsync(rhs, 0, sizeof(double) * n_c, st));
       hipLaunchKernelGGL(k_schur, dim3(nblk(n_obs * DC)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, W.p, Y.p, gp.p, S.p, rhs);
       LAUNCH_CHECK("schur kernels");
-      RC(ar(S.p, (int64_t)nc1 * nc1 + n_c));          // sum of U_local - Schur_local and of -Y g_p
+      phase(0);
+      RC(ar(S.p, (int64_t)nc1 * nc1 + n_c));
+      phase(1);          // sum of U_local - Schur_local and of -Y g_p
       // rhs += g_c (global), S += D_c / radius
       hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * n_c)), dim3(256), 0, st, n_c, U.p, damp_c.p, inv_radius, S.p, 0);
-      rocblas_status bs;
-      {
-        const double one = 1.0;
-        bs = rocblas_daxpy(blas, n_c, &one, gc, 1, rhs, 1);
-        PXR_REQUIRE(bs == rocblas_status_success, "rocblas_daxpy failed (%d)", (int)bs);
-      }
-      // row-major upper == column-major lower
-      bs = rocsolver_dpotrf(blas, rocblas_fill_lower, n_c, S.p, n_c, d_info);
-      PXR_REQUIRE(bs == rocblas_status_success, "rocsolver_dpotrf failed (%d)", (int)bs);
-      rocblas_int info = 0;
-      PXR_HIP(hipMemcpyAsync(&info, d_info, sizeof(info), hipMemcpyDeviceToHost, st));
-      PXR_HIP(hipStreamSynchronize(st));
-      if (info != 0) ok = false;
-      if (ok) {
-        bs = rocsolver_dpotrs(blas, rocblas_fill_lower, n_c, 1, S.p, n_c, rhs, n_c);
-        PXR_REQUIRE(bs == rocblas_status_success, "rocsolver_dpotrs failed (%d)", (int)bs);
-        hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, rhs, gc, damp_c.p, inv_radius, delta_c.p, scal_rep);
-      }
+      hipLaunchKernelGGL(k_axpy1, dim3(nblk(n_c)), dim3(256), 0, st, n_c, gc, rhs);
+      // row-major upper == column-major lower; the pivot check is read back with the scalars of
+      // this attempt (no extra host synchronisation): a failed factorisation = invalid step.
+      RC(chol_factor(st, S.p, n_c, n_c, d_info));
+      phase(2);
+      RC(chol_solve(st, S.p, n_c, n_c, rhs));
+      hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, rhs, gc, damp_c.p, inv_radius, delta_c.p, scal_rep);
     }
+    phase(3);
     double model_cost_change = 0, cand_cost = 0, step_norm = 0, x_norm = 0;
     if (ok) {
       hipLaunchKernelGGL(k_backsub, dim3(nblk(n_pts)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, W.p, T.p, gp.p, delta_c.p, Vd0.p, inv_radius, delta_p.p, scal_sum);
       ParamPtrs out{q1.p, t1.p, k1.p, X1.p};
       hipLaunchKernelGGL(k_update, dim3(nblk((int64_t)n_img + n_cam + n_pts)), dim3(256), 0, st, dv, delta_c.p, delta_p.p, out, scal_rep, scal_sum);
       LAUNCH_CHECK("step kernels");
+      phase(4);
       RC(evaluate(cand_view, rec_cand));
+      int h_info = 0;
+      PXR_HIP(hipMemcpyAsync(&h_info, d_info, sizeof(int), hipMemcpyDeviceToHost, st));
       RC(read_scal(hs));
+      if (n_c > 0 && h_info != 0) ok = false;
+      phase(5);
       cand_cost = hs[0];
       model_cost_change = 0.5 * (hs[1] + hs[8]);     // 0.5 * delta.(D^2 delta - g) == -(J d).(r + J d / 2)
       step_norm = std::sqrt(hs[2] + hs[9]);
@@ -767,6 +776,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       std::swap(rec_cur, rec_cand);
       cost = cand_cost;
       RC(linearize(rec_cur));
+      phase(6);
       ++sum->num_successful;
       const double tmp = 2.0 * rel - 1.0;
       radius = radius / std::max(1.0 / 3.0, 1.0 - tmp * tmp * tmp);
@@ -785,6 +795,10 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     }
   }
   PXR_HIP(hipStreamSynchronize(st));
+  if (phase_timing)
+    fprintf(stderr, "[pxr_ba_solve] phase ms over %d iterations: schur-build %.2f allreduce %.2f potrf %.2f potrs %.2f "
+            "backsub+update %.2f eval+cost %.2f linearize %.2f other %.2f\n", sum->iterations, ph_ms[0], ph_ms[1],
+            ph_ms[2], ph_ms[3], ph_ms[4], ph_ms[5], ph_ms[6], ph_ms[7]);
   sum->final_cost = cost; sum->final_radius = radius;
   sum->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop0).count();
   return PXR_OK;

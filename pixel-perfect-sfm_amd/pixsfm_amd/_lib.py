@@ -85,6 +85,7 @@ _SIGNATURES = {
     "pxr_ba_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BaView), C.POINTER(InterpCfg), C.POINTER(Loss),
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(LMOptions),
                                C.c_void_p, C.c_void_p, C.POINTER(LMSummary)]),
+    "pxr_dense_spd_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "pxr_ba_cost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Loss), C.POINTER(C.c_double)]),
 }
 

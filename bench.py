@@ -188,7 +188,7 @@ def main():
             out["lm"] = {"iters_per_sec": lm["iterations"] / (lm["total_ms"] * 1e-3), "iterations": lm["iterations"],
                          "successful": lm["num_successful"], "ms_per_iter": lm["total_ms"] / max(1, lm["iterations"]),
                          "setup_ms": lm["setup_ms"], "initial_cost": lm["initial_cost"], "final_cost": lm["final_cost"],
-                         "reduced_system": lm["num_camera_unknowns"], "linear_solver": "Schur + dense Cholesky (rocSOLVER)",
+                         "reduced_system": lm["num_camera_unknowns"], "linear_solver": "point Schur complement (LDS-privatised) + hand-written blocked dense Cholesky",
                          "inner_iterations": False}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(prob, patches, args.cpu_sample)

@@ -287,6 +287,66 @@ __global__ __launch_bounds__(256) void k_schur(const SolveDev d, const int64_t* 
   }
 }
 
+// ---- K_schur_lds: same contraction, privatised in LDS ------------------------------------------------
+// A workgroup owns (image chunk, column tile): it accumulates the block row
+//   S[rows of (pose(img), intr(cam)), c0 : c0 + CT]  -=  Y_i W_j^T
+// in LDS with ds_add_f64 and flushes it once with global atomics.  The dense-S atomics drop
+// from one per (i, j, a, b) contribution (~1.7e8 at 1M observations) to one per (chunk, row,
+// column) (~2.5e6); the contraction itself runs at LDS-atomic speed.
+__global__ __launch_bounds__(1024) void k_schur_lds(const SolveDev d, const ImgChunk* __restrict__ chunks,
+                                                    const int4* __restrict__ obs_cols,
+                                                    const int64_t* __restrict__ img_obs,
+                                                   const int64_t* __restrict__ pt_ptr,
+                                                   const int64_t* __restrict__ pt_obs,
+                                                   const double* __restrict__ W, const double* __restrict__ Y,
+                                                   const double* __restrict__ gp, int CT,
+                                                   double* __restrict__ S, double* __restrict__ rhs) {
+  extern __shared__ double acc[];              // [DC][CT] then [DC] for the right-hand side
+  const ImgChunk ch = chunks[blockIdx.x];
+  const int img = ch.img, cam = d.v.d_image_camera[img];
+  const int dci = d.pose_dim[img] + d.intr_dim[cam];
+  if (dci == 0) return;
+  const int c0 = blockIdx.y * CT, c1 = min(d.n_c, c0 + CT);
+  double* racc = acc + (size_t)d.DC * CT;
+  for (int e = threadIdx.x; e < dci * CT + d.DC; e += blockDim.x) {
+    if (e < dci * CT) acc[(e / CT) * CT + (e % CT)] = 0.0; else racc[e - dci * CT] = 0.0;
+  }
+  __syncthreads();
+  const int64_t n_tasks = (ch.end - ch.begin) * dci;
+  for (int64_t task = threadIdx.x; task < n_tasks; task += blockDim.x) {
+    const int64_t i = img_obs[ch.begin + task / dci];
+    const int a = (int)(task % dci);
+    const int pt = d.v.d_obs_point[i];
+    if (!d.pt_var[pt]) continue;
+    const double* Yi = Y + ((size_t)i * d.DC + a) * 3;
+    const double y0 = Yi[0], y1 = Yi[1], y2 = Yi[2];
+    const int r = col_index(d, img, cam, a);
+    if (blockIdx.y == 0)
+      atomicAdd(racc + a, -(y0 * gp[3 * (size_t)pt] + y1 * gp[3 * (size_t)pt + 1] + y2 * gp[3 * (size_t)pt + 2]));
+    for (int64_t o = pt_ptr[pt]; o < pt_ptr[pt + 1]; ++o) {
+      const int64_t j = pt_obs[o];
+      const int4 cj = obs_cols[j];               // {pose_off, pose_dim, intr_off, intr_dim} of observation j
+      const int pdj = cj.y, dcj = pdj + cj.w;
+      const double* Wj = W + (size_t)j * d.DC * 3;
+      for (int b = 0; b < dcj; ++b) {
+        const int c = b < pdj ? cj.x + b : cj.z + (b - pdj);
+        if (c < r || c < c0 || c >= c1) continue;   // upper triangle, this column tile
+        atomicAdd(acc + (size_t)a * CT + (c - c0), -(y0 * Wj[3 * b] + y1 * Wj[3 * b + 1] + y2 * Wj[3 * b + 2]));
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < dci * CT; e += blockDim.x) {
+    const int a = e / CT, cl = e % CT;
+    const double v = acc[(size_t)a * CT + cl];
+    if (v != 0.0) atomicAdd(S + (size_t)col_index(d, img, cam, a) * d.n_c + (c0 + cl), v);
+  }
+  if (blockIdx.y == 0 && threadIdx.x < dci) {
+    const double v = racc[threadIdx.x];
+    if (v != 0.0) atomicAdd(rhs + col_index(d, img, cam, threadIdx.x), v);
+  }
+}
+
 // ---- small vector kernels --------------------------------------------------------------------------
 __global__ void k_copy_upper_add_diag(int n, const double* __restrict__ U, const double* __restrict__ damp,
                                       double inv_radius, double* __restrict__ S, int add_u) {
@@ -591,14 +651,29 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     for (int64_t b = img_cnt[i]; b < img_cnt[i + 1]; b += CH)
       chunks.push_back({i, b, std::min(img_cnt[i + 1], b + CH)});
 
+  // Schur contraction: larger chunks (fewer LDS flushes), and per-observation column descriptors so the
+  // inner loop does not chase obs -> image -> camera -> offsets
+  std::vector<ImgChunk> schur_chunks;
+  const int64_t SCH = 8192;
+  for (int i = 0; i < n_img; ++i)
+    for (int64_t b = img_cnt[i]; b < img_cnt[i + 1]; b += SCH)
+      schur_chunks.push_back({i, b, std::min(img_cnt[i + 1], b + SCH)});
+  std::vector<int4> obs_cols(n_obs);
+  for (int64_t i = 0; i < n_obs; ++i) {
+    const int im = obs_image[i], cm = image_camera[im];
+    obs_cols[i] = make_int4(pose_off[im], pose_dim[im], intr_off[cm], intr_dim[cm]);
+  }
+
   // ---- device buffers ---------------------------------------------------------------------------
   DevBuf<int> d_pose_off, d_pose_dim, d_tmask, d_intr_off, d_intr_dim, d_cmask, d_pt_var;
   DevBuf<int64_t> d_img_obs, d_pt_ptr, d_pt_obs;
-  DevBuf<ImgChunk> d_chunks;
+  DevBuf<ImgChunk> d_chunks, d_schur_chunks;
+  DevBuf<int4> d_obs_cols;
   RC(d_pose_off.upload(pose_off, st)); RC(d_pose_dim.upload(pose_dim, st)); RC(d_tmask.upload(tmask, st));
   RC(d_intr_off.upload(intr_off, st)); RC(d_intr_dim.upload(intr_dim, st)); RC(d_cmask.upload(cmask, st));
   RC(d_pt_var.upload(pt_var, st)); RC(d_img_obs.upload(img_obs, st)); RC(d_pt_ptr.upload(pt_cnt, st));
   RC(d_pt_obs.upload(pt_obs, st)); RC(d_chunks.upload(chunks, st));
+  RC(d_schur_chunks.upload(schur_chunks, st)); RC(d_obs_cols.upload(obs_cols, st));
   const size_t nc1 = n_c ? n_c : 1;
   DevBuf<double> L, V, gp, Vd0, T, W, Y, U, S /* S | rhs */, gcd /* diagU | g_c */, damp_c, scale_c, scale_p,
       delta_c, delta_p, rec_a, rec_b, q1, t1, k1, X1, scal;
@@ -672,6 +747,15 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   sum->setup_ms = std::chrono::duration<double, std::milli>(t_loop0 - t_setup0).count();
   sum->num_camera_unknowns = n_c; sum->num_point_unknowns = 3 * n_pvar;
   sum->iterations = 0; sum->num_successful = 0; sum->termination = PXR_TERM_NO_CONVERGENCE;
+  // LDS-privatised Schur contraction: column tile so that DC x CT doubles fit in 128 KiB of LDS
+  const bool use_lds_schur = std::getenv("PXR_SCHUR_GLOBAL_ATOMICS") == nullptr;
+  int CT = n_c > 0 ? std::min(n_c, (int)((128 * 1024 / 8 - DC) / DC)) : 1;
+  const int n_ctiles = n_c > 0 ? (n_c + CT - 1) / CT : 1;
+  CT = n_c > 0 ? (n_c + n_ctiles - 1) / n_ctiles : 1;       // balance the tiles
+  const size_t schur_shmem = sizeof(double) * ((size_t)DC * CT + DC);
+  if (use_lds_schur && n_c > 0)
+    PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)schur_shmem));
   const bool verbose = std::getenv("PXR_VERBOSE") != nullptr;
   const bool phase_timing = std::getenv("PXR_PHASE_TIMING") != nullptr;   // adds a stream sync per phase
   double ph_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -720,7 +804,12 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       hipLaunchKernelGGL(k_wy, dim3(nblk(n_obs)), dim3(256), 0, st, dv, L.p, T.p, W.p, Y.p);
       hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * n_c)), dim3(256), 0, st, n_c, U.p, (const double*)nullptr, 0.0, S.p, 1);
       PXR_HIP(hipMemsetAsync(rhs, 0, sizeof(double) * n_c, st));
-      hipLaunchKernelGGL(k_schur, dim3(nblk(n_obs * DC)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, W.p, Y.p, gp.p, S.p, rhs);
+      if (use_lds_schur) {
+        hipLaunchKernelGGL(k_schur_lds, dim3((unsigned)schur_chunks.size(), (unsigned)n_ctiles), dim3(1024), schur_shmem, st, dv,
+                           d_schur_chunks.p, d_obs_cols.p, d_img_obs.p, d_pt_ptr.p, d_pt_obs.p, W.p, Y.p, gp.p, CT, S.p, rhs);
+      } else {
+        hipLaunchKernelGGL(k_schur, dim3(nblk(n_obs * DC)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, W.p, Y.p, gp.p, S.p, rhs);
+      }
       LAUNCH_CHECK("schur kernels");
       phase(0);
       RC(ar(S.p, (int64_t)nc1 * nc1 + n_c));

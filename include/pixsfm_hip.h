@@ -199,6 +199,45 @@ int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const 
                  pxr_lm_summary* summary);
 
 
+/* ---- KA ---------------------------------------------------------------------------------
+ * Batched replacement of FeatureMetricKeypointOptimizer::RunParallel / RunSubset
+ * (keypoint_adjustment/src/featuremetric_keypoint_optimizer.h:69-137) for the flat edge list
+ * the host builds from TopologicalKeypointOptimizer::SetUp + AddIntraResiduals
+ * (topological_keypoint_optimizer.h:97-175, featuremetric_keypoint_optimizer.h:158-202):
+ * one residual block per edge, r = f(patch[src], kp[src]) - f(patch[dst], kp[dst])
+ * (FeatureMetric2DCostFunctor, residuals/src/featuremetric.h:44-63), ScaledLoss(loss, weight).
+ * Sub-problems (ParallelOptimizer groups, base/src/parallel_optimizer.h:77-211) are given in
+ * CSR form; each is solved by ONE workgroup that runs the whole bounded LM loop
+ * (KeypointOptimizerBase::SolveProblem + ParameterizeKeypoints, keypoint_optimizer.h:77-157)
+ * on the device.  All arrays are device pointers; d_kp is refined IN PLACE. */
+typedef struct {
+  int64_t n_nodes;
+  double* d_kp;                   /* [n_nodes][2] keypoints in COLMAP image coordinates   */
+  const int64_t* d_node_patch;    /* [n_nodes] patch index in the arena                   */
+  const uint8_t* d_node_const;    /* [n_nodes] 1 = constant (roots, KeypointAdjustmentSetup) */
+  int64_t n_edges;
+  const int32_t* d_edge_src;      /* [n_edges]                                            */
+  const int32_t* d_edge_dst;
+  const double* d_edge_w;         /* ScaledLoss weight (similarity if weight_by_sim, else 1) */
+  int32_t n_problems;
+  const int64_t* d_prob_node_ptr; /* [n_problems + 1] into d_prob_nodes (ascending node ids) */
+  const int32_t* d_prob_nodes;
+  const int64_t* d_prob_edge_ptr; /* [n_problems + 1] into d_prob_edges                    */
+  const int32_t* d_prob_edges;
+} pxr_ka_view;
+
+/* Per-edge evaluation for parity checks: d_cost [n_edges] = 0.5 w rho(|r|^2); optional
+ * d_r [n_edges][C], d_J1 / d_J2 [n_edges][C][2] (dr/dkp_src, dr/dkp_dst, row-major). */
+int pxr_ka_eval(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* view, const pxr_interp_cfg* cfg,
+                const pxr_loss* loss, double* d_cost, double* d_r, double* d_J1, double* d_J2);
+
+/* Solve every sub-problem.  bound: KeypointOptimizerOptions::bound (4.0,
+ * keypoint_adjustment/main.py:78).  h_summaries: NULL or [n_problems] per-problem summaries;
+ * *total accumulates them like AccumulateSummaries (util/src/statistics.h:131-160). */
+int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* view, const pxr_interp_cfg* cfg,
+                 const pxr_loss* loss, double bound, const pxr_lm_options* options,
+                 pxr_lm_summary* h_summaries, pxr_lm_summary* total);
+
 /* Dense SPD solve used for the reduced camera system (what Ceres' DENSE_SCHUR / SPARSE_SCHUR
  * Cholesky does on the CPU, bundle_optimizer.h:181-191): blocked right-looking Cholesky +
  * substitution in hand-written HIP.  d_a: n x n row-major, UPPER triangle filled (overwritten

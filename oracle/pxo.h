@@ -215,6 +215,29 @@ int pxo_ba_solve(pxo_ba_batch* b, int n_images, int n_cams, int64_t n_points,
                  const uint8_t* tvec_const_mask, const uint16_t* cam_const_mask,
                  const uint8_t* point_const, const pxo_lm_options* opt, pxo_lm_summary* sum);
 
+
+/* ---- KA --------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t n_nodes;
+  double* kp;                 /* [n_nodes][2] keypoints, COLMAP coords, refined IN PLACE          */
+  const int64_t* node_patch;  /* [n_nodes] patch of each node in the arena                        */
+  const uint8_t* node_const;  /* [n_nodes] 1 = constant (track roots, KeypointAdjustmentSetup)    */
+  int64_t n_edges;
+  const int32_t* edge_src;    /* residual blocks: FeatureMetric2DCostFunctor(patch[src], patch[dst]) */
+  const int32_t* edge_dst;
+  const double* edge_w;       /* ScaledLoss weight (match similarity or 1)                        */
+  const void* arena; int32_t dtype, H, W, C;
+  const int32_t* corners; const double* scales;
+} pxo_ka_batch;
+
+/* One independent sub-problem (one ceres::Problem of RunSubset,
+ * featuremetric_keypoint_optimizer.h:118-137): nodes[nn] / edges[m] index into the batch.
+ * Ceres TR-LM with box bounds: ParameterBlock::Plus projects onto the bounds; projected Armijo
+ * line search along the LM step (DoLineSearch) [upstream Ceres 2.1]. */
+int pxo_ka_solve_problem(pxo_ka_batch* b, const int32_t* nodes, int nn, const int32_t* edges, int m,
+                         const pxo_interp_cfg* cfg, const pxo_loss* loss, double bound,
+                         const pxo_lm_options* opt, pxo_lm_summary* sum);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,46 @@
+"""ctypes binding of the oracle's keypoint-adjustment solver (TEST INFRASTRUCTURE ONLY)."""
+import ctypes as C
+
+import numpy as np
+
+import pxo
+
+
+class KaBatch(C.Structure):
+    _fields_ = [("n_nodes", C.c_int64), ("kp", C.c_void_p), ("node_patch", C.c_void_p), ("node_const", C.c_void_p),
+                ("n_edges", C.c_int64), ("edge_src", C.c_void_p), ("edge_dst", C.c_void_p), ("edge_w", C.c_void_p),
+                ("arena", C.c_void_p), ("dtype", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("corners", C.c_void_p), ("scales", C.c_void_p)]
+
+
+def ka_solve(problem, config, ls, bound=4.0, opts=None):
+    """Solves every sub-problem (node_problem labels) with the oracle LM.  Returns
+    (refined keypoints copy, list of per-problem summary dicts)."""
+    keep = {}
+
+    def arr(name, dt):
+        a = np.ascontiguousarray(problem[name], dtype=dt)
+        keep[name] = a
+        return a.ctypes.data
+
+    kp = np.array(problem["kp"], dtype=np.float64, order="C", copy=True)
+    patches = np.ascontiguousarray(problem["patches"])
+    n_p, H, W, ch = patches.shape
+    b = KaBatch(len(kp), kp.ctypes.data, arr("node_patch", np.int64), arr("node_const", np.uint8),
+                len(problem["edge_src"]), arr("edge_src", np.int32), arr("edge_dst", np.int32), arr("edge_w", np.float64),
+                patches.ctypes.data, pxo._NP2DT[patches.dtype], H, W, ch, arr("corners", np.int32),
+                arr("scales", np.float64))
+    opts = opts or pxo.lm_options(parameter_tolerance=1e-5)
+    node_problem = np.asarray(problem["node_problem"])
+    edge_problem = node_problem[np.asarray(problem["edge_src"])]
+    summaries = []
+    lib = pxo.lib()
+    for p in range(int(node_problem.max()) + 1):
+        nodes = np.ascontiguousarray(np.nonzero(node_problem == p)[0], dtype=np.int32)
+        edges = np.ascontiguousarray(np.nonzero(edge_problem == p)[0], dtype=np.int32)
+        s = pxo.LMSummary()
+        rc = lib.pxo_ka_solve_problem(C.byref(b), pxo._p(nodes), len(nodes), pxo._p(edges), len(edges), C.byref(config),
+                                      C.byref(ls), C.c_double(bound), C.byref(opts), C.byref(s))
+        assert rc == 0
+        summaries.append(s.as_dict())
+    return kp, summaries

@@ -398,3 +398,293 @@ int pxo_ba_solve(pxo_ba_batch* b, int n_images, int n_cams, int64_t n_points,
   free(c.L.pose_off); free(c.L.pose_dim); free(c.L.intr_off); free(c.L.intr_dim); free(c.L.pt_off);
   return 0;
 }
+
+/* ======================================================================================
+ * Keypoint adjustment (KA)
+ * ====================================================================================== */
+
+/* ParameterizeKeypoints box (keypoint_adjustment/src/keypoint_optimizer.h:127-152). */
+static void ka_bounds(const pxo_ka_batch* b, int64_t node, double bound, double lo[2], double hi[2]) {
+  const int64_t pi = b->node_patch[node];
+  const double sx = b->scales[2 * pi], sy = b->scales[2 * pi + 1];
+  const double* kp = b->kp + 2 * node;
+  lo[0] = (b->corners[2 * pi] + 0.5) / sx;     lo[1] = (b->corners[2 * pi + 1] + 0.5) / sy;
+  hi[0] = lo[0] + b->W / sx;                   hi[1] = lo[1] + b->H / sy;
+  if (bound > 0.0) {
+    hi[0] = fmin(kp[0] + bound / sx, hi[0]); hi[1] = fmin(kp[1] + bound / sy, hi[1]);
+    lo[0] = fmax(kp[0] - bound / sx, lo[0]); lo[1] = fmax(kp[1] - bound / sy, lo[1]);
+  }
+}
+
+typedef struct {
+  const pxo_ka_batch* b; const pxo_interp_cfg* cfg; const pxo_loss* loss;
+  const int32_t* edges; int m;    /* edge ids of this problem */
+  const int* var_of_node;         /* global node -> local unknown offset or -1 */
+  int n;                          /* unknowns */
+} ka_ctx;
+
+static pxo_patch ka_patch(const pxo_ka_batch* b, int64_t pi) {
+  const size_t es = b->dtype == PXO_F16 ? 2 : (b->dtype == PXO_F32 ? 4 : 8);
+  pxo_patch p;
+  p.data = (const char*)b->arena + (size_t)pi * b->H * b->W * b->C * es;
+  p.dtype = b->dtype; p.H = b->H; p.W = b->W; p.C = b->C;
+  p.x0 = b->corners[2 * pi]; p.y0 = b->corners[2 * pi + 1];
+  p.sx = b->scales[2 * pi]; p.sy = b->scales[2 * pi + 1]; p.up = 1.0;
+  return p;
+}
+
+/* cost = sum 0.5 w rho(|r|^2); optional dense H = J~^T J~, g = J~^T r~ over the unknowns.
+ * kp: full keypoint array (the candidate being evaluated). */
+static double ka_evaluate(const ka_ctx* c, const double* kp, double* H, double* g) {
+  const pxo_ka_batch* b = c->b;
+  const int C = b->C, n = c->n;
+  double cost = 0;
+  if (H) { memset(H, 0, sizeof(double) * (size_t)n * n); memset(g, 0, sizeof(double) * n); }
+  double r[PXO_MAXC], J[PXO_MAXC * 4], J1[PXO_MAXC * 2], J2[PXO_MAXC * 2];
+  for (int e = 0; e < c->m; ++e) {
+    const int32_t ed = c->edges[e];
+    const int64_t n1 = b->edge_src[ed], n2 = b->edge_dst[ed];
+    pxo_patch p1 = ka_patch(b, b->node_patch[n1]), p2 = ka_patch(b, b->node_patch[n2]);
+    pxo_ka_residual(&p1, &p2, c->cfg, kp + 2 * n1, kp + 2 * n2, r, H ? J1 : NULL, H ? J2 : NULL);
+    double s = 0;
+    for (int k = 0; k < C; ++k) s += r[k] * r[k];
+    double rho[3];
+    pxo_loss_eval(c->loss, b->edge_w[ed], s, rho);   /* ScaledLoss, featuremetric_keypoint_optimizer.h:193 */
+    cost += 0.5 * rho[0];
+    if (!H) continue;
+    int idx[4], dl = 0;
+    const int v1 = c->var_of_node[n1], v2 = c->var_of_node[n2];
+    if (v1 >= 0) { for (int k = 0; k < C; ++k) { J[k * 4 + dl] = J1[k * 2]; J[k * 4 + dl + 1] = J1[k * 2 + 1]; } idx[dl] = v1; idx[dl + 1] = v1 + 1; dl += 2; }
+    if (v2 >= 0) { for (int k = 0; k < C; ++k) { J[k * 4 + dl] = J2[k * 2]; J[k * 4 + dl + 1] = J2[k * 2 + 1]; } idx[dl] = v2; idx[dl + 1] = v2 + 1; dl += 2; }
+    if (dl == 0) continue;
+    double Jc[PXO_MAXC * 4];
+    for (int k = 0; k < C; ++k) for (int a = 0; a < dl; ++a) Jc[k * dl + a] = J[k * 4 + a];
+    pxo_corrector(s, rho, C, dl, r, Jc);
+    for (int a = 0; a < dl; ++a) {
+      double ga = 0;
+      for (int k = 0; k < C; ++k) ga += Jc[k * dl + a] * r[k];
+      g[idx[a]] += ga;
+      for (int bb = 0; bb < dl; ++bb) {
+        double h = 0;
+        for (int k = 0; k < C; ++k) h += Jc[k * dl + a] * Jc[k * dl + bb];
+        H[(size_t)idx[a] * n + idx[bb]] += h;
+      }
+    }
+  }
+  return cost;
+}
+
+/* [upstream Ceres 2.1 polynomial.cc] minimise the interpolating polynomial on [lo, hi]:
+ * quadratic through (0, f0, g0), (x1, f1); cubic through (0, f0, g0), (x1, f1), (x2, f2). */
+static double poly_eval(const double* c, int deg, double x) {
+  double v = 0;
+  for (int i = deg; i >= 0; --i) v = v * x + c[i];
+  return v;
+}
+static double minimize_poly(const double* c, int deg, double lo, double hi) {
+  double best_x = lo, best = poly_eval(c, deg, lo);
+  double v = poly_eval(c, deg, hi);
+  if (v < best) { best = v; best_x = hi; }
+  /* roots of the derivative */
+  if (deg == 2) {
+    if (c[2] != 0.0) { double x = -c[1] / (2 * c[2]); if (x > lo && x < hi && poly_eval(c, 2, x) < best) { best_x = x; } }
+  } else if (deg == 3) {
+    const double a = 3 * c[3], bq = 2 * c[2], cq = c[1];
+    if (a == 0.0) {
+      if (bq != 0.0) { double x = -cq / bq; if (x > lo && x < hi && poly_eval(c, 3, x) < best) best_x = x; }
+    } else {
+      const double disc = bq * bq - 4 * a * cq;
+      if (disc >= 0) {
+        const double sq = sqrt(disc);
+        const double x1 = (-bq + sq) / (2 * a), x2 = (-bq - sq) / (2 * a);
+        if (x1 > lo && x1 < hi) { v = poly_eval(c, 3, x1); if (v < best) { best = v; best_x = x1; } }
+        if (x2 > lo && x2 < hi) { v = poly_eval(c, 3, x2); if (v < best) { best = v; best_x = x2; } }
+      }
+    }
+  }
+  return best_x;
+}
+static double interpolating_step(double f0, double g0, int have_prev, double xp, double fp, double xc, double fc,
+                                 double lo, double hi) {
+  double c[4];
+  if (!have_prev) { /* quadratic: c0 = f0, c1 = g0, c2 from f(xc) */
+    c[0] = f0; c[1] = g0; c[2] = (fc - f0 - g0 * xc) / (xc * xc);
+    return minimize_poly(c, 2, lo, hi);
+  }
+  /* cubic: f0 + g0 x + a x^2 + b x^3 through (xp, fp), (xc, fc) */
+  const double rp = (fp - f0 - g0 * xp) / (xp * xp), rc = (fc - f0 - g0 * xc) / (xc * xc);
+  const double bcoef = (rc - rp) / (xc - xp), acoef = rc - bcoef * xc;
+  c[0] = f0; c[1] = g0; c[2] = acoef; c[3] = bcoef;
+  return minimize_poly(c, 3, lo, hi);
+}
+
+static void ka_plus(const ka_ctx* c, const int32_t* nodes, int nn, const double* x0, const double* delta,
+                    double alpha, const double* lo, const double* hi, double* x1) {
+  /* ParameterBlock::Plus [upstream Ceres]: x + delta then projection onto the box */
+  const pxo_ka_batch* b = c->b;
+  memcpy(x1, x0, sizeof(double) * 2 * b->n_nodes);
+  for (int i = 0; i < nn; ++i) {
+    const int64_t nd = nodes[i];
+    const int v = c->var_of_node[nd];
+    if (v < 0) continue;
+    for (int a = 0; a < 2; ++a) {
+      double val = x0[2 * nd + a] + alpha * delta[v + a];
+      if (val < lo[v + a]) val = lo[v + a];
+      if (val > hi[v + a]) val = hi[v + a];
+      x1[2 * nd + a] = val;
+    }
+  }
+}
+
+int pxo_ka_solve_problem(pxo_ka_batch* b, const int32_t* nodes, int nn, const int32_t* edges, int m,
+                         const pxo_interp_cfg* cfg, const pxo_loss* loss, double bound,
+                         const pxo_lm_options* opt, pxo_lm_summary* sum) {
+  ka_ctx c;
+  c.b = b; c.cfg = cfg; c.loss = loss; c.edges = edges; c.m = m;
+  int* var_of_node = (int*)malloc(sizeof(int) * b->n_nodes);
+  for (int64_t i = 0; i < b->n_nodes; ++i) var_of_node[i] = -1;
+  /* will_be_optimized_: endpoints of this problem's edges (featuremetric_keypoint_optimizer.h:198-199) */
+  uint8_t* used = (uint8_t*)calloc(b->n_nodes, 1);
+  for (int e = 0; e < m; ++e) { used[b->edge_src[edges[e]]] = 1; used[b->edge_dst[edges[e]]] = 1; }
+  int n = 0;
+  for (int i = 0; i < nn; ++i) {
+    const int64_t nd = nodes[i];
+    if (used[nd] && !b->node_const[nd]) { var_of_node[nd] = n; n += 2; }
+  }
+  free(used);
+  c.var_of_node = var_of_node; c.n = n;
+  memset(sum, 0, sizeof(*sum));
+  sum->num_unknowns = n; sum->termination = PXO_TERM_NO_CONVERGENCE;
+  double* x = b->kp;
+  if (n == 0 || m == 0) {
+    sum->initial_cost = sum->final_cost = ka_evaluate(&c, x, NULL, NULL);
+    sum->termination = PXO_TERM_CONVERGENCE;
+    free(var_of_node);
+    return 0;
+  }
+  double* lo = (double*)malloc(sizeof(double) * n); double* hi = (double*)malloc(sizeof(double) * n);
+  int feasible = 1;
+  for (int i = 0; i < nn; ++i) {
+    const int64_t nd = nodes[i];
+    const int v = var_of_node[nd];
+    if (v < 0) continue;
+    ka_bounds(b, nd, bound, lo + v, hi + v);
+    for (int a = 0; a < 2; ++a) if (x[2 * nd + a] < lo[v + a] || x[2 * nd + a] > hi[v + a]) feasible = 0;
+  }
+  double* H = (double*)malloc(sizeof(double) * (size_t)n * n); double* A = (double*)malloc(sizeof(double) * (size_t)n * n);
+  double* g = (double*)malloc(sizeof(double) * n); double* gun = (double*)malloc(sizeof(double) * n);
+  double* scale = (double*)malloc(sizeof(double) * n);
+  double* step = (double*)malloc(sizeof(double) * n); double* delta = (double*)malloc(sizeof(double) * n);
+  double* diag = (double*)malloc(sizeof(double) * n);
+  double* x1 = (double*)malloc(sizeof(double) * 2 * b->n_nodes);
+  double cost = ka_evaluate(&c, x, H, g);
+  sum->initial_cost = cost;
+  if (!feasible) { /* [upstream] Program::IsFeasible fails -> Solve returns FAILURE, parameters untouched */
+    sum->final_cost = cost; sum->termination = PXO_TERM_FAILURE;
+    goto done;
+  }
+  memcpy(gun, g, sizeof(double) * n);
+  for (int j = 0; j < n; ++j) scale[j] = opt->jacobi_scaling ? 1.0 / (1.0 + sqrt(H[(size_t)j * n + j])) : 1.0;
+#define KA_SCALE()                                                                       \
+  do {                                                                                   \
+    for (int a = 0; a < n; ++a) {                                                        \
+      g[a] *= scale[a];                                                                  \
+      for (int bb = 0; bb < n; ++bb) H[(size_t)a * n + bb] *= scale[a] * scale[bb];     \
+    }                                                                                    \
+  } while (0)
+  KA_SCALE();
+  {
+    double radius = opt->initial_radius, decrease_factor = 2.0;
+    int invalid = 0, reuse_diag = 0;
+    while (1) {
+      if (sum->iterations >= opt->max_iterations) { sum->termination = PXO_TERM_NO_CONVERGENCE; break; }
+      if (radius < opt->min_radius) { sum->termination = PXO_TERM_CONVERGENCE; break; }
+      ++sum->iterations;
+      if (!reuse_diag)
+        for (int j = 0; j < n; ++j) {
+          double d = H[(size_t)j * n + j];
+          diag[j] = d < opt->min_lm_diagonal ? opt->min_lm_diagonal : (d > opt->max_lm_diagonal ? opt->max_lm_diagonal : d);
+        }
+      memcpy(A, H, sizeof(double) * (size_t)n * n);
+      for (int j = 0; j < n; ++j) { A[(size_t)j * n + j] += diag[j] / radius; step[j] = -g[j]; }
+      int ok = chol_solve(n, A, step) == 0;
+      double model_cost_change = 0;
+      if (ok) {
+        double dg = 0, dHd = 0;
+        for (int a = 0; a < n; ++a) {
+          dg += step[a] * g[a];
+          double hr = 0;
+          for (int bb = 0; bb < n; ++bb) hr += H[(size_t)a * n + bb] * step[bb];
+          dHd += step[a] * hr;
+          if (!isfinite(step[a])) ok = 0;
+        }
+        model_cost_change = -dg - 0.5 * dHd;
+        if (!(model_cost_change > 0.0)) ok = 0;
+      }
+      if (!ok) {
+        if (++invalid >= opt->max_consecutive_invalid_steps) { sum->termination = PXO_TERM_FAILURE; break; }
+        radius *= 0.5; reuse_diag = 1;
+        continue;
+      }
+      invalid = 0;
+      for (int j = 0; j < n; ++j) delta[j] = step[j] * scale[j];
+      /* DoLineSearch [upstream trust_region_minimizer.cc]: projected Armijo search along delta,
+       * phi(a) = cost(P(x + a delta)), sufficient decrease 1e-4, cubic interpolation, contraction
+       * within [1e-3, 0.6], at most 20 evaluations, minimum step 1e-9. */
+      {
+        double g0 = 0;
+        for (int j = 0; j < n; ++j) g0 += gun[j] * delta[j];
+        double xc = 1.0, fc, xp = 0, fp = 0;
+        int have_prev = 0, iters = 0, success = 0;
+        ka_plus(&c, nodes, nn, x, delta, xc, lo, hi, x1);
+        fc = ka_evaluate(&c, x1, NULL, NULL);
+        while (1) {
+          if (isfinite(fc) && fc <= cost + 1e-4 * g0 * xc) { success = 1; break; }
+          if (++iters >= 20) break;
+          double nx;
+          if (!isfinite(fc)) nx = fmin(fmax(xc * 0.5, xc * 1e-3), xc * 0.6);
+          else nx = interpolating_step(cost, g0, have_prev, xp, fp, xc, fc, xc * 1e-3, xc * 0.6);
+          if (nx < 1e-9) break;
+          if (isfinite(fc)) { xp = xc; fp = fc; have_prev = 1; }
+          xc = nx;
+          ka_plus(&c, nodes, nn, x, delta, xc, lo, hi, x1);
+          fc = ka_evaluate(&c, x1, NULL, NULL);
+        }
+        if (success) for (int j = 0; j < n; ++j) delta[j] *= xc;
+      }
+      ka_plus(&c, nodes, nn, x, delta, 1.0, lo, hi, x1);
+      const double cand = ka_evaluate(&c, x1, NULL, NULL);
+      double step2 = 0, x2 = 0;
+      for (int i = 0; i < nn; ++i) {
+        const int64_t nd = nodes[i];
+        if (var_of_node[nd] < 0) continue;
+        for (int a = 0; a < 2; ++a) { const double d = x1[2 * nd + a] - x[2 * nd + a]; step2 += d * d; x2 += x[2 * nd + a] * x[2 * nd + a]; }
+      }
+      if (sqrt(step2) <= opt->parameter_tolerance * (sqrt(x2) + opt->parameter_tolerance)) { sum->termination = PXO_TERM_CONVERGENCE; break; }
+      const double cost_change = cost - cand;
+      if (fabs(cost_change) <= opt->function_tolerance * cost) { sum->termination = PXO_TERM_CONVERGENCE; break; }
+      const double rel = cost_change / model_cost_change;
+      if (rel > opt->min_relative_decrease) {
+        for (int i = 0; i < nn; ++i) { const int64_t nd = nodes[i]; x[2 * nd] = x1[2 * nd]; x[2 * nd + 1] = x1[2 * nd + 1]; }
+        cost = ka_evaluate(&c, x, H, g);
+        memcpy(gun, g, sizeof(double) * n);
+        KA_SCALE();
+        ++sum->num_successful;
+        const double tmp = 2.0 * rel - 1.0;
+        double f = 1.0 - tmp * tmp * tmp;
+        if (f < 1.0 / 3.0) f = 1.0 / 3.0;
+        radius = radius / f;
+        if (radius > opt->max_radius) radius = opt->max_radius;
+        decrease_factor = 2.0; reuse_diag = 0;
+      } else {
+        radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diag = 1;
+      }
+    }
+    sum->final_radius = radius;
+  }
+  sum->final_cost = cost;
+done:
+  free(lo); free(hi); free(H); free(A); free(g); free(gun); free(scale); free(step); free(delta); free(diag); free(x1);
+  free(var_of_node);
+  return 0;
+}

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include "pxr_device.h"
+#include "pxr_interp.h"
 #include "pxr_internal.h"
 
 namespace pxr {
@@ -42,170 +43,6 @@ struct BaEvalArgs {
   double* out_gx;
   double* out_gy;
 };
-
-template <typename ST>
-struct Texel8;  // 8 consecutive channels of one texel, widened for the horizontal pass
-
-template <>
-struct Texel8<_Float16> {
-  typedef float work_t;
-  uint4 raw;
-  __device__ __forceinline__ void load(const _Float16* p) { raw = *reinterpret_cast<const uint4*>(p); }
-  __device__ __forceinline__ void unpack(float out[8]) const {
-    union { uint4 u; half8_t h; } cvt;
-    cvt.u = raw;
-    const float8_t f = __builtin_convertvector(cvt.h, float8_t);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) out[i] = f[i];
-  }
-};
-template <>
-struct Texel8<float> {
-  typedef float work_t;
-  float4 a, b;
-  __device__ __forceinline__ void load(const float* p) {
-    a = *reinterpret_cast<const float4*>(p);
-    b = *reinterpret_cast<const float4*>(p + 4);
-  }
-  __device__ __forceinline__ void unpack(float out[8]) const {
-    out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
-    out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
-  }
-};
-template <>
-struct Texel8<double> {
-  typedef double work_t;
-  double2 a, b, c, d;
-  __device__ __forceinline__ void load(const double* p) {
-    a = *reinterpret_cast<const double2*>(p);
-    b = *reinterpret_cast<const double2*>(p + 2);
-    c = *reinterpret_cast<const double2*>(p + 4);
-    d = *reinterpret_cast<const double2*>(p + 6);
-  }
-  __device__ __forceinline__ void unpack(double out[8]) const {
-    out[0] = a.x; out[1] = a.y; out[2] = b.x; out[3] = b.y;
-    out[4] = c.x; out[5] = c.y; out[6] = d.x; out[7] = d.y;
-  }
-};
-
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-// Normalised descriptor + gradients of 8 channels of one observation, all lanes of the
-// observation's lane group cooperating.  LPO = lanes per observation (C / 8).
-template <typename ST, int LPO, bool WITH_JAC, bool FLOAT_SIMD>
-__device__ __forceinline__ void interp8(const ST* __restrict__ patch, int H, int W, int C, int sub,
-                                        double u, double v, bool l2_normalize, double f[8],
-                                        double fr[8], double fc[8]) {
-  // BiCubicInterpolator::EvaluateSIMD: r = v (row), c = u (column)
-  const double rf = floor(v), cf = floor(u);
-  const int row = (int)rf, col = (int)cf;
-  const double dy = v - rf, dx = u - cf;
-  int ro[4], co[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    ro[j] = clampi(row - 1 + j, 0, H - 1) * W;   // Grid2D::GetPointer clamping, grid2d.h:64-73
-    co[j] = clampi(col - 1 + j, 0, W - 1);
-  }
-  Texel8<ST> tx[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) tx[j][i].load(patch + (size_t)(ro[j] + co[i]) * C + sub * 8);
-
-  typedef typename Texel8<ST>::work_t HT;  // horizontal-pass arithmetic type
-  HT h[4][8], hd[4][8];
-  if constexpr (sizeof(HT) == 4) {
-    const SplineCoefF32 kh(dx);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float p0[8], p1[8], p2[8], p3[8];
-      tx[j][0].unpack(p0); tx[j][1].unpack(p1); tx[j][2].unpack(p2); tx[j][3].unpack(p3);
-#pragma unroll
-      for (int ch = 0; ch < 8; ++ch) {
-        float dd = 0.f;
-        spline_f32<WITH_JAC>(p0[ch], p1[ch], p2[ch], p3[ch], kh, h[j][ch], dd);
-        hd[j][ch] = dd;
-      }
-    }
-  } else {
-    const SplineCoefF64 kh(dx);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      double p0[8], p1[8], p2[8], p3[8];
-      tx[j][0].unpack(p0); tx[j][1].unpack(p1); tx[j][2].unpack(p2); tx[j][3].unpack(p3);
-#pragma unroll
-      for (int ch = 0; ch < 8; ++ch) {
-        double ff = 0, dd = 0;
-        spline_f64<true, WITH_JAC>(p0[ch], p1[ch], p2[ch], p3[ch], kh, ff, dd);
-        if (FLOAT_SIMD) { ff = (double)(float)ff; dd = (double)(float)dd; }
-        h[j][ch] = ff; hd[j][ch] = dd;
-      }
-    }
-  }
-  // vertical pass
-  if constexpr (FLOAT_SIMD) {
-    const SplineCoefF32 kv(dy);
-#pragma unroll
-    for (int ch = 0; ch < 8; ++ch) {
-      float ff, dd = 0.f, cc = 0.f, dummy = 0.f;
-      spline_f32<WITH_JAC>((float)h[0][ch], (float)h[1][ch], (float)h[2][ch], (float)h[3][ch], kv, ff, dd);
-      if (WITH_JAC)
-        spline_f32<false>((float)hd[0][ch], (float)hd[1][ch], (float)hd[2][ch], (float)hd[3][ch], kv, cc, dummy);
-      f[ch] = (double)ff; fr[ch] = (double)dd; fc[ch] = (double)cc;
-    }
-  } else {
-    const SplineCoefF64 kv(dy);
-#pragma unroll
-    for (int ch = 0; ch < 8; ++ch) {
-      double ff = 0, dd = 0, cc = 0, dummy = 0;
-      spline_f64<true, WITH_JAC>((double)h[0][ch], (double)h[1][ch], (double)h[2][ch], (double)h[3][ch], kv, ff, dd);
-      if (WITH_JAC)
-        spline_f64<true, false>((double)hd[0][ch], (double)hd[1][ch], (double)hd[2][ch], (double)hd[3][ch], kv, cc, dummy);
-      f[ch] = ff; fr[ch] = dd; fc[ch] = cc;
-    }
-  }
-  // PixelInterpolator::Evaluate L2 normalisation + chain rule, interpolation.h:648-666
-  if (l2_normalize) {
-    double ss = 0.0;
-#pragma unroll
-    for (int ch = 0; ch < 8; ++ch) ss = fma(f[ch], f[ch], ss);
-    ss = (LPO == 16) ? row16_sum(ss) : row8_sum(ss);
-    const double ninv = 1.0 / sqrt(ss);
-#pragma unroll
-    for (int ch = 0; ch < 8; ++ch) f[ch] *= ninv;
-    if (WITH_JAC) {
-      double dc = 0.0, dr = 0.0;
-#pragma unroll
-      for (int ch = 0; ch < 8; ++ch) {
-        fc[ch] *= ninv; fr[ch] *= ninv;
-        dc = fma(f[ch], fc[ch], dc);
-        dr = fma(f[ch], fr[ch], dr);
-      }
-      if (LPO == 16) { dc = row16_sum(dc); dr = row16_sum(dr); }
-      else { dc = row8_sum(dc); dr = row8_sum(dr); }
-#pragma unroll
-      for (int ch = 0; ch < 8; ++ch) {
-        fc[ch] = fma(-dc, f[ch], fc[ch]);
-        fr[ch] = fma(-dr, f[ch], fr[ch]);
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ double shfl_f64(double v, int src) {
-  union { double d; int i[2]; } a;
-  a.d = v;
-  a.i[0] = __shfl(a.i[0], src);
-  a.i[1] = __shfl(a.i[1], src);
-  return a.d;
-}
-__device__ __forceinline__ int64_t shfl_i64(int64_t v, int src) {
-  union { int64_t l; int i[2]; } a;
-  a.l = v;
-  a.i[0] = __shfl(a.i[0], src);
-  a.i[1] = __shfl(a.i[1], src);
-  return a.l;
-}
 
 template <typename ST, int C, bool WITH_JAC, bool FLOAT_SIMD>
 __global__ __launch_bounds__(256) void ba_eval_kernel(const BaEvalArgs a) {

@@ -57,6 +57,14 @@ class LMSummary(C.Structure):
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
 
+
+class KaView(C.Structure):
+    _fields_ = [("n_nodes", C.c_int64), ("d_kp", C.c_void_p), ("d_node_patch", C.c_void_p),
+                ("d_node_const", C.c_void_p), ("n_edges", C.c_int64), ("d_edge_src", C.c_void_p),
+                ("d_edge_dst", C.c_void_p), ("d_edge_w", C.c_void_p), ("n_problems", C.c_int32),
+                ("d_prob_node_ptr", C.c_void_p), ("d_prob_nodes", C.c_void_p), ("d_prob_edge_ptr", C.c_void_p),
+                ("d_prob_edges", C.c_void_p)]
+
 # every symbol include/pixsfm_hip.h declares (checked by tests/test_cabi.py)
 _SIGNATURES = {
     "pxr_version": (C.c_int, []),
@@ -85,6 +93,10 @@ _SIGNATURES = {
     "pxr_ba_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BaView), C.POINTER(InterpCfg), C.POINTER(Loss),
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(LMOptions),
                                C.c_void_p, C.c_void_p, C.POINTER(LMSummary)]),
+    "pxr_ka_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(KaView), C.POINTER(InterpCfg), C.POINTER(Loss),
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pxr_ka_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(KaView), C.POINTER(InterpCfg), C.POINTER(Loss),
+                               C.c_double, C.POINTER(LMOptions), C.c_void_p, C.POINTER(LMSummary)]),
     "pxr_dense_spd_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "pxr_ba_cost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Loss), C.POINTER(C.c_double)]),
 }

@@ -1,0 +1,82 @@
+"""Device-resident keypoint-adjustment problem (pxr_ka_view) and its solve / eval calls."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KaView, check
+from .engine import lm_options
+
+
+def _csr(labels, n_groups):
+    """Stable grouping: returns (ptr[n_groups + 1], ids sorted by label then by id)."""
+    labels = np.asarray(labels, dtype=np.int64)
+    order = np.argsort(labels, kind="stable")
+    counts = np.bincount(labels, minlength=n_groups)
+    ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    return ptr, order.astype(np.int32)
+
+
+class KAProblem:
+    """problem: dict with kp (n,2), node_patch, node_const, node_problem, edge_src, edge_dst, edge_w.
+    An edge belongs to the sub-problem of its source node (edges are intra-track and a track
+    lives in exactly one sub-problem, keypoint_adjustment/main.py:13-57)."""
+
+    def __init__(self, ctx, arena, problem):
+        self.ctx, self.arena = ctx, arena
+        g = problem
+        self.n_nodes = len(g["kp"])
+        self.n_edges = len(g["edge_src"])
+        node_problem = np.asarray(g["node_problem"], dtype=np.int64)
+        if self.n_nodes and node_problem.min() < 0:
+            raise ValueError("every node needs a problem label >= 0")
+        self.n_problems = int(node_problem.max()) + 1 if self.n_nodes else 0
+        edge_src = np.asarray(g["edge_src"], dtype=np.int32)
+        edge_dst = np.asarray(g["edge_dst"], dtype=np.int32)
+        if self.n_edges and not np.array_equal(node_problem[edge_src], node_problem[edge_dst]):
+            raise ValueError("an edge connects two different sub-problems")
+        node_ptr, nodes = _csr(node_problem, self.n_problems)
+        edge_ptr, edges = _csr(node_problem[edge_src] if self.n_edges else np.zeros(0, np.int64), self.n_problems)
+        self.d = {
+            "kp": ctx.to_device(g["kp"], np.float64),
+            "node_patch": ctx.to_device(g["node_patch"], np.int64),
+            "node_const": ctx.to_device(g["node_const"], np.uint8),
+            "edge_src": ctx.to_device(edge_src, np.int32),
+            "edge_dst": ctx.to_device(edge_dst, np.int32),
+            "edge_w": ctx.to_device(g["edge_w"], np.float64),
+            "node_ptr": ctx.to_device(node_ptr, np.int64), "nodes": ctx.to_device(nodes, np.int32),
+            "edge_ptr": ctx.to_device(edge_ptr, np.int64), "edges": ctx.to_device(edges, np.int32),
+        }
+        d = self.d
+        self.view = KaView(self.n_nodes, d["kp"].ptr, d["node_patch"].ptr, d["node_const"].ptr, self.n_edges,
+                           d["edge_src"].ptr, d["edge_dst"].ptr, d["edge_w"].ptr, self.n_problems,
+                           d["node_ptr"].ptr, d["nodes"].ptr, d["edge_ptr"].ptr, d["edges"].ptr)
+        self.problem_sizes = np.diff(edge_ptr)
+
+    def eval(self, cfg, loss, materialize=False):
+        ctx = self.ctx
+        cost = ctx.empty((self.n_edges,), np.float64)
+        r = J1 = J2 = None
+        if materialize:
+            r = ctx.empty((self.n_edges, self.arena.C), np.float64)
+            J1 = ctx.empty((self.n_edges, self.arena.C, 2), np.float64)
+            J2 = ctx.empty((self.n_edges, self.arena.C, 2), np.float64)
+        check(ctx.lib.pxr_ka_eval(ctx.handle, self.arena.handle, C.byref(self.view), C.byref(cfg), C.byref(loss),
+                                  cost.ptr, r.ptr if r else None, J1.ptr if J1 else None, J2.ptr if J2 else None),
+              "pxr_ka_eval")
+        return cost, r, J1, J2
+
+    def solve(self, cfg, loss, bound=4.0, options=None, per_problem=False):
+        """Refines the keypoints in place on the device; returns (total summary dict, per-problem list|None)."""
+        ctx = self.ctx
+        opts = options or lm_options(parameter_tolerance=1e-5)
+        total = _lib.LMSummary()
+        arr = (_lib.LMSummary * max(1, self.n_problems))() if per_problem else None
+        check(ctx.lib.pxr_ka_solve(ctx.handle, self.arena.handle, C.byref(self.view), C.byref(cfg), C.byref(loss),
+                                   C.c_double(bound), C.byref(opts), C.cast(arr, C.c_void_p) if arr else None,
+                                   C.byref(total)), "pxr_ka_solve")
+        per = [arr[i].as_dict() for i in range(self.n_problems)] if per_problem else None
+        return total.as_dict(), per
+
+    def keypoints(self):
+        return self.d["kp"].download()

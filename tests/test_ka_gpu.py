@@ -1,0 +1,125 @@
+"""GPU parity for keypoint adjustment: per-edge residuals/Jacobians (pxr_ka_eval) and the
+in-kernel bounded LM (pxr_ka_solve) vs the oracle (oracle/pxo_solve.c).
+Tolerances: residual/Jacobian 1e-10 relative (north_star: 1e-5); refined keypoints 1e-6 px
+while the trajectories coincide (north_star: 1e-4).  Parity unpinned w.r.t. real Ceres."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(ctx, **kw):
+    from pixsfm_amd import synthetic_ka
+    from pixsfm_amd.engine import PatchArena
+    from pixsfm_amd.ka_engine import KAProblem
+    prob = synthetic_ka.make_ka_problem(**kw)
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    return prob, arena, KAProblem(ctx, arena, prob)
+
+
+def _oracle_edges(prob, cfg_kw=None):
+    import pxo
+    cfg = pxo.cfg(**(cfg_kw or {}))
+    ls = pxo.loss("cauchy", 0.25)
+    R, J1s, J2s, costs = [], [], [], []
+    for s, d, w in zip(prob["edge_src"], prob["edge_dst"], prob["edge_w"]):
+        p1 = pxo.make_patch(prob["patches"][s], prob["corners"][s], prob["scales"][s])
+        p2 = pxo.make_patch(prob["patches"][d], prob["corners"][d], prob["scales"][d])
+        r, J1, J2 = pxo.ka_residual(p1, p2, cfg, prob["kp"][s], prob["kp"][d])
+        R.append(r); J1s.append(J1); J2s.append(J2)
+        costs.append(0.5 * pxo.loss_eval(ls, float(r @ r), w)[0])
+    return np.array(R), np.array(J1s), np.array(J2s), np.array(costs)
+
+
+@pytest.mark.parametrize("dtype,channels,scale", [(np.float16, 128, (1.0, 1.0)), (np.float16, 64, (0.5, 0.25)),
+                                                   (np.float32, 128, (1.0, 1.0)), (np.float64, 128, (2.0, 1.0))])
+def test_edge_residuals_and_jacobians(ctx, dtype, channels, scale):
+    from pixsfm_amd.engine import interp_cfg, make_loss
+    prob, arena, ka = _setup(ctx, n_tracks=6, track_len=4, seed=11, dtype=dtype, channels=channels, scale=scale)
+    cost, r, J1, J2 = ka.eval(interp_cfg(), make_loss("cauchy", [0.25]), materialize=True)
+    R, J1o, J2o, co = _oracle_edges(prob)
+    rel = lambda a, b: np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+    assert rel(r.download(), R) < 1e-10
+    assert rel(J1.download(), J1o) < 1e-10
+    assert rel(J2.download(), J2o) < 1e-10
+    assert rel(cost.download(), co) < 1e-10
+
+
+def test_solve_matches_oracle_default_options(ctx):
+    """KeypointAdjuster defaults (keypoint_adjustment/main.py:61-82): Cauchy(0.25), bound 4,
+    parameter_tolerance 1e-5, <= 50 keypoints per sub-problem, roots constant."""
+    import pxo
+    import pxo_ka
+    from pixsfm_amd.engine import interp_cfg, make_loss
+    prob, arena, ka = _setup(ctx, n_tracks=30, track_len=6, seed=5, max_kps_per_problem=50)
+    total, per = ka.solve(interp_cfg(), make_loss("cauchy", [0.25]), bound=4.0, per_problem=True)
+    kp = ka.keypoints()
+    kpo, sums = pxo_ka.ka_solve(prob, pxo.cfg(), pxo.loss("cauchy", 0.25), 4.0)
+    assert len(per) == len(sums) == prob["n_problems"]
+    for g, o in zip(per, sums):
+        assert g["iterations"] == o["iterations"] and g["num_successful"] == o["num_successful"]
+        assert g["termination"] == o["termination"]
+        assert abs(g["initial_cost"] - o["initial_cost"]) < 1e-10 * o["initial_cost"]
+        assert abs(g["final_cost"] - o["final_cost"]) < 1e-7 * max(o["final_cost"], 1e-6)
+    assert np.abs(kp - kpo).max() < 1e-6
+    root = prob["node_const"].astype(bool)
+    assert np.array_equal(kp[root], prob["kp"][root])            # roots stay fixed (main.py:175-177)
+    assert total["final_cost"] < 0.05 * total["initial_cost"]
+    assert abs(total["initial_cost"] - sum(s["initial_cost"] for s in sums)) < 1e-9 * total["initial_cost"]
+
+
+def test_solve_with_active_bounds_and_many_iterations(ctx):
+    """Large detection noise: several nodes end on their +-bound box; tight tolerance so the LM
+    runs long.  End points must agree within north_star's 1e-4."""
+    import pxo
+    import pxo_ka
+    from pixsfm_amd.engine import interp_cfg, lm_options, make_loss
+    prob, arena, ka = _setup(ctx, n_tracks=10, track_len=5, seed=9, sigma=2.5, max_kps_per_problem=25)
+    opts = dict(parameter_tolerance=1e-9, max_iterations=40)
+    total, per = ka.solve(interp_cfg(), make_loss("cauchy", [0.25]), bound=2.0, options=lm_options(**opts),
+                          per_problem=True)
+    kp = ka.keypoints()
+    kpo, sums = pxo_ka.ka_solve(prob, pxo.cfg(), pxo.loss("cauchy", 0.25), 2.0, pxo.lm_options(**opts))
+    assert np.abs(kp - kpo).max() < 1e-4
+    moved = np.abs(kp - prob["kp"]).max(axis=1)
+    assert (np.abs(moved - 2.0) < 1e-9).any(), "expected at least one keypoint on its bound"
+    assert moved.max() <= 2.0 + 1e-12
+
+
+def test_oversized_problem_uses_global_matrix(ctx):
+    """> 112 unknowns in one sub-problem: the damped matrix falls back from LDS to global scratch."""
+    import pxo
+    import pxo_ka
+    from pixsfm_amd.engine import interp_cfg, make_loss
+    prob, arena, ka = _setup(ctx, n_tracks=16, track_len=5, seed=2, max_kps_per_problem=200)
+    assert prob["n_problems"] == 1
+    total, _ = ka.solve(interp_cfg(), make_loss("cauchy", [0.25]))
+    kpo, sums = pxo_ka.ka_solve(prob, pxo.cfg(), pxo.loss("cauchy", 0.25), 4.0)
+    assert total["num_point_unknowns"] == sums[0]["num_unknowns"] == 2 * (80 - 16)
+    assert np.abs(ka.keypoints() - kpo).max() < 1e-6
+
+
+def test_infeasible_start_and_empty_problems(ctx):
+    import pxo
+    import pxo_ka
+    from pixsfm_amd.engine import PatchArena, interp_cfg, make_loss
+    from pixsfm_amd.ka_engine import KAProblem
+    from pixsfm_amd import synthetic_ka
+    prob = synthetic_ka.make_ka_problem(n_tracks=4, track_len=3, seed=4, max_kps_per_problem=3)
+    # push one free keypoint outside its patch: Ceres declares the problem infeasible and leaves it untouched
+    free = np.nonzero(prob["node_const"] == 0)[0][0]
+    prob["kp"][free] += 30.0
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ka = KAProblem(ctx, arena, prob)
+    total, per = ka.solve(interp_cfg(), make_loss(), per_problem=True)
+    kpo, sums = pxo_ka.ka_solve(prob, pxo.cfg(), pxo.loss(), 4.0)
+    bad = prob["node_problem"][free]
+    assert per[bad]["termination"] == 2 == sums[bad]["termination"]
+    assert np.abs(ka.keypoints() - kpo).max() < 1e-6
+    assert np.array_equal(ka.keypoints()[free], prob["kp"][free])
+    # no edges at all
+    for k in ("edge_src", "edge_dst", "edge_w"):
+        prob[k] = prob[k][:0]
+    ka2 = KAProblem(ctx, arena, prob)
+    total2, _ = ka2.solve(interp_cfg(), make_loss())
+    assert total2["initial_cost"] == 0.0 and np.array_equal(ka2.keypoints(), prob["kp"])

@@ -113,6 +113,34 @@ def test_unsupported_channels_raise(ctx):
         ba.eval(interp_cfg())
 
 
+@pytest.mark.parametrize("name,dtype,fs", [("f16", np.float16, 0), ("f16", np.float16, 1), ("f32", np.float32, 0),
+                                           ("f64", np.float64, 0)])
+def test_kernel_reproduces_reference_golden_vectors(ctx, name, dtype, fs):
+    """tests/golden/bicubic_ref.npz was produced by the REFERENCE's own spline/grid code
+    (tests/golden/make_golden.py).  Drive the fused kernel so that it evaluates exactly those
+    (r, c) positions: identity pose, SIMPLE_PINHOLE f = 1, c = 0, X = (c + .5, r + .5, 1), no
+    normalisation, zero reference => r = f, gx = dfdc, gy = dfdr."""
+    import os
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "bicubic_ref.npz"))
+    pos = gold["positions_rc"]
+    n = len(pos)
+    grid = np.ascontiguousarray(gold["grid_" + name].astype(dtype))[None]
+    prob = dict(obs_image=np.zeros(n, np.int32), obs_point=np.arange(n, dtype=np.int32),
+                obs_patch=np.zeros(n, np.int64), image_camera=np.zeros(1, np.int32),
+                qvec=np.array([[1.0, 0, 0, 0]]), tvec=np.zeros((1, 3)), cam_model=np.zeros(1, np.int32),
+                cam_params=np.array([[1.0, 0.0, 0.0]]), refs=np.zeros((n, 128)),
+                xyz=np.stack([pos[:, 1] + 0.5, pos[:, 0] + 0.5, np.ones(n)], 1))
+    arena = PatchArena.from_numpy(ctx, grid, np.zeros((1, 2), np.int32), np.ones((1, 2)))
+    ba = BAProblem(ctx, arena, prob)
+    _, r, gx, gy = ba.eval(interp_cfg(l2_normalize=False, use_float_simd=bool(fs)), with_jacobian=True, materialize=True)
+    want = gold["out_%s_fs%d" % (name, fs)]
+    tol = 1e-12 * np.abs(want).max()          # (c + .5) - .5 may differ from c by one ulp
+    assert np.abs(r.download() - want[:, 0]).max() < tol
+    assert np.abs(gy.download() - want[:, 1]).max() < tol
+    assert np.abs(gx.download() - want[:, 2]).max() < tol
+
+
 def test_linearity_in_reference_full_size_property(ctx):
     """Size-independent property: r(ref) - r(0) == -ref for every observation."""
     from pixsfm_amd.engine import interp_cfg

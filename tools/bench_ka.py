@@ -1,0 +1,109 @@
+#!/usr/bin/env python
+"""KA throughput on BASELINE.json configs[1]: synthetic 10k tracks / 100k observations (nodes),
+complete intra-track graph (45 edges per 10-node track -> 450k residual blocks), 128-ch fp16
+16x16 patches, Cauchy(0.25), bound 4 px, <= 50 keypoints per sub-problem.
+
+Reports (one JSON line): per-edge residual+Jacobian evaluation rate (pxr_ka_eval, the
+reference's unit of work: 2 interpolations per edge) and the full bounded-LM solve time
+(pxr_ka_solve: node-centric evaluation inside one workgroup per sub-problem).
+Not the headline bench (bench.py is); numbers are quoted in DESIGN.md.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pixel-perfect-sfm_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def make_problem_gpu(dev, n_tracks, track_len, C=128, PS=16, seed=1, sigma=1.0, chunk=16384):
+    from pixsfm_amd import synthetic, synthetic_ka
+    rng = np.random.default_rng(seed)
+    n = n_tracks * track_len
+    track = np.repeat(np.arange(n_tracks), track_len)
+    true_xy = rng.uniform(50, 950, (n, 2))
+    kp0 = true_xy + rng.normal(0, sigma, (n, 2))
+    corners = np.floor(kp0 - PS / 2.0).astype(np.int32)
+    wx, wy, th = (torch.tensor(a, dtype=torch.float32, device=dev) for a in synthetic._basis())
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    A = torch.randn((n_tracks, C, synthetic.N_BASIS), generator=g, device=dev).half()
+    patches = torch.empty((n, PS, PS, C), dtype=torch.float16, device=dev)
+    ii = torch.arange(PS, device=dev, dtype=torch.float32)
+    cr = torch.tensor(corners, device=dev, dtype=torch.float32)
+    ct = torch.tensor(true_xy, device=dev, dtype=torch.float32)
+    tr = torch.tensor(track, device=dev)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        cx = cr[s:e, 0:1] + ii[None] + 0.5 - ct[s:e, 0:1]
+        cy = cr[s:e, 1:2] + ii[None] + 0.5 - ct[s:e, 1:2]
+        ph = torch.cos(cy[:, :, None, None] * wy + cx[:, None, :, None] * wx + th)
+        val = torch.bmm(ph.reshape(e - s, PS * PS, -1), A[tr[s:e]].float().transpose(1, 2))
+        patches[s:e] = (val / val.norm(dim=-1, keepdim=True)).reshape(e - s, PS, PS, C).half()
+    # complete intra-track graph, one direction per pair
+    a_idx, b_idx = np.triu_indices(track_len, 1)
+    base = (np.arange(n_tracks) * track_len)[:, None]
+    edge_src = (base + a_idx[None]).reshape(-1).astype(np.int32)
+    edge_dst = (base + b_idx[None]).reshape(-1).astype(np.int32)
+    edge_w = rng.uniform(0.5, 1.0, len(edge_src))
+    score = np.zeros(n); np.add.at(score, edge_src, edge_w); np.add.at(score, edge_dst, edge_w)
+    node_const = np.zeros(n, np.uint8)
+    node_const[(np.arange(n_tracks) * track_len) + score.reshape(n_tracks, track_len).argmax(1)] = 1
+    labels, bins = synthetic_ka.find_problem_labels(track, 50)
+    return dict(kp=kp0, node_patch=np.arange(n, dtype=np.int64), node_const=node_const,
+                node_problem=np.array(labels, np.int32), edge_src=edge_src, edge_dst=edge_dst, edge_w=edge_w,
+                corners=corners, scales=np.ones((n, 2)), true_xy=true_xy, n_problems=len(bins)), patches
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tracks", type=int, default=10000)
+    ap.add_argument("--track-len", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    args = ap.parse_args()
+    from pixsfm_amd.engine import Context, PatchArena, interp_cfg, make_loss
+    from pixsfm_amd.ka_engine import KAProblem
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    prob, patches = make_problem_gpu(dev, args.tracks, args.track_len)
+    ctx = Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    n = len(prob["kp"])
+    arena = PatchArena(ctx, n, 16, 16, 128, np.float16, device_ptr=patches.data_ptr())
+    arena.upload(0, None, prob["corners"], prob["scales"])
+    ka = KAProblem(ctx, arena, prob)
+    cfg, ls = interp_cfg(), make_loss("cauchy", [0.25])
+    ka.eval(cfg, ls)
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        cost, _, _, _ = ka.eval(cfg, ls)
+    ms = ctx.timer_stop() / args.steps
+    c0 = float(cost.download().sum())
+    t0 = time.perf_counter()
+    total, _ = ka.solve(cfg, ls, bound=4.0)
+    wall = time.perf_counter() - t0
+    kp = ka.keypoints()
+    # expected optimum: true + (root offset)
+    tl = args.track_len
+    root = prob["node_const"].astype(bool)
+    off = (prob["kp"][root] - prob["true_xy"][root]).repeat(tl, axis=0)
+    err0 = np.linalg.norm(prob["kp"] - (prob["true_xy"] + off), axis=1)
+    err1 = np.linalg.norm(kp - (prob["true_xy"] + off), axis=1)
+    out = {"workload": "BASELINE.json configs[1]: %d tracks x %d nodes, %d edges, %d sub-problems, 128-ch fp16 16x16"
+                       % (args.tracks, tl, ka.n_edges, ka.n_problems),
+           "edge_eval": {"edges_per_s": ka.n_edges / (ms * 1e-3), "kernel_ms": ms,
+                         "algorithmic_GBps": 8244 * ka.n_edges / (ms * 1e-3) / 1e9},
+           "solve": {"wall_ms": wall * 1e3, "kernel_ms": total["total_ms"], "lm_iterations_max": total["iterations"],
+                     "successful_steps": total["num_successful"], "initial_cost": total["initial_cost"],
+                     "final_cost": total["final_cost"], "initial_cost_check": c0},
+           "accuracy_px": {"median_before": float(np.median(err0)), "median_after": float(np.median(err1)),
+                           "p95_after": float(np.percentile(err1, 95))}}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -117,6 +117,12 @@ def load():
         raise PixsfmHipError(
             "libpixsfm_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: when PyTorch-ROCm is installed it must load ITS libamdhip64 first
+    # (loading ours first makes a later torch.cuda initialisation fail with "No HIP GPUs are available").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)

@@ -199,6 +199,18 @@ int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const 
                  pxr_lm_summary* summary);
 
 
+/* ---- BA reference extraction -----------------------------------------------------------
+ * Replaces ReferenceExtractor::Run (bundle_adjustment/src/reference_extractor.h:125-318) +
+ * RobustMeanIRLS (base/src/irls_optim.h:24-71) for N_NODES = 1: per point, descriptors of all
+ * its observations at the CURRENT projection (view->d_refs is ignored), IRLS robust mean with
+ * `loss` (ReferenceConfig.loss, Cauchy(0.25)) and `iters` (100) iterations, reference = the
+ * observation descriptor closest to the robust mean.  Outputs (device): d_refs_out
+ * [n_points][C], d_ref_obs_out [n_points] (index of the chosen observation, -1 if the point has
+ * none), optional d_robust_mean_out [n_points][C]. */
+int pxr_ba_compute_references(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view,
+                              const pxr_interp_cfg* cfg, const pxr_loss* loss, int iters,
+                              double* d_refs_out, int64_t* d_ref_obs_out, double* d_robust_mean_out);
+
 /* ---- KA ---------------------------------------------------------------------------------
  * Batched replacement of FeatureMetricKeypointOptimizer::RunParallel / RunSubset
  * (keypoint_adjustment/src/featuremetric_keypoint_optimizer.h:69-137) for the flat edge list

@@ -93,11 +93,15 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(const BaEvalArgs a) {
     const int64_t pi = shfl_i64(pidx, src);
     const int pti = __shfl(pt, src);
     // reference descriptor slice of this lane: 8 doubles (issued before the texel math)
-    const double* refp = a.v.d_refs + (size_t)pti * C + sub * 8;
-    double2 rf0 = *reinterpret_cast<const double2*>(refp);
-    double2 rf1 = *reinterpret_cast<const double2*>(refp + 2);
-    double2 rf2 = *reinterpret_cast<const double2*>(refp + 4);
-    double2 rf3 = *reinterpret_cast<const double2*>(refp + 6);
+    // (d_refs == NULL: no reference is subtracted -- the descriptor pass of the reference extraction)
+    double2 rf0 = make_double2(0, 0), rf1 = rf0, rf2 = rf0, rf3 = rf0;
+    if (a.v.d_refs) {
+      const double* refp = a.v.d_refs + (size_t)pti * C + sub * 8;
+      rf0 = *reinterpret_cast<const double2*>(refp);
+      rf1 = *reinterpret_cast<const double2*>(refp + 2);
+      rf2 = *reinterpret_cast<const double2*>(refp + 4);
+      rf3 = *reinterpret_cast<const double2*>(refp + 6);
+    }
 
     double f[8], fr[8], fc[8];
     interp8<ST, LPO, WITH_JAC, FLOAT_SIMD>(arena + (size_t)pi * patch_elems, a.H, a.W, C, sub, u, v,

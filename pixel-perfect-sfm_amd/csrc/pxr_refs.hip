@@ -1,0 +1,215 @@
+// pxr_refs.hip -- reference-descriptor extraction for featuremetric BA on gfx950.
+//
+// Replaces ReferenceExtractor::Run / RunSubset / ComputeReference / FillDescriptorTrack
+// (bundle_adjustment/src/reference_extractor.h:125-318) and RobustMeanIRLS
+// (base/src/irls_optim.h:24-71): per 3D point, interpolate the normalised descriptor of every
+// observation at the point's CURRENT projection (value only), run the IRLS robust mean
+// (weights 1/rho(|d_i - mu|^2) with the loss VALUE, early return if rho <= 0, 100 iterations),
+// and keep the observation descriptor closest to the robust mean (closest_to_robust_mean = true,
+// reference_extractor.h:63,249-272).
+//
+// Pass 1 reuses the fused BA kernel with no reference (d_refs = NULL) in materialise mode: the
+// descriptors land in an [n_obs][C] fp64 scratch.  Pass 2: one 16-lane row per point, a lane owns
+// 8 channels; tracks of up to 8 observations keep all descriptors in registers for the 100 IRLS
+// iterations (no memory traffic in the loop), longer tracks re-read them from L2.
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "pxr_device.h"
+#include "pxr_internal.h"
+
+namespace pxr {
+
+constexpr int REF_REG_TRACK = 8;
+
+template <int C>
+__global__ __launch_bounds__(256) void k_irls(int64_t n_points, const int64_t* __restrict__ pt_ptr,
+                                              const int64_t* __restrict__ pt_obs,
+                                              const double* __restrict__ desc, pxr_loss loss, int iters,
+                                              int l2_normalize, double* __restrict__ wbuf,
+                                              double* __restrict__ refs, int64_t* __restrict__ ref_obs,
+                                              double* __restrict__ robust_mean) {
+  constexpr int LPO = C / 8, G = 256 / LPO;
+  const int sub = threadIdx.x % LPO;
+  const int64_t p = (int64_t)blockIdx.x * G + threadIdx.x / LPO;
+  if (p >= n_points) return;
+  const int64_t o0 = pt_ptr[p], o1 = pt_ptr[p + 1];
+  const int n = (int)(o1 - o0);
+  if (n == 0) { if (sub == 0) ref_obs[p] = -1; return; }
+  auto rsum = [](double v) { return LPO == 16 ? row16_sum(v) : row8_sum(v); };
+
+  double mu[8];
+  int early = -1;
+  if (n <= REF_REG_TRACK) {
+    double d[REF_REG_TRACK][8], w[REF_REG_TRACK];
+#pragma unroll
+    for (int i = 0; i < REF_REG_TRACK; ++i) {
+      w[i] = 1.0;
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) d[i][ch] = (i < n) ? desc[(size_t)pt_obs[o0 + i] * C + sub * 8 + ch] : 0.0;
+    }
+    for (int k = 0; k < iters && early < 0; ++k) {
+      double sw = 0.0;
+#pragma unroll
+      for (int i = 0; i < REF_REG_TRACK; ++i) if (i < n) sw += w[i];
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) mu[ch] = 0.0;
+#pragma unroll
+      for (int i = 0; i < REF_REG_TRACK; ++i) {
+        if (i >= n) continue;
+        w[i] = w[i] / sw;                                    // irls_optim.h:44
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) mu[ch] += d[i][ch] * w[i];   // :46-48
+      }
+      if (l2_normalize) {                                    // :54-58
+        double ss = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) ss = fma(mu[ch], mu[ch], ss);
+        const double nrm = sqrt(rsum(ss));
+        if (nrm > 0.0) {
+#pragma unroll
+          for (int ch = 0; ch < 8; ++ch) mu[ch] /= nrm;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < REF_REG_TRACK; ++i) {              // :60-69
+        if (i >= n || early >= 0) continue;
+        double s = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) { const double df = d[i][ch] - mu[ch]; s = fma(df, df, s); }
+        s = rsum(s);
+        double rho[3];
+        loss_eval(loss.type, loss.a, 1.0, s, rho);
+        if (rho[0] > 0.0) w[i] = 1.0 / rho[0];
+        else {
+          early = i;
+#pragma unroll
+          for (int ch = 0; ch < 8; ++ch) mu[ch] = d[i][ch];
+        }
+      }
+    }
+  } else {
+    double* w = wbuf + o0;   // per-observation weights in L2-resident scratch (all lanes of the row write the same value)
+    for (int i = 0; i < n; ++i) w[i] = 1.0;
+    for (int k = 0; k < iters && early < 0; ++k) {
+      double sw = 0.0;
+      for (int i = 0; i < n; ++i) sw += w[i];
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) mu[ch] = 0.0;
+      for (int i = 0; i < n; ++i) {
+        const double wi = w[i] / sw;
+        w[i] = wi;
+        const double* di = desc + (size_t)pt_obs[o0 + i] * C + sub * 8;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) mu[ch] += di[ch] * wi;
+      }
+      if (l2_normalize) {
+        double ss = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) ss = fma(mu[ch], mu[ch], ss);
+        const double nrm = sqrt(rsum(ss));
+        if (nrm > 0.0) {
+#pragma unroll
+          for (int ch = 0; ch < 8; ++ch) mu[ch] /= nrm;
+        }
+      }
+      for (int i = 0; i < n && early < 0; ++i) {
+        const double* di = desc + (size_t)pt_obs[o0 + i] * C + sub * 8;
+        double s = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) { const double df = di[ch] - mu[ch]; s = fma(df, df, s); }
+        s = rsum(s);
+        double rho[3];
+        loss_eval(loss.type, loss.a, 1.0, s, rho);
+        if (rho[0] > 0.0) w[i] = 1.0 / rho[0];
+        else {
+          early = i;
+#pragma unroll
+          for (int ch = 0; ch < 8; ++ch) mu[ch] = di[ch];
+        }
+      }
+    }
+  }
+  // ComputeReference: observation closest to the robust mean (first minimum, Eigen minCoeff)
+  int best = 0;
+  double bestd = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double* di = desc + (size_t)pt_obs[o0 + i] * C + sub * 8;
+    double s = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) { const double df = di[ch] - mu[ch]; s = fma(df, df, s); }
+    s = rsum(s);
+    if (i == 0 || s < bestd) { bestd = s; best = i; }
+  }
+  const int64_t bo = pt_obs[o0 + best];
+#pragma unroll
+  for (int ch = 0; ch < 8; ++ch) {
+    refs[(size_t)p * C + sub * 8 + ch] = desc[(size_t)bo * C + sub * 8 + ch];
+    if (robust_mean) robust_mean[(size_t)p * C + sub * 8 + ch] = mu[ch];
+  }
+  if (sub == 0) ref_obs[p] = bo;
+}
+
+}  // namespace pxr
+
+extern "C" int pxr_ba_compute_references(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view,
+                                         const pxr_interp_cfg* cfg, const pxr_loss* loss, int iters,
+                                         double* d_refs_out, int64_t* d_ref_obs_out, double* d_robust_mean_out) {
+  using namespace pxr;
+  PXR_REQUIRE(ctx && arena && view && cfg && loss && d_refs_out && d_ref_obs_out, "pxr_ba_compute_references: NULL argument");
+  PXR_REQUIRE(arena->C == 128 || arena->C == 64, "pxr_ba_compute_references: CHANNELS=%d not supported (128, 64)", arena->C);
+  PXR_REQUIRE(iters >= 0, "pxr_ba_compute_references: negative iteration count");
+  PXR_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int64_t n_obs = view->n_obs, n_pts = view->n_points;
+  const int C = arena->C;
+  if (n_pts == 0) return PXR_OK;
+  // CSR of observations per point (host, structure only)
+  std::vector<int32_t> obs_point(n_obs);
+  PXR_HIP(hipMemcpyAsync(obs_point.data(), view->d_obs_point, 4 * n_obs, hipMemcpyDeviceToHost, st));
+  PXR_HIP(hipStreamSynchronize(st));
+  std::vector<int64_t> ptr(n_pts + 1, 0), lst(n_obs);
+  for (int64_t i = 0; i < n_obs; ++i) {
+    PXR_REQUIRE(obs_point[i] >= 0 && obs_point[i] < n_pts, "pxr_ba_compute_references: point index out of range");
+    ++ptr[obs_point[i] + 1];
+  }
+  for (int64_t p = 0; p < n_pts; ++p) ptr[p + 1] += ptr[p];
+  {
+    std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
+    for (int64_t i = 0; i < n_obs; ++i) lst[cur[obs_point[i]]++] = i;
+  }
+  double *d_desc = nullptr, *d_rec = nullptr, *d_w = nullptr;
+  int64_t *d_ptr = nullptr, *d_lst = nullptr;
+  auto cleanup = [&]() { (void)hipFree(d_desc); (void)hipFree(d_rec); (void)hipFree(d_w); (void)hipFree(d_ptr); (void)hipFree(d_lst); };
+  const size_t no1 = n_obs ? (size_t)n_obs : 1;
+  if (hipMalloc((void**)&d_desc, sizeof(double) * no1 * C) != hipSuccess ||
+      hipMalloc((void**)&d_rec, sizeof(double) * no1 * PXR_OBS_REC) != hipSuccess ||
+      hipMalloc((void**)&d_w, sizeof(double) * no1) != hipSuccess ||
+      hipMalloc((void**)&d_ptr, sizeof(int64_t) * (n_pts + 1)) != hipSuccess ||
+      hipMalloc((void**)&d_lst, sizeof(int64_t) * no1) != hipSuccess) {
+    cleanup();
+    return set_error(PXR_ENOMEM, "pxr_ba_compute_references: scratch allocation failed");
+  }
+  int rc = hip_check(hipMemcpyAsync(d_ptr, ptr.data(), sizeof(int64_t) * (n_pts + 1), hipMemcpyHostToDevice, st), "H2D");
+  if (!rc && n_obs) rc = hip_check(hipMemcpyAsync(d_lst, lst.data(), sizeof(int64_t) * n_obs, hipMemcpyHostToDevice, st), "H2D");
+  if (!rc && n_obs) {   // pass 1: descriptors at the current projections, no reference subtracted
+    pxr_ba_view v = *view;
+    v.d_refs = nullptr;
+    rc = pxr_ba_eval(ctx, arena, &v, cfg, 0, d_rec, d_desc, nullptr, nullptr);
+  }
+  if (!rc) {
+    const int G = 256 / (C / 8);
+    const unsigned blocks = (unsigned)((n_pts + G - 1) / G);
+    if (C == 128)
+      hipLaunchKernelGGL((k_irls<128>), dim3(blocks), dim3(256), 0, st, n_pts, d_ptr, d_lst, d_desc, *loss, iters,
+                         cfg->l2_normalize, d_w, d_refs_out, d_ref_obs_out, d_robust_mean_out);
+    else
+      hipLaunchKernelGGL((k_irls<64>), dim3(blocks), dim3(256), 0, st, n_pts, d_ptr, d_lst, d_desc, *loss, iters,
+                         cfg->l2_normalize, d_w, d_refs_out, d_ref_obs_out, d_robust_mean_out);
+    rc = hip_check(hipGetLastError(), "k_irls launch");
+  }
+  if (!rc) rc = hip_check(hipStreamSynchronize(st), "sync");
+  cleanup();
+  return rc;
+}

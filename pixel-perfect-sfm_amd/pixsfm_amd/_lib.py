@@ -93,6 +93,8 @@ _SIGNATURES = {
     "pxr_ba_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BaView), C.POINTER(InterpCfg), C.POINTER(Loss),
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(LMOptions),
                                C.c_void_p, C.c_void_p, C.POINTER(LMSummary)]),
+    "pxr_ba_compute_references": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BaView), C.POINTER(InterpCfg),
+                                            C.POINTER(Loss), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pxr_ka_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(KaView), C.POINTER(InterpCfg), C.POINTER(Loss),
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pxr_ka_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(KaView), C.POINTER(InterpCfg), C.POINTER(Loss),

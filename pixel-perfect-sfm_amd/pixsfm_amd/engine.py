@@ -281,6 +281,17 @@ class BAProblem:
               "pxr_ba_solve")
         return summ.as_dict()
 
+    def compute_references(self, cfg, loss, iters=100, keep_mean=False):
+        """ReferenceExtractor.run on the GPU: fills this problem's `refs` in place (device) and
+        returns (ref_obs indices, robust means | None) as numpy arrays."""
+        ctx = self.ctx
+        ref_obs = ctx.empty((self.n_points,), np.int64)
+        mean = ctx.empty((self.n_points, self.arena.C), np.float64) if keep_mean else None
+        check(ctx.lib.pxr_ba_compute_references(ctx.handle, self.arena.handle, C.byref(self.view), C.byref(cfg),
+                                                C.byref(loss), int(iters), self.d["refs"].ptr, ref_obs.ptr,
+                                                mean.ptr if mean else None), "pxr_ba_compute_references")
+        return ref_obs.download(), (mean.download() if mean else None)
+
     def params(self):
         """Download (qvec, tvec, cam_params, xyz)."""
         d = self.d

@@ -1,0 +1,71 @@
+"""GPU parity: reference extraction (pxr_ba_compute_references) vs the oracle's restatement of
+ReferenceExtractor::ComputeReference + RobustMeanIRLS (reference_extractor.h:238-272,
+irls_optim.h:24-71).  Tolerance 1e-10 on descriptors / robust means; chosen observation equal."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_refs(prob, iters, l2=True):
+    import pxo
+    cfg = pxo.cfg(l2_normalize=l2)
+    ls = pxo.loss("cauchy", 0.25)
+    n_pts = len(prob["xyz"])
+    C = prob["patches"].shape[-1]
+    refs, means, chosen = np.zeros((n_pts, C)), np.zeros((n_pts, C)), np.full(n_pts, -1)
+    for p in range(n_pts):
+        obs = np.nonzero(prob["obs_point"] == p)[0]
+        if len(obs) == 0:
+            continue
+        descs = []
+        for i in obs:
+            img = prob["obs_image"][i]
+            cam = prob["image_camera"][img]
+            patch = pxo.make_patch(prob["patches"][prob["obs_patch"][i]], prob["corners"][prob["obs_patch"][i]],
+                                   prob["scales"][prob["obs_patch"][i]])
+            K = pxo.lib().pxo_camera_num_params(int(prob["cam_model"][cam]))
+            f, *_ = pxo.ba_residual(patch, cfg, int(prob["cam_model"][cam]), prob["qvec"][img], prob["tvec"][img],
+                                    prob["xyz"][p], prob["cam_params"][cam][:K], None, jac=False)
+            descs.append(f)
+        idx, ref, mean = pxo.compute_reference(np.array(descs), ls, iters, l2)
+        refs[p], means[p], chosen[p] = ref, mean, obs[idx]
+    return refs, means, chosen
+
+
+@pytest.mark.parametrize("obs_per_point,noise", [(4, 0.3), (8, 0.3), (11, 0.5)])
+def test_references_match_oracle(ctx, obs_per_point, noise):
+    """tracks <= 8 use the register path, longer tracks the L2 path; per-image noise makes the
+    descriptors of a track differ so that the IRLS has something to do."""
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, make_loss
+    prob = synthetic.make_ba_problem(n_cams=12, n_points=37, obs_per_point=obs_per_point, seed=obs_per_point, noise=noise)
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    chosen, mean = ba.compute_references(interp_cfg(), make_loss("cauchy", [0.25]), iters=100, keep_mean=True)
+    refs = ba.d["refs"].download()
+    refs_o, means_o, chosen_o = _oracle_refs(prob, 100)
+    assert np.array_equal(chosen, chosen_o)
+    assert np.abs(mean - means_o).max() < 1e-10
+    assert np.abs(refs - refs_o).max() < 1e-10
+    assert np.abs(np.linalg.norm(refs, axis=1) - 1).max() < 1e-12
+    # the refreshed references are immediately usable by the residual kernel
+    rec, *_ = ba.eval(interp_cfg(), with_jacobian=False)
+    assert np.isfinite(rec.download()).all()
+
+
+def test_point_without_observations_and_unnormalised(ctx):
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, make_loss
+    prob = synthetic.make_ba_problem(n_cams=5, n_points=9, obs_per_point=3, seed=2, noise=0.2)
+    keep = prob["obs_point"] != 4
+    for k in ("obs_image", "obs_point", "obs_patch"):
+        prob[k] = prob[k][keep]
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    before = ba.d["refs"].download()[4].copy()
+    chosen, mean = ba.compute_references(interp_cfg(l2_normalize=False), make_loss("cauchy", [0.25]), iters=20, keep_mean=True)
+    refs_o, means_o, chosen_o = _oracle_refs(prob, 20, l2=False)
+    assert chosen[4] == -1 and np.array_equal(ba.d["refs"].download()[4], before)
+    m = np.arange(9) != 4
+    assert np.array_equal(chosen[m], chosen_o[m]) and np.abs(mean[m] - means_o[m]).max() < 1e-10

@@ -1,0 +1,389 @@
+"""Mirror of pixsfm's featuremetric bundle-adjustment surface for the accelerated path:
+`BundleAdjuster.create(conf).refine_multilevel(reconstruction, feature_manager)`
+(pixsfm/bundle_adjustment/main.py:30-154) and the `_bundle_adjustment` pybind classes it drives
+(pixsfm/bundle_adjustment/bindings.cc:21-141): BundleAdjustmentSetup, ReferenceExtractor,
+FeatureReferenceBundleOptimizer.  Same names, argument meaning and defaults; problem
+construction follows BundleOptimizer::SetUp / Parameterize (bundle_optimizer.h:139-165,247-453);
+the Ceres solve is replaced by pxr_ba_solve on the GPU.
+
+Deviation (documented in DESIGN.md): `use_inner_iterations` (default True in the reference,
+bundle_adjustment/main.py:43) is accepted but not applied yet.
+"""
+from copy import deepcopy
+
+import numpy as np
+
+from ..engine import BAProblem, lm_options, make_loss
+from . import base, features
+from .keypoint_adjustment import Summary, default_context
+from .reconstruction import CAMERA_MODELS
+
+
+def default_problem_setup(reconstruction):                    # main.py:12-18
+    reg_image_ids = reconstruction.reg_image_ids()
+    ba_setup = BundleAdjustmentSetup()
+    ba_setup.add_images(set(reg_image_ids))
+    ba_setup.set_constant_pose(reg_image_ids[0])
+    ba_setup.set_constant_tvec(reg_image_ids[1], [0])
+    return ba_setup
+
+
+def find_problem_labels(reconstruction, max_tracks_per_problem):   # main.py:21-27
+    problem_labels = [-1 for _ in range(max(reconstruction.point3D_ids()) + 1)]
+    for p3D_id in reconstruction.point3D_ids():
+        problem_labels[p3D_id] = int(p3D_id // max_tracks_per_problem)
+    return problem_labels
+
+
+class BundleAdjustmentSetup:
+    """colmap::BundleAdjustmentConfig [upstream] + pixsfm's overrides
+    (bundle_adjustment/src/bundle_adjustment_options.h:28-42)."""
+
+    def __init__(self):
+        self.image_ids = set()
+        self.constant_poses = set()
+        self.constant_tvecs = {}
+        self.constant_cameras = set()
+        self.variable_points = set()
+        self.constant_points = set()
+
+    def add_image(self, image_id):
+        self.image_ids.add(int(image_id))
+
+    def add_images(self, image_ids):
+        for i in image_ids:
+            self.add_image(i)
+
+    def has_image(self, image_id):
+        return int(image_id) in self.image_ids
+
+    def num_images(self):
+        return len(self.image_ids)
+
+    def set_constant_pose(self, image_id):
+        if not self.has_image(image_id):
+            raise ValueError("image %d is not part of the problem" % image_id)
+        if int(image_id) in self.constant_tvecs:
+            raise ValueError("image %d already has a constant tvec subset" % image_id)
+        self.constant_poses.add(int(image_id))
+
+    def has_constant_pose(self, image_id):
+        return int(image_id) in self.constant_poses
+
+    def set_constant_tvec(self, image_id, idxs):
+        idxs = [int(i) for i in idxs]
+        if not (0 < len(idxs) <= 3) or len(set(idxs)) != len(idxs) or any(i < 0 or i > 2 for i in idxs):
+            raise ValueError("constant tvec indices must be a non-empty duplicate-free subset of {0,1,2}")
+        if not self.has_image(image_id):
+            raise ValueError("image %d is not part of the problem" % image_id)
+        if self.has_constant_pose(image_id):
+            raise ValueError("image %d already has a constant pose" % image_id)
+        self.constant_tvecs[int(image_id)] = idxs
+
+    def has_constant_tvec(self, image_id):
+        return int(image_id) in self.constant_tvecs
+
+    def constant_tvec(self, image_id):
+        return self.constant_tvecs[int(image_id)]
+
+    def set_constant_camera(self, camera_id):
+        self.constant_cameras.add(int(camera_id))
+
+    def is_constant_camera(self, camera_id):
+        return int(camera_id) in self.constant_cameras
+
+    def add_variable_point(self, point3D_id):
+        if int(point3D_id) in self.constant_points:
+            raise ValueError("point %d is already constant" % point3D_id)
+        self.variable_points.add(int(point3D_id))
+
+    def add_constant_point(self, point3D_id):
+        if int(point3D_id) in self.variable_points:
+            raise ValueError("point %d is already variable" % point3D_id)
+        self.constant_points.add(int(point3D_id))
+
+
+class FeatureView:
+    """features.FeatureView(feature_set, reconstruction) (main.py:128-131): resolves the patch of
+    (image_id, point2D_idx) through the image name, like featureview.cc:192-195."""
+
+    def __init__(self, feature_set, reconstruction):
+        self.feature_set, self.reconstruction = feature_set, reconstruction
+
+    def has_fpatch(self, image_id, point2D_idx):
+        name = self.reconstruction.images[image_id].name
+        return self.feature_set.has_fmap(name) and self.feature_set.fmap(name).has_fpatch(point2D_idx)
+
+    def fpatch(self, image_id, point2D_idx):
+        return self.feature_set.fmap(self.reconstruction.images[image_id].name).fpatch(point2D_idx)
+
+    @property
+    def channels(self):
+        return self.feature_set.channels
+
+
+class _FlatBA:
+    """Flat arrays of the residual blocks BundleOptimizer::SetUp would add (bundle_optimizer.h:139-165):
+    AddImageToProblem for every image of the setup, AddPointToProblem for the extra variable / constant
+    points (observations in images outside the setup get a constant pose, :299-333)."""
+
+    def __init__(self, reconstruction, setup, feature_view, options=None, point_filter=None):
+        rec = reconstruction
+        opt = options or {}
+        min_track_length = opt.get('min_track_length', -1)
+        refine_extrinsics = opt.get('refine_extrinsics', True)
+        self.image_ids, self.camera_ids, self.point_ids = [], [], []
+        img_idx, cam_idx, pt_idx = {}, {}, {}
+        obs_image, obs_point, patches, self.obs_keys = [], [], [], []
+        reg_count = {}
+
+        def idx_of(table, lst, key):
+            if key not in table:
+                table[key] = len(lst)
+                lst.append(key)
+            return table[key]
+
+        def add_obs(image_id, p2d_idx, point3D_id):
+            im = rec.images[image_id]
+            if not feature_view.has_fpatch(image_id, p2d_idx):
+                return
+            obs_image.append(idx_of(img_idx, self.image_ids, image_id))
+            idx_of(cam_idx, self.camera_ids, im.camera_id)
+            obs_point.append(idx_of(pt_idx, self.point_ids, point3D_id))
+            patches.append(feature_view.fpatch(image_id, p2d_idx))
+            self.obs_keys.append((image_id, p2d_idx))
+            reg_count[point3D_id] = reg_count.get(point3D_id, 0) + 1
+
+        for image_id in sorted(setup.image_ids):                          # AddImageToProblem, :247-275
+            im = rec.images[image_id]
+            im.qvec = np.asarray(im.qvec, dtype=np.float64) / np.linalg.norm(im.qvec)      # NormalizeQvec :255
+            for p2d_idx, p2d in enumerate(im.points2D):
+                if not p2d.has_point3D():
+                    continue
+                if point_filter is not None and p2d.point3D_id not in point_filter:
+                    continue
+                if rec.points3D[p2d.point3D_id].track.length() < min_track_length:
+                    continue
+                add_obs(image_id, p2d_idx, p2d.point3D_id)
+        self.outside_images = set()
+        for pid in list(sorted(setup.variable_points)) + list(sorted(setup.constant_points)):   # AddPointToProblem
+            p = rec.points3D[pid]
+            if reg_count.get(pid, 0) == p.track.length():
+                continue
+            for el in p.track.elements:
+                if setup.has_image(el.image_id):
+                    continue
+                self.outside_images.add(el.image_id)
+                add_obs(el.image_id, el.point2D_idx, pid)
+        self.obs_image = np.array(obs_image, np.int32)
+        self.obs_point = np.array(obs_point, np.int32)
+        self.patches = patches
+        n_img, n_cam, n_pt = len(self.image_ids), len(self.camera_ids), len(self.point_ids)
+        self.image_camera = np.array([cam_idx[rec.images[i].camera_id] for i in self.image_ids], np.int32)
+        self.qvec = np.array([rec.images[i].qvec for i in self.image_ids], np.float64).reshape(n_img, 4)
+        self.tvec = np.array([rec.images[i].tvec for i in self.image_ids], np.float64).reshape(n_img, 3)
+        self.cam_model = np.array([rec.cameras[c].model_id for c in self.camera_ids], np.int32)
+        self.cam_params = np.zeros((n_cam, 12))
+        for k, c in enumerate(self.camera_ids):
+            self.cam_params[k, :len(rec.cameras[c].params)] = rec.cameras[c].params
+        self.xyz = np.array([rec.points3D[p].xyz for p in self.point_ids], np.float64).reshape(n_pt, 3)
+        # ---- parameterisation (Parameterize*, :335-453) ----------------------------------------------
+        self.pose_const = np.zeros(n_img, np.uint8)
+        self.tvec_mask = np.zeros(n_img, np.uint8)
+        for k, i in enumerate(self.image_ids):
+            if (not refine_extrinsics) or setup.has_constant_pose(i) or (not setup.has_image(i)):
+                self.pose_const[k] = 1
+            elif setup.has_constant_tvec(i):
+                self.tvec_mask[k] = sum(1 << a for a in setup.constant_tvec(i))
+        const_camera = not (opt.get('refine_focal_length', True) or opt.get('refine_principal_point', False)
+                            or opt.get('refine_extra_params', True))
+        cams_with_inside_obs = {rec.images[i].camera_id for i in self.image_ids if setup.has_image(i)}
+        self.cam_mask = np.zeros(n_cam, np.uint16)
+        for k, c in enumerate(self.camera_ids):
+            cam = rec.cameras[c]
+            K = CAMERA_MODELS[cam.model_id][1]
+            if const_camera or setup.is_constant_camera(c) or c not in cams_with_inside_obs:   # :320-322, :405-409
+                self.cam_mask[k] = (1 << K) - 1
+                continue
+            const = []
+            if not opt.get('refine_focal_length', True):
+                const += cam.focal_length_idxs()
+            if not opt.get('refine_principal_point', False):
+                const += cam.principal_point_idxs()
+            if not opt.get('refine_extra_params', True):
+                const += cam.extra_params_idxs()
+            self.cam_mask[k] = sum(1 << a for a in const)
+        self.point_const = np.zeros(n_pt, np.uint8)
+        for k, pid in enumerate(self.point_ids):                            # ParameterizePoints :335-364
+            tl = rec.points3D[pid].track.length()
+            need = min(min_track_length, tl) if min_track_length > 0 else tl
+            if need > reg_count.get(pid, 0) or pid in setup.constant_points:
+                self.point_const[k] = 1
+
+    def problem_dict(self, refs):
+        return dict(obs_image=self.obs_image, obs_point=self.obs_point,
+                    obs_patch=np.arange(len(self.obs_image), dtype=np.int64), image_camera=self.image_camera,
+                    qvec=self.qvec, tvec=self.tvec, cam_model=self.cam_model, cam_params=self.cam_params,
+                    xyz=self.xyz, refs=refs)
+
+
+class ReferenceExtractor:
+    """_bundle_adjustment.ReferenceExtractor(ref_conf, interp_conf).run(problem_labels, reconstruction,
+    feature_set) -> {point3D_id: Reference} (bindings.cc:28-34,172-177; reference_extractor.h:125-162)."""
+    default_conf = {'loss': {'name': 'cauchy', 'params': [0.25]}, 'iters': 100, 'keep_observations': False,
+                    'compute_offsets3D': False, 'num_threads': -1}
+
+    def __init__(self, config=None, interpolation_config=None, ctx=None):
+        self.config = base.merge_conf(self.default_conf, config)
+        ic = interpolation_config
+        self.interpolation = ic if isinstance(ic, base.InterpolationConfig) else base.InterpolationConfig(ic)
+        self.ctx = ctx
+        if self.config['keep_observations'] or self.config['compute_offsets3D']:
+            raise ValueError("keep_observations / compute_offsets3D are outside the accelerated path")
+
+    def run(self, problem_labels, reconstruction, feature_set):
+        ctx = self.ctx or default_context()
+        wanted = {p for p in reconstruction.point3D_ids() if p < len(problem_labels) and problem_labels[p] >= 0}
+        setup = BundleAdjustmentSetup()
+        setup.add_images(reconstruction.reg_image_ids())
+        flat = _FlatBA(reconstruction, setup, FeatureView(feature_set, reconstruction), point_filter=wanted)
+        if len(flat.obs_image) == 0:
+            return {}
+        arena = features.to_arena(ctx, flat.patches)
+        ba = BAProblem(ctx, arena, flat.problem_dict(np.zeros((len(flat.point_ids), arena.C))))
+        chosen, _ = ba.compute_references(self.interpolation.to_engine(),
+                                          make_loss(self.config['loss']['name'], self.config['loss']['params']),
+                                          iters=self.config['iters'])
+        refs = ba.d["refs"].download()
+        out = {}
+        for k, pid in enumerate(flat.point_ids):
+            if chosen[k] >= 0:
+                image_id, p2d_idx = flat.obs_keys[int(chosen[k])]
+                out[pid] = features.Reference(image_id, p2d_idx, refs[k])
+        arena.close()
+        return out
+
+
+class FeatureReferenceBundleOptimizer:
+    """_bundle_adjustment.FeatureReferenceBundleOptimizer(options, setup, interp_conf)
+    .run(reconstruction, feature_view, references) (bindings.cc:36-51,137-141)."""
+    option_defaults = {
+        'loss': {'name': 'cauchy', 'params': [0.25]},
+        'solver': {**base.solver_default_conf},
+        'print_summary': True,
+        'refine_focal_length': True, 'refine_principal_point': False, 'refine_extra_params': True,
+        'refine_extrinsics': True, 'min_track_length': -1,
+    }
+
+    def __init__(self, options=None, setup=None, interpolation_config=None, ctx=None, allreduce=None):
+        self.options = base.merge_conf(self.option_defaults, options)
+        if setup is None:
+            raise ValueError("a BundleAdjustmentSetup is required")
+        self.setup = setup
+        ic = interpolation_config
+        self.interpolation = ic if isinstance(ic, base.InterpolationConfig) else base.InterpolationConfig(ic)
+        self.ctx, self.allreduce = ctx, allreduce
+        self._summary = None
+        self._used = False
+
+    def run(self, reconstruction, feature_view, references):
+        if reconstruction is None:
+            raise ValueError("reconstruction cannot be NULL.")                  # bundle_optimizer.h:117-118
+        if self._used:
+            raise ValueError("Cannot use the same BundleOptimizer multiple times")   # :120-121
+        self._used = True
+        ctx = self.ctx or default_context()
+        if isinstance(feature_view, features.FeatureSet):
+            feature_view = FeatureView(feature_view, reconstruction)
+        flat = _FlatBA(reconstruction, self.setup, feature_view, self.options)
+        if len(flat.obs_image) == 0:
+            return False                                                         # NumResiduals() == 0, :174-176
+        C = flat.patches[0].shape[2]
+        refs = np.zeros((len(flat.point_ids), C))
+        for k, pid in enumerate(flat.point_ids):
+            refs[k] = references[pid].descriptor.reshape(-1)                     # references.at(point3D_id)
+        arena = features.to_arena(ctx, flat.patches)
+        ba = BAProblem(ctx, arena, flat.problem_dict(refs))
+        s = self.options['solver']
+        lm = lm_options(max_iterations=s['max_num_iterations'], function_tolerance=s['function_tolerance'],
+                        gradient_tolerance=s['gradient_tolerance'], parameter_tolerance=s['parameter_tolerance'],
+                        max_consecutive_invalid_steps=s['max_num_consecutive_invalid_steps'])
+        summ = ba.solve(self.interpolation.to_engine(),
+                        make_loss(self.options['loss']['name'], self.options['loss']['params']),
+                        flat.pose_const, flat.tvec_mask, flat.cam_mask, flat.point_const, options=lm,
+                        allreduce=self.allreduce)
+        q, t, k, X = ba.params()
+        for n, i in enumerate(flat.image_ids):       # in place, like feature_reference_bundle_optimizer.h:111-114
+            reconstruction.images[i].qvec = q[n].copy()
+            reconstruction.images[i].tvec = t[n].copy()
+        for n, c in enumerate(flat.camera_ids):
+            cam = reconstruction.cameras[c]
+            cam.params = k[n, :len(cam.params)].copy()
+        for n, pid in enumerate(flat.point_ids):
+            reconstruction.points3D[pid].xyz = X[n].copy()
+        self._summary = Summary(summ, num_residuals=len(flat.obs_image) * C)
+        arena.close()
+        return True
+
+    def summary(self):
+        return self._summary
+
+
+class BundleAdjuster:
+    """pixsfm/bundle_adjustment/main.py:30-102."""
+    default_conf = {
+        'apply': True,
+        'interpolation': base.interpolation_default_conf,
+        'level_indices': None,
+        'max_tracks_per_problem': 10,
+        'optimizer': {
+            'loss': {'name': 'cauchy', 'params': [0.25]},
+            'solver': {**base.solver_default_conf, 'use_inner_iterations': True},
+            'print_summary': False,
+            'refine_focal_length': True, 'refine_principal_point': False, 'refine_extra_params': True,
+            'refine_extrinsics': True,
+        },
+        'references': {'loss': {'name': 'cauchy', 'params': [0.25]}, 'iters': 100, 'keep_observations': False,
+                       'compute_offsets3D': False, 'num_threads': -1},
+        'strategy': 'feature_reference',
+    }
+
+    @classmethod
+    def create(cls, conf):
+        strategy = conf.get("strategy", cls.default_conf["strategy"])
+        if strategy != "feature_reference":
+            raise ValueError("strategy %r is outside the accelerated path (feature_reference only)" % strategy)
+        return FeatureReferenceBundleAdjuster(conf)
+
+    def refine(self, reconstruction, feature_set, problem_setup=None):
+        raise NotImplementedError()
+
+    def refine_multilevel(self, reconstruction, feature_manager, problem_setup=None):
+        levels = self.conf['level_indices'] if self.conf['level_indices'] not in [None, "all"] else \
+            list(reversed(range(feature_manager.num_levels)))
+        outputs = {}
+        for level_index in levels:
+            out = self.refine(reconstruction, feature_manager.fset(level_index), problem_setup)
+            for k, v in out.items():
+                outputs.setdefault(k, []).append(v)
+        return outputs
+
+
+class FeatureReferenceBundleAdjuster(BundleAdjuster):
+    """main.py:105-154."""
+    default_conf = deepcopy(BundleAdjuster.default_conf)
+
+    def __init__(self, conf):
+        self.conf = base.merge_conf(self.default_conf, conf)
+
+    def refine(self, reconstruction, feature_set, problem_setup=None):
+        if problem_setup is None:
+            problem_setup = default_problem_setup(reconstruction)
+        feature_view = FeatureView(feature_set, reconstruction)
+        problem_labels = find_problem_labels(reconstruction, self.conf['max_tracks_per_problem'])
+        ref_extractor = ReferenceExtractor(deepcopy(self.conf['references']), self.conf['interpolation'])
+        references = ref_extractor.run(problem_labels, reconstruction, feature_set)
+        solver = FeatureReferenceBundleOptimizer(deepcopy(self.conf['optimizer']), problem_setup,
+                                                 self.conf['interpolation'])
+        solver.run(reconstruction, feature_view, references)
+        return {"references": references, "summary": solver.summary()}

@@ -1,0 +1,124 @@
+"""Mirror of the `pixsfm._pixsfm._features` containers the adjusters touch
+(pixsfm/features/bindings.cc:38-300): FeaturePatch -> FeatureMap (per image) -> FeatureSet
+(per level) -> FeatureManager, plus Reference.  They are thin host-side holders of numpy
+views (the reference's patches built from numpy are non-owning views too,
+features/src/featurepatch.cc:45); the hot path consumes the flat HBM arena built from them
+(`to_arena`).  HDF5 loading / caching is out of scope.
+"""
+import numpy as np
+
+kDenseId = 1000000      # util/src/types.h:33
+
+
+class FeaturePatch:
+    """features/src/featurepatch.h:40-156: HWC data + corner (x0, y0) + scale (sx, sy)."""
+
+    def __init__(self, data, corner=(0, 0), scale=(1.0, 1.0)):
+        data = np.asarray(data)
+        if data.ndim != 3:
+            raise ValueError("FeaturePatch expects an H x W x C array")
+        if data.dtype not in (np.float16, np.float32, np.float64):
+            raise ValueError("FeaturePatch dtype must be float16/32/64")     # featurepatch.cc:365-367
+        self.data = np.ascontiguousarray(data)
+        self.corner = np.asarray(corner, dtype=np.int32).reshape(2)
+        self.scale = np.asarray(scale, dtype=np.float64).reshape(2)
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    def to_pixel_coordinates(self, xy):          # featurepatch.h:250-255
+        return np.asarray(xy) * self.scale - 0.5 - self.corner
+
+    def to_image_coordinates(self, uv):          # featurepatch.h:257-262
+        return (np.asarray(uv) + self.corner + 0.5) / self.scale
+
+
+class FeatureMap:
+    """Patches of one image keyed by keypoint index (features/src/featuremap.h:104-118)."""
+
+    def __init__(self, patches=None, is_sparse=True):
+        self.patches = dict(patches or {})
+        self.is_sparse = is_sparse
+
+    @classmethod
+    def from_arrays(cls, patches, keypoint_ids, corners, scale):
+        """Same inputs as the reference's FeatureMap(patches, point2D_ids, corners, metadata) numpy
+        constructor (features/src/featuremap.cc:25-61): N x H x W x C patches."""
+        scale = np.broadcast_to(np.asarray(scale, dtype=np.float64), (2,))
+        return cls({int(k): FeaturePatch(p, c, scale) for k, p, c in zip(keypoint_ids, patches, corners)})
+
+    def fpatch(self, keypoint_id):
+        return self.patches[int(keypoint_id)]
+
+    def has_fpatch(self, keypoint_id):
+        return int(keypoint_id) in self.patches
+
+    def keys(self):
+        return list(self.patches.keys())
+
+
+class FeatureSet:
+    """One feature level: image name -> FeatureMap (features/src/featureset.h)."""
+
+    def __init__(self, fmaps=None, channels=None):
+        self.fmaps = dict(fmaps or {})
+        self._channels = channels
+
+    def fmap(self, image_name):
+        return self.fmaps[image_name]
+
+    def has_fmap(self, image_name):
+        return image_name in self.fmaps
+
+    @property
+    def channels(self):
+        if self._channels is None:
+            for fm in self.fmaps.values():
+                for p in fm.patches.values():
+                    return p.shape[2]
+        return self._channels
+
+    def _first_patch(self):
+        for fm in self.fmaps.values():
+            for p in fm.patches.values():
+                return p
+        raise ValueError("empty FeatureSet")
+
+
+class FeatureManager:
+    """features/src/featuremanager.h: one FeatureSet per feature level."""
+
+    def __init__(self, fsets):
+        self.fsets = list(fsets)
+
+    @property
+    def num_levels(self):
+        return len(self.fsets)
+
+    def fset(self, level_index):
+        return self.fsets[level_index]
+
+
+class Reference:
+    """features/src/references.h:29-72 (N_NODES = 1): source observation + 1 x C descriptor."""
+
+    def __init__(self, image_id, point2D_idx, descriptor):
+        self.source = (int(image_id), int(point2D_idx))
+        self.descriptor = np.asarray(descriptor, dtype=np.float64).reshape(1, -1)
+
+
+def to_arena(ctx, patch_list):
+    """Stack FeaturePatch objects (identical H, W, C, dtype) into an HBM arena."""
+    from ..engine import PatchArena
+    if not patch_list:
+        raise ValueError("no patches")
+    shape, dtype = patch_list[0].shape, patch_list[0].data.dtype
+    for p in patch_list:
+        if p.shape != shape or p.data.dtype != dtype:
+            raise ValueError("the accelerated path needs patches of identical shape and dtype "
+                             "(sparse mode, pixsfm/features/extractor.py:33-51)")
+    data = np.stack([p.data for p in patch_list])
+    corners = np.stack([p.corner for p in patch_list])
+    scales = np.stack([p.scale for p in patch_list])
+    return PatchArena.from_numpy(ctx, data, corners, scales)

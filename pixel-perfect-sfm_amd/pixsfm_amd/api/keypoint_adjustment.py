@@ -1,0 +1,296 @@
+"""Mirror of pixsfm's keypoint-adjustment surface for the accelerated path:
+`KeypointAdjuster.create(conf).refine_multilevel(keypoints, feature_manager, graph)`
+(pixsfm/keypoint_adjustment/main.py:60-247) and the `_keypoint_adjustment` pybind classes it
+drives (pixsfm/keypoint_adjustment/bindings.cc:17-81).  Same names, argument meaning and
+defaults; the Ceres/C++ solve is replaced by pxr_ka_solve on the GPU.
+"""
+from copy import deepcopy
+
+import numpy as np
+
+from .. import _lib
+from ..engine import Context, lm_options, make_loss
+from ..ka_engine import KAProblem
+from ..synthetic_ka import find_problem_labels  # noqa: F401  (same algorithm as main.py:13-57)
+from . import base, features
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class KeypointAdjustmentSetup:
+    """keypoint_adjustment/src/keypoint_adjustment_options.h:19-40."""
+
+    def __init__(self):
+        self.constant_images = set()
+        self.constant_keypoints = {}
+
+    def set_image_constant(self, image_id):
+        self.constant_images.add(int(image_id))
+
+    def set_keypoint_constant(self, image_id, feature_idx):
+        self.constant_keypoints.setdefault(int(image_id), set()).add(int(feature_idx))
+
+    def set_keypoints_constant(self, image_id, feature_idxs):
+        for f in feature_idxs:
+            self.set_keypoint_constant(image_id, f)
+
+    def set_node_constant(self, node):
+        self.set_keypoint_constant(node.image_id, node.feature_idx)
+
+    def set_masked_nodes_constant(self, graph, mask):
+        if len(mask) != len(graph.nodes):
+            raise ValueError("mask size does not match the number of graph nodes")
+        for node, m in zip(graph.nodes, mask):
+            if m:
+                self.set_node_constant(node)
+
+    def is_keypoint_constant(self, image_id, feature_idx):
+        return int(image_id) in self.constant_images or \
+            int(feature_idx) in self.constant_keypoints.get(int(image_id), ())
+
+    def is_node_constant(self, node):
+        return self.is_keypoint_constant(node.image_id, node.feature_idx)
+
+
+class Summary:
+    """The ceres::Solver::Summary fields pixsfm reads (util/src/statistics.h:162-217)."""
+
+    def __init__(self, d, num_residuals=0):
+        self.initial_cost, self.final_cost = d["initial_cost"], d["final_cost"]
+        self.num_iterations = d["iterations"]
+        self.num_successful_steps = d["num_successful"]
+        self.termination_type = {0: "CONVERGENCE", 1: "NO_CONVERGENCE", 2: "FAILURE"}[d["termination"]]
+        self.total_time_in_seconds = d["total_ms"] * 1e-3
+        self.num_residuals_reduced = num_residuals
+        self.raw = d
+
+    def BriefReport(self):
+        return "pixsfm_amd: iterations %d, initial cost %e, final cost %e, termination %s" % (
+            self.num_iterations, self.initial_cost, self.final_cost, self.termination_type)
+
+
+def build_edges(graph, keypoints, track_labels, root_labels, nodes_in_problem=None, weight_by_sim=True,
+                root_edges_only=False, root_regularize_weight=-1.0):
+    """TopologicalKeypointOptimizer::SetUp + FeatureMetricKeypointOptimizer::AddIntraResiduals
+    (topological_keypoint_optimizer.h:97-175, featuremetric_keypoint_optimizer.h:158-202).
+    Returns (src, dst, weight) lists of residual blocks, in the reference's insertion order."""
+    nodes = graph.nodes
+    node_ids = range(len(nodes)) if nodes_in_problem is None else nodes_in_problem
+    regularize = root_regularize_weight > 0.0
+    connected_to_root = {}
+    track_root = {}
+    cand = []
+    for i in node_ids:
+        for m in nodes[i].out_matches:
+            j = m.node_idx
+            if track_labels[i] != track_labels[j]:
+                continue                                     # inter-track: TODO in the reference too (:140-142)
+            cand.append((i, j, m.sim))
+            if regularize:
+                for r in (i, j):
+                    if root_labels[r]:
+                        track_root[track_labels[r]] = r
+                        connected_to_root[i] = connected_to_root[j] = True
+    src, dst, w = [], [], []
+
+    def same_keypoint(a, b):                                 # "avoid optimizing a keypoint to itself" (:147-150)
+        na, nb = nodes[a], nodes[b]
+        return na.image_id == nb.image_id and na.feature_idx == nb.feature_idx
+
+    def add(a, b, weight):                                   # AddIntraResiduals
+        if track_labels[a] != track_labels[b]:
+            return
+        if root_edges_only and not root_labels[a] and not root_labels[b]:
+            return
+        src.append(a); dst.append(b); w.append(weight)
+
+    for i, j, sim in cand:
+        if same_keypoint(i, j):
+            continue
+        add(i, j, sim if weight_by_sim else 1.0)
+        if regularize:
+            for k in (i, j):
+                if not connected_to_root.get(k, False):
+                    add(k, track_root[track_labels[k]], root_regularize_weight)
+                    connected_to_root[k] = True
+    return src, dst, w
+
+
+class FeatureMetricKeypointOptimizer:
+    """_keypoint_adjustment.FeatureMetricKeypointOptimizer (bindings.cc:77-81):
+    ctor (options, setup, interpolation_config); run(problem_labels, keypoints, graph, track_labels,
+    root_labels, feature_set) or run(keypoints, graph, track_labels, root_labels, feature_set)."""
+
+    option_defaults = {
+        'loss': {'name': 'cauchy', 'params': [0.25]},
+        'solver': {**base.solver_default_conf, 'parameter_tolerance': 1.0e-4, 'num_threads': 1},
+        'print_summary': True, 'bound': 4.0, 'num_threads': -1,
+        'root_regularize_weight': -1.0, 'weight_by_sim': True, 'root_edges_only': False,
+    }
+
+    def __init__(self, options=None, setup=None, interpolation_config=None, ctx=None):
+        self.options = base.merge_conf(self.option_defaults, options)
+        self.setup = setup if setup is not None else KeypointAdjustmentSetup()
+        ic = interpolation_config
+        self.interpolation = ic if isinstance(ic, base.InterpolationConfig) else base.InterpolationConfig(ic)
+        self.ctx = ctx
+        self._summary = None
+        self._used = False
+
+    def _run(self, problem_labels, keypoints, graph, track_labels, root_labels, feature_set):
+        if keypoints is None:
+            raise ValueError("keypoints cannot be NULL.")                       # topological_keypoint_optimizer.h:73-74
+        if self._used:
+            raise ValueError("Cannot use the same KeypointOptimizer multiple times")   # :75-77
+        self._used = True
+        n = len(graph.nodes)
+        if len(track_labels) != n or len(root_labels) != n or (problem_labels is not None and len(problem_labels) != n):
+            raise ValueError("label arrays must have one entry per graph node")  # THROW_CHECK_EQ, featuremetric_keypoint_optimizer.h:82-85
+        ctx = self.ctx or default_context()
+        o = self.options
+        src, dst, w = build_edges(graph, keypoints, track_labels, root_labels, None, o['weight_by_sim'],
+                                  o['root_edges_only'], o['root_regularize_weight'])
+        names = [graph.image_id_to_name[nd.image_id] for nd in graph.nodes]
+        kp = np.array([keypoints[nm][nd.feature_idx] for nm, nd in zip(names, graph.nodes)], dtype=np.float64).reshape(-1, 2)
+        patches = [feature_set.fmap(nm).fpatch(nd.feature_idx) for nm, nd in zip(names, graph.nodes)]
+        arena = features.to_arena(ctx, patches)
+        labels = np.zeros(n, np.int32) if problem_labels is None else np.asarray(problem_labels, dtype=np.int32)
+        prob = dict(kp=kp, node_patch=np.arange(n, dtype=np.int64),
+                    node_const=np.array([self.setup.is_node_constant(nd) for nd in graph.nodes], np.uint8),
+                    node_problem=labels, edge_src=np.array(src, np.int32), edge_dst=np.array(dst, np.int32),
+                    edge_w=np.array(w, np.float64))
+        ka = KAProblem(ctx, arena, prob)
+        s = o['solver']
+        lm = lm_options(max_iterations=s['max_num_iterations'], function_tolerance=s['function_tolerance'],
+                        gradient_tolerance=s['gradient_tolerance'], parameter_tolerance=s['parameter_tolerance'],
+                        max_consecutive_invalid_steps=s['max_num_consecutive_invalid_steps'])
+        total, _ = ka.solve(self.interpolation.to_engine(), make_loss(o['loss']['name'], o['loss']['params']),
+                            bound=o['bound'], options=lm)
+        out = ka.keypoints()
+        for nm, nd, xy in zip(names, graph.nodes, out):       # in place, like featuremetric_keypoint_optimizer.h:195-196
+            keypoints[nm][nd.feature_idx] = xy
+        self._summary = Summary(total, num_residuals=len(src) * arena.C)
+        arena.close()
+        return True
+
+    def run(self, *args):
+        if len(args) == 6:
+            return self._run(*args)
+        if len(args) == 5:
+            return self._run(None, *args)
+        raise TypeError("run(problem_labels, keypoints, graph, track_labels, root_labels, feature_set) or "
+                        "run(keypoints, graph, track_labels, root_labels, feature_set)")
+
+    def summary(self):
+        return self._summary
+
+
+class TopologicalReferenceKeypointOptimizer(FeatureMetricKeypointOptimizer):
+    """Option preset (topological_reference_keypoint_optimizer.h:8-15): star graph to the root."""
+
+    def __init__(self, options=None, setup=None, interpolation_config=None, ctx=None):
+        options = dict(options or {})
+        options.update(weight_by_sim=False, root_regularize_weight=1.0, root_edges_only=True)
+        super().__init__(options, setup, interpolation_config, ctx)
+
+
+class KeypointAdjuster:
+    """pixsfm/keypoint_adjustment/main.py:60-137."""
+    default_conf = {
+        'strategy': 'featuremetric',
+        'apply': True,
+        'interpolation': base.interpolation_default_conf,
+        'level_indices': None,
+        'max_kps_per_problem': 50,
+        'optimizer': {
+            'loss': {'name': 'cauchy', 'params': [0.25]},
+            'solver': {**base.solver_default_conf, 'parameter_tolerance': 1.0e-5, 'num_threads': 1},
+            'print_summary': False,
+            'bound': 4.0,
+            'num_threads': -1,
+        },
+        'split_in_subproblems': True,
+    }
+
+    @classmethod
+    def create(cls, conf):
+        strategy_to_solver = {"featuremetric": FeatureMetricKeypointAdjuster,
+                              "topological_reference": TopologicalReferenceKeypointAdjuster}
+        strategy = conf["strategy"] if "strategy" in conf else cls.default_conf["strategy"]
+        return strategy_to_solver[strategy](conf)
+
+    def refine(self, keypoints_dict, feature_set, graph, track_labels, root_labels, problem_setup=None):
+        raise NotImplementedError
+
+    def refine_multilevel(self, keypoints_dict, feature_manager, graph, track_labels=None, root_labels=None,
+                          problem_setup=None):
+        if track_labels is None:
+            track_labels = base.compute_track_labels(graph)
+        if root_labels is None:
+            score_labels = base.compute_score_labels(graph, track_labels)
+            root_labels = base.compute_root_labels(graph, track_labels, score_labels)
+        levels = self.conf['level_indices'] if self.conf['level_indices'] not in [None, "all"] else \
+            list(reversed(range(feature_manager.num_levels)))
+        outputs = {}
+        for level_index in levels:
+            out = self.refine(keypoints_dict, feature_manager.fset(level_index), graph, track_labels, root_labels,
+                              problem_setup=problem_setup)
+            for k, v in out.items():
+                outputs.setdefault(k, []).append(v)
+        return outputs
+
+    _solver_cls = None
+
+    def _refine(self, keypoints_dict, feature_set, graph, track_labels, root_labels, problem_setup):
+        if problem_setup is None:
+            problem_setup = KeypointAdjustmentSetup()
+            problem_setup.set_masked_nodes_constant(graph, root_labels)          # main.py:175-177
+        solver = self._solver_cls(deepcopy(self.conf['optimizer']), problem_setup, self.conf['interpolation'])
+        if self.conf['split_in_subproblems']:
+            problem_labels, _ = find_problem_labels(track_labels, self.conf['max_kps_per_problem'])
+            solver.run(problem_labels, keypoints_dict, graph, track_labels, root_labels, feature_set)
+        else:
+            solver.run(keypoints_dict, graph, track_labels, root_labels, feature_set)
+        return {"summary": solver.summary()}
+
+
+class FeatureMetricKeypointAdjuster(KeypointAdjuster):
+    """main.py:140-203."""
+    default_conf = deepcopy(KeypointAdjuster.default_conf)
+    default_conf["optimizer"] = {**default_conf["optimizer"], "root_regularize_weight": -1, "weight_by_sim": True,
+                                 "root_edges_only": False, "num_threads": -1}
+    _solver_cls = FeatureMetricKeypointOptimizer
+
+    def __init__(self, conf):
+        self.conf = base.merge_conf(self.default_conf, conf)
+
+    def refine(self, keypoints_dict, feature_set, graph, track_labels, root_labels, problem_setup=None):
+        return self._refine(keypoints_dict, feature_set, graph, track_labels, root_labels, problem_setup)
+
+
+class TopologicalReferenceKeypointAdjuster(KeypointAdjuster):
+    """main.py:206-247."""
+    default_conf = deepcopy(KeypointAdjuster.default_conf)
+    default_conf["optimizer"] = {**default_conf["optimizer"], "num_threads": -1}
+    _solver_cls = TopologicalReferenceKeypointOptimizer
+
+    def __init__(self, conf):
+        self.conf = base.merge_conf(self.default_conf, conf)
+
+    def refine(self, keypoints_dict, feature_set, graph, track_labels, root_labels, problem_setup=None):
+        return self._refine(keypoints_dict, feature_set, graph, track_labels, root_labels, problem_setup)
+
+
+def build_matching_graph(pairs, matches, scores=None):          # main.py:250-260
+    graph = base.Graph()
+    scores = scores if scores is not None else [None for _ in matches]
+    for (name1, name2), m, s in zip(pairs, matches, scores):
+        graph.register_matches(name1, name2, m, s)
+    return graph

@@ -1,0 +1,121 @@
+"""CPU: host-side logic of the pixsfm-compatible API (no GPU calls): graph labelling
+(base/src/graph.cc:126-256), edge enumeration (topological_keypoint_optimizer.h:97-175),
+BA problem flattening + parameterisation (bundle_optimizer.h:139-165,247-453), setups, confs."""
+import numpy as np
+import pytest
+
+from pixsfm_amd import synthetic
+from pixsfm_amd.api import base, features
+from pixsfm_amd.api.bundle_adjustment import (BundleAdjuster, BundleAdjustmentSetup, FeatureView, _FlatBA,
+                                              default_problem_setup, find_problem_labels)
+from pixsfm_amd.api.keypoint_adjustment import (KeypointAdjuster, KeypointAdjustmentSetup, build_edges,
+                                                build_matching_graph)
+from pixsfm_amd.api.reconstruction import reconstruction_from_flat
+
+
+def _toy_graph():
+    # three images, two physical tracks; a conflicting weak match tries to pull two keypoints of
+    # image "a" into one track and must be rejected by the one-feature-per-image rule
+    pairs = [("a", "b"), ("b", "c"), ("a", "c"), ("a", "b")]
+    matches = [np.array([[0, 0], [1, 1]]), np.array([[0, 0], [1, 1]]), np.array([[0, 0]]), np.array([[1, 0]])]
+    scores = [np.array([0.9, 0.8]), np.array([0.7, 0.95]), np.array([0.6]), np.array([0.1])]
+    return build_matching_graph(pairs, matches, scores)
+
+
+def test_graph_and_labels():
+    g = _toy_graph()
+    assert len(g.nodes) == 6 and g.image_name_to_id == {"a": 0, "b": 1, "c": 2}
+    labels = base.compute_track_labels(g)
+    key = {(g.image_id_to_name[n.image_id], n.feature_idx): labels[n.node_idx] for n in g.nodes}
+    assert key[("a", 0)] == key[("b", 0)] == key[("c", 0)]
+    assert key[("a", 1)] == key[("b", 1)] == key[("c", 1)] != key[("a", 0)]
+    for t in set(labels):                                       # never two features of one image in a track
+        imgs = [g.nodes[i].image_id for i in range(6) if labels[i] == t]
+        assert len(imgs) == len(set(imgs))
+    scores = base.compute_score_labels(g, labels)
+    roots = base.compute_root_labels(g, labels, scores)
+    assert sum(roots) == 2
+    for t in set(labels):
+        ids = [i for i in range(6) if labels[i] == t]
+        assert roots[max(ids, key=lambda i: scores[i])]
+
+
+def test_build_edges_variants():
+    g = _toy_graph()
+    labels = base.compute_track_labels(g)
+    roots = base.compute_root_labels(g, labels, base.compute_score_labels(g, labels))
+    kps = {"a": np.zeros((2, 2)), "b": np.zeros((2, 2)), "c": np.zeros((2, 2))}
+    src, dst, w = build_edges(g, kps, labels, roots)
+    want = [(n.node_idx, m.node_idx, m.sim) for n in g.nodes for m in n.out_matches if labels[n.node_idx] == labels[m.node_idx]]
+    assert list(zip(src, dst, w)) == want and len(want) == 5      # the conflicting a1-b0 match is inter-track
+    _, _, w1 = build_edges(g, kps, labels, roots, weight_by_sim=False)
+    assert set(w1) == {1.0}
+    s2, d2, _ = build_edges(g, kps, labels, roots, root_edges_only=True)
+    assert all(roots[a] or roots[b] for a, b in zip(s2, d2)) and len(s2) < len(src)
+    # topological_reference preset: star to the root, missing root edges are added with weight 1
+    s3, d3, w3 = build_edges(g, kps, labels, roots, weight_by_sim=False, root_edges_only=True, root_regularize_weight=1.0)
+    for t in set(labels):
+        ids = {i for i in range(6) if labels[i] == t}
+        r = [i for i in ids if roots[i]][0]
+        touched = {a for a, b in zip(s3, d3) if b == r or a == r} | {b for a, b in zip(s3, d3) if a == r or b == r}
+        assert ids <= touched
+
+
+def test_keypoint_setup_and_confs():
+    g = _toy_graph()
+    s = KeypointAdjustmentSetup()
+    s.set_masked_nodes_constant(g, [True, False, False, False, False, True])
+    assert s.is_node_constant(g.nodes[0]) and not s.is_node_constant(g.nodes[1])
+    s.set_image_constant(1)
+    assert all(s.is_node_constant(n) for n in g.nodes if n.image_id == 1)
+    with pytest.raises(ValueError):
+        s.set_masked_nodes_constant(g, [True])
+    adj = KeypointAdjuster.create({"strategy": "topological_reference", "optimizer": {"bound": 2.0}})
+    assert adj.conf["optimizer"]["bound"] == 2.0 and adj.conf["max_kps_per_problem"] == 50
+    assert adj.conf["optimizer"]["solver"]["parameter_tolerance"] == 1e-5
+    with pytest.raises(ValueError):
+        KeypointAdjuster.create({"optimizer": {"no_such_option": 1}})
+    with pytest.raises(ValueError):
+        BundleAdjuster.create({"strategy": "costmaps"})
+    ba = BundleAdjuster.create({})
+    assert ba.conf["optimizer"]["solver"]["use_inner_iterations"] is True and ba.conf["references"]["iters"] == 100
+
+
+def _fset(prob, rec, patch_of):
+    fmaps = {}
+    for (image_id, p2d), pi in patch_of.items():
+        fm = fmaps.setdefault(rec.images[image_id].name, features.FeatureMap())
+        fm.patches[p2d] = features.FeaturePatch(prob["patches"][pi], prob["corners"][pi], prob["scales"][pi])
+    return features.FeatureSet(fmaps)
+
+
+def test_flat_ba_matches_reference_parameterisation():
+    prob = synthetic.make_ba_problem(n_cams=5, n_points=20, obs_per_point=3, seed=4, channels=8, patch_size=8, model=3)
+    rec, patch_of = reconstruction_from_flat(prob)
+    fset = _fset(prob, rec, patch_of)
+    setup = default_problem_setup(rec)
+    assert setup.has_constant_pose(1) and setup.constant_tvec(2) == [0]
+    flat = _FlatBA(rec, setup, FeatureView(fset, rec), {"refine_principal_point": False})
+    assert len(flat.obs_image) == 60 and sorted(flat.point_ids) == list(range(1, 21))
+    assert flat.pose_const.tolist() == [1, 0, 0, 0, 0] and flat.tvec_mask.tolist() == [0, 1, 0, 0, 0]
+    assert set(flat.cam_mask.tolist()) == {0b00110}              # RADIAL: cx, cy constant; f, k1, k2 refined
+    assert not flat.point_const.any()
+    # an image left out of the setup: its observations disappear, the affected points become constant
+    setup2 = BundleAdjustmentSetup()
+    setup2.add_images([1, 2, 3, 4])
+    setup2.set_constant_pose(1)
+    flat2 = _FlatBA(rec, setup2, FeatureView(fset, rec), {})
+    touched = {int(p) + 1 for p in prob["obs_point"][prob["obs_image"] == 4]}
+    const_ids = {pid for pid, c in zip(flat2.point_ids, flat2.point_const) if c}
+    assert const_ids == touched & set(flat2.point_ids)
+    # ... unless they are added as variable points: then the outside observations come back with a constant pose
+    for pid in touched:
+        setup2.add_variable_point(pid)
+    flat3 = _FlatBA(rec, setup2, FeatureView(fset, rec), {})
+    assert len(flat3.obs_image) == 60 and not flat3.point_const.any()
+    k5 = flat3.image_ids.index(5)
+    assert flat3.pose_const[k5] == 1 and flat3.cam_mask[flat3.camera_ids.index(rec.images[5].camera_id)] == 0b11111
+    with pytest.raises(ValueError):
+        setup2.set_constant_tvec(1, [0])                          # already constant pose
+    labels = find_problem_labels(rec, 10)
+    assert labels[0] == -1 and labels[1] == 0 and labels[20] == 2

@@ -1,0 +1,110 @@
+"""GPU: the pixsfm-compatible API end to end, written the way a pixsfm user would call it
+(keypoint_adjustment/main.py:85-137, bundle_adjustment/main.py:65-154), checked against the
+low-level engine / oracle on the same inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ka_inputs(seed=3, n_tracks=12, track_len=5):
+    """A pixsfm-style KA input: keypoints per image, a match graph, one patch per keypoint."""
+    from pixsfm_amd import synthetic_ka
+    from pixsfm_amd.api import features
+    from pixsfm_amd.api.keypoint_adjustment import build_matching_graph
+    prob = synthetic_ka.make_ka_problem(n_tracks=n_tracks, track_len=track_len, seed=seed, directed_both=False)
+    # node (t, k) lives in image k with keypoint index t
+    n = n_tracks * track_len
+    img = np.arange(n) % track_len
+    kid = np.arange(n) // track_len
+    names = ["im%d" % k for k in range(track_len)]
+    keypoints = {names[k]: prob["kp"][img == k].copy() for k in range(track_len)}
+    pairs, matches, scores = [], [], []
+    for a in range(track_len):
+        for b in range(a + 1, track_len):
+            sel = (img[prob["edge_src"]] == a) & (img[prob["edge_dst"]] == b)
+            pairs.append((names[a], names[b]))
+            matches.append(np.stack([kid[prob["edge_src"][sel]], kid[prob["edge_dst"][sel]]], 1))
+            scores.append(prob["edge_w"][sel])
+    graph = build_matching_graph(pairs, matches, scores)
+    fmaps = {names[k]: features.FeatureMap.from_arrays(prob["patches"][img == k], kid[img == k],
+                                                       prob["corners"][img == k], (1.0, 1.0)) for k in range(track_len)}
+    return prob, keypoints, graph, features.FeatureManager([features.FeatureSet(fmaps)]), (img, kid, names)
+
+
+def test_keypoint_adjuster_like_pixsfm(ctx):
+    import pxo
+    import pxo_ka
+    from pixsfm_amd.api import KeypointAdjuster, base
+    prob, keypoints, graph, fmanager, (img, kid, names) = _ka_inputs()
+    adjuster = KeypointAdjuster.create({"strategy": "featuremetric"})
+    out = adjuster.refine_multilevel(keypoints, fmanager, graph)
+    summary = out["summary"][0]
+    assert summary.final_cost < 0.05 * summary.initial_cost and summary.termination_type == "CONVERGENCE"
+    # same problem through the oracle: graph order differs from the synthetic node order, so rebuild from the graph
+    labels = base.compute_track_labels(graph)
+    roots = base.compute_root_labels(graph, labels, base.compute_score_labels(graph, labels))
+    from pixsfm_amd.api.keypoint_adjustment import build_edges, find_problem_labels
+    src, dst, w = build_edges(graph, keypoints, labels, roots)
+    node_of = [int(np.nonzero((img == n.image_id) & (kid == n.feature_idx))[0][0]) for n in graph.nodes]
+    plabels, _ = find_problem_labels(labels, 50)
+    oprob = dict(kp=prob["kp"][node_of], node_patch=np.arange(len(node_of), dtype=np.int64),
+                 node_const=np.array(roots, np.uint8), node_problem=np.array(plabels, np.int32),
+                 edge_src=np.array(src, np.int32), edge_dst=np.array(dst, np.int32), edge_w=np.array(w),
+                 patches=prob["patches"][node_of], corners=prob["corners"][node_of], scales=prob["scales"][node_of])
+    kpo, _ = pxo_ka.ka_solve(oprob, pxo.cfg(), pxo.loss("cauchy", 0.25), 4.0, pxo.lm_options(parameter_tolerance=1e-5))
+    got = np.array([keypoints[names[n.image_id]][n.feature_idx] for n in graph.nodes])
+    assert np.abs(got - kpo).max() < 1e-6
+    # an optimizer object is single-use (topological_keypoint_optimizer.h:75-77)
+    from pixsfm_amd.api import FeatureMetricKeypointOptimizer, KeypointAdjustmentSetup
+    opt = FeatureMetricKeypointOptimizer({}, KeypointAdjustmentSetup(), {})
+    opt.run(keypoints, graph, labels, roots, fmanager.fset(0))
+    with pytest.raises(ValueError):
+        opt.run(keypoints, graph, labels, roots, fmanager.fset(0))
+
+
+def test_topological_reference_adjuster(ctx):
+    from pixsfm_amd.api import KeypointAdjuster
+    prob, keypoints, graph, fmanager, _ = _ka_inputs(seed=8)
+    before = {k: v.copy() for k, v in keypoints.items()}
+    out = KeypointAdjuster.create({"strategy": "topological_reference"}).refine_multilevel(keypoints, fmanager, graph)
+    s = out["summary"][0]
+    assert s.final_cost < 0.1 * s.initial_cost
+    assert any(np.abs(keypoints[k] - before[k]).max() > 0.1 for k in keypoints)
+
+
+def test_bundle_adjuster_like_pixsfm(ctx):
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.api import BundleAdjuster, features
+    from pixsfm_amd.api.reconstruction import reconstruction_from_flat
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    prob = synthetic.make_ba_problem(n_cams=6, n_points=70, obs_per_point=4, seed=17, noise=0.05)
+    rec, patch_of = reconstruction_from_flat(prob)
+    fmaps = {}
+    for (image_id, p2d), pi in patch_of.items():
+        fm = fmaps.setdefault(rec.images[image_id].name, features.FeatureMap())
+        fm.patches[p2d] = features.FeaturePatch(prob["patches"][pi], prob["corners"][pi], prob["scales"][pi])
+    fmanager = features.FeatureManager([features.FeatureSet(fmaps)])
+    conf = {"optimizer": {"solver": {"max_num_iterations": 8}}}
+    out = BundleAdjuster.create(conf).refine_multilevel(rec, fmanager)
+    summary, references = out["summary"][0], out["references"][0]
+    # (per-image feature noise + references taken at the perturbed projections leave a cost floor)
+    assert len(references) == 70 and summary.final_cost < 0.5 * summary.initial_cost
+    # the same thing through the low-level engine: references by the GPU extractor, default gauge
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    ba.compute_references(interp_cfg(), make_loss("cauchy", [0.25]), iters=100)
+    n_img = 6
+    pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
+    tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
+    s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), pose_const, tmask, np.full(n_img, 0b0110, np.uint16),
+                 np.zeros(70, np.uint8), options=lm_options(max_iterations=8))
+    q, t, k, X = ba.params()
+    assert abs(s["final_cost"] - summary.final_cost) < 1e-8 * max(s["final_cost"], 1e-12)
+    assert np.abs(np.array([rec.images[i + 1].qvec for i in range(n_img)]) - q).max() < 1e-9   # obs order differs -> summation order
+    assert np.abs(np.array([rec.points3D[p + 1].xyz for p in range(70)]) - X).max() < 1e-9
+    assert np.abs(rec.cameras[1].params - k[0, :4]).max() < 1e-9 * 1200
+    # reference source is one of the point's own observations (references.h:29-72)
+    for pid, ref in references.items():
+        assert ref.source in [(e.image_id, e.point2D_idx) for e in rec.points3D[pid].track.elements]
+        assert abs(np.linalg.norm(ref.descriptor) - 1) < 1e-12

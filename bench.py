@@ -83,9 +83,14 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
-    if world > 1:
+    # PXR_BENCH_FORCE_DIST=1 exercises the RCCL code path with a single rank (used to validate the
+    # all-reduce plumbing on a 1-GPU box)
+    dist_on = world > 1 or os.environ.get("PXR_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29531"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
 
     from pixsfm_amd import synthetic_gpu
     from pixsfm_amd.engine import BAProblem, Context, PatchArena, interp_cfg, make_loss
@@ -104,7 +109,7 @@ def main():
     cfg = interp_cfg(use_float_simd=args.float_simd)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -118,7 +123,7 @@ def main():
     kernel_ms = ctx.timer_stop() / args.steps            # HIP events on the launch stream
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
@@ -145,7 +150,7 @@ def main():
         t1 = time.perf_counter()
         lm = ba.solve(cfg, make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,
                       options=lm_options(max_iterations=args.lm_iters),
-                      allreduce=make_allreduce() if world > 1 else None)
+                      allreduce=make_allreduce() if dist_on else None)
         barrier()
         lm["wall_s"] = time.perf_counter() - t1
 
@@ -193,7 +198,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(prob, patches, args.cpu_sample)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

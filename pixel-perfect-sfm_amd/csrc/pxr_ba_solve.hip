@@ -50,6 +50,7 @@ struct SolveDev {          // device-side problem description shared by the kern
   const double* scale_c;   // [n_c]   Jacobi scaling, camera side
   const double* scale_p;   // [n_points][3]
   int n_c; int DC; int LS; // reduced system size, max camera-side columns, Lrec stride
+  int ldS;                 // leading dimension of the reduced system buffer: n_c + 1 (rhs = last column)
 };
 
 // ---- K_jac ------------------------------------------------------------------------------------
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void k_schur(const SolveDev d, const int64_t* 
   const double* Yi = Y + ((size_t)i * d.DC + a) * 3;
   const double y0 = Yi[0], y1 = Yi[1], y2 = Yi[2];
   const int r = col_index(d, img, cam, a);
-  atomicAdd(rhs + r, -(y0 * gp[3 * (size_t)pt] + y1 * gp[3 * (size_t)pt + 1] + y2 * gp[3 * (size_t)pt + 2]));
+  atomicAdd(rhs + (size_t)r * d.ldS, -(y0 * gp[3 * (size_t)pt] + y1 * gp[3 * (size_t)pt + 1] + y2 * gp[3 * (size_t)pt + 2]));
   for (int64_t o = pt_ptr[pt]; o < pt_ptr[pt + 1]; ++o) {
     const int64_t j = pt_obs[o];
     const int imgj = d.v.d_obs_image[j], camj = d.v.d_image_camera[imgj];
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void k_schur(const SolveDev d, const int64_t* 
     for (int b = 0; b < dcj; ++b) {
       const int c = col_index(d, imgj, camj, b);
       if (r > c) continue;   // upper triangle only: the mirrored entry comes from the ordered pair (j, i)
-      atomicAdd(S + (size_t)r * d.n_c + c, -(y0 * Wj[3 * b] + y1 * Wj[3 * b + 1] + y2 * Wj[3 * b + 2]));
+      atomicAdd(S + (size_t)r * d.ldS + c, -(y0 * Wj[3 * b] + y1 * Wj[3 * b + 1] + y2 * Wj[3 * b + 2]));
     }
   }
 }
@@ -339,23 +340,30 @@ __global__ __launch_bounds__(1024) void k_schur_lds(const SolveDev d, const ImgC
   for (int e = threadIdx.x; e < dci * CT; e += blockDim.x) {
     const int a = e / CT, cl = e % CT;
     const double v = acc[(size_t)a * CT + cl];
-    if (v != 0.0) atomicAdd(S + (size_t)col_index(d, img, cam, a) * d.n_c + (c0 + cl), v);
+    if (v != 0.0) atomicAdd(S + (size_t)col_index(d, img, cam, a) * d.ldS + (c0 + cl), v);
   }
   if (blockIdx.y == 0 && threadIdx.x < dci) {
     const double v = racc[threadIdx.x];
-    if (v != 0.0) atomicAdd(rhs + col_index(d, img, cam, threadIdx.x), v);
+    if (v != 0.0) atomicAdd(rhs + (size_t)col_index(d, img, cam, threadIdx.x) * d.ldS, v);
   }
 }
 
 // ---- small vector kernels --------------------------------------------------------------------------
+// S is n x (n + 1) row-major (column n = right-hand side).  add_u = 1: S <- [upper(U) | 0];
+// add_u = 0: S += diag(damp) / radius and rhs += gc (after the all-reduce).
 __global__ void k_copy_upper_add_diag(int n, const double* __restrict__ U, const double* __restrict__ damp,
-                                      double inv_radius, double* __restrict__ S, int add_u) {
+                                      double inv_radius, const double* __restrict__ gc, double* __restrict__ S,
+                                      int add_u) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)n * n) return;
-  const int r = (int)(t / n), c = (int)(t % n);
+  const int ld = n + 1;
+  if (t >= (int64_t)n * ld) return;
+  const int r = (int)(t / ld), c = (int)(t % ld);
   double v = S[t];
-  if (add_u) v = (r <= c) ? U[t] : 0.0;
-  if (damp && r == c) v += damp[r] * inv_radius;
+  if (add_u) v = (c < n && r <= c) ? U[(size_t)r * n + c] : 0.0;
+  else {
+    if (r == c) v += damp[r] * inv_radius;
+    if (c == n) v += gc[r];
+  }
   S[t] = v;
 }
 
@@ -571,8 +579,9 @@ struct DevBuf {
   ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
-int chol_factor(hipStream_t st, double* a, int n, int lda, int* d_info);   // pxr_chol.hip
-int chol_solve(hipStream_t st, const double* a, int n, int lda, double* b);
+// pxr_chol.hip: factor the n x n SPD system stored row-major (upper) in the n x (n + 1) buffer `a` whose last
+// column is the right-hand side (forward substitution is fused into the factorisation), then back-substitute.
+int chol_factor_solve(hipStream_t st, double* a, int n, int* d_info, double* linv_ws, double* x_out);
 
 static inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 
@@ -680,13 +689,17 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   RC(L.alloc((size_t)n_obs * LS)); RC(V.alloc((size_t)n_pts * 6)); RC(gp.alloc((size_t)n_pts * 3));
   RC(Vd0.alloc((size_t)n_pts * 3)); RC(T.alloc((size_t)n_pts * 6));
   RC(W.alloc((size_t)n_obs * DC * 3)); RC(Y.alloc((size_t)n_obs * DC * 3));
-  RC(U.alloc(nc1 * nc1)); RC(S.alloc(nc1 * nc1 + nc1)); RC(gcd.alloc(2 * nc1)); RC(damp_c.alloc(nc1));
+  // S: n_c x (n_c + 1) [S | rhs] + one spare row for the factorisation
+  RC(U.alloc(nc1 * nc1)); RC(S.alloc((nc1 + 1) * (nc1 + 1))); RC(gcd.alloc(2 * nc1)); RC(damp_c.alloc(nc1));
   RC(scale_c.alloc(nc1)); RC(scale_p.alloc((size_t)n_pts * 3)); RC(delta_c.alloc(nc1)); RC(delta_p.alloc((size_t)n_pts * 3));
   RC(rec_a.alloc((size_t)n_obs * PXR_OBS_REC)); RC(rec_b.alloc((size_t)n_obs * PXR_OBS_REC));
   RC(q1.alloc((size_t)n_img * 4)); RC(t1.alloc((size_t)n_img * 3)); RC(k1.alloc((size_t)n_cam * PXR_KPAD)); RC(X1.alloc((size_t)n_pts * 3));
   RC(scal.alloc(16));   // [0..7] summed over ranks, [8..15] replicated
   double* scal_sum = scal.p; double* scal_rep = scal.p + 8;
-  double* rhs = S.p + nc1 * nc1;
+  const int ldS = n_c + 1;
+  double* rhs = S.p + n_c;          // column n_c of S, stride ldS
+  DevBuf<double> xsol, linv;
+  RC(xsol.alloc(nc1)); RC(linv.alloc((size_t)((n_c + 63) / 64 + 1) * 64 * 64));
   double* diagU = gcd.p; double* gc = gcd.p + nc1;
   DevBuf<int> info_buf;
   RC(info_buf.alloc(1));
@@ -700,7 +713,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   dv.v = *view;
   dv.pose_off = d_pose_off.p; dv.pose_dim = d_pose_dim.p; dv.tmask = d_tmask.p;
   dv.intr_off = d_intr_off.p; dv.intr_dim = d_intr_dim.p; dv.cmask = d_cmask.p; dv.pt_var = d_pt_var.p;
-  dv.scale_c = scale_c.p; dv.scale_p = scale_p.p; dv.n_c = n_c; dv.DC = DC; dv.LS = LS;
+  dv.scale_c = scale_c.p; dv.scale_p = scale_p.p; dv.n_c = n_c; dv.DC = DC; dv.LS = LS; dv.ldS = ldS;
   pxr_ba_view cand_view = *view;
   cand_view.d_qvec = q1.p; cand_view.d_tvec = t1.p; cand_view.d_cam_params = k1.p; cand_view.d_xyz = X1.p;
 
@@ -802,8 +815,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     bool ok = true;
     if (n_c > 0) {
       hipLaunchKernelGGL(k_wy, dim3(nblk(n_obs)), dim3(256), 0, st, dv, L.p, T.p, W.p, Y.p);
-      hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * n_c)), dim3(256), 0, st, n_c, U.p, (const double*)nullptr, 0.0, S.p, 1);
-      PXR_HIP(hipMemsetAsync(rhs, 0, sizeof(double) * n_c, st));
+      hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, n_c, U.p, (const double*)nullptr, 0.0, (const double*)nullptr, S.p, 1);
       if (use_lds_schur) {
         hipLaunchKernelGGL(k_schur_lds, dim3((unsigned)schur_chunks.size(), (unsigned)n_ctiles), dim3(1024), schur_shmem, st, dv,
                            d_schur_chunks.p, d_obs_cols.p, d_img_obs.p, d_pt_ptr.p, d_pt_obs.p, W.p, Y.p, gp.p, CT, S.p, rhs);
@@ -812,17 +824,15 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       }
       LAUNCH_CHECK("schur kernels");
       phase(0);
-      RC(ar(S.p, (int64_t)nc1 * nc1 + n_c));
+      RC(ar(S.p, (int64_t)n_c * ldS));
       phase(1);          // sum of U_local - Schur_local and of -Y g_p
       // rhs += g_c (global), S += D_c / radius
-      hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * n_c)), dim3(256), 0, st, n_c, U.p, damp_c.p, inv_radius, S.p, 0);
-      hipLaunchKernelGGL(k_axpy1, dim3(nblk(n_c)), dim3(256), 0, st, n_c, gc, rhs);
+      hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, n_c, U.p, damp_c.p, inv_radius, gc, S.p, 0);
       // row-major upper == column-major lower; the pivot check is read back with the scalars of
       // this attempt (no extra host synchronisation): a failed factorisation = invalid step.
-      RC(chol_factor(st, S.p, n_c, n_c, d_info));
+      RC(chol_factor_solve(st, S.p, n_c, d_info, linv.p, xsol.p));
       phase(2);
-      RC(chol_solve(st, S.p, n_c, n_c, rhs));
-      hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, rhs, gc, damp_c.p, inv_radius, delta_c.p, scal_rep);
+      hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, xsol.p, gc, damp_c.p, inv_radius, delta_c.p, scal_rep);
     }
     phase(3);
     double model_cost_change = 0, cand_cost = 0, step_norm = 0, x_norm = 0;

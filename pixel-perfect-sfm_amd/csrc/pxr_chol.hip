@@ -1,19 +1,20 @@
-// pxr_chol.hip -- dense fp64 Cholesky factorisation + solve of the reduced camera system on
-// gfx950, written for the LM loop of pxr_ba_solve: no host synchronisation, no workspace
-// allocation, a fixed short chain of launches (the library path -- rocSOLVER potrf/potrs --
-// cost 24 ms + 8 ms of host-side overhead per call at n = 1593 for ~4 ms of kernels).
+// pxr_chol.hip -- dense fp64 Cholesky solve of the reduced camera system on gfx950, written for
+// the LM loop of pxr_ba_solve: no host synchronisation, no workspace allocation, a fixed short
+// chain of launches (the library path -- rocSOLVER potrf/potrs -- cost 24 ms + 8 ms of host-side
+// overhead per call at n = 1593 for ~4 ms of kernels).
 //
-// Storage: the reduced system S is built row-major with only its UPPER triangle filled, which
-// is the column-major LOWER triangle of the same buffer: A(i,j) = a[i + j*lda], i >= j.
-// Right-looking blocked algorithm, NB = 64:
-//   k_chol_panel  WG 0 factors the 64x64 diagonal block in LDS and writes it back; WG b >= 1
-//                 factors it redundantly (cheaper than a launch boundary) and solves
-//                 X L_kk^T = A(rows, k:k+NB) for its 128 rows as a small LDS-tiled GEMM with the
-//                 explicit inverse of the triangular block (8x4 register micro-tiles).
-//   k_chol_syrk   trailing update A22 -= P P^T on 64x64 tiles (lower tiles only), 4x4
-//                 register micro-tiles, both panel tiles staged through LDS.
-//   k_chol_solve  forward + backward substitution for one right-hand side by a single
-//                 workgroup (the vector lives in LDS, the factor streams from L2).
+// Storage: the system is built row-major as the n x (n + 1) matrix [S | rhs] with only the UPPER
+// triangle of S filled.  Read column-major with leading dimension ld = n + 1 this is the LOWER
+// triangle A(i,j) = a[i + j*ld], i >= j, plus one extra ROW i = n holding the right-hand side:
+// a right-looking Cholesky that treats row n like any other sub-diagonal row performs the forward
+// substitution L y = b for free (row n of the factor is y^T).
+//   k_chol_panel   every workgroup factors the 64x64 diagonal block AND inverts its triangular
+//                  factor in one 64-step sweep on 4x4 register tiles (one barrier per step);
+//                  WG 0 writes L_kk and inv(L_kk) back, WG b >= 1 computes its 128 panel rows
+//                  X = B inv(L_kk)^T as an LDS-tiled GEMM (8x4 register micro-tiles).
+//   k_chol_syrk    trailing update A22 -= P P^T on 64x64 tiles (lower tiles only).
+//   k_chol_backsolve  L^T x = y right-looking by one workgroup: x_k = inv(L_kk)^T z_k (mat-vec with the
+//                  stored block inverse), then z_c -= L(k-block, c)^T x_k, one thread per column c.
 #include <hip/hip_runtime.h>
 
 #include "pxr_internal.h"
@@ -21,79 +22,124 @@
 namespace pxr {
 
 constexpr int CNB = 64;
-
-// factor the NB x NB block held in LDS (lower), all 256 threads; two barriers per column.
-// Pivots go to pv[] so that no thread overwrites D[j][j] while others still read it.
-// Returns the first non-positive pivot (1-based) or 0.
-__device__ int potf2_lds(double (*D)[CNB + 1], double* pv) {
-  const int tid = threadIdx.x;
-  const int ti = tid >> 4, tj = tid & 15;
-  int bad = 0;
-  for (int j = 0; j < CNB; ++j) {
-    const double djj = D[j][j];
-    if (!(djj > 0.0) && bad == 0) bad = j + 1;
-    const double piv = djj > 0.0 ? sqrt(djj) : 1.0;
-    const double inv = 1.0 / piv;
-    if (tid == j) pv[j] = piv;
-    else if (tid > j && tid < CNB) D[tid][j] *= inv;
-    __syncthreads();
-    // trailing update D[i][c] -= D[i][j] * D[c][j], j < c <= i, 16 x 16 thread grid strided by 16
-    for (int i = j + 1 + ti; i < CNB; i += 16) {
-      const double lij = D[i][j];
-      for (int c = j + 1 + tj; c <= i; c += 16) D[i][c] -= lij * D[c][j];
-    }
-    __syncthreads();
-  }
-  if (tid < CNB) D[tid][tid] = pv[tid];
-  __syncthreads();
-  return bad;
-}
-
 constexpr int PROWS = 128;   // panel rows per workgroup in the TRSM part
 
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ a, int n, int lda, int k,
-                                                    int* __restrict__ info) {
-  __shared__ double D[CNB][CNB + 1];      // L_kk
+// n_rows = rows of the (augmented) matrix, n_cols = columns to factor, k = first column of the panel.
+__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ a, int n_rows, int n_cols, int lda, int k,
+                                                    int* __restrict__ info, double* __restrict__ linv_out) {
   __shared__ double Lt[CNB][CNB];         // Lt[m][j] = inv(L_kk)[j][m]
   __shared__ double Bs[CNB][PROWS];       // panel tile, Bs[m][row]
-  __shared__ double pv[CNB];
+  __shared__ double colb[2][CNB], rowb[2][CNB];
   const int tid = threadIdx.x;
-  const int nb = min(CNB, n - k);
-  for (int e = tid; e < CNB * CNB; e += blockDim.x) {   // diagonal block, identity padding beyond nb
-    const int i = e % CNB, j = e / CNB;
-    double v = (i == j) ? 1.0 : 0.0;
-    if (i < nb && j < nb && i >= j) v = a[(size_t)(k + i) + (size_t)(k + j) * lda];
-    D[i][j] = v;
-  }
-  __syncthreads();
-  const int bad = potf2_lds(D, pv);
-  if (blockIdx.x == 0) {
-    if (bad && tid == 0) atomicCAS(info, 0, k + bad);
-    for (int e = tid; e < CNB * CNB; e += blockDim.x) {
-      const int i = e % CNB, j = e / CNB;
-      if (i < nb && j < nb && i >= j) a[(size_t)(k + i) + (size_t)(k + j) * lda] = D[i][j];
+  const int ti = tid >> 4, tj = tid & 15;
+  const int nb = min(CNB, n_cols - k);
+  const bool is_panel_wg = blockIdx.x > 0;
+  const int r0 = k + nb + ((int)blockIdx.x - 1) * PROWS;
+  // issue the panel-tile loads first: they fly while the diagonal block is factored
+  double breg[CNB * PROWS / 256];
+  if (is_panel_wg) {
+#pragma unroll
+    for (int q = 0; q < CNB * PROWS / 256; ++q) {
+      const int e = tid + q * 256, i = e % PROWS, m = e / PROWS;
+      breg[q] = (r0 + i < n_rows && m < nb) ? a[(size_t)(r0 + i) + (size_t)(k + m) * lda] : 0.0;
     }
-    return;
   }
-  // inverse of the triangular factor, row by row: Linv[i][c] = (d_ic - sum_{m=c}^{i-1} L[i][m] Linv[m][c]) / L[i][i]
-  for (int e = tid; e < CNB * CNB; e += blockDim.x) Lt[e / CNB][e % CNB] = 0.0;
-  __syncthreads();
-  for (int i = 0; i < CNB; ++i) {
-    if (tid <= i) {
-      const int c = tid;
-      double s = (c == i) ? 1.0 : 0.0;
-      for (int m = c; m < i; ++m) s = fma(-D[i][m], Lt[c][m], s);   // Lt[c][m] = Linv[m][c]
-      Lt[c][i] = s / D[i][i];
+  double Dt[4][4], Xt[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int R = 4 * ti + u, Cc = 4 * tj + w;
+      double v = (R == Cc) ? 1.0 : 0.0;                     // identity padding beyond nb
+      if (R < nb && Cc < nb && R >= Cc) v = a[(size_t)(k + R) + (size_t)(k + Cc) * lda];
+      Dt[u][w] = v;
+      Xt[u][w] = (R == Cc) ? 1.0 : 0.0;
+    }
+  int bad = 0;
+  // 64-step sweep:  L[i][j] = D[i][j] / sqrt(D[j][j]);  D[i][c] -= L[i][j] L[c][j];
+  //                 X[j][:] /= L[j][j];  X[i][:] -= L[i][j] X[j][:]      (X: I -> inv(L))
+#pragma unroll 4
+  for (int j = 0; j < CNB; ++j) {
+    const int jb = j >> 2, jo = j & 3, buf = j & 1;
+    if (tj == jb) {                                          // owners of column j of D
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        double v = Dt[u][0];
+        if (jo == 1) v = Dt[u][1]; else if (jo == 2) v = Dt[u][2]; else if (jo == 3) v = Dt[u][3];
+        colb[buf][4 * ti + u] = v;
+      }
+    }
+    if (ti == jb) {                                          // owners of row j of X
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        double v = Xt[0][w];
+        if (jo == 1) v = Xt[1][w]; else if (jo == 2) v = Xt[2][w]; else if (jo == 3) v = Xt[3][w];
+        rowb[buf][4 * tj + w] = v;
+      }
     }
     __syncthreads();
+    const double djj = colb[buf][j];
+    if (!(djj > 0.0) && bad == 0) bad = j + 1;
+    const double inv = djj > 0.0 ? rsqrt(djj) : 1.0;
+    double li[4], lc[4], xr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) li[u] = (4 * ti + u > j) ? colb[buf][4 * ti + u] * inv : 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      lc[w] = (4 * tj + w > j) ? colb[buf][4 * tj + w] * inv : 0.0;
+      xr[w] = rowb[buf][4 * tj + w] * inv;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        Dt[u][w] = fma(-li[u], lc[w], Dt[u][w]);
+        Xt[u][w] = fma(-li[u], xr[w], Xt[u][w]);
+      }
+    if (tj == jb) {                                          // store the finished column j of L
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int R = 4 * ti + u;
+        if (R >= j) {
+          const double v = (R == j) ? djj * inv : li[u];
+          if (jo == 0) Dt[u][0] = v; else if (jo == 1) Dt[u][1] = v; else if (jo == 2) Dt[u][2] = v; else Dt[u][3] = v;
+        }
+      }
+    }
+    if (ti == jb) {                                          // finished row j of inv(L)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (jo == 0) Xt[0][w] = xr[w]; else if (jo == 1) Xt[1][w] = xr[w]; else if (jo == 2) Xt[2][w] = xr[w]; else Xt[3][w] = xr[w];
+      }
+    }
   }
-  // X = B inv(L)^T for this workgroup's PROWS rows: x[row][j] = sum_m B[row][m] Linv[j][m] = sum_m Bs[m][row] Lt[m][j]
-  const int r0 = k + CNB + (blockIdx.x - 1) * PROWS;
-  for (int e = tid; e < CNB * PROWS; e += blockDim.x) {
-    const int i = e % PROWS, m = e / PROWS;
-    Bs[m][i] = (r0 + i < n && m < nb) ? a[(size_t)(r0 + i) + (size_t)(k + m) * lda] : 0.0;
+  if (!is_panel_wg) {
+    if (bad && bad <= nb && tid == 0) atomicCAS(info, 0, k + bad);
+    double* lo = linv_out + (size_t)(k / CNB) * CNB * CNB;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int R = 4 * ti + u, Cc = 4 * tj + w;
+        if (R < nb && Cc < nb && R >= Cc) a[(size_t)(k + R) + (size_t)(k + Cc) * lda] = Dt[u][w];
+        lo[R * CNB + Cc] = (R >= Cc) ? Xt[u][w] : 0.0;      // inv(L_kk), row-major
+      }
+    return;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int R = 4 * ti + u, Cc = 4 * tj + w;
+      Lt[Cc][R] = (R >= Cc) ? Xt[u][w] : 0.0;               // Lt[m][j] = inv(L)[j][m]
+    }
+#pragma unroll
+  for (int q = 0; q < CNB * PROWS / 256; ++q) {
+    const int e = tid + q * 256;
+    Bs[e / PROWS][e % PROWS] = breg[q];
   }
   __syncthreads();
+  // X = B inv(L)^T for this workgroup's PROWS rows: x[row][j] = sum_m Bs[m][row] Lt[m][j]
   const int tx = tid & 15, ty = tid >> 4;   // ty: 8 rows, tx: 4 columns
   double acc[8][4];
 #pragma unroll
@@ -119,31 +165,30 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ a, int 
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int r = r0 + 8 * ty + u;
-      if (r < n) a[(size_t)r + (size_t)(k + j) * lda] = acc[u][w];
+      if (r < n_rows) a[(size_t)r + (size_t)(k + j) * lda] = acc[u][w];
     }
   }
 }
 
-// A22 -= P P^T, tiles of 64 x 64; P = A(k+NB : n, k : k+NB)
-__global__ __launch_bounds__(256) void k_chol_syrk(double* __restrict__ a, int n, int lda, int k) {
+// A22 -= P P^T, tiles of 64 x 64; P = A(k+nb : n_rows, k : k+nb)
+__global__ __launch_bounds__(256) void k_chol_syrk(double* __restrict__ a, int n_rows, int lda, int k, int nb) {
   const int ti = blockIdx.y, tj = blockIdx.x;
   if (tj > ti) return;
   __shared__ double Pi[CNB][CNB];   // [m][row]
   __shared__ double Pj[CNB][CNB];
-  const int r0 = k + CNB;
+  const int r0 = k + nb;
   const int tid = threadIdx.x;
-  const int nb = CNB;               // a full panel precedes every non-empty trailing block
   for (int e = tid; e < CNB * CNB; e += 256) {
     const int i = e % CNB, m = e / CNB;
     const int gi = r0 + ti * CNB + i, gj = r0 + tj * CNB + i;
-    Pi[m][i] = (gi < n) ? a[(size_t)gi + (size_t)(k + m) * lda] : 0.0;
-    Pj[m][i] = (gj < n) ? a[(size_t)gj + (size_t)(k + m) * lda] : 0.0;
+    Pi[m][i] = (gi < n_rows && m < nb) ? a[(size_t)gi + (size_t)(k + m) * lda] : 0.0;
+    Pj[m][i] = (gj < n_rows && m < nb) ? a[(size_t)gj + (size_t)(k + m) * lda] : 0.0;
   }
   __syncthreads();
   const int tx = tid & 15, ty = tid >> 4;
   double acc[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll 8
-  for (int m = 0; m < nb; ++m) {
+  for (int m = 0; m < CNB; ++m) {
     double pi[4], pj[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) { pi[u] = Pi[m][4 * ty + u]; pj[u] = Pj[m][4 * tx + u]; }
@@ -155,123 +200,121 @@ __global__ __launch_bounds__(256) void k_chol_syrk(double* __restrict__ a, int n
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
     const int gj = r0 + tj * CNB + 4 * tx + w;
-    if (gj >= n) continue;
+    if (gj >= n_rows) continue;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int gi = r0 + ti * CNB + 4 * ty + u;
-      if (gi < n && gi >= gj) a[(size_t)gi + (size_t)gj * lda] -= acc[u][w];
+      if (gi < n_rows && gi >= gj) a[(size_t)gi + (size_t)gj * lda] -= acc[u][w];
     }
   }
 }
 
-// single right-hand side: L y = b, L^T x = y; one workgroup of 1024 threads, b in LDS
-__global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ a, int n, int lda,
-                                                     double* __restrict__ b) {
+// L^T x = y with y = row n of the factored augmented matrix; one workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void k_chol_backsolve(const double* __restrict__ a, int n, int lda,
+                                                         const double* __restrict__ linv, double* __restrict__ x_out) {
   extern __shared__ double xs[];   // n doubles
-  __shared__ double Dd[CNB][CNB + 1];
+  __shared__ double part[16][CNB];
+  __shared__ double xk[CNB];
   const int tid = threadIdx.x, nt = blockDim.x;
-  for (int i = tid; i < n; i += nt) xs[i] = b[i];
+  for (int j = tid; j < n; j += nt) xs[j] = a[(size_t)n + (size_t)j * lda];
   __syncthreads();
-  // forward
-  for (int k = 0; k < n; k += CNB) {
-    const int nb = min(CNB, n - k);
-    for (int e = tid; e < CNB * CNB; e += nt) {
-      const int i = e % CNB, j = e / CNB;
-      Dd[i][j] = (i < nb && j < nb && i >= j) ? a[(size_t)(k + i) + (size_t)(k + j) * lda] : (i == j ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    if (tid < 64) {   // one wave: sequential over columns, lanes = rows (wave-synchronous)
-      double v = (tid < nb) ? xs[k + tid] : 0.0;
-      for (int j = 0; j < nb; ++j) {
-        const double yj = __shfl(v, j) / Dd[j][j];
-        if (tid == j) v = yj;
-        else if (tid > j) v = fma(-Dd[tid][j], yj, v);
-      }
-      if (tid < nb) xs[k + tid] = v;
-    }
-    __syncthreads();
-    // xs[i] -= sum_j A(i, k+j) y_j for i >= k + nb : one thread per row, coalesced over rows
-    for (int i = k + nb + tid; i < n; i += nt) {
-      double s = xs[i];
-      for (int j = 0; j < nb; ++j) s = fma(-a[(size_t)i + (size_t)(k + j) * lda], xs[k + j], s);
-      xs[i] = s;
-    }
-    __syncthreads();
-  }
-  // backward: L^T x = y
   const int nblk = (n + CNB - 1) / CNB;
   for (int bk = nblk - 1; bk >= 0; --bk) {
     const int k = bk * CNB, nb = min(CNB, n - k);
-    // xs[k+j] -= sum_{i >= k+nb} A(i, k+j) x_i : a wave per column (columns are contiguous)
+    // x_k = inv(L_kk)^T z_k :  x_k[c] = sum_r Linv[r][c] z[r]   (16 row slices x 64 columns)
     {
-      const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
-      for (int j = wv; j < nb; j += nw) {
-        double s = 0.0;
-        for (int i = k + nb + lane; i < n; i += 64) s = fma(a[(size_t)i + (size_t)(k + j) * lda], xs[i], s);
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) xs[k + j] -= s;
+      const double* Li = linv + (size_t)bk * CNB * CNB;
+      const int c = tid & (CNB - 1), sl = tid >> 6;
+      double s = 0.0;
+      for (int r = sl; r < nb; r += 16) s = fma(Li[r * CNB + c], xs[k + r], s);
+      part[sl][c] = s;
+      __syncthreads();
+      if (tid < CNB) {
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot += part[q][tid];
+        xk[tid] = (tid < nb) ? tot : 0.0;
       }
       __syncthreads();
+      if (tid < nb) xs[k + tid] = xk[tid];
     }
-    for (int e = tid; e < CNB * CNB; e += nt) {
-      const int i = e % CNB, j = e / CNB;
-      Dd[i][j] = (i < nb && j < nb && i >= j) ? a[(size_t)(k + i) + (size_t)(k + j) * lda] : (i == j ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    if (tid < 64) {
-      double v = (tid < nb) ? xs[k + tid] : 0.0;
-      for (int j = nb - 1; j >= 0; --j) {
-        const double xj = __shfl(v, j) / Dd[j][j];
-        if (tid == j) v = xj;
-        else if (tid < j) v = fma(-Dd[j][tid], xj, v);   // L^T(tid, j) = L(j, tid)
-      }
-      if (tid < nb) xs[k + tid] = v;
+    // z_c -= sum_r L(k + r, c) x_k[r] for every column c < k: contiguous 64-vector per column
+    for (int c = tid; c < k; c += nt) {
+      const double* col = a + (size_t)k + (size_t)c * lda;
+      double s = 0.0;
+#pragma unroll 8
+      for (int r = 0; r < CNB; ++r) s = fma((r < nb) ? col[r] : 0.0, xk[r], s);
+      xs[c] -= s;
     }
     __syncthreads();
   }
-  for (int i = tid; i < n; i += nt) b[i] = xs[i];
+  for (int j = tid; j < n; j += nt) x_out[j] = xs[j];
 }
 
-// Enqueue the factorisation of the n x n SPD matrix (column-major lower / row-major upper).
-// *d_info (device int, zeroed here) receives the 1-based index of the first non-positive pivot.
-int chol_factor(hipStream_t st, double* a, int n, int lda, int* d_info) {
+int chol_factor_solve(hipStream_t st, double* a, int n, int* d_info, double* linv_ws, double* x_out) {
+  const int lda = n + 1, n_rows = n + 1;
   if (int rc = hip_check(hipMemsetAsync(d_info, 0, sizeof(int), st), "memset info")) return rc;
   for (int k = 0; k < n; k += CNB) {
-    const int rem = n - k - CNB;   // rows below the diagonal block
-    const int wgs = 1 + (rem > 0 ? (rem + PROWS - 1) / PROWS : 0);
-    hipLaunchKernelGGL(k_chol_panel, dim3(wgs), dim3(256), 0, st, a, n, lda, k, d_info);
-    if (rem > 0) {
-      const int T = (rem + CNB - 1) / CNB;
-      hipLaunchKernelGGL(k_chol_syrk, dim3(T, T), dim3(256), 0, st, a, n, lda, k);
-    }
+    const int nb = (n - k < CNB) ? n - k : CNB;
+    const int rem = n_rows - k - nb;   // rows below the diagonal block (>= 1: the rhs row)
+    const int wgs = 1 + (rem + PROWS - 1) / PROWS;
+    hipLaunchKernelGGL(k_chol_panel, dim3(wgs), dim3(256), 0, st, a, n_rows, n, lda, k, d_info, linv_ws);
+    const int T = (rem + CNB - 1) / CNB;
+    hipLaunchKernelGGL(k_chol_syrk, dim3(T, T), dim3(256), 0, st, a, n_rows, lda, k, nb);
   }
+  const size_t shmem = sizeof(double) * (size_t)n;
+  if (shmem > 100 * 1024) return set_error(PXR_EUNSUPPORTED, "chol_factor_solve: n = %d exceeds the LDS-resident limit", n);
+  if (shmem > 32 * 1024) {
+    if (int rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_backsolve),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem),
+                           "hipFuncSetAttribute(k_chol_backsolve)"))
+      return rc;
+  }
+  hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(1024), shmem, st, a, n, lda, linv_ws, x_out);
   return hip_check(hipGetLastError(), "cholesky launch");
 }
 
-int chol_solve(hipStream_t st, const double* a, int n, int lda, double* b) {
-  const size_t shmem = sizeof(double) * (size_t)n;
-  if (shmem > 120 * 1024) return set_error(PXR_EUNSUPPORTED, "chol_solve: n = %d exceeds the LDS-resident limit", n);
-  if (shmem > 48 * 1024) {
-    if (int rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_solve),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem),
-                           "hipFuncSetAttribute(k_chol_solve)"))
-      return rc;
-  }
-  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), shmem, st, a, n, lda, b);
-  return hip_check(hipGetLastError(), "cholesky solve launch");
+// pack a plain n x n (row-major, upper) system + rhs into the augmented layout and back
+__global__ void k_aug_pack(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ aug) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int ld = n + 1;
+  if (t >= (int64_t)(n + 1) * ld) return;
+  const int r = (int)(t / ld), c = (int)(t % ld);
+  double v = 0.0;
+  if (r < n) v = (c == n) ? b[r] : (r <= c ? a[(size_t)r * n + c] : 0.0);
+  aug[t] = v;
+}
+__global__ void k_aug_unpack(int n, const double* __restrict__ aug, double* __restrict__ a) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)n * n) return;
+  const int r = (int)(t / n), c = (int)(t % n);
+  if (r <= c) a[t] = aug[(size_t)r * (n + 1) + c];
 }
 
 }  // namespace pxr
 
-// C-ABI: factor + solve in place.  d_a: n x n row-major with the UPPER triangle filled (the strictly
-// lower part is ignored and overwritten); d_b: right-hand side, overwritten by the solution.
+// C-ABI: factor + solve.  d_a: n x n row-major with the UPPER triangle filled (the strictly lower part is
+// ignored); on return the upper triangle holds the Cholesky factor (row-major upper = column-major lower L);
+// d_b: right-hand side, overwritten by the solution.
 extern "C" int pxr_dense_spd_solve(pxr_ctx* ctx, double* d_a, int n, double* d_b, int* h_info) {
+  using namespace pxr;
   PXR_REQUIRE(ctx && d_a && d_b && h_info && n > 0, "pxr_dense_spd_solve: invalid argument");
   PXR_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  double *aug = nullptr, *linv = nullptr;
+  const size_t na = (size_t)(n + 1) * (n + 1), nl = (size_t)((n + 63) / 64 + 1) * 64 * 64;
+  if (hipMalloc((void**)&aug, sizeof(double) * na) != hipSuccess || hipMalloc((void**)&linv, sizeof(double) * nl) != hipSuccess) {
+    (void)hipFree(aug); (void)hipFree(linv);
+    return set_error(PXR_ENOMEM, "pxr_dense_spd_solve: workspace allocation failed");
+  }
   int* d_info = reinterpret_cast<int*>(ctx->d_scratch);
-  if (int rc = pxr::chol_factor(ctx->stream, d_a, n, n, d_info)) return rc;
-  if (int rc = pxr::chol_solve(ctx->stream, d_a, n, n, d_b)) return rc;
-  PXR_HIP(hipMemcpyAsync(h_info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  PXR_HIP(hipStreamSynchronize(ctx->stream));
-  return PXR_OK;
+  hipLaunchKernelGGL(k_aug_pack, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, st, n, d_a, d_b, aug);
+  int rc = chol_factor_solve(st, aug, n, d_info, linv, d_b);
+  if (!rc) {
+    hipLaunchKernelGGL(k_aug_unpack, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, n, aug, d_a);
+    rc = hip_check(hipMemcpyAsync(h_info, d_info, sizeof(int), hipMemcpyDeviceToHost, st), "D2H info");
+  }
+  if (!rc) rc = hip_check(hipStreamSynchronize(st), "sync");
+  (void)hipFree(aug); (void)hipFree(linv);
+  return rc;
 }

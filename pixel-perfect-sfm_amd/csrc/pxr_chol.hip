@@ -239,12 +239,23 @@ __global__ __launch_bounds__(1024) void k_chol_backsolve(const double* __restric
       if (tid < nb) xs[k + tid] = xk[tid];
     }
     // z_c -= sum_r L(k + r, c) x_k[r] for every column c < k: contiguous 64-vector per column
-    for (int c = tid; c < k; c += nt) {
-      const double* col = a + (size_t)k + (size_t)c * lda;
-      double s = 0.0;
-#pragma unroll 8
-      for (int r = 0; r < CNB; ++r) s = fma((r < nb) ? col[r] : 0.0, xk[r], s);
-      xs[c] -= s;
+    // (a wave per column, lanes along the contiguous 64 rows: one coalesced 512-B load per column,
+    //  four columns in flight per wave)
+    {
+      const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+      const double xl = (lane < nb) ? xk[lane] : 0.0;
+      for (int c = wv * 4; c < k; c += nw * 4) {
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          v[q] = (c + q < k && lane < nb) ? a[(size_t)k + lane + (size_t)(c + q) * lda] * xl : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          double s = v[q];
+          for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+          if (lane == 0 && c + q < k) xs[c + q] -= s;
+        }
+      }
     }
     __syncthreads();
   }

@@ -42,7 +42,8 @@ enum { PXR_OK = 0, PXR_EINVAL = -1, PXR_EHIP = -2, PXR_ENOMEM = -3, PXR_EUNSUPPO
 enum { PXR_F16 = 0, PXR_F32 = 1, PXR_F64 = 2 };
 /* COLMAP 3.8 camera model ids (CAMERA_MODEL_SWITCH_CASES, residuals/src/feature_reference.h:232) */
 enum { PXR_SIMPLE_PINHOLE = 0, PXR_PINHOLE = 1, PXR_SIMPLE_RADIAL = 2, PXR_RADIAL = 3,
-       PXR_OPENCV = 4 };
+       PXR_OPENCV = 4, PXR_OPENCV_FISHEYE = 5, PXR_FULL_OPENCV = 6, PXR_FOV = 7,
+       PXR_SIMPLE_RADIAL_FISHEYE = 8, PXR_RADIAL_FISHEYE = 9, PXR_THIN_PRISM_FISHEYE = 10 };
 /* ceres loss functions reachable through options.loss
  * (keypoint_adjustment_options.h:53, bundle_adjustment_options.h:49) */
 enum { PXR_LOSS_TRIVIAL = 0, PXR_LOSS_CAUCHY = 1, PXR_LOSS_HUBER = 2, PXR_LOSS_SOFTL1 = 3 };

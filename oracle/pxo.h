@@ -38,8 +38,10 @@ enum {
   PXO_OPENCV = 4,
   PXO_OPENCV_FISHEYE = 5,
   PXO_FULL_OPENCV = 6,
+  PXO_FOV = 7,
   PXO_SIMPLE_RADIAL_FISHEYE = 8,
-  PXO_RADIAL_FISHEYE = 9
+  PXO_RADIAL_FISHEYE = 9,
+  PXO_THIN_PRISM_FISHEYE = 10
 };
 
 /* Ceres loss functions [upstream ceres/loss_function.h] */

@@ -12,7 +12,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 F16, F32, F64 = 0, 1, 2
 KPAD = 12
-CAMERA_MODELS = {"SIMPLE_PINHOLE": 0, "PINHOLE": 1, "SIMPLE_RADIAL": 2, "RADIAL": 3, "OPENCV": 4}
+CAMERA_MODELS = {"SIMPLE_PINHOLE": 0, "PINHOLE": 1, "SIMPLE_RADIAL": 2, "RADIAL": 3, "OPENCV": 4, "OPENCV_FISHEYE": 5,
+                 "FULL_OPENCV": 6, "FOV": 7, "SIMPLE_RADIAL_FISHEYE": 8, "RADIAL_FISHEYE": 9, "THIN_PRISM_FISHEYE": 10}
 LOSSES = {"trivial": 0, "cauchy": 1, "huber": 2, "soft_l1": 3}
 _NP2DT = {np.dtype(np.float16): F16, np.dtype(np.float32): F32, np.dtype(np.float64): F64}
 

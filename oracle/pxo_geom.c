@@ -14,6 +14,10 @@
 #define PXO_MAXC 512
 #define PXO_KPAD 12
 
+int pxo_camera_num_params_ext(int model);
+int pxo_world_to_image_ext(int model, const double* k, double u, double v, double* x, double* y,
+                           double* J_uv, double* J_k);
+
 /* [upstream COLMAP 3.8 camera_models.h] kNumParams */
 int pxo_camera_num_params(int model) {
   switch (model) {
@@ -22,7 +26,7 @@ int pxo_camera_num_params(int model) {
     case PXO_SIMPLE_RADIAL: return 4;
     case PXO_RADIAL: return 5;
     case PXO_OPENCV: return 8;
-    default: return -1;
+    default: return pxo_camera_num_params_ext(model);   /* pxo_camera_ext.c */
   }
 }
 
@@ -37,6 +41,7 @@ int pxo_world_to_image(int model, const double* k, double u, double v, double* x
                        double* J_uv, double* J_k) {
   const int K = pxo_camera_num_params(model);
   if (K < 0) return -1;
+  if (model > PXO_OPENCV) return pxo_world_to_image_ext(model, k, u, v, x, y, J_uv, J_k);
   double fx, fy, cx, cy;
   double du = 0, dv = 0, duu = 0, duv = 0, dvu = 0, dvv = 0; /* d(du)/du ... */
   const double u2 = u * u, v2 = v * v, uv = u * v, r2 = u2 + v2;

@@ -613,9 +613,9 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   PXR_HIP(hipMemcpyAsync(image_camera.data(), view->d_image_camera, 4 * n_img, hipMemcpyDeviceToHost, st));
   PXR_HIP(hipMemcpyAsync(cam_model.data(), view->d_cam_model, 4 * n_cam, hipMemcpyDeviceToHost, st));
   PXR_HIP(hipStreamSynchronize(st));
-  static const int kNumParams[5] = {3, 4, 4, 5, 8};
+  static const int kNumParams[11] = {3, 4, 4, 5, 8, 8, 12, 5, 4, 5, 12};   // [upstream COLMAP 3.8] kNumParams by model id
   for (int c = 0; c < n_cam; ++c)
-    PXR_REQUIRE(cam_model[c] >= 0 && cam_model[c] <= 4, "pxr_ba_solve: unsupported camera model id %d", cam_model[c]);
+    PXR_REQUIRE(cam_model[c] >= 0 && cam_model[c] <= 10, "pxr_ba_solve: unsupported camera model id %d", cam_model[c]);
   std::vector<int64_t> img_cnt(n_img + 1, 0), pt_cnt(n_pts + 1, 0);
   for (int64_t i = 0; i < n_obs; ++i) {
     PXR_REQUIRE(obs_image[i] >= 0 && obs_image[i] < n_img && obs_point[i] >= 0 && obs_point[i] < n_pts,

@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "pixsfm_hip.h"
+#include "pxr_camera_ext.h"
 
 namespace pxr {
 
@@ -137,7 +138,8 @@ __device__ __forceinline__ bool world_to_image(int model, const double* __restri
       x = k[0] * (u + du) + k[2]; y = k[1] * (v + dv) + k[3];
       return true;
     }
-    default:
+    default:   // OPENCV_FISHEYE ... THIN_PRISM_FISHEYE (pxr_camera_ext.h)
+      if (world_to_image_ext<double>(model, k, u, v, x, y)) return true;
       x = y = 0.0;
       return false;
   }
@@ -150,7 +152,7 @@ __device__ __forceinline__ int camera_num_params(int model) {
     case PXR_SIMPLE_RADIAL: return 4;
     case PXR_RADIAL: return 5;
     case PXR_OPENCV: return 8;
-    default: return 0;
+    default: return camera_num_params_ext(model);
   }
 }
 
@@ -202,7 +204,7 @@ __device__ inline bool world_to_pixel_jac(int model, const double* __restrict__ 
   double fx, fy, cx, cy, du = 0, dv = 0, duu = 0, duv = 0, dvu = 0, dvv = 0;
 #pragma unroll
   for (int j = 0; j < PXR_KPAD; ++j) { Pk[0][j] = 0.0; Pk[1][j] = 0.0; }
-  bool two_focal = false;
+  bool two_focal = false, ext_model = false;
   switch (model) {
     case PXR_SIMPLE_PINHOLE:
       fx = fy = k[0]; cx = k[1]; cy = k[2];
@@ -244,17 +246,23 @@ __device__ inline bool world_to_pixel_jac(int model, const double* __restrict__ 
       break;
     }
     default:
-      x = y = 0.0;
-      return false;
+      ext_model = true;
+      fx = fy = cx = cy = 0.0;
+      break;
   }
-  x = fx * (u + du) + cx;
-  y = fy * (v + dv) + cy;
-  if (two_focal) {
-    Pk[0][0] = u + du; Pk[1][1] = v + dv; Pk[0][2] = 1.0; Pk[1][3] = 1.0;
+  double Juv[2][2];
+  if (ext_model) {   // forward-mode duals (pxr_camera_ext.h)
+    if (!world_to_image_ext_jac(model, k, u, v, x, y, Juv, Pk)) { x = y = 0.0; return false; }
   } else {
-    Pk[0][0] = u + du; Pk[1][0] = v + dv; Pk[0][1] = 1.0; Pk[1][2] = 1.0;
+    x = fx * (u + du) + cx;
+    y = fy * (v + dv) + cy;
+    if (two_focal) {
+      Pk[0][0] = u + du; Pk[1][1] = v + dv; Pk[0][2] = 1.0; Pk[1][3] = 1.0;
+    } else {
+      Pk[0][0] = u + du; Pk[1][0] = v + dv; Pk[0][1] = 1.0; Pk[1][2] = 1.0;
+    }
+    Juv[0][0] = fx * (1.0 + duu); Juv[0][1] = fx * duv; Juv[1][0] = fy * dvu; Juv[1][1] = fy * (1.0 + dvv);
   }
-  const double Juv[2][2] = {{fx * (1.0 + duu), fx * duv}, {fy * dvu, fy * (1.0 + dvv)}};
   const double D[2][3] = {{iz, 0.0, -p[0] * iz * iz}, {0.0, iz, -p[1] * iz * iz}};
 #pragma unroll
   for (int i = 0; i < 2; ++i)

@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(HERE, "libpixsfm_hip.so")
 KPAD = 12
 OBS_REC = 8
 F16, F32, F64 = 0, 1, 2
-CAMERA_MODEL_IDS = {"SIMPLE_PINHOLE": 0, "PINHOLE": 1, "SIMPLE_RADIAL": 2, "RADIAL": 3, "OPENCV": 4}
+CAMERA_MODEL_IDS = {"SIMPLE_PINHOLE": 0, "PINHOLE": 1, "SIMPLE_RADIAL": 2, "RADIAL": 3, "OPENCV": 4, "OPENCV_FISHEYE": 5,
+                    "FULL_OPENCV": 6, "FOV": 7, "SIMPLE_RADIAL_FISHEYE": 8, "RADIAL_FISHEYE": 9, "THIN_PRISM_FISHEYE": 10}
 LOSS_IDS = {"trivial": 0, "cauchy": 1, "huber": 2, "soft_l1": 3}
 
 

@@ -13,6 +13,12 @@ CAMERA_MODELS = {
     2: ("SIMPLE_RADIAL", 4, [0], [1, 2], [3]),
     3: ("RADIAL", 5, [0], [1, 2], [3, 4]),
     4: ("OPENCV", 8, [0, 1], [2, 3], [4, 5, 6, 7]),
+    5: ("OPENCV_FISHEYE", 8, [0, 1], [2, 3], [4, 5, 6, 7]),
+    6: ("FULL_OPENCV", 12, [0, 1], [2, 3], [4, 5, 6, 7, 8, 9, 10, 11]),
+    7: ("FOV", 5, [0, 1], [2, 3], [4]),
+    8: ("SIMPLE_RADIAL_FISHEYE", 4, [0], [1, 2], [3]),
+    9: ("RADIAL_FISHEYE", 5, [0], [1, 2], [3, 4]),
+    10: ("THIN_PRISM_FISHEYE", 12, [0, 1], [2, 3], [4, 5, 6, 7, 8, 9, 10, 11]),
 }
 CAMERA_MODEL_NAME_TO_ID = {v[0]: k for k, v in CAMERA_MODELS.items()}
 

@@ -36,7 +36,7 @@ constexpr int KA_NLDS = 112;   // largest sub-problem (unknowns) whose damped ma
 struct KaArgs {
   pxr_ka_view v;
   const void* arena; const int32_t* corners; const double* scales; int H, W;
-  int l2_normalize;
+  int l2_normalize; int float_simd;
   pxr_loss loss; double bound; pxr_lm_options opt;
   // scratch
   double* desc;          // [n_nodes][3][C]: f, df/dx, df/dy
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void ka_solve_kernel(const KaArgs a) {
   __shared__ double sh4[4];
   __shared__ int sh_n, sh_feasible;
   const int prob = blockIdx.x, tid = threadIdx.x;
-  const bool fsimd = false;
+  const bool fsimd = a.float_simd != 0;
   KaProb p;
   p.np0 = a.v.d_prob_node_ptr[prob]; p.np1 = a.v.d_prob_node_ptr[prob + 1];
   p.ne0 = a.v.d_prob_edge_ptr[prob]; p.ne1 = a.v.d_prob_edge_ptr[prob + 1];
@@ -492,7 +492,7 @@ static int fill_args(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* view, co
                      const pxr_loss* loss, KaArgs& a) {
   a.v = *view;
   a.arena = arena->d_data; a.corners = arena->d_corners; a.scales = arena->d_scales;
-  a.H = arena->H; a.W = arena->W; a.l2_normalize = cfg->l2_normalize; a.loss = *loss;
+  a.H = arena->H; a.W = arena->W; a.l2_normalize = cfg->l2_normalize; a.float_simd = cfg->use_float_simd; a.loss = *loss;
   return PXR_OK;
 }
 
@@ -534,7 +534,6 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
                             pxr_lm_summary* h_summaries, pxr_lm_summary* total) {
   using namespace pxr;
   PXR_REQUIRE(ctx && arena && view && cfg && loss && options && total, "pxr_ka_solve: NULL argument");
-  PXR_REQUIRE(cfg->use_float_simd == 0, "pxr_ka_solve: use_float_simd is not supported by the KA solver yet");
   PXR_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int np = view->n_problems;

@@ -68,6 +68,19 @@ def test_solve_matches_oracle_default_options(ctx):
     assert abs(total["initial_cost"] - sum(s["initial_cost"] for s in sums)) < 1e-9 * total["initial_cost"]
 
 
+def test_solve_use_float_simd_and_huber(ctx):
+    """InterpolationConfig.use_float_simd (fp32 vertical pass, interpolation.h:620-623) + a non-default loss."""
+    import pxo
+    import pxo_ka
+    from pixsfm_amd.engine import interp_cfg, make_loss
+    prob, arena, ka = _setup(ctx, n_tracks=14, track_len=5, seed=21, max_kps_per_problem=30)
+    total, per = ka.solve(interp_cfg(use_float_simd=True), make_loss("huber", [0.3]), bound=4.0, per_problem=True)
+    kpo, sums = pxo_ka.ka_solve(prob, pxo.cfg(use_float_simd=True), pxo.loss("huber", 0.3), 4.0)
+    for g, o in zip(per, sums):
+        assert g["iterations"] == o["iterations"] and g["termination"] == o["termination"]
+    assert np.abs(ka.keypoints() - kpo).max() < 1e-6
+
+
 def test_solve_with_active_bounds_and_many_iterations(ctx):
     """Large detection noise: several nodes end on their +-bound box; tight tolerance so the LM
     runs long.  End points must agree within north_star's 1e-4."""

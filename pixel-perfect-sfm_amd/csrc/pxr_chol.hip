@@ -13,8 +13,8 @@
 //                  WG 0 writes L_kk and inv(L_kk) back, WG b >= 1 computes its 128 panel rows
 //                  X = B inv(L_kk)^T as an LDS-tiled GEMM (8x4 register micro-tiles).
 //   k_chol_syrk    trailing update A22 -= P P^T on 64x64 tiles (lower tiles only).
-//   k_chol_backsolve  L^T x = y right-looking by one workgroup: x_k = inv(L_kk)^T z_k (mat-vec with the
-//                  stored block inverse), then z_c -= L(k-block, c)^T x_k, one thread per column c.
+//   k_chol_backstep  L^T x = y right-looking, one launch per block step, many workgroups:
+//                  x_k = inv(L_kk)^T z_k (mat-vec with the stored block inverse), z_c -= L(k-block, c)^T x_k.
 #include <hip/hip_runtime.h>
 
 #include "pxr_internal.h"
@@ -209,57 +209,47 @@ __global__ __launch_bounds__(256) void k_chol_syrk(double* __restrict__ a, int n
   }
 }
 
-// L^T x = y with y = row n of the factored augmented matrix; one workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void k_chol_backsolve(const double* __restrict__ a, int n, int lda,
-                                                         const double* __restrict__ linv, double* __restrict__ x_out) {
-  extern __shared__ double xs[];   // n doubles
-  __shared__ double part[16][CNB];
+// One block step of L^T x = y (right-looking), many workgroups.  z = row n of the augmented matrix
+// (in place): every workgroup recomputes x_k = inv(L_kk)^T z_k (64 x 64 mat-vec with the stored block
+// inverse; cheaper than a launch boundary), workgroup 0 publishes it, and workgroup w updates the 64
+// columns c in [64 w, 64 w + 64) below the block:  z_c -= L(k-block, c)^T x_k  -- a wave per 16
+// columns, lanes along the contiguous 64 rows (one coalesced 512-B load per column, 4 in flight).
+__global__ __launch_bounds__(256) void k_chol_backstep(double* __restrict__ a, int n, int lda,
+                                                       const double* __restrict__ linv, double* __restrict__ x_out,
+                                                       int bk) {
+  __shared__ double part[4][CNB];
   __shared__ double xk[CNB];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int j = tid; j < n; j += nt) xs[j] = a[(size_t)n + (size_t)j * lda];
-  __syncthreads();
-  const int nblk = (n + CNB - 1) / CNB;
-  for (int bk = nblk - 1; bk >= 0; --bk) {
-    const int k = bk * CNB, nb = min(CNB, n - k);
-    // x_k = inv(L_kk)^T z_k :  x_k[c] = sum_r Linv[r][c] z[r]   (16 row slices x 64 columns)
-    {
-      const double* Li = linv + (size_t)bk * CNB * CNB;
-      const int c = tid & (CNB - 1), sl = tid >> 6;
-      double s = 0.0;
-      for (int r = sl; r < nb; r += 16) s = fma(Li[r * CNB + c], xs[k + r], s);
-      part[sl][c] = s;
-      __syncthreads();
-      if (tid < CNB) {
-        double tot = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) tot += part[q][tid];
-        xk[tid] = (tid < nb) ? tot : 0.0;
-      }
-      __syncthreads();
-      if (tid < nb) xs[k + tid] = xk[tid];
-    }
-    // z_c -= sum_r L(k + r, c) x_k[r] for every column c < k: contiguous 64-vector per column
-    // (a wave per column, lanes along the contiguous 64 rows: one coalesced 512-B load per column,
-    //  four columns in flight per wave)
-    {
-      const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
-      const double xl = (lane < nb) ? xk[lane] : 0.0;
-      for (int c = wv * 4; c < k; c += nw * 4) {
-        double v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          v[q] = (c + q < k && lane < nb) ? a[(size_t)k + lane + (size_t)(c + q) * lda] * xl : 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          double s = v[q];
-          for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-          if (lane == 0 && c + q < k) xs[c + q] -= s;
-        }
-      }
+  const int tid = threadIdx.x;
+  const int k = bk * CNB, nb = min(CNB, n - k);
+  {
+    const double* Li = linv + (size_t)bk * CNB * CNB;
+    const int c = tid & (CNB - 1), sl = tid >> 6;
+    double s = 0.0;
+    for (int r = sl; r < nb; r += 4) s = fma(Li[r * CNB + c], a[(size_t)n + (size_t)(k + r) * lda], s);
+    part[sl][c] = s;
+    __syncthreads();
+    if (tid < CNB) {
+      const double tot = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+      xk[tid] = (tid < nb) ? tot : 0.0;
+      if (blockIdx.x == 0 && tid < nb) x_out[k + tid] = tot;
     }
     __syncthreads();
   }
-  for (int j = tid; j < n; j += nt) x_out[j] = xs[j];
+  const int lane = tid & 63, wv = tid >> 6;
+  const double xl = xk[lane];
+  const int c_begin = blockIdx.x * CNB + wv * 16;
+  for (int c = c_begin; c < c_begin + 16 && c < k; c += 4) {
+    double v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      v[q] = (c + q < k && lane < nb) ? a[(size_t)k + lane + (size_t)(c + q) * lda] * xl : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double s = v[q];
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (lane == 0 && c + q < k) a[(size_t)n + (size_t)(c + q) * lda] -= s;
+    }
+  }
 }
 
 int chol_factor_solve(hipStream_t st, double* a, int n, int* d_info, double* linv_ws, double* x_out) {
@@ -273,15 +263,9 @@ int chol_factor_solve(hipStream_t st, double* a, int n, int* d_info, double* lin
     const int T = (rem + CNB - 1) / CNB;
     hipLaunchKernelGGL(k_chol_syrk, dim3(T, T), dim3(256), 0, st, a, n_rows, lda, k, nb);
   }
-  const size_t shmem = sizeof(double) * (size_t)n;
-  if (shmem > 100 * 1024) return set_error(PXR_EUNSUPPORTED, "chol_factor_solve: n = %d exceeds the LDS-resident limit", n);
-  if (shmem > 32 * 1024) {
-    if (int rc = hip_check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_backsolve),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem),
-                           "hipFuncSetAttribute(k_chol_backsolve)"))
-      return rc;
-  }
-  hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(1024), shmem, st, a, n, lda, linv_ws, x_out);
+  const int nblk = (n + CNB - 1) / CNB;
+  for (int bk = nblk - 1; bk >= 0; --bk)
+    hipLaunchKernelGGL(k_chol_backstep, dim3(bk > 0 ? bk : 1), dim3(256), 0, st, a, n, lda, linv_ws, x_out, bk);
   return hip_check(hipGetLastError(), "cholesky launch");
 }
 

@@ -137,7 +137,7 @@ def main():
     # ---- second half of the metric: LM iterations / s on the same problem ------------------------
     # default gauge (bundle_adjustment/main.py:12-18) and refine flags (bundle_adjustment_options.h:66-76);
     # one iteration = linearise + Schur + Cholesky + back-substitution + evaluation at the trial point.
-    lm = None
+    lm = {}
     if args.lm_iters > 0:
         from pixsfm_amd.engine import lm_options
         from pixsfm_amd.parallel import make_allreduce
@@ -146,13 +146,19 @@ def main():
         tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
         cmask = np.full(n_img, 0b0110, np.uint16)          # SIMPLE_RADIAL: refine f and k, keep cx, cy
         ptc = np.zeros(len(prob["xyz"]), np.uint8)
-        barrier()
-        t1 = time.perf_counter()
-        lm = ba.solve(cfg, make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,
-                      options=lm_options(max_iterations=args.lm_iters),
-                      allreduce=make_allreduce() if dist_on else None)
-        barrier()
-        lm["wall_s"] = time.perf_counter() - t1
+        # "lm": pixsfm's default BA configuration (use_inner_iterations = True, bundle_adjustment/main.py:43);
+        # "lm_no_inner": the plain trust-region loop.  Same initial parameters for both.
+        for key, inner in (("lm", True), ("lm_no_inner", False)):
+            for name in ("qvec", "tvec", "cam_params", "xyz"):
+                host = prob[name]
+                if name == "cam_params":
+                    host = np.zeros((len(prob["cam_model"]), 12)); host[:, :prob["cam_params"].shape[1]] = prob["cam_params"]
+                ba.d[name].upload(host)
+            barrier()
+            lm[key] = ba.solve(cfg, make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,
+                               options=lm_options(max_iterations=args.lm_iters, use_inner_iterations=inner),
+                               allreduce=make_allreduce() if dist_on else None)
+            barrier()
 
     if rank == 0:
         bpo = algorithmic_bytes_per_obs(C)
@@ -189,12 +195,13 @@ def main():
                          "algorithmic_bytes_per_obs": bpo},
             "initial_cost": cost,
         }
-        if lm is not None:
-            out["lm"] = {"iters_per_sec": lm["iterations"] / (lm["total_ms"] * 1e-3), "iterations": lm["iterations"],
-                         "successful": lm["num_successful"], "ms_per_iter": lm["total_ms"] / max(1, lm["iterations"]),
-                         "setup_ms": lm["setup_ms"], "initial_cost": lm["initial_cost"], "final_cost": lm["final_cost"],
-                         "reduced_system": lm["num_camera_unknowns"], "linear_solver": "point Schur complement (LDS-privatised) + hand-written blocked dense Cholesky",
-                         "inner_iterations": False}
+        for key, v in lm.items():
+            out[key] = {"iters_per_sec": v["iterations"] / (v["total_ms"] * 1e-3), "iterations": v["iterations"],
+                        "successful": v["num_successful"], "ms_per_iter": v["total_ms"] / max(1, v["iterations"]),
+                        "setup_ms": v["setup_ms"], "initial_cost": v["initial_cost"], "final_cost": v["final_cost"],
+                        "reduced_system": v["num_camera_unknowns"],
+                        "linear_solver": "point Schur complement (LDS-privatised) + hand-written blocked dense Cholesky",
+                        "inner_iterations": key == "lm"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(prob, patches, args.cpu_sample)
         print(json.dumps(out))

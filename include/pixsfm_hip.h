@@ -168,6 +168,10 @@ typedef struct {
   double max_lm_diagonal;        /* 1e32                                                */
   int32_t max_consecutive_invalid_steps; /* 10 (bundle_adjustment_options.h:56)         */
   int32_t jacobi_scaling;        /* 1                                                   */
+  int32_t use_inner_iterations;  /* BA: refine every variable point on its own after each trust-region step
+                                    (bundle_adjustment/main.py:43 default True; [upstream Ceres]
+                                    coordinate descent); ignored by pxr_ka_solve          */
+  double inner_iteration_tolerance; /* 1e-3 [upstream]: disabled once the relative gain falls below */
 } pxr_lm_options;
 
 typedef struct {

@@ -196,6 +196,8 @@ typedef struct {
   double max_lm_diagonal;              /* 1e32                                              */
   int32_t max_consecutive_invalid_steps; /* 10 (bundle_adjustment_options.h:56)             */
   int32_t jacobi_scaling;              /* 1                                                 */
+  int32_t use_inner_iterations;        /* BA only: True by default (bundle_adjustment/main.py:43) */
+  double inner_iteration_tolerance;    /* 1e-3 [upstream]                                   */
 } pxo_lm_options;
 
 typedef struct {

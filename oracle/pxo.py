@@ -273,7 +273,8 @@ class LMOptions(C.Structure):
                 ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
                 ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
                 ("max_lm_diagonal", C.c_double), ("max_consecutive_invalid_steps", C.c_int32),
-                ("jacobi_scaling", C.c_int32)]
+                ("jacobi_scaling", C.c_int32), ("use_inner_iterations", C.c_int32),
+                ("inner_iteration_tolerance", C.c_double)]
 
 
 class LMSummary(C.Structure):
@@ -287,10 +288,12 @@ class LMSummary(C.Structure):
 
 def lm_options(max_iterations=100, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0,
                initial_radius=1e4, max_radius=1e16, min_radius=1e-32, min_relative_decrease=1e-3,
-               min_lm_diagonal=1e-6, max_lm_diagonal=1e32, max_consecutive_invalid_steps=10, jacobi_scaling=1):
+               min_lm_diagonal=1e-6, max_lm_diagonal=1e32, max_consecutive_invalid_steps=10, jacobi_scaling=1,
+               use_inner_iterations=0, inner_iteration_tolerance=1e-3):
     return LMOptions(max_iterations, function_tolerance, gradient_tolerance, parameter_tolerance,
                      initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal,
-                     max_lm_diagonal, max_consecutive_invalid_steps, jacobi_scaling)
+                     max_lm_diagonal, max_consecutive_invalid_steps, jacobi_scaling, int(use_inner_iterations),
+                     inner_iteration_tolerance)
 
 
 def ba_solve(problem, config, ls, pose_const, tvec_const_mask, cam_const_mask, point_const, opts=None):

@@ -283,6 +283,122 @@ static double ba_ambient_sqnorm(ba_ctx* c, const double* q, const double* t, con
   return s;
 }
 
+/* ---- inner iterations ---------------------------------------------------------------------
+ * [upstream Ceres 2.1 coordinate_descent_minimizer.cc + trust_region_minimizer.cc
+ * DoInnerIterationsIfNeeded]  pixsfm enables them by default for BA
+ * (bundle_adjustment/main.py:43) with all variable points in group 0
+ * (bundle_optimizer.h:350-355): after the trust-region step every variable point is re-optimised
+ * on its own (cameras fixed at the candidate) by a nested TR-LM with Ceres' DEFAULT solver
+ * options -- 50 iterations, function/gradient/parameter tolerance 1e-6 / 1e-10 / 1e-8, initial
+ * radius 1e4, Jacobi scaling, at most 5 consecutive invalid steps.
+ * cost_p(X) = sum over the point's observations of 0.5 rho(|r|^2). */
+static double point_eval(ba_ctx* c, const double* q, const double* t, const double* k, int64_t p,
+                         const int64_t* obs, int n_obs, const double* X, double* H, double* g) {
+  const pxo_ba_batch* b = c->b;
+  const int C = b->C;
+  double cost = 0, r[PXO_MAXC], JX[PXO_MAXC * 3];
+  if (H) { memset(H, 0, sizeof(double) * 9); memset(g, 0, sizeof(double) * 3); }
+  for (int o = 0; o < n_obs; ++o) {
+    const int64_t i = obs[o];
+    const int img = b->obs_image[i], cam = b->image_camera[img];
+    pxo_patch pt = ba_patch(b, b->obs_patch[i]);
+    pxo_ba_residual(&pt, c->cfg, b->cam_model[cam], q + 4 * img, t + 3 * img, X, k + PXO_KPAD * cam,
+                    b->refs + (size_t)C * p, r, NULL, NULL, H ? JX : NULL, NULL);
+    double s = 0;
+    for (int m = 0; m < C; ++m) s += r[m] * r[m];
+    double rho[3];
+    pxo_loss_eval(c->loss, 1.0, s, rho);
+    cost += 0.5 * rho[0];
+    if (!H) continue;
+    pxo_corrector(s, rho, C, 3, r, JX);
+    for (int a = 0; a < 3; ++a) {
+      for (int m = 0; m < C; ++m) g[a] += JX[m * 3 + a] * r[m];
+      for (int bb = 0; bb < 3; ++bb) {
+        double h = 0;
+        for (int m = 0; m < C; ++m) h += JX[m * 3 + a] * JX[m * 3 + bb];
+        H[a * 3 + bb] += h;
+      }
+    }
+  }
+  return cost;
+}
+
+static void point_inner_lm(ba_ctx* c, const double* q, const double* t, const double* k, int64_t p,
+                           const int64_t* obs, int n_obs, double* X) {
+  double H[9], A[9], g[3], scale[3], diag[3], step[3], Xc[3];
+  double cost = point_eval(c, q, t, k, p, obs, n_obs, X, H, g);
+  double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+  if (gmax <= 1e-10) return;
+  for (int j = 0; j < 3; ++j) scale[j] = 1.0 / (1.0 + sqrt(H[j * 3 + j]));
+#define PT_SCALE() do { for (int a = 0; a < 3; ++a) { g[a] *= scale[a]; for (int bb = 0; bb < 3; ++bb) H[a * 3 + bb] *= scale[a] * scale[bb]; } } while (0)
+  PT_SCALE();
+  double radius = 1e4, decrease_factor = 2.0;
+  int invalid = 0, reuse_diag = 0;
+  for (int it = 0; it < 50; ++it) {
+    if (radius < 1e-32) break;
+    if (!reuse_diag)
+      for (int j = 0; j < 3; ++j) diag[j] = fmin(fmax(H[j * 3 + j], 1e-6), 1e32);
+    memcpy(A, H, sizeof(A));
+    for (int j = 0; j < 3; ++j) { A[j * 3 + j] += diag[j] / radius; step[j] = -g[j]; }
+    int ok = chol_solve(3, A, step) == 0;
+    double mcc = 0;
+    if (ok) {
+      double dg = 0, dHd = 0;
+      for (int a = 0; a < 3; ++a) {
+        dg += step[a] * g[a];
+        for (int bb = 0; bb < 3; ++bb) dHd += step[a] * H[a * 3 + bb] * step[bb];
+        if (!isfinite(step[a])) ok = 0;
+      }
+      mcc = -dg - 0.5 * dHd;
+      if (!(mcc > 0.0)) ok = 0;
+    }
+    if (!ok) {
+      if (++invalid >= 5) break;
+      radius *= 0.5; reuse_diag = 1;
+      continue;
+    }
+    invalid = 0;
+    for (int j = 0; j < 3; ++j) Xc[j] = X[j] + step[j] * scale[j];
+    const double cand = point_eval(c, q, t, k, p, obs, n_obs, Xc, NULL, NULL);
+    double s2 = 0, x2 = 0;
+    for (int j = 0; j < 3; ++j) { s2 += (Xc[j] - X[j]) * (Xc[j] - X[j]); x2 += X[j] * X[j]; }
+    if (sqrt(s2) <= 1e-8 * (sqrt(x2) + 1e-8)) break;
+    const double cost_change = cost - cand;
+    if (fabs(cost_change) <= 1e-6 * cost) break;
+    const double rel = cost_change / mcc;
+    if (rel > 1e-3) {
+      memcpy(X, Xc, sizeof(Xc));
+      cost = point_eval(c, q, t, k, p, obs, n_obs, X, H, g);
+      gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+      PT_SCALE();
+      const double tmp = 2.0 * rel - 1.0;
+      radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - tmp * tmp * tmp));
+      decrease_factor = 2.0; reuse_diag = 0;
+      if (gmax <= 1e-10) break;
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0; reuse_diag = 1;
+    }
+  }
+#undef PT_SCALE
+}
+
+/* re-optimise every variable point in place (X1), cameras fixed */
+static void ba_inner_iterations(ba_ctx* c, const double* q1, const double* t1, const double* k1, double* X1) {
+  const pxo_ba_batch* b = c->b;
+  int64_t* cnt = (int64_t*)calloc(c->n_points + 1, sizeof(int64_t));
+  for (int64_t i = 0; i < b->n_obs; ++i) ++cnt[b->obs_point[i] + 1];
+  for (int64_t p = 0; p < c->n_points; ++p) cnt[p + 1] += cnt[p];
+  int64_t* lst = (int64_t*)malloc(sizeof(int64_t) * (b->n_obs ? b->n_obs : 1));
+  int64_t* cur = (int64_t*)malloc(sizeof(int64_t) * (c->n_points + 1));
+  memcpy(cur, cnt, sizeof(int64_t) * (c->n_points + 1));
+  for (int64_t i = 0; i < b->n_obs; ++i) lst[cur[b->obs_point[i]]++] = i;
+  for (int64_t p = 0; p < c->n_points; ++p) {
+    if (c->L.pt_off[p] < 0 || cnt[p + 1] == cnt[p]) continue;
+    point_inner_lm(c, q1, t1, k1, p, lst + cnt[p], (int)(cnt[p + 1] - cnt[p]), X1 + 3 * p);
+  }
+  free(cnt); free(lst); free(cur);
+}
+
 int pxo_ba_solve(pxo_ba_batch* b, int n_images, int n_cams, int64_t n_points,
                  const pxo_interp_cfg* cfg, const pxo_loss* loss, const uint8_t* pose_const,
                  const uint8_t* tvec_const_mask, const uint16_t* cam_const_mask,
@@ -329,6 +445,7 @@ int pxo_ba_solve(pxo_ba_batch* b, int n_images, int n_cams, int64_t n_points,
   double radius = opt->initial_radius, decrease_factor = 2.0;
   int invalid = 0;
   int reuse_diag = 0;
+  int inner_enabled = opt->use_inner_iterations;
   while (1) {
     if (sum->iterations >= opt->max_iterations) { sum->termination = PXO_TERM_NO_CONVERGENCE; break; }
     if (radius < opt->min_radius) { sum->termination = PXO_TERM_CONVERGENCE; break; }
@@ -364,7 +481,16 @@ int pxo_ba_solve(pxo_ba_batch* b, int n_images, int n_cams, int64_t n_points,
     invalid = 0;
     for (int j = 0; j < n; ++j) delta[j] = step[j] * scale[j];
     ba_plus(&c, q, t, k, X, delta, q1, t1, k1, X1);
-    const double cand = ba_evaluate(&c, q1, t1, k1, X1, NULL, NULL);
+    double cand = ba_evaluate(&c, q1, t1, k1, X1, NULL, NULL);
+    int inner_useful = 0;
+    if (inner_enabled && isfinite(cand)) { /* DoInnerIterationsIfNeeded [upstream trust_region_minimizer.cc] */
+      ba_inner_iterations(&c, q1, t1, k1, X1);
+      const double inner_cost = ba_evaluate(&c, q1, t1, k1, X1, NULL, NULL);
+      model_cost_change += cand - inner_cost;
+      inner_useful = inner_cost < cost;
+      inner_enabled = (1.0 - inner_cost / cand) > opt->inner_iteration_tolerance;
+      cand = inner_cost;
+    }
     const double step_norm = sqrt(ba_ambient_sqnorm(&c, q, t, k, X, q1, t1, k1, X1));
     const double x_norm = sqrt(ba_ambient_sqnorm(&c, q, t, k, X, NULL, NULL, NULL, NULL));
     if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) {
@@ -373,7 +499,7 @@ int pxo_ba_solve(pxo_ba_batch* b, int n_images, int n_cams, int64_t n_points,
     const double cost_change = cost - cand;
     if (fabs(cost_change) <= opt->function_tolerance * cost) { sum->termination = PXO_TERM_CONVERGENCE; break; }
     const double rel = cost_change / model_cost_change;
-    if (rel > opt->min_relative_decrease) { /* HandleSuccessfulStep */
+    if (inner_useful || rel > opt->min_relative_decrease) { /* IsStepSuccessful + HandleSuccessfulStep */
       memcpy(q, q1, sizeof(double) * 4 * n_images); memcpy(t, t1, sizeof(double) * 3 * n_images);
       memcpy(k, k1, sizeof(double) * PXO_KPAD * n_cams); memcpy(X, X1, sizeof(double) * 3 * n_points);
       cost = ba_evaluate(&c, q, t, k, X, H, g);

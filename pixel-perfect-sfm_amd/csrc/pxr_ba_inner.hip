@@ -1,0 +1,232 @@
+// pxr_ba_inner.hip -- Ceres-style inner iterations for featuremetric BA on gfx950.
+//
+// pixsfm enables `use_inner_iterations` for bundle adjustment by default
+// (bundle_adjustment/main.py:43) with every variable point in inner-iteration group 0
+// (bundle_adjustment/src/bundle_optimizer.h:350-355).  [upstream Ceres 2.1
+// coordinate_descent_minimizer.cc, trust_region_minimizer.cc::DoInnerIterationsIfNeeded]: after
+// the trust-region step, each point of the independent set is re-optimised on its own -- cameras
+// fixed at the candidate -- by a nested TR-LM with Ceres' default options (<= 50 iterations,
+// function / gradient / parameter tolerance 1e-6 / 1e-10 / 1e-8, initial radius 1e4, Jacobi
+// scaling, <= 5 consecutive invalid steps).
+//
+// Mapping: one wave per point, its four 16-lane rows evaluate four observations at a time with
+// the same interpolation core as the fused BA kernel; the per-observation 2x2 / 2-vector blocks
+// are folded with d(x,y)/dX into the point's 3x3 normal matrix and reduced across the rows with
+// two shuffles.  The whole nested LM runs in registers; consecutive evaluations re-read the same
+// 4 KiB stencils from L2.  The kernel also returns the cost at the (unrefined) candidate, so the
+// outer loop needs no separate evaluation for Ceres' inner-iteration bookkeeping.
+#include <hip/hip_runtime.h>
+
+#include "pxr_device.h"
+#include "pxr_interp.h"
+#include "pxr_internal.h"
+
+namespace pxr {
+
+struct InnerArgs {
+  pxr_ba_view v;               // candidate parameters; d_xyz is updated in place
+  const void* arena; const int32_t* corners; const double* scales; int H, W;
+  int l2_normalize;
+  pxr_loss loss;
+  const int64_t* pt_ptr; const int64_t* pt_obs; const int* pt_var;
+  double* xyz_out;             // == v.d_xyz (mutable alias)
+  double* cost_before;         // += sum of 0.5 rho at the unrefined candidate
+};
+
+__device__ __forceinline__ double rows4_sum(double v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+template <typename ST, int C>
+__global__ __launch_bounds__(256) void k_inner_points(const InnerArgs a) {
+  static_assert(C == 128, "one observation per 16-lane row");
+  const int lane = threadIdx.x & 63, row = lane >> 4, sub = lane & 15;
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= a.v.n_points) return;
+  const int64_t o0 = a.pt_ptr[p];
+  const int n = (int)(a.pt_ptr[p + 1] - o0);
+  if (n == 0) return;
+  const bool variable = a.pt_var[p] != 0;
+  double X[3] = {a.v.d_xyz[3 * p], a.v.d_xyz[3 * p + 1], a.v.d_xyz[3 * p + 2]};
+  const ST* arena = reinterpret_cast<const ST*>(a.arena);
+  const size_t patch_elems = (size_t)a.H * a.W * C;
+  const double* refp = a.v.d_refs + (size_t)p * C + sub * 8;
+  double ref[8];
+#pragma unroll
+  for (int ch = 0; ch < 8; ++ch) ref[ch] = refp[ch];
+
+  // cost (+ normal equations H (6: xx xy xz yy yz zz), g (3)) of this point at Xc
+  auto eval = [&](const double* Xc, bool with_jac, double* Hn, double* gn) -> double {
+    double cost = 0.0, acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int chunk = 0; chunk < n; chunk += 4) {
+      const int oi = chunk + row;
+      const bool valid = oi < n;
+      const int64_t i = a.pt_obs[o0 + (valid ? oi : n - 1)];
+      const int img = a.v.d_obs_image[i], cam = a.v.d_image_camera[img];
+      const int64_t pi = a.v.d_obs_patch[i];
+      double q[4], t[3], k[PXR_KPAD];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[j] = a.v.d_qvec[4 * (size_t)img + j];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) t[j] = a.v.d_tvec[3 * (size_t)img + j];
+#pragma unroll
+      for (int j = 0; j < PXR_KPAD; ++j) k[j] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + j];
+      double x, y, A[2][3], Pq[2][4], PX[2][3], Pk[2][PXR_KPAD];
+      world_to_pixel_jac(a.v.d_cam_model[cam], k, q, t, Xc, x, y, A, Pq, PX, Pk);
+      const double sx = a.scales[2 * pi], sy = a.scales[2 * pi + 1];
+      const double u = x * sx - 0.5 - (double)a.corners[2 * pi];
+      const double v = y * sy - 0.5 - (double)a.corners[2 * pi + 1];
+      double f[8], fr[8], fc[8];
+      interp8<ST, 16, true, false>(arena + (size_t)pi * patch_elems, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f, fr, fc);
+      double s = 0, gcc = 0, gcr = 0, grr = 0, bc = 0, br = 0;
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        const double r = f[ch] - ref[ch];
+        s = fma(r, r, s);
+        gcc = fma(fc[ch], fc[ch], gcc); gcr = fma(fc[ch], fr[ch], gcr); grr = fma(fr[ch], fr[ch], grr);
+        bc = fma(fc[ch], r, bc); br = fma(fr[ch], r, br);
+      }
+      s = row16_sum(s);
+      double rho[3];
+      loss_eval(a.loss.type, a.loss.a, 1.0, s, rho);
+      if (valid) cost += 0.5 * rho[0];
+      if (with_jac) {
+        gcc = row16_sum(gcc) * sx * sx; gcr = row16_sum(gcr) * sx * sy; grr = row16_sum(grr) * sy * sy;
+        bc = row16_sum(bc) * sx; br = row16_sum(br) * sy;
+        double kappa = 0.0;
+        if (s != 0.0 && rho[2] > 0.0) {
+          const double D = 1.0 + 2.0 * s * rho[2] / rho[1];
+          const double alpha = 1.0 - sqrt(D);
+          kappa = (2.0 * alpha - alpha * alpha) / s;
+        }
+        const double w8 = valid ? rho[1] : 0.0;
+        const double m00 = w8 * (gcc - kappa * bc * bc), m01 = w8 * (gcr - kappa * bc * br), m11 = w8 * (grr - kappa * br * br);
+        const double b0 = w8 * bc, b1 = w8 * br;
+        double me0[3], me1[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { me0[j] = m00 * PX[0][j] + m01 * PX[1][j]; me1[j] = m01 * PX[0][j] + m11 * PX[1][j]; }
+        acc[0] += PX[0][0] * me0[0] + PX[1][0] * me1[0];
+        acc[1] += PX[0][0] * me0[1] + PX[1][0] * me1[1];
+        acc[2] += PX[0][0] * me0[2] + PX[1][0] * me1[2];
+        acc[3] += PX[0][1] * me0[1] + PX[1][1] * me1[1];
+        acc[4] += PX[0][1] * me0[2] + PX[1][1] * me1[2];
+        acc[5] += PX[0][2] * me0[2] + PX[1][2] * me1[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[6 + j] += PX[0][j] * b0 + PX[1][j] * b1;
+      }
+    }
+    cost = rows4_sum(cost);   // every lane of a row holds the row's cost -> sum of the 4 rows
+    if (with_jac) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) Hn[j] = rows4_sum(acc[j]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) gn[j] = rows4_sum(acc[6 + j]);
+    }
+    return cost;
+  };
+
+  double H[6], g[3];
+  double cost = eval(X, variable, H, g);
+  if (lane == 0) atomicAdd(a.cost_before, cost);
+  if (!variable) return;
+  // nested TR-LM (same loop as pxr_ba_solve, Ceres default options)
+  double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+  if (gmax <= 1e-10) return;
+  const double sc[3] = {1.0 / (1.0 + sqrt(H[0])), 1.0 / (1.0 + sqrt(H[3])), 1.0 / (1.0 + sqrt(H[5]))};
+  auto scale_sys = [&]() {
+    H[0] *= sc[0] * sc[0]; H[1] *= sc[0] * sc[1]; H[2] *= sc[0] * sc[2];
+    H[3] *= sc[1] * sc[1]; H[4] *= sc[1] * sc[2]; H[5] *= sc[2] * sc[2];
+    g[0] *= sc[0]; g[1] *= sc[1]; g[2] *= sc[2];
+  };
+  scale_sys();
+  double radius = 1e4, decrease_factor = 2.0, diag[3] = {0, 0, 0};
+  int invalid = 0;
+  bool reuse_diag = false;
+  for (int it = 0; it < 50; ++it) {
+    if (radius < 1e-32) break;
+    if (!reuse_diag) {
+      diag[0] = fmin(fmax(H[0], 1e-6), 1e32); diag[1] = fmin(fmax(H[3], 1e-6), 1e32); diag[2] = fmin(fmax(H[5], 1e-6), 1e32);
+    }
+    // Cholesky of the damped 3x3
+    const double a00 = H[0] + diag[0] / radius, a01 = H[1], a02 = H[2], a11 = H[3] + diag[1] / radius, a12 = H[4],
+                 a22 = H[5] + diag[2] / radius;
+    bool ok = a00 > 0.0;
+    const double l00 = sqrt(a00), l10 = a01 / l00, l20 = a02 / l00;
+    const double d1 = a11 - l10 * l10;
+    ok = ok && d1 > 0.0;
+    const double l11 = sqrt(d1), l21 = (a12 - l20 * l10) / l11;
+    const double d2 = a22 - l20 * l20 - l21 * l21;
+    ok = ok && d2 > 0.0;
+    const double l22 = sqrt(d2);
+    const double y0 = -g[0] / l00, y1 = (-g[1] - l10 * y0) / l11, y2 = (-g[2] - l20 * y0 - l21 * y1) / l22;
+    double st[3];
+    st[2] = y2 / l22; st[1] = (y1 - l21 * st[2]) / l11; st[0] = (y0 - l10 * st[1] - l20 * st[2]) / l00;
+    double mcc = 0.0;
+    if (ok) {
+      const double dg = st[0] * g[0] + st[1] * g[1] + st[2] * g[2];
+      const double dHd = st[0] * (H[0] * st[0] + H[1] * st[1] + H[2] * st[2]) + st[1] * (H[1] * st[0] + H[3] * st[1] + H[4] * st[2]) +
+                         st[2] * (H[2] * st[0] + H[4] * st[1] + H[5] * st[2]);
+      mcc = -dg - 0.5 * dHd;
+      if (!(mcc > 0.0) || !isfinite(st[0]) || !isfinite(st[1]) || !isfinite(st[2])) ok = false;
+    }
+    if (!ok) {
+      if (++invalid >= 5) break;
+      radius *= 0.5; reuse_diag = true;
+      continue;
+    }
+    invalid = 0;
+    const double Xc[3] = {X[0] + st[0] * sc[0], X[1] + st[1] * sc[1], X[2] + st[2] * sc[2]};
+    double Hc[6], gc[3];
+    const double cand = eval(Xc, true, Hc, gc);   // with Jacobians: an accepted step needs no second evaluation
+    const double s2 = (Xc[0] - X[0]) * (Xc[0] - X[0]) + (Xc[1] - X[1]) * (Xc[1] - X[1]) + (Xc[2] - X[2]) * (Xc[2] - X[2]);
+    const double x2 = X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+    if (sqrt(s2) <= 1e-8 * (sqrt(x2) + 1e-8)) break;
+    const double cost_change = cost - cand;
+    if (fabs(cost_change) <= 1e-6 * cost) break;
+    const double rel = cost_change / mcc;
+    if (rel > 1e-3) {
+      X[0] = Xc[0]; X[1] = Xc[1]; X[2] = Xc[2];
+      cost = cand;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) H[j] = Hc[j];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) g[j] = gc[j];
+      gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+      scale_sys();
+      const double tmp = 2.0 * rel - 1.0;
+      radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - tmp * tmp * tmp));
+      decrease_factor = 2.0; reuse_diag = false;
+      if (gmax <= 1e-10) break;
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0; reuse_diag = true;
+    }
+  }
+  if (lane == 0) { a.xyz_out[3 * p] = X[0]; a.xyz_out[3 * p + 1] = X[1]; a.xyz_out[3 * p + 2] = X[2]; }
+}
+
+// Enqueue the inner iterations on the candidate parameters `view` (xyz refined in place);
+// *d_cost_before (device double, caller-zeroed) receives the cost at the unrefined candidate.
+int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
+                            const pxr_loss* loss, const int64_t* d_pt_ptr, const int64_t* d_pt_obs,
+                            const int* d_pt_var, double* d_cost_before) {
+  if (arena->C != 128) return set_error(PXR_EUNSUPPORTED, "inner iterations: CHANNELS=%d not supported (128)", arena->C);
+  if (cfg->use_float_simd) return set_error(PXR_EUNSUPPORTED, "inner iterations with use_float_simd are not supported");
+  InnerArgs a;
+  a.v = *view;
+  a.arena = arena->d_data; a.corners = arena->d_corners; a.scales = arena->d_scales;
+  a.H = arena->H; a.W = arena->W; a.l2_normalize = cfg->l2_normalize; a.loss = *loss;
+  a.pt_ptr = d_pt_ptr; a.pt_obs = d_pt_obs; a.pt_var = d_pt_var;
+  a.xyz_out = const_cast<double*>(view->d_xyz); a.cost_before = d_cost_before;
+  const unsigned blocks = (unsigned)((view->n_points + 3) / 4);
+  if (blocks == 0) return PXR_OK;
+  switch (arena->dtype) {
+    case PXR_F16: hipLaunchKernelGGL((k_inner_points<_Float16, 128>), dim3(blocks), dim3(256), 0, ctx->stream, a); break;
+    case PXR_F32: hipLaunchKernelGGL((k_inner_points<float, 128>), dim3(blocks), dim3(256), 0, ctx->stream, a); break;
+    default: return set_error(PXR_EUNSUPPORTED, "inner iterations: fp64 patches are not supported");
+  }
+  return hip_check(hipGetLastError(), "k_inner_points launch");
+}
+
+}  // namespace pxr

@@ -530,6 +530,16 @@ __global__ __launch_bounds__(256) void k_update(const SolveDev d, const double* 
   }
 }
 
+__global__ void k_point_step_norm(int64_t n_points, const int* __restrict__ pt_var, const double* __restrict__ X0,
+                                  const double* __restrict__ X1, double* __restrict__ out) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double s = 0.0;
+  if (p < n_points && pt_var[p])
+    for (int j = 0; j < 3; ++j) { const double d = X1[3 * p + j] - X0[3 * p + j]; s += d * d; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(out, s);
+}
+
 __global__ void k_normalize_q(int n, double* __restrict__ q) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -582,6 +592,11 @@ struct DevBuf {
 // pxr_chol.hip: factor the n x n SPD system stored row-major (upper) in the n x (n + 1) buffer `a` whose last
 // column is the right-hand side (forward substitution is fused into the factorisation), then back-substitute.
 int chol_factor_solve(hipStream_t st, double* a, int n, int* d_info, double* linv_ws, double* x_out);
+
+// pxr_ba_inner.hip
+int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
+                            const pxr_loss* loss, const int64_t* d_pt_ptr, const int64_t* d_pt_obs,
+                            const int* d_pt_var, double* d_cost_before);
 
 static inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 
@@ -801,6 +816,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   double radius = opt->initial_radius, decrease_factor = 2.0;
   int invalid = 0;
   bool reuse_diag = false;
+  bool inner_enabled = opt->use_inner_iterations != 0, inner_useful = false;
 
   while (true) {
     if (sum->iterations >= opt->max_iterations) { sum->termination = PXR_TERM_NO_CONVERGENCE; break; }
@@ -841,6 +857,13 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       ParamPtrs out{q1.p, t1.p, k1.p, X1.p};
       hipLaunchKernelGGL(k_update, dim3(nblk((int64_t)n_img + n_cam + n_pts)), dim3(256), 0, st, dv, delta_c.p, delta_p.p, out, scal_rep, scal_sum);
       LAUNCH_CHECK("step kernels");
+      const bool do_inner = inner_enabled;
+      if (do_inner) {   // DoInnerIterationsIfNeeded [upstream]: refine every variable point of the candidate on its own
+        RC(launch_inner_iterations(ctx, arena, &cand_view, cfg, loss, d_pt_ptr.p, d_pt_obs.p, d_pt_var.p, scal_sum + 4));
+        PXR_HIP(hipMemsetAsync(scal_sum + 2, 0, sizeof(double), st));   // point part of |x - candidate|^2 after refinement
+        hipLaunchKernelGGL(k_point_step_norm, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, d_pt_var.p, cur_X, X1.p, scal_sum + 2);
+        LAUNCH_CHECK("inner iteration kernels");
+      }
       phase(4);
       RC(evaluate(cand_view, rec_cand));
       int h_info = 0;
@@ -853,6 +876,13 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       step_norm = std::sqrt(hs[2] + hs[9]);
       x_norm = std::sqrt(hs[3] + hs[10]);
       if (!(model_cost_change > 0.0) || !std::isfinite(model_cost_change) || !std::isfinite(cand_cost)) ok = false;
+      inner_useful = false;
+      if (ok && do_inner) {
+        const double cost_before = hs[4];                 // cost at the candidate before the inner iterations
+        model_cost_change += cost_before - cand_cost;
+        inner_useful = cand_cost < cost;
+        inner_enabled = (1.0 - cand_cost / cost_before) > opt->inner_iteration_tolerance;
+      }
     }
     if (verbose)
       fprintf(stderr, "[pxr_ba_solve] it %3d cost %.9e cand %.9e mcc %.3e radius %.3e |dx| %.3e %s\n", sum->iterations,
@@ -867,7 +897,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     const double cost_change = cost - cand_cost;
     if (std::fabs(cost_change) <= opt->function_tolerance * cost) { sum->termination = PXR_TERM_CONVERGENCE; break; }
     const double rel = cost_change / model_cost_change;
-    if (rel > opt->min_relative_decrease) {   // HandleSuccessfulStep
+    if (inner_useful || rel > opt->min_relative_decrease) {   // IsStepSuccessful + HandleSuccessfulStep
       PXR_HIP(hipMemcpyAsync(cur_q, q1.p, sizeof(double) * 4 * n_img, hipMemcpyDeviceToDevice, st));
       PXR_HIP(hipMemcpyAsync(cur_t, t1.p, sizeof(double) * 3 * n_img, hipMemcpyDeviceToDevice, st));
       PXR_HIP(hipMemcpyAsync(cur_k, k1.p, sizeof(double) * PXR_KPAD * n_cam, hipMemcpyDeviceToDevice, st));

@@ -43,7 +43,8 @@ class LMOptions(C.Structure):
                 ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
                 ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
                 ("max_lm_diagonal", C.c_double), ("max_consecutive_invalid_steps", C.c_int32),
-                ("jacobi_scaling", C.c_int32)]
+                ("jacobi_scaling", C.c_int32), ("use_inner_iterations", C.c_int32),
+                ("inner_iteration_tolerance", C.c_double)]
 
 
 class LMSummary(C.Structure):

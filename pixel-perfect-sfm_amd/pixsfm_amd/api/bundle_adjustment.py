@@ -6,8 +6,8 @@ FeatureReferenceBundleOptimizer.  Same names, argument meaning and defaults; pro
 construction follows BundleOptimizer::SetUp / Parameterize (bundle_optimizer.h:139-165,247-453);
 the Ceres solve is replaced by pxr_ba_solve on the GPU.
 
-Deviation (documented in DESIGN.md): `use_inner_iterations` (default True in the reference,
-bundle_adjustment/main.py:43) is accepted but not applied yet.
+`use_inner_iterations` (default True, bundle_adjustment/main.py:43) is honoured: every variable point is
+re-optimised on its own after each trust-region step (pxr_ba_inner.hip).
 """
 from copy import deepcopy
 
@@ -307,7 +307,8 @@ class FeatureReferenceBundleOptimizer:
         s = self.options['solver']
         lm = lm_options(max_iterations=s['max_num_iterations'], function_tolerance=s['function_tolerance'],
                         gradient_tolerance=s['gradient_tolerance'], parameter_tolerance=s['parameter_tolerance'],
-                        max_consecutive_invalid_steps=s['max_num_consecutive_invalid_steps'])
+                        max_consecutive_invalid_steps=s['max_num_consecutive_invalid_steps'],
+                        use_inner_iterations=s['use_inner_iterations'])
         summ = ba.solve(self.interpolation.to_engine(),
                         make_loss(self.options['loss']['name'], self.options['loss']['params']),
                         flat.pose_const, flat.tvec_mask, flat.cam_mask, flat.point_const, options=lm,

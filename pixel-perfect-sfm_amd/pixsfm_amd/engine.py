@@ -176,14 +176,15 @@ def make_loss(name="cauchy", params=(0.25,)):
 def lm_options(max_iterations=100, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0,
                initial_radius=1e4, max_radius=1e16, min_radius=1e-32, min_relative_decrease=1e-3,
                min_lm_diagonal=1e-6, max_lm_diagonal=1e32, max_consecutive_invalid_steps=10, jacobi_scaling=1,
-               **ignored):
+               use_inner_iterations=False, inner_iteration_tolerance=1e-3, **ignored):
     """Subset of ceres::Solver::Options the engine honours (pixsfm/base/main.py:9-22 +
     bundle_adjustment_options.h:48-64); unknown keys are ignored like pyceres ignores nothing --
     callers should pass only what they need."""
     return _lib.LMOptions(int(max_iterations), float(function_tolerance), float(gradient_tolerance),
                           float(parameter_tolerance), float(initial_radius), float(max_radius), float(min_radius),
                           float(min_relative_decrease), float(min_lm_diagonal), float(max_lm_diagonal),
-                          int(max_consecutive_invalid_steps), int(jacobi_scaling))
+                          int(max_consecutive_invalid_steps), int(jacobi_scaling), int(bool(use_inner_iterations)),
+                          float(inner_iteration_tolerance))
 
 
 class BAProblem:

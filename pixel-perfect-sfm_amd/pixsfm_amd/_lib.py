@@ -65,7 +65,9 @@ class KaView(C.Structure):
                 ("d_node_const", C.c_void_p), ("n_edges", C.c_int64), ("d_edge_src", C.c_void_p),
                 ("d_edge_dst", C.c_void_p), ("d_edge_w", C.c_void_p), ("n_problems", C.c_int32),
                 ("d_prob_node_ptr", C.c_void_p), ("d_prob_nodes", C.c_void_p), ("d_prob_edge_ptr", C.c_void_p),
-                ("d_prob_edges", C.c_void_p)]
+                ("d_prob_edges", C.c_void_p), ("n_unary", C.c_int64), ("d_unary_node", C.c_void_p),
+                ("d_unary_ref", C.c_void_p), ("d_unary_w", C.c_void_p), ("d_prob_unary_ptr", C.c_void_p),
+                ("d_prob_unary", C.c_void_p)]
 
 # every symbol include/pixsfm_hip.h declares (checked by tests/test_cabi.py)
 _SIGNATURES = {

@@ -20,7 +20,9 @@ def _csr(labels, n_groups):
 class KAProblem:
     """problem: dict with kp (n,2), node_patch, node_const, node_problem, edge_src, edge_dst, edge_w.
     An edge belongs to the sub-problem of its source node (edges are intra-track and a track
-    lives in exactly one sub-problem, keypoint_adjustment/main.py:13-57)."""
+    lives in exactly one sub-problem, keypoint_adjustment/main.py:13-57).
+    Optional unary reference terms (localization QKA, query_keypoint_optimizer.h:122-139):
+    unary_node (m,), unary_ref (m, C), unary_w (m,) or None; a term belongs to its node's sub-problem."""
 
     def __init__(self, ctx, arena, problem):
         self.ctx, self.arena = ctx, arena
@@ -37,6 +39,7 @@ class KAProblem:
             raise ValueError("an edge connects two different sub-problems")
         node_ptr, nodes = _csr(node_problem, self.n_problems)
         edge_ptr, edges = _csr(node_problem[edge_src] if self.n_edges else np.zeros(0, np.int64), self.n_problems)
+        self.n_unary = len(g["unary_node"]) if g.get("unary_node") is not None else 0
         self.d = {
             "kp": ctx.to_device(g["kp"], np.float64),
             "node_patch": ctx.to_device(g["node_patch"], np.int64),
@@ -50,7 +53,27 @@ class KAProblem:
         d = self.d
         self.view = KaView(self.n_nodes, d["kp"].ptr, d["node_patch"].ptr, d["node_const"].ptr, self.n_edges,
                            d["edge_src"].ptr, d["edge_dst"].ptr, d["edge_w"].ptr, self.n_problems,
-                           d["node_ptr"].ptr, d["nodes"].ptr, d["edge_ptr"].ptr, d["edges"].ptr)
+                           d["node_ptr"].ptr, d["nodes"].ptr, d["edge_ptr"].ptr, d["edges"].ptr,
+                           0, None, None, None, None, None)
+        if self.n_unary:
+            unary_node = np.asarray(g["unary_node"], dtype=np.int32)
+            unary_ref = np.ascontiguousarray(g["unary_ref"], dtype=np.float64)
+            if unary_ref.shape != (self.n_unary, arena.C):
+                raise ValueError("unary_ref must be (n_unary, CHANNELS)")
+            if unary_node.min() < 0 or unary_node.max() >= self.n_nodes:
+                raise ValueError("unary_node out of range")
+            u_ptr, u_ids = _csr(node_problem[unary_node], self.n_problems)
+            d["unary_node"] = ctx.to_device(unary_node, np.int32)
+            d["unary_ref"] = ctx.to_device(unary_ref, np.float64)
+            d["unary_ptr"] = ctx.to_device(u_ptr, np.int64)
+            d["unary_ids"] = ctx.to_device(u_ids, np.int32)
+            v = self.view
+            v.n_unary = self.n_unary
+            v.d_unary_node, v.d_unary_ref = d["unary_node"].ptr, d["unary_ref"].ptr
+            v.d_prob_unary_ptr, v.d_prob_unary = d["unary_ptr"].ptr, d["unary_ids"].ptr
+            if g.get("unary_w") is not None:
+                d["unary_w"] = ctx.to_device(g["unary_w"], np.float64)
+                v.d_unary_w = d["unary_w"].ptr
         self.problem_sizes = np.diff(edge_ptr)
 
     def eval(self, cfg, loss, materialize=False):

@@ -15,6 +15,10 @@ struct pxr_ctx {
   double* d_scratch = nullptr;   // small reduction scratch (device)
   size_t scratch_bytes = 0;
   int num_cus = 256;
+  void* d_workspace = nullptr;   // grow-only solver workspace (KA), reused across calls
+  size_t workspace_bytes = 0;
+  void* d_workspace_mat = nullptr;   // grow-only storage of the KA normal-matrix blocks
+  size_t workspace_mat_bytes = 0;
 };
 
 struct pxr_arena {

@@ -36,7 +36,10 @@
 
 namespace pxr {
 
-constexpr int KA_NLDS = 112;   // LDS budget for the damped blocks: KA_NLDS^2 doubles (98 KiB)
+constexpr int KA_NT = 256;     // threads per sub-problem workgroup
+constexpr int KA_NLDS = 100;   // LDS budget for the damped blocks: KA_NLDS^2 doubles (78 KiB: two workgroups per CU,
+                               // which is also what the kernel's ~240 VGPRs allow; forcing 3 waves/SIMD spills and
+                               // was measured to MISCOMPILE (deterministic wrong steps), so occupancy is left alone)
 
 struct KaArgs {
   pxr_ka_view v;
@@ -79,16 +82,19 @@ __device__ __forceinline__ void ka_eval_node(const KaArgs& a, int64_t node, cons
 
 __device__ __forceinline__ double lpo_sum(double v, int LPO) { return LPO == 16 ? row16_sum(v) : row8_sum(v); }
 
-// block-wide sum, result broadcast to every thread (256 threads)
+// block-wide sum, result broadcast to every thread (KA_NT threads)
 __device__ __forceinline__ double block_sum(double v, double* sh4) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
   __syncthreads();
-  return sh4[0] + sh4[1] + sh4[2] + sh4[3];
+  double t = sh4[0];
+#pragma unroll
+  for (int k = 1; k < KA_NT / 64; ++k) t += sh4[k];
+  return t;
 }
 
-// block-wide exclusive prefix sum over the 256 threads (in thread order); total broadcast
+// block-wide exclusive prefix sum over the KA_NT threads (in thread order); total broadcast
 __device__ __forceinline__ int block_excl_scan(int v, int* sh_scan, int& total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int x = v;
@@ -98,7 +104,9 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh_scan, int& total) 
   __syncthreads();
   int base = 0;
   for (int k = 0; k < w; ++k) base += sh_scan[k];
-  total = sh_scan[0] + sh_scan[1] + sh_scan[2] + sh_scan[3];
+  total = 0;
+#pragma unroll
+  for (int k = 0; k < KA_NT / 64; ++k) total += sh_scan[k];
   return base + x - v;
 }
 
@@ -120,7 +128,7 @@ struct KaProb {
 // evaluate all nodes of the problem at keypoints `kp`
 template <typename ST, int C, bool WITH_JAC>
 __device__ void ka_nodes(const KaArgs& a, const KaProb& p, const double* kp, bool fsimd) {
-  constexpr int LPO = C / 8, G = 256 / LPO;
+  constexpr int LPO = C / 8, G = KA_NT / LPO;
   const int grp = threadIdx.x / LPO, sub = threadIdx.x % LPO;
   for (int64_t i = p.np0 + grp; i < p.np1; i += G) {
     const int64_t node = a.v.d_prob_nodes[i];
@@ -144,7 +152,7 @@ __device__ __forceinline__ double ka_kappa(double s, const double* rho) {
 // and g (unscaled).
 template <int C, bool WITH_JAC>
 __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
-  constexpr int LPO = C / 8, G = 256 / LPO;
+  constexpr int LPO = C / 8, G = KA_NT / LPO;
   const int grp = threadIdx.x / LPO, sub = threadIdx.x % LPO;
   double cost = 0.0;
   for (int64_t i = p.ne0 + grp; i < p.ne1; i += G) {
@@ -303,9 +311,9 @@ __device__ bool ka_chol_block(double* A, int n, double* b) {
     const double piv = d > 0.0 ? sqrt(d) : 1.0, inv = 1.0 / piv;
     __syncthreads();
     if (tid == 0) A[(size_t)j * n + j] = piv;
-    for (int i = j + 1 + tid; i < n; i += 256) A[(size_t)i * n + j] *= inv;
+    for (int i = j + 1 + tid; i < n; i += KA_NT) A[(size_t)i * n + j] *= inv;
     __syncthreads();
-    for (int i = j + 1 + ti; i < n; i += 16) {
+    for (int i = j + 1 + ti; i < n; i += KA_NT / 16) {
       const double lij = A[(size_t)i * n + j];
       for (int c = j + 1 + tj; c <= i; c += 16) A[(size_t)i * n + c] -= lij * A[(size_t)c * n + j];
     }
@@ -315,14 +323,14 @@ __device__ bool ka_chol_block(double* A, int n, double* b) {
     const double yj = b[j] / A[(size_t)j * n + j];
     __syncthreads();
     if (tid == 0) b[j] = yj;
-    for (int i = j + 1 + tid; i < n; i += 256) b[i] -= A[(size_t)i * n + j] * yj;
+    for (int i = j + 1 + tid; i < n; i += KA_NT) b[i] -= A[(size_t)i * n + j] * yj;
     __syncthreads();
   }
   for (int j = n - 1; j >= 0; --j) {   // backward: L^T x = y
     const double xj = b[j] / A[(size_t)j * n + j];
     __syncthreads();
     if (tid == 0) b[j] = xj;
-    for (int i = tid; i < j; i += 256) b[i] -= A[(size_t)j * n + i] * xj;
+    for (int i = tid; i < j; i += KA_NT) b[i] -= A[(size_t)j * n + i] * xj;
     __syncthreads();
   }
   return ok;
@@ -374,36 +382,29 @@ __device__ __forceinline__ bool ka_chol_2x2(const double* A, double* b) {
   return ok;
 }
 
-template <typename ST, int C>
-__global__ __launch_bounds__(256) void ka_solve_kernel(const KaArgs a) {
-  extern __shared__ double sh_A[];      // lds_elems doubles (damped blocks) when the sub-problem fits
-  __shared__ double sh4[4];
-  __shared__ int sh_scan[4];
-  __shared__ int sh_flag, sh_feasible, sh_maxnc, sh_ok;
+// ---- setup: one workgroup per sub-problem finds the connected components of its variable nodes,
+// lays the unknowns out component by component and writes the box bounds.  Its per-problem block
+// sizes let the host size the normal-matrix storage exactly before the solve kernel starts.
+struct KaInfo { int n, ncomp, hsz, maxnc, feasible; };
+
+__global__ __launch_bounds__(KA_NT) void ka_setup_kernel(const KaArgs a, KaInfo* __restrict__ info) {
+  __shared__ int sh_scan[KA_NT / 64];
+  __shared__ int sh_flag, sh_feasible, sh_maxnc;
   const int prob = blockIdx.x, tid = threadIdx.x;
-  const bool fsimd = a.float_simd != 0;
   KaProb p;
   p.np0 = a.v.d_prob_node_ptr[prob]; p.np1 = a.v.d_prob_node_ptr[prob + 1];
   p.ne0 = a.v.d_prob_edge_ptr[prob]; p.ne1 = a.v.d_prob_edge_ptr[prob + 1];
   p.nu0 = p.nu1 = 0;
   if (a.v.n_unary > 0) { p.nu0 = a.v.d_prob_unary_ptr[prob]; p.nu1 = a.v.d_prob_unary_ptr[prob + 1]; }
   const size_t vstride = 2 * (size_t)a.v.n_nodes, vb = 2 * (size_t)p.np0;
-  p.g = a.vec + 0 * vstride + vb; p.gun = a.vec + 1 * vstride + vb; p.scale = a.vec + 2 * vstride + vb;
-  p.diag = a.vec + 3 * vstride + vb; p.step = a.vec + 4 * vstride + vb; p.delta = a.vec + 5 * vstride + vb;
-  p.lo = a.vec + 6 * vstride + vb; p.hi = a.vec + 7 * vstride + vb; p.rhs = a.vec + 8 * vstride + vb;
+  p.lo = a.vec + 6 * vstride + vb; p.hi = a.vec + 7 * vstride + vb;
   p.row_off = a.irow + 0 * vstride + vb; p.row_v0 = a.irow + 1 * vstride + vb; p.row_nc = a.irow + 2 * vstride + vb;
   p.comp_v0 = a.comp_v0 + p.np0;
-  p.Hm = a.Hbuf + a.prob_h_ptr[prob];
   const int nloc = (int)(p.np1 - p.np0);
   int* cnt = a.ipos + 0 * (size_t)a.v.n_nodes + p.np0;
   int* cstart = a.ipos + 1 * (size_t)a.v.n_nodes + p.np0;
   int* hoff = a.ipos + 2 * (size_t)a.v.n_nodes + p.np0;
   int* cidx = a.ipos + 3 * (size_t)a.v.n_nodes + p.np0;
-  pxr_lm_summary sm;
-  sm.iterations = 0; sm.num_successful = 0; sm.termination = PXR_TERM_NO_CONVERGENCE;
-  sm.num_camera_unknowns = 0; sm.num_point_unknowns = 0; sm.initial_cost = 0; sm.final_cost = 0;
-  sm.final_radius = 0; sm.total_ms = 0; sm.setup_ms = 0;
-
   // will_be_optimized_ (featuremetric_keypoint_optimizer.h:198-199): nodes touched by a residual block
   for (int64_t i = p.ne0 + tid; i < p.ne1; i += blockDim.x) {
     const int e = a.v.d_prob_edges[i];
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(256) void ka_solve_kernel(const KaArgs a) {
   __syncthreads();
   // component order = order of first nodes; scans give each component's first unknown, block offset, index
   int run_nodes = 0, run_h = 0, run_c = 0;
-  for (int base = 0; base < nloc; base += 256) {
+  for (int base = 0; base < nloc; base += KA_NT) {
     const int i = base + tid;
     const int c = i < nloc ? cnt[i] : 0;
     int tot;
@@ -468,7 +469,6 @@ __global__ __launch_bounds__(256) void ka_solve_kernel(const KaArgs a) {
   }
   __syncthreads();
   const int n = 2 * run_nodes, hsz = run_h;
-  p.n = n; p.ncomp = run_c;
   // unknown layout: components in order, nodes inside a component in ascending order; box bounds
   // (keypoint_optimizer.h:127-152)
   for (int i = tid; i < nloc; i += blockDim.x) {
@@ -498,7 +498,41 @@ __global__ __launch_bounds__(256) void ka_solve_kernel(const KaArgs a) {
     a.var_of_node[node] = v;
   }
   __syncthreads();
-  const int maxnc = sh_maxnc;
+  if (tid == 0) {
+    KaInfo o;
+    o.n = n; o.ncomp = run_c; o.hsz = hsz; o.maxnc = sh_maxnc; o.feasible = sh_feasible;
+    info[prob] = o;
+  }
+}
+
+
+template <typename ST, int C>
+__global__ __launch_bounds__(KA_NT) void ka_solve_kernel(const KaArgs a, const KaInfo* __restrict__ info) {
+  extern __shared__ double sh_A[];      // lds_elems doubles (damped blocks) when the sub-problem fits
+  __shared__ double sh4[KA_NT / 64];
+  __shared__ int sh_ok;
+  const int prob = blockIdx.x, tid = threadIdx.x;
+  const bool fsimd = a.float_simd != 0;
+  KaProb p;
+  p.np0 = a.v.d_prob_node_ptr[prob]; p.np1 = a.v.d_prob_node_ptr[prob + 1];
+  p.ne0 = a.v.d_prob_edge_ptr[prob]; p.ne1 = a.v.d_prob_edge_ptr[prob + 1];
+  p.nu0 = p.nu1 = 0;
+  if (a.v.n_unary > 0) { p.nu0 = a.v.d_prob_unary_ptr[prob]; p.nu1 = a.v.d_prob_unary_ptr[prob + 1]; }
+  const size_t vstride = 2 * (size_t)a.v.n_nodes, vb = 2 * (size_t)p.np0;
+  p.g = a.vec + 0 * vstride + vb; p.gun = a.vec + 1 * vstride + vb; p.scale = a.vec + 2 * vstride + vb;
+  p.diag = a.vec + 3 * vstride + vb; p.step = a.vec + 4 * vstride + vb; p.delta = a.vec + 5 * vstride + vb;
+  p.lo = a.vec + 6 * vstride + vb; p.hi = a.vec + 7 * vstride + vb; p.rhs = a.vec + 8 * vstride + vb;
+  p.row_off = a.irow + 0 * vstride + vb; p.row_v0 = a.irow + 1 * vstride + vb; p.row_nc = a.irow + 2 * vstride + vb;
+  p.comp_v0 = a.comp_v0 + p.np0;
+  p.Hm = a.Hbuf + a.prob_h_ptr[prob];
+  pxr_lm_summary sm;
+  sm.iterations = 0; sm.num_successful = 0; sm.termination = PXR_TERM_NO_CONVERGENCE;
+  sm.num_camera_unknowns = 0; sm.num_point_unknowns = 0; sm.initial_cost = 0; sm.final_cost = 0;
+  sm.final_radius = 0; sm.total_ms = 0; sm.setup_ms = 0;
+
+  const KaInfo inf = info[prob];
+  const int n = inf.n, hsz = inf.hsz, maxnc = inf.maxnc;
+  p.n = n; p.ncomp = inf.ncomp;
   sm.num_camera_unknowns = n;
   double* A = (hsz <= a.lds_elems) ? sh_A : (a.Abuf + a.prob_h_ptr[prob]);
   const pxr_lm_options& opt = a.opt;
@@ -541,7 +575,7 @@ __global__ __launch_bounds__(256) void ka_solve_kernel(const KaArgs a) {
   }
   double cost = linearize(true);
   sm.initial_cost = cost;
-  if (!sh_feasible) {   // [upstream] Program::IsFeasible fails: FAILURE, parameters untouched
+  if (!inf.feasible) {   // [upstream] Program::IsFeasible fails: FAILURE, parameters untouched
     sm.final_cost = cost; sm.termination = PXR_TERM_FAILURE;
     if (tid == 0) a.summaries[prob] = sm;
     return;
@@ -571,7 +605,7 @@ __global__ __launch_bounds__(256) void ka_solve_kernel(const KaArgs a) {
       if (p.row_nc[v0] == 2 && !ka_chol_2x2(A + p.row_off[v0], p.step + v0)) sh_ok = 0;
     }
     if (maxnc > 2) {
-      for (int c = tid >> 6; c < p.ncomp; c += 4) {
+      for (int c = tid >> 6; c < p.ncomp; c += KA_NT / 64) {
         const int v0 = p.comp_v0[c], nc = p.row_nc[v0];
         if (nc > 2 && nc <= 64 && !ka_chol_wave(A + p.row_off[v0], nc, p.step + v0)) sh_ok = 0;
       }
@@ -774,57 +808,76 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   const int np = view->n_problems;
   memset(total, 0, sizeof(*total));
   if (np == 0) return PXR_OK;
-  // per-problem normal-matrix offsets from the node counts (upper bound 2 * nodes unknowns)
   std::vector<int64_t> node_ptr(np + 1), h_ptr(np + 1, 0);
   PXR_HIP(hipMemcpyAsync(node_ptr.data(), view->d_prob_node_ptr, sizeof(int64_t) * (np + 1), hipMemcpyDeviceToHost, st));
   PXR_HIP(hipStreamSynchronize(st));
   PXR_REQUIRE(node_ptr[0] == 0 && node_ptr[np] <= view->n_nodes, "pxr_ka_solve: every node belongs to at most one sub-problem");
-  int64_t largest = 1;
   for (int i = 0; i < np; ++i) {
     const int64_t nmax = 2 * (node_ptr[i + 1] - node_ptr[i]);
     PXR_REQUIRE(nmax >= 0 && nmax < 46000, "pxr_ka_solve: sub-problem too large (< 23000 nodes each)");
-    h_ptr[i + 1] = h_ptr[i] + nmax * nmax;
-    largest = std::max(largest, nmax);
   }
-  // LDS for the damped blocks: enough for the largest sub-problem as ONE dense block, capped; the
-  // block-diagonal storage of most sub-problems is far smaller and several workgroups share a CU
-  const int lds_elems = (int)std::min<int64_t>(largest * largest, (int64_t)KA_NLDS * KA_NLDS);
-  const bool need_aglob = largest * largest > lds_elems;
   const auto t0 = std::chrono::steady_clock::now();
-  KaBuf<double> desc, kp_cand, vec, Hbuf, Abuf;
-  KaBuf<int> var_of_node, label, ipos, irow, comp_v0;
-  KaBuf<uint8_t> used;
-  KaBuf<int64_t> d_hptr;
-  KaBuf<pxr_lm_summary> d_sum;
+  // every scratch array is carved out of the context's grow-only workspaces (no hipMalloc per call
+  // once they have reached their high-water mark)
+  auto grow = [&](void** buf, size_t* have, size_t want) -> int {
+    if (want <= *have) return PXR_OK;
+    PXR_HIP(hipStreamSynchronize(st));
+    if (*buf) { PXR_HIP(hipFree(*buf)); *buf = nullptr; *have = 0; }
+    PXR_HIP(hipMalloc(buf, want));
+    *have = want;
+    return PXR_OK;
+  };
   const size_t nn = (size_t)view->n_nodes;
-  if (int rc = desc.alloc(nn * 3 * arena->C)) return rc;
-  if (int rc = kp_cand.alloc(nn * 2)) return rc;
-  if (int rc = vec.alloc(nn * 2 * 9)) return rc;
-  if (int rc = Hbuf.alloc((size_t)h_ptr[np])) return rc;
-  if (int rc = Abuf.alloc(need_aglob ? (size_t)h_ptr[np] : 1)) return rc;
-  if (int rc = var_of_node.alloc(nn)) return rc;
-  if (int rc = label.alloc(nn)) return rc;
-  if (int rc = ipos.alloc(nn * 4)) return rc;
-  if (int rc = irow.alloc(nn * 2 * 3)) return rc;
-  if (int rc = comp_v0.alloc(nn)) return rc;
-  if (int rc = used.alloc(nn)) return rc;
-  if (int rc = d_hptr.alloc(np + 1)) return rc;
-  if (int rc = d_sum.alloc(np)) return rc;
-  PXR_HIP(hipMemsetAsync(used.p, 0, nn, st));
-  PXR_HIP(hipMemcpyAsync(d_hptr.p, h_ptr.data(), sizeof(int64_t) * (np + 1), hipMemcpyHostToDevice, st));
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_desc = carve(sizeof(double) * nn * 3 * arena->C), o_cand = carve(sizeof(double) * nn * 2);
+  const size_t o_vec = carve(sizeof(double) * nn * 2 * 9);
+  const size_t o_var = carve(sizeof(int) * nn), o_label = carve(sizeof(int) * nn), o_ipos = carve(sizeof(int) * nn * 4);
+  const size_t o_irow = carve(sizeof(int) * nn * 6), o_comp = carve(sizeof(int) * nn), o_used = carve(nn);
+  const size_t o_hptr = carve(sizeof(int64_t) * (np + 1)), o_sum = carve(sizeof(pxr_lm_summary) * np);
+  const size_t o_info = carve(sizeof(KaInfo) * np);
+  if (int rc = grow(&ctx->d_workspace, &ctx->workspace_bytes, off)) return rc;
+  char* ws = static_cast<char*>(ctx->d_workspace);
+  int64_t* d_hptr = (int64_t*)(ws + o_hptr);
+  pxr_lm_summary* d_sum = (pxr_lm_summary*)(ws + o_sum);
+  KaInfo* d_info = (KaInfo*)(ws + o_info);
+  PXR_HIP(hipMemsetAsync(ws + o_used, 0, nn, st));
   KaArgs a{};
   fill_args(ctx, arena, view, cfg, loss, a);
   a.bound = bound; a.opt = *options;
-  a.desc = desc.p; a.kp_cand = kp_cand.p; a.var_of_node = var_of_node.p; a.used = used.p; a.vec = vec.p;
-  a.label = label.p; a.ipos = ipos.p; a.irow = irow.p; a.comp_v0 = comp_v0.p;
-  a.prob_h_ptr = d_hptr.p; a.Hbuf = Hbuf.p; a.Abuf = Abuf.p; a.summaries = d_sum.p;
+  a.desc = (double*)(ws + o_desc); a.kp_cand = (double*)(ws + o_cand); a.vec = (double*)(ws + o_vec);
+  a.var_of_node = (int*)(ws + o_var); a.label = (int*)(ws + o_label); a.ipos = (int*)(ws + o_ipos);
+  a.irow = (int*)(ws + o_irow); a.comp_v0 = (int*)(ws + o_comp); a.used = (uint8_t*)(ws + o_used);
+  a.prob_h_ptr = d_hptr; a.summaries = d_sum;
+  // 1. components, unknown layout, bounds; the block sizes come back to size the matrices exactly
+  hipLaunchKernelGGL(ka_setup_kernel, dim3(np), dim3(KA_NT), 0, st, a, d_info);
+  PXR_HIP(hipGetLastError());
+  std::vector<KaInfo> infos(np);
+  PXR_HIP(hipMemcpyAsync(infos.data(), d_info, sizeof(KaInfo) * np, hipMemcpyDeviceToHost, st));
+  PXR_HIP(hipStreamSynchronize(st));
+  int64_t largest = 1;
+  for (int i = 0; i < np; ++i) {
+    h_ptr[i + 1] = h_ptr[i] + infos[i].hsz;
+    largest = std::max<int64_t>(largest, infos[i].hsz);
+  }
+  // LDS for the damped blocks: the largest block-diagonal system, capped so that two workgroups
+  // share a CU; sub-problems beyond the cap keep their damped blocks in global memory (L2)
+  const int lds_elems = (int)std::min<int64_t>(largest, (int64_t)KA_NLDS * KA_NLDS);
+  const bool need_aglob = largest > lds_elems;
+  const size_t hbytes = (sizeof(double) * (size_t)h_ptr[np] + 255) & ~(size_t)255;
+  if (int rc = grow(&ctx->d_workspace_mat, &ctx->workspace_mat_bytes, hbytes * (need_aglob ? 2 : 1) + 256)) return rc;
+  a.Hbuf = (double*)ctx->d_workspace_mat;
+  a.Abuf = need_aglob ? (double*)((char*)ctx->d_workspace_mat + hbytes) : a.Hbuf;
   a.lds_elems = lds_elems;
+  PXR_HIP(hipMemcpyAsync(d_hptr, h_ptr.data(), sizeof(int64_t) * (np + 1), hipMemcpyHostToDevice, st));
   const size_t shmem = sizeof(double) * (size_t)lds_elems;
 #define KA_SOLVE_LAUNCH(ST, CC)                                                                              \
   do {                                                                                                       \
     PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ka_solve_kernel<ST, CC>),                      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                    \
-    hipLaunchKernelGGL((ka_solve_kernel<ST, CC>), dim3(np), dim3(256), shmem, st, a);                        \
+    PXR_HIP(hipEventRecord(ctx->ev_start, st));                                                              \
+    hipLaunchKernelGGL((ka_solve_kernel<ST, CC>), dim3(np), dim3(KA_NT), shmem, st, a, d_info);              \
+    PXR_HIP(hipEventRecord(ctx->ev_stop, st));                                                               \
   } while (0)
   if (arena->dtype == PXR_F16 && arena->C == 128) KA_SOLVE_LAUNCH(_Float16, 128);
   else if (arena->dtype == PXR_F16 && arena->C == 64) KA_SOLVE_LAUNCH(_Float16, 64);
@@ -834,9 +887,14 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
 #undef KA_SOLVE_LAUNCH
   PXR_HIP(hipGetLastError());
   std::vector<pxr_lm_summary> sums(np);
-  PXR_HIP(hipMemcpyAsync(sums.data(), d_sum.p, sizeof(pxr_lm_summary) * np, hipMemcpyDeviceToHost, st));
+  PXR_HIP(hipMemcpyAsync(sums.data(), d_sum, sizeof(pxr_lm_summary) * np, hipMemcpyDeviceToHost, st));
   PXR_HIP(hipStreamSynchronize(st));
   total->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  {   // setup_ms = everything but the solve kernel itself (workspace, uploads, summaries download)
+    float kms = 0.f;
+    PXR_HIP(hipEventElapsedTime(&kms, ctx->ev_start, ctx->ev_stop));
+    total->setup_ms = total->total_ms - (double)kms;
+  }
   total->termination = PXR_TERM_CONVERGENCE;
   for (int i = 0; i < np; ++i) {   // AccumulateSummaries (util/src/statistics.h:131-160)
     total->initial_cost += sums[i].initial_cost; total->final_cost += sums[i].final_cost;

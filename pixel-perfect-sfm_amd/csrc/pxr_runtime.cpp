@@ -49,6 +49,8 @@ int pxr_ctx_destroy(pxr_ctx* ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   if (ctx->d_scratch) hipFree(ctx->d_scratch);
+  if (ctx->d_workspace) hipFree(ctx->d_workspace);
+  if (ctx->d_workspace_mat) hipFree(ctx->d_workspace_mat);
   if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) hipEventDestroy(ctx->ev_stop);
   delete ctx;

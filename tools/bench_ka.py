@@ -83,6 +83,9 @@ def main():
         cost, _, _, _ = ka.eval(cfg, ls)
     ms = ctx.timer_stop() / args.steps
     c0 = float(cost.download().sum())
+    cold, _ = ka.solve(cfg, ls, bound=4.0)          # first call: grows the context workspace
+    ka.d["kp"].upload(np.ascontiguousarray(prob["kp"], dtype=np.float64))
+    ctx.sync()
     t0 = time.perf_counter()
     total, _ = ka.solve(cfg, ls, bound=4.0)
     wall = time.perf_counter() - t0
@@ -97,7 +100,8 @@ def main():
                        % (args.tracks, tl, ka.n_edges, ka.n_problems),
            "edge_eval": {"edges_per_s": ka.n_edges / (ms * 1e-3), "kernel_ms": ms,
                          "algorithmic_GBps": 8244 * ka.n_edges / (ms * 1e-3) / 1e9},
-           "solve": {"wall_ms": wall * 1e3, "kernel_ms": total["total_ms"], "lm_iterations_max": total["iterations"],
+           "solve": {"wall_ms": wall * 1e3, "first_call_ms": cold["total_ms"], "total_ms": total["total_ms"],
+                     "kernel_ms": total["total_ms"] - total["setup_ms"], "lm_iterations_max": total["iterations"],
                      "successful_steps": total["num_successful"], "initial_cost": total["initial_cost"],
                      "final_cost": total["final_cost"], "initial_cost_check": c0},
            "accuracy_px": {"median_before": float(np.median(err0)), "median_after": float(np.median(err1)),

@@ -37,9 +37,10 @@
 namespace pxr {
 
 constexpr int KA_NT = 256;     // threads per sub-problem workgroup
-constexpr int KA_NLDS = 100;   // LDS budget for the damped blocks: KA_NLDS^2 doubles (78 KiB: two workgroups per CU,
-                               // which is also what the kernel's ~240 VGPRs allow; forcing 3 waves/SIMD spills and
-                               // was measured to MISCOMPILE (deterministic wrong steps), so occupancy is left alone)
+constexpr int KA_NLDS = 100;   // LDS budget for the damped blocks: KA_NLDS^2 doubles (78 KiB).  Occupancy is set by the
+                               // ~284 VGPRs of the 16-texel bicubic stencil + LM state (one workgroup per CU); capping
+                               // them (amdgpu_waves_per_eu) spills to scratch and was measured to produce wrong steps,
+                               // so the register budget is left to the compiler
 
 struct KaArgs {
   pxr_ka_view v;
@@ -130,6 +131,7 @@ template <typename ST, int C, bool WITH_JAC>
 __device__ void ka_nodes(const KaArgs& a, const KaProb& p, const double* kp, bool fsimd) {
   constexpr int LPO = C / 8, G = KA_NT / LPO;
   const int grp = threadIdx.x / LPO, sub = threadIdx.x % LPO;
+#pragma nounroll
   for (int64_t i = p.np0 + grp; i < p.np1; i += G) {
     const int64_t node = a.v.d_prob_nodes[i];
     if (!a.used[node]) continue;
@@ -155,6 +157,7 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
   constexpr int LPO = C / 8, G = KA_NT / LPO;
   const int grp = threadIdx.x / LPO, sub = threadIdx.x % LPO;
   double cost = 0.0;
+#pragma nounroll
   for (int64_t i = p.ne0 + grp; i < p.ne1; i += G) {
     const int e = a.v.d_prob_edges[i];
     const int n1 = a.v.d_edge_src[e], n2 = a.v.d_edge_dst[e];
@@ -209,6 +212,7 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
     }
   }
   // FeatureReference2DCostFunctor blocks: r = f - ref, J = [gx gy]
+#pragma nounroll
   for (int64_t i = p.nu0 + grp; i < p.nu1; i += G) {
     const int u = a.v.d_prob_unary[i];
     const int n1 = a.v.d_unary_node[u];
@@ -860,8 +864,7 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
     h_ptr[i + 1] = h_ptr[i] + infos[i].hsz;
     largest = std::max<int64_t>(largest, infos[i].hsz);
   }
-  // LDS for the damped blocks: the largest block-diagonal system, capped so that two workgroups
-  // share a CU; sub-problems beyond the cap keep their damped blocks in global memory (L2)
+  // LDS for the damped blocks: the largest block-diagonal system, capped at half a CU's LDS; sub-problems beyond the cap keep their damped blocks in global memory (L2)
   const int lds_elems = (int)std::min<int64_t>(largest, (int64_t)KA_NLDS * KA_NLDS);
   const bool need_aglob = largest > lds_elems;
   const size_t hbytes = (sizeof(double) * (size_t)h_ptr[np] + 255) & ~(size_t)255;

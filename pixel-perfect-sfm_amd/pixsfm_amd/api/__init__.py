@@ -1,6 +1,6 @@
 """pixsfm-compatible Python surface of the accelerated KA/BA path (same class / method names as
 pixsfm.keypoint_adjustment, pixsfm.bundle_adjustment, pixsfm._pixsfm._base/_features)."""
-from . import base, features, reconstruction  # noqa: F401
+from . import base, features, localization, reconstruction  # noqa: F401
 from .bundle_adjustment import (BundleAdjuster, BundleAdjustmentSetup, FeatureReferenceBundleAdjuster,  # noqa: F401
                                 FeatureReferenceBundleOptimizer, FeatureView, ReferenceExtractor,
                                 default_problem_setup)
@@ -8,3 +8,4 @@ from .keypoint_adjustment import (FeatureMetricKeypointAdjuster, FeatureMetricKe
                                   KeypointAdjuster, KeypointAdjustmentSetup,
                                   TopologicalReferenceKeypointAdjuster, TopologicalReferenceKeypointOptimizer,
                                   build_matching_graph, find_problem_labels)
+from .localization import QueryKeypointAdjuster, QueryKeypointOptimizer, find_feature_inliers  # noqa: F401,E402

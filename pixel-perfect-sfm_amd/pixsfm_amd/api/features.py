@@ -103,9 +103,14 @@ class FeatureManager:
 class Reference:
     """features/src/references.h:29-72 (N_NODES = 1): source observation + 1 x C descriptor."""
 
-    def __init__(self, image_id, point2D_idx, descriptor):
+    def __init__(self, image_id, point2D_idx, descriptor, observations=None):
         self.source = (int(image_id), int(point2D_idx))
         self.descriptor = np.asarray(descriptor, dtype=np.float64).reshape(1, -1)
+        # per-observation descriptors (references.h:52-60), used by "all"-reference localization
+        self.observations = [np.asarray(o, dtype=np.float64).reshape(1, -1) for o in (observations or [])]
+
+    def has_observations(self):
+        return len(self.observations) > 0
 
 
 def to_arena(ctx, patch_list):

@@ -1,0 +1,192 @@
+"""Mirror of pixsfm's query keypoint adjustment (QKA) for the accelerated path:
+`QueryKeypointAdjuster(conf).refine(pnp_points2D, fmap, references, point2D_idxs)`
+(pixsfm/localization/main.py:89-192) and the `_localization.QueryKeypointOptimizer` it drives
+(pixsfm/localization/bindings.cc:36-57, src/single_query_keypoint_optimizer.h:86-222).
+
+One Ceres problem over all 2D-3D correspondences of a query, one FeatureReference2DCostFunctor
+block per (keypoint, reference descriptor), box bounds from the patch extent and `bound`
+(src/query_keypoint_optimizer.h:141-172).  Here: one pxr_ka_solve sub-problem whose terms are the
+unary reference terms of pxr_ka_view; the keypoints are independent 2x2 components of it.
+
+The pose refinement half of localization (QueryBundleAdjuster / PnP, main.py:194-560) is outside
+the accelerated path (control plane).
+"""
+from copy import deepcopy
+
+import numpy as np
+
+from ..engine import lm_options, make_loss
+from ..ka_engine import KAProblem
+from . import base, features
+from .keypoint_adjustment import default_context
+
+
+def resolve_level_indices(level_indices, n_levels):      # pixsfm/util/misc.py:19-23
+    if level_indices not in [None, "all"]:
+        return level_indices
+    return list(reversed(range(n_levels)))
+
+
+def _reference_descriptors(ref):
+    """The descriptors one correspondence contributes (single_query_keypoint_optimizer.h:86-222)."""
+    if isinstance(ref, features.Reference):
+        return ref.observations if ref.has_observations() else [ref.descriptor]
+    if isinstance(ref, (list, tuple)):
+        return [np.asarray(r, dtype=np.float64).reshape(1, -1) for r in ref]
+    return [np.asarray(ref, dtype=np.float64).reshape(1, -1)]
+
+
+def _build_problem(keypoints, fmap, references, patch_idxs, inliers, per_keypoint_problems=False):
+    n = len(keypoints)
+    if len(references) != n:
+        raise ValueError("references.size() != keypoints.rows()")           # THROW_CHECK_EQ, :96 / :134 / :180
+    if patch_idxs is not None and len(patch_idxs) != n:
+        raise ValueError("patch_idxs.size() != keypoints.rows()")           # :70-72
+    rows, patches, unary_node, unary_ref = [], [], [], []
+    for idx in range(n):
+        if inliers is not None and not inliers[idx]:
+            continue
+        descs = _reference_descriptors(references[idx])
+        if not descs:
+            continue                                                        # added_to_problem == false, :140-154
+        node = len(rows)
+        rows.append(idx)
+        patches.append(fmap.fpatch(idx if patch_idxs is None else patch_idxs[idx]))
+        for d in descs:
+            unary_node.append(node)
+            unary_ref.append(d.reshape(-1))
+    m = len(rows)
+    prob = dict(kp=np.asarray(keypoints, dtype=np.float64)[rows].reshape(-1, 2),
+                node_patch=np.arange(m, dtype=np.int64), node_const=np.zeros(m, np.uint8),
+                node_problem=np.arange(m, dtype=np.int32) if per_keypoint_problems else np.zeros(m, np.int32),
+                edge_src=np.zeros(0, np.int32), edge_dst=np.zeros(0, np.int32), edge_w=np.zeros(0),
+                unary_node=np.asarray(unary_node, dtype=np.int32),
+                unary_ref=np.asarray(unary_ref, dtype=np.float64).reshape(len(unary_node), -1), unary_w=None)
+    return rows, patches, prob
+
+
+def find_feature_inliers(p2Ds, fmap, references, interpolation_config, thresh=-1, ctx=None):
+    """localization/main.py:20-35: keep a correspondence when |f(patch_i, p2D_i) - reference_i| <= thresh
+    (only array references are tested; patch index = correspondence index, as in the reference).
+    The descriptor distances come from the device: one zero-iteration sub-problem per keypoint,
+    whose initial cost is 0.5 |f - ref|^2 under the trivial loss."""
+    inliers = [True] * len(p2Ds)
+    if thresh < 0.0 or len(p2Ds) == 0:
+        return inliers
+    tested = [i for i, r in enumerate(references) if isinstance(r, np.ndarray)]
+    if not tested:
+        return inliers
+    ic = interpolation_config if isinstance(interpolation_config, base.InterpolationConfig) \
+        else base.InterpolationConfig(interpolation_config)
+    ctx = ctx or default_context()
+    mask = [i in set(tested) for i in range(len(p2Ds))]
+    rows, patches, prob = _build_problem(np.asarray(p2Ds, dtype=np.float64), fmap, references, None, mask,
+                                         per_keypoint_problems=True)
+    arena = features.to_arena(ctx, patches)
+    ka = KAProblem(ctx, arena, prob)
+    _, per = ka.solve(ic.to_engine(), make_loss('trivial', []), bound=0.0, options=lm_options(max_iterations=0),
+                      per_problem=True)
+    arena.close()
+    for i, s in zip(rows, per):
+        if np.sqrt(2.0 * s['initial_cost']) > thresh:
+            inliers[i] = False
+    return inliers
+
+
+class QueryKeypointOptimizer:
+    """_localization.QueryKeypointOptimizer: ctor (options, interpolation_config);
+    run(keypoints, fmap, references, patch_idxs=None, inliers=None) refines `keypoints` in place and
+    returns False when the problem has no residuals (query_keypoint_optimizer.h:56-59)."""
+
+    option_defaults = {
+        'loss': {'name': 'trivial', 'params': []},
+        'solver': {**base.solver_default_conf, 'parameter_tolerance': 1e-05},
+        'print_summary': False, 'bound': 4.0,
+    }
+
+    def __init__(self, options=None, interpolation_config=None, ctx=None):
+        self.options = base.merge_conf(self.option_defaults, options)
+        ic = interpolation_config
+        self.interpolation = ic if isinstance(ic, base.InterpolationConfig) else base.InterpolationConfig(ic)
+        self.ctx = ctx
+        self.last_summary = None
+
+    def run(self, keypoints, fmap, references, patch_idxs=None, inliers=None):
+        keypoints = np.asarray(keypoints)
+        if keypoints.ndim != 2 or keypoints.shape[1] != 2 or keypoints.dtype != np.float64:
+            raise ValueError("keypoints must be an (N, 2) float64 array (refined in place)")
+        rows, patches, prob = _build_problem(keypoints, fmap, references, patch_idxs, inliers)
+        if len(prob['unary_node']) == 0:
+            return False
+        ctx = self.ctx or default_context()
+        arena = features.to_arena(ctx, patches)
+        o, s = self.options, self.options['solver']
+        # ParameterizeKeypoint: bounds when bound > 0 or the map is sparse (:145); the accelerated
+        # path holds sparse maps only (features.to_arena), so the patch box always applies.
+        ka = KAProblem(ctx, arena, prob)
+        lm = lm_options(max_iterations=s['max_num_iterations'], function_tolerance=s['function_tolerance'],
+                        gradient_tolerance=s['gradient_tolerance'], parameter_tolerance=s['parameter_tolerance'],
+                        max_consecutive_invalid_steps=s['max_num_consecutive_invalid_steps'])
+        total, _ = ka.solve(self.interpolation.to_engine(), make_loss(o['loss']['name'], o['loss']['params']),
+                            bound=o['bound'], options=lm)
+        keypoints[rows] = ka.keypoints()
+        self.last_summary = total
+        arena.close()
+        return True
+
+
+class QueryKeypointAdjuster:
+    """pixsfm/localization/main.py:89-192."""
+
+    default_conf = {
+        'apply': True,
+        'feature_inlier_thresh': -1,
+        'interpolation': base.interpolation_default_conf,
+        'level_indices': None,
+        'stack_correspondences': False,
+        'optimizer': {
+            'loss': {'name': 'trivial', 'params': []},
+            'solver': {**base.solver_default_conf, 'parameter_tolerance': 1e-05},
+            'print_summary': False,
+            'bound': 4.0,
+        },
+    }
+
+    def __init__(self, conf=None, callbacks=None, ctx=None):
+        self.conf = base.merge_conf(deepcopy(self.default_conf), conf)
+        self.ctx = ctx
+        self.solver = QueryKeypointOptimizer(self.conf['optimizer'], self.conf['interpolation'], ctx=ctx)
+
+    def refine(self, pnp_points2D, fmap, references, point2D_idxs=None):
+        qka_inliers = find_feature_inliers(pnp_points2D, fmap, references, self.conf['interpolation'],
+                                           thresh=self.conf['feature_inlier_thresh'], ctx=self.ctx)
+        if self.conf['stack_correspondences']:
+            self.refine_stacked(pnp_points2D, fmap, references, point2D_idxs, inliers=qka_inliers)
+        else:
+            self.solver.run(pnp_points2D, fmap, references, patch_idxs=point2D_idxs, inliers=qka_inliers)
+
+    def refine_multilevel(self, pnp_points2D, query_fmaps, references, point2D_idxs=None):
+        for l_idx in resolve_level_indices(self.conf['level_indices'], len(query_fmaps)):
+            self.refine(pnp_points2D, query_fmaps[l_idx], references[l_idx], point2D_idxs=point2D_idxs)
+
+    def refine_stacked(self, pnp_points2D, fmap, references, point2D_idxs, inliers=None):
+        if point2D_idxs is None:
+            raise ValueError("point2D_idxs must not be None in stacked QKA.")
+        unique_p2D_idxs = list(dict.fromkeys(point2D_idxs))
+        pos = {p: i for i, p in enumerate(unique_p2D_idxs)}
+        old_to_new = [pos[p] for p in point2D_idxs]
+        unique_kps = np.zeros((len(unique_p2D_idxs), 2), dtype=np.float64)
+        for idx, new in enumerate(old_to_new):
+            unique_kps[new] = pnp_points2D[idx]
+        stacked_refs = [[] for _ in unique_p2D_idxs]
+        for idx, query_ref in enumerate(references):
+            if not isinstance(query_ref, np.ndarray):
+                raise ValueError("Stacked QKA requires a np.ndarray reference for each 2D-3D correspondence. "
+                                 "Consider setting target_references='nearest'.")
+            stacked_refs[old_to_new[idx]].append(query_ref)
+        # the reference forwards the per-correspondence inlier list to the per-keypoint problem
+        # (main.py:186-188); it only has the right length when every point2D_idx is unique
+        run_inliers = inliers if inliers is not None and len(inliers) == len(unique_p2D_idxs) else None
+        self.solver.run(unique_kps, fmap, stacked_refs, patch_idxs=unique_p2D_idxs, inliers=run_inliers)
+        for i in range(len(point2D_idxs)):
+            pnp_points2D[i] = unique_kps[old_to_new[i]]

@@ -119,3 +119,29 @@ def test_flat_ba_matches_reference_parameterisation():
         setup2.set_constant_tvec(1, [0])                          # already constant pose
     labels = find_problem_labels(rec, 10)
     assert labels[0] == -1 and labels[1] == 0 and labels[20] == 2
+
+
+def test_qka_problem_assembly_and_validation():
+    """Host side of the localization QKA mirror: term assembly, inlier masks, argument checks."""
+    from pixsfm_amd.api import QueryKeypointAdjuster, features
+    from pixsfm_amd.api.localization import _build_problem, resolve_level_indices
+    rng = np.random.default_rng(0)
+    patches = rng.normal(size=(4, 16, 16, 128)).astype(np.float16)
+    fmap = features.FeatureMap.from_arrays(patches, np.arange(4), np.zeros((4, 2), np.int32), (1.0, 1.0))
+    kps = rng.uniform(4, 12, (3, 2))
+    refs = [rng.normal(size=128), features.Reference(0, 1, rng.normal(size=128), observations=[rng.normal(size=128)] * 2),
+            [rng.normal(size=128), rng.normal(size=128), rng.normal(size=128)]]
+    rows, plist, prob = _build_problem(kps, fmap, refs, [3, 1, 0], [True, True, True])
+    assert rows == [0, 1, 2] and prob["unary_node"].tolist() == [0, 1, 1, 2, 2, 2]
+    assert prob["unary_ref"].shape == (6, 128) and plist[0] is fmap.fpatch(3)
+    rows, _, prob = _build_problem(kps, fmap, refs, None, [True, False, True])
+    assert rows == [0, 2] and prob["unary_node"].tolist() == [0, 1, 1, 1] and np.array_equal(prob["kp"], kps[[0, 2]])
+    with pytest.raises(ValueError):
+        _build_problem(kps, fmap, refs[:2], None, None)
+    with pytest.raises(ValueError):
+        _build_problem(kps, fmap, refs, [0, 1], None)
+    assert resolve_level_indices(None, 3) == [2, 1, 0] and resolve_level_indices([0], 3) == [0]
+    adj = QueryKeypointAdjuster({"optimizer": {"bound": 2.0}})
+    assert adj.conf["optimizer"]["bound"] == 2.0 and adj.conf["optimizer"]["solver"]["parameter_tolerance"] == 1e-5
+    with pytest.raises(ValueError):
+        adj.refine_stacked(kps, fmap, refs, None)

@@ -109,3 +109,57 @@ def test_bundle_adjuster_like_pixsfm(ctx):
     for pid, ref in references.items():
         assert ref.source in [(e.image_id, e.point2D_idx) for e in rec.points3D[pid].track.elements]
         assert abs(np.linalg.norm(ref.descriptor) - 1) < 1e-12
+
+
+def test_query_keypoint_adjuster_like_pixsfm(ctx):
+    """localization QKA (localization/main.py:89-192): refine / stacked / feature-inlier gating
+    against the oracle solving the same one-problem-per-query system."""
+    import pxo
+    import pxo_ka
+    from pixsfm_amd import synthetic_ka
+    from pixsfm_amd.api import QueryKeypointAdjuster, features, find_feature_inliers
+    n = 24
+    base = synthetic_ka.make_ka_problem(n_tracks=n, track_len=2, seed=31, sigma=0.7)
+    q = np.arange(0, 2 * n, 2)
+    cfg = pxo.cfg()
+    refs = []
+    for nd in q + 1:           # the 3D point's reference = the descriptor of its other observation
+        p = pxo.make_patch(base["patches"][nd], base["corners"][nd], base["scales"][nd])
+        refs.append(pxo.ref2d_residual(p, cfg, base["true_xy"][nd], np.zeros(128))[0])
+    fmap = features.FeatureMap.from_arrays(base["patches"][q], np.arange(n), base["corners"][q], (1.0, 1.0))
+    kp0 = base["kp"][q].copy()
+    # oracle: one problem, unary terms only
+    oprob = dict(base)
+    oprob.update(kp=kp0.copy(), node_patch=q.astype(np.int64), node_const=np.zeros(n, np.uint8),
+                 node_problem=np.zeros(n, np.int32), edge_src=np.zeros(0, np.int32), edge_dst=np.zeros(0, np.int32),
+                 edge_w=np.zeros(0), unary_node=np.arange(n, dtype=np.int32), unary_ref=np.array(refs), unary_w=None)
+    kpo, sums = pxo_ka.ka_solve(oprob, cfg, pxo.loss("trivial"), 4.0, pxo.lm_options(parameter_tolerance=1e-5))
+    adjuster = QueryKeypointAdjuster(ctx=ctx)
+    kp = kp0.copy()
+    adjuster.refine(kp, fmap, [np.asarray(r) for r in refs])
+    assert np.abs(kp - kpo).max() < 1e-6
+    assert adjuster.solver.last_summary["iterations"] == sums[0]["iterations"]
+    assert np.median(np.linalg.norm(kp - base["true_xy"][q], axis=1)) < 0.05
+    # Reference objects (descriptor / per-observation descriptors) are accepted like arrays
+    kp2 = kp0.copy()
+    adjuster.refine(kp2, fmap, [features.Reference(0, i, r) for i, r in enumerate(refs)])
+    assert np.array_equal(kp2, kp)
+    # stacked: duplicated correspondences of one 2D point collapse onto one keypoint with two terms
+    idxs = list(range(n)) + [0, 1]
+    kp3 = np.concatenate([kp0, kp0[:2]])
+    stacked = QueryKeypointAdjuster({"stack_correspondences": True}, ctx=ctx)
+    stacked.refine(kp3, fmap, [np.asarray(r) for r in refs] + [np.asarray(refs[0]), np.asarray(refs[1])], point2D_idxs=idxs)
+    assert np.array_equal(kp3[-2:], kp3[:2]) and np.abs(kp3[:n] - kpo).max() < 1e-3
+    # feature-inlier gating: |f - ref| at the initial keypoints, thresholded
+    dist = []
+    for i, nd in enumerate(q):
+        p = pxo.make_patch(base["patches"][nd], base["corners"][nd], base["scales"][nd])
+        dist.append(np.linalg.norm(pxo.ref2d_residual(p, cfg, kp0[i], refs[i])[0]))
+    thr = float(np.median(dist))
+    inl = find_feature_inliers(kp0, fmap, [np.asarray(r) for r in refs], adjuster.conf["interpolation"], thresh=thr, ctx=ctx)
+    assert inl == [bool(d <= thr) for d in dist] and 0 < sum(inl) < n
+    gated = QueryKeypointAdjuster({"feature_inlier_thresh": thr}, ctx=ctx)
+    kp4 = kp0.copy()
+    gated.refine(kp4, fmap, [np.asarray(r) for r in refs])
+    out = ~np.array(inl)
+    assert np.array_equal(kp4[out], kp0[out]) and np.abs(kp4[~out] - kp0[~out]).max() > 1e-3

@@ -8,4 +8,5 @@ from .keypoint_adjustment import (FeatureMetricKeypointAdjuster, FeatureMetricKe
                                   KeypointAdjuster, KeypointAdjustmentSetup,
                                   TopologicalReferenceKeypointAdjuster, TopologicalReferenceKeypointOptimizer,
                                   build_matching_graph, find_problem_labels)
-from .localization import QueryKeypointAdjuster, QueryKeypointOptimizer, find_feature_inliers  # noqa: F401,E402
+from .localization import (QueryBundleAdjuster, QueryBundleOptimizer, QueryKeypointAdjuster,  # noqa: F401,E402
+                           QueryKeypointOptimizer, find_feature_inliers)  # noqa: F401,E402

@@ -8,14 +8,20 @@ block per (keypoint, reference descriptor), box bounds from the patch extent and
 (src/query_keypoint_optimizer.h:141-172).  Here: one pxr_ka_solve sub-problem whose terms are the
 unary reference terms of pxr_ka_view; the keypoints are independent 2x2 components of it.
 
-The pose refinement half of localization (QueryBundleAdjuster / PnP, main.py:194-560) is outside
-the accelerated path (control plane).
+`QueryBundleAdjuster(conf).refine(qvec, tvec, camera, points3D, fmap, references, inliers,
+point2D_idxs)` (main.py:194-258; src/single_query_bundle_optimizer.h:91-222, query_bundle_optimizer.h:
+114-151) is the one-image BA: FeatureReferenceCostFunctor blocks against CONSTANT 3D points, pose on
+the quaternion manifold, intrinsics constant unless refine_* says otherwise.  It runs on pxr_ba_solve
+with every (correspondence, reference descriptor) pair as its own constant point.
+
+PnP / retrieval / QueryLocalizer orchestration (main.py:261-560) stay outside the accelerated path
+(control plane).
 """
 from copy import deepcopy
 
 import numpy as np
 
-from ..engine import lm_options, make_loss
+from ..engine import BAProblem, lm_options, make_loss
 from ..ka_engine import KAProblem
 from . import base, features
 from .keypoint_adjustment import default_context
@@ -190,3 +196,115 @@ class QueryKeypointAdjuster:
         self.solver.run(unique_kps, fmap, stacked_refs, patch_idxs=unique_p2D_idxs, inliers=run_inliers)
         for i in range(len(point2D_idxs)):
             pnp_points2D[i] = unique_kps[old_to_new[i]]
+
+
+class QueryBundleOptimizer:
+    """_localization.QueryBundleOptimizer: ctor (options, interpolation_config);
+    run(qvec, tvec, camera, points3D, fmap, references, inliers=None, patch_idxs=None) refines qvec,
+    tvec (numpy arrays) and camera.params in place; False when no residual was added."""
+
+    option_defaults = {
+        'loss': {'name': 'cauchy', 'params': [0.25]},
+        'solver': {**base.solver_default_conf},
+        'print_summary': False,
+        'refine_focal_length': False, 'refine_principal_point': False, 'refine_extra_params': False,
+    }
+
+    def __init__(self, options=None, interpolation_config=None, ctx=None):
+        self.options = base.merge_conf(self.option_defaults, options)
+        ic = interpolation_config
+        self.interpolation = ic if isinstance(ic, base.InterpolationConfig) else base.InterpolationConfig(ic)
+        self.ctx = ctx
+        self.last_summary = None
+
+    def run(self, qvec, tvec, camera, points3D, fmap, references, inliers=None, patch_idxs=None):
+        n = len(points3D)
+        if len(references) != n:
+            raise ValueError("references.size() != points3D.size()")          # THROW_CHECK_EQ, :100 / :141 / :183
+        if patch_idxs is not None and len(patch_idxs) != n:
+            raise ValueError("patch_idxs.size() != points3D.size()")
+        if inliers is not None and len(inliers) != n:
+            raise ValueError("inliers.size() != points3D.size()")
+        for name, v, k in (("qvec", qvec, 4), ("tvec", tvec, 3)):
+            if not isinstance(v, np.ndarray) or v.dtype != np.float64 or v.size != k:
+                raise ValueError("%s must be a float64 numpy array of %d values (refined in place)" % (name, k))
+        patches, xyz, refs = [], [], []
+        for idx in range(n):
+            if inliers is not None and not inliers[idx]:
+                continue
+            patch = fmap.fpatch(idx if patch_idxs is None else patch_idxs[idx])
+            for d in _reference_descriptors(references[idx]):
+                patches.append(patch)
+                xyz.append(np.asarray(points3D[idx], dtype=np.float64).reshape(3))
+                refs.append(d.reshape(-1))
+        if not patches:
+            return False
+        ctx = self.ctx or default_context()
+        arena = features.to_arena(ctx, patches)
+        m = len(patches)
+        o, s = self.options, self.options['solver']
+        q = qvec.reshape(4)
+        params = np.zeros((1, 12))
+        params[0, :len(camera.params)] = camera.params
+        prob = dict(obs_image=np.zeros(m, np.int32), obs_point=np.arange(m, dtype=np.int32),
+                    obs_patch=np.arange(m, dtype=np.int64), image_camera=np.zeros(1, np.int32),
+                    qvec=q.reshape(1, 4).copy(), tvec=tvec.reshape(1, 3).copy(),
+                    cam_model=np.array([camera.model_id], np.int32), cam_params=params,
+                    xyz=np.array(xyz), refs=np.array(refs))
+        ba = BAProblem(ctx, arena, prob)
+        K = len(camera.params)
+        if not (o['refine_focal_length'] or o['refine_principal_point'] or o['refine_extra_params']):
+            cam_mask = (1 << K) - 1                                           # query_bundle_optimizer.h:121-126
+        else:
+            const = []
+            if not o['refine_focal_length']:
+                const += camera.focal_length_idxs()
+            if not o['refine_principal_point']:
+                const += camera.principal_point_idxs()
+            if not o['refine_extra_params']:
+                const += camera.extra_params_idxs()
+            cam_mask = sum(1 << a for a in const)
+        lm = lm_options(max_iterations=s['max_num_iterations'], function_tolerance=s['function_tolerance'],
+                        gradient_tolerance=s['gradient_tolerance'], parameter_tolerance=s['parameter_tolerance'],
+                        max_consecutive_invalid_steps=s['max_num_consecutive_invalid_steps'],
+                        use_inner_iterations=False)     # every point is constant: nothing for inner iterations
+        summary = ba.solve(self.interpolation.to_engine(), make_loss(o['loss']['name'], o['loss']['params']),
+                           np.zeros(1, np.uint8), np.zeros(1, np.uint8), np.array([cam_mask], np.uint16),
+                           np.ones(m, np.uint8), options=lm)
+        q_out, t_out, cam_out, _ = ba.params()
+        qvec.reshape(4)[:] = q_out[0]
+        tvec.reshape(3)[:] = t_out[0]
+        camera.params[:] = cam_out[0, :K]
+        self.last_summary = summary
+        arena.close()
+        return True
+
+
+class QueryBundleAdjuster:
+    """pixsfm/localization/main.py:194-258."""
+
+    default_conf = {
+        'apply': True,
+        'interpolation': base.interpolation_default_conf,
+        'level_indices': None,
+        'optimizer': {
+            'loss': {'name': 'cauchy', 'params': [0.25]},
+            'solver': {**base.solver_default_conf},
+            'print_summary': False,
+            'refine_focal_length': False, 'refine_principal_point': False, 'refine_extra_params': False,
+        },
+    }
+
+    def __init__(self, conf=None, callbacks=None, ctx=None):
+        self.conf = base.merge_conf(deepcopy(self.default_conf), conf)
+        self.solver = QueryBundleOptimizer(self.conf['optimizer'], self.conf['interpolation'], ctx=ctx)
+
+    def refine(self, qvec, tvec, camera, points3D, fmap, references, inliers=None, point2D_idxs=None):
+        return self.solver.run(qvec, tvec, camera, points3D, fmap, references, inliers=inliers,
+                               patch_idxs=point2D_idxs)
+
+    def refine_multilevel(self, qvec, tvec, camera, points3D, fmaps, references, inliers=None, point2D_idxs=None):
+        assert len(fmaps) == len(references)
+        for level in resolve_level_indices(self.conf['level_indices'], len(fmaps)):
+            self.refine(qvec, tvec, camera, points3D, fmaps[level], references[level], inliers=inliers,
+                        point2D_idxs=point2D_idxs)

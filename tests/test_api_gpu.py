@@ -163,3 +163,55 @@ def test_query_keypoint_adjuster_like_pixsfm(ctx):
     gated.refine(kp4, fmap, [np.asarray(r) for r in refs])
     out = ~np.array(inl)
     assert np.array_equal(kp4[out], kp0[out]) and np.abs(kp4[~out] - kp0[~out]).max() > 1e-3
+
+
+@pytest.mark.parametrize("refine_focal", [False, True])
+def test_query_bundle_adjuster_like_pixsfm(ctx, refine_focal):
+    """localization QBA (localization/main.py:194-258): one image, constant 3D points, pose on the
+    quaternion manifold (+ focal length when asked) -- vs the oracle LM on the same flat problem."""
+    import pxo
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.api import QueryBundleAdjuster, features
+    from pixsfm_amd.api.reconstruction import Camera
+    full = synthetic.make_ba_problem(n_cams=4, n_points=120, obs_per_point=3, seed=12, model=2, rot_deg=0.3, trans=0.02)
+    sel = np.nonzero(full["obs_image"] == 0)[0]
+    pts = full["obs_point"][sel]
+    n = len(sel)
+    assert n > 40
+    points3D = [full["gt_xyz"][p].copy() for p in pts]
+    refs = [full["refs"][p].copy() for p in pts]
+    refs[3] = [refs[3], refs[3] + 1e-3]                          # a correspondence with two references
+    fmap = features.FeatureMap.from_arrays(full["patches"][sel], np.arange(n), full["corners"][sel], (1.0, 1.0))
+    cam = Camera(1, 2, 1000, 1000, full["cam_params"][full["image_camera"][0], :4].copy())
+    qvec, tvec = full["qvec"][0].copy(), full["tvec"][0].copy()
+    inliers = [True] * n
+    inliers[5] = False
+    opt = {"refine_focal_length": refine_focal}
+    adj = QueryBundleAdjuster({"optimizer": opt}, ctx=ctx)
+    assert adj.refine(qvec, tvec, cam, points3D, fmap, refs, inliers=inliers)
+    # oracle on the flat problem the reference would build
+    rows = [i for i in range(n) if inliers[i]]
+    o_patch, o_xyz, o_refs = [], [], []
+    for i in rows:
+        for d in (refs[i] if isinstance(refs[i], list) else [refs[i]]):
+            o_patch.append(sel[i]); o_xyz.append(points3D[i]); o_refs.append(d)
+    m = len(o_patch)
+    flat = dict(obs_image=np.zeros(m, np.int32), obs_point=np.arange(m, dtype=np.int32),
+                obs_patch=np.arange(m, dtype=np.int64), image_camera=np.zeros(1, np.int32),
+                qvec=full["qvec"][:1].copy(), tvec=full["tvec"][:1].copy(), cam_model=np.array([2], np.int32),
+                cam_params=full["cam_params"][full["image_camera"][0]][None].copy(), xyz=np.array(o_xyz),
+                refs=np.array(o_refs), patches=np.ascontiguousarray(full["patches"][o_patch]),
+                corners=full["corners"][o_patch], scales=full["scales"][o_patch])
+    mask = 0b1110 if refine_focal else 0b1111
+    so, qo, to, co, _ = pxo.ba_solve(flat, pxo.cfg(), pxo.loss("cauchy", 0.25), [0], [0], [mask], np.ones(m, np.uint8),
+                                     pxo.lm_options())
+    s = adj.solver.last_summary
+    assert s["num_camera_unknowns"] == (7 if refine_focal else 6) and s["num_point_unknowns"] == 0
+    assert abs(s["initial_cost"] - so["initial_cost"]) < 1e-10 * so["initial_cost"]
+    assert abs(s["final_cost"] - so["final_cost"]) < 1e-6 * so["initial_cost"]
+    assert np.abs(qvec - qo[0]).max() < 1e-6 and np.abs(tvec - to[0]).max() < 1e-6
+    assert np.abs(cam.params - co[0, :4]).max() < 1e-4 * 1200
+    if not refine_focal:
+        assert np.array_equal(cam.params, full["cam_params"][full["image_camera"][0], :4])
+    # the refined pose is closer to the ground truth than the perturbed start
+    assert np.linalg.norm(tvec - full["gt_tvec"][0]) < 0.2 * np.linalg.norm(full["tvec"][0] - full["gt_tvec"][0])

@@ -96,6 +96,19 @@ int pxr_arena_destroy(pxr_arena* a);
  * scales double[count][2].  h_patches may be NULL to only set metadata. */
 int pxr_arena_upload(pxr_arena* a, int64_t first, int64_t count, const void* h_patches,
                      const int32_t* h_corners, const double* h_scales);
+/* Sparse patch producer on the device: replaces FeatureExtractor.tensor_to_fmap's
+ * sparse branch + extract_patches_torch/_numpy (pixsfm/features/extractor.py:152-199,
+ * features/extract_patches.py:13-44) and the GPU -> CPU -> optimiser copies behind them.
+ * d_fmap: ONE image's dense feature map on the device, torch layout [C][h][w], src_dtype PXR_F16 or
+ * PXR_F32, C = the arena's channels.  d_keypoints [n][2]: COLMAP image coordinates.  scale =
+ * (w / image_w, h / image_h); corner = clip((int)(kp * scale - 8), 0, (w, h) - 16 - 1) (C truncation,
+ * like astype(np.int32)); l2_normalize: torch.nn.functional.normalize over channels (fp32,
+ * eps 1e-12) before the cast to the arena dtype (extractor.py:173-175).  Fills patches
+ * [first, first + n) of the arena (16 x 16 only) with their corners and scales; asynchronous on
+ * the context's stream. */
+int pxr_arena_extract(pxr_ctx* ctx, pxr_arena* a, int64_t first, int64_t n, const void* d_fmap,
+                      int src_dtype, int h, int w, const double* d_keypoints, double image_w,
+                      double image_h, int l2_normalize);
 void* pxr_arena_data(pxr_arena* a);     /* device pointer of patch 0 */
 int32_t* pxr_arena_corners(pxr_arena* a); /* device int32[n][2] */
 double* pxr_arena_scales(pxr_arena* a);   /* device double[n][2] */

@@ -1,0 +1,122 @@
+// pxr_extract.hip -- sparse patch producer: dense feature map (device, CHW) -> arena patches (HWC).
+//
+// Reference path: FeatureExtractor.tensor_to_fmap, sparse branch
+// (pixsfm/features/extractor.py:152-199): L2-normalise the map over channels, cast to the storage
+// dtype, corners = clip(int(kp * scale - ps / 2), 0, (w, h) - ps - 1), gather ps x ps windows with
+// extract_patches_torch and permute to [n][ps][ps][C] -- then copy GPU -> CPU numpy, which the
+// reference itself flags as "main performance bottleneck" (features/extract_patches.py:41-44), and
+// later back to wherever the optimiser runs.  Here the gather writes straight into the HBM arena the
+// KA / BA kernels read; nothing crosses PCIe.
+//
+// HBM-bound transposition: one workgroup per patch, one patch row per step.  Reads are the CHW
+// rows (16 contiguous x per channel = 64 B at fp32), staged through a padded LDS tile so that the
+// writes are the arena's channel-fastest texels (256 B per pixel at fp16, 16 B per lane).
+#include <hip/hip_runtime.h>
+
+#include "pxr_device.h"
+#include "pxr_internal.h"
+
+namespace pxr {
+
+// corner of keypoint k in map texels (extractor.py:192-193): C-style truncation like astype(np.int32)
+__device__ __forceinline__ void ex_corner(const double* kp, double sx, double sy, int ps, int w, int h, int& x0, int& y0) {
+  x0 = (int)(kp[0] * sx - ps / 2.0);
+  y0 = (int)(kp[1] * sy - ps / 2.0);
+  x0 = min(max(x0, 0), w - ps - 1);
+  y0 = min(max(y0, 0), h - ps - 1);
+}
+
+// PS = 16 (patch side), C multiple of 16.  256 threads.
+template <typename SRC, typename DST, int C>
+__global__ __launch_bounds__(256) void extract_kernel(const SRC* __restrict__ fmap, int h, int w,
+                                                      const double* __restrict__ kps, double sx, double sy,
+                                                      int l2_normalize, DST* __restrict__ out,
+                                                      int32_t* __restrict__ corners, double* __restrict__ scales,
+                                                      int64_t first) {
+  constexpr int PS = 16, CP = C + 1;            // +1 float of padding: conflict-free column reads
+  __shared__ float tile[2 * PS * CP];
+  const int64_t k = blockIdx.x;
+  const int tid = threadIdx.x;
+  int x0, y0;
+  ex_corner(kps + 2 * k, sx, sy, PS, w, h, x0, y0);
+  if (tid == 0) {
+    corners[2 * (first + k)] = x0; corners[2 * (first + k) + 1] = y0;
+    scales[2 * (first + k)] = sx; scales[2 * (first + k) + 1] = sy;
+  }
+  DST* patch = out + (size_t)(first + k) * PS * PS * C;
+  const size_t plane = (size_t)h * w;
+  const int lx = tid & 15, lc = tid >> 4;       // load mapping: 16 x-contiguous lanes, 16 channels per pass
+  const int px = tid >> 4, sub = tid & 15;      // store mapping: 16 lanes per pixel, C/16 channels per lane
+  constexpr int CPL = C / 16;
+  // software pipeline: the CHW loads of row y + 1 are in flight while row y goes through the
+  // (double-buffered) LDS tile, the normalisation and the HWC stores; one barrier per row
+  SRC cur[CPL], nxt[CPL];
+  {
+    const SRC* row = fmap + (size_t)y0 * w + x0 + lx;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) cur[j] = row[(size_t)(lc + 16 * j) * plane];
+  }
+  for (int y = 0; y < PS; ++y) {
+    float* tl = tile + (y & 1) * (PS * CP);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) tl[lx * CP + lc + 16 * j] = (float)cur[j];
+    if (y + 1 < PS) {
+      const SRC* row = fmap + (size_t)(y0 + y + 1) * w + x0 + lx;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) nxt[j] = row[(size_t)(lc + 16 * j) * plane];
+    }
+    __syncthreads();
+    float v[CPL];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { v[j] = tl[px * CP + sub * CPL + j]; ss = fmaf(v[j], v[j], ss); }
+    if (l2_normalize) {   // torch.nn.functional.normalize(dim=1): v / max(||v||_2, 1e-12), fp32
+      for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+      const float den = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) v[j] = v[j] / den;
+    }
+    typedef DST vec_t __attribute__((ext_vector_type(CPL)));   // one lane's share of a texel: a single 16-B store at fp16
+    vec_t o;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) o[j] = (DST)v[j];
+    *reinterpret_cast<vec_t*>(patch + ((size_t)y * PS + px) * C + sub * CPL) = o;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) cur[j] = nxt[j];
+  }
+}
+
+}  // namespace pxr
+
+extern "C" int pxr_arena_extract(pxr_ctx* ctx, pxr_arena* a, int64_t first, int64_t n, const void* d_fmap,
+                                 int src_dtype, int h, int w, const double* d_keypoints, double image_w,
+                                 double image_h, int l2_normalize) {
+  using namespace pxr;
+  PXR_REQUIRE(ctx && a && d_fmap && d_keypoints, "pxr_arena_extract: NULL argument");
+  PXR_REQUIRE(first >= 0 && n >= 0 && first + n <= a->n, "pxr_arena_extract: range [%lld, %lld) outside arena of %lld patches",
+              (long long)first, (long long)(first + n), (long long)a->n);
+  PXR_REQUIRE(a->H == 16 && a->W == 16, "pxr_arena_extract: patch size %dx%d not supported (16x16)", a->H, a->W);
+  PXR_REQUIRE(h > 16 && w > 16, "pxr_arena_extract: feature map %dx%d must exceed the patch size", h, w);
+  PXR_REQUIRE(image_w > 0 && image_h > 0, "pxr_arena_extract: image size must be positive");
+  if (n == 0) return PXR_OK;
+  PXR_HIP(hipSetDevice(ctx->device));
+  const double sx = (double)w / image_w, sy = (double)h / image_h;   // extractor.py:177
+#define EX_LAUNCH(SRC, DST, CC)                                                                              \
+  hipLaunchKernelGGL((extract_kernel<SRC, DST, CC>), dim3((unsigned)n), dim3(256), 0, ctx->stream,          \
+                     (const SRC*)d_fmap, h, w, d_keypoints, sx, sy, l2_normalize, (DST*)a->d_data,          \
+                     a->d_corners, a->d_scales, first)
+#define EX_DST(SRC, CC)                                                   \
+  do {                                                                    \
+    if (a->dtype == PXR_F16) EX_LAUNCH(SRC, _Float16, CC);                \
+    else if (a->dtype == PXR_F32) EX_LAUNCH(SRC, float, CC);              \
+    else EX_LAUNCH(SRC, double, CC);                                      \
+  } while (0)
+  if (src_dtype == PXR_F32 && a->C == 128) EX_DST(float, 128);
+  else if (src_dtype == PXR_F32 && a->C == 64) EX_DST(float, 64);
+  else if (src_dtype == PXR_F16 && a->C == 128) EX_DST(_Float16, 128);
+  else if (src_dtype == PXR_F16 && a->C == 64) EX_DST(_Float16, 64);
+  else return set_error(PXR_EUNSUPPORTED, "pxr_arena_extract: source dtype %d / CHANNELS %d not supported (f16/f32 x 128/64)", src_dtype, a->C);
+#undef EX_DST
+#undef EX_LAUNCH
+  return hip_check(hipGetLastError(), "extract_kernel launch");
+}

@@ -127,3 +127,13 @@ def to_arena(ctx, patch_list):
     corners = np.stack([p.corner for p in patch_list])
     scales = np.stack([p.scale for p in patch_list])
     return PatchArena.from_numpy(ctx, data, corners, scales)
+
+
+def tensor_to_arena(arena, first, featuremap, image_size, keypoints, l2_normalize=True):
+    """GPU-resident counterpart of FeatureExtractor.tensor_to_fmap(featuremap, image_size, keypoints)
+    (pixsfm/features/extractor.py:152-199, sparse branch): the dense map stays on the device and its
+    16 x 16 windows are written straight into `arena` (patches first .. first + n - 1, with corners and
+    scale) by pxr_arena_extract -- no numpy copy, no PCIe crossing (extract_patches.py:41-44 names that
+    copy the main bottleneck).  featuremap: torch.cuda tensor (1, C, h, w) or (C, h, w), fp16/fp32,
+    contiguous; image_size: (width, height); returns the number of patches written."""
+    return arena.extract(first, featuremap, keypoints, image_size, l2_normalize=l2_normalize)

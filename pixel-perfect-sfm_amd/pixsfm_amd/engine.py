@@ -137,6 +137,56 @@ class PatchArena:
             None if corners is None else corners.ctypes.data,
             None if scales is None else scales.ctypes.data), "pxr_arena_upload")
 
+    def extract(self, first, fmap, keypoints, image_size, l2_normalize=True):
+        """Fill patches [first, first + len(keypoints)) from ONE image's dense feature map that is
+        already on the device (FeatureExtractor.tensor_to_fmap sparse branch, extractor.py:152-199,
+        without the GPU -> CPU -> GPU round trip).
+
+        fmap: a CUDA/ROCm tensor-like exposing __cuda_array_interface__ (e.g. a contiguous
+        torch.cuda tensor) of shape (C, h, w) or (1, C, h, w), float16 or float32.
+        keypoints: (n, 2) COLMAP image coordinates (host array or DeviceArray).
+        image_size: (width, height) of the image the keypoints live in."""
+        cai = fmap.__cuda_array_interface__
+        shape = tuple(cai["shape"])
+        if len(shape) == 4 and shape[0] == 1:
+            shape = shape[1:]
+        if len(shape) != 3 or shape[0] != self.C:
+            raise ValueError("feature map must be (C=%d, h, w); got %r" % (self.C, tuple(cai["shape"])))
+        if cai.get("strides") is not None:
+            item = int(cai["typestr"][2:])
+            full = tuple(cai["shape"])
+            expect = tuple(int(np.prod(full[i + 1:])) * item for i in range(len(full)))
+            if tuple(cai["strides"]) != expect:
+                raise ValueError("feature map must be contiguous (call .contiguous())")
+        src = {"<f2": _lib.F16, "<f4": _lib.F32}.get(cai["typestr"])
+        if src is None:
+            raise ValueError("feature map dtype %s not supported (float16 / float32)" % cai["typestr"])
+        if isinstance(keypoints, DeviceArray):
+            d_kp, n = keypoints, keypoints.shape[0]
+        else:
+            kp = np.ascontiguousarray(keypoints, dtype=np.float64).reshape(-1, 2)
+            d_kp, n = self.ctx.to_device(kp, np.float64), len(kp)
+        check(self.ctx.lib.pxr_arena_extract(self.ctx.handle, self.handle, int(first), int(n), C.c_void_p(cai["data"][0]),
+                                             src, int(shape[1]), int(shape[2]), d_kp.ptr, float(image_size[0]),
+                                             float(image_size[1]), int(bool(l2_normalize))), "pxr_arena_extract")
+        self.ctx.sync()          # the temporary keypoint upload may be released after this
+        return n
+
+    def download(self, first=0, count=None):
+        """(patches, corners, scales) of a range of the arena as numpy arrays (tests / debugging)."""
+        count = self.n - first if count is None else count
+        patches = np.empty((count, self.H, self.W, self.C), dtype=self.dtype)
+        corners = np.empty((count, 2), dtype=np.int32)
+        scales = np.empty((count, 2), dtype=np.float64)
+        lib, h = self.ctx.lib, self.ctx.handle
+        pb = patches[0].nbytes if count else 0
+        check(lib.pxr_memcpy_d2h(h, patches.ctypes.data, C.c_void_p(self.data_ptr + pb * first), patches.nbytes), "d2h")
+        check(lib.pxr_memcpy_d2h(h, corners.ctypes.data, C.c_void_p(lib.pxr_arena_corners(self.handle) + 8 * first),
+                                 corners.nbytes), "d2h")
+        check(lib.pxr_memcpy_d2h(h, scales.ctypes.data, C.c_void_p(lib.pxr_arena_scales(self.handle) + 16 * first),
+                                 scales.nbytes), "d2h")
+        return patches, corners, scales
+
     @property
     def data_ptr(self):
         return self.ctx.lib.pxr_arena_data(self.handle)

@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32768)
     ap.add_argument("--lm-iters", type=int, default=10, help="LM iterations for the iters/s figure (0 = skip)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank owns --points points (N x the observations, cameras shared); "
+                         "strong: --points points in total, sharded over the ranks")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -81,6 +84,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # PXR_BENCH_ONE_DEVICE=1 + PXR_BENCH_BACKEND=gloo: several ranks on ONE GPU, used to validate the
+    # multi-process flow (sharding, barriers, max-over-ranks timing, all-reduce callback) on a 1-GPU box
+    if os.environ.get("PXR_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     # PXR_BENCH_FORCE_DIST=1 exercises the RCCL code path with a single rank (used to validate the
@@ -90,15 +97,22 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29531"
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        backend = os.environ.get("PXR_BENCH_BACKEND", "nccl")          # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from pixsfm_amd import synthetic_gpu
     from pixsfm_amd.engine import BAProblem, Context, PatchArena, interp_cfg, make_loss
 
     C, PS = 128, 16
-    per = (args.points + world - 1) // world
-    lo, hi = rank * per, min(args.points, (rank + 1) * per)
-    prob, patches = synthetic_gpu.make_ba_problem_gpu(dev, n_cams=args.cams, n_points=args.points,
+    # points (with their observations, patches and references) are the sharded unit; cameras and poses
+    # are replicated.  weak: the scene grows with the ranks, strong: it is split.
+    total_points = args.points * world if args.scaling == "weak" else args.points
+    per = (total_points + world - 1) // world
+    lo, hi = rank * per, min(total_points, (rank + 1) * per)
+    prob, patches = synthetic_gpu.make_ba_problem_gpu(dev, n_cams=args.cams, n_points=total_points,
                                                       obs_per_point=args.obs_per_point, channels=C,
                                                       patch_size=PS, seed=2, point_range=(lo, hi))
     n_obs_local = len(prob["obs_image"])
@@ -133,6 +147,10 @@ def main():
     else:
         n_obs_total = n_obs_local
     cost = ba.cost(make_loss("cauchy", [0.25]))
+    if dist_on:                                   # cost of the whole (sharded) problem
+        ctot = torch.tensor([cost], dtype=torch.float64, device=dev)
+        dist.all_reduce(ctot)
+        cost = ctot.item()
 
     # ---- second half of the metric: LM iterations / s on the same problem ------------------------
     # default gauge (bundle_adjustment/main.py:12-18) and refine flags (bundle_adjustment_options.h:66-76);
@@ -176,17 +194,18 @@ def main():
             "unit": "residual_blocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32 horizontal / f64 vertical+normalisation on f16 patches"
                      if not args.float_simd else "f32 splines / f64 normalisation on f16 patches",
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2]: synthetic %d cams / %d points / %d obs "
                                    "featuremetric BA residual+Jacobian evaluation, %d-ch fp16 %dx%d patches, "
                                    "SIMPLE_RADIAL, fused six-scalar Jacobian reduction"
-                                   % (args.cams, args.points, n_obs_total, C, PS, PS),
+                                   % (args.cams, total_points, n_obs_total, C, PS, PS),
                        "n_obs": n_obs_total, "channels": C, "patch": PS,
                        "arena_GB": n_obs_total * PS * PS * C * 2 / 1e9,
-                       "partition": "points" if world > 1 else "none"},
+                       "obs_per_gpu": n_obs_local,
+                       "partition": "points sharded, cameras replicated" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": "bytes/launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "

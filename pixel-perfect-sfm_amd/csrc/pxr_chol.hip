@@ -13,8 +13,8 @@
 //                  WG 0 writes L_kk and inv(L_kk) back, WG b >= 1 computes its 128 panel rows
 //                  X = B inv(L_kk)^T as an LDS-tiled GEMM (8x4 register micro-tiles).
 //   k_chol_syrk    trailing update A22 -= P P^T on 64x64 tiles (lower tiles only).
-//   k_chol_backstep  L^T x = y right-looking, one launch per block step, many workgroups:
-//                  x_k = inv(L_kk)^T z_k (mat-vec with the stored block inverse), z_c -= L(k-block, c)^T x_k.
+//   k_chol_backsolve L^T x = y in one launch: a workgroup per block column, solution blocks handed on
+//                  through flags; x_k = inv(L_kk)^T z_k, z_c -= L(k-block, c-block)^T x_k.
 #include <hip/hip_runtime.h>
 
 #include "pxr_internal.h"
@@ -78,16 +78,21 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ a, int 
       }
     }
     __syncthreads();
+    // all 13 LDS reads are issued unconditionally, back to back (one wait), and masked in registers:
+    // conditional loads made the compiler emit a branch + wait per value (13 serialized LDS round trips)
     const double djj = colb[buf][j];
+    double cu[4], cw[4], rw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { cu[u] = colb[buf][4 * ti + u]; cw[u] = colb[buf][4 * tj + u]; rw[u] = rowb[buf][4 * tj + u]; }
     if (!(djj > 0.0) && bad == 0) bad = j + 1;
     const double inv = djj > 0.0 ? rsqrt(djj) : 1.0;
     double li[4], lc[4], xr[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) li[u] = (4 * ti + u > j) ? colb[buf][4 * ti + u] * inv : 0.0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      lc[w] = (4 * tj + w > j) ? colb[buf][4 * tj + w] * inv : 0.0;
-      xr[w] = rowb[buf][4 * tj + w] * inv;
+    for (int u = 0; u < 4; ++u) {
+      const double a_ = cu[u] * inv, b_ = cw[u] * inv;
+      li[u] = (4 * ti + u > j) ? a_ : 0.0;
+      lc[u] = (4 * tj + u > j) ? b_ : 0.0;
+      xr[u] = rw[u] * inv;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -209,46 +214,59 @@ __global__ __launch_bounds__(256) void k_chol_syrk(double* __restrict__ a, int n
   }
 }
 
-// One block step of L^T x = y (right-looking), many workgroups.  z = row n of the augmented matrix
-// (in place): every workgroup recomputes x_k = inv(L_kk)^T z_k (64 x 64 mat-vec with the stored block
-// inverse; cheaper than a launch boundary), workgroup 0 publishes it, and workgroup w updates the 64
-// columns c in [64 w, 64 w + 64) below the block:  z_c -= L(k-block, c)^T x_k  -- a wave per 16
-// columns, lanes along the contiguous 64 rows (one coalesced 512-B load per column, 4 in flight).
-__global__ __launch_bounds__(256) void k_chol_backstep(double* __restrict__ a, int n, int lda,
-                                                       const double* __restrict__ linv, double* __restrict__ x_out,
-                                                       int bk) {
-  __shared__ double part[4][CNB];
-  __shared__ double xk[CNB];
+// L^T x = y in ONE launch: workgroup b owns block column c = nblk - 1 - b (64 unknowns) and keeps its
+// slice z_c of the right-hand side in LDS.  It consumes the solution blocks x_k, k = nblk-1 .. c+1, in
+// order as they are published (flag per block, acquire/release through L2):  z_c -= L(k-block, c-block)^T x_k
+// (64 x 64 mat-vec on its own tile of the factor), then x_c = inv(L_cc)^T z_c with the stored block
+// inverse, publishes it and raises its flag.  Dependencies only point to LOWER workgroup ids, which the
+// dispatcher starts first, so the spin-waits cannot deadlock even when the grid exceeds the machine.
+// Critical path: nblk x (one 64x64 mat-vec + one flag hop) instead of nblk kernel launches.
+__global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict__ a, int n, int lda,
+                                                        const double* __restrict__ linv, double* x_out,
+                                                        int* flags, int nblk) {
+  __shared__ double z[CNB], xk[CNB], part[4][CNB];
   const int tid = threadIdx.x;
-  const int k = bk * CNB, nb = min(CNB, n - k);
-  {
-    const double* Li = linv + (size_t)bk * CNB * CNB;
-    const int c = tid & (CNB - 1), sl = tid >> 6;
+  const int c = nblk - 1 - (int)blockIdx.x;
+  const int c0 = c * CNB, nbc = min(CNB, n - c0);
+  const int j = tid & (CNB - 1), sl = tid >> 6;     // column j of the tile, row slice sl (4 x 16 rows)
+  if (tid < CNB) z[tid] = (tid < nbc) ? a[(size_t)n + (size_t)(c0 + tid) * lda] : 0.0;
+  for (int k = nblk - 1; k > c; --k) {
+    const int k0 = k * CNB, nbk = min(CNB, n - k0);
+    // issue this tile's loads before waiting for x_k: L(k0 + r, c0 + j), r contiguous in memory
+    double lv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int r = sl * 16 + q;
+      lv[q] = (r < nbk && j < nbc) ? a[(size_t)(k0 + r) + (size_t)(c0 + j) * lda] : 0.0;
+    }
+    if (tid == 0) while (__hip_atomic_load(&flags[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {}
+    __syncthreads();
+    if (tid < CNB) xk[tid] = (tid < nbk) ? __hip_atomic_load(&x_out[k0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    __syncthreads();
     double s = 0.0;
-    for (int r = sl; r < nb; r += 4) s = fma(Li[r * CNB + c], a[(size_t)n + (size_t)(k + r) * lda], s);
-    part[sl][c] = s;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s = fma(lv[q], xk[sl * 16 + q], s);
+    part[sl][j] = s;
     __syncthreads();
-    if (tid < CNB) {
-      const double tot = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
-      xk[tid] = (tid < nb) ? tot : 0.0;
-      if (blockIdx.x == 0 && tid < nb) x_out[k + tid] = tot;
-    }
-    __syncthreads();
+    if (tid < CNB) z[tid] -= part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
   }
-  const int lane = tid & 63, wv = tid >> 6;
-  const double xl = xk[lane];
-  const int c_begin = blockIdx.x * CNB + wv * 16;
-  for (int c = c_begin; c < c_begin + 16 && c < k; c += 4) {
-    double v[4];
+  __syncthreads();
+  // x_c = inv(L_cc)^T z_c:  x[j] = sum_{r >= j} Linv[r][j] z[r]
+  const double* Li = linv + (size_t)c * CNB * CNB;
+  double s = 0.0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      v[q] = (c + q < k && lane < nb) ? a[(size_t)k + lane + (size_t)(c + q) * lda] * xl : 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      double s = v[q];
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-      if (lane == 0 && c + q < k) a[(size_t)n + (size_t)(c + q) * lda] -= s;
-    }
+  for (int q = 0; q < 16; ++q) {
+    const int r = sl * 16 + q;
+    s = fma(Li[r * CNB + j], z[r], s);              // entries above the diagonal / beyond nbc are stored as 0
+  }
+  part[sl][j] = s;
+  __syncthreads();
+  if (tid < nbc) __hip_atomic_store(&x_out[c0 + tid], part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid],
+                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    __hip_atomic_store(&flags[c], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -264,8 +282,9 @@ int chol_factor_solve(hipStream_t st, double* a, int n, int* d_info, double* lin
     hipLaunchKernelGGL(k_chol_syrk, dim3(T, T), dim3(256), 0, st, a, n_rows, lda, k, nb);
   }
   const int nblk = (n + CNB - 1) / CNB;
-  for (int bk = nblk - 1; bk >= 0; --bk)
-    hipLaunchKernelGGL(k_chol_backstep, dim3(bk > 0 ? bk : 1), dim3(256), 0, st, a, n, lda, linv_ws, x_out, bk);
+  int* flags = reinterpret_cast<int*>(linv_ws + (size_t)nblk * CNB * CNB);   // spare block of the workspace
+  if (int rc = hip_check(hipMemsetAsync(flags, 0, sizeof(int) * nblk, st), "memset flags")) return rc;
+  hipLaunchKernelGGL(k_chol_backsolve, dim3(nblk), dim3(256), 0, st, a, n, lda, linv_ws, x_out, flags, nblk);
   return hip_check(hipGetLastError(), "cholesky launch");
 }
 

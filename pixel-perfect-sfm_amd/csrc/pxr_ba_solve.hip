@@ -18,7 +18,7 @@
 //   K_img     block/(image,chunk)  U (pose/intrinsics blocks, upper) and g_c, LDS-reduced
 // per LM attempt (radius changes on rejection, linearisation is reused):
 //   K_pinv    thread/point  T_p = (V_p + D_p/radius)^-1
-//   K_wy      thread/obs    W_i = B^T M~ E (dc x 3), Y_i = W_i T_p
+//   (W_i = B^T M~ E (dc x 3) is written by K_jac once per linearisation; Y_i = W_i T_p on the fly)
 //   K_schur   thread/(obs,row)  S -= Y_i W_j^T over the point's observation pairs (upper
 //             triangle only), rhs -= Y_i g_p      [atomics into the dense reduced system]
 //   all-reduce(S | rhs) over ranks (RCCL, multi-GPU), + LM damping, rocSOLVER potrf/potrs
@@ -55,7 +55,7 @@ struct SolveDev {          // device-side problem description shared by the kern
 
 // ---- K_jac ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_jac(const SolveDev d, const double* __restrict__ rec,
-                                             pxr_loss loss, double* __restrict__ L) {
+                                             pxr_loss loss, double* __restrict__ L, double* __restrict__ W) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= d.v.n_obs) return;
   const int img = d.v.d_obs_image[i], pt = d.v.d_obs_point[i], cam = d.v.d_image_camera[img];
@@ -82,23 +82,40 @@ __global__ __launch_bounds__(256) void k_jac(const SolveDev d, const double* __r
     kappa = (2.0 * alpha - alpha * alpha) / s;
   }
   double* Lo = L + (size_t)i * d.LS;
-  Lo[0] = rho[1] * (gxx - kappa * bx * bx);
-  Lo[1] = rho[1] * (gxy - kappa * bx * by);
-  Lo[2] = rho[1] * (gyy - kappa * by * by);
+  const double m00 = rho[1] * (gxx - kappa * bx * bx), m01 = rho[1] * (gxy - kappa * bx * by),
+               m11 = rho[1] * (gyy - kappa * by * by);
+  Lo[0] = m00; Lo[1] = m01; Lo[2] = m11;
   Lo[3] = rho[1] * bx;
   Lo[4] = rho[1] * by;
   // E = d(x,y)/dX, scaled
   const bool pvar = d.pt_var[pt] != 0;
+  double e0[3], e1[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const double sc = pvar ? d.scale_p[3 * (size_t)pt + j] : 0.0;
-    Lo[5 + j] = PX[0][j] * sc;
-    Lo[8 + j] = PX[1][j] * sc;
+    e0[j] = PX[0][j] * sc; e1[j] = PX[1][j] * sc;
+    Lo[5 + j] = e0[j];
+    Lo[8 + j] = e1[j];
   }
+  // W = B^T M~ E (dc x 3) is fixed for the whole linearisation point (it does not depend on the
+  // trust-region radius), so it is produced here once instead of once per LM attempt
+  double me0[3], me1[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    me0[j] = m00 * e0[j] + m01 * e1[j];
+    me1[j] = m01 * e0[j] + m11 * e1[j];
+  }
+  double* Wo = W + (size_t)i * d.DC * 3;
   // B: tangent pose columns then variable intrinsics columns
   double* B0 = Lo + 11;
   double* B1 = B0 + d.DC;
   int col = 0;
+  auto put = [&](int c, double b0, double b1) {
+    B0[c] = b0; B1[c] = b1;
+    Wo[3 * c] = b0 * me0[0] + b1 * me1[0];
+    Wo[3 * c + 1] = b0 * me0[1] + b1 * me1[1];
+    Wo[3 * c + 2] = b0 * me0[2] + b1 * me1[2];
+  };
   if (d.pose_dim[img] > 0) {
     const int po = d.pose_off[img];
     // QuaternionManifold::PlusJacobian [upstream Ceres manifold.cc], 4x3
@@ -106,8 +123,8 @@ __global__ __launch_bounds__(256) void k_jac(const SolveDev d, const double* __r
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const double sc = d.scale_c[po + a];
-      B0[col] = (Pq[0][0] * PJ[0][a] + Pq[0][1] * PJ[1][a] + Pq[0][2] * PJ[2][a] + Pq[0][3] * PJ[3][a]) * sc;
-      B1[col] = (Pq[1][0] * PJ[0][a] + Pq[1][1] * PJ[1][a] + Pq[1][2] * PJ[2][a] + Pq[1][3] * PJ[3][a]) * sc;
+      put(col, (Pq[0][0] * PJ[0][a] + Pq[0][1] * PJ[1][a] + Pq[0][2] * PJ[2][a] + Pq[0][3] * PJ[3][a]) * sc,
+          (Pq[1][0] * PJ[0][a] + Pq[1][1] * PJ[1][a] + Pq[1][2] * PJ[2][a] + Pq[1][3] * PJ[3][a]) * sc);
       ++col;
     }
     const int tm = d.tmask[img];
@@ -115,7 +132,7 @@ __global__ __launch_bounds__(256) void k_jac(const SolveDev d, const double* __r
     for (int a = 0; a < 3; ++a) {
       if ((tm >> a) & 1) continue;
       const double sc = d.scale_c[po + col];
-      B0[col] = A[0][a] * sc; B1[col] = A[1][a] * sc;
+      put(col, A[0][a] * sc, A[1][a] * sc);
       ++col;
     }
   }
@@ -126,11 +143,11 @@ __global__ __launch_bounds__(256) void k_jac(const SolveDev d, const double* __r
     for (int a = 0; a < PXR_KPAD; ++a) {
       if (a >= K || ((cm >> a) & 1)) continue;
       const double sc = d.scale_c[io + kc];
-      B0[col] = Pk[0][a] * sc; B1[col] = Pk[1][a] * sc;
+      put(col, Pk[0][a] * sc, Pk[1][a] * sc);
       ++col; ++kc;
     }
   }
-  for (; col < d.DC; ++col) { B0[col] = 0.0; B1[col] = 0.0; }
+  for (; col < d.DC; ++col) put(col, 0.0, 0.0);
 }
 
 // global column index of camera-side column `a` of an observation in image img / camera cam
@@ -190,12 +207,24 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
   else { int rem = e; a = 0; while (rem >= dc - a) { rem -= dc - a; ++a; } b = a + rem; }
   double acc = 0.0;
   if (sl < slices) {
-    for (int64_t o = ch.begin + sl; o < ch.end; o += slices) {
-      const double* Lo = L + (size_t)img_obs[o] * d.LS;
-      const double* B0 = Lo + 11; const double* B1 = B0 + d.DC;
-      if (is_g) acc += B0[a] * Lo[3] + B1[a] * Lo[4];
-      else acc += B0[a] * (Lo[0] * B0[b] + Lo[1] * B1[b]) + B1[a] * (Lo[1] * B0[b] + Lo[2] * B1[b]);
+    // four independent gathers in flight per thread (the loop is bound by HBM latency, not bandwidth)
+    double acc4[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t o = ch.begin + sl; o < ch.end; o += 4 * (int64_t)slices) {
+      const double* Lo[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t ou = o + (int64_t)u * slices;
+        Lo[u] = ou < ch.end ? L + (size_t)img_obs[ou] * d.LS : nullptr;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!Lo[u]) continue;
+        const double* B0 = Lo[u] + 11; const double* B1 = B0 + d.DC;
+        if (is_g) acc4[u] += B0[a] * Lo[u][3] + B1[a] * Lo[u][4];
+        else acc4[u] += B0[a] * (Lo[u][0] * B0[b] + Lo[u][1] * B1[b]) + B1[a] * (Lo[u][1] * B0[b] + Lo[u][2] * B1[b]);
+      }
     }
+    acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
   }
   red[threadIdx.x] = acc;
   __syncthreads();
@@ -227,39 +256,21 @@ __global__ __launch_bounds__(256) void k_pinv(int64_t n_points, const int* __res
   To[5] = (a00 * a11 - a01 * a01) * id;
 }
 
-// ---- K_wy: W = B^T M~ E, Y = W T ----------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_wy(const SolveDev d, const double* __restrict__ L,
-                                            const double* __restrict__ T, double* __restrict__ W,
-                                            double* __restrict__ Y) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.v.n_obs) return;
-  const double* Lo = L + (size_t)i * d.LS;
-  const int pt = d.v.d_obs_point[i];
+// Y_i = W_i T_p is formed on the fly where it is consumed (row a of observation i)
+__device__ __forceinline__ void y_row(const double* __restrict__ W, const double* __restrict__ T, int64_t i, int a, int DC,
+                                      int64_t pt, double& y0, double& y1, double& y2) {
+  const double* Wi = W + ((size_t)i * DC + a) * 3;
   const double* Tp = T + 6 * (size_t)pt;
-  const double t00 = Tp[0], t01 = Tp[1], t02 = Tp[2], t11 = Tp[3], t12 = Tp[4], t22 = Tp[5];
-  double me0[3], me1[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    me0[j] = Lo[0] * Lo[5 + j] + Lo[1] * Lo[8 + j];
-    me1[j] = Lo[1] * Lo[5 + j] + Lo[2] * Lo[8 + j];
-  }
-  const double* B0 = Lo + 11; const double* B1 = B0 + d.DC;
-  double* Wo = W + (size_t)i * d.DC * 3; double* Yo = Y + (size_t)i * d.DC * 3;
-  for (int a = 0; a < d.DC; ++a) {
-    const double w0 = B0[a] * me0[0] + B1[a] * me1[0];
-    const double w1 = B0[a] * me0[1] + B1[a] * me1[1];
-    const double w2 = B0[a] * me0[2] + B1[a] * me1[2];
-    Wo[3 * a] = w0; Wo[3 * a + 1] = w1; Wo[3 * a + 2] = w2;
-    Yo[3 * a] = w0 * t00 + w1 * t01 + w2 * t02;
-    Yo[3 * a + 1] = w0 * t01 + w1 * t11 + w2 * t12;
-    Yo[3 * a + 2] = w0 * t02 + w1 * t12 + w2 * t22;
-  }
+  const double w0 = Wi[0], w1 = Wi[1], w2 = Wi[2];
+  y0 = w0 * Tp[0] + w1 * Tp[1] + w2 * Tp[2];
+  y1 = w0 * Tp[1] + w1 * Tp[3] + w2 * Tp[4];
+  y2 = w0 * Tp[2] + w1 * Tp[4] + w2 * Tp[5];
 }
 
 // ---- K_schur: S -= Y_i W_j^T (upper), rhs -= Y_i g_p ----------------------------------------------
 __global__ __launch_bounds__(256) void k_schur(const SolveDev d, const int64_t* __restrict__ pt_ptr,
                                                const int64_t* __restrict__ pt_obs,
-                                               const double* __restrict__ W, const double* __restrict__ Y,
+                                               const double* __restrict__ W, const double* __restrict__ T,
                                                const double* __restrict__ gp, double* __restrict__ S,
                                                double* __restrict__ rhs) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -271,8 +282,8 @@ __global__ __launch_bounds__(256) void k_schur(const SolveDev d, const int64_t* 
   if (a >= dci) return;
   const int pt = d.v.d_obs_point[i];
   if (!d.pt_var[pt]) return;
-  const double* Yi = Y + ((size_t)i * d.DC + a) * 3;
-  const double y0 = Yi[0], y1 = Yi[1], y2 = Yi[2];
+  double y0, y1, y2;
+  y_row(W, T, i, a, d.DC, pt, y0, y1, y2);
   const int r = col_index(d, img, cam, a);
   atomicAdd(rhs + (size_t)r * d.ldS, -(y0 * gp[3 * (size_t)pt] + y1 * gp[3 * (size_t)pt + 1] + y2 * gp[3 * (size_t)pt + 2]));
   for (int64_t o = pt_ptr[pt]; o < pt_ptr[pt + 1]; ++o) {
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(1024) void k_schur_lds(const SolveDev d, const ImgC
                                                     const int64_t* __restrict__ img_obs,
                                                    const int64_t* __restrict__ pt_ptr,
                                                    const int64_t* __restrict__ pt_obs,
-                                                   const double* __restrict__ W, const double* __restrict__ Y,
+                                                   const double* __restrict__ W, const double* __restrict__ T,
                                                    const double* __restrict__ gp, int CT,
                                                    double* __restrict__ S, double* __restrict__ rhs) {
   extern __shared__ double acc[];              // [DC][CT] then [DC] for the right-hand side
@@ -319,8 +330,8 @@ __global__ __launch_bounds__(1024) void k_schur_lds(const SolveDev d, const ImgC
     const int a = (int)(task % dci);
     const int pt = d.v.d_obs_point[i];
     if (!d.pt_var[pt]) continue;
-    const double* Yi = Y + ((size_t)i * d.DC + a) * 3;
-    const double y0 = Yi[0], y1 = Yi[1], y2 = Yi[2];
+    double y0, y1, y2;
+    y_row(W, T, i, a, d.DC, pt, y0, y1, y2);
     const int r = col_index(d, img, cam, a);
     if (blockIdx.y == 0)
       atomicAdd(racc + a, -(y0 * gp[3 * (size_t)pt] + y1 * gp[3 * (size_t)pt + 1] + y2 * gp[3 * (size_t)pt + 2]));
@@ -670,7 +681,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     for (int64_t i = 0; i < n_obs; ++i) { img_obs[ic[obs_image[i]]++] = i; pt_obs[pc[obs_point[i]]++] = i; }
   }
   std::vector<ImgChunk> chunks;
-  const int64_t CH = 2048;
+  const int64_t CH = 384;    // short chunks: the per-thread gather loop in k_img is latency-bound
   for (int i = 0; i < n_img; ++i)
     for (int64_t b = img_cnt[i]; b < img_cnt[i + 1]; b += CH)
       chunks.push_back({i, b, std::min(img_cnt[i + 1], b + CH)});
@@ -699,11 +710,11 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   RC(d_pt_obs.upload(pt_obs, st)); RC(d_chunks.upload(chunks, st));
   RC(d_schur_chunks.upload(schur_chunks, st)); RC(d_obs_cols.upload(obs_cols, st));
   const size_t nc1 = n_c ? n_c : 1;
-  DevBuf<double> L, V, gp, Vd0, T, W, Y, U, S /* S | rhs */, gcd /* diagU | g_c */, damp_c, scale_c, scale_p,
+  DevBuf<double> L, V, gp, Vd0, T, W, U, S /* S | rhs */, gcd /* diagU | g_c */, damp_c, scale_c, scale_p,
       delta_c, delta_p, rec_a, rec_b, q1, t1, k1, X1, scal;
   RC(L.alloc((size_t)n_obs * LS)); RC(V.alloc((size_t)n_pts * 6)); RC(gp.alloc((size_t)n_pts * 3));
   RC(Vd0.alloc((size_t)n_pts * 3)); RC(T.alloc((size_t)n_pts * 6));
-  RC(W.alloc((size_t)n_obs * DC * 3)); RC(Y.alloc((size_t)n_obs * DC * 3));
+  RC(W.alloc((size_t)n_obs * DC * 3));
   // S: n_c x (n_c + 1) [S | rhs] + one spare row for the factorisation
   RC(U.alloc(nc1 * nc1)); RC(S.alloc((nc1 + 1) * (nc1 + 1))); RC(gcd.alloc(2 * nc1)); RC(damp_c.alloc(nc1));
   RC(scale_c.alloc(nc1)); RC(scale_p.alloc((size_t)n_pts * 3)); RC(delta_c.alloc(nc1)); RC(delta_p.alloc((size_t)n_pts * 3));
@@ -751,7 +762,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   };
   // linearise at the CURRENT parameters from record buffer `rec`
   auto linearize = [&](const double* rec) -> int {
-    hipLaunchKernelGGL(k_jac, dim3(nblk(n_obs)), dim3(256), 0, st, dv, rec, *loss, L.p);
+    hipLaunchKernelGGL(k_jac, dim3(nblk(n_obs)), dim3(256), 0, st, dv, rec, *loss, L.p, W.p);
     hipLaunchKernelGGL(k_point, dim3(nblk(n_pts)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, L.p, V.p, gp.p);
     PXR_HIP(hipMemsetAsync(U.p, 0, sizeof(double) * nc1 * nc1, st));
     PXR_HIP(hipMemsetAsync(gcd.p, 0, sizeof(double) * 2 * nc1, st));
@@ -830,13 +841,12 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * 16, st));
     bool ok = true;
     if (n_c > 0) {
-      hipLaunchKernelGGL(k_wy, dim3(nblk(n_obs)), dim3(256), 0, st, dv, L.p, T.p, W.p, Y.p);
       hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, n_c, U.p, (const double*)nullptr, 0.0, (const double*)nullptr, S.p, 1);
       if (use_lds_schur) {
         hipLaunchKernelGGL(k_schur_lds, dim3((unsigned)schur_chunks.size(), (unsigned)n_ctiles), dim3(1024), schur_shmem, st, dv,
-                           d_schur_chunks.p, d_obs_cols.p, d_img_obs.p, d_pt_ptr.p, d_pt_obs.p, W.p, Y.p, gp.p, CT, S.p, rhs);
+                           d_schur_chunks.p, d_obs_cols.p, d_img_obs.p, d_pt_ptr.p, d_pt_obs.p, W.p, T.p, gp.p, CT, S.p, rhs);
       } else {
-        hipLaunchKernelGGL(k_schur, dim3(nblk(n_obs * DC)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, W.p, Y.p, gp.p, S.p, rhs);
+        hipLaunchKernelGGL(k_schur, dim3(nblk(n_obs * DC)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, W.p, T.p, gp.p, S.p, rhs);
       }
       LAUNCH_CHECK("schur kernels");
       phase(0);

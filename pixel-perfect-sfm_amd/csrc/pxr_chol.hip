@@ -9,7 +9,8 @@
 // a right-looking Cholesky that treats row n like any other sub-diagonal row performs the forward
 // substitution L y = b for free (row n of the factor is y^T).
 //   k_chol_panel   every workgroup factors the 64x64 diagonal block AND inverts its triangular
-//                  factor in one 64-step sweep on 4x4 register tiles (one barrier per step);
+//                  factor in one 64-step sweep on 4x4 register tiles (one barrier per step, finished
+//                  columns of L / rows of inv(L) exported to LDS so the updates need no masks);
 //                  WG 0 writes L_kk and inv(L_kk) back, WG b >= 1 computes its 128 panel rows
 //                  X = B inv(L_kk)^T as an LDS-tiled GEMM (8x4 register micro-tiles).
 //   k_chol_syrk    trailing update A22 -= P P^T on 64x64 tiles (lower tiles only).
@@ -86,14 +87,12 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ a, int 
     for (int u = 0; u < 4; ++u) { cu[u] = colb[buf][4 * ti + u]; cw[u] = colb[buf][4 * tj + u]; rw[u] = rowb[buf][4 * tj + u]; }
     if (!(djj > 0.0) && bad == 0) bad = j + 1;
     const double inv = djj > 0.0 ? rsqrt(djj) : 1.0;
+    // No masks: once column j of L and row j of inv(L) have been exported to LDS (below), the
+    // register entries of finished rows / columns are dead -- they are never read again, so the
+    // rank-1 updates may overwrite them with garbage.
     double li[4], lc[4], xr[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const double a_ = cu[u] * inv, b_ = cw[u] * inv;
-      li[u] = (4 * ti + u > j) ? a_ : 0.0;
-      lc[u] = (4 * tj + u > j) ? b_ : 0.0;
-      xr[u] = rw[u] * inv;
-    }
+    for (int u = 0; u < 4; ++u) { li[u] = cu[u] * inv; lc[u] = cw[u] * inv; xr[u] = rw[u] * inv; }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -101,23 +100,16 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ a, int 
         Dt[u][w] = fma(-li[u], lc[w], Dt[u][w]);
         Xt[u][w] = fma(-li[u], xr[w], Xt[u][w]);
       }
-    if (tj == jb) {                                          // store the finished column j of L
+    if (tj == jb && !is_panel_wg) {                          // column j of L (rows >= j are meaningful)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int R = 4 * ti + u;
-        if (R >= j) {
-          const double v = (R == j) ? djj * inv : li[u];
-          if (jo == 0) Dt[u][0] = v; else if (jo == 1) Dt[u][1] = v; else if (jo == 2) Dt[u][2] = v; else Dt[u][3] = v;
-        }
-      }
+      for (int u = 0; u < 4; ++u) Bs[j][4 * ti + u] = li[u];
     }
-    if (ti == jb) {                                          // finished row j of inv(L)
+    if (ti == jb) {                                          // row j of inv(L): Lt[m][j] = inv(L)[j][m], zero for m > j
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        if (jo == 0) Xt[0][w] = xr[w]; else if (jo == 1) Xt[1][w] = xr[w]; else if (jo == 2) Xt[2][w] = xr[w]; else Xt[3][w] = xr[w];
-      }
+      for (int w = 0; w < 4; ++w) Lt[4 * tj + w][j] = (4 * tj + w <= j) ? xr[w] : 0.0;
     }
   }
+  __syncthreads();
   if (!is_panel_wg) {
     if (bad && bad <= nb && tid == 0) atomicCAS(info, 0, k + bad);
     double* lo = linv_out + (size_t)(k / CNB) * CNB * CNB;
@@ -126,18 +118,11 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ a, int 
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         const int R = 4 * ti + u, Cc = 4 * tj + w;
-        if (R < nb && Cc < nb && R >= Cc) a[(size_t)(k + R) + (size_t)(k + Cc) * lda] = Dt[u][w];
-        lo[R * CNB + Cc] = (R >= Cc) ? Xt[u][w] : 0.0;      // inv(L_kk), row-major
+        if (R < nb && Cc < nb && R >= Cc) a[(size_t)(k + R) + (size_t)(k + Cc) * lda] = Bs[Cc][R];
+        lo[R * CNB + Cc] = Lt[Cc][R];                        // inv(L_kk), row-major
       }
     return;
   }
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const int R = 4 * ti + u, Cc = 4 * tj + w;
-      Lt[Cc][R] = (R >= Cc) ? Xt[u][w] : 0.0;               // Lt[m][j] = inv(L)[j][m]
-    }
 #pragma unroll
   for (int q = 0; q < CNB * PROWS / 256; ++q) {
     const int e = tid + q * 256;

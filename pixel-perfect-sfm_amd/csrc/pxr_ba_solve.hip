@@ -305,14 +305,14 @@ __global__ __launch_bounds__(256) void k_schur(const SolveDev d, const int64_t* 
 // in LDS with ds_add_f64 and flushes it once with global atomics.  The dense-S atomics drop
 // from one per (i, j, a, b) contribution (~1.7e8 at 1M observations) to one per (chunk, row,
 // column) (~2.5e6); the contraction itself runs at LDS-atomic speed.
+template <int G>   // lanes per observation: G >= DC (8, 16 or 32)
 __global__ __launch_bounds__(1024) void k_schur_lds(const SolveDev d, const ImgChunk* __restrict__ chunks,
-                                                    const int4* __restrict__ obs_cols,
-                                                    const int64_t* __restrict__ img_obs,
-                                                   const int64_t* __restrict__ pt_ptr,
-                                                   const int64_t* __restrict__ pt_obs,
-                                                   const double* __restrict__ W, const double* __restrict__ T,
-                                                   const double* __restrict__ gp, int CT,
-                                                   double* __restrict__ S, double* __restrict__ rhs) {
+                                                    const int4* __restrict__ so,      // per image-ordered slot: {obs, point, first partner, partners (0 = constant point)}
+                                                    const int* __restrict__ pj,       // partner observation of each (point, k) slot
+                                                    const int4* __restrict__ pcols,   // its {pose_off, pose_dim, intr_off, intr_dim}
+                                                    const double* __restrict__ W, const double* __restrict__ T,
+                                                    const double* __restrict__ gp, int CT,
+                                                    double* __restrict__ S, double* __restrict__ rhs) {
   extern __shared__ double acc[];              // [DC][CT] then [DC] for the right-hand side
   const ImgChunk ch = chunks[blockIdx.x];
   const int img = ch.img, cam = d.v.d_image_camera[img];
@@ -324,26 +324,60 @@ __global__ __launch_bounds__(1024) void k_schur_lds(const SolveDev d, const ImgC
     if (e < dci * CT) acc[(e / CT) * CT + (e % CT)] = 0.0; else racc[e - dci * CT] = 0.0;
   }
   __syncthreads();
-  const int64_t n_tasks = (ch.end - ch.begin) * dci;
-  for (int64_t task = threadIdx.x; task < n_tasks; task += blockDim.x) {
-    const int64_t i = img_obs[ch.begin + task / dci];
-    const int a = (int)(task % dci);
-    const int pt = d.v.d_obs_point[i];
-    if (!d.pt_var[pt]) continue;
-    double y0, y1, y2;
-    y_row(W, T, i, a, d.DC, pt, y0, y1, y2);
-    const int r = col_index(d, img, cam, a);
-    if (blockIdx.y == 0)
-      atomicAdd(racc + a, -(y0 * gp[3 * (size_t)pt] + y1 * gp[3 * (size_t)pt + 1] + y2 * gp[3 * (size_t)pt + 2]));
-    for (int64_t o = pt_ptr[pt]; o < pt_ptr[pt + 1]; ++o) {
-      const int64_t j = pt_obs[o];
-      const int4 cj = obs_cols[j];               // {pose_off, pose_dim, intr_off, intr_dim} of observation j
-      const int pdj = cj.y, dcj = pdj + cj.w;
-      const double* Wj = W + (size_t)j * d.DC * 3;
-      for (int b = 0; b < dcj; ++b) {
-        const int c = b < pdj ? cj.x + b : cj.z + (b - pdj);
-        if (c < r || c < c0 || c >= c1) continue;   // upper triangle, this column tile
-        atomicAdd(acc + (size_t)a * CT + (c - c0), -(y0 * Wj[3 * b] + y1 * Wj[3 * b + 1] + y2 * Wj[3 * b + 2]));
+  // G lanes share one observation.  Lane a first forms row a of Y_i = W_i T_p; the dc_i x 3 rows are
+  // handed round the group ONCE per observation (shuffles).  Then, per partner observation j of the
+  // same point, lane b loads row b of W_j (one coalesced read of the whole dc_j x 3 block per group,
+  // all partners of a batch in flight together) and adds its column of the block -Y_i W_j^T to the
+  // LDS tile.  The host flattens obs -> point -> partner list -> column descriptors into three
+  // levels of loads (so[], then pj / pcols / W_i / T / gp, then W_j).
+  const int lane_b = threadIdx.x % G, grp = threadIdx.x / G, n_grp = blockDim.x / G;
+  const int gbase = (threadIdx.x & 63) - lane_b;          // first lane of this group inside the wavefront
+  int rrow[G];                                             // global row of Y_i row a (same for every observation of the image)
+#pragma unroll
+  for (int a = 0; a < G; ++a) rrow[a] = a < dci ? col_index(d, img, cam, a) : 0x7fffffff;
+  for (int64_t o = ch.begin + grp; o < ch.end; o += n_grp) {
+    const int4 s = so[o];
+    if (s.w == 0) continue;                               // constant point (uniform over the group)
+    const int64_t i = s.x, pt = s.y;
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    if (lane_b < dci) y_row(W, T, i, lane_b, d.DC, pt, y0, y1, y2);
+    if (blockIdx.y == 0 && lane_b < dci)
+      atomicAdd(racc + lane_b, -(y0 * gp[3 * (size_t)pt] + y1 * gp[3 * (size_t)pt + 1] + y2 * gp[3 * (size_t)pt + 2]));
+    double ya[G][3];
+#pragma unroll
+    for (int a = 0; a < G; ++a) {
+      ya[a][0] = __shfl(y0, gbase + a); ya[a][1] = __shfl(y1, gbase + a); ya[a][2] = __shfl(y2, gbase + a);
+    }
+    constexpr int PB = 8;                                  // partners per batch of loads in flight
+    for (int kb = 0; kb < s.w; kb += PB) {
+      int4 cc[PB];
+      double mm[PB][3];
+      int jj[PB];
+#pragma unroll
+      for (int u = 0; u < PB; ++u) {
+        const int idx = s.z + min(kb + u, s.w - 1);
+        jj[u] = pj[idx]; cc[u] = pcols[idx];
+      }
+#pragma unroll
+      for (int u = 0; u < PB; ++u) {
+        mm[u][0] = mm[u][1] = mm[u][2] = 0.0;               // row lane_b of W_j
+        if (kb + u < s.w && lane_b < cc[u].y + cc[u].w) {
+          const double* Wj = W + ((size_t)jj[u] * d.DC + lane_b) * 3;
+          mm[u][0] = Wj[0]; mm[u][1] = Wj[1]; mm[u][2] = Wj[2];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PB; ++u) {
+        if (kb + u >= s.w) break;
+        const int4 cj = cc[u];
+        const int pdj = cj.y, dcj = pdj + cj.w;
+        const int c = lane_b < pdj ? cj.x + lane_b : cj.z + (lane_b - pdj);   // global column of W_j row lane_b
+        if (lane_b >= dcj || c < c0 || c >= c1) continue;
+#pragma unroll
+        for (int a = 0; a < G; ++a) {
+          if (c >= rrow[a])                                  // upper triangle (rrow = INT_MAX beyond dc_i)
+            atomicAdd(acc + (size_t)a * CT + (c - c0), -(ya[a][0] * mm[u][0] + ya[a][1] * mm[u][1] + ya[a][2] * mm[u][2]));
+        }
       }
     }
   }
@@ -689,26 +723,35 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   // Schur contraction: larger chunks (fewer LDS flushes), and per-observation column descriptors so the
   // inner loop does not chase obs -> image -> camera -> offsets
   std::vector<ImgChunk> schur_chunks;
-  const int64_t SCH = 8192;
+  const int64_t SCH = 1024;
   for (int i = 0; i < n_img; ++i)
     for (int64_t b = img_cnt[i]; b < img_cnt[i + 1]; b += SCH)
       schur_chunks.push_back({i, b, std::min(img_cnt[i + 1], b + SCH)});
-  std::vector<int4> obs_cols(n_obs);
-  for (int64_t i = 0; i < n_obs; ++i) {
-    const int im = obs_image[i], cm = image_camera[im];
-    obs_cols[i] = make_int4(pose_off[im], pose_dim[im], intr_off[cm], intr_dim[cm]);
+  PXR_REQUIRE(n_obs < ((int64_t)1 << 31), "pxr_ba_solve: more than 2^31 observations per rank");
+  std::vector<int4> obs_cols(n_obs), so_desc(n_obs);   // partner column descriptors in pt_obs order, slots in img_obs order
+  std::vector<int> part_obs(n_obs);
+  for (int64_t o = 0; o < n_obs; ++o) {
+    const int64_t j = pt_obs[o];
+    const int im = obs_image[j], cm = image_camera[im];
+    obs_cols[o] = make_int4(pose_off[im], pose_dim[im], intr_off[cm], intr_dim[cm]);
+    part_obs[o] = (int)j;
+    const int64_t i = img_obs[o];
+    const int64_t pt = obs_point[i];
+    so_desc[o] = make_int4((int)i, (int)pt, (int)pt_cnt[pt], pt_var[pt] ? (int)(pt_cnt[pt + 1] - pt_cnt[pt]) : 0);
   }
 
   // ---- device buffers ---------------------------------------------------------------------------
   DevBuf<int> d_pose_off, d_pose_dim, d_tmask, d_intr_off, d_intr_dim, d_cmask, d_pt_var;
   DevBuf<int64_t> d_img_obs, d_pt_ptr, d_pt_obs;
   DevBuf<ImgChunk> d_chunks, d_schur_chunks;
-  DevBuf<int4> d_obs_cols;
+  DevBuf<int4> d_obs_cols, d_so;
+  DevBuf<int> d_part_obs;
   RC(d_pose_off.upload(pose_off, st)); RC(d_pose_dim.upload(pose_dim, st)); RC(d_tmask.upload(tmask, st));
   RC(d_intr_off.upload(intr_off, st)); RC(d_intr_dim.upload(intr_dim, st)); RC(d_cmask.upload(cmask, st));
   RC(d_pt_var.upload(pt_var, st)); RC(d_img_obs.upload(img_obs, st)); RC(d_pt_ptr.upload(pt_cnt, st));
   RC(d_pt_obs.upload(pt_obs, st)); RC(d_chunks.upload(chunks, st));
   RC(d_schur_chunks.upload(schur_chunks, st)); RC(d_obs_cols.upload(obs_cols, st));
+  RC(d_so.upload(so_desc, st)); RC(d_part_obs.upload(part_obs, st));
   const size_t nc1 = n_c ? n_c : 1;
   DevBuf<double> L, V, gp, Vd0, T, W, U, S /* S | rhs */, gcd /* diagU | g_c */, damp_c, scale_c, scale_p,
       delta_c, delta_p, rec_a, rec_b, q1, t1, k1, X1, scal;
@@ -793,8 +836,8 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   CT = n_c > 0 ? (n_c + n_ctiles - 1) / n_ctiles : 1;       // balance the tiles
   const size_t schur_shmem = sizeof(double) * ((size_t)DC * CT + DC);
   if (use_lds_schur && n_c > 0)
-    PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)schur_shmem));
+    PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(DC <= 8 ? k_schur_lds<8> : (DC <= 16 ? k_schur_lds<16> : k_schur_lds<32>)),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_shmem));
   const bool verbose = std::getenv("PXR_VERBOSE") != nullptr;
   const bool phase_timing = std::getenv("PXR_PHASE_TIMING") != nullptr;   // adds a stream sync per phase
   double ph_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -843,8 +886,11 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     if (n_c > 0) {
       hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, n_c, U.p, (const double*)nullptr, 0.0, (const double*)nullptr, S.p, 1);
       if (use_lds_schur) {
-        hipLaunchKernelGGL(k_schur_lds, dim3((unsigned)schur_chunks.size(), (unsigned)n_ctiles), dim3(1024), schur_shmem, st, dv,
-                           d_schur_chunks.p, d_obs_cols.p, d_img_obs.p, d_pt_ptr.p, d_pt_obs.p, W.p, T.p, gp.p, CT, S.p, rhs);
+#define SCHUR_LAUNCH(GG)                                                                                              \
+  hipLaunchKernelGGL(k_schur_lds<GG>, dim3((unsigned)schur_chunks.size(), (unsigned)n_ctiles), dim3(1024), schur_shmem, st, dv, \
+                     d_schur_chunks.p, d_so.p, d_part_obs.p, d_obs_cols.p, W.p, T.p, gp.p, CT, S.p, rhs)
+        if (DC <= 8) SCHUR_LAUNCH(8); else if (DC <= 16) SCHUR_LAUNCH(16); else SCHUR_LAUNCH(32);
+#undef SCHUR_LAUNCH
       } else {
         hipLaunchKernelGGL(k_schur, dim3(nblk(n_obs * DC)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, W.p, T.p, gp.p, S.p, rhs);
       }

@@ -39,9 +39,12 @@ __device__ __forceinline__ double rows4_sum(double v) {
   return v;
 }
 
+constexpr int INNER_MAXO = 16;   // observations per point staged in LDS
+
 template <typename ST, int C>
 __global__ __launch_bounds__(256) void k_inner_points(const InnerArgs a) {
   static_assert(C == 128, "one observation per 16-lane row");
+  __shared__ double sh_obs[4][INNER_MAXO][26];   // per wavefront: q(4) t(3) k(12) sx sy corner(2) model patch
   const int lane = threadIdx.x & 63, row = lane >> 4, sub = lane & 15;
   const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= a.v.n_points) return;
@@ -57,27 +60,69 @@ __global__ __launch_bounds__(256) void k_inner_points(const InnerArgs a) {
 #pragma unroll
   for (int ch = 0; ch < 8; ++ch) ref[ch] = refp[ch];
 
+  // stage the observations' camera / patch data (lane 0 of each 16-lane row, one observation each)
+  for (int oi = row; oi < n && oi < INNER_MAXO; oi += 4) {
+    if (sub == 0) {
+      double* ob = sh_obs[threadIdx.x >> 6][oi];
+      const int64_t i = a.pt_obs[o0 + oi];
+      const int img = a.v.d_obs_image[i], cam = a.v.d_image_camera[img];
+      const int64_t pi = a.v.d_obs_patch[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ob[j] = a.v.d_qvec[4 * (size_t)img + j];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) ob[4 + j] = a.v.d_tvec[3 * (size_t)img + j];
+#pragma unroll
+      for (int j = 0; j < PXR_KPAD; ++j) ob[7 + j] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + j];
+      ob[19] = a.scales[2 * pi]; ob[20] = a.scales[2 * pi + 1];
+      ob[21] = (double)a.corners[2 * pi]; ob[22] = (double)a.corners[2 * pi + 1];
+      ob[23] = (double)a.v.d_cam_model[cam]; ob[24] = (double)pi;
+    }
+  }
+  __threadfence_block();                 // lane-0 writes -> visible to the other lanes of this wavefront
+  __builtin_amdgcn_wave_barrier();
+
   // cost (+ normal equations H (6: xx xy xz yy yz zz), g (3)) of this point at Xc
   auto eval = [&](const double* Xc, bool with_jac, double* Hn, double* gn) -> double {
     double cost = 0.0, acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int chunk = 0; chunk < n; chunk += 4) {
       const int oi = chunk + row;
       const bool valid = oi < n;
-      const int64_t i = a.pt_obs[o0 + (valid ? oi : n - 1)];
-      const int img = a.v.d_obs_image[i], cam = a.v.d_image_camera[img];
-      const int64_t pi = a.v.d_obs_patch[i];
-      double q[4], t[3], k[PXR_KPAD];
+      const int oc = valid ? oi : n - 1;
+      // camera / patch data of the observation: staged once per point in LDS (the nested LM evaluates
+      // the same observations ~10 times; the obs -> image -> camera -> parameters chain of dependent
+      // global loads was most of every evaluation's latency); tracks longer than INNER_MAXO observations
+      // read the tail from global memory
+      double q[4], t[3], k[PXR_KPAD], sx, sy, cx, cy;
+      int model;
+      int64_t pi;
+      if (oc < INNER_MAXO) {
+        const double* ob = sh_obs[threadIdx.x >> 6][oc];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) q[j] = a.v.d_qvec[4 * (size_t)img + j];
+        for (int j = 0; j < 4; ++j) q[j] = ob[j];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) t[j] = a.v.d_tvec[3 * (size_t)img + j];
+        for (int j = 0; j < 3; ++j) t[j] = ob[4 + j];
 #pragma unroll
-      for (int j = 0; j < PXR_KPAD; ++j) k[j] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + j];
+        for (int j = 0; j < PXR_KPAD; ++j) k[j] = ob[7 + j];
+        sx = ob[19]; sy = ob[20]; cx = ob[21]; cy = ob[22];
+        model = (int)ob[23]; pi = (int64_t)ob[24];
+      } else {
+        const int64_t i = a.pt_obs[o0 + oc];
+        const int img = a.v.d_obs_image[i], cam = a.v.d_image_camera[img];
+        pi = a.v.d_obs_patch[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = a.v.d_qvec[4 * (size_t)img + j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) t[j] = a.v.d_tvec[3 * (size_t)img + j];
+#pragma unroll
+        for (int j = 0; j < PXR_KPAD; ++j) k[j] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + j];
+        model = a.v.d_cam_model[cam];
+        sx = a.scales[2 * pi]; sy = a.scales[2 * pi + 1];
+        cx = (double)a.corners[2 * pi]; cy = (double)a.corners[2 * pi + 1];
+      }
       double x, y, A[2][3], Pq[2][4], PX[2][3], Pk[2][PXR_KPAD];
-      world_to_pixel_jac(a.v.d_cam_model[cam], k, q, t, Xc, x, y, A, Pq, PX, Pk);
-      const double sx = a.scales[2 * pi], sy = a.scales[2 * pi + 1];
-      const double u = x * sx - 0.5 - (double)a.corners[2 * pi];
-      const double v = y * sy - 0.5 - (double)a.corners[2 * pi + 1];
+      world_to_pixel_jac(model, k, q, t, Xc, x, y, A, Pq, PX, Pk);
+      const double u = x * sx - 0.5 - cx;
+      const double v = y * sy - 0.5 - cy;
       double f[8], fr[8], fc[8];
       interp8<ST, 16, true, false>(arena + (size_t)pi * patch_elems, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f, fr, fc);
       double s = 0, gcc = 0, gcr = 0, grr = 0, bc = 0, br = 0;

@@ -227,7 +227,20 @@ int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const 
  * none), optional d_robust_mean_out [n_points][C]. */
 int pxr_ba_compute_references(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view,
                               const pxr_interp_cfg* cfg, const pxr_loss* loss, int iters,
-                              double* d_refs_out, int64_t* d_ref_obs_out, double* d_robust_mean_out);
+                              double* d_refs_out, int64_t* d_ref_obs_out, double* d_robust_mean_out,
+                              double* d_obs_desc_out /* NULL, or [n_obs][C]: the per-observation descriptors
+                                                        (ReferenceConfig::keep_observations, reference_extractor.h:60,259-265) */);
+
+/* FindNearestReferences (localization/src/nearest_references.h:20-52): for each 2D-3D correspondence i the
+ * query descriptor f(patch[d_patch[i]], d_kp[i]) is compared with its candidates -- rows
+ * d_cand_index[d_cand_ptr[i] .. d_cand_ptr[i+1]) of d_cand_desc [*][C] (d_cand_index NULL: the rows
+ * themselves), i.e. the observation descriptors of its 3D point (Reference::observations).  d_best[i] =
+ * row of the nearest candidate (squared L2, first minimum wins; -1 without candidates), optional
+ * d_best_dist[i], optional copy of the winner into d_out_desc [n][C]. */
+int pxr_nearest_references(pxr_ctx* ctx, pxr_arena* arena, const pxr_interp_cfg* cfg, int64_t n,
+                           const double* d_kp, const int64_t* d_patch, const int64_t* d_cand_ptr,
+                           const int64_t* d_cand_index, const double* d_cand_desc, int64_t* d_best,
+                           double* d_best_dist, double* d_out_desc);
 
 /* ---- KA ---------------------------------------------------------------------------------
  * Batched replacement of FeatureMetricKeypointOptimizer::RunParallel / RunSubset

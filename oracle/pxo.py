@@ -316,3 +316,17 @@ def ba_solve(problem, config, ls, pose_const, tvec_const_mask, cam_const_mask, p
                             _p(ptc), C.byref(opts), C.byref(s))
     assert rc == 0
     return s.as_dict(), prob["qvec"], prob["tvec"], prob["cam_params"], prob["xyz"]
+
+
+def nearest_reference(patch, config, kp, candidates):
+    """FindNearestReferences for one correspondence (localization/src/nearest_references.h:36-49):
+    index of the candidate descriptor with the smallest squared distance to the query descriptor
+    (first minimum wins) and that distance."""
+    q, _ = ref2d_residual(patch, config, kp, np.zeros(patch.C), jac=False)
+    best, dmin = -1, np.finfo(np.float64).max
+    for i, d in enumerate(candidates):
+        e = np.asarray(d, dtype=np.float64).reshape(-1) - q
+        s = float(e @ e)
+        if s < dmin:
+            best, dmin = i, s
+    return best, dmin

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "pxr_device.h"
+#include "pxr_interp.h"
 #include "pxr_internal.h"
 
 namespace pxr {
@@ -151,11 +152,79 @@ __global__ __launch_bounds__(256) void k_irls(int64_t n_points, const int64_t* _
   if (sub == 0) ref_obs[p] = bo;
 }
 
+// ---- FindNearestReferences (localization/src/nearest_references.h:20-52) ---------------------------------
+// One DPP row (C/8 lanes) per 2D-3D correspondence: interpolate the query descriptor once, then scan
+// the candidate descriptors (the observations of its 3D point) for the smallest squared distance;
+// the first minimum wins, like the reference's strict `d < min_distance`.
+template <typename ST, int C>
+__global__ __launch_bounds__(256) void k_nearest(int64_t n, const ST* __restrict__ arena, const int32_t* __restrict__ corners,
+                                                 const double* __restrict__ scales, int H, int W, int l2_normalize,
+                                                 int float_simd, const double* __restrict__ kp,
+                                                 const int64_t* __restrict__ patch, const int64_t* __restrict__ cand_ptr,
+                                                 const int64_t* __restrict__ cand_index, const double* __restrict__ cand_desc,
+                                                 int64_t* __restrict__ best, double* __restrict__ best_dist,
+                                                 double* __restrict__ out_desc) {
+  constexpr int LPO = C / 8, G = 256 / LPO;
+  const int sub = threadIdx.x % LPO;
+  const int64_t i = (int64_t)blockIdx.x * G + threadIdx.x / LPO;
+  if (i >= n) return;
+  const int64_t pi = patch[i];
+  const double sx = scales[2 * pi], sy = scales[2 * pi + 1];
+  const double u = kp[2 * i] * sx - 0.5 - (double)corners[2 * pi];          // featurepatch.h:250-255
+  const double v = kp[2 * i + 1] * sy - 0.5 - (double)corners[2 * pi + 1];
+  const ST* p = arena + (size_t)pi * H * W * C;
+  double f[8], fr[8], fc[8];
+  if (float_simd) interp8<ST, LPO, false, true>(p, H, W, C, sub, u, v, l2_normalize != 0, f, fr, fc);
+  else interp8<ST, LPO, false, false>(p, H, W, C, sub, u, v, l2_normalize != 0, f, fr, fc);
+  double dmin = 1.7976931348623157e308;
+  int64_t bi = -1;
+  for (int64_t o = cand_ptr[i]; o < cand_ptr[i + 1]; ++o) {
+    const int64_t row = cand_index ? cand_index[o] : o;
+    const double* d = cand_desc + (size_t)row * C + sub * 8;
+    double s = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) { const double e = d[ch] - f[ch]; s = fma(e, e, s); }
+    s = LPO == 16 ? row16_sum(s) : row8_sum(s);
+    if (s < dmin) { dmin = s; bi = row; }
+  }
+  if (sub == 0) { best[i] = bi; if (best_dist) best_dist[i] = dmin; }
+  if (out_desc && bi >= 0) {
+    const double* d = cand_desc + (size_t)bi * C + sub * 8;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) out_desc[(size_t)i * C + sub * 8 + ch] = d[ch];
+  }
+}
+
 }  // namespace pxr
+
+extern "C" int pxr_nearest_references(pxr_ctx* ctx, pxr_arena* arena, const pxr_interp_cfg* cfg, int64_t n,
+                                      const double* d_kp, const int64_t* d_patch, const int64_t* d_cand_ptr,
+                                      const int64_t* d_cand_index, const double* d_cand_desc, int64_t* d_best,
+                                      double* d_best_dist, double* d_out_desc) {
+  using namespace pxr;
+  PXR_REQUIRE(ctx && arena && cfg && d_kp && d_patch && d_cand_ptr && d_cand_desc && d_best, "pxr_nearest_references: NULL argument");
+  if (n == 0) return PXR_OK;
+  PXR_HIP(hipSetDevice(ctx->device));
+#define NEAREST_LAUNCH(ST, CC)                                                                                     \
+  hipLaunchKernelGGL((k_nearest<ST, CC>), dim3((unsigned)((n + (256 / (CC / 8)) - 1) / (256 / (CC / 8)))), dim3(256), 0,     \
+                     ctx->stream, n, (const ST*)arena->d_data, arena->d_corners, arena->d_scales, arena->H, arena->W, \
+                     cfg->l2_normalize, cfg->use_float_simd, d_kp, d_patch, d_cand_ptr, d_cand_index, d_cand_desc, d_best, \
+                     d_best_dist, d_out_desc)
+  if (arena->dtype == PXR_F16 && arena->C == 128) NEAREST_LAUNCH(_Float16, 128);
+  else if (arena->dtype == PXR_F16 && arena->C == 64) NEAREST_LAUNCH(_Float16, 64);
+  else if (arena->dtype == PXR_F32 && arena->C == 128) NEAREST_LAUNCH(float, 128);
+  else if (arena->dtype == PXR_F32 && arena->C == 64) NEAREST_LAUNCH(float, 64);
+  else if (arena->dtype == PXR_F64 && arena->C == 128) NEAREST_LAUNCH(double, 128);
+  else if (arena->dtype == PXR_F64 && arena->C == 64) NEAREST_LAUNCH(double, 64);
+  else return set_error(PXR_EUNSUPPORTED, "pxr_nearest_references: CHANNELS=%d not supported (128, 64)", arena->C);
+#undef NEAREST_LAUNCH
+  return hip_check(hipGetLastError(), "k_nearest launch");
+}
 
 extern "C" int pxr_ba_compute_references(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view,
                                          const pxr_interp_cfg* cfg, const pxr_loss* loss, int iters,
-                                         double* d_refs_out, int64_t* d_ref_obs_out, double* d_robust_mean_out) {
+                                         double* d_refs_out, int64_t* d_ref_obs_out, double* d_robust_mean_out,
+                                         double* d_obs_desc_out) {
   using namespace pxr;
   PXR_REQUIRE(ctx && arena && view && cfg && loss && d_refs_out && d_ref_obs_out, "pxr_ba_compute_references: NULL argument");
   PXR_REQUIRE(arena->C == 128 || arena->C == 64, "pxr_ba_compute_references: CHANNELS=%d not supported (128, 64)", arena->C);
@@ -179,11 +248,13 @@ extern "C" int pxr_ba_compute_references(pxr_ctx* ctx, pxr_arena* arena, const p
     std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
     for (int64_t i = 0; i < n_obs; ++i) lst[cur[obs_point[i]]++] = i;
   }
-  double *d_desc = nullptr, *d_rec = nullptr, *d_w = nullptr;
+  // keep_observations (reference_extractor.h:60,259-265): the caller's buffer receives the per-observation
+  // descriptors the IRLS runs on; otherwise they live in scratch
+  double *d_desc = d_obs_desc_out, *d_desc_own = nullptr, *d_rec = nullptr, *d_w = nullptr;
   int64_t *d_ptr = nullptr, *d_lst = nullptr;
-  auto cleanup = [&]() { (void)hipFree(d_desc); (void)hipFree(d_rec); (void)hipFree(d_w); (void)hipFree(d_ptr); (void)hipFree(d_lst); };
+  auto cleanup = [&]() { (void)hipFree(d_desc_own); (void)hipFree(d_rec); (void)hipFree(d_w); (void)hipFree(d_ptr); (void)hipFree(d_lst); };
   const size_t no1 = n_obs ? (size_t)n_obs : 1;
-  if (hipMalloc((void**)&d_desc, sizeof(double) * no1 * C) != hipSuccess ||
+  if ((!d_desc && hipMalloc((void**)&d_desc_own, sizeof(double) * no1 * C) != hipSuccess) ||
       hipMalloc((void**)&d_rec, sizeof(double) * no1 * PXR_OBS_REC) != hipSuccess ||
       hipMalloc((void**)&d_w, sizeof(double) * no1) != hipSuccess ||
       hipMalloc((void**)&d_ptr, sizeof(int64_t) * (n_pts + 1)) != hipSuccess ||
@@ -191,6 +262,7 @@ extern "C" int pxr_ba_compute_references(pxr_ctx* ctx, pxr_arena* arena, const p
     cleanup();
     return set_error(PXR_ENOMEM, "pxr_ba_compute_references: scratch allocation failed");
   }
+  if (!d_desc) d_desc = d_desc_own;
   int rc = hip_check(hipMemcpyAsync(d_ptr, ptr.data(), sizeof(int64_t) * (n_pts + 1), hipMemcpyHostToDevice, st), "H2D");
   if (!rc && n_obs) rc = hip_check(hipMemcpyAsync(d_lst, lst.data(), sizeof(int64_t) * n_obs, hipMemcpyHostToDevice, st), "H2D");
   if (!rc && n_obs) {   // pass 1: descriptors at the current projections, no reference subtracted

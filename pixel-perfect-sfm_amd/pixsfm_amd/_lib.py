@@ -100,7 +100,9 @@ _SIGNATURES = {
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(LMOptions),
                                C.c_void_p, C.c_void_p, C.POINTER(LMSummary)]),
     "pxr_ba_compute_references": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BaView), C.POINTER(InterpCfg),
-                                            C.POINTER(Loss), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                            C.POINTER(Loss), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pxr_nearest_references": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(InterpCfg), C.c_int64, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pxr_ka_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(KaView), C.POINTER(InterpCfg), C.POINTER(Loss),
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pxr_ka_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(KaView), C.POINTER(InterpCfg), C.POINTER(Loss),

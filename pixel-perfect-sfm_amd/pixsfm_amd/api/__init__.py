@@ -9,4 +9,4 @@ from .keypoint_adjustment import (FeatureMetricKeypointAdjuster, FeatureMetricKe
                                   TopologicalReferenceKeypointAdjuster, TopologicalReferenceKeypointOptimizer,
                                   build_matching_graph, find_problem_labels)
 from .localization import (QueryBundleAdjuster, QueryBundleOptimizer, QueryKeypointAdjuster,  # noqa: F401,E402
-                           QueryKeypointOptimizer, find_feature_inliers)  # noqa: F401,E402
+                           QueryKeypointOptimizer, find_feature_inliers, find_nearest_references)  # noqa: F401,E402

@@ -238,8 +238,8 @@ class ReferenceExtractor:
         ic = interpolation_config
         self.interpolation = ic if isinstance(ic, base.InterpolationConfig) else base.InterpolationConfig(ic)
         self.ctx = ctx
-        if self.config['keep_observations'] or self.config['compute_offsets3D']:
-            raise ValueError("keep_observations / compute_offsets3D are outside the accelerated path")
+        if self.config['compute_offsets3D']:
+            raise ValueError("compute_offsets3D is outside the accelerated path (N_NODES = 1: offsets are zero)")
 
     def run(self, problem_labels, reconstruction, feature_set):
         ctx = self.ctx or default_context()
@@ -251,15 +251,22 @@ class ReferenceExtractor:
             return {}
         arena = features.to_arena(ctx, flat.patches)
         ba = BAProblem(ctx, arena, flat.problem_dict(np.zeros((len(flat.point_ids), arena.C))))
+        keep = bool(self.config['keep_observations'])
         chosen, _ = ba.compute_references(self.interpolation.to_engine(),
                                           make_loss(self.config['loss']['name'], self.config['loss']['params']),
-                                          iters=self.config['iters'])
+                                          iters=self.config['iters'], keep_observations=keep)
         refs = ba.d["refs"].download()
+        obs_desc = ba.obs_desc.download() if keep else None                 # reference_extractor.h:259-265
+        obs_of_point = {}
+        if keep:
+            for i, k in enumerate(flat.obs_point):
+                obs_of_point.setdefault(int(k), []).append(i)
         out = {}
         for k, pid in enumerate(flat.point_ids):
             if chosen[k] >= 0:
                 image_id, p2d_idx = flat.obs_keys[int(chosen[k])]
-                out[pid] = features.Reference(image_id, p2d_idx, refs[k])
+                out[pid] = features.Reference(image_id, p2d_idx, refs[k],
+                                              observations=[obs_desc[i] for i in obs_of_point[k]] if keep else None)
         arena.close()
         return out
 

@@ -21,7 +21,7 @@ from copy import deepcopy
 
 import numpy as np
 
-from ..engine import BAProblem, lm_options, make_loss
+from ..engine import BAProblem, lm_options, make_loss, nearest_references
 from ..ka_engine import KAProblem
 from . import base, features
 from .keypoint_adjustment import default_context
@@ -97,6 +97,37 @@ def find_feature_inliers(p2Ds, fmap, references, interpolation_config, thresh=-1
         if np.sqrt(2.0 * s['initial_cost']) > thresh:
             inliers[i] = False
     return inliers
+
+
+def find_nearest_references(query_fmap, references, keypoints, point3D_ids, interpolation_config, patch_idxs=None,
+                            ctx=None):
+    """_localization.find_nearest_references (bindings.cc:60; src/nearest_references.h:20-52): for every
+    2D-3D correspondence, the observation descriptor of its 3D point's Reference that is nearest to the
+    query descriptor interpolated at the keypoint.  `references`: {point3D_id: Reference} extracted with
+    keep_observations=True.  Returns a list of (1, C) arrays."""
+    ic = interpolation_config if isinstance(interpolation_config, base.InterpolationConfig) \
+        else base.InterpolationConfig(interpolation_config)
+    keypoints = np.asarray(keypoints, dtype=np.float64).reshape(-1, 2)
+    n = len(keypoints)
+    if len(point3D_ids) != n or (patch_idxs is not None and len(patch_idxs) != n):
+        raise ValueError("keypoints, point3D_ids and patch_idxs must have the same length")
+    if n == 0:
+        return []
+    cand, ptr = [], [0]
+    for pid in point3D_ids:
+        ref = references[pid]
+        if not ref.has_observations():
+            raise ValueError("Missing observations in references. Extract references with option "
+                             "keep_observations=True.")                     # THROW_CHECK_MSG, :33-35
+        cand.extend(o.reshape(-1) for o in ref.observations)
+        ptr.append(len(cand))
+    ctx = ctx or default_context()
+    patches = [query_fmap.fpatch(i if patch_idxs is None else patch_idxs[i]) for i in range(n)]
+    arena = features.to_arena(ctx, patches)
+    cand = np.asarray(cand, dtype=np.float64)
+    best, _, _ = nearest_references(ctx, arena, ic.to_engine(), keypoints, np.arange(n), ptr, cand)
+    arena.close()
+    return [cand[b].reshape(1, -1).copy() for b in best]
 
 
 class QueryKeypointOptimizer:

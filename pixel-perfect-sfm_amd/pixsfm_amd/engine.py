@@ -203,6 +203,26 @@ class PatchArena:
             pass
 
 
+def nearest_references(ctx, arena, cfg, keypoints, patch_idx, cand_ptr, cand_desc, cand_index=None, want_desc=False):
+    """FindNearestReferences (localization/src/nearest_references.h:20-52) on the device.
+    keypoints (n, 2), patch_idx (n,) arena patches of the query keypoints; candidates of correspondence i:
+    rows cand_index[cand_ptr[i]:cand_ptr[i+1]] of cand_desc (a DeviceArray or host array (m, C); cand_index None:
+    the rows themselves).  Returns (best row per correspondence, squared distances, winners (n, C) | None)."""
+    kp = ctx.to_device(np.ascontiguousarray(keypoints, dtype=np.float64).reshape(-1, 2), np.float64)
+    n = kp.shape[0]
+    pidx = ctx.to_device(np.ascontiguousarray(patch_idx, dtype=np.int64), np.int64)
+    cptr = ctx.to_device(np.ascontiguousarray(cand_ptr, dtype=np.int64), np.int64)
+    cidx = None if cand_index is None else ctx.to_device(np.ascontiguousarray(cand_index, dtype=np.int64), np.int64)
+    cdesc = cand_desc if isinstance(cand_desc, DeviceArray) else ctx.to_device(np.ascontiguousarray(cand_desc, dtype=np.float64), np.float64)
+    best = ctx.empty((n,), np.int64)
+    dist = ctx.empty((n,), np.float64)
+    out = ctx.empty((n, arena.C), np.float64) if want_desc else None
+    check(ctx.lib.pxr_nearest_references(ctx.handle, arena.handle, C.byref(cfg), n, kp.ptr, pidx.ptr, cptr.ptr,
+                                         cidx.ptr if cidx else None, cdesc.ptr, best.ptr, dist.ptr,
+                                         out.ptr if out else None), "pxr_nearest_references")
+    return best.download(), dist.download(), (out.download() if out else None)
+
+
 def interp_cfg(l2_normalize=True, use_float_simd=False, check_bounds=False, mode="BICUBIC", nodes=None,
                ncc_normalize=False, **_):
     """InterpolationConfig (pixsfm/base/main.py:1-7).  Only the hot-path configuration is accepted."""
@@ -332,15 +352,19 @@ class BAProblem:
               "pxr_ba_solve")
         return summ.as_dict()
 
-    def compute_references(self, cfg, loss, iters=100, keep_mean=False):
+    def compute_references(self, cfg, loss, iters=100, keep_mean=False, keep_observations=False):
         """ReferenceExtractor.run on the GPU: fills this problem's `refs` in place (device) and
-        returns (ref_obs indices, robust means | None) as numpy arrays."""
+        returns (ref_obs indices, robust means | None) as numpy arrays.  keep_observations
+        (reference_extractor.h:60): the per-observation descriptors stay on the device in
+        self.obs_desc (n_obs x C), e.g. as candidates for nearest_references()."""
         ctx = self.ctx
         ref_obs = ctx.empty((self.n_points,), np.int64)
         mean = ctx.empty((self.n_points, self.arena.C), np.float64) if keep_mean else None
+        self.obs_desc = ctx.empty((self.n_obs, self.arena.C), np.float64) if keep_observations else None
         check(ctx.lib.pxr_ba_compute_references(ctx.handle, self.arena.handle, C.byref(self.view), C.byref(cfg),
                                                 C.byref(loss), int(iters), self.d["refs"].ptr, ref_obs.ptr,
-                                                mean.ptr if mean else None), "pxr_ba_compute_references")
+                                                mean.ptr if mean else None,
+                                                self.obs_desc.ptr if self.obs_desc else None), "pxr_ba_compute_references")
         return ref_obs.download(), (mean.download() if mean else None)
 
     def params(self):

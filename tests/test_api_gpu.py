@@ -215,3 +215,38 @@ def test_query_bundle_adjuster_like_pixsfm(ctx, refine_focal):
         assert np.array_equal(cam.params, full["cam_params"][full["image_camera"][0], :4])
     # the refined pose is closer to the ground truth than the perturbed start
     assert np.linalg.norm(tvec - full["gt_tvec"][0]) < 0.2 * np.linalg.norm(full["tvec"][0] - full["gt_tvec"][0])
+
+
+def test_reference_extractor_keep_observations_and_find_nearest(ctx):
+    """ReferenceExtractor(keep_observations=True) -> Reference.observations; find_nearest_references returns, for
+    a query keypoint placed on one of a point's observations, that observation's descriptor."""
+    from pixsfm_amd.api import ReferenceExtractor, features, find_nearest_references
+    from pixsfm_amd.api.reconstruction import reconstruction_from_flat
+    from pixsfm_amd import synthetic
+    prob = synthetic.make_ba_problem(n_cams=4, n_points=40, obs_per_point=3, seed=41)
+    rec, patch_of = reconstruction_from_flat(prob)
+    fmaps = {}
+    for (image_id, p2d), pi in patch_of.items():
+        fm = fmaps.setdefault(rec.images[image_id].name, features.FeatureMap())
+        fm.patches[p2d] = features.FeaturePatch(prob["patches"][pi], prob["corners"][pi], prob["scales"][pi])
+    fset = features.FeatureSet(fmaps)
+    refs = ReferenceExtractor({"keep_observations": True, "iters": 10}, None, ctx=ctx).run(
+        [0] * (max(rec.point3D_ids()) + 1), rec, fset)
+    assert len(refs) == 40
+    for pid, r in refs.items():
+        assert r.has_observations() and len(r.observations) == rec.points3D[pid].track.length()
+        d = np.array([np.linalg.norm(o - r.descriptor) for o in r.observations])
+        assert d.min() < 1e-12                              # the reference IS one of the observations (closest to the mean)
+    # query = observations of image 0, keypoints at their detections
+    im = rec.images[min(rec.images)]
+    idxs = [k for k, p in enumerate(im.points2D) if p.has_point3D()]
+    kps = np.array([im.points2D[k].xy for k in idxs])
+    pids = [im.points2D[k].point3D_id for k in idxs]
+    near = find_nearest_references(fset.fmap(im.name), refs, kps, pids, None, patch_idxs=idxs, ctx=ctx)
+    assert len(near) == len(idxs) and near[0].shape == (1, 128)
+    hits = 0
+    for k, pid, nd in zip(idxs, pids, near):
+        d = [np.linalg.norm(o - nd) for o in refs[pid].observations]
+        assert min(d) == 0.0                                # the winner is one of the candidates
+        hits += 1
+    assert hits == len(idxs)

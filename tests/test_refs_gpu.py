@@ -69,3 +69,43 @@ def test_point_without_observations_and_unnormalised(ctx):
     assert chosen[4] == -1 and np.array_equal(ba.d["refs"].download()[4], before)
     m = np.arange(9) != 4
     assert np.array_equal(chosen[m], chosen_o[m]) and np.abs(mean[m] - means_o[m]).max() < 1e-10
+
+
+def test_keep_observations_and_nearest_references(ctx):
+    """ReferenceExtractor keep_observations (reference_extractor.h:60,259-265) + FindNearestReferences
+    (localization/src/nearest_references.h:20-52) vs the oracle: per-observation descriptors, and for
+    query keypoints near each observation the nearest of its point's observation descriptors."""
+    import pxo
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, make_loss, nearest_references
+    prob = synthetic.make_ba_problem(n_cams=5, n_points=60, obs_per_point=4, seed=23, noise=0.05)
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    ba.compute_references(interp_cfg(), make_loss("cauchy", [0.25]), iters=20, keep_observations=True)
+    desc = ba.obs_desc.download()
+    cfg = pxo.cfg()
+    n_obs = len(prob["obs_image"])
+    # descriptors at the current projections (value-only interpolation, A19)
+    rec, r, _, _ = ba.eval(interp_cfg(), with_jacobian=False, materialize=True)
+    for i in (0, 7, n_obs - 1):
+        p = pxo.make_patch(prob["patches"][i], prob["corners"][i], prob["scales"][i])
+        img, pt = prob["obs_image"][i], prob["obs_point"][i]
+        out = pxo.ba_residual(p, cfg, int(prob["cam_model"][prob["image_camera"][img]]), prob["qvec"][img], prob["tvec"][img],
+                              prob["xyz"][pt], prob["cam_params"][prob["image_camera"][img]], np.zeros(128), jac=False)
+        assert np.abs(desc[i] - out[0]).max() < 1e-12
+    # query: every observation's own patch with a perturbed keypoint; candidates = its point's observations
+    rng = np.random.default_rng(4)
+    order = np.argsort(prob["obs_point"], kind="stable")
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(prob["obs_point"], minlength=60))])
+    kps = prob["centers"] + rng.normal(0, 0.4, (n_obs, 2))
+    cand_ptr = np.concatenate([[0], np.cumsum([ptr[p + 1] - ptr[p] for p in prob["obs_point"]])])
+    cand_index = np.concatenate([order[ptr[p]:ptr[p + 1]] for p in prob["obs_point"]])
+    best, dist, win = nearest_references(ctx, arena, interp_cfg(), kps, np.arange(n_obs), cand_ptr, ba.obs_desc,
+                                         cand_index=cand_index, want_desc=True)
+    for i in range(0, n_obs, 7):
+        p = pxo.make_patch(prob["patches"][i], prob["corners"][i], prob["scales"][i])
+        rows = cand_index[cand_ptr[i]:cand_ptr[i + 1]]
+        b, d = pxo.nearest_reference(p, cfg, kps[i], desc[rows])
+        assert best[i] == rows[b] and abs(dist[i] - d) <= 1e-12 * max(d, 1e-12)
+        assert np.array_equal(win[i], desc[best[i]])
+    assert all(best[i] in cand_index[cand_ptr[i]:cand_ptr[i + 1]] for i in range(n_obs))

@@ -9,7 +9,8 @@
 // function / gradient / parameter tolerance 1e-6 / 1e-10 / 1e-8, initial radius 1e4, Jacobi
 // scaling, <= 5 consecutive invalid steps).
 //
-// Mapping: one wave per point, its four 16-lane rows evaluate four observations at a time with
+// Mapping: one wave per point, its rows of C/8 lanes (four at C = 128, eight at C = 64) evaluate that many
+// observations at a time with
 // the same interpolation core as the fused BA kernel; the per-observation 2x2 / 2-vector blocks
 // are folded with d(x,y)/dX into the point's 3x3 normal matrix and reduced across the rows with
 // two shuffles.  The whole nested LM runs in registers; consecutive evaluations re-read the same
@@ -33,7 +34,10 @@ struct InnerArgs {
   double* cost_before;         // += sum of 0.5 rho at the unrefined candidate
 };
 
-__device__ __forceinline__ double rows4_sum(double v) {
+// sum over the wavefront's rows (LPO lanes each); every lane of a row holds the row's value
+template <int LPO>
+__device__ __forceinline__ double rows_sum(double v) {
+  if (LPO == 8) v += __shfl_xor(v, 8);
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
   return v;
@@ -41,11 +45,12 @@ __device__ __forceinline__ double rows4_sum(double v) {
 
 constexpr int INNER_MAXO = 16;   // observations per point staged in LDS
 
-template <typename ST, int C>
+template <typename ST, int C, bool FS>   // FS: InterpolationConfig.use_float_simd
 __global__ __launch_bounds__(256) void k_inner_points(const InnerArgs a) {
-  static_assert(C == 128, "one observation per 16-lane row");
+  static_assert(C == 128 || C == 64, "one observation per row of C / 8 lanes");
+  constexpr int LPO = C / 8, ROWS = 64 / LPO;
   __shared__ double sh_obs[4][INNER_MAXO][26];   // per wavefront: q(4) t(3) k(12) sx sy corner(2) model patch
-  const int lane = threadIdx.x & 63, row = lane >> 4, sub = lane & 15;
+  const int lane = threadIdx.x & 63, row = lane / LPO, sub = lane % LPO;
   const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= a.v.n_points) return;
   const int64_t o0 = a.pt_ptr[p];
@@ -60,8 +65,9 @@ __global__ __launch_bounds__(256) void k_inner_points(const InnerArgs a) {
 #pragma unroll
   for (int ch = 0; ch < 8; ++ch) ref[ch] = refp[ch];
 
-  // stage the observations' camera / patch data (lane 0 of each 16-lane row, one observation each)
-  for (int oi = row; oi < n && oi < INNER_MAXO; oi += 4) {
+  auto rsum = [](double v) { return LPO == 16 ? row16_sum(v) : row8_sum(v); };
+  // stage the observations' camera / patch data (lane 0 of each row, one observation each)
+  for (int oi = row; oi < n && oi < INNER_MAXO; oi += ROWS) {
     if (sub == 0) {
       double* ob = sh_obs[threadIdx.x >> 6][oi];
       const int64_t i = a.pt_obs[o0 + oi];
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256) void k_inner_points(const InnerArgs a) {
   // cost (+ normal equations H (6: xx xy xz yy yz zz), g (3)) of this point at Xc
   auto eval = [&](const double* Xc, bool with_jac, double* Hn, double* gn) -> double {
     double cost = 0.0, acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int chunk = 0; chunk < n; chunk += 4) {
+    for (int chunk = 0; chunk < n; chunk += ROWS) {
       const int oi = chunk + row;
       const bool valid = oi < n;
       const int oc = valid ? oi : n - 1;
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void k_inner_points(const InnerArgs a) {
       const double u = x * sx - 0.5 - cx;
       const double v = y * sy - 0.5 - cy;
       double f[8], fr[8], fc[8];
-      interp8<ST, 16, true, false>(arena + (size_t)pi * patch_elems, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f, fr, fc);
+      interp8<ST, LPO, true, FS>(arena + (size_t)pi * patch_elems, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f, fr, fc);
       double s = 0, gcc = 0, gcr = 0, grr = 0, bc = 0, br = 0;
 #pragma unroll
       for (int ch = 0; ch < 8; ++ch) {
@@ -133,13 +139,13 @@ __global__ __launch_bounds__(256) void k_inner_points(const InnerArgs a) {
         gcc = fma(fc[ch], fc[ch], gcc); gcr = fma(fc[ch], fr[ch], gcr); grr = fma(fr[ch], fr[ch], grr);
         bc = fma(fc[ch], r, bc); br = fma(fr[ch], r, br);
       }
-      s = row16_sum(s);
+      s = rsum(s);
       double rho[3];
       loss_eval(a.loss.type, a.loss.a, 1.0, s, rho);
       if (valid) cost += 0.5 * rho[0];
       if (with_jac) {
-        gcc = row16_sum(gcc) * sx * sx; gcr = row16_sum(gcr) * sx * sy; grr = row16_sum(grr) * sy * sy;
-        bc = row16_sum(bc) * sx; br = row16_sum(br) * sy;
+        gcc = rsum(gcc) * sx * sx; gcr = rsum(gcr) * sx * sy; grr = rsum(grr) * sy * sy;
+        bc = rsum(bc) * sx; br = rsum(br) * sy;
         double kappa = 0.0;
         if (s != 0.0 && rho[2] > 0.0) {
           const double D = 1.0 + 2.0 * s * rho[2] / rho[1];
@@ -162,12 +168,12 @@ __global__ __launch_bounds__(256) void k_inner_points(const InnerArgs a) {
         for (int j = 0; j < 3; ++j) acc[6 + j] += PX[0][j] * b0 + PX[1][j] * b1;
       }
     }
-    cost = rows4_sum(cost);   // every lane of a row holds the row's cost -> sum of the 4 rows
+    cost = rows_sum<LPO>(cost);   // every lane of a row holds the row's cost -> sum of the 4 rows
     if (with_jac) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) Hn[j] = rows4_sum(acc[j]);
+      for (int j = 0; j < 6; ++j) Hn[j] = rows_sum<LPO>(acc[j]);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) gn[j] = rows4_sum(acc[6 + j]);
+      for (int j = 0; j < 3; ++j) gn[j] = rows_sum<LPO>(acc[6 + j]);
     }
     return cost;
   };
@@ -256,8 +262,8 @@ __global__ __launch_bounds__(256) void k_inner_points(const InnerArgs a) {
 int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
                             const pxr_loss* loss, const int64_t* d_pt_ptr, const int64_t* d_pt_obs,
                             const int* d_pt_var, double* d_cost_before) {
-  if (arena->C != 128) return set_error(PXR_EUNSUPPORTED, "inner iterations: CHANNELS=%d not supported (128)", arena->C);
-  if (cfg->use_float_simd) return set_error(PXR_EUNSUPPORTED, "inner iterations with use_float_simd are not supported");
+  if (arena->C != 128 && arena->C != 64)
+    return set_error(PXR_EUNSUPPORTED, "inner iterations: CHANNELS=%d not supported (128, 64)", arena->C);
   InnerArgs a;
   a.v = *view;
   a.arena = arena->d_data; a.corners = arena->d_corners; a.scales = arena->d_scales;
@@ -266,11 +272,18 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   a.xyz_out = const_cast<double*>(view->d_xyz); a.cost_before = d_cost_before;
   const unsigned blocks = (unsigned)((view->n_points + 3) / 4);
   if (blocks == 0) return PXR_OK;
-  switch (arena->dtype) {
-    case PXR_F16: hipLaunchKernelGGL((k_inner_points<_Float16, 128>), dim3(blocks), dim3(256), 0, ctx->stream, a); break;
-    case PXR_F32: hipLaunchKernelGGL((k_inner_points<float, 128>), dim3(blocks), dim3(256), 0, ctx->stream, a); break;
-    default: return set_error(PXR_EUNSUPPORTED, "inner iterations: fp64 patches are not supported");
-  }
+#define INNER_LAUNCH(ST, CC)                                                                                  \
+  do {                                                                                                        \
+    if (cfg->use_float_simd) hipLaunchKernelGGL((k_inner_points<ST, CC, true>), dim3(blocks), dim3(256), 0, ctx->stream, a);  \
+    else hipLaunchKernelGGL((k_inner_points<ST, CC, false>), dim3(blocks), dim3(256), 0, ctx->stream, a);     \
+  } while (0)
+  if (arena->dtype == PXR_F16 && arena->C == 128) INNER_LAUNCH(_Float16, 128);
+  else if (arena->dtype == PXR_F16 && arena->C == 64) INNER_LAUNCH(_Float16, 64);
+  else if (arena->dtype == PXR_F32 && arena->C == 128) INNER_LAUNCH(float, 128);
+  else if (arena->dtype == PXR_F32 && arena->C == 64) INNER_LAUNCH(float, 64);
+  else if (arena->dtype == PXR_F64 && arena->C == 128) INNER_LAUNCH(double, 128);
+  else INNER_LAUNCH(double, 64);
+#undef INNER_LAUNCH
   return hip_check(hipGetLastError(), "k_inner_points launch");
 }
 

@@ -45,3 +45,26 @@ def test_inner_iterations_match_oracle(ctx, obs_per_point, pt_sigma):
     s1 = ba1.solve(interp_cfg(), make_loss("cauchy", [0.25]), *gauge,
                    options=lm_options(max_iterations=1, use_inner_iterations=True))
     assert s1["final_cost"] < s0["final_cost"]
+
+
+@pytest.mark.parametrize("dtype,channels,float_simd", [(np.float16, 64, False), (np.float64, 128, False),
+                                                        (np.float32, 64, True), (np.float16, 128, True)])
+def test_inner_iterations_other_storage_and_float_simd(ctx, dtype, channels, float_simd):
+    """The nested LM for CHANNELS = 64, fp64 patches and InterpolationConfig.use_float_simd (rows of 8 lanes,
+    fp32 vertical pass) against the oracle."""
+    import pxo
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    prob = synthetic.make_ba_problem(n_cams=6, n_points=40, obs_per_point=5, seed=77, dtype=dtype, channels=channels,
+                                     pt_sigma=0.02)
+    gauge = _gauge(prob)
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    s = ba.solve(interp_cfg(use_float_simd=float_simd), make_loss("cauchy", [0.25]), *gauge,
+                 options=lm_options(max_iterations=3, use_inner_iterations=True))
+    q, t, k, X = ba.params()
+    so, qo, to, ko, Xo = pxo.ba_solve(prob, pxo.cfg(use_float_simd=float_simd), pxo.loss("cauchy", 0.25), *gauge,
+                                      pxo.lm_options(max_iterations=3, use_inner_iterations=1))
+    assert s["iterations"] == so["iterations"] and s["num_successful"] == so["num_successful"]
+    assert abs(s["final_cost"] - so["final_cost"]) < 1e-4 * max(so["final_cost"], 1e-9)
+    assert np.abs(q - qo).max() < 1e-4 and np.abs(t - to).max() < 1e-4 and np.abs(X - Xo).max() < 1e-4

@@ -886,7 +886,9 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   else if (arena->dtype == PXR_F16 && arena->C == 64) KA_SOLVE_LAUNCH(_Float16, 64);
   else if (arena->dtype == PXR_F32 && arena->C == 128) KA_SOLVE_LAUNCH(float, 128);
   else if (arena->dtype == PXR_F64 && arena->C == 128) KA_SOLVE_LAUNCH(double, 128);
-  else return set_error(PXR_EUNSUPPORTED, "pxr_ka_solve: dtype/CHANNELS combination not supported (f16/f32/f64 x 128, f16 x 64)");
+  else if (arena->dtype == PXR_F32 && arena->C == 64) KA_SOLVE_LAUNCH(float, 64);
+  else if (arena->dtype == PXR_F64 && arena->C == 64) KA_SOLVE_LAUNCH(double, 64);
+  else return set_error(PXR_EUNSUPPORTED, "pxr_ka_solve: CHANNELS=%d not supported (128, 64)", arena->C);
 #undef KA_SOLVE_LAUNCH
   PXR_HIP(hipGetLastError());
   std::vector<pxr_lm_summary> sums(np);

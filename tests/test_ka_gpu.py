@@ -136,3 +136,20 @@ def test_infeasible_start_and_empty_problems(ctx):
     ka2 = KAProblem(ctx, arena, prob)
     total2, _ = ka2.solve(interp_cfg(), make_loss())
     assert total2["initial_cost"] == 0.0 and np.array_equal(ka2.keypoints(), prob["kp"])
+
+
+@pytest.mark.parametrize("dtype,channels", [(np.float16, 64), (np.float32, 64), (np.float64, 64), (np.float32, 128),
+                                             (np.float64, 128)])
+def test_solve_every_storage_type_and_channel_count(ctx, dtype, channels):
+    """FeaturePatch storage half / float / double (featurepatch.cc:365-367) x CHANNELS 128 / 64 through the
+    in-kernel LM (the fp64 variants run with register spills: parity is what is checked here)."""
+    import pxo
+    import pxo_ka
+    from pixsfm_amd.engine import interp_cfg, make_loss
+    prob, arena, ka = _setup(ctx, n_tracks=8, track_len=4, seed=33, dtype=dtype, channels=channels, max_kps_per_problem=16)
+    total, per = ka.solve(interp_cfg(), make_loss("cauchy", [0.25]), bound=4.0, per_problem=True)
+    kpo, sums = pxo_ka.ka_solve(prob, pxo.cfg(), pxo.loss("cauchy", 0.25), 4.0)
+    for g, o in zip(per, sums):
+        assert g["iterations"] == o["iterations"] and g["termination"] == o["termination"]
+        assert abs(g["final_cost"] - o["final_cost"]) < 1e-7 * max(o["final_cost"], 1e-6)
+    assert np.abs(ka.keypoints() - kpo).max() < 1e-6

@@ -13,7 +13,7 @@
 //                  columns of L / rows of inv(L) exported to LDS so the updates need no masks);
 //                  WG 0 writes L_kk and inv(L_kk) back, WG b >= 1 computes its 128 panel rows
 //                  X = B inv(L_kk)^T as an LDS-tiled GEMM (8x4 register micro-tiles).
-//   k_chol_syrk    trailing update A22 -= P P^T on 64x64 tiles (lower tiles only).
+//   k_chol_syrk    trailing update A22 -= P P^T on 64x64 tiles (lower tiles only), fp64 MFMA.
 //   k_chol_backsolve L^T x = y in one launch: a workgroup per block column, solution blocks handed on
 //                  through flags; x_k = inv(L_kk)^T z_k, z_c -= L(k-block, c-block)^T x_k.
 #include <hip/hip_runtime.h>
@@ -160,43 +160,63 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ a, int 
   }
 }
 
-// A22 -= P P^T, tiles of 64 x 64; P = A(k+nb : n_rows, k : k+nb)
+// A22 -= P P^T on 64 x 64 tiles (lower tiles only); P = A(k+nb : n_rows, k : k+nb).  The one GEMM-shaped
+// piece of the path: fp64 MFMA (v_mfma_f64_16x16x4_f64).  Each of the four wavefronts owns a 32 x 32
+// quarter = 2 x 2 MFMA blocks, K = 64 in 16 steps.  Operands come from the LDS-staged panel rows
+// (Pt[m][row]: lane l feeds row l % 16, k = l / 16 for A and for B alike).  The product is formed
+// TRANSPOSED (A <- rows of the column tile, B <- rows of the row tile) so that the accumulator's
+// lane index (col = lane & 15) runs along the matrix ROWS, which are contiguous in memory:
+// C/D layout of the f64 MFMA is col = lane & 15, row = (lane >> 4) + 4 * reg.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+constexpr int SPAD = CNB + 8;   // LDS row stride: spreads the four k-rows of a step over the banks
+
 __global__ __launch_bounds__(256) void k_chol_syrk(double* __restrict__ a, int n_rows, int lda, int k, int nb) {
   const int ti = blockIdx.y, tj = blockIdx.x;
   if (tj > ti) return;
-  __shared__ double Pi[CNB][CNB];   // [m][row]
-  __shared__ double Pj[CNB][CNB];
+  __shared__ double Pi[CNB][SPAD];   // [m][row of the row tile]
+  __shared__ double Pj[CNB][SPAD];   // [m][row of the column tile]
   const int r0 = k + nb;
   const int tid = threadIdx.x;
-  for (int e = tid; e < CNB * CNB; e += 256) {
-    const int i = e % CNB, m = e / CNB;
+#pragma unroll
+  for (int q = 0; q < CNB * CNB / 256; ++q) {
+    const int e = tid + q * 256, i = e % CNB, m = e / CNB;
     const int gi = r0 + ti * CNB + i, gj = r0 + tj * CNB + i;
-    Pi[m][i] = (gi < n_rows && m < nb) ? a[(size_t)gi + (size_t)(k + m) * lda] : 0.0;
-    Pj[m][i] = (gj < n_rows && m < nb) ? a[(size_t)gj + (size_t)(k + m) * lda] : 0.0;
+    // clamped address + select (a conditional load costs a branch and a wait per element)
+    const size_t col = (size_t)(k + min(m, nb - 1)) * lda;
+    const double vi = a[(size_t)min(gi, n_rows - 1) + col], vj = a[(size_t)min(gj, n_rows - 1) + col];
+    Pi[m][i] = (gi < n_rows && m < nb) ? vi : 0.0;
+    Pj[m][i] = (gj < n_rows && m < nb) ? vj : 0.0;
   }
   __syncthreads();
-  const int tx = tid & 15, ty = tid >> 4;
-  double acc[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll 8
-  for (int m = 0; m < CNB; ++m) {
-    double pi[4], pj[4];
+  const int lane = tid & 63, w = tid >> 6, wi = w >> 1, wj = w & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  mfma_d4 acc[2][2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { pi[u] = Pi[m][4 * ty + u]; pj[u] = Pj[m][4 * tx + u]; }
+  for (int x = 0; x < 2; ++x)
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int w = 0; w < 4; ++w) acc[u][w] = fma(pi[u], pj[w], acc[u][w]);
+    for (int y = 0; y < 2; ++y) acc[x][y] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int s = 0; s < CNB / 4; ++s) {
+    const int m = 4 * s + lk;
+    const double aj0 = Pj[m][32 * wj + lr], aj1 = Pj[m][32 * wj + 16 + lr];       // A: column-tile rows
+    const double bi0 = Pi[m][32 * wi + lr], bi1 = Pi[m][32 * wi + 16 + lr];       // B: row-tile rows
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj0, bi0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj0, bi1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj1, bi0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj1, bi1, acc[1][1], 0, 0, 0);
   }
+  // acc[x][y][r] = sum_m P[gj][m] P[gi][m]  with  gj = column-tile row 32 wj + 16 x + (lane >> 4) + 4 r,
+  //                                               gi = row-tile row    32 wi + 16 y + (lane & 15)
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const int gj = r0 + tj * CNB + 4 * tx + w;
-    if (gj >= n_rows) continue;
+  for (int x = 0; x < 2; ++x)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int gi = r0 + ti * CNB + 4 * ty + u;
-      if (gi < n_rows && gi >= gj) a[(size_t)gi + (size_t)gj * lda] -= acc[u][w];
-    }
-  }
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gj = r0 + tj * CNB + 32 * wj + 16 * x + lk + 4 * r;
+        const int gi = r0 + ti * CNB + 32 * wi + 16 * y + lr;
+        if (gi < n_rows && gj < n_rows && gi >= gj) a[(size_t)gi + (size_t)gj * lda] -= acc[x][y][r];
+      }
 }
 
 // L^T x = y in ONE launch: workgroup b owns block column c = nblk - 1 - b (64 unknowns) and keeps its

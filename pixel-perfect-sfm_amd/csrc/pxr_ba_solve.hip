@@ -54,10 +54,22 @@ struct SolveDev {          // device-side problem description shared by the kern
 };
 
 // ---- K_jac ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_jac(const SolveDev d, const double* __restrict__ rec,
-                                             pxr_loss loss, double* __restrict__ L, double* __restrict__ W) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= d.v.n_obs) return;
+// The 216-B L record and the 192-B W block of an observation are assembled in LDS (one row per lane)
+// and written out by the wavefront as contiguous, fully coalesced streams: per-lane stores of
+// 27 + 24 scattered doubles left partially written lines to be evicted and re-merged in HBM.
+constexpr int JAC_THREADS = 128;
+
+__global__ __launch_bounds__(JAC_THREADS) void k_jac(const SolveDev d, const double* __restrict__ rec,
+                                                     pxr_loss loss, double* __restrict__ L, double* __restrict__ W) {
+  extern __shared__ double jstage[];            // per wavefront: [64][LS] then [64][WS]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int LS = d.LS, W3 = 3 * d.DC, WS = W3 + 1;
+  double* Lw = jstage + (size_t)wave * 64 * (LS + WS);
+  double* Ww = Lw + (size_t)64 * LS;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + wave * 64;      // first observation of this wavefront
+  const int64_t i = i0 + lane;
+  const int n_valid = (int)min((int64_t)64, d.v.n_obs - i0);
+  if (i < d.v.n_obs) {
   const int img = d.v.d_obs_image[i], pt = d.v.d_obs_point[i], cam = d.v.d_image_camera[img];
   double q[4], t[3], X[3], k[PXR_KPAD];
 #pragma unroll
@@ -81,7 +93,7 @@ __global__ __launch_bounds__(256) void k_jac(const SolveDev d, const double* __r
     const double alpha = 1.0 - sqrt(D);
     kappa = (2.0 * alpha - alpha * alpha) / s;
   }
-  double* Lo = L + (size_t)i * d.LS;
+  double* Lo = Lw + (size_t)lane * LS;
   const double m00 = rho[1] * (gxx - kappa * bx * bx), m01 = rho[1] * (gxy - kappa * bx * by),
                m11 = rho[1] * (gyy - kappa * by * by);
   Lo[0] = m00; Lo[1] = m01; Lo[2] = m11;
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(256) void k_jac(const SolveDev d, const double* __r
     me0[j] = m00 * e0[j] + m01 * e1[j];
     me1[j] = m01 * e0[j] + m11 * e1[j];
   }
-  double* Wo = W + (size_t)i * d.DC * 3;
+  double* Wo = Ww + (size_t)lane * WS;
   // B: tangent pose columns then variable intrinsics columns
   double* B0 = Lo + 11;
   double* B1 = B0 + d.DC;
@@ -148,6 +160,14 @@ __global__ __launch_bounds__(256) void k_jac(const SolveDev d, const double* __r
     }
   }
   for (; col < d.DC; ++col) put(col, 0.0, 0.0);
+  }
+  __threadfence_block();                        // LDS rows of the other lanes of this wavefront
+  __builtin_amdgcn_wave_barrier();
+  if (n_valid <= 0) return;
+  double* Lg = L + (size_t)i0 * LS;
+  for (int x = lane; x < n_valid * LS; x += 64) Lg[x] = Lw[x];
+  double* Wg = W + (size_t)i0 * W3;
+  for (int x = lane; x < n_valid * W3; x += 64) { const int o = x / W3; Wg[x] = Ww[o * WS + (x - o * W3)]; }
 }
 
 // global column index of camera-side column `a` of an observation in image img / camera cam
@@ -189,15 +209,19 @@ __global__ __launch_bounds__(256) void k_point(const SolveDev d, const int64_t* 
 // ---- K_img: U and g_c --------------------------------------------------------------------------
 struct ImgChunk { int img; int64_t begin, end; };
 
+constexpr int IMG_BATCH = 128;   // observations staged in LDS per pass
+
 __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* __restrict__ chunks,
                                              const int64_t* __restrict__ img_obs,
                                              const double* __restrict__ L, double* __restrict__ U,
                                              double* __restrict__ gc) {
-  __shared__ double red[256];
+  extern __shared__ double stage[];            // [IMG_BATCH][LS] records, then [256] reduction slots
   const ImgChunk ch = chunks[blockIdx.x];
   const int img = ch.img, cam = d.v.d_image_camera[img];
   const int dc = d.pose_dim[img] + d.intr_dim[cam];
   if (dc == 0) return;
+  const int LS = d.LS;
+  double* red = stage + (size_t)IMG_BATCH * LS;
   const int NP = dc * (dc + 1) / 2, NE = NP + dc;
   const int slices = 256 / NE;                 // NE <= 189
   const int e = threadIdx.x % NE, sl = threadIdx.x / NE;
@@ -206,25 +230,26 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
   if (is_g) { a = e - NP; }
   else { int rem = e; a = 0; while (rem >= dc - a) { rem -= dc - a; ++a; } b = a + rem; }
   double acc = 0.0;
-  if (sl < slices) {
-    // four independent gathers in flight per thread (the loop is bound by HBM latency, not bandwidth)
-    double acc4[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int64_t o = ch.begin + sl; o < ch.end; o += 4 * (int64_t)slices) {
-      const double* Lo[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t ou = o + (int64_t)u * slices;
-        Lo[u] = ou < ch.end ? L + (size_t)img_obs[ou] * d.LS : nullptr;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (!Lo[u]) continue;
-        const double* B0 = Lo[u] + 11; const double* B1 = B0 + d.DC;
-        if (is_g) acc4[u] += B0[a] * Lo[u][3] + B1[a] * Lo[u][4];
-        else acc4[u] += B0[a] * (Lo[u][0] * B0[b] + Lo[u][1] * B1[b]) + B1[a] * (Lo[u][1] * B0[b] + Lo[u][2] * B1[b]);
+  // The records of an image's observations are gathered (216 B each at DC = 8) into LDS with
+  // coalesced, independent loads -- consecutive lanes read consecutive doubles of a record -- and
+  // every thread then accumulates its matrix entry from LDS.  (A per-thread gather loop over the
+  // observations was bound by the latency of its dependent loads.)
+  for (int64_t base = ch.begin; base < ch.end; base += IMG_BATCH) {
+    const int nb = (int)min((int64_t)IMG_BATCH, ch.end - base);
+    for (int x = threadIdx.x; x < nb * LS; x += 256) {
+      const int o = x / LS, f = x - o * LS;
+      stage[x] = L[(size_t)img_obs[base + o] * LS + f];
+    }
+    __syncthreads();
+    if (sl < slices) {
+      for (int o = sl; o < nb; o += slices) {
+        const double* Lo = stage + (size_t)o * LS;
+        const double* B0 = Lo + 11; const double* B1 = B0 + d.DC;
+        if (is_g) acc += B0[a] * Lo[3] + B1[a] * Lo[4];
+        else acc += B0[a] * (Lo[0] * B0[b] + Lo[1] * B1[b]) + B1[a] * (Lo[1] * B0[b] + Lo[2] * B1[b]);
       }
     }
-    acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+    __syncthreads();
   }
   red[threadIdx.x] = acc;
   __syncthreads();
@@ -715,7 +740,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     for (int64_t i = 0; i < n_obs; ++i) { img_obs[ic[obs_image[i]]++] = i; pt_obs[pc[obs_point[i]]++] = i; }
   }
   std::vector<ImgChunk> chunks;
-  const int64_t CH = 384;    // short chunks: the per-thread gather loop in k_img is latency-bound
+  const int64_t CH = 512;    // observations per k_img workgroup (4 LDS batches)
   for (int i = 0; i < n_img; ++i)
     for (int64_t b = img_cnt[i]; b < img_cnt[i + 1]; b += CH)
       chunks.push_back({i, b, std::min(img_cnt[i + 1], b + CH)});
@@ -805,12 +830,14 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   };
   // linearise at the CURRENT parameters from record buffer `rec`
   auto linearize = [&](const double* rec) -> int {
-    hipLaunchKernelGGL(k_jac, dim3(nblk(n_obs)), dim3(256), 0, st, dv, rec, *loss, L.p, W.p);
+    hipLaunchKernelGGL(k_jac, dim3((unsigned)((n_obs + JAC_THREADS - 1) / JAC_THREADS)), dim3(JAC_THREADS),
+                       sizeof(double) * (JAC_THREADS / 64) * 64 * (LS + 3 * DC + 1), st, dv, rec, *loss, L.p, W.p);
     hipLaunchKernelGGL(k_point, dim3(nblk(n_pts)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, L.p, V.p, gp.p);
     PXR_HIP(hipMemsetAsync(U.p, 0, sizeof(double) * nc1 * nc1, st));
     PXR_HIP(hipMemsetAsync(gcd.p, 0, sizeof(double) * 2 * nc1, st));
     if (n_c > 0 && !chunks.empty()) {
-      hipLaunchKernelGGL(k_img, dim3((unsigned)chunks.size()), dim3(256), 0, st, dv, d_chunks.p, d_img_obs.p, L.p, U.p, gc);
+      hipLaunchKernelGGL(k_img, dim3((unsigned)chunks.size()), dim3(256), sizeof(double) * ((size_t)IMG_BATCH * LS + 256), st, dv,
+                         d_chunks.p, d_img_obs.p, L.p, U.p, gc);
       hipLaunchKernelGGL(k_extract_diag, dim3(nblk(n_c)), dim3(256), 0, st, n_c, U.p, diagU);
     }
     LAUNCH_CHECK("linearize kernels");
@@ -838,6 +865,8 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   if (use_lds_schur && n_c > 0)
     PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(DC <= 8 ? k_schur_lds<8> : (DC <= 16 ? k_schur_lds<16> : k_schur_lds<32>)),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_shmem));
+  PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_jac), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(double) * (JAC_THREADS / 64) * 64 * (LS + 3 * DC + 1))));
   const bool verbose = std::getenv("PXR_VERBOSE") != nullptr;
   const bool phase_timing = std::getenv("PXR_PHASE_TIMING") != nullptr;   // adds a stream sync per phase
   double ph_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};

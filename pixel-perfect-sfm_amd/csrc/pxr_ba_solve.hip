@@ -13,15 +13,15 @@
 // kernel per LM iteration, everything else is per-observation 2 x (dc+3) algebra.
 //
 // Pipeline per linearisation (observations sorted by point for K1 locality):
-//   K_jac     thread/obs    M~, b~, E = d(x,y)/dX (2x3), B = d(x,y)/d(pose,intr) tangent (2xdc)
+//   K_jac     thread/obs    M~, b~, E = d(x,y)/dX (2x3), B = d(x,y)/d(pose,intr) tangent (2xdc) and
+//             W_i = B^T M~ E (dc x 3); records assembled in LDS, written as coalesced streams
 //   K_point   thread/point  V_p = sum E^T M~ E, g_p = sum E^T b~
-//   K_img     block/(image,chunk)  U (pose/intrinsics blocks, upper) and g_c, LDS-reduced
+//   K_img     block/(image,chunk)  U (pose/intrinsics blocks, upper) and g_c from LDS-staged records
 // per LM attempt (radius changes on rejection, linearisation is reused):
 //   K_pinv    thread/point  T_p = (V_p + D_p/radius)^-1
-//   (W_i = B^T M~ E (dc x 3) is written by K_jac once per linearisation; Y_i = W_i T_p on the fly)
-//   K_schur   thread/(obs,row)  S -= Y_i W_j^T over the point's observation pairs (upper
-//             triangle only), rhs -= Y_i g_p      [atomics into the dense reduced system]
-//   all-reduce(S | rhs) over ranks (RCCL, multi-GPU), + LM damping, rocSOLVER potrf/potrs
+//   K_schur_lds  block/(image chunk, column tile)  S -= Y_i W_j^T over the point's observation pairs
+//             (upper triangle only), rhs -= Y_i g_p, Y_i = W_i T_p formed on the fly; privatised in LDS
+//   all-reduce(S | rhs) over ranks (RCCL, multi-GPU), + LM damping, blocked dense Cholesky (pxr_chol.hip)
 //   K_backsub thread/point  delta_p = -T_p (g_p + sum W_i^T delta_c)
 //   K_update  x (+) delta (quaternion manifold, subset manifolds), then pxr_ba_eval at the
 //             candidate WITH Jacobians (same HBM traffic as cost-only, saves the second
@@ -40,7 +40,6 @@
 
 namespace pxr {
 
-constexpr int DC_CAP = 6 + PXR_KPAD;  // pose tangent (6) + intrinsics
 
 struct SolveDev {          // device-side problem description shared by the kernels
   pxr_ba_view v;           // parameters being linearised (current or candidate)

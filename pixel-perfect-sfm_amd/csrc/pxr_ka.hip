@@ -37,10 +37,7 @@
 namespace pxr {
 
 constexpr int KA_NT = 256;     // threads per sub-problem workgroup
-constexpr int KA_NLDS = 100;   // LDS budget for the damped blocks: KA_NLDS^2 doubles (78 KiB).  Occupancy is set by the
-                               // ~284 VGPRs of the 16-texel bicubic stencil + LM state (one workgroup per CU); capping
-                               // them (amdgpu_waves_per_eu) spills to scratch and was measured to produce wrong steps,
-                               // so the register budget is left to the compiler
+constexpr int KA_NLDS = 100;   // LDS budget for the damped blocks: KA_NLDS^2 doubles (78 KiB: two workgroups per CU)
 
 struct KaArgs {
   pxr_ka_view v;
@@ -511,8 +508,7 @@ __global__ __launch_bounds__(KA_NT) void ka_setup_kernel(const KaArgs a, KaInfo*
 
 
 template <typename ST, int C>
-__global__ __launch_bounds__(KA_NT) void ka_solve_kernel(const KaArgs a, const KaInfo* __restrict__ info) {
-  extern __shared__ double sh_A[];      // lds_elems doubles (damped blocks) when the sub-problem fits
+__device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __restrict__ info, double* sh_A) {
   __shared__ double sh4[KA_NT / 64];
   __shared__ int sh_ok;
   const int prob = blockIdx.x, tid = threadIdx.x;
@@ -717,6 +713,22 @@ __global__ __launch_bounds__(KA_NT) void ka_solve_kernel(const KaArgs a, const K
   if (tid == 0) a.summaries[prob] = sm;
 }
 
+// Two entry points over the same body.  The fp16 / fp32 instantiations need ~284 VGPRs unconstrained,
+// i.e. one wavefront per SIMD; capped at 256 (two wavefronts per SIMD, ~60 registers spilled to
+// scratch) the whole config-2 solve drops from 12.7 to 9.6 ms.  The fp64-storage instantiations keep the
+// compiler's own budget: capped, they spill ~950 registers.  (A tighter cap of 3 waves/SIMD produced
+// wrong steps on ROCm 7.2 and is not used.)
+template <typename ST, int C>
+__global__ __launch_bounds__(KA_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void ka_solve_kernel_occ2(const KaArgs a, const KaInfo* __restrict__ info) {
+  extern __shared__ double sh_A[];      // lds_elems doubles (damped blocks) when the sub-problem fits
+  ka_solve_body<ST, C>(a, info, sh_A);
+}
+template <typename ST, int C>
+__global__ __launch_bounds__(KA_NT) void ka_solve_kernel(const KaArgs a, const KaInfo* __restrict__ info) {
+  extern __shared__ double sh_A[];
+  ka_solve_body<ST, C>(a, info, sh_A);
+}
+
 // ---- per-edge evaluation (parity checks) -------------------------------------------------------------------
 template <typename ST, int C>
 __global__ __launch_bounds__(256) void ka_eval_kernel(const KaArgs a, bool fsimd, double* __restrict__ cost,
@@ -874,20 +886,20 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   a.lds_elems = lds_elems;
   PXR_HIP(hipMemcpyAsync(d_hptr, h_ptr.data(), sizeof(int64_t) * (np + 1), hipMemcpyHostToDevice, st));
   const size_t shmem = sizeof(double) * (size_t)lds_elems;
-#define KA_SOLVE_LAUNCH(ST, CC)                                                                              \
+#define KA_SOLVE_LAUNCH(KERNEL, ST, CC)                                                                      \
   do {                                                                                                       \
-    PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ka_solve_kernel<ST, CC>),                      \
+    PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<ST, CC>),                               \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                    \
     PXR_HIP(hipEventRecord(ctx->ev_start, st));                                                              \
-    hipLaunchKernelGGL((ka_solve_kernel<ST, CC>), dim3(np), dim3(KA_NT), shmem, st, a, d_info);              \
+    hipLaunchKernelGGL((KERNEL<ST, CC>), dim3(np), dim3(KA_NT), shmem, st, a, d_info);                       \
     PXR_HIP(hipEventRecord(ctx->ev_stop, st));                                                               \
   } while (0)
-  if (arena->dtype == PXR_F16 && arena->C == 128) KA_SOLVE_LAUNCH(_Float16, 128);
-  else if (arena->dtype == PXR_F16 && arena->C == 64) KA_SOLVE_LAUNCH(_Float16, 64);
-  else if (arena->dtype == PXR_F32 && arena->C == 128) KA_SOLVE_LAUNCH(float, 128);
-  else if (arena->dtype == PXR_F64 && arena->C == 128) KA_SOLVE_LAUNCH(double, 128);
-  else if (arena->dtype == PXR_F32 && arena->C == 64) KA_SOLVE_LAUNCH(float, 64);
-  else if (arena->dtype == PXR_F64 && arena->C == 64) KA_SOLVE_LAUNCH(double, 64);
+  if (arena->dtype == PXR_F16 && arena->C == 128) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, _Float16, 128);
+  else if (arena->dtype == PXR_F16 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, _Float16, 64);
+  else if (arena->dtype == PXR_F32 && arena->C == 128) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, float, 128);
+  else if (arena->dtype == PXR_F64 && arena->C == 128) KA_SOLVE_LAUNCH(ka_solve_kernel, double, 128);
+  else if (arena->dtype == PXR_F32 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, float, 64);
+  else if (arena->dtype == PXR_F64 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel, double, 64);
   else return set_error(PXR_EUNSUPPORTED, "pxr_ka_solve: CHANNELS=%d not supported (128, 64)", arena->C);
 #undef KA_SOLVE_LAUNCH
   PXR_HIP(hipGetLastError());

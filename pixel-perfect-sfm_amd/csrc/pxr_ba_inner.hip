@@ -46,10 +46,9 @@ __device__ __forceinline__ double rows_sum(double v) {
 constexpr int INNER_MAXO = 16;   // observations per point staged in LDS
 
 template <typename ST, int C, bool FS>   // FS: InterpolationConfig.use_float_simd
-__global__ __launch_bounds__(256) void k_inner_points(const InnerArgs a) {
+__device__ __forceinline__ void inner_points_body(const InnerArgs& a, double (*sh_obs)[INNER_MAXO][26]) {
   static_assert(C == 128 || C == 64, "one observation per row of C / 8 lanes");
   constexpr int LPO = C / 8, ROWS = 64 / LPO;
-  __shared__ double sh_obs[4][INNER_MAXO][26];   // per wavefront: q(4) t(3) k(12) sx sy corner(2) model patch
   const int lane = threadIdx.x & 63, row = lane / LPO, sub = lane % LPO;
   const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= a.v.n_points) return;
@@ -257,6 +256,20 @@ __global__ __launch_bounds__(256) void k_inner_points(const InnerArgs a) {
   if (lane == 0) { a.xyz_out[3 * p] = X[0]; a.xyz_out[3 * p + 1] = X[1]; a.xyz_out[3 * p + 2] = X[2]; }
 }
 
+// Two entry points over the same body: the fp16 / fp32 instantiations are capped at 256 VGPRs (two
+// wavefronts per SIMD; unconstrained they take ~330 and run one), the fp64-storage ones keep the
+// compiler's budget (capped they would spill several hundred registers).
+template <typename ST, int C, bool FS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_inner_points_occ2(const InnerArgs a) {
+  __shared__ double sh_obs[4][INNER_MAXO][26];   // per wavefront: q(4) t(3) k(12) sx sy corner(2) model patch
+  inner_points_body<ST, C, FS>(a, sh_obs);
+}
+template <typename ST, int C, bool FS>
+__global__ __launch_bounds__(256) void k_inner_points(const InnerArgs a) {
+  __shared__ double sh_obs[4][INNER_MAXO][26];
+  inner_points_body<ST, C, FS>(a, sh_obs);
+}
+
 // Enqueue the inner iterations on the candidate parameters `view` (xyz refined in place);
 // *d_cost_before (device double, caller-zeroed) receives the cost at the unrefined candidate.
 int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
@@ -272,17 +285,17 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   a.xyz_out = const_cast<double*>(view->d_xyz); a.cost_before = d_cost_before;
   const unsigned blocks = (unsigned)((view->n_points + 3) / 4);
   if (blocks == 0) return PXR_OK;
-#define INNER_LAUNCH(ST, CC)                                                                                  \
+#define INNER_LAUNCH(KERNEL, ST, CC)                                                                          \
   do {                                                                                                        \
-    if (cfg->use_float_simd) hipLaunchKernelGGL((k_inner_points<ST, CC, true>), dim3(blocks), dim3(256), 0, ctx->stream, a);  \
-    else hipLaunchKernelGGL((k_inner_points<ST, CC, false>), dim3(blocks), dim3(256), 0, ctx->stream, a);     \
+    if (cfg->use_float_simd) hipLaunchKernelGGL((KERNEL<ST, CC, true>), dim3(blocks), dim3(256), 0, ctx->stream, a);  \
+    else hipLaunchKernelGGL((KERNEL<ST, CC, false>), dim3(blocks), dim3(256), 0, ctx->stream, a);             \
   } while (0)
-  if (arena->dtype == PXR_F16 && arena->C == 128) INNER_LAUNCH(_Float16, 128);
-  else if (arena->dtype == PXR_F16 && arena->C == 64) INNER_LAUNCH(_Float16, 64);
-  else if (arena->dtype == PXR_F32 && arena->C == 128) INNER_LAUNCH(float, 128);
-  else if (arena->dtype == PXR_F32 && arena->C == 64) INNER_LAUNCH(float, 64);
-  else if (arena->dtype == PXR_F64 && arena->C == 128) INNER_LAUNCH(double, 128);
-  else INNER_LAUNCH(double, 64);
+  if (arena->dtype == PXR_F16 && arena->C == 128) INNER_LAUNCH(k_inner_points_occ2, _Float16, 128);
+  else if (arena->dtype == PXR_F16 && arena->C == 64) INNER_LAUNCH(k_inner_points_occ2, _Float16, 64);
+  else if (arena->dtype == PXR_F32 && arena->C == 128) INNER_LAUNCH(k_inner_points_occ2, float, 128);
+  else if (arena->dtype == PXR_F32 && arena->C == 64) INNER_LAUNCH(k_inner_points_occ2, float, 64);
+  else if (arena->dtype == PXR_F64 && arena->C == 128) INNER_LAUNCH(k_inner_points, double, 128);
+  else INNER_LAUNCH(k_inner_points, double, 64);
 #undef INNER_LAUNCH
   return hip_check(hipGetLastError(), "k_inner_points launch");
 }

@@ -56,7 +56,10 @@ typedef struct pxr_arena pxr_arena;
 typedef struct {
   int32_t l2_normalize;   /* default 1 */
   int32_t use_float_simd; /* default 0: fp32 horizontal pass, fp64 vertical pass */
-  int32_t check_bounds;   /* default 0 */
+  int32_t check_bounds;   /* default 0.  1: an evaluation outside 0 < u < W, 0 < v < H of its patch FAILS
+                           * (patch_interpolator.h:125-135,160-166): the block's cost / squared norm is NaN,
+                           * the solvers treat a non-finite trial cost as an invalid step and a non-finite
+                           * initial cost as PXR_TERM_FAILURE, like Ceres does when Evaluate returns false */
 } pxr_interp_cfg;
 
 typedef struct {

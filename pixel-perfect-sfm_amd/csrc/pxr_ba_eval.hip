@@ -38,6 +38,7 @@ struct BaEvalArgs {
   const double* scales;
   int H, W;
   int l2_normalize;
+  int check_bounds;
   double* rec;
   double* out_r;
   double* out_gx;
@@ -143,6 +144,10 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(const BaEvalArgs a) {
   if (mine_valid) {
     // Jet bridge: d/dx = dfdc * sx, d/dy = dfdr * sy  (interpolation.h:130-140 + featurepatch.h:250-255)
     rec[1] *= sx * sx; rec[2] *= sx * sy; rec[3] *= sy * sy; rec[4] *= sx; rec[5] *= sy;
+    // InterpolationConfig.check_bounds (patch_interpolator.h:125-135,160-166): outside 0 < u < W, 0 < v < H the
+    // functor returns false, i.e. the evaluation fails; here the block's squared norm becomes NaN, which makes
+    // the cost non-finite -> the solver treats the step as invalid (FAILURE at the initial point), like Ceres
+    if (a.check_bounds && !(my_u > 0.0 && my_u < (double)a.W && my_v > 0.0 && my_v < (double)a.H)) rec[0] = __builtin_nan("");
     double2* o = reinterpret_cast<double2*>(a.rec + (size_t)mine * PXR_OBS_REC);
     o[0] = make_double2(rec[0], rec[1]);
     o[1] = make_double2(rec[2], rec[3]);
@@ -229,7 +234,7 @@ int pxr_ba_eval(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const p
   pxr::BaEvalArgs a;
   a.v = *view;
   a.arena = arena->d_data; a.corners = arena->d_corners; a.scales = arena->d_scales;
-  a.H = arena->H; a.W = arena->W; a.l2_normalize = cfg->l2_normalize;
+  a.H = arena->H; a.W = arena->W; a.l2_normalize = cfg->l2_normalize; a.check_bounds = cfg->check_bounds;
   a.rec = d_rec; a.out_r = d_r; a.out_gx = d_gx; a.out_gy = d_gy;
   const bool wj = with_jacobian != 0, fs = cfg->use_float_simd != 0;
   switch (arena->dtype) {

@@ -27,7 +27,7 @@ namespace pxr {
 struct InnerArgs {
   pxr_ba_view v;               // candidate parameters; d_xyz is updated in place
   const void* arena; const int32_t* corners; const double* scales; int H, W;
-  int l2_normalize;
+  int l2_normalize, check_bounds;
   pxr_loss loss;
   const int64_t* pt_ptr; const int64_t* pt_obs; const int* pt_var;
   double* xyz_out;             // == v.d_xyz (mutable alias)
@@ -142,6 +142,8 @@ __device__ __forceinline__ void inner_points_body(const InnerArgs& a, double (*s
       double rho[3];
       loss_eval(a.loss.type, a.loss.a, 1.0, s, rho);
       if (valid) cost += 0.5 * rho[0];
+      // check_bounds: a projection outside its patch fails the evaluation -> non-finite cost -> the step is rejected
+      if (valid && a.check_bounds && !(u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H)) cost = __builtin_nan("");
       if (with_jac) {
         gcc = rsum(gcc) * sx * sx; gcr = rsum(gcr) * sx * sy; grr = rsum(grr) * sy * sy;
         bc = rsum(bc) * sx; br = rsum(br) * sy;
@@ -280,7 +282,7 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   InnerArgs a;
   a.v = *view;
   a.arena = arena->d_data; a.corners = arena->d_corners; a.scales = arena->d_scales;
-  a.H = arena->H; a.W = arena->W; a.l2_normalize = cfg->l2_normalize; a.loss = *loss;
+  a.H = arena->H; a.W = arena->W; a.l2_normalize = cfg->l2_normalize; a.check_bounds = cfg->check_bounds; a.loss = *loss;
   a.pt_ptr = d_pt_ptr; a.pt_obs = d_pt_obs; a.pt_var = d_pt_var;
   a.xyz_out = const_cast<double*>(view->d_xyz); a.cost_before = d_cost_before;
   const unsigned blocks = (unsigned)((view->n_points + 3) / 4);

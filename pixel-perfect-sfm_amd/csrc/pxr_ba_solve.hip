@@ -886,6 +886,11 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   RC(read_scal(hs));
   double cost = hs[0];
   sum->initial_cost = cost;
+  if (!std::isfinite(cost)) {   // [upstream] "Initial residual and Jacobian evaluation failed" (e.g. check_bounds)
+    sum->final_cost = cost; sum->termination = PXR_TERM_FAILURE;
+    sum->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop0).count();
+    return PXR_OK;
+  }
   hipLaunchKernelGGL(k_fill, dim3(nblk(nc1)), dim3(256), 0, st, (int64_t)nc1, 1.0, scale_c.p);
   hipLaunchKernelGGL(k_fill, dim3(nblk(n_pts * 3)), dim3(256), 0, st, n_pts * 3, 1.0, scale_p.p);
   RC(linearize(rec_cur));

@@ -42,7 +42,7 @@ constexpr int KA_NLDS = 100;   // LDS budget for the damped blocks: KA_NLDS^2 do
 struct KaArgs {
   pxr_ka_view v;
   const void* arena; const int32_t* corners; const double* scales; int H, W;
-  int l2_normalize; int float_simd; int lds_elems;   // lds_elems: doubles of dynamic LDS for the damped blocks
+  int l2_normalize; int float_simd; int check_bounds; int lds_elems;   // lds_elems: doubles of dynamic LDS for the damped blocks
   pxr_loss loss; double bound; pxr_lm_options opt;
   // scratch
   double* desc;          // [n_nodes][3][C]: f, df/dx, df/dy
@@ -70,6 +70,13 @@ __device__ __forceinline__ void ka_eval_node(const KaArgs& a, int64_t node, cons
   double f[8], fr[8], fc[8];
   if (fsimd) interp8<ST, C / 8, WITH_JAC, true>(patch, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f, fr, fc);
   else interp8<ST, C / 8, WITH_JAC, false>(patch, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f, fr, fc);
+  // InterpolationConfig.check_bounds (patch_interpolator.h:125-135,160-166): outside 0 < u < W, 0 < v < H the
+  // functor's evaluation fails; a NaN descriptor makes every cost it enters non-finite, which the line
+  // search / step acceptance treat as a failed evaluation
+  if (a.check_bounds && !(u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H)) {
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) f[ch] = __builtin_nan("");
+  }
   double* d = a.desc + (size_t)node * 3 * C + sub * 8;
 #pragma unroll
   for (int ch = 0; ch < 8; ++ch) {
@@ -575,7 +582,8 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   }
   double cost = linearize(true);
   sm.initial_cost = cost;
-  if (!inf.feasible) {   // [upstream] Program::IsFeasible fails: FAILURE, parameters untouched
+  if (!inf.feasible || !isfinite(cost)) {   // [upstream] Program::IsFeasible fails / the initial evaluation fails
+                                            // (check_bounds): FAILURE, parameters untouched
     sm.final_cost = cost; sm.termination = PXR_TERM_FAILURE;
     if (tid == 0) a.summaries[prob] = sm;
     return;
@@ -740,12 +748,14 @@ __global__ __launch_bounds__(256) void ka_eval_kernel(const KaArgs a, bool fsimd
   if (e >= a.v.n_edges) return;
   const int nn[2] = {a.v.d_edge_src[e], a.v.d_edge_dst[e]};
   double f[2][8], gx[2][8], gy[2][8];
+  bool inside = true;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int64_t pi = a.v.d_node_patch[nn[k]];
     const double sx = a.scales[2 * pi], sy = a.scales[2 * pi + 1];
     const double u = a.v.d_kp[2 * (size_t)nn[k]] * sx - 0.5 - (double)a.corners[2 * pi];
     const double v = a.v.d_kp[2 * (size_t)nn[k] + 1] * sy - 0.5 - (double)a.corners[2 * pi + 1];
+    inside = inside && u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H;
     const ST* patch = reinterpret_cast<const ST*>(a.arena) + (size_t)pi * a.H * a.W * C;
     double fr[8], fc[8];
     if (fsimd) interp8<ST, LPO, true, true>(patch, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f[k], fr, fc);
@@ -759,7 +769,7 @@ __global__ __launch_bounds__(256) void ka_eval_kernel(const KaArgs a, bool fsimd
   s = lpo_sum(s, LPO);
   double rho[3];
   loss_eval(a.loss.type, a.loss.a, a.v.d_edge_w[e], s, rho);
-  if (sub == 0) cost[e] = 0.5 * rho[0];
+  if (sub == 0) cost[e] = (a.check_bounds && !inside) ? __builtin_nan("") : 0.5 * rho[0];   // failed evaluation
   if (out_r) {
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
@@ -775,7 +785,7 @@ static int fill_args(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* view, co
                      const pxr_loss* loss, KaArgs& a) {
   a.v = *view;
   a.arena = arena->d_data; a.corners = arena->d_corners; a.scales = arena->d_scales;
-  a.H = arena->H; a.W = arena->W; a.l2_normalize = cfg->l2_normalize; a.float_simd = cfg->use_float_simd; a.loss = *loss;
+  a.H = arena->H; a.W = arena->W; a.l2_normalize = cfg->l2_normalize; a.float_simd = cfg->use_float_simd; a.check_bounds = cfg->check_bounds; a.loss = *loss;
   return PXR_OK;
 }
 

@@ -152,3 +152,36 @@ def test_linearity_in_reference_full_size_property(ctx):
     r0 = r0.download()
     assert np.abs((r0 - r1) - prob["refs"][prob["obs_point"]]).max() < 1e-15
     assert np.abs((r0 ** 2).sum(1) - 1.0).max() < 1e-12   # unit-norm descriptors (interpolation_test.cc:187-207)
+
+
+def test_check_bounds_marks_failed_evaluations(ctx):
+    """InterpolationConfig.check_bounds (patch_interpolator.h:125-135,160-166): observations that project outside
+    0 < u < W, 0 < v < H fail to evaluate -- their record's squared norm is NaN (all other fields as usual);
+    which observations fail is checked against the oracle's is_inside; the BA solver reports FAILURE when the
+    initial evaluation fails, and without the option the same problem evaluates normally."""
+    import pxo
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    prob = synthetic.make_ba_problem(n_cams=4, n_points=40, obs_per_point=3, seed=3)
+    prob["corners"] = prob["corners"].copy()
+    prob["corners"][::5, 0] += 9                      # shift some patches: the projection falls left of the patch
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    rec_on = ba.eval(interp_cfg(check_bounds=True), with_jacobian=True)[0].download()
+    rec_off = ba.eval(interp_cfg(check_bounds=False), with_jacobian=True)[0].download()
+    inside = []
+    for i in range(len(prob["obs_image"])):
+        p = pxo.make_patch(prob["patches"][i], prob["corners"][i], prob["scales"][i])
+        xy = rec_off[i, 6:8]
+        inside.append(pxo.patch_eval(p, xy, pxo.cfg(check_bounds=True))[3] == 1)
+    inside = np.array(inside)
+    assert 0 < (~inside).sum() < len(inside)
+    assert np.array_equal(np.isnan(rec_on[:, 0]), ~inside)
+    assert np.array_equal(rec_on[inside], rec_off[inside]) and np.array_equal(rec_on[:, 1:], rec_off[:, 1:])
+    assert np.isfinite(rec_off).all()
+    gauge = (np.array([1, 0, 0, 0], np.uint8), np.array([0, 1, 0, 0], np.uint8), np.full(4, 0b0110, np.uint16),
+             np.zeros(40, np.uint8))
+    s = ba.solve(interp_cfg(check_bounds=True), make_loss("cauchy", [0.25]), *gauge, options=lm_options(max_iterations=5))
+    assert s["termination"] == 2 and s["iterations"] == 0 and np.isnan(s["initial_cost"])     # PXR_TERM_FAILURE
+    s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *gauge, options=lm_options(max_iterations=2))
+    assert s["termination"] != 2 and np.isfinite(s["final_cost"])

@@ -153,3 +153,23 @@ def test_solve_every_storage_type_and_channel_count(ctx, dtype, channels):
         assert g["iterations"] == o["iterations"] and g["termination"] == o["termination"]
         assert abs(g["final_cost"] - o["final_cost"]) < 1e-7 * max(o["final_cost"], 1e-6)
     assert np.abs(ka.keypoints() - kpo).max() < 1e-6
+
+
+def test_check_bounds_failure_leaves_keypoints_untouched(ctx):
+    """check_bounds with a keypoint outside its patch: the initial evaluation of its sub-problem fails ->
+    FAILURE and untouched keypoints there, the other sub-problems solve as usual."""
+    import pxo
+    import pxo_ka
+    from pixsfm_amd.engine import interp_cfg, make_loss
+    prob, arena, ka = _setup(ctx, n_tracks=6, track_len=4, seed=12, max_kps_per_problem=8)
+    bad = int(np.nonzero(prob["node_problem"] == 1)[0][0])
+    kp = prob["kp"].copy()
+    kp[bad, 0] = prob["corners"][bad, 0] - 3.0                      # left of its patch
+    ka.d["kp"].upload(kp)
+    total, per = ka.solve(interp_cfg(check_bounds=True), make_loss("cauchy", [0.25]), bound=4.0, per_problem=True)
+    out = ka.keypoints()
+    assert per[1]["termination"] == 2 and np.isnan(per[1]["initial_cost"])
+    sel = prob["node_problem"] == 1
+    assert np.array_equal(out[sel], kp[sel])
+    assert all(p["termination"] == 0 for i, p in enumerate(per) if i != 1)
+    assert total["termination"] == 2

@@ -180,6 +180,14 @@ class FeatureMetricKeypointOptimizer:
         arena.close()
         return True
 
+    def run_subset(self, nodes_in_problem, keypoints, graph, track_labels, root_labels, feature_set):
+        """RunSubset (featuremetric_keypoint_optimizer.h:116-137): one problem over the given node indices only
+        (what ParallelOptimizer hands to each worker); the other keypoints are left untouched."""
+        labels = np.full(len(graph.nodes), -1, dtype=np.int32)
+        labels[np.fromiter(nodes_in_problem, dtype=np.int64)] = 0
+        self._run(labels, keypoints, graph, track_labels, root_labels, feature_set)
+        return self._summary
+
     def run(self, *args):
         if len(args) == 6:
             return self._run(*args)

@@ -30,15 +30,19 @@ class KAProblem:
         self.n_nodes = len(g["kp"])
         self.n_edges = len(g["edge_src"])
         node_problem = np.asarray(g["node_problem"], dtype=np.int64)
-        if self.n_nodes and node_problem.min() < 0:
-            raise ValueError("every node needs a problem label >= 0")
+        if self.n_nodes and node_problem.min() < -1:
+            raise ValueError("problem labels are >= 0, or -1 for nodes outside every sub-problem (run_subset)")
         self.n_problems = int(node_problem.max()) + 1 if self.n_nodes else 0
         edge_src = np.asarray(g["edge_src"], dtype=np.int32)
         edge_dst = np.asarray(g["edge_dst"], dtype=np.int32)
         if self.n_edges and not np.array_equal(node_problem[edge_src], node_problem[edge_dst]):
             raise ValueError("an edge connects two different sub-problems")
-        node_ptr, nodes = _csr(node_problem, self.n_problems)
-        edge_ptr, edges = _csr(node_problem[edge_src] if self.n_edges else np.zeros(0, np.int64), self.n_problems)
+        # label -1: the node / edge takes part in no sub-problem (the extra group is dropped)
+        node_ptr, nodes = _csr(np.where(node_problem < 0, self.n_problems, node_problem), self.n_problems + 1)
+        node_ptr, nodes = node_ptr[:-1], nodes[:node_ptr[-2]]
+        ep = node_problem[edge_src] if self.n_edges else np.zeros(0, np.int64)
+        edge_ptr, edges = _csr(np.where(ep < 0, self.n_problems, ep), self.n_problems + 1)
+        edge_ptr, edges = edge_ptr[:-1], edges[:edge_ptr[-2]]
         self.n_unary = len(g["unary_node"]) if g.get("unary_node") is not None else 0
         self.d = {
             "kp": ctx.to_device(g["kp"], np.float64),
@@ -62,7 +66,9 @@ class KAProblem:
                 raise ValueError("unary_ref must be (n_unary, CHANNELS)")
             if unary_node.min() < 0 or unary_node.max() >= self.n_nodes:
                 raise ValueError("unary_node out of range")
-            u_ptr, u_ids = _csr(node_problem[unary_node], self.n_problems)
+            up = node_problem[unary_node]
+            u_ptr, u_ids = _csr(np.where(up < 0, self.n_problems, up), self.n_problems + 1)
+            u_ptr, u_ids = u_ptr[:-1], u_ids[:u_ptr[-2]]
             d["unary_node"] = ctx.to_device(unary_node, np.int32)
             d["unary_ref"] = ctx.to_device(unary_ref, np.float64)
             d["unary_ptr"] = ctx.to_device(u_ptr, np.int64)

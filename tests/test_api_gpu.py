@@ -250,3 +250,32 @@ def test_reference_extractor_keep_observations_and_find_nearest(ctx):
         assert min(d) == 0.0                                # the winner is one of the candidates
         hits += 1
     assert hits == len(idxs)
+
+
+def test_run_subset_only_touches_its_nodes(ctx):
+    """FeatureMetricKeypointOptimizer.run_subset (featuremetric_keypoint_optimizer.h:116-137): the tracks in the
+    subset end where a full run puts them (tracks are independent), every other keypoint is untouched."""
+    from pixsfm_amd.api import FeatureMetricKeypointOptimizer, KeypointAdjustmentSetup, base
+    prob, keypoints, graph, fmanager, (img, kid, names) = _ka_inputs(seed=5, n_tracks=10, track_len=4)
+    track_labels = base.compute_track_labels(graph)
+    score = base.compute_score_labels(graph, track_labels)
+    roots = base.compute_root_labels(graph, track_labels, score)
+
+    def fresh():
+        setup = KeypointAdjustmentSetup()
+        setup.set_masked_nodes_constant(graph, roots)
+        return FeatureMetricKeypointOptimizer({"solver": {"parameter_tolerance": 1e-5}}, setup, None, ctx=ctx)
+
+    kp_full = {k: v.copy() for k, v in keypoints.items()}
+    assert fresh().run(kp_full, graph, track_labels, roots, fmanager.fset(0))
+    chosen = set(sorted(set(track_labels))[:4])
+    subset = {i for i, t in enumerate(track_labels) if t in chosen}
+    kp_sub = {k: v.copy() for k, v in keypoints.items()}
+    summary = fresh().run_subset(subset, kp_sub, graph, track_labels, roots, fmanager.fset(0))
+    assert summary is not None and summary.final_cost < summary.initial_cost
+    for i, nd in enumerate(graph.nodes):
+        nm = graph.image_id_to_name[nd.image_id]
+        if i in subset:
+            assert np.abs(kp_sub[nm][nd.feature_idx] - kp_full[nm][nd.feature_idx]).max() < 1e-9
+        else:
+            assert np.array_equal(kp_sub[nm][nd.feature_idx], keypoints[nm][nd.feature_idx])

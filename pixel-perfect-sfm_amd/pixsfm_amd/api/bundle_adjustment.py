@@ -293,7 +293,10 @@ class FeatureReferenceBundleOptimizer:
         self._summary = None
         self._used = False
 
-    def run(self, reconstruction, feature_view, references):
+    def set_up(self, reconstruction, loss_function, feature_view, references):
+        """SetUp (feature_reference_bundle_optimizer.h:73-87, bundle_optimizer.h:113-166): builds the problem --
+        here the flat device arrays -- without solving it.  loss_function: {'name', 'params'} (the dict form of
+        the reference's ceres::LossFunction argument) or None for the optimizer's own loss."""
         if reconstruction is None:
             raise ValueError("reconstruction cannot be NULL.")                  # bundle_optimizer.h:117-118
         if self._used:
@@ -302,22 +305,38 @@ class FeatureReferenceBundleOptimizer:
         ctx = self.ctx or default_context()
         if isinstance(feature_view, features.FeatureSet):
             feature_view = FeatureView(feature_view, reconstruction)
+        self._loss = loss_function or self.options['loss']
         flat = _FlatBA(reconstruction, self.setup, feature_view, self.options)
+        self._flat, self._ba, self._arena = flat, None, None
         if len(flat.obs_image) == 0:
-            return False                                                         # NumResiduals() == 0, :174-176
+            return
         C = flat.patches[0].shape[2]
         refs = np.zeros((len(flat.point_ids), C))
         for k, pid in enumerate(flat.point_ids):
             refs[k] = references[pid].descriptor.reshape(-1)                     # references.at(point3D_id)
-        arena = features.to_arena(ctx, flat.patches)
-        ba = BAProblem(ctx, arena, flat.problem_dict(refs))
+        self._arena = features.to_arena(ctx, flat.patches)
+        self._ba = BAProblem(ctx, self._arena, flat.problem_dict(refs))
+
+    @property
+    def problem(self):
+        """The reference exposes its ceres::Problem here; the accelerated path exposes the device-resident
+        BAProblem (evaluate / inspect it with its eval(), cost() and params())."""
+        return self._ba
+
+    def solve_problem(self, reconstruction):
+        """SolveProblem (bundle_optimizer.h:172-245): False when the problem has no residuals."""
+        if getattr(self, "_flat", None) is None:
+            raise ValueError("set_up() has not been called")
+        flat, ba = self._flat, self._ba
+        if ba is None:
+            return False                                                         # NumResiduals() == 0, :174-176
+        C = self._arena.C
         s = self.options['solver']
         lm = lm_options(max_iterations=s['max_num_iterations'], function_tolerance=s['function_tolerance'],
                         gradient_tolerance=s['gradient_tolerance'], parameter_tolerance=s['parameter_tolerance'],
                         max_consecutive_invalid_steps=s['max_num_consecutive_invalid_steps'],
                         use_inner_iterations=s['use_inner_iterations'])
-        summ = ba.solve(self.interpolation.to_engine(),
-                        make_loss(self.options['loss']['name'], self.options['loss']['params']),
+        summ = ba.solve(self.interpolation.to_engine(), make_loss(self._loss['name'], self._loss['params']),
                         flat.pose_const, flat.tvec_mask, flat.cam_mask, flat.point_const, options=lm,
                         allreduce=self.allreduce)
         q, t, k, X = ba.params()
@@ -330,8 +349,23 @@ class FeatureReferenceBundleOptimizer:
         for n, pid in enumerate(flat.point_ids):
             reconstruction.points3D[pid].xyz = X[n].copy()
         self._summary = Summary(summ, num_residuals=len(flat.obs_image) * C)
-        arena.close()
         return True
+
+    def reset(self):
+        """Reset (bundle_optimizer.h:124-129): drop the problem; the optimizer can be set up again."""
+        if getattr(self, "_arena", None) is not None:
+            self._arena.close()
+        self._flat = self._ba = self._arena = None
+        self._used = False
+
+    def run(self, reconstruction, feature_view, references):
+        """Run = SetUp + SolveProblem (feature_reference_bundle_optimizer.h:54-71)."""
+        self.set_up(reconstruction, None, feature_view, references)
+        ok = self.solve_problem(reconstruction)
+        if self._arena is not None:
+            self._arena.close()
+            self._arena = None
+        return ok
 
     def summary(self):
         return self._summary

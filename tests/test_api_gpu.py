@@ -279,3 +279,40 @@ def test_run_subset_only_touches_its_nodes(ctx):
             assert np.abs(kp_sub[nm][nd.feature_idx] - kp_full[nm][nd.feature_idx]).max() < 1e-9
         else:
             assert np.array_equal(kp_sub[nm][nd.feature_idx], keypoints[nm][nd.feature_idx])
+
+
+def test_bundle_optimizer_set_up_solve_reset(ctx):
+    """FeatureReferenceBundleOptimizer.set_up / .problem / .solve_problem / .reset (bindings.cc:36-51): the two-step
+    form gives what run() gives; reset() allows a second set_up; a second run() without reset raises."""
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.api import FeatureReferenceBundleOptimizer, ReferenceExtractor, default_problem_setup, features
+    from pixsfm_amd.api.reconstruction import reconstruction_from_flat
+
+    def inputs():
+        prob = synthetic.make_ba_problem(n_cams=5, n_points=50, obs_per_point=3, seed=29)
+        rec, patch_of = reconstruction_from_flat(prob)
+        fmaps = {}
+        for (image_id, p2d), pi in patch_of.items():
+            fm = fmaps.setdefault(rec.images[image_id].name, features.FeatureMap())
+            fm.patches[p2d] = features.FeaturePatch(prob["patches"][pi], prob["corners"][pi], prob["scales"][pi])
+        return rec, features.FeatureSet(fmaps)
+
+    opts = {"solver": {"max_num_iterations": 5}}
+    rec1, fset1 = inputs()
+    refs = ReferenceExtractor({"iters": 10}, None, ctx=ctx).run([0] * 51, rec1, fset1)
+    o1 = FeatureReferenceBundleOptimizer(opts, default_problem_setup(rec1), None, ctx=ctx)
+    assert o1.run(rec1, fset1, refs)
+    with pytest.raises(ValueError):
+        o1.run(rec1, fset1, refs)
+    rec2, fset2 = inputs()
+    o2 = FeatureReferenceBundleOptimizer(opts, default_problem_setup(rec2), None, ctx=ctx)
+    o2.set_up(rec2, {"name": "cauchy", "params": [0.25]}, fset2, refs)
+    cost0 = o2.problem.eval(o2.interpolation.to_engine())[0].download()[:, 0].sum()
+    assert cost0 > 0 and o2.solve_problem(rec2)
+    assert abs(o2.summary().final_cost - o1.summary().final_cost) < 1e-12 * max(o1.summary().final_cost, 1e-12)
+    for i in rec1.images:
+        assert np.abs(rec1.images[i].qvec - rec2.images[i].qvec).max() < 1e-9   # atomics: summation order varies
+    o2.reset()
+    assert o2.problem is None
+    o2.set_up(rec2, None, fset2, refs)                     # usable again after reset()
+    assert o2.solve_problem(rec2)

@@ -39,6 +39,8 @@ struct BaEvalArgs {
   int H, W;
   int l2_normalize;
   int check_bounds;
+  pxr_loss loss;      // used when cost_out != NULL
+  double* cost_out;   // NULL, or += sum over the launch of 0.5 rho(|r|^2) (fused cost reduction for the LM loop)
   double* rec;
   double* out_r;
   double* out_gx;
@@ -154,6 +156,16 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(const BaEvalArgs a) {
     o[2] = make_double2(rec[4], rec[5]);
     o[3] = make_double2(rec[6], rec[7]);
   }
+  if (a.cost_out) {   // one atomic per wavefront; saves the solver a separate pass over the records
+    double c = 0.0;
+    if (mine_valid) {
+      double rho[3];
+      loss_eval(a.loss.type, a.loss.a, 1.0, rec[0], rho);
+      c = 0.5 * rho[0];
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(a.cost_out, c);
+  }
 }
 
 // ---- projection Jacobians (parity checks) ------------------------------------------------
@@ -225,7 +237,16 @@ extern "C" {
 
 int pxr_ba_eval(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
                 int with_jacobian, double* d_rec, double* d_r, double* d_gx, double* d_gy) {
+  return pxr::ba_eval_with_cost(ctx, arena, view, cfg, with_jacobian, d_rec, d_r, d_gx, d_gy, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+int pxr::ba_eval_with_cost(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
+                           int with_jacobian, double* d_rec, double* d_r, double* d_gx, double* d_gy,
+                           const pxr_loss* loss, double* d_cost_sum) {
   PXR_REQUIRE(ctx && arena && view && cfg && d_rec, "pxr_ba_eval: NULL argument");
+  PXR_REQUIRE(!d_cost_sum || loss, "pxr_ba_eval: the fused cost needs a loss");
   PXR_REQUIRE(view->n_obs >= 0, "pxr_ba_eval: negative n_obs");
   PXR_REQUIRE((d_gx == nullptr) == (d_gy == nullptr), "pxr_ba_eval: d_gx and d_gy must be given together");
   PXR_REQUIRE(!(d_gx && !d_r), "pxr_ba_eval: d_gx/d_gy require d_r");
@@ -236,6 +257,8 @@ int pxr_ba_eval(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const p
   a.arena = arena->d_data; a.corners = arena->d_corners; a.scales = arena->d_scales;
   a.H = arena->H; a.W = arena->W; a.l2_normalize = cfg->l2_normalize; a.check_bounds = cfg->check_bounds;
   a.rec = d_rec; a.out_r = d_r; a.out_gx = d_gx; a.out_gy = d_gy;
+  a.cost_out = d_cost_sum;
+  if (loss) a.loss = *loss; else { a.loss.type = PXR_LOSS_TRIVIAL; a.loss.a = 1.0; }
   const bool wj = with_jacobian != 0, fs = cfg->use_float_simd != 0;
   switch (arena->dtype) {
     case PXR_F16: return pxr::launch_eval_c<_Float16>(ctx, arena->C, a, wj, fs);
@@ -244,6 +267,8 @@ int pxr_ba_eval(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const p
   }
   return pxr::set_error(PXR_EINVAL, "pxr_ba_eval: bad arena dtype");
 }
+
+extern "C" {
 
 int pxr_ba_projection_jacobian(pxr_ctx* ctx, const pxr_ba_view* view, double* d_P) {
   PXR_REQUIRE(ctx && view && d_P, "pxr_ba_projection_jacobian: NULL argument");

@@ -822,9 +822,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     return PXR_OK;
   };
   auto evaluate = [&](const pxr_ba_view& v, double* rec) -> int {   // rec + cost into scal_sum[0]
-    RC(pxr_ba_eval(ctx, arena, &v, cfg, 1, rec, nullptr, nullptr, nullptr));
-    hipLaunchKernelGGL(k_cost, dim3(std::min<unsigned>(2048, nblk(n_obs))), dim3(256), 0, st, rec, n_obs, *loss, scal_sum);
-    LAUNCH_CHECK("k_cost");
+    RC(ba_eval_with_cost(ctx, arena, &v, cfg, 1, rec, nullptr, nullptr, nullptr, loss, scal_sum));   // cost fused
     return PXR_OK;
   };
   // linearise at the CURRENT parameters from record buffer `rec`

@@ -39,6 +39,10 @@ inline int hip_check(hipError_t e, const char* what) {
   if (e == hipSuccess) return PXR_OK;
   return set_error(PXR_EHIP, "%s: %s", what, hipGetErrorString(e));
 }
+// pxr_ba_eval with the cost reduction fused into the residual kernel: *d_cost_sum += sum 0.5 rho(|r|^2)
+int ba_eval_with_cost(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
+                      int with_jacobian, double* d_rec, double* d_r, double* d_gx, double* d_gy,
+                      const pxr_loss* loss, double* d_cost_sum);
 }  // namespace pxr
 
 #define PXR_HIP(call)                                        \

@@ -616,19 +616,6 @@ __global__ void k_normalize_q(int n, double* __restrict__ q) {
   for (int j = 0; j < 4; ++j) q[4 * i + j] /= nn;   // colmap::Image::NormalizeQvec, bundle_optimizer.h:255
 }
 
-// cost accumulation into scal_sum[0] (no host sync)
-__global__ __launch_bounds__(256) void k_cost(const double* __restrict__ rec, int64_t n, pxr_loss loss,
-                                              double* __restrict__ out) {
-  double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double rho[3];
-    loss_eval(loss.type, loss.a, 1.0, rec[i * PXR_OBS_REC], rho);
-    acc += 0.5 * rho[0];
-  }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
-}
-
 __global__ void k_absmax_unscaled(int64_t n, const double* __restrict__ g, const double* __restrict__ scale,
                                   double* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -489,7 +489,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // ---- K_backsub: delta_p = -T (g_p + sum_i W_i^T delta_c) ---------------------------------------------
 __global__ __launch_bounds__(256) void k_backsub(const SolveDev d, const int64_t* __restrict__ pt_ptr,
-                                                 const int64_t* __restrict__ pt_obs,
+                                                 const int* __restrict__ pj, const int4* __restrict__ pcols,
                                                  const double* __restrict__ W, const double* __restrict__ T,
                                                  const double* __restrict__ gp, const double* __restrict__ delta_c,
                                                  const double* __restrict__ Vdiag0, double inv_radius,
@@ -501,12 +501,12 @@ __global__ __launch_bounds__(256) void k_backsub(const SolveDev d, const int64_t
     if (d.pt_var[p]) {
       double v[3] = {gp[3 * p], gp[3 * p + 1], gp[3 * p + 2]};
       for (int64_t o = pt_ptr[p]; o < pt_ptr[p + 1]; ++o) {
-        const int64_t i = pt_obs[o];
-        const int img = d.v.d_obs_image[i], cam = d.v.d_image_camera[img];
-        const int dci = d.pose_dim[img] + d.intr_dim[cam];
+        const int64_t i = pj[o];                      // observation and its column descriptors, flattened per point
+        const int4 ci = pcols[o];                     // {pose_off, pose_dim, intr_off, intr_dim}
+        const int dci = ci.y + ci.w;
         const double* Wi = W + (size_t)i * d.DC * 3;
         for (int a = 0; a < dci; ++a) {
-          const double dcv = delta_c[col_index(d, img, cam, a)];
+          const double dcv = delta_c[a < ci.y ? ci.x + a : ci.z + (a - ci.y)];
           v[0] += Wi[3 * a] * dcv; v[1] += Wi[3 * a + 1] * dcv; v[2] += Wi[3 * a + 2] * dcv;
         }
       }
@@ -927,7 +927,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     phase(3);
     double model_cost_change = 0, cand_cost = 0, step_norm = 0, x_norm = 0;
     if (ok) {
-      hipLaunchKernelGGL(k_backsub, dim3(nblk(n_pts)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, W.p, T.p, gp.p, delta_c.p, Vd0.p, inv_radius, delta_p.p, scal_sum);
+      hipLaunchKernelGGL(k_backsub, dim3(nblk(n_pts)), dim3(256), 0, st, dv, d_pt_ptr.p, d_part_obs.p, d_obs_cols.p, W.p, T.p, gp.p, delta_c.p, Vd0.p, inv_radius, delta_p.p, scal_sum);
       ParamPtrs out{q1.p, t1.p, k1.p, X1.p};
       hipLaunchKernelGGL(k_update, dim3(nblk((int64_t)n_img + n_cam + n_pts)), dim3(256), 0, st, dv, delta_c.p, delta_p.p, out, scal_rep, scal_sum);
       LAUNCH_CHECK("step kernels");

@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32768)
     ap.add_argument("--lm-iters", type=int, default=10, help="LM iterations for the iters/s figure (0 = skip)")
+    ap.add_argument("--no-ka", action="store_true", help="skip the keypoint-adjustment half of the metric (BASELINE configs[1])")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: every rank owns --points points (N x the observations, cameras shared); "
                          "strong: --points points in total, sharded over the ranks")
@@ -223,6 +224,12 @@ def main():
                         "inner_iterations": key == "lm"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(prob, patches, args.cpu_sample)
+        if not args.no_ka and world == 1:
+            # the other unit of work of the metric: one KA edge (A7).  BASELINE configs[1] (10k tracks / 100k
+            # keypoints / 450k edges / 2000 sub-problems): per-edge residual+Jacobian rate and the whole bounded LM
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_ka
+            out["ka"] = bench_ka.run(device_index=local_rank)
         print(json.dumps(out))
     if dist_on:
         dist.destroy_process_group()

@@ -59,18 +59,16 @@ def make_problem_gpu(dev, n_tracks, track_len, C=128, PS=16, seed=1, sigma=1.0, 
                 corners=corners, scales=np.ones((n, 2)), true_xy=true_xy, n_problems=len(bins)), patches
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--tracks", type=int, default=10000)
-    ap.add_argument("--track-len", type=int, default=10)
-    ap.add_argument("--steps", type=int, default=20)
-    args = ap.parse_args()
+def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None):
+    """Runs the KA benchmark and returns its result dict (bench.py attaches it as "ka")."""
+    import types
+    args = types.SimpleNamespace(tracks=tracks, track_len=track_len, steps=steps)
     from pixsfm_amd.engine import Context, PatchArena, interp_cfg, make_loss
     from pixsfm_amd.ka_engine import KAProblem
-    dev = "cuda:0"
-    torch.cuda.set_device(0)
+    dev = "cuda:%d" % device_index
+    torch.cuda.set_device(device_index)
     prob, patches = make_problem_gpu(dev, args.tracks, args.track_len)
-    ctx = Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    ctx = ctx or Context(device_index, stream=torch.cuda.current_stream().cuda_stream)
     n = len(prob["kp"])
     arena = PatchArena(ctx, n, 16, 16, 128, np.float16, device_ptr=patches.data_ptr())
     arena.upload(0, None, prob["corners"], prob["scales"])
@@ -106,7 +104,17 @@ def main():
                      "final_cost": total["final_cost"], "initial_cost_check": c0},
            "accuracy_px": {"median_before": float(np.median(err0)), "median_after": float(np.median(err1)),
                            "p95_after": float(np.percentile(err1, 95))}}
-    print(json.dumps(out))
+    arena.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tracks", type=int, default=10000)
+    ap.add_argument("--track-len", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    args = ap.parse_args()
+    print(json.dumps(run(args.tracks, args.track_len, args.steps)))
 
 
 if __name__ == "__main__":

@@ -674,6 +674,12 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   PXR_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const auto t_setup0 = std::chrono::steady_clock::now();
+  const bool setup_verbose = std::getenv("PXR_VERBOSE") != nullptr;
+  auto setup_mark = [&](const char* what) {
+    if (setup_verbose)
+      fprintf(stderr, "[pxr_ba_solve] setup: %-28s at %.2f ms\n", what,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_setup0).count());
+  };
   const int64_t n_obs = view->n_obs, n_pts = view->n_points;
   const int n_img = view->n_images, n_cam = view->n_cameras;
 
@@ -684,6 +690,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   PXR_HIP(hipMemcpyAsync(image_camera.data(), view->d_image_camera, 4 * n_img, hipMemcpyDeviceToHost, st));
   PXR_HIP(hipMemcpyAsync(cam_model.data(), view->d_cam_model, 4 * n_cam, hipMemcpyDeviceToHost, st));
   PXR_HIP(hipStreamSynchronize(st));
+  setup_mark("index arrays on the host");
   static const int kNumParams[11] = {3, 4, 4, 5, 8, 8, 12, 5, 4, 5, 12};   // [upstream COLMAP 3.8] kNumParams by model id
   for (int c = 0; c < n_cam; ++c)
     PXR_REQUIRE(cam_model[c] >= 0 && cam_model[c] <= 10, "pxr_ba_solve: unsupported camera model id %d", cam_model[c]);
@@ -751,6 +758,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     so_desc[o] = make_int4((int)i, (int)pt, (int)pt_cnt[pt], pt_var[pt] ? (int)(pt_cnt[pt + 1] - pt_cnt[pt]) : 0);
   }
 
+  setup_mark("host structure (CSR, chunks)");
   // ---- device buffers ---------------------------------------------------------------------------
   DevBuf<int> d_pose_off, d_pose_dim, d_tmask, d_intr_off, d_intr_dim, d_cmask, d_pt_var;
   DevBuf<int64_t> d_img_obs, d_pt_ptr, d_pt_obs;
@@ -763,6 +771,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   RC(d_pt_obs.upload(pt_obs, st)); RC(d_chunks.upload(chunks, st));
   RC(d_schur_chunks.upload(schur_chunks, st)); RC(d_obs_cols.upload(obs_cols, st));
   RC(d_so.upload(so_desc, st)); RC(d_part_obs.upload(part_obs, st));
+  setup_mark("index uploads");
   const size_t nc1 = n_c ? n_c : 1;
   DevBuf<double> L, V, gp, Vd0, T, W, U, S /* S | rhs */, gcd /* diagU | g_c */, damp_c, scale_c, scale_p,
       delta_c, delta_p, rec_a, rec_b, q1, t1, k1, X1, scal;
@@ -785,6 +794,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   RC(info_buf.alloc(1));
   int* d_info = info_buf.p;
 
+  setup_mark("work buffers allocated");
   double* cur_q = const_cast<double*>(view->d_qvec); double* cur_t = const_cast<double*>(view->d_tvec);
   double* cur_k = const_cast<double*>(view->d_cam_params); double* cur_X = const_cast<double*>(view->d_xyz);
   hipLaunchKernelGGL(k_normalize_q, dim3(nblk(n_img)), dim3(256), 0, st, n_img, cur_q);

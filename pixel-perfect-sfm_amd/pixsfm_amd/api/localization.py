@@ -171,6 +171,58 @@ class QueryKeypointOptimizer:
         arena.close()
         return True
 
+    def run_batch(self, queries):
+        """Many queries in ONE launch ("batch across queries for throughput"): `queries` is a list of
+        (keypoints, fmap, references, patch_idxs | None, inliers | None) tuples with run()'s meaning.  Each query
+        is its own sub-problem -- its own trust region, step acceptance and termination, exactly as if run() had
+        been called on it -- but all of them share one arena upload and one pxr_ka_solve call.  Returns the list
+        of run()'s booleans; per-query summaries in self.last_summaries."""
+        built = []
+        for q in queries:
+            keypoints, fmap, references = q[0], q[1], q[2]
+            patch_idxs = q[3] if len(q) > 3 else None
+            inliers = q[4] if len(q) > 4 else None
+            keypoints = np.asarray(keypoints)
+            if keypoints.ndim != 2 or keypoints.shape[1] != 2 or keypoints.dtype != np.float64:
+                raise ValueError("keypoints must be an (N, 2) float64 array (refined in place)")
+            built.append((keypoints,) + _build_problem(keypoints, fmap, references, patch_idxs, inliers))
+        live = [i for i, b in enumerate(built) if len(b[3]['unary_node'])]
+        ok = [False] * len(queries)
+        self.last_summaries = [None] * len(queries)
+        if not live:
+            return ok
+        patches, parts, n0, u0 = [], [], 0, 0
+        for slot, i in enumerate(live):
+            _, rows, plist, prob = built[i]
+            m = len(rows)
+            patches += plist
+            parts.append(dict(kp=prob['kp'], node_patch=prob['node_patch'] + n0, node_problem=np.full(m, slot, np.int32),
+                              unary_node=prob['unary_node'] + n0, unary_ref=prob['unary_ref']))
+            n0 += m
+        cat = {k: np.concatenate([p_[k] for p_ in parts]) for k in parts[0]}
+        cat.update(node_const=np.zeros(n0, np.uint8), edge_src=np.zeros(0, np.int32), edge_dst=np.zeros(0, np.int32),
+                   edge_w=np.zeros(0), unary_w=None)
+        ctx = self.ctx or default_context()
+        arena = features.to_arena(ctx, patches)
+        o, s = self.options, self.options['solver']
+        ka = KAProblem(ctx, arena, cat)
+        lm = lm_options(max_iterations=s['max_num_iterations'], function_tolerance=s['function_tolerance'],
+                        gradient_tolerance=s['gradient_tolerance'], parameter_tolerance=s['parameter_tolerance'],
+                        max_consecutive_invalid_steps=s['max_num_consecutive_invalid_steps'])
+        total, per = ka.solve(self.interpolation.to_engine(), make_loss(o['loss']['name'], o['loss']['params']),
+                              bound=o['bound'], options=lm, per_problem=True)
+        out = ka.keypoints()
+        n0 = 0
+        for slot, i in enumerate(live):
+            keypoints, rows = built[i][0], built[i][1]
+            keypoints[rows] = out[n0:n0 + len(rows)]
+            n0 += len(rows)
+            ok[i] = True
+            self.last_summaries[i] = per[slot]
+        self.last_summary = total
+        arena.close()
+        return ok
+
 
 class QueryKeypointAdjuster:
     """pixsfm/localization/main.py:89-192."""
@@ -205,6 +257,20 @@ class QueryKeypointAdjuster:
     def refine_multilevel(self, pnp_points2D, query_fmaps, references, point2D_idxs=None):
         for l_idx in resolve_level_indices(self.conf['level_indices'], len(query_fmaps)):
             self.refine(pnp_points2D, query_fmaps[l_idx], references[l_idx], point2D_idxs=point2D_idxs)
+
+    def refine_batch(self, queries):
+        """refine() for many queries at once: `queries` = [(pnp_points2D, fmap, references, point2D_idxs | None), ...];
+        one GPU launch, each query solved as its own problem (not available with stack_correspondences)."""
+        if self.conf['stack_correspondences']:
+            raise ValueError("refine_batch does not stack correspondences; call refine() per query")
+        batch = []
+        for q in queries:
+            pts, fmap, refs = q[0], q[1], q[2]
+            idxs = q[3] if len(q) > 3 else None
+            inl = find_feature_inliers(pts, fmap, refs, self.conf['interpolation'],
+                                       thresh=self.conf['feature_inlier_thresh'], ctx=self.ctx)
+            batch.append((pts, fmap, refs, idxs, inl))
+        return self.solver.run_batch(batch)
 
     def refine_stacked(self, pnp_points2D, fmap, references, point2D_idxs, inliers=None):
         if point2D_idxs is None:

@@ -316,3 +316,30 @@ def test_bundle_optimizer_set_up_solve_reset(ctx):
     assert o2.problem is None
     o2.set_up(rec2, None, fset2, refs)                     # usable again after reset()
     assert o2.solve_problem(rec2)
+
+
+def test_query_keypoint_adjuster_batch_equals_sequential(ctx):
+    """refine_batch: many queries in one launch, each its own sub-problem -> the same keypoints as refine() per query."""
+    import pxo
+    from pixsfm_amd import synthetic_ka
+    from pixsfm_amd.api import QueryKeypointAdjuster, features
+    queries_a, queries_b = [], []
+    for qi, n in enumerate((9, 1, 17, 30)):
+        base = synthetic_ka.make_ka_problem(n_tracks=n, track_len=2, seed=60 + qi, sigma=0.6)
+        q = np.arange(0, 2 * n, 2)
+        refs = []
+        for nd in q + 1:
+            p = pxo.make_patch(base["patches"][nd], base["corners"][nd], base["scales"][nd])
+            refs.append(pxo.ref2d_residual(p, pxo.cfg(), base["true_xy"][nd], np.zeros(128))[0])
+        fmap = features.FeatureMap.from_arrays(base["patches"][q], np.arange(n), base["corners"][q], (1.0, 1.0))
+        queries_a.append((base["kp"][q].copy(), fmap, [np.asarray(r) for r in refs]))
+        queries_b.append((base["kp"][q].copy(), fmap, [np.asarray(r) for r in refs]))
+    seq = QueryKeypointAdjuster(ctx=ctx)
+    its = []
+    for pts, fmap, refs in queries_a:
+        seq.refine(pts, fmap, refs)
+        its.append(seq.solver.last_summary["iterations"])
+    bat = QueryKeypointAdjuster(ctx=ctx)
+    assert bat.refine_batch(queries_b) == [True] * 4
+    for (pa, _, _), (pb, _, _), it, s in zip(queries_a, queries_b, its, bat.solver.last_summaries):
+        assert np.abs(pa - pb).max() < 1e-12 and s["iterations"] == it

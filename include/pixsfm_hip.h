@@ -295,6 +295,21 @@ int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* view, const 
                  const pxr_loss* loss, double bound, const pxr_lm_options* options,
                  pxr_lm_summary* h_summaries, pxr_lm_summary* total);
 
+/* ---- match-graph labelling (host code) ----------------------------------
+ * ComputeTrackLabels / ComputeScoreLabels / ComputeRootLabels (base/src/graph.cc:126-256), the
+ * pre-processing KeypointAdjuster.refine runs before the optimisers (keypoint_adjustment/main.py:111-118),
+ * over flat HOST arrays: node_image [n_nodes] (FeatureNode::image_id), edges in Graph order (for node in
+ * nodes: for match in node.out_matches) as edge_src / edge_dst / edge_sim.  Sequential by construction
+ * (every union depends on the earlier ones), native so that it does not become the bottleneck. */
+int pxr_graph_track_labels(int64_t n_nodes, const int32_t* node_image, int64_t n_edges,
+                           const int64_t* edge_src, const int64_t* edge_dst, const double* edge_sim,
+                           int64_t* track_labels /* [n_nodes] */, int64_t* n_tracks_out /* may be NULL */);
+int pxr_graph_score_labels(int64_t n_nodes, int64_t n_edges, const int64_t* edge_src,
+                           const int64_t* edge_dst, const double* edge_sim, const int64_t* track_labels,
+                           double* scores /* [n_nodes] */);
+int pxr_graph_root_labels(int64_t n_nodes, const int64_t* track_labels, const double* scores,
+                          uint8_t* is_root /* [n_nodes] */);
+
 /* Dense SPD solve used for the reduced camera system (what Ceres' DENSE_SCHUR / SPARSE_SCHUR
  * Cholesky does on the CPU, bundle_optimizer.h:181-191): blocked right-looking Cholesky +
  * substitution in hand-written HIP.  d_a: n x n row-major, UPPER triangle filled (overwritten

@@ -108,6 +108,10 @@ _SIGNATURES = {
     "pxr_ka_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(KaView), C.POINTER(InterpCfg), C.POINTER(Loss),
                                C.c_double, C.POINTER(LMOptions), C.c_void_p, C.POINTER(LMSummary)]),
     "pxr_dense_spd_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
+    "pxr_graph_track_labels": (C.c_int, [C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(C.c_int64)]),
+    "pxr_graph_score_labels": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pxr_graph_root_labels": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pxr_ba_cost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Loss), C.POINTER(C.c_double)]),
 }
 

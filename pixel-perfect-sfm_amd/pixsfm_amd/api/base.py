@@ -1,8 +1,8 @@
 """Mirror of `pixsfm._pixsfm._base` (pixsfm/base/bindings.cc:29-154) for the accelerated path:
 Graph / FeatureNode / Match, track / score / root labelling, InterpolationConfig, default confs.
 
-Graph labelling is host pre-processing (component 6): it is restated in plain
-Python so that the adjusters can be driven exactly like pixsfm's; it is not on the GPU path.
+Graph labelling is host pre-processing (component 6; section 8f row 3): native host
+code in libpixsfm_hip.so (csrc/pxr_graph.cpp), like the reference's graph.cc; it is not on the GPU path.
 """
 from copy import deepcopy
 
@@ -118,62 +118,52 @@ class Graph:
         return s
 
 
+def _flat_graph(graph):
+    """Flat host arrays of the graph in the reference's enumeration order (for node in nodes: for match in
+    node.out_matches, graph.cc:133-139)."""
+    node_image = np.array([nd.image_id for nd in graph.nodes], dtype=np.int32)
+    src, dst, sim = [], [], []
+    for nd in graph.nodes:
+        for m in nd.out_matches:
+            src.append(nd.node_idx); dst.append(m.node_idx); sim.append(m.sim)
+    return (node_image, np.array(src, dtype=np.int64), np.array(dst, dtype=np.int64), np.array(sim, dtype=np.float64))
+
+
 def compute_track_labels(graph):
-    """ComputeTrackLabels (graph.cc:126-206): maximum-spanning-forest union-find over edges sorted by
-    descending (sim, src, dst), never merging two components that share an image."""
-    n = len(graph.nodes)
-    edges = sorted(((m.sim, nd.node_idx, m.node_idx) for nd in graph.nodes for m in nd.out_matches), reverse=True)
-    parent = [-1] * n
-    images = [{nd.image_id} for nd in graph.nodes]
-
-    def root(i):
-        path = []
-        while parent[i] != -1:
-            path.append(i)
-            i = parent[i]
-        for p in path:
-            parent[p] = i
-        return i
-
-    for _, a, b in edges:
-        ra, rb = root(a), root(b)
-        if ra == rb or (images[ra] & images[rb]):
-            continue
-        if len(images[ra]) < len(images[rb]):
-            parent[ra] = rb; images[rb] |= images[ra]; images[ra] = set()
-        else:
-            parent[rb] = ra; images[ra] |= images[rb]; images[rb] = set()
-    labels = [-1] * n
-    n_tracks = 0
-    for i in range(n):
-        if parent[i] == -1:
-            labels[i] = n_tracks
-            n_tracks += 1
-    for i in range(n):
-        if labels[i] == -1:
-            labels[i] = labels[root(i)]
-    return labels
+    """_base.compute_track_labels (base/bindings.cc:29-131 -> ComputeTrackLabels, graph.cc:126-206): maximum-spanning-
+    forest union-find over the matches in descending (sim, src, dst) order, never merging two components that share
+    an image.  Native host code (pxr_graph_track_labels), like the reference's."""
+    from .. import _lib
+    lib = _lib.load()
+    node_image, src, dst, sim = _flat_graph(graph)
+    labels = np.empty(len(node_image), dtype=np.int64)
+    _lib.check(lib.pxr_graph_track_labels(len(node_image), node_image.ctypes.data, len(src), src.ctypes.data,
+                                          dst.ctypes.data, sim.ctypes.data, labels.ctypes.data, None),
+               "pxr_graph_track_labels")
+    return labels.tolist()
 
 
 def compute_score_labels(graph, track_labels):                       # graph.cc:208-223
-    s = [0.0] * len(graph.nodes)
-    for nd in graph.nodes:
-        for m in nd.out_matches:
-            if track_labels[nd.node_idx] == track_labels[m.node_idx]:
-                s[nd.node_idx] += m.sim
-                s[m.node_idx] += m.sim
-    return s
+    from .. import _lib
+    lib = _lib.load()
+    node_image, src, dst, sim = _flat_graph(graph)
+    tl = np.ascontiguousarray(track_labels, dtype=np.int64)
+    if len(tl) != len(node_image):
+        raise ValueError("track_labels must have one entry per graph node")
+    scores = np.empty(len(node_image), dtype=np.float64)
+    _lib.check(lib.pxr_graph_score_labels(len(node_image), len(src), src.ctypes.data, dst.ctypes.data, sim.ctypes.data,
+                                          tl.ctypes.data, scores.ctypes.data), "pxr_graph_score_labels")
+    return scores.tolist()
 
 
 def compute_root_labels(graph, track_labels, score_labels):          # graph.cc:225-256
+    from .. import _lib
+    lib = _lib.load()
     n = len(graph.nodes)
-    order = sorted(((score_labels[i], i) for i in range(n)), reverse=True)
-    is_root = [False] * n
-    has_root = set()
-    for _, i in order:
-        t = track_labels[i]
-        if t in has_root:
-            continue
-        is_root[i] = True
-        has_root.add(t)
-    return is_root
+    tl = np.ascontiguousarray(track_labels, dtype=np.int64)
+    sc = np.ascontiguousarray(score_labels, dtype=np.float64)
+    if len(tl) != n or len(sc) != n:
+        raise ValueError("track_labels / score_labels must have one entry per graph node")
+    is_root = np.empty(n, dtype=np.uint8)
+    _lib.check(lib.pxr_graph_root_labels(n, tl.ctypes.data, sc.ctypes.data, is_root.ctypes.data), "pxr_graph_root_labels")
+    return [bool(v) for v in is_root]

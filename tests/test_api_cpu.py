@@ -145,3 +145,33 @@ def test_qka_problem_assembly_and_validation():
     assert adj.conf["optimizer"]["bound"] == 2.0 and adj.conf["optimizer"]["solver"]["parameter_tolerance"] == 1e-5
     with pytest.raises(ValueError):
         adj.refine_stacked(kps, fmap, refs, None)
+
+
+def test_native_graph_labelling_matches_the_python_restatement():
+    """csrc/pxr_graph.cpp (ComputeTrackLabels / ScoreLabels / RootLabels, graph.cc:126-256) vs oracle/pxo_graph.py on
+    random match graphs with conflicting matches (two keypoints of one image competing for a track) and score ties."""
+    import pxo_graph
+    from pixsfm_amd.api import base
+    rng = np.random.default_rng(7)
+    for trial in range(6):
+        n_img, per_img = 6, 25
+        g = base.Graph()
+        names = ["im%d" % i for i in range(n_img)]
+        for a in range(n_img):
+            for b in range(a + 1, n_img):
+                m = int(rng.integers(5, 30))
+                matches = np.stack([rng.integers(0, per_img, m), rng.integers(0, per_img, m)], 1)
+                sims = np.round(rng.uniform(0.2, 1.0, m), 1 if trial % 2 else 6)     # coarse similarities: many ties
+                g.register_matches(names[a], names[b], matches, sims)
+        tl = base.compute_track_labels(g)
+        assert tl == pxo_graph.compute_track_labels(g)
+        sc = base.compute_score_labels(g, tl)
+        assert np.allclose(sc, pxo_graph.compute_score_labels(g, tl), rtol=0, atol=1e-12)
+        assert base.compute_root_labels(g, tl, sc) == pxo_graph.compute_root_labels(g, tl, sc)
+        # invariants: one feature per image per track, exactly one root per track
+        seen = {}
+        for nd, t in zip(g.nodes, tl):
+            assert (t, nd.image_id) not in seen
+            seen[(t, nd.image_id)] = 1
+        roots = base.compute_root_labels(g, tl, sc)
+        assert sorted(t for t, r in zip(tl, roots) if r) == sorted(set(tl))

@@ -309,6 +309,19 @@ int pxr_graph_score_labels(int64_t n_nodes, int64_t n_edges, const int64_t* edge
                            double* scores /* [n_nodes] */);
 int pxr_graph_root_labels(int64_t n_nodes, const int64_t* track_labels, const double* scores,
                           uint8_t* is_root /* [n_nodes] */);
+/* Residual-block selection of TopologicalKeypointOptimizer::SetUp + AddIntraResiduals (A12,
+ * topological_keypoint_optimizer.h:97-175, featuremetric_keypoint_optimizer.h:158-202): intra-track matches,
+ * minus keypoint aliases, optionally root edges only, plus root-regularisation blocks; weights = similarity
+ * (weight_by_sim) or 1 / root_regularize_weight.  HOST arrays; node_feature [n_nodes] = FeatureNode::feature_idx;
+ * edges grouped by ascending source node (Graph order); nodes_in_problem NULL = every node;
+ * out_src / out_dst / out_w have capacity 3 * n_edges, *n_out receives the number of blocks.  The output is what
+ * pxr_ka_view's d_edge_src / d_edge_dst / d_edge_w take. */
+int pxr_ka_build_edges(int64_t n_nodes, const int32_t* node_image, const int32_t* node_feature,
+                       int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst, const double* edge_sim,
+                       const int64_t* track_labels, const uint8_t* root_labels, const int64_t* nodes_in_problem,
+                       int64_t n_in_problem, int weight_by_sim, int root_edges_only,
+                       double root_regularize_weight, int64_t* out_src, int64_t* out_dst, double* out_w,
+                       int64_t* n_out);
 
 /* Dense SPD solve used for the reduced camera system (what Ceres' DENSE_SCHUR / SPARSE_SCHUR
  * Cholesky does on the CPU, bundle_optimizer.h:181-191): blocked right-looking Cholesky +

@@ -62,3 +62,50 @@ def compute_root_labels(graph, track_labels, score_labels):          # graph.cc:
         is_root[i] = True
         has_root.add(t)
     return is_root
+
+
+def build_edges(graph, keypoints, track_labels, root_labels, nodes_in_problem=None, weight_by_sim=True,
+                root_edges_only=False, root_regularize_weight=-1.0):
+    """TopologicalKeypointOptimizer::SetUp + FeatureMetricKeypointOptimizer::AddIntraResiduals
+    (topological_keypoint_optimizer.h:97-175, featuremetric_keypoint_optimizer.h:158-202).
+    Returns (src, dst, weight) lists of residual blocks, in the reference's insertion order."""
+    nodes = graph.nodes
+    node_ids = range(len(nodes)) if nodes_in_problem is None else nodes_in_problem
+    regularize = root_regularize_weight > 0.0
+    connected_to_root = {}
+    track_root = {}
+    cand = []
+    for i in node_ids:
+        for m in nodes[i].out_matches:
+            j = m.node_idx
+            if track_labels[i] != track_labels[j]:
+                continue                                     # inter-track: TODO in the reference too (:140-142)
+            cand.append((i, j, m.sim))
+            if regularize:
+                for r in (i, j):
+                    if root_labels[r]:
+                        track_root[track_labels[r]] = r
+                        connected_to_root[i] = connected_to_root[j] = True
+    src, dst, w = [], [], []
+
+    def same_keypoint(a, b):                                 # "avoid optimizing a keypoint to itself" (:147-150)
+        na, nb = nodes[a], nodes[b]
+        return na.image_id == nb.image_id and na.feature_idx == nb.feature_idx
+
+    def add(a, b, weight):                                   # AddIntraResiduals
+        if track_labels[a] != track_labels[b]:
+            return
+        if root_edges_only and not root_labels[a] and not root_labels[b]:
+            return
+        src.append(a); dst.append(b); w.append(weight)
+
+    for i, j, sim in cand:
+        if same_keypoint(i, j):
+            continue
+        add(i, j, sim if weight_by_sim else 1.0)
+        if regularize:
+            for k in (i, j):
+                if not connected_to_root.get(k, False):
+                    add(k, track_root[track_labels[k]], root_regularize_weight)
+                    connected_to_root[k] = True
+    return src, dst, w

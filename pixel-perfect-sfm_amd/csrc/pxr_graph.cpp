@@ -115,3 +115,76 @@ extern "C" int pxr_graph_root_labels(int64_t n_nodes, const int64_t* track_label
   }
   return PXR_OK;
 }
+
+// TopologicalKeypointOptimizer::SetUp + FeatureMetricKeypointOptimizer::AddIntraResiduals
+// (keypoint_adjustment/src/topological_keypoint_optimizer.h:97-175, featuremetric_keypoint_optimizer.h:158-202):
+// which matches become residual blocks, with which ScaledLoss weight, in the reference's insertion order.
+//   - intra-track matches only (:111-116); a match between two aliases of one keypoint is skipped (:147-150);
+//   - root_edges_only keeps blocks with a root endpoint (featuremetric_keypoint_optimizer.h:169-172);
+//   - root_regularize_weight > 0 adds one block node -> track root for nodes no match connects to their
+//     root (:156-170; an unknown root defaults to node 0 like the reference's unordered_map::operator[]).
+// nodes_in_problem: NULL (all nodes in order) or the n_in_problem node indices to enumerate.  The edge arrays are
+// in Graph order (grouped by ascending source node).  out_*: capacity 3 * n_edges; *n_out receives the count.
+extern "C" int pxr_ka_build_edges(int64_t n_nodes, const int32_t* node_image, const int32_t* node_feature,
+                                  int64_t n_edges, const int64_t* edge_src, const int64_t* edge_dst,
+                                  const double* edge_sim, const int64_t* track_labels, const uint8_t* root_labels,
+                                  const int64_t* nodes_in_problem, int64_t n_in_problem, int weight_by_sim,
+                                  int root_edges_only, double root_regularize_weight, int64_t* out_src,
+                                  int64_t* out_dst, double* out_w, int64_t* n_out) {
+  PXR_REQUIRE(n_nodes >= 0 && n_edges >= 0 && n_out && (n_nodes == 0 || (node_image && node_feature && track_labels && root_labels)) &&
+                  (n_edges == 0 || (edge_src && edge_dst && edge_sim && out_src && out_dst && out_w)),
+              "pxr_ka_build_edges: NULL argument");
+  std::vector<int64_t> row_ptr((size_t)n_nodes + 1, 0);
+  for (int64_t e = 0; e < n_edges; ++e) {
+    PXR_REQUIRE(edge_src[e] >= 0 && edge_src[e] < n_nodes && edge_dst[e] >= 0 && edge_dst[e] < n_nodes,
+                "pxr_ka_build_edges: edge %lld out of range", (long long)e);
+    PXR_REQUIRE(e == 0 || edge_src[e] >= edge_src[e - 1], "pxr_ka_build_edges: edges must be grouped by ascending source node");
+    ++row_ptr[(size_t)edge_src[e] + 1];
+  }
+  for (int64_t i = 0; i < n_nodes; ++i) row_ptr[(size_t)i + 1] += row_ptr[(size_t)i];
+  const bool regularize = root_regularize_weight > 0.0;
+  std::vector<char> connected((size_t)n_nodes, 0);
+  std::vector<int64_t> track_root;   // by track label, default 0
+  if (regularize) {
+    int64_t n_tracks = 0;
+    for (int64_t i = 0; i < n_nodes; ++i) n_tracks = std::max(n_tracks, track_labels[i] + 1);
+    track_root.assign((size_t)n_tracks, 0);
+  }
+  std::vector<int64_t> cand;         // edge ids of the intra-track matches of the problem, in enumeration order
+  const int64_t n_enum = nodes_in_problem ? n_in_problem : n_nodes;
+  for (int64_t x = 0; x < n_enum; ++x) {
+    const int64_t i = nodes_in_problem ? nodes_in_problem[x] : x;
+    PXR_REQUIRE(i >= 0 && i < n_nodes, "pxr_ka_build_edges: node %lld out of range", (long long)i);
+    for (int64_t e = row_ptr[(size_t)i]; e < row_ptr[(size_t)i + 1]; ++e) {
+      const int64_t j = edge_dst[e];
+      if (track_labels[i] != track_labels[j]) continue;
+      cand.push_back(e);
+      if (regularize) {
+        if (root_labels[i]) { track_root[(size_t)track_labels[i]] = i; connected[(size_t)i] = connected[(size_t)j] = 1; }
+        if (root_labels[j]) { track_root[(size_t)track_labels[j]] = j; connected[(size_t)i] = connected[(size_t)j] = 1; }
+      }
+    }
+  }
+  int64_t m = 0;
+  auto add = [&](int64_t a, int64_t b, double w) {   // AddIntraResiduals
+    if (track_labels[a] != track_labels[b]) return;
+    if (root_edges_only && !root_labels[a] && !root_labels[b]) return;
+    out_src[m] = a; out_dst[m] = b; out_w[m] = w; ++m;
+  };
+  for (const int64_t e : cand) {
+    const int64_t i = edge_src[e], j = edge_dst[e];
+    if (node_image[i] == node_image[j] && node_feature[i] == node_feature[j]) continue;   // same keypoint
+    add(i, j, weight_by_sim ? edge_sim[e] : 1.0);
+    if (regularize) {
+      const int64_t both[2] = {i, j};
+      for (const int64_t k : both) {
+        if (!connected[(size_t)k]) {
+          add(k, track_root[(size_t)track_labels[k]], root_regularize_weight);
+          connected[(size_t)k] = 1;
+        }
+      }
+    }
+  }
+  *n_out = m;
+  return PXR_OK;
+}

@@ -4,6 +4,7 @@
 drives (pixsfm/keypoint_adjustment/bindings.cc:17-81).  Same names, argument meaning and
 defaults; the Ceres/C++ solve is replaced by pxr_ka_solve on the GPU.
 """
+import ctypes as C
 from copy import deepcopy
 
 import numpy as np
@@ -80,47 +81,28 @@ def build_edges(graph, keypoints, track_labels, root_labels, nodes_in_problem=No
                 root_edges_only=False, root_regularize_weight=-1.0):
     """TopologicalKeypointOptimizer::SetUp + FeatureMetricKeypointOptimizer::AddIntraResiduals
     (topological_keypoint_optimizer.h:97-175, featuremetric_keypoint_optimizer.h:158-202).
-    Returns (src, dst, weight) lists of residual blocks, in the reference's insertion order."""
-    nodes = graph.nodes
-    node_ids = range(len(nodes)) if nodes_in_problem is None else nodes_in_problem
-    regularize = root_regularize_weight > 0.0
-    connected_to_root = {}
-    track_root = {}
-    cand = []
-    for i in node_ids:
-        for m in nodes[i].out_matches:
-            j = m.node_idx
-            if track_labels[i] != track_labels[j]:
-                continue                                     # inter-track: TODO in the reference too (:140-142)
-            cand.append((i, j, m.sim))
-            if regularize:
-                for r in (i, j):
-                    if root_labels[r]:
-                        track_root[track_labels[r]] = r
-                        connected_to_root[i] = connected_to_root[j] = True
-    src, dst, w = [], [], []
-
-    def same_keypoint(a, b):                                 # "avoid optimizing a keypoint to itself" (:147-150)
-        na, nb = nodes[a], nodes[b]
-        return na.image_id == nb.image_id and na.feature_idx == nb.feature_idx
-
-    def add(a, b, weight):                                   # AddIntraResiduals
-        if track_labels[a] != track_labels[b]:
-            return
-        if root_edges_only and not root_labels[a] and not root_labels[b]:
-            return
-        src.append(a); dst.append(b); w.append(weight)
-
-    for i, j, sim in cand:
-        if same_keypoint(i, j):
-            continue
-        add(i, j, sim if weight_by_sim else 1.0)
-        if regularize:
-            for k in (i, j):
-                if not connected_to_root.get(k, False):
-                    add(k, track_root[track_labels[k]], root_regularize_weight)
-                    connected_to_root[k] = True
-    return src, dst, w
+    Returns (src, dst, weight) lists of residual blocks, in the reference's insertion order.
+    Native host code (pxr_ka_build_edges), like the reference's."""
+    lib = _lib.load()
+    node_image, src, dst, sim = base._flat_graph(graph)
+    n = len(node_image)
+    node_feature = np.array([nd.feature_idx for nd in graph.nodes], dtype=np.int32)
+    tl = np.ascontiguousarray(track_labels, dtype=np.int64)
+    rl = np.ascontiguousarray(np.asarray(root_labels, dtype=bool), dtype=np.uint8)
+    if len(tl) != n or len(rl) != n:
+        raise ValueError("label arrays must have one entry per graph node")
+    sub = None if nodes_in_problem is None else np.ascontiguousarray(list(nodes_in_problem), dtype=np.int64)
+    cap = max(1, 3 * len(src))
+    o_src, o_dst, o_w = np.empty(cap, np.int64), np.empty(cap, np.int64), np.empty(cap, np.float64)
+    m = C.c_int64()
+    _lib.check(lib.pxr_ka_build_edges(n, node_image.ctypes.data, node_feature.ctypes.data, len(src), src.ctypes.data,
+                                      dst.ctypes.data, sim.ctypes.data, tl.ctypes.data, rl.ctypes.data,
+                                      None if sub is None else sub.ctypes.data, 0 if sub is None else len(sub),
+                                      int(bool(weight_by_sim)), int(bool(root_edges_only)), float(root_regularize_weight),
+                                      o_src.ctypes.data, o_dst.ctypes.data, o_w.ctypes.data, C.byref(m)),
+               "pxr_ka_build_edges")
+    k = m.value
+    return o_src[:k].tolist(), o_dst[:k].tolist(), o_w[:k].tolist()
 
 
 class FeatureMetricKeypointOptimizer:

@@ -175,3 +175,28 @@ def test_native_graph_labelling_matches_the_python_restatement():
             seen[(t, nd.image_id)] = 1
         roots = base.compute_root_labels(g, tl, sc)
         assert sorted(t for t, r in zip(tl, roots) if r) == sorted(set(tl))
+
+
+@pytest.mark.parametrize("weight_by_sim,root_edges_only,reg", [(True, False, -1.0), (False, True, -1.0), (False, True, 1.0),
+                                                               (True, False, 0.5)])
+def test_native_edge_construction_matches_the_python_restatement(weight_by_sim, root_edges_only, reg):
+    """pxr_ka_build_edges (SetUp + AddIntraResiduals, A12) vs oracle/pxo_graph.build_edges, incl. node subsets."""
+    import pxo_graph
+    from pixsfm_amd.api import base
+    from pixsfm_amd.api.keypoint_adjustment import build_edges
+    rng = np.random.default_rng(11)
+    g = base.Graph()
+    names = ["im%d" % i for i in range(5)]
+    for a in range(5):
+        for b in range(a + 1, 5):
+            m = int(rng.integers(8, 25))
+            g.register_matches(names[a], names[b], np.stack([rng.integers(0, 20, m), rng.integers(0, 20, m)], 1),
+                               rng.uniform(0.2, 1.0, m))
+    tl = base.compute_track_labels(g)
+    sc = base.compute_score_labels(g, tl)
+    roots = base.compute_root_labels(g, tl, sc)
+    for subset in (None, [i for i, t in enumerate(tl) if t % 2 == 0]):
+        got = build_edges(g, None, tl, roots, subset, weight_by_sim, root_edges_only, reg)
+        want = pxo_graph.build_edges(g, None, tl, roots, subset, weight_by_sim, root_edges_only, reg)
+        assert got[0] == list(want[0]) and got[1] == list(want[1]) and np.array_equal(got[2], want[2])
+        assert len(got[0]) > 0

@@ -220,9 +220,11 @@ class _FlatBA:
             if need > reg_count.get(pid, 0) or pid in setup.constant_points:
                 self.point_const[k] = 1
 
-    def problem_dict(self, refs):
+    def problem_dict(self, refs, patch_index=None):
+        """patch_index: arena patch of each observation (features.to_arena(...).index); default 0 .. n_obs - 1."""
+        obs_patch = np.arange(len(self.obs_image), dtype=np.int64) if patch_index is None else patch_index
         return dict(obs_image=self.obs_image, obs_point=self.obs_point,
-                    obs_patch=np.arange(len(self.obs_image), dtype=np.int64), image_camera=self.image_camera,
+                    obs_patch=obs_patch, image_camera=self.image_camera,
                     qvec=self.qvec, tvec=self.tvec, cam_model=self.cam_model, cam_params=self.cam_params,
                     xyz=self.xyz, refs=refs)
 
@@ -250,7 +252,7 @@ class ReferenceExtractor:
         if len(flat.obs_image) == 0:
             return {}
         arena = features.to_arena(ctx, flat.patches)
-        ba = BAProblem(ctx, arena, flat.problem_dict(np.zeros((len(flat.point_ids), arena.C))))
+        ba = BAProblem(ctx, arena, flat.problem_dict(np.zeros((len(flat.point_ids), arena.C)), arena.index))
         keep = bool(self.config['keep_observations'])
         chosen, _ = ba.compute_references(self.interpolation.to_engine(),
                                           make_loss(self.config['loss']['name'], self.config['loss']['params']),
@@ -315,7 +317,7 @@ class FeatureReferenceBundleOptimizer:
         for k, pid in enumerate(flat.point_ids):
             refs[k] = references[pid].descriptor.reshape(-1)                     # references.at(point3D_id)
         self._arena = features.to_arena(ctx, flat.patches)
-        self._ba = BAProblem(ctx, self._arena, flat.problem_dict(refs))
+        self._ba = BAProblem(ctx, self._arena, flat.problem_dict(refs, self._arena.index))
 
     @property
     def problem(self):

@@ -113,11 +113,48 @@ class Reference:
         return len(self.observations) > 0
 
 
+class ArenaPatch:
+    """A patch that already lives in a device arena (written by tensor_to_arena / pxr_arena_extract, or adopted
+    from a torch tensor): the FeaturePatch of the GPU-resident flow.  FeatureMap / FeatureSet hold these like
+    FeaturePatch objects; the optimisers then index the arena in place instead of stacking and uploading."""
+
+    def __init__(self, arena, index):
+        self.arena, self.index = arena, int(index)
+
+    @property
+    def shape(self):
+        return (self.arena.H, self.arena.W, self.arena.C)
+
+
+class ArenaRef:
+    """What to_arena returns: the arena the kernels read + `index`, the arena patch of each list entry.
+    Attribute access falls through to the arena; close() frees it only when to_arena created it."""
+
+    def __init__(self, arena, index, owned):
+        self._arena, self.index, self._owned = arena, np.ascontiguousarray(index, dtype=np.int64), owned
+
+    def __getattr__(self, name):
+        return getattr(self._arena, name)
+
+    def close(self):
+        if self._owned:
+            self._arena.close()
+
+
 def to_arena(ctx, patch_list):
-    """Stack FeaturePatch objects (identical H, W, C, dtype) into an HBM arena."""
+    """FeaturePatch objects (identical H, W, C, dtype) are stacked into a new HBM arena; ArenaPatch objects
+    of one arena are used where they are (no copy)."""
     from ..engine import PatchArena
     if not patch_list:
         raise ValueError("no patches")
+    on_device = [isinstance(p, ArenaPatch) for p in patch_list]
+    if all(on_device):
+        arena = patch_list[0].arena
+        if any(p.arena is not arena for p in patch_list):
+            raise ValueError("the patches of one problem must live in one arena")
+        return ArenaRef(arena, [p.index for p in patch_list], owned=False)
+    if any(on_device):
+        raise ValueError("cannot mix host FeaturePatch and device ArenaPatch objects in one problem")
     shape, dtype = patch_list[0].shape, patch_list[0].data.dtype
     for p in patch_list:
         if p.shape != shape or p.data.dtype != dtype:
@@ -126,7 +163,7 @@ def to_arena(ctx, patch_list):
     data = np.stack([p.data for p in patch_list])
     corners = np.stack([p.corner for p in patch_list])
     scales = np.stack([p.scale for p in patch_list])
-    return PatchArena.from_numpy(ctx, data, corners, scales)
+    return ArenaRef(PatchArena.from_numpy(ctx, data, corners, scales), np.arange(len(patch_list)), owned=True)
 
 
 def tensor_to_arena(arena, first, featuremap, image_size, keypoints, l2_normalize=True):
@@ -137,3 +174,12 @@ def tensor_to_arena(arena, first, featuremap, image_size, keypoints, l2_normaliz
     copy the main bottleneck).  featuremap: torch.cuda tensor (1, C, h, w) or (C, h, w), fp16/fp32,
     contiguous; image_size: (width, height); returns the number of patches written."""
     return arena.extract(first, featuremap, keypoints, image_size, l2_normalize=l2_normalize)
+
+
+def fmap_from_arena(arena, first, keypoint_ids):
+    """FeatureMap over patches first .. first + len(keypoint_ids) - 1 of a device arena (e.g. the ones
+    tensor_to_arena just wrote for one image)."""
+    fm = FeatureMap()
+    for k, kid in enumerate(keypoint_ids):
+        fm.patches[int(kid)] = ArenaPatch(arena, first + k)
+    return fm

@@ -144,7 +144,7 @@ class FeatureMetricKeypointOptimizer:
         patches = [feature_set.fmap(nm).fpatch(nd.feature_idx) for nm, nd in zip(names, graph.nodes)]
         arena = features.to_arena(ctx, patches)
         labels = np.zeros(n, np.int32) if problem_labels is None else np.asarray(problem_labels, dtype=np.int32)
-        prob = dict(kp=kp, node_patch=np.arange(n, dtype=np.int64),
+        prob = dict(kp=kp, node_patch=arena.index,
                     node_const=np.array([self.setup.is_node_constant(nd) for nd in graph.nodes], np.uint8),
                     node_problem=labels, edge_src=np.array(src, np.int32), edge_dst=np.array(dst, np.int32),
                     edge_w=np.array(w, np.float64))

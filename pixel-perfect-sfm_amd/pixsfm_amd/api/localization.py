@@ -89,6 +89,7 @@ def find_feature_inliers(p2Ds, fmap, references, interpolation_config, thresh=-1
     rows, patches, prob = _build_problem(np.asarray(p2Ds, dtype=np.float64), fmap, references, None, mask,
                                          per_keypoint_problems=True)
     arena = features.to_arena(ctx, patches)
+    prob['node_patch'] = arena.index
     ka = KAProblem(ctx, arena, prob)
     _, per = ka.solve(ic.to_engine(), make_loss('trivial', []), bound=0.0, options=lm_options(max_iterations=0),
                       per_problem=True)
@@ -125,7 +126,7 @@ def find_nearest_references(query_fmap, references, keypoints, point3D_ids, inte
     patches = [query_fmap.fpatch(i if patch_idxs is None else patch_idxs[i]) for i in range(n)]
     arena = features.to_arena(ctx, patches)
     cand = np.asarray(cand, dtype=np.float64)
-    best, _, _ = nearest_references(ctx, arena, ic.to_engine(), keypoints, np.arange(n), ptr, cand)
+    best, _, _ = nearest_references(ctx, arena, ic.to_engine(), keypoints, arena.index, ptr, cand)
     arena.close()
     return [cand[b].reshape(1, -1).copy() for b in best]
 
@@ -157,6 +158,7 @@ class QueryKeypointOptimizer:
             return False
         ctx = self.ctx or default_context()
         arena = features.to_arena(ctx, patches)
+        prob['node_patch'] = arena.index
         o, s = self.options, self.options['solver']
         # ParameterizeKeypoint: bounds when bound > 0 or the map is sparse (:145); the accelerated
         # path holds sparse maps only (features.to_arena), so the patch box always applies.
@@ -204,6 +206,7 @@ class QueryKeypointOptimizer:
                    edge_w=np.zeros(0), unary_w=None)
         ctx = self.ctx or default_context()
         arena = features.to_arena(ctx, patches)
+        cat['node_patch'] = arena.index[cat['node_patch']]
         o, s = self.options, self.options['solver']
         ka = KAProblem(ctx, arena, cat)
         lm = lm_options(max_iterations=s['max_num_iterations'], function_tolerance=s['function_tolerance'],
@@ -344,7 +347,7 @@ class QueryBundleOptimizer:
         params = np.zeros((1, 12))
         params[0, :len(camera.params)] = camera.params
         prob = dict(obs_image=np.zeros(m, np.int32), obs_point=np.arange(m, dtype=np.int32),
-                    obs_patch=np.arange(m, dtype=np.int64), image_camera=np.zeros(1, np.int32),
+                    obs_patch=arena.index, image_camera=np.zeros(1, np.int32),
                     qvec=q.reshape(1, 4).copy(), tvec=tvec.reshape(1, 3).copy(),
                     cam_model=np.array([camera.model_id], np.int32), cam_params=params,
                     xyz=np.array(xyz), refs=np.array(refs))

@@ -343,3 +343,53 @@ def test_query_keypoint_adjuster_batch_equals_sequential(ctx):
     assert bat.refine_batch(queries_b) == [True] * 4
     for (pa, _, _), (pb, _, _), it, s in zip(queries_a, queries_b, its, bat.solver.last_summaries):
         assert np.abs(pa - pb).max() < 1e-12 and s["iterations"] == it
+
+
+def test_device_resident_feature_flow_equals_host_flow(ctx):
+    """SURVEY 8f row 2 end to end: dense maps stay on the device, tensor_to_arena writes the patches straight into
+    an arena, FeatureMaps hold ArenaPatch handles and KeypointAdjuster indexes that arena in place -- and gives
+    exactly what the host flow (numpy FeaturePatch objects, stacked and uploaded) gives on the same patches."""
+    import torch
+    from pixsfm_amd.api import KeypointAdjuster, features
+    from pixsfm_amd.api.keypoint_adjustment import build_matching_graph
+    from pixsfm_amd.engine import PatchArena
+    n_img, n_kp, C, h, w = 4, 30, 128, 96, 128
+    g = torch.Generator(device="cuda").manual_seed(1)
+    ys, xs = torch.meshgrid(torch.arange(h, device="cuda", dtype=torch.float32),
+                            torch.arange(w, device="cuda", dtype=torch.float32), indexing="ij")
+    freq = torch.rand((C, 2), generator=g, device="cuda") * 0.25
+    phase = torch.rand((C,), generator=g, device="cuda") * 6.28
+    rng = np.random.default_rng(2)
+    shifts = rng.uniform(-6, 6, (n_img, 2))
+    pts = rng.uniform(30, 90, (n_kp, 2)) * [1.0, 0.7]
+    names = ["im%d" % i for i in range(n_img)]
+    arena = PatchArena(ctx, n_img * n_kp, 16, 16, C, np.float16)
+    keypoints, fmaps_dev = {}, {}
+    for i in range(n_img):
+        fmap = torch.cos(freq[:, 0, None, None] * (xs + float(shifts[i, 0])) + freq[:, 1, None, None] * (ys + float(shifts[i, 1]))
+                         + phase[:, None, None]).contiguous()                    # (C, h, w), the "dense features" of image i
+        kps = pts - shifts[i] + rng.normal(0, 0.7, pts.shape)
+        keypoints[names[i]] = kps.copy()
+        assert features.tensor_to_arena(arena, i * n_kp, fmap, (float(w), float(h)), kps) == n_kp
+        fmaps_dev[names[i]] = features.fmap_from_arena(arena, i * n_kp, range(n_kp))
+    pairs = [(names[a], names[b]) for a in range(n_img) for b in range(a + 1, n_img)]
+    matches = [np.stack([np.arange(n_kp), np.arange(n_kp)], 1) for _ in pairs]
+    graph = build_matching_graph(pairs, matches, [rng.uniform(0.5, 1, n_kp) for _ in pairs])
+    # host flow on the very same texels
+    patches, corners, scales = arena.download()
+    fmaps_host = {names[i]: features.FeatureMap.from_arrays(patches[i * n_kp:(i + 1) * n_kp], np.arange(n_kp),
+                                                              corners[i * n_kp:(i + 1) * n_kp], tuple(scales[i * n_kp]))
+                  for i in range(n_img)}
+    out = {}
+    for tag, fmaps in (("device", fmaps_dev), ("host", fmaps_host)):
+        kp = {k: v.copy() for k, v in keypoints.items()}
+        KeypointAdjuster.create({"strategy": "featuremetric"}).refine_multilevel(
+            kp, features.FeatureManager([features.FeatureSet(fmaps)]), graph)
+        out[tag] = kp
+    moved = 0.0
+    for nm in names:
+        assert np.abs(out["device"][nm] - out["host"][nm]).max() < 1e-12
+        moved = max(moved, np.abs(out["device"][nm] - keypoints[nm]).max())
+    assert moved > 0.1
+    # the arena is still alive and untouched by the adjuster (it does not own it)
+    assert np.array_equal(arena.download(0, 4)[0], patches[:4])

@@ -234,6 +234,13 @@ int pxr_ba_compute_references(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view*
                               double* d_obs_desc_out /* NULL, or [n_obs][C]: the per-observation descriptors
                                                         (ReferenceConfig::keep_observations, reference_extractor.h:60,259-265) */);
 
+/* PatchInterpolator::Evaluate / InterpolateNodes, batched (A5, features/src/patch_interpolator.h:86-135;
+ * `_features.PatchInterpolator(config).interpolate_nodes(fpatch, xy)`, features/bindings.cc): the normalised
+ * bicubic descriptor of arena patch d_patch[i] at keypoint d_kp[i] (COLMAP image coordinates) into
+ * d_desc [n][C], and optionally its Jacobian with respect to the keypoint, d_J [n][C][2] (d/dx, d/dy). */
+int pxr_interpolate(pxr_ctx* ctx, pxr_arena* arena, const pxr_interp_cfg* cfg, int64_t n, const double* d_kp,
+                    const int64_t* d_patch, double* d_desc, double* d_J /* may be NULL */);
+
 /* FindNearestReferences (localization/src/nearest_references.h:20-52): for each 2D-3D correspondence i the
  * query descriptor f(patch[d_patch[i]], d_kp[i]) is compared with its candidates -- rows
  * d_cand_index[d_cand_ptr[i] .. d_cand_ptr[i+1]) of d_cand_desc [*][C] (d_cand_index NULL: the rows

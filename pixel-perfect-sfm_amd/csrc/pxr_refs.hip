@@ -195,7 +195,60 @@ __global__ __launch_bounds__(256) void k_nearest(int64_t n, const ST* __restrict
   }
 }
 
+// ---- PatchInterpolator::Evaluate (features/src/patch_interpolator.h:86-135), batched -------------------------
+template <typename ST, int C>
+__global__ __launch_bounds__(256) void k_interpolate(int64_t n, const ST* __restrict__ arena, const int32_t* __restrict__ corners,
+                                                     const double* __restrict__ scales, int H, int W, int l2_normalize,
+                                                     int float_simd, const double* __restrict__ kp,
+                                                     const int64_t* __restrict__ patch, double* __restrict__ out_f,
+                                                     double* __restrict__ out_J) {
+  constexpr int LPO = C / 8, G = 256 / LPO;
+  const int sub = threadIdx.x % LPO;
+  const int64_t i = (int64_t)blockIdx.x * G + threadIdx.x / LPO;
+  if (i >= n) return;
+  const int64_t pi = patch[i];
+  const double sx = scales[2 * pi], sy = scales[2 * pi + 1];
+  const double u = kp[2 * i] * sx - 0.5 - (double)corners[2 * pi];
+  const double v = kp[2 * i + 1] * sy - 0.5 - (double)corners[2 * pi + 1];
+  const ST* p = arena + (size_t)pi * H * W * C;
+  double f[8], fr[8], fc[8];
+  if (out_J) {
+    if (float_simd) interp8<ST, LPO, true, true>(p, H, W, C, sub, u, v, l2_normalize != 0, f, fr, fc);
+    else interp8<ST, LPO, true, false>(p, H, W, C, sub, u, v, l2_normalize != 0, f, fr, fc);
+  } else {
+    if (float_simd) interp8<ST, LPO, false, true>(p, H, W, C, sub, u, v, l2_normalize != 0, f, fr, fc);
+    else interp8<ST, LPO, false, false>(p, H, W, C, sub, u, v, l2_normalize != 0, f, fr, fc);
+  }
+#pragma unroll
+  for (int ch = 0; ch < 8; ++ch) {
+    const size_t o = (size_t)i * C + sub * 8 + ch;
+    out_f[o] = f[ch];
+    if (out_J) { out_J[2 * o] = fc[ch] * sx; out_J[2 * o + 1] = fr[ch] * sy; }   // d/dx, d/dy in image coordinates
+  }
+}
+
 }  // namespace pxr
+
+extern "C" int pxr_interpolate(pxr_ctx* ctx, pxr_arena* arena, const pxr_interp_cfg* cfg, int64_t n, const double* d_kp,
+                               const int64_t* d_patch, double* d_desc, double* d_J) {
+  using namespace pxr;
+  PXR_REQUIRE(ctx && arena && cfg && d_kp && d_patch && d_desc, "pxr_interpolate: NULL argument");
+  if (n == 0) return PXR_OK;
+  PXR_HIP(hipSetDevice(ctx->device));
+#define INTERP_LAUNCH(ST, CC)                                                                                      \
+  hipLaunchKernelGGL((k_interpolate<ST, CC>), dim3((unsigned)((n + (256 / (CC / 8)) - 1) / (256 / (CC / 8)))), dim3(256), 0, \
+                     ctx->stream, n, (const ST*)arena->d_data, arena->d_corners, arena->d_scales, arena->H, arena->W, \
+                     cfg->l2_normalize, cfg->use_float_simd, d_kp, d_patch, d_desc, d_J)
+  if (arena->dtype == PXR_F16 && arena->C == 128) INTERP_LAUNCH(_Float16, 128);
+  else if (arena->dtype == PXR_F16 && arena->C == 64) INTERP_LAUNCH(_Float16, 64);
+  else if (arena->dtype == PXR_F32 && arena->C == 128) INTERP_LAUNCH(float, 128);
+  else if (arena->dtype == PXR_F32 && arena->C == 64) INTERP_LAUNCH(float, 64);
+  else if (arena->dtype == PXR_F64 && arena->C == 128) INTERP_LAUNCH(double, 128);
+  else if (arena->dtype == PXR_F64 && arena->C == 64) INTERP_LAUNCH(double, 64);
+  else return set_error(PXR_EUNSUPPORTED, "pxr_interpolate: CHANNELS=%d not supported (128, 64)", arena->C);
+#undef INTERP_LAUNCH
+  return hip_check(hipGetLastError(), "k_interpolate launch");
+}
 
 extern "C" int pxr_nearest_references(pxr_ctx* ctx, pxr_arena* arena, const pxr_interp_cfg* cfg, int64_t n,
                                       const double* d_kp, const int64_t* d_patch, const int64_t* d_cand_ptr,

@@ -183,3 +183,30 @@ def fmap_from_arena(arena, first, keypoint_ids):
     for k, kid in enumerate(keypoint_ids):
         fm.patches[int(kid)] = ArenaPatch(arena, first + k)
     return fm
+
+
+class PatchInterpolator:
+    """_features.PatchInterpolator(interpolation_config) (features/bindings.cc; features/src/patch_interpolator.h):
+    interpolate_nodes(fpatch, xy) -> (1, C) descriptor of the patch at a keypoint in COLMAP image coordinates, on
+    the GPU (pxr_interpolate).  interpolate_many is the batched form the kernels are made for."""
+
+    def __init__(self, interpolation_config=None, ctx=None):
+        from . import base
+        ic = interpolation_config
+        self.interpolation = ic if isinstance(ic, base.InterpolationConfig) else base.InterpolationConfig(ic)
+        self.ctx = ctx
+
+    def interpolate_many(self, fpatches, xys, jacobian=False):
+        from ..engine import interpolate
+        from .keypoint_adjustment import default_context
+        ctx = self.ctx or default_context()
+        arena = to_arena(ctx, list(fpatches))
+        desc, J = interpolate(ctx, arena, self.interpolation.to_engine(), xys, arena.index, jacobian=jacobian)
+        arena.close()
+        return (desc, J) if jacobian else desc
+
+    def interpolate_nodes(self, fpatch, xy):
+        return self.interpolate_many([fpatch], np.asarray(xy, dtype=np.float64).reshape(1, 2))
+
+    def interpolate(self, fpatch, xy):
+        return self.interpolate_nodes(fpatch, xy).reshape(-1)

@@ -203,6 +203,19 @@ class PatchArena:
             pass
 
 
+def interpolate(ctx, arena, cfg, keypoints, patch_idx, jacobian=False):
+    """PatchInterpolator::Evaluate, batched (pxr_interpolate): descriptors (n, C) of arena patches patch_idx at
+    the keypoints (COLMAP image coordinates) and, with jacobian=True, their (n, C, 2) derivatives d/d(x, y)."""
+    kp = ctx.to_device(np.ascontiguousarray(keypoints, dtype=np.float64).reshape(-1, 2), np.float64)
+    n = kp.shape[0]
+    pidx = ctx.to_device(np.ascontiguousarray(patch_idx, dtype=np.int64), np.int64)
+    desc = ctx.empty((n, arena.C), np.float64)
+    J = ctx.empty((n, arena.C, 2), np.float64) if jacobian else None
+    check(ctx.lib.pxr_interpolate(ctx.handle, arena.handle, C.byref(cfg), n, kp.ptr, pidx.ptr, desc.ptr,
+                                  J.ptr if J else None), "pxr_interpolate")
+    return desc.download(), (J.download() if J else None)
+
+
 def nearest_references(ctx, arena, cfg, keypoints, patch_idx, cand_ptr, cand_desc, cand_index=None, want_desc=False):
     """FindNearestReferences (localization/src/nearest_references.h:20-52) on the device.
     keypoints (n, 2), patch_idx (n,) arena patches of the query keypoints; candidates of correspondence i:

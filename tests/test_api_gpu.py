@@ -393,3 +393,21 @@ def test_device_resident_feature_flow_equals_host_flow(ctx):
     assert moved > 0.1
     # the arena is still alive and untouched by the adjuster (it does not own it)
     assert np.array_equal(arena.download(0, 4)[0], patches[:4])
+
+
+def test_patch_interpolator_matches_oracle(ctx):
+    """features.PatchInterpolator (patch_interpolator.h:86-135): descriptors and keypoint Jacobians vs the oracle."""
+    import pxo
+    from pixsfm_amd import synthetic_ka
+    from pixsfm_amd.api import features
+    base = synthetic_ka.make_ka_problem(n_tracks=5, track_len=3, seed=4, scale=(0.5, 0.25))
+    fps = [features.FeaturePatch(base["patches"][i], base["corners"][i], base["scales"][i]) for i in range(15)]
+    pi = features.PatchInterpolator(ctx=ctx)
+    desc, J = pi.interpolate_many(fps, base["kp"], jacobian=True)
+    cfg = pxo.cfg()
+    for i in (0, 6, 14):
+        p = pxo.make_patch(base["patches"][i], base["corners"][i], base["scales"][i])
+        r, Jo = pxo.ref2d_residual(p, cfg, base["kp"][i], np.zeros(128))
+        assert np.abs(desc[i] - r).max() < 1e-14 and np.abs(J[i] - Jo).max() < 1e-12 * max(1.0, np.abs(Jo).max())
+    one = pi.interpolate_nodes(fps[3], base["kp"][3])
+    assert one.shape == (1, 128) and np.array_equal(one[0], desc[3]) and abs(np.linalg.norm(one) - 1) < 1e-12

@@ -107,8 +107,8 @@ int pxr_arena_upload(pxr_arena* a, int64_t first, int64_t count, const void* h_p
  * (w / image_w, h / image_h); corner = clip((int)(kp * scale - 8), 0, (w, h) - 16 - 1) (C truncation,
  * like astype(np.int32)); l2_normalize: torch.nn.functional.normalize over channels (fp32,
  * eps 1e-12) before the cast to the arena dtype (extractor.py:173-175).  Fills patches
- * [first, first + n) of the arena (16 x 16 only) with their corners and scales; asynchronous on
- * the context's stream. */
+ * [first, first + n) of the arena (square patches of side ps <= 16; "8" / "16" above read ps / 2 and
+ * ps) with their corners and scales; asynchronous on the context's stream. */
 int pxr_arena_extract(pxr_ctx* ctx, pxr_arena* a, int64_t first, int64_t n, const void* d_fmap,
                       int src_dtype, int h, int w, const double* d_keypoints, double image_w,
                       double image_h, int l2_normalize);

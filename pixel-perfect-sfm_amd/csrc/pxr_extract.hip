@@ -26,26 +26,27 @@ __device__ __forceinline__ void ex_corner(const double* kp, double sx, double sy
   y0 = min(max(y0, 0), h - ps - 1);
 }
 
-// PS = 16 (patch side), C multiple of 16.  256 threads.
+// ps <= 16 (patch side: 16 by default, 10 / 8 in the reference's lighter configurations), C multiple of 16.
+// 256 threads: 16 x-lanes x 16 channel groups for the loads, 16 pixels x 16 channel groups for the stores.
 template <typename SRC, typename DST, int C>
 __global__ __launch_bounds__(256) void extract_kernel(const SRC* __restrict__ fmap, int h, int w,
                                                       const double* __restrict__ kps, double sx, double sy,
                                                       int l2_normalize, DST* __restrict__ out,
                                                       int32_t* __restrict__ corners, double* __restrict__ scales,
-                                                      int64_t first) {
-  constexpr int PS = 16, CP = C + 1;            // +1 float of padding: conflict-free column reads
-  __shared__ float tile[2 * PS * CP];
+                                                      int64_t first, int ps) {
+  constexpr int PSM = 16, CP = C + 1;           // +1 float of padding: conflict-free column reads
+  __shared__ float tile[2 * PSM * CP];
   const int64_t k = blockIdx.x;
   const int tid = threadIdx.x;
   int x0, y0;
-  ex_corner(kps + 2 * k, sx, sy, PS, w, h, x0, y0);
+  ex_corner(kps + 2 * k, sx, sy, ps, w, h, x0, y0);
   if (tid == 0) {
     corners[2 * (first + k)] = x0; corners[2 * (first + k) + 1] = y0;
     scales[2 * (first + k)] = sx; scales[2 * (first + k) + 1] = sy;
   }
-  DST* patch = out + (size_t)(first + k) * PS * PS * C;
+  DST* patch = out + (size_t)(first + k) * ps * ps * C;
   const size_t plane = (size_t)h * w;
-  const int lx = tid & 15, lc = tid >> 4;       // load mapping: 16 x-contiguous lanes, 16 channels per pass
+  const int lx = min(tid & 15, ps - 1), lc = tid >> 4;   // load mapping: 16 x-contiguous lanes (clamped to the patch), 16 channels per pass
   const int px = tid >> 4, sub = tid & 15;      // store mapping: 16 lanes per pixel, C/16 channels per lane
   constexpr int CPL = C / 16;
   // software pipeline: the CHW loads of row y + 1 are in flight while row y goes through the
@@ -56,11 +57,11 @@ __global__ __launch_bounds__(256) void extract_kernel(const SRC* __restrict__ fm
 #pragma unroll
     for (int j = 0; j < CPL; ++j) cur[j] = row[(size_t)(lc + 16 * j) * plane];
   }
-  for (int y = 0; y < PS; ++y) {
-    float* tl = tile + (y & 1) * (PS * CP);
+  for (int y = 0; y < ps; ++y) {
+    float* tl = tile + (y & 1) * (PSM * CP);
 #pragma unroll
     for (int j = 0; j < CPL; ++j) tl[lx * CP + lc + 16 * j] = (float)cur[j];
-    if (y + 1 < PS) {
+    if (y + 1 < ps) {
       const SRC* row = fmap + (size_t)(y0 + y + 1) * w + x0 + lx;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) nxt[j] = row[(size_t)(lc + 16 * j) * plane];
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void extract_kernel(const SRC* __restrict__ fm
     vec_t o;
 #pragma unroll
     for (int j = 0; j < CPL; ++j) o[j] = (DST)v[j];
-    *reinterpret_cast<vec_t*>(patch + ((size_t)y * PS + px) * C + sub * CPL) = o;
+    if (px < ps) *reinterpret_cast<vec_t*>(patch + ((size_t)y * ps + px) * C + sub * CPL) = o;
 #pragma unroll
     for (int j = 0; j < CPL; ++j) cur[j] = nxt[j];
   }
@@ -95,8 +96,8 @@ extern "C" int pxr_arena_extract(pxr_ctx* ctx, pxr_arena* a, int64_t first, int6
   PXR_REQUIRE(ctx && a && d_fmap && d_keypoints, "pxr_arena_extract: NULL argument");
   PXR_REQUIRE(first >= 0 && n >= 0 && first + n <= a->n, "pxr_arena_extract: range [%lld, %lld) outside arena of %lld patches",
               (long long)first, (long long)(first + n), (long long)a->n);
-  PXR_REQUIRE(a->H == 16 && a->W == 16, "pxr_arena_extract: patch size %dx%d not supported (16x16)", a->H, a->W);
-  PXR_REQUIRE(h > 16 && w > 16, "pxr_arena_extract: feature map %dx%d must exceed the patch size", h, w);
+  PXR_REQUIRE(a->H == a->W && a->H >= 1 && a->H <= 16, "pxr_arena_extract: patch size %dx%d not supported (square, <= 16)", a->H, a->W);
+  PXR_REQUIRE(h > a->H && w > a->W, "pxr_arena_extract: feature map %dx%d must exceed the patch size", h, w);
   PXR_REQUIRE(image_w > 0 && image_h > 0, "pxr_arena_extract: image size must be positive");
   if (n == 0) return PXR_OK;
   PXR_HIP(hipSetDevice(ctx->device));
@@ -104,7 +105,7 @@ extern "C" int pxr_arena_extract(pxr_ctx* ctx, pxr_arena* a, int64_t first, int6
 #define EX_LAUNCH(SRC, DST, CC)                                                                              \
   hipLaunchKernelGGL((extract_kernel<SRC, DST, CC>), dim3((unsigned)n), dim3(256), 0, ctx->stream,          \
                      (const SRC*)d_fmap, h, w, d_keypoints, sx, sy, l2_normalize, (DST*)a->d_data,          \
-                     a->d_corners, a->d_scales, first)
+                     a->d_corners, a->d_scales, first, a->H)
 #define EX_DST(SRC, CC)                                                   \
   do {                                                                    \
     if (a->dtype == PXR_F16) EX_LAUNCH(SRC, _Float16, CC);                \

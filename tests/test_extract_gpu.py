@@ -123,3 +123,47 @@ def test_full_size_extract_properties(ctx):
     gbps = n * 16 * 16 * 128 * (4 + 2) / (ms * 1e-3) / 1e9   # fp32 read + fp16 write per texel
     print("extract: %.3f ms for %d patches, %.0f GB/s algorithmic" % (ms, n, gbps))
     assert ms < 50.0
+
+
+@pytest.mark.parametrize("ps", [8, 10])
+def test_other_patch_sizes_through_producer_and_solvers(ctx, ps):
+    """Patch sides other than 16 (the reference's lighter configurations use 10 / 8): the producer against the
+    restatement, then KA edges and a BA evaluation on such patches against the oracle."""
+    import torch
+    import pxo
+    import pxo_extract
+    from pixsfm_amd import synthetic, synthetic_ka
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, make_loss
+    from pixsfm_amd.ka_engine import KAProblem
+    rng = np.random.default_rng(ps)
+    fmap = rng.normal(0, 1, (128, 40, 50)).astype(np.float32)
+    kps = rng.uniform(-3, 210, (60, 2))
+    want, corners, scale = pxo_extract.sparse_patches(fmap, kps, (200.0, 160.0), ps=ps)
+    arena = PatchArena(ctx, len(kps), ps, ps, 128, np.float16)
+    arena.extract(0, torch.from_numpy(fmap).cuda(), kps, (200.0, 160.0))
+    patches, c, s = arena.download()
+    assert np.array_equal(c, corners) and patches.shape == (60, ps, ps, 128)
+    assert _ulp16(patches, want).max() <= 1
+    # KA edges on ps x ps patches
+    kprob = synthetic_ka.make_ka_problem(n_tracks=5, track_len=3, seed=ps, patch_size=ps, sigma=0.5)
+    karena = PatchArena.from_numpy(ctx, kprob["patches"], kprob["corners"], kprob["scales"])
+    cost, r, J1, J2 = KAProblem(ctx, karena, kprob).eval(interp_cfg(), make_loss("cauchy", [0.25]), materialize=True)
+    r, J1 = r.download(), J1.download()
+    for e in (0, len(kprob["edge_src"]) - 1):
+        a_, b_ = kprob["edge_src"][e], kprob["edge_dst"][e]
+        p1 = pxo.make_patch(kprob["patches"][a_], kprob["corners"][a_], kprob["scales"][a_])
+        p2 = pxo.make_patch(kprob["patches"][b_], kprob["corners"][b_], kprob["scales"][b_])
+        ro, J1o, _ = pxo.ka_residual(p1, p2, pxo.cfg(), kprob["kp"][a_], kprob["kp"][b_])
+        assert np.abs(r[e] - ro).max() < 1e-12 and np.abs(J1[e] - J1o).max() < 1e-10
+    # BA evaluation on ps x ps patches
+    bprob = synthetic.make_ba_problem(n_cams=3, n_points=20, obs_per_point=2, seed=ps, patch_size=ps)
+    barena = PatchArena.from_numpy(ctx, bprob["patches"], bprob["corners"], bprob["scales"])
+    rec, rr, _, _ = BAProblem(ctx, barena, bprob).eval(interp_cfg(), with_jacobian=True, materialize=True)
+    rr = rr.download()
+    for i in (0, 17, 39):
+        p = pxo.make_patch(bprob["patches"][i], bprob["corners"][i], bprob["scales"][i])
+        img, pt = bprob["obs_image"][i], bprob["obs_point"][i]
+        cam = bprob["image_camera"][img]
+        out = pxo.ba_residual(p, pxo.cfg(), int(bprob["cam_model"][cam]), bprob["qvec"][img], bprob["tvec"][img],
+                              bprob["xyz"][pt], bprob["cam_params"][cam], bprob["refs"][pt], jac=False)
+        assert np.abs(rr[i] - out[0]).max() < 1e-12

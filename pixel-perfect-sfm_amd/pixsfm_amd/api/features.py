@@ -48,11 +48,19 @@ class FeatureMap:
         scale = np.broadcast_to(np.asarray(scale, dtype=np.float64), (2,))
         return cls({int(k): FeaturePatch(p, c, scale) for k, p, c in zip(keypoint_ids, patches, corners)})
 
-    def fpatch(self, keypoint_id):
-        return self.patches[int(keypoint_id)]
+    @classmethod
+    def dense(cls, featuremap_hwc, scale):
+        """A dense map (is_sparse = False, extractor.py:200-212): ONE patch under kDenseId that covers the whole
+        image, corner (0, 0); every keypoint of the image resolves to it."""
+        return cls({kDenseId: FeaturePatch(featuremap_hwc, (0, 0), scale)}, is_sparse=False)
 
-    def has_fpatch(self, keypoint_id):
-        return int(keypoint_id) in self.patches
+    def fpatch(self, keypoint_id):               # featuremap.h:104-111
+        return self.patches[int(keypoint_id)] if self.is_sparse else self.patches[kDenseId]
+
+    def has_fpatch(self, keypoint_id):           # featuremap.h:113-118
+        if self.is_sparse:
+            return int(keypoint_id) in self.patches
+        return len(self.patches) == 1 and kDenseId in self.patches
 
     def keys(self):
         return list(self.patches.keys())
@@ -155,15 +163,22 @@ def to_arena(ctx, patch_list):
         return ArenaRef(arena, [p.index for p in patch_list], owned=False)
     if any(on_device):
         raise ValueError("cannot mix host FeaturePatch and device ArenaPatch objects in one problem")
-    shape, dtype = patch_list[0].shape, patch_list[0].data.dtype
-    for p in patch_list:
+    # one arena entry per DISTINCT patch object: in dense mode all keypoints of an image share one (large) patch
+    slot, uniq, index = {}, [], np.empty(len(patch_list), dtype=np.int64)
+    for k, p in enumerate(patch_list):
+        if id(p) not in slot:
+            slot[id(p)] = len(uniq)
+            uniq.append(p)
+        index[k] = slot[id(p)]
+    shape, dtype = uniq[0].shape, uniq[0].data.dtype
+    for p in uniq:
         if p.shape != shape or p.data.dtype != dtype:
-            raise ValueError("the accelerated path needs patches of identical shape and dtype "
-                             "(sparse mode, pixsfm/features/extractor.py:33-51)")
-    data = np.stack([p.data for p in patch_list])
-    corners = np.stack([p.corner for p in patch_list])
-    scales = np.stack([p.scale for p in patch_list])
-    return ArenaRef(PatchArena.from_numpy(ctx, data, corners, scales), np.arange(len(patch_list)), owned=True)
+            raise ValueError("the accelerated path needs patches of identical shape and dtype (sparse patches of one "
+                             "patch_size, pixsfm/features/extractor.py:33-51, or dense maps of equal size)")
+    data = np.stack([p.data for p in uniq])
+    corners = np.stack([p.corner for p in uniq])
+    scales = np.stack([p.scale for p in uniq])
+    return ArenaRef(PatchArena.from_numpy(ctx, data, corners, scales), index, owned=True)
 
 
 def tensor_to_arena(arena, first, featuremap, image_size, keypoints, l2_normalize=True):

@@ -411,3 +411,39 @@ def test_patch_interpolator_matches_oracle(ctx):
         assert np.abs(desc[i] - r).max() < 1e-14 and np.abs(J[i] - Jo).max() < 1e-12 * max(1.0, np.abs(Jo).max())
     one = pi.interpolate_nodes(fps[3], base["kp"][3])
     assert one.shape == (1, 128) and np.array_equal(one[0], desc[3]) and abs(np.linalg.norm(one) - 1) < 1e-12
+
+
+def test_dense_feature_maps_equal_sparse_patches(ctx):
+    """Dense mode (FeatureMap.is_sparse = False, one kDenseId patch per image, featuremap.h:104-118): KA on dense maps
+    gives what KA gives on 16x16 patches cropped from the same maps, as long as the stencils stay inside the crops."""
+    from pixsfm_amd.api import KeypointAdjuster, features
+    from pixsfm_amd.api.keypoint_adjustment import build_matching_graph
+    rng = np.random.default_rng(5)
+    n_img, n_kp, C, h, w = 3, 12, 128, 40, 48
+    ys, xs = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    freq, phase = rng.uniform(0, 0.3, (C, 2)), rng.uniform(0, 6.28, C)
+    shifts = rng.uniform(-3, 3, (n_img, 2))
+    pts = rng.uniform(14, 26, (n_kp, 2))
+    names = ["im%d" % i for i in range(n_img)]
+    keypoints, dense, sparse = {}, {}, {}
+    for i in range(n_img):
+        m = np.cos(freq[:, 0] * (xs[..., None] + shifts[i, 0]) + freq[:, 1] * (ys[..., None] + shifts[i, 1]) + phase)
+        m = (m / np.linalg.norm(m, axis=-1, keepdims=True)).astype(np.float16)          # (h, w, C)
+        kps = pts - shifts[i] + rng.normal(0, 0.4, pts.shape)
+        keypoints[names[i]] = kps
+        dense[names[i]] = features.FeatureMap.dense(m, (1.0, 1.0))
+        corners = np.clip((kps - 8).astype(np.int32), 0, [w - 17, h - 17])
+        sparse[names[i]] = features.FeatureMap.from_arrays(
+            np.stack([m[c[1]:c[1] + 16, c[0]:c[0] + 16] for c in corners]), np.arange(n_kp), corners, (1.0, 1.0))
+    pairs = [(names[a], names[b]) for a in range(n_img) for b in range(a + 1, n_img)]
+    graph = build_matching_graph(pairs, [np.stack([np.arange(n_kp)] * 2, 1)] * len(pairs), [np.ones(n_kp)] * len(pairs))
+    out = {}
+    for tag, fm in (("dense", dense), ("sparse", sparse)):
+        kp = {k: v.copy() for k, v in keypoints.items()}
+        conf = {"strategy": "featuremetric", "optimizer": {"bound": 2.0}}
+        KeypointAdjuster.create(conf).refine_multilevel(kp, features.FeatureManager([features.FeatureSet(fm)]), graph)
+        out[tag] = kp
+    assert dense[names[0]].has_fpatch(7) and dense[names[0]].fpatch(3) is dense[names[0]].fpatch(9)
+    for nm in names:
+        assert np.abs(out["dense"][nm] - out["sparse"][nm]).max() < 1e-9
+    assert max(np.abs(out["dense"][nm] - keypoints[nm]).max() for nm in names) > 0.05     # (the root image stays put)

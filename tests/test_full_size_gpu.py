@@ -85,3 +85,45 @@ def test_lm_descends_monotonically_at_full_size(ctx, big):
     # the summary's final cost is the cost of the parameters left on the device
     ba.eval(interp_cfg(), with_jacobian=False)
     assert abs(ba.cost(make_loss("cauchy", [0.25])) - s["final_cost"]) < 1e-9 * s["final_cost"]
+
+
+def test_ka_config0_scale_matches_oracle(ctx):
+    """BASELINE configs[0] scale (sacre_coeur: ~8 000 observations in ~1 900 tracks, demo.ipynb:271-274): every
+    sub-problem of the KA solve against the oracle LM -- same iteration counts, termination and keypoints."""
+    import pxo
+    import pxo_ka
+    from pixsfm_amd import synthetic_ka
+    from pixsfm_amd.engine import PatchArena, interp_cfg, make_loss
+    from pixsfm_amd.ka_engine import KAProblem
+    rng = np.random.default_rng(0)
+    parts, off = [], 0
+    # tracks of 3 .. 6 nodes (mean ~4.2) packed into <= 50-keypoint sub-problems like keypoint_adjustment/main.py:13-57
+    prob = None
+    for tl, nt in ((3, 500), (4, 700), (5, 500), (6, 200)):
+        p = synthetic_ka.make_ka_problem(n_tracks=nt, track_len=tl, seed=100 + tl, max_kps_per_problem=50)
+        parts.append(p)
+    n_nodes = sum(len(p["kp"]) for p in parts)
+    assert 7500 <= n_nodes <= 8500
+    cat = {}
+    node_off = prob_off = 0
+    for p in parts:
+        q = dict(p)
+        q["node_patch"] = p["node_patch"] + node_off
+        q["edge_src"] = p["edge_src"] + node_off
+        q["edge_dst"] = p["edge_dst"] + node_off
+        q["node_problem"] = p["node_problem"] + prob_off
+        for k in ("kp", "node_patch", "node_const", "node_problem", "edge_src", "edge_dst", "edge_w", "patches", "corners", "scales"):
+            cat.setdefault(k, []).append(q[k])
+        node_off += len(p["kp"]); prob_off += p["n_problems"]
+    cat = {k: np.concatenate(v) for k, v in cat.items()}
+    arena = PatchArena.from_numpy(ctx, cat["patches"], cat["corners"], cat["scales"])
+    ka = KAProblem(ctx, arena, cat)
+    total, per = ka.solve(interp_cfg(), make_loss("cauchy", [0.25]), bound=4.0, per_problem=True)
+    kp = ka.keypoints()
+    kpo, sums = pxo_ka.ka_solve(cat, pxo.cfg(), pxo.loss("cauchy", 0.25), 4.0)
+    assert len(per) == len(sums) == prob_off
+    same_traj = sum(g["iterations"] == o["iterations"] and g["termination"] == o["termination"] for g, o in zip(per, sums))
+    assert same_traj >= 0.995 * len(per)            # a borderline tolerance decision may differ in a handful of problems
+    assert np.abs(kp - kpo).max() < 1e-4            # north_star bar for refined parameters
+    assert np.percentile(np.abs(kp - kpo).max(axis=1), 99) < 1e-7
+    assert abs(total["final_cost"] - sum(o["final_cost"] for o in sums)) < 1e-6 * total["initial_cost"]

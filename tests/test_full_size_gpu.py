@@ -127,3 +127,26 @@ def test_ka_config0_scale_matches_oracle(ctx):
     assert np.abs(kp - kpo).max() < 1e-4            # north_star bar for refined parameters
     assert np.percentile(np.abs(kp - kpo).max(axis=1), 99) < 1e-7
     assert abs(total["final_cost"] - sum(o["final_cost"] for o in sums)) < 1e-6 * total["initial_cost"]
+
+
+def test_ba_courtyard_shape_matches_oracle(ctx):
+    """BASELINE configs[3] shape (38 images) at a size the oracle's dense LM finishes in seconds: 38 cameras,
+    500 points, 3 000 observations, reduced camera system of ~300 unknowns (several Cholesky panels)."""
+    import pxo
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    prob = synthetic.make_ba_problem(n_cams=38, n_points=500, obs_per_point=6, seed=38)
+    n_img = 38
+    pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
+    tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
+    gauge = (pose_const, tmask, np.full(n_img, 0b0110, np.uint16), np.zeros(500, np.uint8))
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *gauge, options=lm_options(max_iterations=4))
+    q, t, k, X = ba.params()
+    so, qo, to, ko, Xo = pxo.ba_solve(prob, pxo.cfg(), pxo.loss("cauchy", 0.25), *gauge, pxo.lm_options(max_iterations=4))
+    assert s["num_camera_unknowns"] > 250 and s["num_point_unknowns"] == 1500
+    assert s["iterations"] == so["iterations"] and s["num_successful"] == so["num_successful"]
+    assert abs(s["final_cost"] - so["final_cost"]) < 1e-7 * so["initial_cost"]
+    assert np.abs(q - qo).max() < 1e-7 and np.abs(t - to).max() < 1e-7 and np.abs(X - Xo).max() < 1e-6
+    assert np.abs(k[:, :4] - ko[:, :4]).max() < 1e-5 * 1200

@@ -150,3 +150,38 @@ def test_ba_courtyard_shape_matches_oracle(ctx):
     assert abs(s["final_cost"] - so["final_cost"]) < 1e-7 * so["initial_cost"]
     assert np.abs(q - qo).max() < 1e-7 and np.abs(t - to).max() < 1e-7 and np.abs(X - Xo).max() < 1e-6
     assert np.abs(k[:, :4] - ko[:, :4]).max() < 1e-5 * 1200
+
+
+def test_many_cameras_column_tiled_schur_and_long_cholesky(ctx):
+    """More than 2047 camera unknowns: the LDS-privatised Schur contraction runs over several column tiles and the
+    Cholesky over ~40 panels.  No oracle at this size (its dense LM is cubic in ALL unknowns); the independent
+    global-atomics contraction (PXR_SCHUR_GLOBAL_ATOMICS=1) must give the same trajectory, and the solve must
+    reduce the cost towards the noise floor."""
+    import os
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    n_img = 320
+    prob = synthetic.make_ba_problem(n_cams=n_img, n_points=2500, obs_per_point=6, seed=77)
+    pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
+    tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
+    gauge = (pose_const, tmask, np.full(n_img, 0b0110, np.uint16), np.zeros(2500, np.uint8))
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    out = {}
+    for tag, env in (("lds", None), ("global", "1")):
+        if env:
+            os.environ["PXR_SCHUR_GLOBAL_ATOMICS"] = env
+        else:
+            os.environ.pop("PXR_SCHUR_GLOBAL_ATOMICS", None)
+        try:
+            ba = BAProblem(ctx, arena, prob)
+            s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *gauge, options=lm_options(max_iterations=4))
+            out[tag] = (s, ba.params())
+        finally:
+            os.environ.pop("PXR_SCHUR_GLOBAL_ATOMICS", None)
+    s1, p1 = out["lds"]; s2, p2 = out["global"]
+    assert s1["num_camera_unknowns"] > 2047
+    assert s1["iterations"] == s2["iterations"] and s1["num_successful"] == s2["num_successful"]
+    assert abs(s1["final_cost"] - s2["final_cost"]) < 1e-9 * s1["initial_cost"]
+    for a_, b_ in zip(p1, p2):
+        assert np.abs(a_ - b_).max() < 1e-8 * max(1.0, np.abs(b_).max())
+    assert s1["final_cost"] < 0.01 * s1["initial_cost"]

@@ -136,7 +136,8 @@ typedef struct {
   const double* d_cam_params;    /* [n_cameras][PXR_KPAD] */
   int64_t n_points;
   const double* d_xyz;           /* [n_points][3] */
-  const double* d_refs;          /* [n_points][C]  Reference::descriptor (references.h:65) */
+  const double* d_refs;          /* [n_points][C]  Reference::descriptor (references.h:65); NULL = no reference
+                                    is subtracted (cost-map BA, costmap_bundle_optimizer.h:104-119) */
 } pxr_ba_view;
 
 /* Fused evaluation.  Per observation i writes the record d_rec[i][0..7]:
@@ -233,6 +234,21 @@ int pxr_ba_compute_references(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view*
                               double* d_refs_out, int64_t* d_ref_obs_out, double* d_robust_mean_out,
                               double* d_obs_desc_out /* NULL, or [n_obs][C]: the per-observation descriptors
                                                         (ReferenceConfig::keep_observations, reference_extractor.h:60,259-265) */);
+
+/* ---- cost maps (the reference's low-memory BA) -----------------------------
+ * Replaces CostMapExtractor::RunSubset / FillPointCostmap (bundle_adjustment/src/costmap_extractor.h:177-358)
+ * for CostMapConfig.upsampling_factor = 1, compute_cross_derivative = false on sparse patches: cost map
+ * first_out + i of `costmaps` (C = 3 [cost, dcost/dr, dcost/dc] when as_gradientfield, else 1 [cost]; H, W as
+ * the features; any dtype -- the reference's binding uses the features', bundle_adjustment/bindings.cc:21)
+ * = featuremetric error of every texel of feature patch d_patch[i] against reference descriptor
+ * d_refs[d_ref_index[i]] (the observation's 3D point), robustified with `loss` (CostMapConfig.loss), central
+ * differences in the storage type, optional sqrt (CostMapConfig.apply_sqrt); corner and scale are copied from
+ * the feature patch.  The cost-map BA (CostMapBundleOptimizer, costmap_bundle_optimizer.h) is then
+ * pxr_ba_solve on the `costmaps` arena with view->d_refs = NULL and cfg->l2_normalize = 0
+ * (bundle_adjustment/main.py:270): the residual block is the interpolated 3- (or 1-) channel texel. */
+int pxr_costmap_extract(pxr_ctx* ctx, pxr_arena* features, pxr_arena* costmaps, int64_t first_out, int64_t n,
+                        const int64_t* d_patch, const int32_t* d_ref_index, const double* d_refs,
+                        const pxr_loss* loss, int as_gradientfield, int apply_sqrt);
 
 /* PatchInterpolator::Evaluate / InterpolateNodes, batched (A5, features/src/patch_interpolator.h:86-135;
  * `_features.PatchInterpolator(config).interpolate_nodes(fpatch, xy)`, features/bindings.cc): the normalised

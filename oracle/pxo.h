@@ -164,7 +164,8 @@ typedef struct {
   const int32_t* cam_model;   /* [n_cams] */
   const double* cam_params;   /* [n_cams][12] (padded) */
   const double* xyz;          /* [n_points][3] */
-  const double* refs;         /* [n_points][C] */
+  const double* refs;         /* [n_points][C]; NULL = no reference is subtracted (costmap BA,
+                               * bundle_adjustment/src/costmap_bundle_optimizer.h:104-119 passes nullptr) */
   /* uniform patch arena */
   const void* arena; int32_t dtype, H, W, C;
   const int32_t* corners;     /* [n_patches][2] */

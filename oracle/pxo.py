@@ -252,7 +252,7 @@ def ba_batch(problem):
     b = BaBatch(len(problem["obs_image"]), arr("obs_image", np.int32), arr("obs_point", np.int32),
                 arr("obs_patch", np.int64), arr("image_camera", np.int32), arr("qvec", np.float64),
                 arr("tvec", np.float64), arr("cam_model", np.int32), arr("cam_params", np.float64),
-                arr("xyz", np.float64), arr("refs", np.float64), arena.ctypes.data,
+                arr("xyz", np.float64), arr("refs", np.float64) if problem.get("refs") is not None else None, arena.ctypes.data,
                 _NP2DT[arena.dtype], H, W, ch, arr("corners", np.int32), arr("scales", np.float64))
     return b, keep
 

@@ -407,7 +407,7 @@ static void* ba_worker(void* arg) {
     const int model = b->cam_model[cam];
     const int K = pxo_camera_num_params(model);
     pxo_ba_residual(&p, j->cfg, model, b->qvec + 4 * img, b->tvec + 3 * img, b->xyz + 3 * (int64_t)pt,
-                    b->cam_params + PXO_KPAD * cam, b->refs + (int64_t)C * pt, r, Jq, Jt, JX, Jk);
+                    b->cam_params + PXO_KPAD * cam, b->refs ? b->refs + (int64_t)C * pt : NULL, r, Jq, Jt, JX, Jk);
     double s = 0;
     for (int c = 0; c < C; ++c) s += r[c] * r[c];
     double rho[3];

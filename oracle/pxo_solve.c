@@ -164,7 +164,7 @@ static double ba_evaluate(ba_ctx* c, const double* qvec, const double* tvec, con
     const int model = b->cam_model[cam], K = pxo_camera_num_params(model);
     pxo_patch p = ba_patch(b, b->obs_patch[i]);
     pxo_ba_residual(&p, c->cfg, model, qvec + 4 * img, tvec + 3 * img, xyz + 3 * pt,
-                    cams + PXO_KPAD * cam, b->refs + (size_t)C * pt, r, H ? Jq : NULL, H ? Jt : NULL,
+                    cams + PXO_KPAD * cam, b->refs ? b->refs + (size_t)C * pt : NULL, r, H ? Jq : NULL, H ? Jt : NULL,
                     H ? JX : NULL, H ? Jk : NULL);
     double s = 0;
     for (int k = 0; k < C; ++k) s += r[k] * r[k];
@@ -303,7 +303,7 @@ static double point_eval(ba_ctx* c, const double* q, const double* t, const doub
     const int img = b->obs_image[i], cam = b->image_camera[img];
     pxo_patch pt = ba_patch(b, b->obs_patch[i]);
     pxo_ba_residual(&pt, c->cfg, b->cam_model[cam], q + 4 * img, t + 3 * img, X, k + PXO_KPAD * cam,
-                    b->refs + (size_t)C * p, r, NULL, NULL, H ? JX : NULL, NULL);
+                    b->refs ? b->refs + (size_t)C * p : NULL, r, NULL, NULL, H ? JX : NULL, NULL);
     double s = 0;
     for (int m = 0; m < C; ++m) s += r[m] * r[m];
     double rho[3];

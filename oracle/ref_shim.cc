@@ -109,4 +109,17 @@ double pxo_ref_bicubic_many_half128(const uint16_t* arena, int64_t n, int H, int
   }
   return acc;
 }
+// The reference's vendored half.hpp (third-party/half.hpp, 2.2.0) arithmetic the cost-map extraction leans on
+// (bundle_adjustment/src/costmap_extractor.h:266-279 subtracts texels in the storage type; FeaturePatch::SetEntry,
+// features/src/featurepatch.h:246-248, casts the double cost to the storage type).  Element-wise, n entries.
+void pxo_ref_half_sub(const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n) {
+  const half* ha = (const half*)a;
+  const half* hb = (const half*)b;
+  half* ho = (half*)out;
+  for (int64_t i = 0; i < n; ++i) ho[i] = ha[i] - hb[i];
+}
+void pxo_ref_half_from_double(const double* v, uint16_t* out, int64_t n) {
+  half* ho = (half*)out;
+  for (int64_t i = 0; i < n; ++i) ho[i] = half(v[i]);
+}
 }

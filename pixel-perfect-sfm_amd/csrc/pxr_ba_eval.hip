@@ -168,6 +168,82 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(const BaEvalArgs a) {
   }
 }
 
+// ---- few-channel patches: cost-map BA ------------------------------------------------------------
+// CostMapBundleOptimizer (bundle_adjustment/src/costmap_bundle_optimizer.h:76-132) runs the same functor on
+// 1- or 3-channel cost maps with no reference descriptor (nullptr, "just minimize"): the residual block IS the
+// interpolated texel.  16 texels of 2..24 bytes per observation: one lane per observation, the record and the
+// fused cost exactly as above, so the whole Schur pipeline is shared.
+template <typename ST, int C, bool WITH_JAC>
+__global__ __launch_bounds__(256) void ba_eval_small_kernel(const BaEvalArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = a.v.n_obs;
+  const bool valid = i < n;
+  double rec[PXR_OBS_REC];
+#pragma unroll
+  for (int j = 0; j < PXR_OBS_REC; ++j) rec[j] = 0.0;
+  if (valid) {
+    const int img = a.v.d_obs_image[i];
+    const int pt = a.v.d_obs_point[i];
+    const int64_t pidx = a.v.d_obs_patch[i];
+    const int cam = a.v.d_image_camera[img];
+    double q[4], t[3], X[3], k[PXR_KPAD];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = a.v.d_qvec[4 * (size_t)img + j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { t[j] = a.v.d_tvec[3 * (size_t)img + j]; X[j] = a.v.d_xyz[3 * (size_t)pt + j]; }
+#pragma unroll
+    for (int j = 0; j < PXR_KPAD; ++j) k[j] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + j];
+    double x, y;
+    world_to_pixel(a.v.d_cam_model[cam], k, q, t, X, x, y);
+    const double sx = a.scales[2 * pidx], sy = a.scales[2 * pidx + 1];
+    const double u = x * sx - 0.5 - (double)a.corners[2 * pidx];
+    const double v = y * sy - 0.5 - (double)a.corners[2 * pidx + 1];
+    double f[C], fr[C], fc[C];
+    interp_small<ST, C>(reinterpret_cast<const ST*>(a.arena) + (size_t)pidx * a.H * a.W * C, a.H, a.W, u, v,
+                        a.l2_normalize != 0, f, fr, fc);
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+      const double r = a.v.d_refs ? f[ch] - a.v.d_refs[(size_t)pt * C + ch] : f[ch];
+      rec[0] = fma(r, r, rec[0]);
+      if (WITH_JAC) {
+        rec[1] = fma(fc[ch], fc[ch], rec[1]); rec[2] = fma(fc[ch], fr[ch], rec[2]); rec[3] = fma(fr[ch], fr[ch], rec[3]);
+        rec[4] = fma(fc[ch], r, rec[4]); rec[5] = fma(fr[ch], r, rec[5]);
+      }
+      if (a.out_r) {
+        a.out_r[(size_t)i * C + ch] = r;
+        if (WITH_JAC && a.out_gx) { a.out_gx[(size_t)i * C + ch] = fc[ch] * sx; a.out_gy[(size_t)i * C + ch] = fr[ch] * sy; }
+      }
+    }
+    rec[1] *= sx * sx; rec[2] *= sx * sy; rec[3] *= sy * sy; rec[4] *= sx; rec[5] *= sy;
+    rec[6] = x; rec[7] = y;
+    if (a.check_bounds && !(u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H)) rec[0] = __builtin_nan("");
+    double2* o = reinterpret_cast<double2*>(a.rec + (size_t)i * PXR_OBS_REC);
+    o[0] = make_double2(rec[0], rec[1]);
+    o[1] = make_double2(rec[2], rec[3]);
+    o[2] = make_double2(rec[4], rec[5]);
+    o[3] = make_double2(rec[6], rec[7]);
+  }
+  if (a.cost_out) {
+    double c = 0.0;
+    if (valid) {
+      double rho[3];
+      loss_eval(a.loss.type, a.loss.a, 1.0, rec[0], rho);
+      c = 0.5 * rho[0];
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(a.cost_out, c);
+  }
+}
+
+template <typename ST, int C>
+static int launch_eval_small(pxr_ctx* ctx, const BaEvalArgs& a, bool with_jac) {
+  const int64_t blocks = (a.v.n_obs + 255) / 256;
+  if (blocks == 0) return PXR_OK;
+  if (with_jac) hipLaunchKernelGGL((ba_eval_small_kernel<ST, C, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((ba_eval_small_kernel<ST, C, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+  return pxr::hip_check(hipGetLastError(), "ba_eval_small_kernel launch");
+}
+
 // ---- projection Jacobians (parity checks) ------------------------------------------------
 __global__ __launch_bounds__(256) void ba_projjac_kernel(const pxr_ba_view v, double* __restrict__ P) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -226,8 +302,10 @@ static int launch_eval_c(pxr_ctx* ctx, int C, const BaEvalArgs& a, bool with_jac
   switch (C) {
     case 128: return launch_eval<ST, 128>(ctx, a, with_jac, float_simd);
     case 64: return launch_eval<ST, 64>(ctx, a, with_jac, float_simd);
+    case 3: return launch_eval_small<ST, 3>(ctx, a, with_jac);   // cost maps (costmap_bundle_optimizer.h:9-14)
+    case 1: return launch_eval_small<ST, 1>(ctx, a, with_jac);
     default:
-      return set_error(PXR_EUNSUPPORTED, "pxr_ba_eval: CHANNELS=%d not supported (128, 64)", C);
+      return set_error(PXR_EUNSUPPORTED, "pxr_ba_eval: CHANNELS=%d not supported (128, 64; cost maps: 3, 1)", C);
   }
 }
 

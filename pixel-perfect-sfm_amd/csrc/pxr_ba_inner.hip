@@ -37,7 +37,8 @@ struct InnerArgs {
 // sum over the wavefront's rows (LPO lanes each); every lane of a row holds the row's value
 template <int LPO>
 __device__ __forceinline__ double rows_sum(double v) {
-  if (LPO == 8) v += __shfl_xor(v, 8);
+  if (LPO == 1) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); }
+  if (LPO <= 8) v += __shfl_xor(v, 8);
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
   return v;
@@ -47,8 +48,9 @@ constexpr int INNER_MAXO = 16;   // observations per point staged in LDS
 
 template <typename ST, int C, bool FS>   // FS: InterpolationConfig.use_float_simd
 __device__ __forceinline__ void inner_points_body(const InnerArgs& a, double (*sh_obs)[INNER_MAXO][26]) {
-  static_assert(C == 128 || C == 64, "one observation per row of C / 8 lanes");
-  constexpr int LPO = C / 8, ROWS = 64 / LPO;
+  static_assert(C == 128 || C == 64 || C <= 4, "one observation per row of C / 8 lanes, or per lane (cost maps)");
+  // cost maps (C = 1, 3; costmap_bundle_optimizer.h:9-14): the whole texel in one lane, 64 observations per pass
+  constexpr int LPO = C >= 64 ? C / 8 : 1, ROWS = 64 / LPO, CH = C >= 64 ? 8 : C;
   const int lane = threadIdx.x & 63, row = lane / LPO, sub = lane % LPO;
   const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= a.v.n_points) return;
@@ -59,12 +61,11 @@ __device__ __forceinline__ void inner_points_body(const InnerArgs& a, double (*s
   double X[3] = {a.v.d_xyz[3 * p], a.v.d_xyz[3 * p + 1], a.v.d_xyz[3 * p + 2]};
   const ST* arena = reinterpret_cast<const ST*>(a.arena);
   const size_t patch_elems = (size_t)a.H * a.W * C;
-  const double* refp = a.v.d_refs + (size_t)p * C + sub * 8;
-  double ref[8];
+  double ref[CH];   // d_refs == NULL: no reference is subtracted (cost maps)
 #pragma unroll
-  for (int ch = 0; ch < 8; ++ch) ref[ch] = refp[ch];
+  for (int ch = 0; ch < CH; ++ch) ref[ch] = a.v.d_refs ? a.v.d_refs[(size_t)p * C + sub * CH + ch] : 0.0;
 
-  auto rsum = [](double v) { return LPO == 16 ? row16_sum(v) : row8_sum(v); };
+  auto rsum = [](double v) { return LPO == 16 ? row16_sum(v) : (LPO == 8 ? row8_sum(v) : v); };
   // stage the observations' camera / patch data (lane 0 of each row, one observation each)
   for (int oi = row; oi < n && oi < INNER_MAXO; oi += ROWS) {
     if (sub == 0) {
@@ -128,11 +129,14 @@ __device__ __forceinline__ void inner_points_body(const InnerArgs& a, double (*s
       world_to_pixel_jac(model, k, q, t, Xc, x, y, A, Pq, PX, Pk);
       const double u = x * sx - 0.5 - cx;
       const double v = y * sy - 0.5 - cy;
-      double f[8], fr[8], fc[8];
-      interp8<ST, LPO, true, FS>(arena + (size_t)pi * patch_elems, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f, fr, fc);
+      double f[CH], fr[CH], fc[CH];
+      if constexpr (C >= 64)
+        interp8<ST, LPO, true, FS>(arena + (size_t)pi * patch_elems, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f, fr, fc);
+      else
+        interp_small<ST, C>(arena + (size_t)pi * patch_elems, a.H, a.W, u, v, a.l2_normalize != 0, f, fr, fc);
       double s = 0, gcc = 0, gcr = 0, grr = 0, bc = 0, br = 0;
 #pragma unroll
-      for (int ch = 0; ch < 8; ++ch) {
+      for (int ch = 0; ch < CH; ++ch) {
         const double r = f[ch] - ref[ch];
         s = fma(r, r, s);
         gcc = fma(fc[ch], fc[ch], gcc); gcr = fma(fc[ch], fr[ch], gcr); grr = fma(fr[ch], fr[ch], grr);
@@ -277,8 +281,8 @@ __global__ __launch_bounds__(256) void k_inner_points(const InnerArgs a) {
 int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
                             const pxr_loss* loss, const int64_t* d_pt_ptr, const int64_t* d_pt_obs,
                             const int* d_pt_var, double* d_cost_before) {
-  if (arena->C != 128 && arena->C != 64)
-    return set_error(PXR_EUNSUPPORTED, "inner iterations: CHANNELS=%d not supported (128, 64)", arena->C);
+  if (arena->C != 128 && arena->C != 64 && arena->C != 3 && arena->C != 1)
+    return set_error(PXR_EUNSUPPORTED, "inner iterations: CHANNELS=%d not supported (128, 64; cost maps: 3, 1)", arena->C);
   InnerArgs a;
   a.v = *view;
   a.arena = arena->d_data; a.corners = arena->d_corners; a.scales = arena->d_scales;
@@ -292,7 +296,14 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     if (cfg->use_float_simd) hipLaunchKernelGGL((KERNEL<ST, CC, true>), dim3(blocks), dim3(256), 0, ctx->stream, a);  \
     else hipLaunchKernelGGL((KERNEL<ST, CC, false>), dim3(blocks), dim3(256), 0, ctx->stream, a);             \
   } while (0)
-  if (arena->dtype == PXR_F16 && arena->C == 128) INNER_LAUNCH(k_inner_points_occ2, _Float16, 128);
+  if (arena->C <= 4) {
+    if (arena->dtype == PXR_F16 && arena->C == 3) INNER_LAUNCH(k_inner_points, _Float16, 3);
+    else if (arena->dtype == PXR_F16) INNER_LAUNCH(k_inner_points, _Float16, 1);
+    else if (arena->dtype == PXR_F32 && arena->C == 3) INNER_LAUNCH(k_inner_points, float, 3);
+    else if (arena->dtype == PXR_F32) INNER_LAUNCH(k_inner_points, float, 1);
+    else if (arena->C == 3) INNER_LAUNCH(k_inner_points, double, 3);
+    else INNER_LAUNCH(k_inner_points, double, 1);
+  } else if (arena->dtype == PXR_F16 && arena->C == 128) INNER_LAUNCH(k_inner_points_occ2, _Float16, 128);
   else if (arena->dtype == PXR_F16 && arena->C == 64) INNER_LAUNCH(k_inner_points_occ2, _Float16, 64);
   else if (arena->dtype == PXR_F32 && arena->C == 128) INNER_LAUNCH(k_inner_points_occ2, float, 128);
   else if (arena->dtype == PXR_F32 && arena->C == 64) INNER_LAUNCH(k_inner_points_occ2, float, 64);

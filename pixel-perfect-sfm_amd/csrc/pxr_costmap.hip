@@ -1,0 +1,200 @@
+// pxr_costmap.hip -- cost-map extraction for gfx950 (MI355X).
+//
+// CostMapExtractor::FillPointCostmap (bundle_adjustment/src/costmap_extractor.h:230-358) turns the C-channel
+// feature patch of an observation into a 3-channel (cost, dcost/dr, dcost/dc) or 1-channel map of the
+// featuremetric error against the point's reference descriptor; the cost-map BA
+// (costmap_bundle_optimizer.h) then never touches the features again -- the reference's low-memory path
+// (configs/low_memory.yaml).  Here: the case the reference takes without interpolation (cost patch of the
+// feature patch's size, no cross derivative, :253-279 / :330-340), per texel
+//     res = f - ref;  cost = 0.5 rho(|res|^2)[0]
+//     dfdr = 0.5 (f[min(H-1, y+1)] - f[max(0, y-1)]),  dfdc likewise along x   (differences in the STORAGE type)
+//     dcost/dr = rho' <res, dfdr>, dcost/dc = rho' <res, dfdc>   where cost > 1e-8;  optional sqrt.
+//
+// One pass over the feature arena: HBM-bound (H*W*C*sizeof(dtype) + 8 C bytes in, 3 H W sizeof(dtype) out per
+// observation).  Mapping: one workgroup per patch, a group of C/8 lanes (one DPP row at C = 128) per texel COLUMN
+// walking down the rows with the rows y-1, y, y+1 of its column rolling through registers, so every texel
+// is fetched from HBM once; the left / right neighbours come from the L1 lines the adjacent groups fetched.
+// Each lane owns 8 channels (one 16-byte load per fp16 texel), the three channel reductions are DPP
+// row reductions in fp64 (the reference accumulates in double).
+#include <hip/hip_runtime.h>
+
+#include "pxr_device.h"
+#include "pxr_interp.h"
+#include "pxr_internal.h"
+
+namespace pxr {
+
+struct CostmapArgs {
+  const void* fin; const int32_t* cin; const double* sin;     // feature arena: data, corners, scales
+  void* fout; int32_t* cout; double* sout;                    // cost-map arena
+  int H, W, CO, apply_sqrt;
+  int64_t first_out;
+  const int64_t* patch;       // [n] feature patch of each cost map
+  const int32_t* ref_index;   // [n] row of refs (the 3D point)
+  const double* refs;         // [*][C]
+  pxr_loss loss;
+};
+
+// a - b in the storage type (Eigen expression on Map<Matrix<dtype>>, costmap_extractor.h:266-276), widened
+template <typename ST> struct StorageDiff;
+template <> struct StorageDiff<_Float16> {
+  static __device__ __forceinline__ void run(const Texel8<_Float16>& a, const Texel8<_Float16>& b, double out[8]) {
+    union { uint4 u; half8_t h; } x, y;
+    x.u = a.raw; y.u = b.raw;
+    const half8_t d = x.h - y.h;   // v_pk_add_f16: correctly rounded, like half.hpp 2.2.0
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (double)d[i];
+  }
+};
+template <> struct StorageDiff<float> {
+  static __device__ __forceinline__ void run(const Texel8<float>& a, const Texel8<float>& b, double out[8]) {
+    float x[8], y[8];
+    a.unpack(x); b.unpack(y);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (double)__fsub_rn(x[i], y[i]);
+  }
+};
+template <> struct StorageDiff<double> {
+  static __device__ __forceinline__ void run(const Texel8<double>& a, const Texel8<double>& b, double out[8]) {
+    double x[8], y[8];
+    a.unpack(x); b.unpack(y);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = __dsub_rn(x[i], y[i]);
+  }
+};
+
+template <typename ST>
+__device__ __forceinline__ void widen8(const Texel8<ST>& t, double out[8]) {
+  typename Texel8<ST>::work_t w[8];
+  t.unpack(w);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = (double)w[i];
+}
+
+// FeaturePatch::SetEntry (features/src/featurepatch.h:246-248): dtype(double).  half.hpp has no constructor
+// from double, so half storage goes through float -- two roundings, reproduced here.
+template <typename OT> __device__ __forceinline__ OT store_cast(double v);
+template <> __device__ __forceinline__ _Float16 store_cast<_Float16>(double v) { return (_Float16)(float)v; }
+template <> __device__ __forceinline__ float store_cast<float>(double v) { return (float)v; }
+template <> __device__ __forceinline__ double store_cast<double>(double v) { return v; }
+
+template <typename ST, typename OT, int C, bool GRAD>
+__global__ __launch_bounds__(256) void costmap_kernel(const CostmapArgs a) {
+  constexpr int LPO = C / 8;
+  const int x = threadIdx.x / LPO, sub = threadIdx.x % LPO;   // blockDim.x = W * LPO
+  const int64_t i = blockIdx.x;
+  const int64_t pi = a.patch[i];
+  const int H = a.H, W = a.W;
+  const ST* P = reinterpret_cast<const ST*>(a.fin) + (size_t)pi * H * W * C + sub * 8;
+  if (threadIdx.x == 0) {   // CreateShallowCostmapFSet, costmap_extractor.h:382-399: corner and scale are the feature patch's
+    const int64_t o = a.first_out + i;
+    a.cout[2 * o] = a.cin[2 * pi]; a.cout[2 * o + 1] = a.cin[2 * pi + 1];
+    a.sout[2 * o] = a.sin[2 * pi]; a.sout[2 * o + 1] = a.sin[2 * pi + 1];
+  }
+  double ref[8];
+  {
+    const double* rp = a.refs + (size_t)a.ref_index[i] * C + sub * 8;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) ref[ch] = rp[ch];
+  }
+  OT* out = reinterpret_cast<OT*>(a.fout) + (size_t)(a.first_out + i) * H * W * a.CO;
+  const int xl = x > 0 ? x - 1 : 0, xr = x < W - 1 ? x + 1 : W - 1;
+
+  Texel8<ST> up, cur, down;
+  cur.load(P + (size_t)x * C);
+  up = cur;
+  down.load(P + (size_t)((H > 1 ? 1 : 0) * W + x) * C);
+  for (int y = 0; y < H; ++y) {
+    Texel8<ST> nxt, L, R;
+    const int y2 = y + 2 < H ? y + 2 : H - 1;
+    nxt.load(P + (size_t)(y2 * W + x) * C);
+    if (GRAD) { L.load(P + (size_t)(y * W + xl) * C); R.load(P + (size_t)(y * W + xr) * C); }
+    double f[8], s = 0.0, br = 0.0, bc = 0.0;
+    widen8<ST>(cur, f);
+    double res[8];
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) { res[ch] = f[ch] - ref[ch]; s = fma(res[ch], res[ch], s); }
+    if (GRAD) {
+      double dr[8], dc[8];
+      StorageDiff<ST>::run(down, up, dr);
+      StorageDiff<ST>::run(R, L, dc);
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) { br = fma(res[ch], 0.5 * dr[ch], br); bc = fma(res[ch], 0.5 * dc[ch], bc); }
+    }
+    if (LPO == 16) { s = row16_sum(s); if (GRAD) { br = row16_sum(br); bc = row16_sum(bc); } }
+    else { s = row8_sum(s); if (GRAD) { br = row8_sum(br); bc = row8_sum(bc); } }
+    if (sub == 0) {
+      double rho[3];
+      loss_eval(a.loss.type, a.loss.a, 1.0, s, rho);
+      double cost = 0.5 * rho[0];
+      OT* o = out + (size_t)(y * W + x) * a.CO;
+      if (GRAD) {
+        double dcr = 0.0, dcc = 0.0;
+        if (cost > 1.0e-8) {   // costmap_extractor.h:300-318
+          dcr = rho[1] * br; dcc = rho[1] * bc;
+          if (a.apply_sqrt) { cost = sqrt(cost); dcr *= 0.5 / cost; dcc *= 0.5 / cost; }
+        }
+        o[0] = store_cast<OT>(cost); o[1] = store_cast<OT>(dcr); o[2] = store_cast<OT>(dcc);
+      } else {
+        if (a.apply_sqrt) cost = sqrt(cost);   // :351-353
+        o[0] = store_cast<OT>(cost);
+      }
+    }
+    up = cur; cur = down; down = nxt;
+  }
+}
+
+template <typename ST, typename OT, int C>
+static int launch_costmap(pxr_ctx* ctx, const CostmapArgs& a, int64_t n, bool grad) {
+  const dim3 grid((unsigned)n), block((unsigned)(a.W * (C / 8)));
+  if (grad) hipLaunchKernelGGL((costmap_kernel<ST, OT, C, true>), grid, block, 0, ctx->stream, a);
+  else hipLaunchKernelGGL((costmap_kernel<ST, OT, C, false>), grid, block, 0, ctx->stream, a);
+  return hip_check(hipGetLastError(), "costmap_kernel launch");
+}
+
+template <typename ST, int C>
+static int launch_costmap_o(pxr_ctx* ctx, int out_dtype, const CostmapArgs& a, int64_t n, bool grad) {
+  switch (out_dtype) {
+    case PXR_F16: return launch_costmap<ST, _Float16, C>(ctx, a, n, grad);
+    case PXR_F32: return launch_costmap<ST, float, C>(ctx, a, n, grad);
+    default: return launch_costmap<ST, double, C>(ctx, a, n, grad);
+  }
+}
+
+}  // namespace pxr
+
+extern "C" int pxr_costmap_extract(pxr_ctx* ctx, pxr_arena* features, pxr_arena* costmaps, int64_t first_out, int64_t n,
+                                   const int64_t* d_patch, const int32_t* d_ref_index, const double* d_refs,
+                                   const pxr_loss* loss, int as_gradientfield, int apply_sqrt) {
+  PXR_REQUIRE(ctx && features && costmaps && loss, "pxr_costmap_extract: NULL argument");
+  PXR_REQUIRE(n >= 0 && first_out >= 0 && first_out + n <= costmaps->n,
+              "pxr_costmap_extract: cost maps [%lld, %lld) outside the arena of %lld", (long long)first_out,
+              (long long)(first_out + n), (long long)costmaps->n);
+  PXR_REQUIRE(costmaps->H == features->H && costmaps->W == features->W,
+              "pxr_costmap_extract: cost maps are %dx%d, feature patches %dx%d (upsampling_factor != 1 is not supported)",
+              costmaps->H, costmaps->W, features->H, features->W);
+  PXR_REQUIRE(costmaps->C == (as_gradientfield ? 3 : 1),
+              "pxr_costmap_extract: %d cost-map channels, CostMapConfig needs %d (compute_cross_derivative is not supported)",
+              costmaps->C, as_gradientfield ? 3 : 1);
+  if (features->C != 128 && features->C != 64)
+    return pxr::set_error(PXR_EUNSUPPORTED, "pxr_costmap_extract: CHANNELS=%d not supported (128, 64)", features->C);
+  if (features->W * (features->C / 8) > 256)
+    return pxr::set_error(PXR_EUNSUPPORTED, "pxr_costmap_extract: patches wider than %d texels are not supported "
+                          "(dense maps: slice dense_cut_size windows with pxr_arena_extract first)", 256 / (features->C / 8));
+  if (n == 0) return PXR_OK;
+  PXR_REQUIRE(d_patch && d_ref_index && d_refs, "pxr_costmap_extract: NULL argument");
+  PXR_HIP(hipSetDevice(ctx->device));
+  pxr::CostmapArgs a;
+  a.fin = features->d_data; a.cin = features->d_corners; a.sin = features->d_scales;
+  a.fout = costmaps->d_data; a.cout = costmaps->d_corners; a.sout = costmaps->d_scales;
+  a.H = features->H; a.W = features->W; a.CO = costmaps->C; a.apply_sqrt = apply_sqrt;
+  a.first_out = first_out; a.patch = d_patch; a.ref_index = d_ref_index; a.refs = d_refs; a.loss = *loss;
+  const bool grad = as_gradientfield != 0;
+  const int od = costmaps->dtype;
+  if (features->dtype == PXR_F16 && features->C == 128) return pxr::launch_costmap_o<_Float16, 128>(ctx, od, a, n, grad);
+  if (features->dtype == PXR_F16) return pxr::launch_costmap_o<_Float16, 64>(ctx, od, a, n, grad);
+  if (features->dtype == PXR_F32 && features->C == 128) return pxr::launch_costmap_o<float, 128>(ctx, od, a, n, grad);
+  if (features->dtype == PXR_F32) return pxr::launch_costmap_o<float, 64>(ctx, od, a, n, grad);
+  if (features->C == 128) return pxr::launch_costmap_o<double, 128>(ctx, od, a, n, grad);
+  return pxr::launch_costmap_o<double, 64>(ctx, od, a, n, grad);
+}

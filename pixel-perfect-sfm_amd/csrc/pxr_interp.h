@@ -158,6 +158,61 @@ __device__ __forceinline__ void interp8(const ST* __restrict__ patch, int H, int
   }
 }
 
+// ---- few-channel patches (cost maps: C = 1 or 3) ---------------------------------------------
+// With fewer than 8 channels the reference leaves its SIMD path (base/src/interpolation.h:222-227) and runs
+// [upstream] ceres::BiCubicInterpolator on doubles (:240-266): per row the Catmull-Rom spline
+//   a = .5(-p0 + 3p1 - 3p2 + p3), b = .5(2p0 - 5p1 + 4p2 - p3), c = .5(-p0 + p2), d = p1,
+//   f = d + x(c + x(b + x a)), f' = c + x(2b + 3a x)
+// horizontally, then vertically on the four row values (f, df/dr) and on the four row derivatives (df/dc).
+// One lane evaluates the whole texel; PixelInterpolator's L2 normalisation (:648-666) follows when asked for.
+__device__ __forceinline__ void spline_ceres(double p0, double p1, double p2, double p3, double x, double& f,
+                                             double& d) {
+  const double a = 0.5 * (-p0 + 3.0 * p1 - 3.0 * p2 + p3);
+  const double b = 0.5 * (2.0 * p0 - 5.0 * p1 + 4.0 * p2 - p3);
+  const double c = 0.5 * (-p0 + p2);
+  f = p1 + x * (c + x * (b + x * a));
+  d = c + x * (2.0 * b + 3.0 * a * x);
+}
+
+template <typename ST, int C>
+__device__ __forceinline__ void interp_small(const ST* __restrict__ patch, int H, int W, double u, double v,
+                                             bool l2_normalize, double f[C], double fr[C], double fc[C]) {
+  const double rf = floor(v), cf = floor(u);
+  const int row = (int)rf, col = (int)cf;
+  const double dy = v - rf, dx = u - cf;
+  int co[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) co[i] = clampi(col - 1 + i, 0, W - 1) * C;   // Grid2D clamping, grid2d.h:64-73
+  double h[4][C], hd[4][C];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const ST* rp = patch + (size_t)clampi(row - 1 + j, 0, H - 1) * W * C;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch)
+      spline_ceres((double)rp[co[0] + ch], (double)rp[co[1] + ch], (double)rp[co[2] + ch], (double)rp[co[3] + ch], dx,
+                   h[j][ch], hd[j][ch]);
+  }
+  double ss = 0.0;
+#pragma unroll
+  for (int ch = 0; ch < C; ++ch) {
+    double dummy;
+    spline_ceres(h[0][ch], h[1][ch], h[2][ch], h[3][ch], dy, f[ch], fr[ch]);
+    spline_ceres(hd[0][ch], hd[1][ch], hd[2][ch], hd[3][ch], dy, fc[ch], dummy);
+    ss += f[ch] * f[ch];
+  }
+  if (l2_normalize) {
+    const double ninv = 1.0 / sqrt(ss);
+    double dc = 0.0, dr = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+      f[ch] *= ninv; fc[ch] *= ninv; fr[ch] *= ninv;
+      dc += f[ch] * fc[ch]; dr += f[ch] * fr[ch];
+    }
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) { fc[ch] -= dc * f[ch]; fr[ch] -= dr * f[ch]; }
+  }
+}
+
 __device__ __forceinline__ double shfl_f64(double v, int src) {
   union { double d; int i[2]; } a;
   a.d = v;

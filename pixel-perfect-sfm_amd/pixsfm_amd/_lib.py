@@ -101,6 +101,8 @@ _SIGNATURES = {
                                C.c_void_p, C.c_void_p, C.POINTER(LMSummary)]),
     "pxr_ba_compute_references": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BaView), C.POINTER(InterpCfg),
                                             C.POINTER(Loss), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pxr_costmap_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.POINTER(Loss), C.c_int, C.c_int]),
     "pxr_interpolate": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(InterpCfg), C.c_int64, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "pxr_nearest_references": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(InterpCfg), C.c_int64, C.c_void_p, C.c_void_p,

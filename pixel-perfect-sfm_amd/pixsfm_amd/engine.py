@@ -274,7 +274,8 @@ class BAProblem:
     """Device-resident flat arrays of a bundle-adjustment problem (pxr_ba_view).
 
     problem: dict with obs_image, obs_point, obs_patch, image_camera, qvec, tvec,
-    cam_model, cam_params (n_cams x KPAD), xyz, refs (n_points x C).
+    cam_model, cam_params (n_cams x KPAD), xyz, refs (n_points x C; None: no reference is
+    subtracted -- the cost-map BA, costmap_bundle_optimizer.h:104-119).
     """
 
     def __init__(self, ctx, arena, problem):
@@ -297,7 +298,7 @@ class BAProblem:
             "cam_model": ctx.to_device(g["cam_model"], np.int32),
             "cam_params": ctx.to_device(cam_params, np.float64),
             "xyz": ctx.to_device(g["xyz"], np.float64),
-            "refs": ctx.to_device(g["refs"], np.float64),
+            "refs": ctx.to_device(g["refs"], np.float64) if g.get("refs") is not None else None,
         }
         self.rec = ctx.empty((self.n_obs, OBS_REC), np.float64)
         self.view = self._view()
@@ -307,7 +308,36 @@ class BAProblem:
         return BaView(self.n_obs, d["obs_image"].ptr, d["obs_point"].ptr, d["obs_patch"].ptr,
                       self.n_images, d["image_camera"].ptr, d["qvec"].ptr, d["tvec"].ptr,
                       self.n_cameras, d["cam_model"].ptr, d["cam_params"].ptr,
-                      self.n_points, d["xyz"].ptr, d["refs"].ptr)
+                      self.n_points, d["xyz"].ptr, d["refs"].ptr if d["refs"] is not None else None)
+
+    def extract_costmaps(self, loss, as_gradientfield=True, apply_sqrt=False, dtype=None):
+        """CostMapExtractor (bundle_adjustment/src/costmap_extractor.h:177-358) on the GPU: one cost map per
+        observation -- the featuremetric error of every texel of its feature patch against the reference of
+        its 3D point (this problem's `refs`, e.g. after compute_references()).  Returns a PatchArena of
+        n_obs maps, 3 channels [cost, dcost/dr, dcost/dc] (as_gradientfield) or 1, dtype = the features' unless
+        given; map i belongs to observation i."""
+        ctx, a = self.ctx, self.arena
+        if self.d["refs"] is None:
+            raise ValueError("cost maps need reference descriptors")
+        out = PatchArena(ctx, self.n_obs, a.H, a.W, 3 if as_gradientfield else 1, a.dtype if dtype is None else dtype)
+        check(ctx.lib.pxr_costmap_extract(ctx.handle, a.handle, out.handle, 0, self.n_obs, self.d["obs_patch"].ptr,
+                                          self.d["obs_point"].ptr, self.d["refs"].ptr, C.byref(loss),
+                                          int(bool(as_gradientfield)), int(bool(apply_sqrt))), "pxr_costmap_extract")
+        return out
+
+    def costmap_problem(self, costmaps):
+        """The cost-map BA problem over this problem's parameters (CostMapBundleOptimizer::AddResiduals,
+        costmap_bundle_optimizer.h:76-132): the SAME device qvec / tvec / cam_params / xyz arrays (refined in
+        place by either problem), observation i reads cost map i, no reference descriptor."""
+        p = object.__new__(BAProblem)
+        p.ctx, p.arena = self.ctx, costmaps
+        p.n_obs, p.n_images, p.n_cameras, p.n_points = self.n_obs, self.n_images, self.n_cameras, self.n_points
+        p.d = dict(self.d)
+        p.d["obs_patch"] = self.ctx.to_device(np.arange(self.n_obs, dtype=np.int64), np.int64)
+        p.d["refs"] = None
+        p.rec = self.ctx.empty((self.n_obs, OBS_REC), np.float64)
+        p.view = p._view()
+        return p
 
     def eval(self, cfg, with_jacobian=True, materialize=False):
         """Launch the fused residual kernel.  Returns device arrays (rec, r, gx, gy)."""

@@ -1,0 +1,185 @@
+"""GPU parity for the cost-map path: pxr_costmap_extract vs oracle/pxo_costmap.py,
+the 3- / 1-channel residual kernel and the cost-map BA (pxr_ba_solve with no reference) vs the oracle.
+
+Tolerances: the cost maps are STORED in the features' dtype, so the bar is the storage type's: identical
+bits except where the fp64 summation order (16-lane tree here, numpy's einsum there) moves a value across a
+rounding boundary -- at most 1 ulp, on a small fraction of the entries; fp64 maps within 1e-12.  Residuals /
+Jacobians within 1e-10 relative (north_star: 1e-5), refined parameters within 1e-6 (north_star: 1e-4).
+PARITY UNPINNED w.r.t. the real reference: it has no golden vectors for cost maps.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LOSSES = [("trivial", []), ("cauchy", [0.25])]
+
+
+def _setup(ctx, **kw):
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena
+    prob = synthetic.make_ba_problem(**kw)
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    return prob, arena, BAProblem(ctx, arena, prob)
+
+
+def _ulps(a, b):
+    """Distance in units of the storage type's last place (same-sign finite values)."""
+    it = {2: np.int16, 4: np.int32, 8: np.int64}[a.dtype.itemsize]
+    ia, ib = a.view(it).astype(np.int64), b.view(it).astype(np.int64)
+    sign = np.int64(1) << (8 * a.dtype.itemsize - 1)
+    ia = np.where(ia < 0, -(ia + sign), ia)      # sign-magnitude -> monotone integers
+    ib = np.where(ib < 0, -(ib + sign), ib)
+    return np.abs(ia - ib)
+
+
+def _check_maps(got, want):
+    assert got.dtype == want.dtype and got.shape == want.shape
+    if got.dtype == np.float64:
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+        return
+    d = _ulps(got, want)
+    assert d.max() <= 1, "more than one ulp apart"
+    assert (d > 0).mean() < 2e-3, "too many entries differ in the last place: %g" % (d > 0).mean()
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32, np.float64])
+@pytest.mark.parametrize("loss", LOSSES)
+def test_costmaps_match_oracle(ctx, dtype, loss):
+    import pxo_costmap
+    from pixsfm_amd.engine import make_loss
+    prob, arena, ba = _setup(ctx, n_cams=5, n_points=40, obs_per_point=3, seed=71, dtype=dtype)
+    cm = ba.extract_costmaps(make_loss(*loss))
+    got, corners, scales = cm.download()
+    want = pxo_costmap.costmaps(prob["patches"], prob["obs_patch"], prob["obs_point"], prob["refs"],
+                                loss=(loss[0], loss[1][0] if loss[1] else 1.0))
+    _check_maps(got, want)
+    # CreateShallowCostmapFSet: the cost patch sits where the feature patch sits
+    assert np.array_equal(corners, prob["corners"][prob["obs_patch"]])
+    assert np.array_equal(scales, prob["scales"][prob["obs_patch"]])
+
+
+@pytest.mark.parametrize("kw", [dict(apply_sqrt=True), dict(as_gradientfield=False), dict(as_gradientfield=False, apply_sqrt=True)])
+def test_costmap_config_variants(ctx, kw):
+    import pxo_costmap
+    from pixsfm_amd.engine import make_loss
+    prob, arena, ba = _setup(ctx, n_cams=4, n_points=30, obs_per_point=3, seed=72)
+    cm = ba.extract_costmaps(make_loss("cauchy", [0.25]), **kw)
+    want = pxo_costmap.costmaps(prob["patches"], prob["obs_patch"], prob["obs_point"], prob["refs"], loss=("cauchy", 0.25), **kw)
+    _check_maps(cm.download()[0], want)
+
+
+@pytest.mark.parametrize("channels,patch_size", [(64, 16), (128, 8), (128, 10)])
+def test_costmap_shapes(ctx, channels, patch_size):
+    """C = 64 (8 lanes per texel), the low-memory configuration's 8 x 8 patches (configs/low_memory.yaml:7), and a
+    width that does not fill whole wavefronts; fp32 cost maps of fp16 features."""
+    import pxo_costmap
+    from pixsfm_amd.engine import make_loss
+    prob, arena, ba = _setup(ctx, n_cams=4, n_points=25, obs_per_point=3, seed=73, channels=channels, patch_size=patch_size)
+    cm = ba.extract_costmaps(make_loss("trivial", []), dtype=np.float32)
+    want = pxo_costmap.costmaps(prob["patches"], prob["obs_patch"], prob["obs_point"], prob["refs"], out_dtype=np.float32)
+    _check_maps(cm.download()[0], want)
+
+
+def test_costmap_is_zero_at_the_reference_texel(ctx):
+    """Closed-form property: where a texel equals the reference descriptor the cost and both derivatives vanish, and the
+    cost channel is 0.5 |f - ref|^2 everywhere (trivial loss)."""
+    from pixsfm_amd.engine import BAProblem, PatchArena, make_loss
+    rng = np.random.default_rng(5)
+    patches = rng.normal(size=(3, 16, 16, 128))
+    patches /= np.linalg.norm(patches, axis=-1, keepdims=True)
+    patches = patches.astype(np.float16)
+    refs = np.stack([patches[0, 4, 7], patches[1, 15, 0], patches[2, 0, 15]]).astype(np.float64)
+    prob = dict(obs_image=np.zeros(3, np.int32), obs_point=np.arange(3, dtype=np.int32), obs_patch=np.arange(3, dtype=np.int64),
+                image_camera=np.zeros(1, np.int32), qvec=np.array([[1.0, 0, 0, 0]]), tvec=np.zeros((1, 3)),
+                cam_model=np.zeros(1, np.int32), cam_params=np.array([[100.0, 50, 50]]), xyz=np.array([[0, 0, 5.0]] * 3), refs=refs)
+    arena = PatchArena.from_numpy(ctx, patches, np.zeros((3, 2), np.int32))
+    cm = BAProblem(ctx, arena, prob).extract_costmaps(make_loss("trivial", []), dtype=np.float64).download()[0]
+    for i, (y, x) in enumerate([(4, 7), (15, 0), (0, 15)]):
+        assert np.all(cm[i, y, x] == 0.0)
+    want = 0.5 * ((patches.astype(np.float64) - refs[:, None, None, :]) ** 2).sum(-1)
+    assert np.abs(cm[..., 0] - want).max() < 1e-13
+
+
+def _costmap_problem(prob, maps):
+    """The flat problem the oracle sees for the cost-map BA: observation i reads map i, no references."""
+    p = dict(prob)
+    p["patches"], p["obs_patch"], p["refs"] = maps, np.arange(len(maps), dtype=np.int64), None
+    p["corners"], p["scales"] = prob["corners"][prob["obs_patch"]], prob["scales"][prob["obs_patch"]]
+    return p
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float64])
+@pytest.mark.parametrize("as_gradientfield", [True, False])
+def test_costmap_residual_blocks_match_oracle(ctx, dtype, as_gradientfield):
+    """FeatureReferenceCostFunctor<..., CHANNELS = 3 | 1> with ref_descriptor = nullptr (costmap_bundle_optimizer.h:104-119,
+    feature_reference.h:128-130): residuals = the bicubic texel of the cost map ([upstream] scalar Ceres path, C < 8)."""
+    import pxo
+    from pixsfm_amd.engine import interp_cfg, make_loss
+    prob, arena, ba = _setup(ctx, n_cams=5, n_points=50, obs_per_point=3, seed=74, dtype=dtype)
+    cm = ba.extract_costmaps(make_loss("trivial", []), as_gradientfield=as_gradientfield)
+    cba = ba.costmap_problem(cm)
+    rec, r, gx, gy = cba.eval(interp_cfg(l2_normalize=False), with_jacobian=True, materialize=True)
+    P = cba.projection_jacobian().download()
+    r, gx, gy, rec = r.download(), gx.download(), gy.download(), rec.download()
+    cost_o, r_o, J_o = pxo.ba_eval_batch(_costmap_problem(prob, cm.download()[0]), pxo.cfg(l2_normalize=False),
+                                         pxo.loss("cauchy", 0.25), want_r=True, want_J=True)
+    rel = lambda a, b: np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+    assert rel(r, r_o) < 1e-10
+    J = gx[:, :, None] * P[:, None, 0, :] + gy[:, :, None] * P[:, None, 1, :]
+    assert rel(J, J_o) < 1e-10
+    assert rel(rec[:, 0], (r_o ** 2).sum(1)) < 1e-10
+    assert rel(rec[:, 1], (gx * gx).sum(1)) < 1e-10 and rel(rec[:, 3], (gy * gy).sum(1)) < 1e-10
+    assert abs(cba.cost(make_loss("cauchy", [0.25])) - cost_o) < 1e-10 * abs(cost_o)
+
+
+def _gauge(prob):
+    """default_problem_setup (bundle_adjustment/main.py:12-18) with the BundleOptimizerOptions defaults (focal + extra refined)."""
+    n_img, n_cam, n_pt = len(prob["image_camera"]), len(prob["cam_model"]), len(prob["xyz"])
+    pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
+    tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
+    cmask = np.full(n_cam, (1 << 1) | (1 << 2), np.uint16)    # SIMPLE_RADIAL: principal point constant
+    return pose_const, tmask, cmask, np.zeros(n_pt, np.uint8)
+
+
+@pytest.mark.parametrize("inner", [False, True])
+def test_costmap_bundle_adjustment_matches_oracle(ctx, inner):
+    """CostMapBundleAdjuster.refine (bundle_adjustment/main.py:243-286): references -> cost maps -> BA on the maps with
+    l2_normalize = False; same LM loop as the feature-reference BA, trajectories must coincide with the oracle's."""
+    import pxo
+    from pixsfm_amd.engine import interp_cfg, lm_options, make_loss
+    prob, arena, ba = _setup(ctx, n_cams=6, n_points=80, obs_per_point=4, seed=75)
+    cm = ba.extract_costmaps(make_loss("trivial", []))
+    cba = ba.costmap_problem(cm)
+    gauge = _gauge(prob)
+    kw = dict(max_iterations=5, use_inner_iterations=inner)    # still descending: the accept/reject decisions must coincide
+    s_gpu = cba.solve(interp_cfg(l2_normalize=False), make_loss("cauchy", [0.25]), *gauge, options=lm_options(**kw))
+    q, t, k, X = cba.params()
+    s_cpu, qo, to, ko, Xo = pxo.ba_solve(_costmap_problem(prob, cm.download()[0]), pxo.cfg(l2_normalize=False),
+                                         pxo.loss("cauchy", 0.25), *gauge, pxo.lm_options(**kw))
+    assert s_gpu["iterations"] == s_cpu["iterations"] and s_gpu["num_successful"] == s_cpu["num_successful"]
+    assert abs(s_gpu["initial_cost"] - s_cpu["initial_cost"]) < 1e-10 * s_cpu["initial_cost"]
+    assert abs(s_gpu["final_cost"] - s_cpu["final_cost"]) < 1e-6 * s_cpu["final_cost"]
+    assert s_gpu["final_cost"] < s_gpu["initial_cost"]
+    for a, b in zip((q, t, k, X), (qo, to, ko, Xo)):
+        b = np.asarray(b)
+        a = a[:, :b.shape[1]] if a.ndim == 2 else a
+        assert np.abs(a - b).max() < 1e-6 * max(1.0, np.abs(b).max())
+    # the cost-map problem refined the SAME device parameters the feature problem holds
+    assert np.array_equal(ba.params()[3], X)
+
+
+def test_costmap_argument_errors(ctx):
+    from pixsfm_amd._lib import PixsfmHipError
+    from pixsfm_amd.engine import BAProblem, PatchArena, make_loss
+    prob, arena, ba = _setup(ctx, n_cams=3, n_points=10, obs_per_point=2, seed=76)
+    noref = BAProblem(ctx, arena, dict(prob, refs=None))
+    with pytest.raises(ValueError):
+        noref.extract_costmaps(make_loss("trivial", []))
+    import ctypes as C
+    wrong = PatchArena(ctx, ba.n_obs, 16, 16, 4)        # compute_cross_derivative layout: not supported
+    with pytest.raises(PixsfmHipError):
+        from pixsfm_amd._lib import check
+        check(ctx.lib.pxr_costmap_extract(ctx.handle, arena.handle, wrong.handle, 0, ba.n_obs, ba.d["obs_patch"].ptr,
+                                          ba.d["obs_point"].ptr, ba.d["refs"].ptr, C.byref(make_loss("trivial", [])), 1, 0),
+              "pxr_costmap_extract")

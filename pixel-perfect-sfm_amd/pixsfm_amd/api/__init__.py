@@ -1,7 +1,8 @@
 """pixsfm-compatible Python surface of the accelerated KA/BA path (same class / method names as
 pixsfm.keypoint_adjustment, pixsfm.bundle_adjustment, pixsfm._pixsfm._base/_features)."""
 from . import base, features, localization, reconstruction  # noqa: F401
-from .bundle_adjustment import (BundleAdjuster, BundleAdjustmentSetup, FeatureReferenceBundleAdjuster,  # noqa: F401
+from .bundle_adjustment import (BundleAdjuster, BundleAdjustmentSetup, CostMapBundleAdjuster,  # noqa: F401
+                                CostMapBundleOptimizer, CostMapExtractor, FeatureReferenceBundleAdjuster,
                                 FeatureReferenceBundleOptimizer, FeatureView, ReferenceExtractor,
                                 default_problem_setup)
 from .keypoint_adjustment import (FeatureMetricKeypointAdjuster, FeatureMetricKeypointOptimizer,  # noqa: F401

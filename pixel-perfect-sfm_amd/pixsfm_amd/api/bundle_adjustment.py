@@ -253,6 +253,12 @@ class ReferenceExtractor:
             return {}
         arena = features.to_arena(ctx, flat.patches)
         ba = BAProblem(ctx, arena, flat.problem_dict(np.zeros((len(flat.point_ids), arena.C)), arena.index))
+        out = self._references_of(ba, flat)
+        arena.close()
+        return out
+
+    def _references_of(self, ba, flat):
+        """References of the flat problem `ba` (its device `refs` are filled in place) as {point3D_id: Reference}."""
         keep = bool(self.config['keep_observations'])
         chosen, _ = ba.compute_references(self.interpolation.to_engine(),
                                           make_loss(self.config['loss']['name'], self.config['loss']['params']),
@@ -269,8 +275,57 @@ class ReferenceExtractor:
                 image_id, p2d_idx = flat.obs_keys[int(chosen[k])]
                 out[pid] = features.Reference(image_id, p2d_idx, refs[k],
                                               observations=[obs_desc[i] for i in obs_of_point[k]] if keep else None)
-        arena.close()
         return out
+
+
+class CostMapExtractor:
+    """_bundle_adjustment.CostMapExtractor(costmap_conf, interp_conf).run(problem_labels, reconstruction, feature_set,
+    ref_extractor) -> (cost-map FeatureSet, {point3D_id: Reference}) (bindings.cc:20-26,179-184;
+    costmap_extractor.h:118-174): references by IRLS, then per observation the map of the featuremetric error of every
+    texel of its patch against the reference of its 3D point.  Here both steps run on the device on ONE flat problem
+    and the maps stay there: the returned FeatureSet holds features.ArenaPatch entries of a device arena
+    (`.arena` of the set; 3 channels [cost, dcost/dr, dcost/dc] or 1), which CostMapBundleOptimizer consumes in place."""
+    default_conf = {'loss': {'name': 'trivial', 'params': []}, 'as_gradientfield': True, 'compute_cross_derivative': False,
+                    'upsampling_factor': 1.0, 'apply_sqrt': False, 'dense_cut_size': 12, 'num_threads': -1}
+
+    def __init__(self, config=None, interpolation_config=None, ctx=None):
+        self.config = base.merge_conf(self.default_conf, config)
+        ic = interpolation_config
+        self.interpolation = ic if isinstance(ic, base.InterpolationConfig) else base.InterpolationConfig(ic)
+        self.ctx = ctx
+        if self.config['compute_cross_derivative'] or float(self.config['upsampling_factor']) != 1.0:
+            raise ValueError("compute_cross_derivative / upsampling_factor != 1 are outside the accelerated path "
+                             "(the configuration of pixsfm's CostMapBundleAdjuster, main.py:227-238, is supported)")
+
+    def get_effective_channels(self):                                            # costmap_extractor.h:52-61
+        return 3 if self.config['as_gradientfield'] else 1
+
+    def run(self, problem_labels, reconstruction, feature_set, ref_extractor):
+        if ref_extractor is None:
+            raise ValueError("a ReferenceExtractor is required")                 # Run dereferences it, costmap_extractor.h:141
+        ctx = self.ctx or default_context()
+        if any(not fm.is_sparse for fm in feature_set.fmaps.values()):
+            raise ValueError("cost maps of dense feature maps (dense_cut_size windows) are outside the accelerated path")
+        wanted = {p for p in reconstruction.point3D_ids() if p < len(problem_labels) and problem_labels[p] >= 0}
+        setup = BundleAdjustmentSetup()
+        setup.add_images(reconstruction.reg_image_ids())
+        flat = _FlatBA(reconstruction, setup, FeatureView(feature_set, reconstruction), point_filter=wanted)
+        cost_fset = features.FeatureSet(channels=self.get_effective_channels())
+        if len(flat.obs_image) == 0:
+            return cost_fset, {}
+        arena = features.to_arena(ctx, flat.patches)
+        ba = BAProblem(ctx, arena, flat.problem_dict(np.zeros((len(flat.point_ids), arena.C)), arena.index))
+        references = ref_extractor._references_of(ba, flat)
+        costmaps = ba.extract_costmaps(make_loss(self.config['loss']['name'], self.config['loss']['params']),
+                                       as_gradientfield=self.config['as_gradientfield'], apply_sqrt=self.config['apply_sqrt'])
+        arena.close()
+        cost_fset.arena = costmaps
+        for i, (image_id, p2d_idx) in enumerate(flat.obs_keys):                 # CreateShallowCostmapFSet, :360-435
+            name = reconstruction.images[image_id].name
+            if not cost_fset.has_fmap(name):
+                cost_fset.fmaps[name] = features.FeatureMap()
+            cost_fset.fmaps[name].patches[int(p2d_idx)] = features.ArenaPatch(costmaps, i)
+        return cost_fset, references
 
 
 class FeatureReferenceBundleOptimizer:
@@ -313,9 +368,11 @@ class FeatureReferenceBundleOptimizer:
         if len(flat.obs_image) == 0:
             return
         C = flat.patches[0].shape[2]
-        refs = np.zeros((len(flat.point_ids), C))
-        for k, pid in enumerate(flat.point_ids):
-            refs[k] = references[pid].descriptor.reshape(-1)                     # references.at(point3D_id)
+        refs = None                                                              # cost maps: "just minimize"
+        if references is not None:
+            refs = np.zeros((len(flat.point_ids), C))
+            for k, pid in enumerate(flat.point_ids):
+                refs[k] = references[pid].descriptor.reshape(-1)                 # references.at(point3D_id)
         self._arena = features.to_arena(ctx, flat.patches)
         self._ba = BAProblem(ctx, self._arena, flat.problem_dict(refs, self._arena.index))
 
@@ -373,6 +430,26 @@ class FeatureReferenceBundleOptimizer:
         return self._summary
 
 
+class CostMapBundleOptimizer(FeatureReferenceBundleOptimizer):
+    """_bundle_adjustment.CostMapBundleOptimizer(options, setup, interp_conf).run(reconstruction, costmap_view)
+    (bindings.cc:143-146; costmap_bundle_optimizer.h:17-132): the same residual functor on 1- or 3-channel cost maps,
+    no reference descriptor -- the residual block is the interpolated texel of the map."""
+
+    def set_up(self, reconstruction, loss_function, feature_view):
+        channels = (feature_view.feature_set if isinstance(feature_view, FeatureView) else feature_view).channels
+        if channels not in (1, 3):
+            raise ValueError("Unsupported dimensions (CHANNELS).")               # costmap_bundle_optimizer.h:9-14
+        super().set_up(reconstruction, loss_function, feature_view, None)
+
+    def run(self, reconstruction, feature_view):
+        self.set_up(reconstruction, None, feature_view)
+        ok = self.solve_problem(reconstruction)
+        if self._arena is not None:
+            self._arena.close()                                                  # a no-op for device-resident cost maps
+            self._arena = None
+        return ok
+
+
 class BundleAdjuster:
     """pixsfm/bundle_adjustment/main.py:30-102."""
     default_conf = {
@@ -395,9 +472,10 @@ class BundleAdjuster:
     @classmethod
     def create(cls, conf):
         strategy = conf.get("strategy", cls.default_conf["strategy"])
-        if strategy != "feature_reference":
-            raise ValueError("strategy %r is outside the accelerated path (feature_reference only)" % strategy)
-        return FeatureReferenceBundleAdjuster(conf)
+        strategies = {"feature_reference": FeatureReferenceBundleAdjuster, "costmaps": CostMapBundleAdjuster}   # main.py:67-73
+        if strategy not in strategies:
+            raise ValueError("strategy %r is outside the accelerated path (feature_reference, costmaps)" % strategy)
+        return strategies[strategy](conf)
 
     def refine(self, reconstruction, feature_set, problem_setup=None):
         raise NotImplementedError()
@@ -431,3 +509,32 @@ class FeatureReferenceBundleAdjuster(BundleAdjuster):
                                                  self.conf['interpolation'])
         solver.run(reconstruction, feature_view, references)
         return {"references": references, "summary": solver.summary()}
+
+
+class CostMapBundleAdjuster(BundleAdjuster):
+    """main.py:218-286: the reference's low-memory strategy ("costmaps").  References by IRLS, one cost map per
+    observation (the feature patches are not needed afterwards: 1.5 KB instead of 64 KB per observation at 16 x 16 fp16),
+    then BA on the maps with l2_normalize = False (main.py:269-270)."""
+    default_conf = {
+        **deepcopy(BundleAdjuster.default_conf),
+        'costmaps': {'loss': {'name': 'trivial', 'params': []}, 'as_gradientfield': True,
+                     'compute_cross_derivative': False, 'num_threads': -1},
+        'strategy': 'costmaps',
+    }
+
+    def __init__(self, conf):
+        self.conf = base.merge_conf(self.default_conf, conf)
+
+    def refine(self, reconstruction, feature_set, problem_setup=None):
+        if problem_setup is None:
+            problem_setup = default_problem_setup(reconstruction)
+        problem_labels = find_problem_labels(reconstruction, self.conf['max_tracks_per_problem'])
+        interp_conf = deepcopy(self.conf['interpolation'])
+        ref_extractor = ReferenceExtractor(deepcopy(self.conf['references']), interp_conf)
+        ce = CostMapExtractor(deepcopy(self.conf['costmaps']), interp_conf)
+        costmap_fset, references = ce.run(problem_labels, reconstruction, feature_set, ref_extractor)
+        interp_conf = dict(interp_conf, l2_normalize=False)        # "Make sure l2_normalize is set to false before optim!"
+        costmap_view = FeatureView(costmap_fset, reconstruction)
+        solver = CostMapBundleOptimizer(deepcopy(self.conf['optimizer']), problem_setup, interp_conf)
+        solver.run(reconstruction, costmap_view)
+        return {"costmaps": costmap_fset, "references": references, "summary": solver.summary()}

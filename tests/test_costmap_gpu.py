@@ -183,3 +183,50 @@ def test_costmap_argument_errors(ctx):
         check(ctx.lib.pxr_costmap_extract(ctx.handle, arena.handle, wrong.handle, 0, ba.n_obs, ba.d["obs_patch"].ptr,
                                           ba.d["obs_point"].ptr, ba.d["refs"].ptr, C.byref(make_loss("trivial", [])), 1, 0),
               "pxr_costmap_extract")
+
+
+def test_costmap_bundle_adjuster_like_pixsfm(ctx):
+    """BundleAdjuster.create({"strategy": "costmaps"}) the way pixsfm's low_memory configuration drives it
+    (configs/low_memory.yaml:28-47, bundle_adjustment/main.py:218-286) against the same steps on the low-level engine."""
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.api import BundleAdjuster, CostMapBundleAdjuster, CostMapBundleOptimizer, features
+    from pixsfm_amd.api.reconstruction import reconstruction_from_flat
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    prob = synthetic.make_ba_problem(n_cams=6, n_points=70, obs_per_point=4, seed=19, noise=0.02)
+    rec, patch_of = reconstruction_from_flat(prob)
+    fmaps = {}
+    for (image_id, p2d), pi in patch_of.items():
+        fm = fmaps.setdefault(rec.images[image_id].name, features.FeatureMap())
+        fm.patches[p2d] = features.FeaturePatch(prob["patches"][pi], prob["corners"][pi], prob["scales"][pi])
+    fmanager = features.FeatureManager([features.FeatureSet(fmaps)])
+    adjuster = BundleAdjuster.create({"strategy": "costmaps", "optimizer": {"solver": {"max_num_iterations": 6}}})
+    assert isinstance(adjuster, CostMapBundleAdjuster)
+    out = adjuster.refine_multilevel(rec, fmanager)
+    summary, references, cost_fset = out["summary"][0], out["references"][0], out["costmaps"][0]
+    assert len(references) == 70 and summary.final_cost < 0.1 * summary.initial_cost
+    assert cost_fset.channels == 3 and cost_fset.arena.n == len(prob["obs_image"]) and cost_fset.arena.dtype == np.float16
+    assert summary.num_residuals_reduced == 3 * len(prob["obs_image"])
+    # the cost map of an observation sits where its feature patch sits
+    (image_id, p2d), pi = next(iter(patch_of.items()))
+    cp = cost_fset.fmap(rec.images[image_id].name).fpatch(p2d)
+    _, corner, scale = cost_fset.arena.download(cp.index, 1)
+    assert np.array_equal(corner[0], prob["corners"][pi]) and np.array_equal(scale[0], prob["scales"][pi])
+    # the same steps on the low-level engine
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    ba.compute_references(interp_cfg(), make_loss("cauchy", [0.25]), iters=100)
+    cba = ba.costmap_problem(ba.extract_costmaps(make_loss("trivial", [])))
+    n_img = 6
+    pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
+    tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
+    s = cba.solve(interp_cfg(l2_normalize=False), make_loss("cauchy", [0.25]), pose_const, tmask, np.full(n_img, 0b0110, np.uint16),
+                  np.zeros(70, np.uint8), options=lm_options(max_iterations=6, use_inner_iterations=True))
+    q, t, k, X = cba.params()
+    assert abs(s["initial_cost"] - summary.initial_cost) < 1e-9 * s["initial_cost"]
+    assert abs(s["final_cost"] - summary.final_cost) < 1e-4 * max(s["final_cost"], 1e-12)
+    assert np.abs(np.array([rec.images[i + 1].qvec for i in range(n_img)]) - q).max() < 1e-4
+    assert np.abs(np.array([rec.points3D[p + 1].xyz for p in range(70)]) - X).max() < 1e-4
+    # only 1- and 3-channel maps are cost maps (costmap_bundle_optimizer.h:9-14)
+    from pixsfm_amd.api import default_problem_setup
+    with pytest.raises(ValueError, match="Unsupported dimensions"):
+        CostMapBundleOptimizer({}, default_problem_setup(rec), {"l2_normalize": False}).run(rec, fmanager.fset(0))

@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32768)
     ap.add_argument("--lm-iters", type=int, default=10, help="LM iterations for the iters/s figure (0 = skip)")
     ap.add_argument("--no-ka", action="store_true", help="skip the keypoint-adjustment half of the metric (BASELINE configs[1])")
+    ap.add_argument("--no-costmap", action="store_true", help="skip the cost-map extraction / cost-map BA figures")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: every rank owns --points points (N x the observations, cameras shared); "
                          "strong: --points points in total, sharded over the ranks")
@@ -179,6 +180,53 @@ def main():
                                allreduce=make_allreduce() if dist_on else None)
             barrier()
 
+    # ---- the reference's low-memory strategy on the same scene: cost-map extraction (one
+    # HBM-bound pass over the feature arena) and the cost-map BA (3-channel maps, no reference descriptor)
+    costmap = None
+    if not args.no_costmap and world == 1:
+        from pixsfm_amd.engine import lm_options
+        for name in ("qvec", "tvec", "xyz"):
+            ba.d[name].upload(prob[name])
+        host = np.zeros((len(prob["cam_model"]), 12)); host[:, :prob["cam_params"].shape[1]] = prob["cam_params"]
+        ba.d["cam_params"].upload(host)
+        trivial = make_loss("trivial", [])
+        cm = ba.extract_costmaps(trivial)                 # warm-up + the maps used below
+        ctx.sync()
+        reps = 5
+        ctx.timer_start()
+        for _ in range(reps):
+            ba.extract_costmaps(trivial, out=cm)
+        ex_ms = ctx.timer_stop() / reps
+        ex_bytes = PS * PS * C * 2 + C * 8 + 3 * PS * PS * 2          # feature patch + reference in, 3-channel fp16 map out
+        cba = ba.costmap_problem(cm)
+        cfg_cm = interp_cfg(l2_normalize=False)                       # bundle_adjustment/main.py:270
+        for _ in range(3):
+            cba.eval(cfg_cm, with_jacobian=True)
+        ctx.timer_start()
+        for _ in range(20):
+            cba.eval(cfg_cm, with_jacobian=True)
+        ev_ms = ctx.timer_stop() / 20
+        costmap = {"extract_ms": ex_ms, "maps_per_sec": n_obs_local / (ex_ms * 1e-3),
+                   "extract_GBps": ex_bytes * n_obs_local / (ex_ms * 1e-3) / 1e9,
+                   "extract_frac_of_peak": ex_bytes * n_obs_local / (ex_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "extract_bytes_per_map": ex_bytes, "kernel": "costmap_kernel<f16,f16,128,grad>",
+                   "map_arena_GB": n_obs_local * PS * PS * 3 * 2 / 1e9,
+                   "eval_ms": ev_ms, "eval_blocks_per_sec": n_obs_local / (ev_ms * 1e-3)}
+        if args.lm_iters > 0:
+            n_img = args.cams
+            pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
+            tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
+            for key, inner in (("lm", True), ("lm_no_inner", False)):
+                for name in ("qvec", "tvec", "xyz"):
+                    ba.d[name].upload(prob[name])
+                ba.d["cam_params"].upload(host)
+                s = cba.solve(cfg_cm, make_loss("cauchy", [0.25]), pose_const, tmask, np.full(n_img, 0b0110, np.uint16),
+                              np.zeros(len(prob["xyz"]), np.uint8),
+                              options=lm_options(max_iterations=args.lm_iters, use_inner_iterations=inner))
+                costmap[key] = {"iters_per_sec": s["iterations"] / (s["total_ms"] * 1e-3), "iterations": s["iterations"],
+                                "successful": s["num_successful"], "ms_per_iter": s["total_ms"] / max(1, s["iterations"]),
+                                "initial_cost": s["initial_cost"], "final_cost": s["final_cost"], "inner_iterations": inner}
+
     if rank == 0:
         bpo = algorithmic_bytes_per_obs(C)
         # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of
@@ -230,6 +278,8 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_ka
             out["ka"] = bench_ka.run(device_index=local_rank)
+        if costmap is not None:
+            out["costmap"] = costmap
         print(json.dumps(out))
     if dist_on:
         dist.destroy_process_group()

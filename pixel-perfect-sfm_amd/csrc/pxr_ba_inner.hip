@@ -34,25 +34,30 @@ struct InnerArgs {
   double* cost_before;         // += sum of 0.5 rho at the unrefined candidate
 };
 
-// sum over the wavefront's rows (LPO lanes each); every lane of a row holds the row's value
+// sum over the rows (LPO lanes each) of a point's lanes; every lane of a row holds the row's value
 template <int LPO>
 __device__ __forceinline__ double rows_sum(double v) {
-  if (LPO == 1) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); }
-  if (LPO <= 8) v += __shfl_xor(v, 8);
+  if (LPO == 1) return row8_sum(v);   // cost maps: 8 lanes per point, one observation per lane
+  if (LPO == 8) v += __shfl_xor(v, 8);
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
   return v;
 }
 
-constexpr int INNER_MAXO = 16;   // observations per point staged in LDS
+// points per wavefront / observations per point staged in LDS
+template <int C> struct InnerShape { static constexpr int PPW = C >= 64 ? 1 : 8, MAXO = C >= 64 ? 16 : 8; };
 
 template <typename ST, int C, bool FS>   // FS: InterpolationConfig.use_float_simd
-__device__ __forceinline__ void inner_points_body(const InnerArgs& a, double (*sh_obs)[INNER_MAXO][26]) {
+__device__ __forceinline__ void inner_points_body(const InnerArgs& a, double (*sh_obs)[InnerShape<C>::MAXO][26]) {
   static_assert(C == 128 || C == 64 || C <= 4, "one observation per row of C / 8 lanes, or per lane (cost maps)");
-  // cost maps (C = 1, 3; costmap_bundle_optimizer.h:9-14): the whole texel in one lane, 64 observations per pass
-  constexpr int LPO = C >= 64 ? C / 8 : 1, ROWS = 64 / LPO, CH = C >= 64 ? 8 : C;
-  const int lane = threadIdx.x & 63, row = lane / LPO, sub = lane % LPO;
-  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // features: one point per wavefront, an observation per row of C / 8 lanes.  Cost maps (C = 1, 3;
+  // costmap_bundle_optimizer.h:9-14): the whole texel in one lane, so a point takes 8 lanes (one DPP half-row: tracks
+  // of up to 8 observations in one pass) and a wavefront runs 8 points, each group its own nested LM
+  constexpr int PPW = InnerShape<C>::PPW, INNER_MAXO = InnerShape<C>::MAXO, GL = 64 / PPW;
+  constexpr int LPO = C >= 64 ? C / 8 : 1, ROWS = GL / LPO, CH = C >= 64 ? 8 : C;
+  const int lane = (threadIdx.x & 63) % GL, row = lane / LPO, sub = lane % LPO;
+  const int slot = (threadIdx.x >> 6) * PPW + (threadIdx.x & 63) / GL;   // this point's staging slot in LDS
+  const int64_t p = (int64_t)blockIdx.x * 4 * PPW + slot;
   if (p >= a.v.n_points) return;
   const int64_t o0 = a.pt_ptr[p];
   const int n = (int)(a.pt_ptr[p + 1] - o0);
@@ -69,7 +74,7 @@ __device__ __forceinline__ void inner_points_body(const InnerArgs& a, double (*s
   // stage the observations' camera / patch data (lane 0 of each row, one observation each)
   for (int oi = row; oi < n && oi < INNER_MAXO; oi += ROWS) {
     if (sub == 0) {
-      double* ob = sh_obs[threadIdx.x >> 6][oi];
+      double* ob = sh_obs[slot][oi];
       const int64_t i = a.pt_obs[o0 + oi];
       const int img = a.v.d_obs_image[i], cam = a.v.d_image_camera[img];
       const int64_t pi = a.v.d_obs_patch[i];
@@ -102,7 +107,7 @@ __device__ __forceinline__ void inner_points_body(const InnerArgs& a, double (*s
       int model;
       int64_t pi;
       if (oc < INNER_MAXO) {
-        const double* ob = sh_obs[threadIdx.x >> 6][oc];
+        const double* ob = sh_obs[slot][oc];
 #pragma unroll
         for (int j = 0; j < 4; ++j) q[j] = ob[j];
 #pragma unroll
@@ -267,12 +272,12 @@ __device__ __forceinline__ void inner_points_body(const InnerArgs& a, double (*s
 // compiler's budget (capped they would spill several hundred registers).
 template <typename ST, int C, bool FS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_inner_points_occ2(const InnerArgs a) {
-  __shared__ double sh_obs[4][INNER_MAXO][26];   // per wavefront: q(4) t(3) k(12) sx sy corner(2) model patch
+  __shared__ double sh_obs[4 * InnerShape<C>::PPW][InnerShape<C>::MAXO][26];   // per point: q(4) t(3) k(12) sx sy corner(2) model patch
   inner_points_body<ST, C, FS>(a, sh_obs);
 }
 template <typename ST, int C, bool FS>
 __global__ __launch_bounds__(256) void k_inner_points(const InnerArgs a) {
-  __shared__ double sh_obs[4][INNER_MAXO][26];
+  __shared__ double sh_obs[4 * InnerShape<C>::PPW][InnerShape<C>::MAXO][26];
   inner_points_body<ST, C, FS>(a, sh_obs);
 }
 
@@ -289,7 +294,8 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   a.H = arena->H; a.W = arena->W; a.l2_normalize = cfg->l2_normalize; a.check_bounds = cfg->check_bounds; a.loss = *loss;
   a.pt_ptr = d_pt_ptr; a.pt_obs = d_pt_obs; a.pt_var = d_pt_var;
   a.xyz_out = const_cast<double*>(view->d_xyz); a.cost_before = d_cost_before;
-  const unsigned blocks = (unsigned)((view->n_points + 3) / 4);
+  const int ppb = arena->C >= 64 ? 4 : 32;   // points per workgroup (InnerShape)
+  const unsigned blocks = (unsigned)((view->n_points + ppb - 1) / ppb);
   if (blocks == 0) return PXR_OK;
 #define INNER_LAUNCH(KERNEL, ST, CC)                                                                          \
   do {                                                                                                        \

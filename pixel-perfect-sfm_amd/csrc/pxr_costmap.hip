@@ -144,8 +144,181 @@ __global__ __launch_bounds__(256) void costmap_kernel(const CostmapArgs a) {
   }
 }
 
+// ---- the hot configuration: fp16 features, C = 128, square patches of 16 (default) or 8 (low_memory.yaml) ------
+// The generic kernel above is ALU-bound (fp64 channel math + a 16-lane all-reduce and a one-lane epilogue per
+// texel: 0.34 of the HBM peak).  This one
+//   * is persistent (two workgroups per CU) and prefetches the NEXT patch's column into registers while the
+//     current one is processed: 64 KB per workgroup in flight during the arithmetic;
+//   * keeps its whole texel column in registers (vertical neighbours are free) and exchanges the horizontal
+//     neighbours through one LDS copy of the patch (16-byte conflict-free reads);
+//   * replaces the 3 x PS all-reduces by a reduce-scatter over the DPP row (15 combine steps per 16 row sums
+//     instead of 64): lane s of a column ends up with the three sums of ROW s, so the loss, the
+//     `cost > 1e-8` branch, the sqrt and the stores run once per column with all 16 lanes busy.
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_masked(double old, double src) {   // lanes outside BANK keep `old`
+  union { double d; int i[2]; } o, s, r;
+  o.d = old; s.d = src;
+  r.i[0] = __builtin_amdgcn_update_dpp(o.i[0], s.i[0], CTRL, 0xf, BANK, false);
+  r.i[1] = __builtin_amdgcn_update_dpp(o.i[1], s.i[1], CTRL, 0xf, BANK, false);
+  return r.d;
+}
+
+// One reduce-scatter step at lane distance D: A belongs to the rows whose index has bit D clear, B to those with
+// it set.  Lanes with bit D clear keep A and add the partner's A; the others keep B and add the partner's B.
+template <int D>
+__device__ __forceinline__ double rs_combine(double A, double B, int sub) {
+  if constexpr (D == 8) {          // banks 0,1 <-> banks 2,3, partner = row_ror:8
+    const double mine = dpp_masked<0xE4, 0xC>(A, B);
+    const double recv = dpp_masked<0x128, 0x3>(dpp_masked<0x128, 0xC>(0.0, B), A);
+    return mine + recv;
+  } else if constexpr (D == 4) {   // banks 0,2 read lane + 4 (row_shl:4), banks 1,3 read lane - 4 (row_shr:4)
+    const double mine = dpp_masked<0xE4, 0xA>(A, B);
+    const double recv = dpp_masked<0x104, 0x5>(dpp_masked<0x114, 0xA>(0.0, B), A);
+    return mine + recv;
+  } else {                         // inside a quad: quad_perm + select
+    const bool hi = (sub & D) != 0;
+    const double mine = hi ? B : A, send = hi ? A : B;
+    return mine + dpp_f64<D == 2 ? 0x4E : 0xB1>(send);
+  }
+}
+
+struct Sums3 { double s, br, bc; };
+
+template <typename OT, int PS, bool GRAD>
+struct CostmapColumn {
+  const uint4* col;      // this lane's column: PS texels x 8 channels
+  const uint4* sh;       // LDS copy of the patch, [y][x][sub]
+  const double* ref;     // 8 channels of the reference
+  int xl, xr, sub;
+
+  template <int Y>
+  __device__ __forceinline__ Sums3 row() const {
+    Texel8<_Float16> cur, up, down;
+    cur.raw = col[Y]; up.raw = col[Y > 0 ? Y - 1 : 0]; down.raw = col[Y < PS - 1 ? Y + 1 : PS - 1];
+    double f[8], res[8];
+    widen8<_Float16>(cur, f);
+    Sums3 o = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) { res[ch] = f[ch] - ref[ch]; o.s = fma(res[ch], res[ch], o.s); }
+    if (GRAD) {
+      Texel8<_Float16> L, R;
+      L.raw = sh[(Y * PS + xl) * 16 + sub]; R.raw = sh[(Y * PS + xr) * 16 + sub];
+      double dr[8], dc[8];
+      StorageDiff<_Float16>::run(down, up, dr);
+      StorageDiff<_Float16>::run(R, L, dc);
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) { o.br = fma(res[ch], dr[ch], o.br); o.bc = fma(res[ch], dc[ch], o.bc); }
+    }
+    return o;
+  }
+  // reduce-scattered sums of the rows {J, J + STRIDE, J + 2 STRIDE, ...}: depth-first, so only ~log(PS) partial
+  // results are alive at a time
+  template <int J, int STRIDE>
+  __device__ __forceinline__ Sums3 node() const {
+    if constexpr (STRIDE >= PS) {
+      Sums3 v = row<J>();
+      if constexpr (PS == 8) {    // 8 rows on 16 lanes: both halves of the DPP row hold the row sums
+        v.s += dpp_f64<0x128>(v.s);
+        if (GRAD) { v.br += dpp_f64<0x128>(v.br); v.bc += dpp_f64<0x128>(v.bc); }
+      }
+      return v;
+    } else {
+      const Sums3 a = node<J, 2 * STRIDE>(), b = node<J + STRIDE, 2 * STRIDE>();
+      Sums3 o;
+      o.s = rs_combine<STRIDE>(a.s, b.s, sub);
+      o.br = GRAD ? rs_combine<STRIDE>(a.br, b.br, sub) : 0.0;
+      o.bc = GRAD ? rs_combine<STRIDE>(a.bc, b.bc, sub) : 0.0;
+      return o;
+    }
+  }
+};
+
+template <typename OT, int PS, bool GRAD>
+__global__ __launch_bounds__(PS * 16) __attribute__((amdgpu_waves_per_eu(2, 2))) void costmap_kernel_f16(const CostmapArgs a, const int64_t n) {
+  constexpr int C = 128;
+  __shared__ uint4 sh[GRAD ? PS * PS * 16 : 1];
+  const int x = threadIdx.x >> 4, sub = threadIdx.x & 15;
+  const _Float16* fin = reinterpret_cast<const _Float16*>(a.fin);
+  uint4 col[PS], nxt[PS];
+  double ref[8], refn[8];
+  int64_t pi = 0, pin = 0;
+  auto fetch = [&](int64_t i, uint4* c, double* r, int64_t& p) {
+    p = a.patch[i];
+    const _Float16* P = fin + (size_t)p * PS * PS * C + (size_t)x * C + sub * 8;
+#pragma unroll
+    for (int y = 0; y < PS; ++y) c[y] = *reinterpret_cast<const uint4*>(P + (size_t)y * PS * C);
+    const double* rp = a.refs + (size_t)a.ref_index[i] * C + sub * 8;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) r[ch] = rp[ch];
+  };
+  int64_t i = blockIdx.x;
+  if (i < n) fetch(i, col, ref, pi);
+  for (; i < n; i += gridDim.x) {
+    const int64_t inext = i + gridDim.x;
+    if (inext < n) fetch(inext, nxt, refn, pin);     // in flight during this patch's arithmetic
+    if (GRAD) {
+      __syncthreads();                               // the previous patch's neighbour reads are done
+#pragma unroll
+      for (int y = 0; y < PS; ++y) sh[(y * PS + x) * 16 + sub] = col[y];
+      __syncthreads();
+    }
+    const int64_t o_idx = a.first_out + i;
+    if (threadIdx.x == 0) {
+      a.cout[2 * o_idx] = a.cin[2 * pi]; a.cout[2 * o_idx + 1] = a.cin[2 * pi + 1];
+      a.sout[2 * o_idx] = a.sin[2 * pi]; a.sout[2 * o_idx + 1] = a.sin[2 * pi + 1];
+    }
+    CostmapColumn<OT, PS, GRAD> cc;
+    cc.col = col; cc.sh = sh; cc.ref = ref; cc.sub = sub;
+    cc.xl = x > 0 ? x - 1 : 0; cc.xr = x < PS - 1 ? x + 1 : PS - 1;
+    const Sums3 v = cc.template node<0, 1>();        // lane `sub` holds the sums of row `sub` of column x
+    if (sub < PS) {
+      double rho[3];
+      loss_eval(a.loss.type, a.loss.a, 1.0, v.s, rho);
+      double cost = 0.5 * rho[0];
+      OT* o = reinterpret_cast<OT*>(a.fout) + ((size_t)o_idx * PS * PS + (size_t)sub * PS + x) * a.CO;
+      if (GRAD) {
+        double dcr = 0.0, dcc = 0.0;
+        if (cost > 1.0e-8) {
+          dcr = rho[1] * (0.5 * v.br); dcc = rho[1] * (0.5 * v.bc);   // sum(res * 0.5 d) == 0.5 * sum(res * d), exactly
+          if (a.apply_sqrt) { cost = sqrt(cost); dcr *= 0.5 / cost; dcc *= 0.5 / cost; }
+        }
+        o[0] = store_cast<OT>(cost); o[1] = store_cast<OT>(dcr); o[2] = store_cast<OT>(dcc);
+      } else {
+        if (a.apply_sqrt) cost = sqrt(cost);
+        o[0] = store_cast<OT>(cost);
+      }
+    }
+    if (inext < n) {
+#pragma unroll
+      for (int y = 0; y < PS; ++y) col[y] = nxt[y];
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) ref[ch] = refn[ch];
+      pi = pin;
+    }
+  }
+}
+
+template <typename OT>
+static int launch_costmap_f16(pxr_ctx* ctx, const CostmapArgs& a, int64_t n, bool grad) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return set_error(PXR_EHIP, "hipGetDeviceProperties failed");
+  const int64_t resident = (int64_t)prop.multiProcessorCount * (a.H == 16 ? 2 : 8);
+  const dim3 grid((unsigned)(n < resident ? n : resident)), block((unsigned)(a.H * 16));
+  if (a.H == 16) {
+    if (grad) hipLaunchKernelGGL((costmap_kernel_f16<OT, 16, true>), grid, block, 0, ctx->stream, a, n);
+    else hipLaunchKernelGGL((costmap_kernel_f16<OT, 16, false>), grid, block, 0, ctx->stream, a, n);
+  } else {
+    if (grad) hipLaunchKernelGGL((costmap_kernel_f16<OT, 8, true>), grid, block, 0, ctx->stream, a, n);
+    else hipLaunchKernelGGL((costmap_kernel_f16<OT, 8, false>), grid, block, 0, ctx->stream, a, n);
+  }
+  return hip_check(hipGetLastError(), "costmap_kernel_f16 launch");
+}
+
 template <typename ST, typename OT, int C>
 static int launch_costmap(pxr_ctx* ctx, const CostmapArgs& a, int64_t n, bool grad) {
+  if constexpr (sizeof(ST) == 2 && C == 128) {
+    if (a.H == a.W && (a.H == 16 || a.H == 8)) return launch_costmap_f16<OT>(ctx, a, n, grad);
+  }
   const dim3 grid((unsigned)n), block((unsigned)(a.W * (C / 8)));
   if (grad) hipLaunchKernelGGL((costmap_kernel<ST, OT, C, true>), grid, block, 0, ctx->stream, a);
   else hipLaunchKernelGGL((costmap_kernel<ST, OT, C, false>), grid, block, 0, ctx->stream, a);

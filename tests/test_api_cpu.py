@@ -76,7 +76,13 @@ def test_keypoint_setup_and_confs():
     with pytest.raises(ValueError):
         KeypointAdjuster.create({"optimizer": {"no_such_option": 1}})
     with pytest.raises(ValueError):
-        BundleAdjuster.create({"strategy": "costmaps"})
+        BundleAdjuster.create({"strategy": "patch_warp"})             # outside the accelerated path
+    cm = BundleAdjuster.create({"strategy": "costmaps"})             # the low-memory strategy (main.py:218-238)
+    assert cm.conf["costmaps"]["loss"]["name"] == "trivial" and cm.conf["costmaps"]["as_gradientfield"] is True
+    from pixsfm_amd.api import CostMapExtractor
+    assert CostMapExtractor({}).get_effective_channels() == 3 and CostMapExtractor({"as_gradientfield": False}).get_effective_channels() == 1
+    with pytest.raises(ValueError):
+        CostMapExtractor({"compute_cross_derivative": True})
     ba = BundleAdjuster.create({})
     assert ba.conf["optimizer"]["solver"]["use_inner_iterations"] is True and ba.conf["references"]["iters"] == 100
 

@@ -9,11 +9,14 @@ observation owned by the rank: projection, bicubic interpolation of the patch st
 L2-normalisation with analytic gradient, reference subtraction and the six-scalar reduction
 that stands in for the 128 x (10+K) Jacobian block.  Inputs are resident in HBM when the
 timed region starts.  N > 1: points (with all their observations and patches) are
-partitioned over the ranks, no data-path collective in the evaluation; the total
-problem size is fixed (strong scaling).
+partitioned over the ranks, no data-path collective in the evaluation; by default every
+rank owns --points points (weak scaling: N x 1M observations in one scene, cameras shared),
+--scaling strong shards the 1M-observation problem instead.
 
 Rank 0 prints ONE JSON line; see DESIGN.md section "Measurement" for the roofline and
-cpu_baseline definitions.
+cpu_baseline definitions.  Besides the contract's fields it carries `lm` / `lm_no_inner` (LM iterations/s
+on the same problem), `ka` (BASELINE configs[1]) and `costmap` (the reference's low-memory strategy on the
+same scene: cost-map extraction + cost-map BA).
 """
 import argparse
 import json

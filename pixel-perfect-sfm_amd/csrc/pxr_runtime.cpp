@@ -46,13 +46,14 @@ int pxr_ctx_create(int device, void* stream, pxr_ctx** out) {
 
 int pxr_ctx_destroy(pxr_ctx* ctx) {
   if (!ctx) return PXR_OK;
-  hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
-  if (ctx->d_scratch) hipFree(ctx->d_scratch);
-  if (ctx->d_workspace) hipFree(ctx->d_workspace);
-  if (ctx->d_workspace_mat) hipFree(ctx->d_workspace_mat);
-  if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
-  if (ctx->ev_stop) hipEventDestroy(ctx->ev_stop);
+  // teardown: nothing useful can be done with an error here
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+  if (ctx->d_workspace) (void)hipFree(ctx->d_workspace);
+  if (ctx->d_workspace_mat) (void)hipFree(ctx->d_workspace_mat);
+  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   delete ctx;
   return PXR_OK;
 }
@@ -153,11 +154,11 @@ int pxr_arena_create(pxr_ctx* ctx, int dtype, int C, int H, int W, int64_t n_pat
 
 int pxr_arena_destroy(pxr_arena* a) {
   if (!a) return PXR_OK;
-  hipSetDevice(a->ctx->device);
-  hipStreamSynchronize(a->ctx->stream);
-  if (a->owns_data && a->d_data) hipFree(a->d_data);
-  if (a->d_corners) hipFree(a->d_corners);
-  if (a->d_scales) hipFree(a->d_scales);
+  (void)hipSetDevice(a->ctx->device);
+  (void)hipStreamSynchronize(a->ctx->stream);
+  if (a->owns_data && a->d_data) (void)hipFree(a->d_data);
+  if (a->d_corners) (void)hipFree(a->d_corners);
+  if (a->d_scales) (void)hipFree(a->d_scales);
   delete a;
   return PXR_OK;
 }

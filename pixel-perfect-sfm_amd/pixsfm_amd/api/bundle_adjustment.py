@@ -288,11 +288,15 @@ class CostMapExtractor:
     default_conf = {'loss': {'name': 'trivial', 'params': []}, 'as_gradientfield': True, 'compute_cross_derivative': False,
                     'upsampling_factor': 1.0, 'apply_sqrt': False, 'dense_cut_size': 12, 'num_threads': -1}
 
-    def __init__(self, config=None, interpolation_config=None, ctx=None):
+    def __init__(self, config=None, interpolation_config=None, ctx=None, chunk_bytes=16 << 30):
+        """chunk_bytes: device memory the FEATURE patches of one pass may take.  A scene whose patches exceed it is
+        processed in chunks of whole 3D points in problem-label order (the unit of the reference's RunSubset,
+        costmap_extractor.h:177-228): upload the chunk's patches, references, cost maps into the ONE cost-map arena,
+        release -- the low-memory point of the strategy (configs/low_memory.yaml)."""
         self.config = base.merge_conf(self.default_conf, config)
         ic = interpolation_config
         self.interpolation = ic if isinstance(ic, base.InterpolationConfig) else base.InterpolationConfig(ic)
-        self.ctx = ctx
+        self.ctx, self.chunk_bytes = ctx, int(chunk_bytes)
         if self.config['compute_cross_derivative'] or float(self.config['upsampling_factor']) != 1.0:
             raise ValueError("compute_cross_derivative / upsampling_factor != 1 are outside the accelerated path "
                              "(the configuration of pixsfm's CostMapBundleAdjuster, main.py:227-238, is supported)")
@@ -301,6 +305,7 @@ class CostMapExtractor:
         return 3 if self.config['as_gradientfield'] else 1
 
     def run(self, problem_labels, reconstruction, feature_set, ref_extractor):
+        from ..engine import PatchArena
         if ref_extractor is None:
             raise ValueError("a ReferenceExtractor is required")                 # Run dereferences it, costmap_extractor.h:141
         ctx = self.ctx or default_context()
@@ -309,23 +314,68 @@ class CostMapExtractor:
         wanted = {p for p in reconstruction.point3D_ids() if p < len(problem_labels) and problem_labels[p] >= 0}
         setup = BundleAdjustmentSetup()
         setup.add_images(reconstruction.reg_image_ids())
-        flat = _FlatBA(reconstruction, setup, FeatureView(feature_set, reconstruction), point_filter=wanted)
+        flat = _FlatBA(reconstruction, setup, FeatureView(feature_set, reconstruction), point_filter=wanted)   # host lists only
         cost_fset = features.FeatureSet(channels=self.get_effective_channels())
-        if len(flat.obs_image) == 0:
+        n_obs = len(flat.obs_image)
+        if n_obs == 0:
             return cost_fset, {}
-        arena = features.to_arena(ctx, flat.patches)
-        ba = BAProblem(ctx, arena, flat.problem_dict(np.zeros((len(flat.point_ids), arena.C)), arena.index))
-        references = ref_extractor._references_of(ba, flat)
-        costmaps = ba.extract_costmaps(make_loss(self.config['loss']['name'], self.config['loss']['params']),
-                                       as_gradientfield=self.config['as_gradientfield'], apply_sqrt=self.config['apply_sqrt'])
-        arena.close()
+        first = flat.patches[0]
+        H, W, C = first.shape
+        dtype = first.arena.dtype if isinstance(first, features.ArenaPatch) else first.data.dtype
+        costmaps = PatchArena(ctx, n_obs, H, W, self.get_effective_channels(), dtype)
+        loss = make_loss(self.config['loss']['name'], self.config['loss']['params'])
+        # chunks of whole points
+        obs_of_point = [[] for _ in flat.point_ids]
+        for i, k in enumerate(flat.obs_point):
+            obs_of_point[int(k)].append(i)
+        order = sorted(range(len(flat.point_ids)), key=lambda k: (problem_labels[flat.point_ids[k]], flat.point_ids[k]))
+        budget = max(1, self.chunk_bytes // (H * W * C * np.dtype(dtype).itemsize))
+        chunks, cur, cur_obs = [], [], 0
+        for k in order:
+            if cur and cur_obs + len(obs_of_point[k]) > budget:
+                chunks.append(cur)
+                cur, cur_obs = [], 0
+            cur.append(k)
+            cur_obs += len(obs_of_point[k])
+        chunks.append(cur)
+        map_index, offset, references = np.empty(n_obs, np.int64), 0, {}
+        for pts in chunks:
+            sub = _PointSubset(flat, pts, sorted(i for k in pts for i in obs_of_point[k]))
+            arena = features.to_arena(ctx, sub.patches)
+            ba = BAProblem(ctx, arena, sub.problem_dict(np.zeros((len(pts), C)), arena.index))
+            references.update(ref_extractor._references_of(ba, sub))
+            ba.extract_costmaps(loss, as_gradientfield=self.config['as_gradientfield'], apply_sqrt=self.config['apply_sqrt'],
+                                out=costmaps, first_out=offset)
+            arena.close()                                                        # synchronises the stream first
+            map_index[sub.obs] = offset + np.arange(len(sub.obs))
+            offset += len(sub.obs)
         cost_fset.arena = costmaps
         for i, (image_id, p2d_idx) in enumerate(flat.obs_keys):                 # CreateShallowCostmapFSet, :360-435
             name = reconstruction.images[image_id].name
             if not cost_fset.has_fmap(name):
                 cost_fset.fmaps[name] = features.FeatureMap()
-            cost_fset.fmaps[name].patches[int(p2d_idx)] = features.ArenaPatch(costmaps, i)
+            cost_fset.fmaps[name].patches[int(p2d_idx)] = features.ArenaPatch(costmaps, map_index[i])
         return cost_fset, references
+
+
+class _PointSubset:
+    """The observations `obs` (indices into a _FlatBA) of the points `pts` as a flat problem of their own: images and
+    cameras stay those of the parent, points and observations are renumbered."""
+
+    def __init__(self, flat, pts, obs):
+        self.flat, self.obs = flat, np.asarray(obs, dtype=np.int64)
+        local = {k: j for j, k in enumerate(pts)}
+        self.point_ids = [flat.point_ids[k] for k in pts]
+        self.obs_keys = [flat.obs_keys[i] for i in obs]
+        self.obs_image = flat.obs_image[self.obs]
+        self.obs_point = np.array([local[int(flat.obs_point[i])] for i in obs], np.int32)
+        self.patches = [flat.patches[i] for i in obs]
+        self.xyz = flat.xyz[np.asarray(pts, dtype=np.int64)]
+
+    def problem_dict(self, refs, patch_index):
+        f = self.flat
+        return dict(obs_image=self.obs_image, obs_point=self.obs_point, obs_patch=patch_index, image_camera=f.image_camera,
+                    qvec=f.qvec, tvec=f.tvec, cam_model=f.cam_model, cam_params=f.cam_params, xyz=self.xyz, refs=refs)
 
 
 class FeatureReferenceBundleOptimizer:

@@ -310,18 +310,19 @@ class BAProblem:
                       self.n_cameras, d["cam_model"].ptr, d["cam_params"].ptr,
                       self.n_points, d["xyz"].ptr, d["refs"].ptr if d["refs"] is not None else None)
 
-    def extract_costmaps(self, loss, as_gradientfield=True, apply_sqrt=False, dtype=None, out=None):
+    def extract_costmaps(self, loss, as_gradientfield=True, apply_sqrt=False, dtype=None, out=None, first_out=0):
         """CostMapExtractor (bundle_adjustment/src/costmap_extractor.h:177-358) on the GPU: one cost map per
         observation -- the featuremetric error of every texel of its feature patch against the reference of
         its 3D point (this problem's `refs`, e.g. after compute_references()).  Returns a PatchArena of
         n_obs maps, 3 channels [cost, dcost/dr, dcost/dc] (as_gradientfield) or 1, dtype = the features' unless
-        given; map i belongs to observation i.  out: an existing arena of that shape to overwrite."""
+        given; map i belongs to observation i.  out: an existing arena to write into, maps first_out .. first_out + n_obs - 1
+        (several problems -- chunks of a scene too large for the device -- can share one cost-map arena)."""
         ctx, a = self.ctx, self.arena
         if self.d["refs"] is None:
             raise ValueError("cost maps need reference descriptors")
         if out is None:
             out = PatchArena(ctx, self.n_obs, a.H, a.W, 3 if as_gradientfield else 1, a.dtype if dtype is None else dtype)
-        check(ctx.lib.pxr_costmap_extract(ctx.handle, a.handle, out.handle, 0, self.n_obs, self.d["obs_patch"].ptr,
+        check(ctx.lib.pxr_costmap_extract(ctx.handle, a.handle, out.handle, int(first_out), self.n_obs, self.d["obs_patch"].ptr,
                                           self.d["obs_point"].ptr, self.d["refs"].ptr, C.byref(loss),
                                           int(bool(as_gradientfield)), int(bool(apply_sqrt))), "pxr_costmap_extract")
         return out

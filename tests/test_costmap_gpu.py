@@ -230,3 +230,37 @@ def test_costmap_bundle_adjuster_like_pixsfm(ctx):
     from pixsfm_amd.api import default_problem_setup
     with pytest.raises(ValueError, match="Unsupported dimensions"):
         CostMapBundleOptimizer({}, default_problem_setup(rec), {"l2_normalize": False}).run(rec, fmanager.fset(0))
+
+
+def test_costmap_extractor_in_chunks_equals_one_pass(ctx):
+    """A scene whose feature patches exceed CostMapExtractor.chunk_bytes is processed in chunks of whole points with one
+    cost-map arena: same maps (bit for bit), same references, whatever the chunking."""
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.api import CostMapExtractor, ReferenceExtractor, features
+    from pixsfm_amd.api.bundle_adjustment import find_problem_labels
+    from pixsfm_amd.api.reconstruction import reconstruction_from_flat
+    prob = synthetic.make_ba_problem(n_cams=5, n_points=37, obs_per_point=3, seed=23, noise=0.02)
+    rec, patch_of = reconstruction_from_flat(prob)
+    fmaps = {}
+    for (image_id, p2d), pi in patch_of.items():
+        fm = fmaps.setdefault(rec.images[image_id].name, features.FeatureMap())
+        fm.patches[p2d] = features.FeaturePatch(prob["patches"][pi], prob["corners"][pi], prob["scales"][pi])
+    fset = features.FeatureSet(fmaps)
+    labels = find_problem_labels(rec, 10)
+    out = {}
+    for name, chunk_bytes in (("one", 16 << 30), ("many", 10 * 16 * 16 * 128 * 2)):      # 10 patches per chunk -> ~12 chunks
+        ce = CostMapExtractor({"loss": {"name": "cauchy", "params": [0.25]}}, {}, chunk_bytes=chunk_bytes)
+        cost_fset, refs = ce.run(labels, rec, fset, ReferenceExtractor({}, {}))
+        maps = {}
+        for name_img, fm in cost_fset.fmaps.items():
+            for p2d, cp in fm.patches.items():
+                maps[(name_img, p2d)] = cost_fset.arena.download(cp.index, 1)
+        out[name] = (maps, refs)
+    (m1, r1), (m2, r2) = out["one"], out["many"]
+    assert m1.keys() == m2.keys() and len(m1) == len(prob["obs_image"])
+    for key in m1:
+        for a, b in zip(m1[key], m2[key]):
+            assert np.array_equal(a, b)
+    assert r1.keys() == r2.keys()
+    for pid in r1:
+        assert r1[pid].source == r2[pid].source and np.array_equal(r1[pid].descriptor, r2[pid].descriptor)

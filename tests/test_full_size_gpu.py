@@ -87,6 +87,53 @@ def test_lm_descends_monotonically_at_full_size(ctx, big):
     assert abs(ba.cost(make_loss("cauchy", [0.25])) - s["final_cost"]) < 1e-9 * s["final_cost"]
 
 
+def test_cost_maps_at_one_million_observations(ctx, big):
+    """pxr_costmap_extract over the whole 65.5 GB arena (the persistent kernel: ~2000 patches per workgroup), then the
+    cost-map BA on the 1M maps.  Properties: every cost >= 0 and (trivial loss) <= 2 for unit descriptors, the sum of
+    the cost channel equals a torch reduction over the same arena, a random sample equals the oracle, and the
+    cost-map LM descends."""
+    import pxo_costmap
+    import torch
+    from pixsfm_amd.engine import interp_cfg, lm_options, make_loss
+    prob, patches, ba = big
+    cm = ba.extract_costmaps(make_loss("trivial", []), dtype=np.float32)
+    ctx.sync()
+    rng = np.random.default_rng(11)
+    idx = np.sort(rng.choice(ba.n_obs, 300, replace=False))
+    for i in idx[:3].tolist() + [0, ba.n_obs - 1]:                       # first / last / a few single maps, full compare
+        got = cm.download(i, 1)[0][0]
+        want = pxo_costmap.fill_point_costmap(patches[i].cpu().numpy(), prob["refs"][prob["obs_point"][i]], out_dtype=np.float32)
+        assert np.abs(got - want).max() <= 2e-7 * max(1.0, np.abs(want).max())
+    # checksum of the cost channel against an independent torch reduction, in chunks of 50k maps
+    maps_t = torch.empty(0)
+    refs_t = torch.from_numpy(prob["refs"]).to("cuda:0")
+    pts_t = torch.from_numpy(prob["obs_point"].astype(np.int64)).to("cuda:0")
+    total_want, total_got, worst = 0.0, 0.0, 0.0
+    for lo in range(0, ba.n_obs, 50_000):
+        hi = min(ba.n_obs, lo + 50_000)
+        res = patches[lo:hi].double() - refs_t[pts_t[lo:hi]][:, None, None, :]
+        want = 0.5 * (res * res).sum(-1)                                 # (n, 16, 16)
+        got = torch.from_numpy(cm.download(lo, hi - lo)[0][..., 0]).to("cuda:0").double()
+        worst = max(worst, float((got - want).abs().max()))
+        total_want += float(want.sum()); total_got += float(got.sum())
+        assert float(got.min()) >= 0.0 and float(got.max()) <= 2.0 + 1e-6
+    assert worst < 5e-7 and abs(total_got - total_want) < 1e-7 * total_want
+    del maps_t, refs_t, pts_t
+    # cost-map BA at full size
+    cba = ba.costmap_problem(cm)
+    n_img = 200
+    pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
+    tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
+    host = {k: ba.d[k].download() for k in ("qvec", "tvec", "cam_params", "xyz")}
+    s = cba.solve(interp_cfg(l2_normalize=False), make_loss("cauchy", [0.25]), pose_const, tmask, np.full(n_img, 0b0110, np.uint16),
+                  np.zeros(len(prob["xyz"]), np.uint8), options=lm_options(max_iterations=4, use_inner_iterations=True))
+    # (the preceding LM test already refined these parameters: the maps' cost floor is close, it must still go down)
+    assert s["num_successful"] >= 1 and s["final_cost"] < s["initial_cost"] and np.isfinite(s["final_cost"])
+    for k, v in host.items():                                            # leave the shared parameters as they were
+        ba.d[k].upload(v)
+    cm.close()
+
+
 def test_ka_config0_scale_matches_oracle(ctx):
     """BASELINE configs[0] scale (sacre_coeur: ~8 000 observations in ~1 900 tracks, demo.ipynb:271-274): every
     sub-problem of the KA solve against the oracle LM -- same iteration counts, termination and keypoints."""

@@ -225,3 +225,64 @@ class PatchInterpolator:
 
     def interpolate(self, fpatch, xy):
         return self.interpolate_nodes(fpatch, xy).reshape(-1)
+
+
+def load_features_from_cache(cache_path, fill=True, level_prefix="", ctx=None, device=False, required=None):
+    """pixsfm.extract.load_features_from_cache(cache_path, fill) (extract.py:218-222) -> FeatureManager, through the native
+    reader of the cache format (libpixsfm_h5.so: featuremanager.cc:20-40, featuremap.cc:60-267; "chunked" and "grouped"
+    files, dense maps stored once and loaded as sparse windows).
+    device=False: host FeaturePatch objects (numpy arrays read straight from the file).
+    device=True: every level becomes ONE device PatchArena (image by image: read into a staging array, upload) and the
+    FeatureMaps hold ArenaPatch handles -- the flow the optimisers then index in place.
+    required: optional {image name: iterable of keypoint ids}: only these patches are read (FeatureSet::Load with the
+    patch ids a FeatureView needs, featureset.cc:98-135); images not named are skipped.
+    fill=False (metadata now, data on demand) is expressed with `required` here."""
+    from .. import _h5
+    from ..engine import PatchArena
+    if not fill:
+        raise ValueError("fill=False is not supported: pass required={image: keypoint ids} to load a subset")
+    cache = _h5.FeatureCache(cache_path, level_prefix)
+    fsets = []
+    try:
+        for level in range(cache.num_levels):
+            names = [n for n in cache.image_names(level) if required is None or n in required]
+            plan, total, shape = [], 0, None
+            for name in names:
+                info = cache.map_info(level, name)
+                ids, corners, scales = cache.map_meta(level, name, info["n"])
+                which = np.arange(info["n"])
+                if required is not None and info["is_sparse"]:
+                    pos = {int(k): i for i, k in enumerate(ids)}
+                    missing = [k for k in required[name] if int(k) not in pos]
+                    if missing:
+                        raise KeyError("keypoints %r of image %r are not in the cache" % (missing[:5], name))
+                    which = np.array([pos[int(k)] for k in required[name]], dtype=np.int64)
+                plan.append((name, info, ids, corners, scales, which))
+                total += len(which)
+                if device and len(which):
+                    if shape is None:
+                        shape = info["shape"]
+                    elif shape != info["shape"]:
+                        raise ValueError("device=True needs patches of one shape per level (image %r has %r, expected %r)"
+                                         % (name, info["shape"], shape))
+            fset = FeatureSet(channels=cache.channels_per_level[level])
+            arena, first = None, 0
+            if device and total:
+                from .keypoint_adjustment import default_context
+                arena = PatchArena(ctx or default_context(), total, shape[0], shape[1], shape[2], cache.dtype)
+                fset.arena = arena
+            for name, info, ids, corners, scales, which in plan:
+                patches = cache.read_patches(level, name, which)
+                fm = FeatureMap(is_sparse=info["is_sparse"])
+                for j, i in enumerate(which):
+                    key = int(ids[i]) if info["is_sparse"] else kDenseId
+                    fm.patches[key] = ArenaPatch(arena, first + j) if arena is not None else \
+                        FeaturePatch(patches[j], corners[i], scales[i])
+                if arena is not None and len(which):
+                    arena.upload(first, patches, corners[which], scales[which])
+                    first += len(which)
+                fset.fmaps[name] = fm
+            fsets.append(fset)
+    finally:
+        cache.close()
+    return FeatureManager(fsets)

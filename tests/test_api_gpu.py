@@ -447,3 +447,38 @@ def test_dense_feature_maps_equal_sparse_patches(ctx):
     for nm in names:
         assert np.abs(out["dense"][nm] - out["sparse"][nm]).max() < 1e-9
     assert max(np.abs(out["dense"][nm] - keypoints[nm]).max() for nm in names) > 0.05     # (the root image stays put)
+
+
+def test_feature_cache_to_device_flow_equals_host_flow(ctx, tmp_path):
+    """a pixsfm "chunked" feature cache (extract.py:98-127) read by the native reader straight into ONE
+    device arena per level (load_features_from_cache(device=True)) drives the bundle adjuster exactly like host patches."""
+    import h5_writer
+    if not h5_writer.available():
+        pytest.skip("the image's libhdf5 is missing")
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.api import BundleAdjuster, features
+    from pixsfm_amd.api.reconstruction import reconstruction_from_flat
+    prob = synthetic.make_ba_problem(n_cams=5, n_points=50, obs_per_point=3, seed=29, noise=0.03)
+    rec_h, patch_of = reconstruction_from_flat(prob)
+    rec_d, _ = reconstruction_from_flat(prob)
+    level, fmaps = {}, {}
+    for (image_id, p2d), pi in patch_of.items():
+        name = rec_h.images[image_id].name
+        fm = level.setdefault(name, dict(keypoint_ids=[], patches=[], corners=[], scales=[], metadata={"is_sparse": True, "patch_size": 16}))
+        fm["keypoint_ids"].append(p2d); fm["patches"].append(prob["patches"][pi])
+        fm["corners"].append(prob["corners"][pi]); fm["scales"].append(prob["scales"][pi])
+        fmaps.setdefault(name, features.FeatureMap()).patches[p2d] = features.FeaturePatch(prob["patches"][pi], prob["corners"][pi], prob["scales"][pi])
+    for fm in level.values():
+        fm["patches"], fm["corners"] = np.stack(fm["patches"]), np.stack(fm["corners"])
+    path = tmp_path / "features.h5"
+    h5_writer.write_cache(path, [level])
+    fmgr_d = features.load_features_from_cache(path, device=True, ctx=ctx)
+    assert fmgr_d.fset(0).arena.n == len(prob["obs_image"])
+    conf = {"optimizer": {"solver": {"max_num_iterations": 5}}}
+    out_d = BundleAdjuster.create(conf).refine_multilevel(rec_d, fmgr_d)
+    out_h = BundleAdjuster.create(conf).refine_multilevel(rec_h, features.FeatureManager([features.FeatureSet(fmaps)]))
+    assert out_d["summary"][0].final_cost == pytest.approx(out_h["summary"][0].final_cost, rel=1e-9)
+    for i in rec_h.images:
+        assert np.abs(rec_h.images[i].qvec - rec_d.images[i].qvec).max() < 1e-9
+    for p in rec_h.points3D:
+        assert np.abs(rec_h.points3D[p].xyz - rec_d.points3D[p].xyz).max() < 1e-9

@@ -47,6 +47,18 @@ def merge_conf(default, override):
     return out
 
 
+def merge_adjuster_conf(default, override):
+    """The adjusters' own `OmegaConf.merge(self.default_conf, conf)` (keypoint_adjustment/main.py:87, bundle_adjustment/
+    main.py:66-74) accepts keys the adjuster does not know -- pixsfm's YAML files carry pipeline-level entries such as
+    `repeats` / `num_threads` next to the adjuster's (configs/low_memory.yaml:24-31) -- while the nested sections that
+    become C++ option classes (`optimizer`, `references`, `costmaps`, `interpolation`) are strict."""
+    override = dict(override or {})
+    extra = {k: deepcopy(override.pop(k)) for k in list(override) if k not in default}
+    out = merge_conf(default, override)
+    out.update(extra)
+    return out
+
+
 class InterpolationConfig:
     """base/src/interpolation.h:39-51; constructible from a dict like the pybind class."""
 

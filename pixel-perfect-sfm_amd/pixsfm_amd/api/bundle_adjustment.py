@@ -546,7 +546,7 @@ class FeatureReferenceBundleAdjuster(BundleAdjuster):
     default_conf = deepcopy(BundleAdjuster.default_conf)
 
     def __init__(self, conf):
-        self.conf = base.merge_conf(self.default_conf, conf)
+        self.conf = base.merge_adjuster_conf(self.default_conf, conf)
 
     def refine(self, reconstruction, feature_set, problem_setup=None):
         if problem_setup is None:
@@ -573,7 +573,7 @@ class CostMapBundleAdjuster(BundleAdjuster):
     }
 
     def __init__(self, conf):
-        self.conf = base.merge_conf(self.default_conf, conf)
+        self.conf = base.merge_adjuster_conf(self.default_conf, conf)
 
     def refine(self, reconstruction, feature_set, problem_setup=None):
         if problem_setup is None:

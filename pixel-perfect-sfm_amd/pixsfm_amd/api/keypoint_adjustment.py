@@ -259,7 +259,7 @@ class FeatureMetricKeypointAdjuster(KeypointAdjuster):
     _solver_cls = FeatureMetricKeypointOptimizer
 
     def __init__(self, conf):
-        self.conf = base.merge_conf(self.default_conf, conf)
+        self.conf = base.merge_adjuster_conf(self.default_conf, conf)
 
     def refine(self, keypoints_dict, feature_set, graph, track_labels, root_labels, problem_setup=None):
         return self._refine(keypoints_dict, feature_set, graph, track_labels, root_labels, problem_setup)
@@ -272,7 +272,7 @@ class TopologicalReferenceKeypointAdjuster(KeypointAdjuster):
     _solver_cls = TopologicalReferenceKeypointOptimizer
 
     def __init__(self, conf):
-        self.conf = base.merge_conf(self.default_conf, conf)
+        self.conf = base.merge_adjuster_conf(self.default_conf, conf)
 
     def refine(self, keypoints_dict, feature_set, graph, track_labels, root_labels, problem_setup=None):
         return self._refine(keypoints_dict, feature_set, graph, track_labels, root_labels, problem_setup)

@@ -264,3 +264,64 @@ def test_costmap_extractor_in_chunks_equals_one_pass(ctx):
     assert r1.keys() == r2.keys()
     for pid in r1:
         assert r1[pid].source == r2[pid].source and np.array_equal(r1[pid].descriptor, r2[pid].descriptor)
+
+
+# pixsfm/configs/low_memory.yaml, `mapping` section (lines 11-47), as the dicts OmegaConf hands to the adjusters
+LOW_MEMORY_KA = {"apply": True, "strategy": "topological_reference", "split_in_subproblems": True, "max_kps_per_problem": 1000,
+                 "optimizer": {"num_threads": -1, "print_summary": False, "bound": 2.0, "solver": {"parameter_tolerance": 1.0e-5}}}
+LOW_MEMORY_BA = {"apply": True, "strategy": "costmaps", "repeats": 1, "num_threads": -1, "level_indices": None,
+                 "max_tracks_per_problem": 100, "references": {"keep_observations": False}, "costmaps": {"num_threads": -1},
+                 "optimizer": {"loss": {"name": "cauchy", "params": [0.25]}, "print_summary": False, "refine_focal_length": False,
+                               "refine_principal_point": False, "refine_extra_params": False, "refine_extrinsics": False}}
+
+
+def test_low_memory_configuration_end_to_end(ctx):
+    """The reference's low-memory configuration verbatim: 8 x 8 half patches, topological-reference KA with bound 2, cost-map
+    BA that refines the 3D points only (all refine_* flags off)."""
+    from pixsfm_amd import synthetic, synthetic_ka
+    from pixsfm_amd.api import BundleAdjuster, KeypointAdjuster, features
+    from pixsfm_amd.api.keypoint_adjustment import build_matching_graph
+    from pixsfm_amd.api.reconstruction import reconstruction_from_flat
+    # ---- KA on 8 x 8 patches -------------------------------------------------------------------------------------
+    n_tracks, track_len = 10, 4
+    kp = synthetic_ka.make_ka_problem(n_tracks=n_tracks, track_len=track_len, seed=31, patch_size=8, sigma=0.5, directed_both=False)
+    n = n_tracks * track_len
+    img, kid = np.arange(n) % track_len, np.arange(n) // track_len
+    names = ["im%d.jpg" % k for k in range(track_len)]
+    keypoints = {names[k]: kp["kp"][img == k].copy() for k in range(track_len)}
+    pairs, matches, scores = [], [], []
+    for a in range(track_len):
+        for b in range(a + 1, track_len):
+            sel = (img[kp["edge_src"]] == a) & (img[kp["edge_dst"]] == b)
+            pairs.append((names[a], names[b]))
+            matches.append(np.stack([kid[kp["edge_src"][sel]], kid[kp["edge_dst"][sel]]], 1))
+            scores.append(kp["edge_w"][sel])
+    graph = build_matching_graph(pairs, matches, scores)
+    fmaps = {names[k]: features.FeatureMap.from_arrays(kp["patches"][img == k], kid[img == k], kp["corners"][img == k], (1.0, 1.0))
+             for k in range(track_len)}
+    ka = KeypointAdjuster.create(LOW_MEMORY_KA)
+    assert ka.conf["optimizer"]["bound"] == 2.0 and ka.conf["max_kps_per_problem"] == 1000
+    s = ka.refine_multilevel(keypoints, features.FeatureManager([features.FeatureSet(fmaps)]), graph)["summary"][0]
+    assert s.final_cost < 0.5 * s.initial_cost
+    # ---- cost-map BA on 8 x 8 patches, points only ---------------------------------------------------------------
+    prob = synthetic.make_ba_problem(n_cams=6, n_points=60, obs_per_point=4, seed=32, patch_size=8, rot_deg=0.0, trans=0.0, pt_sigma=0.01)
+    rec, patch_of = reconstruction_from_flat(prob)
+    fm = {}
+    for (image_id, p2d), pi in patch_of.items():
+        fm.setdefault(rec.images[image_id].name, features.FeatureMap()).patches[p2d] = \
+            features.FeaturePatch(prob["patches"][pi], prob["corners"][pi], prob["scales"][pi])
+    q0 = {i: rec.images[i].qvec.copy() for i in rec.images}
+    k0 = {c: rec.cameras[c].params.copy() for c in rec.cameras}
+    x0 = np.array([rec.points3D[p + 1].xyz for p in range(60)])
+    ba = BundleAdjuster.create(LOW_MEMORY_BA)
+    assert ba.conf["repeats"] == 1                                         # pipeline-level keys pass through (OmegaConf.merge)
+    out = ba.refine_multilevel(rec, features.FeatureManager([features.FeatureSet(fm)]))
+    s = out["summary"][0]
+    assert out["costmaps"][0].arena.H == 8 and out["costmaps"][0].arena.C == 3
+    assert s.final_cost < 0.2 * s.initial_cost
+    # refine_extrinsics: false (AddImageToProblem still normalises qvec in place, bundle_optimizer.h:255)
+    assert all(np.abs(rec.images[i].qvec - q0[i] / np.linalg.norm(q0[i])).max() < 1e-15 for i in rec.images)
+    assert all(np.array_equal(rec.cameras[c].params, k0[c]) for c in rec.cameras)      # no intrinsics refined
+    x1 = np.array([rec.points3D[p + 1].xyz for p in range(60)])
+    err0, err1 = np.abs(x0 - prob["gt_xyz"]).max(), np.abs(x1 - prob["gt_xyz"]).max()
+    assert np.abs(x1 - x0).max() > 1e-4 and err1 < err0                                # the points moved towards the truth

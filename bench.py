@@ -214,6 +214,8 @@ def main():
                    "extract_frac_of_peak": ex_bytes * n_obs_local / (ex_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "extract_bytes_per_map": ex_bytes, "kernel": "costmap_kernel<f16,f16,128,grad>",
                    "map_arena_GB": n_obs_local * PS * PS * 3 * 2 / 1e9,
+                   "extract_bound": "fp64 VALU issue (the reference's double accumulation); HBM traffic from the PMC counters "
+                                    "is 1.03x the algorithmic bytes (profiles/r1_costmap_pmc.json)",
                    "eval_ms": ev_ms, "eval_blocks_per_sec": n_obs_local / (ev_ms * 1e-3)}
         if args.lm_iters > 0:
             n_img = args.cams

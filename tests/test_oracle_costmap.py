@@ -52,6 +52,19 @@ def test_set_entry_cast_rule_matches_reference_half_hpp():
     assert (out != v.astype(np.float16).view(np.uint16)).any()
 
 
+def test_half_rules_match_the_committed_golden_vectors():
+    """tests/golden/half_rules.npz was produced by the reference's half.hpp (tests/golden/make_golden_half.py); it pins
+    the oracle's two rounding rules wherever oracle/_ref cannot be built."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "half_rules.npz"))
+    a, b = g["a"].view(np.float16), g["b"].view(np.float16)
+    mine = pxo_costmap.storage_diff(a, b).view(np.uint16)
+    want = g["sub"]
+    zero = (mine & 0x7fff == 0) & (want & 0x7fff == 0)                 # +0 / -0 of exact cancellations
+    assert ((mine == want) | zero).all()
+    assert np.array_equal(pxo_costmap.store(g["v"], np.float16).view(np.uint16), g["cast"])
+
+
 def _loop_costmap(patch, ref, loss, as_gradientfield, apply_sqrt):
     """costmap_extractor.h:242-357 one statement at a time (doubles), no vectorisation."""
     H, W, Cn = patch.shape

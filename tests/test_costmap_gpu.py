@@ -325,3 +325,30 @@ def test_low_memory_configuration_end_to_end(ctx):
     x1 = np.array([rec.points3D[p + 1].xyz for p in range(60)])
     err0, err1 = np.abs(x0 - prob["gt_xyz"]).max(), np.abs(x1 - prob["gt_xyz"]).max()
     assert np.abs(x1 - x0).max() > 1e-4 and err1 < err0                                # the points moved towards the truth
+
+
+def test_costmap_ba_check_bounds(ctx):
+    """check_bounds on cost maps (the functor returns is_inside when no reference is given, feature_reference.h:128-130):
+    observations projecting outside their map fail the evaluation -> NaN block norm, FAILURE at the initial point; the
+    same problem without the option evaluates (border-clamped) and solves."""
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    prob = synthetic.make_ba_problem(n_cams=4, n_points=40, obs_per_point=3, seed=3)
+    prob["corners"] = prob["corners"].copy()
+    prob["corners"][::5, 0] += 9
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    cba = ba.costmap_problem(ba.extract_costmaps(make_loss("trivial", [])))
+    rec_on = cba.eval(interp_cfg(l2_normalize=False, check_bounds=True), with_jacobian=True)[0].download()
+    rec_off = cba.eval(interp_cfg(l2_normalize=False), with_jacobian=True)[0].download()
+    uv = rec_off[:, 6:8] * prob["scales"] - 0.5 - prob["corners"]
+    inside = (uv[:, 0] > 0) & (uv[:, 0] < 16) & (uv[:, 1] > 0) & (uv[:, 1] < 16)      # patch_interpolator.h:160-166
+    assert 0 < (~inside).sum() < len(inside)
+    assert np.array_equal(np.isnan(rec_on[:, 0]), ~inside) and np.array_equal(rec_on[inside], rec_off[inside])
+    gauge = (np.array([1, 0, 0, 0], np.uint8), np.array([0, 1, 0, 0], np.uint8), np.full(4, 0b0110, np.uint16), np.zeros(40, np.uint8))
+    for inner in (False, True):
+        s = cba.solve(interp_cfg(l2_normalize=False, check_bounds=True), make_loss("cauchy", [0.25]), *gauge,
+                      options=lm_options(max_iterations=5, use_inner_iterations=inner))
+        assert s["termination"] == 2 and s["iterations"] == 0 and np.isnan(s["initial_cost"])
+    s = cba.solve(interp_cfg(l2_normalize=False), make_loss("cauchy", [0.25]), *gauge, options=lm_options(max_iterations=2))
+    assert s["termination"] != 2 and np.isfinite(s["final_cost"])

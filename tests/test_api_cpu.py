@@ -183,6 +183,44 @@ def test_native_graph_labelling_matches_the_python_restatement():
         assert sorted(t for t, r in zip(tl, roots) if r) == sorted(set(tl))
 
 
+def test_track_labelling_in_parallel_over_match_graph_components():
+    """pxr_graph_track_labels solves the connected components of the match graph concurrently (they are independent
+    sub-problems of the reference's one sequential pass, graph.cc:126-206).  Many components + enough matches to take the
+    threaded path, similarity ties, conflicting matches and cross-component outliers: labels identical to the sequential
+    Python restatement."""
+    import ctypes as C
+    from types import SimpleNamespace as NS
+    import pxo_graph
+    from pixsfm_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    n_groups, per, n_img = 1500, 12, 40
+    n = n_groups * per
+    node_image = rng.integers(0, n_img, n).astype(np.int32)
+    g = rng.integers(0, n_groups, 60000)
+    src = (g * per + rng.integers(0, per, len(g))).astype(np.int64)
+    dst = (g * per + rng.integers(0, per, len(g))).astype(np.int64)
+    out_s = rng.integers(0, n, 300).astype(np.int64)                     # a few matches between groups: larger components
+    out_d = rng.integers(0, n, 300).astype(np.int64)
+    src, dst = np.concatenate([src, out_s]), np.concatenate([dst, out_d])
+    keep = (src != dst) & (node_image[src] != node_image[dst])
+    src, dst = src[keep], dst[keep]
+    sim = np.round(rng.uniform(0.1, 1.0, len(src)), 2)
+    assert len(src) > 20000
+    got, ntr = np.empty(n, np.int64), C.c_int64()
+    _lib.check(lib.pxr_graph_track_labels(n, node_image.ctypes.data, len(src), src.ctypes.data, dst.ctypes.data, sim.ctypes.data,
+                                          got.ctypes.data, C.byref(ntr)), "pxr_graph_track_labels")
+    nodes = [NS(node_idx=i, image_id=int(node_image[i]), out_matches=[]) for i in range(n)]
+    for a, b, s in zip(src, dst, sim):
+        nodes[a].out_matches.append(NS(node_idx=int(b), sim=float(s)))
+    want = np.array(pxo_graph.compute_track_labels(NS(nodes=nodes)))
+    assert np.array_equal(got, want) and ntr.value == want.max() + 1
+    seen = set()
+    for i in range(n):                                                   # one feature per image per track
+        assert (got[i], node_image[i]) not in seen
+        seen.add((got[i], node_image[i]))
+
+
 @pytest.mark.parametrize("weight_by_sim,root_edges_only,reg", [(True, False, -1.0), (False, True, -1.0), (False, True, 1.0),
                                                                (True, False, 0.5)])
 def test_native_edge_construction_matches_the_python_restatement(weight_by_sim, root_edges_only, reg):

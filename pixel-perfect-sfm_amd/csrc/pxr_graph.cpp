@@ -165,23 +165,21 @@ extern "C" int pxr_graph_score_labels(int64_t n_nodes, int64_t n_edges, const in
 extern "C" int pxr_graph_root_labels(int64_t n_nodes, const int64_t* track_labels, const double* scores,
                                      uint8_t* is_root) {
   PXR_REQUIRE(n_nodes >= 0 && (n_nodes == 0 || (track_labels && scores && is_root)), "pxr_graph_root_labels: NULL argument");
-  std::vector<std::pair<double, int64_t>> order((size_t)n_nodes);
+  // The reference sorts all nodes by descending (score, index) and takes the first node of every track
+  // (graph.cc:225-256): that is the per-track maximum of the pair, one linear pass.
   int64_t n_tracks = 0;
   for (int64_t i = 0; i < n_nodes; ++i) {
     PXR_REQUIRE(track_labels[i] >= 0, "pxr_graph_root_labels: negative track label");
-    order[(size_t)i] = std::make_pair(scores[i], i);
     n_tracks = std::max(n_tracks, track_labels[i] + 1);
   }
-  std::sort(order.begin(), order.end());           // ascending pairs, then reversed (graph.cc:238-239)
-  std::reverse(order.begin(), order.end());
-  std::vector<char> has_root((size_t)n_tracks, 0);
-  std::fill(is_root, is_root + n_nodes, (uint8_t)0);
-  for (const auto& it : order) {
-    const int64_t i = it.second;
-    if (has_root[(size_t)track_labels[i]]) continue;
-    is_root[i] = 1;
-    has_root[(size_t)track_labels[i]] = 1;
+  std::vector<int64_t> best((size_t)n_tracks, -1);
+  for (int64_t i = 0; i < n_nodes; ++i) {
+    int64_t& b = best[(size_t)track_labels[i]];
+    if (b < 0 || std::make_pair(scores[i], i) > std::make_pair(scores[b], b)) b = i;
   }
+  std::fill(is_root, is_root + n_nodes, (uint8_t)0);
+  for (int64_t t = 0; t < n_tracks; ++t)
+    if (best[(size_t)t] >= 0) is_root[best[(size_t)t]] = 1;
   return PXR_OK;
 }
 

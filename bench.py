@@ -285,9 +285,22 @@ def main():
             out["ka"] = bench_ka.run(device_index=local_rank)
         if costmap is not None:
             out["costmap"] = costmap
-        print(json.dumps(out))
+        result_line = json.dumps(out)
+    else:
+        result_line = None
+    # The JSON line must be the last thing on stdout: native libraries (RCCL's version banner, ...) write to the C
+    # stdio buffer of every rank, which would otherwise be flushed at exit -- after the line.  Flush it now, wait for
+    # all ranks, tear the process group down, then print.
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.fflush(None)
+    sys.stdout.flush()
     if dist_on:
+        dist.barrier()
         dist.destroy_process_group()
+        libc.fflush(None)
+    if result_line is not None:
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":

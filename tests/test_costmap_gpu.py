@@ -352,3 +352,32 @@ def test_costmap_ba_check_bounds(ctx):
         assert s["termination"] == 2 and s["iterations"] == 0 and np.isnan(s["initial_cost"])
     s = cba.solve(interp_cfg(l2_normalize=False), make_loss("cauchy", [0.25]), *gauge, options=lm_options(max_iterations=2))
     assert s["termination"] != 2 and np.isfinite(s["final_cost"])
+
+
+@pytest.mark.parametrize("H,W", [(12, 12), (12, 10), (20, 5), (1, 16), (7, 1), (1, 1)])
+@pytest.mark.parametrize("channels", [128, 64])
+def test_costmaps_of_odd_patch_shapes(ctx, H, W, channels):
+    """The generic extraction kernel: non-square patches, the 12 x 12 windows the reference cuts out of dense maps
+    (dense_cut_size, costmap_extractor.h:50), and the degenerate 1-texel rows / columns where the clamped central
+    differences vanish (costmap_extractor.h:260-263)."""
+    import pxo_costmap
+    from pixsfm_amd.engine import BAProblem, PatchArena, make_loss
+    rng = np.random.default_rng(H * 100 + W)
+    n = 9
+    patches = rng.normal(size=(n, H, W, channels))
+    patches = (patches / np.linalg.norm(patches, axis=-1, keepdims=True)).astype(np.float16)
+    refs = rng.normal(size=(4, channels)); refs /= np.linalg.norm(refs, axis=-1, keepdims=True)
+    obs_point = rng.integers(0, 4, n).astype(np.int32)
+    prob = dict(obs_image=np.zeros(n, np.int32), obs_point=obs_point, obs_patch=np.arange(n, dtype=np.int64),
+                image_camera=np.zeros(1, np.int32), qvec=np.array([[1.0, 0, 0, 0]]), tvec=np.zeros((1, 3)),
+                cam_model=np.zeros(1, np.int32), cam_params=np.array([[100.0, 50, 50]]), xyz=np.array([[0, 0, 5.0]] * 4), refs=refs)
+    arena = PatchArena.from_numpy(ctx, patches, rng.integers(0, 50, (n, 2)).astype(np.int32))
+    ba = BAProblem(ctx, arena, prob)
+    for kw in (dict(), dict(as_gradientfield=False)):
+        got = ba.extract_costmaps(make_loss("cauchy", [0.25]), **kw).download()[0]
+        want = pxo_costmap.costmaps(patches, prob["obs_patch"], obs_point, refs, loss=("cauchy", 0.25), **kw)
+        _check_maps(got, want)
+        if H == 1 and "as_gradientfield" not in kw:
+            assert np.all(got[..., 1] == 0)
+        if W == 1 and "as_gradientfield" not in kw:
+            assert np.all(got[..., 2] == 0)

@@ -309,8 +309,9 @@ class CostMapExtractor:
         if ref_extractor is None:
             raise ValueError("a ReferenceExtractor is required")                 # Run dereferences it, costmap_extractor.h:141
         ctx = self.ctx or default_context()
-        if any(not fm.is_sparse for fm in feature_set.fmaps.values()):
-            raise ValueError("cost maps of dense feature maps (dense_cut_size windows) are outside the accelerated path")
+        dense = any(not fm.is_sparse for fm in feature_set.fmaps.values())
+        if dense and any(fm.is_sparse for fm in feature_set.fmaps.values()):
+            raise ValueError("a feature set mixing sparse and dense maps is outside the accelerated path")
         wanted = {p for p in reconstruction.point3D_ids() if p < len(problem_labels) and problem_labels[p] >= 0}
         setup = BundleAdjustmentSetup()
         setup.add_images(reconstruction.reg_image_ids())
@@ -321,6 +322,12 @@ class CostMapExtractor:
             return cost_fset, {}
         first = flat.patches[0]
         H, W, C = first.shape
+        if dense:                                      # cost maps of dense_cut_size windows (costmap_extractor.h:50,401-431)
+            if isinstance(first, features.ArenaPatch):
+                raise ValueError("cost maps of device-resident dense maps are not supported: pass host FeatureMap.dense maps")
+            H = W = int(self.config['dense_cut_size'])
+            if any(p.shape[0] < H or p.shape[1] < W for p in flat.patches):
+                raise ValueError("dense_cut_size exceeds a dense feature map")           # THROW_CHECK_LE, featurepatch.cc:342-343
         dtype = first.arena.dtype if isinstance(first, features.ArenaPatch) else first.data.dtype
         costmaps = PatchArena(ctx, n_obs, H, W, self.get_effective_channels(), dtype)
         loss = make_loss(self.config['loss']['name'], self.config['loss']['params'])
@@ -343,7 +350,23 @@ class CostMapExtractor:
             sub = _PointSubset(flat, pts, sorted(i for k in pts for i in obs_of_point[k]))
             arena = features.to_arena(ctx, sub.patches)
             ba = BAProblem(ctx, arena, sub.problem_dict(np.zeros((len(pts), C)), arena.index))
-            references.update(ref_extractor._references_of(ba, sub))
+            references.update(ref_extractor._references_of(ba, sub))             # on the FULL maps, like the reference
+            if dense:
+                # the reference slices a dense_cut_size window around the current reprojection of every observation
+                # (FeaturePatch::Slice / ToCorner, featurepatch.cc:324-359; costmap_extractor.h:210-222) and fills the
+                # cost map from that copy: central differences clamp at the WINDOW border
+                xy = ba.eval(self.interpolation.to_engine(), with_jacobian=False)[0].download()[:, 6:8]
+                windows = []
+                for i, P in enumerate(sub.patches):
+                    uv = xy[i] * P.scale - 0.5 - P.corner
+                    c = np.trunc(uv - H / 2.0).astype(np.int64)                  # Eigen cast<int>: towards zero
+                    x0 = int(min(max(c[0], 0), P.shape[1] - W))
+                    y0 = int(min(max(c[1], 0), P.shape[0] - H))
+                    windows.append(features.FeaturePatch(P.data[y0:y0 + H, x0:x0 + W], (x0, y0), P.scale))
+                refs_host = ba.d["refs"].download()
+                arena.close()
+                arena = features.to_arena(ctx, windows)
+                ba = BAProblem(ctx, arena, sub.problem_dict(refs_host, arena.index))
             ba.extract_costmaps(loss, as_gradientfield=self.config['as_gradientfield'], apply_sqrt=self.config['apply_sqrt'],
                                 out=costmaps, first_out=offset)
             arena.close()                                                        # synchronises the stream first

@@ -381,3 +381,47 @@ def test_costmaps_of_odd_patch_shapes(ctx, H, W, channels):
             assert np.all(got[..., 1] == 0)
         if W == 1 and "as_gradientfield" not in kw:
             assert np.all(got[..., 2] == 0)
+
+
+def test_costmaps_of_dense_feature_maps(ctx):
+    """Dense feature maps (FeatureMap.is_sparse = False): the reference slices a dense_cut_size window around the current
+    reprojection of every observation (FeaturePatch::ToCorner / Slice, featurepatch.cc:324-359; costmap_extractor.h:210-222,
+    401-431) and fills the cost map from that copy; the references come from the full maps."""
+    import pxo
+    import pxo_costmap
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.api import BundleAdjuster, CostMapExtractor, ReferenceExtractor, features
+    from pixsfm_amd.api.bundle_adjustment import find_problem_labels
+    from pixsfm_amd.api.reconstruction import reconstruction_from_flat
+    prob = synthetic.make_ba_problem(n_cams=4, n_points=30, obs_per_point=3, seed=41)     # geometry only
+    rec, patch_of = reconstruction_from_flat(prob)
+    rng = np.random.default_rng(6)
+    h = w = 50
+    scale = np.array([0.05, 0.05])                                                          # 1000 x 1000 images
+    ys, xs = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    freq, phase = rng.uniform(0, 0.25, (128, 2)), rng.uniform(0, 6.28, 128)
+    fmaps, dense = {}, {}
+    for i, im in rec.images.items():
+        m = np.cos(freq[:, 0] * (xs[..., None] + 0.3 * i) + freq[:, 1] * (ys[..., None] - 0.2 * i) + phase)
+        dense[i] = (m / np.linalg.norm(m, axis=-1, keepdims=True)).astype(np.float16)
+        fmaps[im.name] = features.FeatureMap.dense(dense[i], scale)
+    fset = features.FeatureSet(fmaps)
+    ps = 12
+    cost_fset, refs = CostMapExtractor({"dense_cut_size": ps}, {}).run(find_problem_labels(rec, 10), rec, fset, ReferenceExtractor({}, {}))
+    assert cost_fset.arena.H == ps and cost_fset.arena.W == ps and cost_fset.arena.n == len(prob["obs_image"])
+    for (image_id, p2d), _ in patch_of.items():
+        im = rec.images[image_id]
+        cam = rec.cameras[im.camera_id]
+        pid = im.points2D[p2d].point3D_id
+        xy = pxo.world_to_pixel(cam.model_id, np.asarray(cam.params, float), im.qvec, im.tvec, rec.points3D[pid].xyz, jac=False)[0]
+        c = np.trunc(xy * scale - 0.5 - ps / 2.0).astype(int)
+        x0, y0 = int(np.clip(c[0], 0, w - ps)), int(np.clip(c[1], 0, h - ps))
+        want = pxo_costmap.fill_point_costmap(dense[image_id][y0:y0 + ps, x0:x0 + ps], refs[pid].descriptor.reshape(-1))
+        cp = cost_fset.fmap(im.name).fpatch(p2d)
+        got, corner, sc = cost_fset.arena.download(cp.index, 1)
+        assert np.array_equal(corner[0], [x0, y0]) and np.array_equal(sc[0], scale)
+        _check_maps(got[0], want)
+    # and the whole strategy on dense maps
+    s = BundleAdjuster.create({"strategy": "costmaps", "optimizer": {"solver": {"max_num_iterations": 4}}}).refine_multilevel(
+        rec, features.FeatureManager([fset]))["summary"][0]
+    assert s.final_cost < s.initial_cost and s.num_residuals_reduced == 3 * len(prob["obs_image"])

@@ -425,3 +425,22 @@ def test_costmaps_of_dense_feature_maps(ctx):
     s = BundleAdjuster.create({"strategy": "costmaps", "optimizer": {"solver": {"max_num_iterations": 4}}}).refine_multilevel(
         rec, features.FeatureManager([fset]))["summary"][0]
     assert s.final_cost < s.initial_cost and s.num_residuals_reduced == 3 * len(prob["obs_image"])
+
+
+def test_costmap_inner_iterations_on_long_tracks(ctx):
+    """Tracks longer than the 8 lanes a point gets in the cost-map inner-iteration kernel (two passes per evaluation, the
+    tail of the observation data read from global memory instead of the LDS staging): same trajectory as the oracle."""
+    import pxo
+    from pixsfm_amd.engine import interp_cfg, lm_options, make_loss
+    prob, arena, ba = _setup(ctx, n_cams=14, n_points=40, obs_per_point=11, seed=77)
+    cm = ba.extract_costmaps(make_loss("trivial", []))
+    cba = ba.costmap_problem(cm)
+    gauge = _gauge(prob)
+    kw = dict(max_iterations=4, use_inner_iterations=True)
+    s_gpu = cba.solve(interp_cfg(l2_normalize=False), make_loss("cauchy", [0.25]), *gauge, options=lm_options(**kw))
+    q, t, k, X = cba.params()
+    s_cpu, qo, to, ko, Xo = pxo.ba_solve(_costmap_problem(prob, cm.download()[0]), pxo.cfg(l2_normalize=False),
+                                         pxo.loss("cauchy", 0.25), *gauge, pxo.lm_options(**kw))
+    assert s_gpu["iterations"] == s_cpu["iterations"] and s_gpu["num_successful"] == s_cpu["num_successful"]
+    assert abs(s_gpu["final_cost"] - s_cpu["final_cost"]) < 1e-6 * s_cpu["final_cost"]
+    assert np.abs(X - Xo).max() < 1e-6 and np.abs(q - qo).max() < 1e-6

@@ -39,11 +39,15 @@ struct CostmapArgs {
 template <typename ST> struct StorageDiff;
 template <> struct StorageDiff<_Float16> {
   static __device__ __forceinline__ void run(const Texel8<_Float16>& a, const Texel8<_Float16>& b, double out[8]) {
-    union { uint4 u; half8_t h; } x, y;
-    x.u = a.raw; y.u = b.raw;
-    const half8_t d = x.h - y.h;   // v_pk_add_f16: correctly rounded, like half.hpp 2.2.0
+    // four v_pk_add_f16 with the second operand negated (correctly rounded, like half.hpp 2.2.0); written as inline
+    // assembly because the compiler otherwise scalarises the vector subtraction into eight v_sub_f16
+    const unsigned xa[4] = {a.raw.x, a.raw.y, a.raw.z, a.raw.w}, xb[4] = {b.raw.x, b.raw.y, b.raw.z, b.raw.w};
+    union { unsigned u[4]; half8_t h; } d;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) out[i] = (double)d[i];
+    for (int i = 0; i < 4; ++i)
+      asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d.u[i]) : "v"(xa[i]), "v"(xb[i]));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (double)d.h[i];
   }
 };
 template <> struct StorageDiff<float> {

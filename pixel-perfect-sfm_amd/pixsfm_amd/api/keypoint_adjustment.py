@@ -11,9 +11,11 @@ import numpy as np
 
 from .. import _lib
 from ..engine import Context, lm_options, make_loss
-from ..ka_engine import KAProblem
-from ..synthetic_ka import find_problem_labels  # noqa: F401  (same algorithm as main.py:13-57)
+from ..ka_engine import KAProblem, pack_tracks_into_problems
 from . import base, features
+
+# pixsfm's name for the packing of tracks into sub-problems (keypoint_adjustment/main.py:13-57)
+find_problem_labels = pack_tracks_into_problems
 
 _default_ctx = None
 

@@ -17,6 +17,54 @@ def _csr(labels, n_groups):
     return ptr, order.astype(np.int32)
 
 
+def pack_tracks_into_problems(track_labels, max_per_problem, track_edge_counts=None):
+    """Sub-problem label per graph node: whole tracks are packed into sub-problems holding at most
+    `max_per_problem` keypoints (or edges, when `track_edge_counts[track]` gives each track's weight).
+    Drop-in for `find_problem_labels` of pixsfm/keypoint_adjustment/main.py:13-57 -- same (labels, sizes)
+    return value -- which A15's ParallelOptimizer (base/src/parallel_optimizer.h:77-211) and our
+    one-workgroup-per-sub-problem solver both take.  The rule being reproduced:
+      * tracks are visited from the heaviest to the lightest, equal weights in order of first appearance
+        (edge counts: ascending track id);
+      * a track of weight >= the capacity opens a sub-problem of its own;
+      * any other track goes to the first sub-problem with room, the scan starting at the sub-problem the
+        previous track of the SAME weight went to (and at sub-problem 0 for the first track of a weight);
+        without room anywhere it opens a new one;
+      * capacity -1 = the heaviest track.
+    tests/test_cabi_and_host.py checks it against vectors produced by the reference's own function."""
+    labels = np.asarray(track_labels, dtype=np.int64).reshape(-1)
+    if track_edge_counts is None:
+        track_ids, first_seen, weight = np.unique(labels, return_index=True, return_counts=True)
+        visit = np.lexsort((first_seen, -weight))             # weight descending, ties by first appearance
+    else:
+        weight = np.asarray(track_edge_counts, dtype=np.int64).reshape(-1)
+        track_ids = np.arange(len(weight), dtype=np.int64)
+        visit = np.argsort(-weight, kind="stable")
+    n_tracks = len(track_ids)
+    if n_tracks == 0:
+        raise ValueError("no tracks to pack")
+    if track_ids[0] < 0 or track_ids[-1] >= n_tracks or (len(labels) and (labels.min() < 0 or labels.max() >= n_tracks)):
+        raise ValueError("track labels must be the contiguous ids 0 .. n_tracks - 1")
+    capacity = int(weight.max()) if max_per_problem == -1 else int(max_per_problem)
+    occupancy = []                                            # keypoints (edges) per sub-problem
+    problem_of_track = np.full(n_tracks, -1, dtype=np.int64)
+    cursor, weight_class = 0, None
+    for t in visit:
+        w = int(weight[t])
+        if w != weight_class:
+            weight_class, cursor = w, 0
+        slot = len(occupancy)
+        if w < capacity:
+            slot = cursor
+            while slot < len(occupancy) and occupancy[slot] + w > capacity:
+                slot += 1
+        if slot == len(occupancy):
+            occupancy.append(0)
+        occupancy[slot] += w
+        problem_of_track[track_ids[t]] = slot
+        cursor = slot
+    return problem_of_track[labels].tolist(), occupancy
+
+
 class KAProblem:
     """problem: dict with kp (n,2), node_patch, node_const, node_problem, edge_src, edge_dst, edge_w.
     An edge belongs to the sub-problem of its source node (edges are intra-track and a track

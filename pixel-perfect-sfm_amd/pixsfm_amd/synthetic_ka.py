@@ -8,44 +8,7 @@ location + N(0, sigma) px.  Mirrors what pixsfm's extractor produces for sparse 
 import numpy as np
 
 from . import synthetic
-
-
-def find_problem_labels(track_labels, max_per_problem, track_edge_counts=None):
-    """First-fit-decreasing bin packing of tracks into sub-problems -- same algorithm and the
-    same return value as pixsfm/keypoint_adjustment/main.py:13-57 (restated, numpy-free core)."""
-    from collections import Counter
-    import sys
-    if track_edge_counts is None:
-        track_count = Counter(int(t) for t in track_labels)
-    else:
-        track_count = Counter({i: int(v) for i, v in enumerate(track_edge_counts)})
-    if max_per_problem == -1:
-        max_per_problem = max(track_count.values())
-    bins = []
-    track_label_to_problem = [-1] * len(track_count)
-    start = 0
-    last_v = sys.maxsize
-    for k, v in track_count.most_common():
-        if v < last_v:
-            start = 0
-            last_v = v
-        found = False
-        if v < max_per_problem:
-            for i in range(start, len(bins)):
-                if bins[i] + v <= max_per_problem:
-                    bins[i] += v
-                    track_label_to_problem[k] = i
-                    found = True
-                    start = i
-                    break
-        if not found:
-            track_label_to_problem[k] = len(bins)
-            start = len(bins)
-            bins.append(v)
-    problem_labels = [track_label_to_problem[int(v)] for v in track_labels]
-    if -1 in problem_labels:
-        raise ValueError
-    return problem_labels, bins
+from .ka_engine import pack_tracks_into_problems
 
 
 def make_ka_problem(n_tracks=20, track_len=5, channels=128, patch_size=16, seed=1, dtype=np.float16,
@@ -83,7 +46,7 @@ def make_ka_problem(n_tracks=20, track_len=5, channels=128, patch_size=16, seed=
     for t in range(n_tracks):
         ids = np.arange(t * track_len, (t + 1) * track_len)
         node_const[ids[np.argmax(score[ids])]] = 1
-    problem_of_node, bins = find_problem_labels(track_of_node, max_kps_per_problem)
+    problem_of_node, bins = pack_tracks_into_problems(track_of_node, max_kps_per_problem)
     problem_of_node = np.array(problem_of_node, dtype=np.int32)
     return dict(kp=kp0.copy(), node_patch=np.arange(n_nodes, dtype=np.int64), node_const=node_const,
                 node_problem=problem_of_node, edge_src=edge_src, edge_dst=edge_dst, edge_w=edge_w,

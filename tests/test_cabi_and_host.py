@@ -79,7 +79,7 @@ def test_interp_cfg_rejects_configurations_outside_the_path():
 
 def test_find_problem_labels_first_fit_decreasing():
     """keypoint_adjustment/main.py:13-57: every track in one bin, bins <= max unless a single track is larger."""
-    from pixsfm_amd.synthetic_ka import find_problem_labels
+    from pixsfm_amd.api.keypoint_adjustment import find_problem_labels
     rng = np.random.default_rng(0)
     sizes = rng.integers(2, 30, 40)
     track_labels = np.repeat(np.arange(40), sizes)
@@ -95,6 +95,36 @@ def test_find_problem_labels_first_fit_decreasing():
     # max_per_problem == -1: bins sized by the largest track
     _, bins3 = find_problem_labels(np.repeat([0, 1, 2], [7, 5, 2]), -1)
     assert max(bins3) == 7
+
+
+def test_problem_packing_matches_reference_vectors():
+    """pack_tracks_into_problems (our rewrite) against labels / bin sizes produced by the REFERENCE's own
+    find_problem_labels (keypoint_adjustment/main.py:13-57, run by tests/golden/make_golden_packing.py)."""
+    import importlib.util
+    from pixsfm_amd.ka_engine import pack_tracks_into_problems
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden_packing", os.path.join(here, "golden", "make_golden_packing.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gold = np.load(os.path.join(here, "golden", "packing_ref.npz"))
+    n = 0
+    for name, labels, cap, edge_counts in gen.cases():
+        got_labels, got_bins = pack_tracks_into_problems(labels, cap, edge_counts)
+        assert np.array_equal(np.asarray(got_labels), gold[name + "_labels"]), name
+        assert np.array_equal(np.asarray(got_bins), gold[name + "_bins"]), name
+        n += 1
+    assert n >= 40
+    if os.path.exists(gen.SRC):          # build container: also against the reference function run live
+        ref = gen.load_reference_function()
+        rng = np.random.default_rng(5)
+        for _ in range(20):
+            sizes = rng.integers(1, 40, int(rng.integers(1, 200)))
+            labels = rng.permutation(np.repeat(np.arange(len(sizes)), sizes))
+            want = ref([int(v) for v in labels], 50)
+            got = pack_tracks_into_problems(labels, 50)
+            assert list(want[0]) == list(got[0]) and list(want[1]) == list(got[1])
+    with pytest.raises(ValueError):
+        pack_tracks_into_problems(np.array([0, 2, 2]), 50)     # label 1 missing: not contiguous track ids
 
 
 def test_ka_csr_grouping_and_validation():

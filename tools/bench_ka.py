@@ -22,7 +22,8 @@ import torch  # noqa: E402
 
 
 def make_problem_gpu(dev, n_tracks, track_len, C=128, PS=16, seed=1, sigma=1.0, chunk=16384):
-    from pixsfm_amd import synthetic, synthetic_ka
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.ka_engine import pack_tracks_into_problems
     rng = np.random.default_rng(seed)
     n = n_tracks * track_len
     track = np.repeat(np.arange(n_tracks), track_len)
@@ -53,7 +54,7 @@ def make_problem_gpu(dev, n_tracks, track_len, C=128, PS=16, seed=1, sigma=1.0, 
     score = np.zeros(n); np.add.at(score, edge_src, edge_w); np.add.at(score, edge_dst, edge_w)
     node_const = np.zeros(n, np.uint8)
     node_const[(np.arange(n_tracks) * track_len) + score.reshape(n_tracks, track_len).argmax(1)] = 1
-    labels, bins = synthetic_ka.find_problem_labels(track, 50)
+    labels, bins = pack_tracks_into_problems(track, 50)
     return dict(kp=kp0, node_patch=np.arange(n, dtype=np.int64), node_const=node_const,
                 node_problem=np.array(labels, np.int32), edge_src=edge_src, edge_dst=edge_dst, edge_w=edge_w,
                 corners=corners, scales=np.ones((n, 2)), true_xy=true_xy, n_problems=len(bins)), patches

@@ -1,6 +1,6 @@
 """Debug helper: dirty a large part of the device memory (0xFF bytes -> NaN doubles, -1 indices), release it, then run
 the GPU tests in the SAME process, so that every kernel that reads memory it never wrote sees garbage instead of the
-zeros a fresh box usually hands out.  python tools/_poison_then_test.py [GiB] [pytest args...]"""
+zeros a fresh box usually hands out.  python tools/poison_device_memory.py [GiB] [pytest args...]"""
 import sys
 
 import torch

@@ -189,7 +189,17 @@ typedef struct {
                                     (bundle_adjustment/main.py:43 default True; [upstream Ceres]
                                     coordinate descent); ignored by pxr_ka_solve          */
   double inner_iteration_tolerance; /* 1e-3 [upstream]: disabled once the relative gain falls below */
+  /* linear solver of the reduced camera system (BA only; bundle_optimizer.h:180-191 overrides the user's choice
+   * by image count: <= 50 DENSE_SCHUR, <= 1000 SPARSE_SCHUR -- both = exact Schur complement + Cholesky, here the
+   * dense GPU Cholesky -- and above ITERATIVE_SCHUR + SCHUR_JACOBI) */
+  int32_t linear_solver;         /* PXR_LINEAR_AUTO: that rule on view->n_images; _DIRECT / _ITERATIVE force one   */
+  int32_t max_linear_solver_iterations; /* 200 (bundle_adjustment_options.h:55)                                   */
+  double eta;                    /* 0.1 [upstream Solver::Options::eta]: CG stops at i (Q_i - Q_{i-1}) / Q_i < eta,
+                                    Q = x.Sx/2 - x.b (the only test the LM strategy leaves enabled [upstream])    */
+  double linear_r_tolerance;     /* -1 = off like [upstream]; > 0: also stop at |r| <= tol |b| (parity tests)     */
 } pxr_lm_options;
+enum { PXR_LINEAR_AUTO = 0, PXR_LINEAR_DIRECT = 1, PXR_LINEAR_ITERATIVE = 2 };
+#define PXR_MAX_IMAGES_DIRECT 1000 /* kMaxNumImagesDirectSparseSolver, bundle_optimizer.h:179 */
 
 typedef struct {
   int32_t iterations;      /* LM iterations attempted                                   */
@@ -200,12 +210,38 @@ typedef struct {
   double initial_cost, final_cost, final_radius;
   double total_ms;         /* wall time of the LM loop (set-up excluded)                */
   double setup_ms;         /* host-side index construction + allocations                */
+  int32_t linear_solver;   /* PXR_LINEAR_DIRECT / _ITERATIVE actually used (BA)         */
+  int32_t reserved_;
+  int64_t linear_iterations; /* conjugate-gradient iterations summed over the LM attempts (iterative solver)   */
 } pxr_lm_summary;
 
-/* In-place sum over ranks of `count` doubles at device pointer d_buf, enqueued on / ordered
- * with the context's stream (RCCL all-reduce over xGMI in the Python host layer).  NULL for a
- * single GPU.  With N ranks every rank holds ALL images and cameras (replicated) and a
- * disjoint shard of the points with all their observations. */
+/* ---- multi-GPU: one process per GPU ---------------------------------------------
+ * With N ranks every rank holds ALL images and cameras (replicated) and a disjoint shard of the points with
+ * all their observations, patches and references; the only exchange of the BA path is an in-place
+ * all-reduce(sum) of doubles on the context's stream: [S | rhs] per linear solve (direct solver) or one
+ * camera-sized vector per conjugate-gradient iteration (iterative solver), diag(U) | g_c per linearisation and
+ * 16 scalars per LM attempt.  KA / reference extraction shard over independent sub-problems / points and
+ * need no collective during the solve (base/src/parallel_optimizer.h:77-211 is the reference's shape).
+ *
+ * Native path: an RCCL communicator owned by the context.  Rank 0 calls pxr_comm_unique_id and hands the 128
+ * bytes to the other ranks by any side channel (torch.distributed broadcast, a file, MPI, ...); then EVERY
+ * rank calls pxr_comm_init (collective).  librccl is resolved at run time (the copy already loaded by the
+ * process, e.g. PyTorch's, else /opt/rocm/lib/librccl.so.1), so the library has no link-time dependency. */
+#define PXR_COMM_ID_BYTES 128
+int pxr_comm_unique_id(void* h_id /* [PXR_COMM_ID_BYTES] */);
+int pxr_comm_init(pxr_ctx* ctx, const void* h_id, int rank, int nranks);
+int pxr_comm_destroy(pxr_ctx* ctx);
+/* rank / size of the context: set by pxr_comm_init, or by pxr_comm_set_rank when the collective is a
+ * caller-supplied callback (below); (0, 1) by default. */
+int pxr_comm_set_rank(pxr_ctx* ctx, int rank, int nranks);
+int pxr_comm_rank(pxr_ctx* ctx, int* rank, int* nranks);
+/* in-place sum over the ranks of `count` doubles at device pointer d_buf, ordered with the context's stream
+ * (ncclAllReduce on that stream); a no-op on a context without communicator / with one rank. */
+int pxr_comm_allreduce_sum(pxr_ctx* ctx, double* d_buf, int64_t count);
+
+/* Caller-supplied collective (same contract as pxr_comm_allreduce_sum), for hosts that bring their own
+ * transport -- the CPU/gloo tests, MPI.  Passed to pxr_ba_solve it takes precedence over the context's
+ * communicator; NULL = use the communicator (or run single-GPU). */
 typedef int (*pxr_allreduce_fn)(void* user, double* d_buf, int64_t count);
 
 /* Parameterisation (host arrays, bundle_optimizer.h:335-453):
@@ -283,7 +319,9 @@ typedef struct {
   int64_t n_nodes;
   double* d_kp;                   /* [n_nodes][2] keypoints in COLMAP image coordinates   */
   const int64_t* d_node_patch;    /* [n_nodes] patch index in the arena                   */
-  const uint8_t* d_node_const;    /* [n_nodes] 1 = constant (roots, KeypointAdjustmentSetup) */
+  const uint8_t* d_node_const;    /* [n_nodes] 1 = constant (roots, KeypointAdjustmentSetup); 2 = variable WITHOUT box
+                                     bounds: a match destination outside RunSubset's nodes_in_problem, which
+                                     ParameterizeKeypoints never visits (keypoint_optimizer.h:117); 0 = variable */
   int64_t n_edges;
   const int32_t* d_edge_src;      /* [n_edges]                                            */
   const int32_t* d_edge_dst;

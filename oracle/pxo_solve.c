@@ -708,7 +708,7 @@ int pxo_ka_solve_problem_u(pxo_ka_batch* b, const int32_t* nodes, int nn, const 
   int n = 0;
   for (int i = 0; i < nn; ++i) {
     const int64_t nd = nodes[i];
-    if (used[nd] && !b->node_const[nd]) { var_of_node[nd] = n; n += 2; }
+    if (used[nd] && b->node_const[nd] != 1) { var_of_node[nd] = n; n += 2; }
   }
   free(used);
   c.var_of_node = var_of_node; c.n = n;
@@ -728,6 +728,9 @@ int pxo_ka_solve_problem_u(pxo_ka_batch* b, const int32_t* nodes, int nn, const 
     const int v = var_of_node[nd];
     if (v < 0) continue;
     ka_bounds(b, nd, bound, lo + v, hi + v);
+    if (b->node_const[nd] == 2) {   /* destination outside nodes_in_problem: ParameterizeKeypoints skips it (keypoint_optimizer.h:117) */
+      lo[v] = lo[v + 1] = -INFINITY; hi[v] = hi[v + 1] = INFINITY;
+    }
     for (int a = 0; a < 2; ++a) if (x[2 * nd + a] < lo[v + a] || x[2 * nd + a] > hi[v + a]) feasible = 0;
   }
   double* H = (double*)malloc(sizeof(double) * (size_t)n * n); double* A = (double*)malloc(sizeof(double) * (size_t)n * n);

@@ -1,0 +1,420 @@
+// pxr_ba_pcg.hip -- iterative solve of the reduced camera system for scenes with more than
+// PXR_MAX_IMAGES_DIRECT images: what ceres::ITERATIVE_SCHUR + SCHUR_JACOBI does in the reference
+// (bundle_adjustment/src/bundle_optimizer.h:180-191, max_linear_solver_iterations = 200,
+// bundle_adjustment_options.h:55).  [upstream Ceres 2.1: implicit_schur_complement.cc,
+// conjugate_gradients_solver.cc, schur_jacobi_preconditioner.cc, levenberg_marquardt_strategy.cc.]
+//
+// The Schur complement S = U + D_c - sum_p W_p T_p W_p^T is never formed.  With the per-observation blocks
+// W_i = B_i^T M~_i E_i (dc x 3) and T_p = (V_p + D_p)^-1 of the current linearisation (pxr_ba_solve.hip):
+//     S v = sum_img U_img v_img + D_c v  -  sum_i W_i T_p(i) sum_{j in p(i)} W_j^T v_j
+// is two passes over W (one point-major, one image-major: 2 x 192 B per observation at DC = 8) plus a
+// block-diagonal product; U is kept as one dc x dc block per image (n_images x DC x DC doubles instead of the
+// n_c x n_c matrix of the direct path: 8.2 GB at 4000 cameras).  Preconditioner: the block diagonal of S
+// over the pose block of every image and the intrinsics block of every camera -- one joint block where a
+// camera belongs to a single image -- with the point contributions of the block's own observations
+// (a point seen twice by one block adds a cross term the reference's SCHUR_JACOBI has and this one drops).
+// Conjugate gradients with Ceres' termination: Q-based, i (Q_i - Q_{i-1}) / Q_i < eta.
+//
+// Multi-GPU: points are sharded, so every rank owns complete T_p and a partial S v; per CG
+// iteration ONE all-reduce of a camera-sized vector (n_c doubles), per linear solve one of the preconditioner
+// blocks and one of the right-hand side.  All CG vectors are replicated.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "pxr_ba_pcg.h"
+#include "pxr_internal.h"
+
+namespace pxr {
+
+static inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
+#define RC(call) do { int _rc = (call); if (_rc != PXR_OK) return _rc; } while (0)
+
+// ---- u_p = T_p (g_p + sum_j W_j^T v_j): the point-major pass ---------------------------------------------
+__global__ __launch_bounds__(256) void k_pt_u(const SolveDev d, const int64_t* __restrict__ pt_ptr,
+                                              const int* __restrict__ pj, const int4* __restrict__ pcols,
+                                              const double* __restrict__ W, const double* __restrict__ T,
+                                              const double* __restrict__ vec /* [n_c] or NULL */,
+                                              const double* __restrict__ gp /* [n_points][3] or NULL */,
+                                              double* __restrict__ u) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= d.v.n_points) return;
+  double v[3] = {0, 0, 0};
+  if (d.pt_var[p]) {
+    if (gp) { v[0] = gp[3 * p]; v[1] = gp[3 * p + 1]; v[2] = gp[3 * p + 2]; }
+    if (vec) {
+      for (int64_t o = pt_ptr[p]; o < pt_ptr[p + 1]; ++o) {
+        const int64_t i = pj[o];
+        const int4 ci = pcols[o];                     // {pose_off, pose_dim, intr_off, intr_dim}
+        const int dci = ci.y + ci.w;
+        const double* Wi = W + (size_t)i * d.DC * 3;
+        for (int a = 0; a < dci; ++a) {
+          const double x = vec[a < ci.y ? ci.x + a : ci.z + (a - ci.y)];
+          v[0] += Wi[3 * a] * x; v[1] += Wi[3 * a + 1] * x; v[2] += Wi[3 * a + 2] * x;
+        }
+      }
+    }
+    const double* Tp = T + 6 * p;
+    const double t0 = Tp[0] * v[0] + Tp[1] * v[1] + Tp[2] * v[2];
+    const double t1 = Tp[1] * v[0] + Tp[3] * v[1] + Tp[4] * v[2];
+    const double t2 = Tp[2] * v[0] + Tp[4] * v[1] + Tp[5] * v[2];
+    v[0] = t0; v[1] = t1; v[2] = t2;
+  }
+  u[3 * p] = v[0]; u[3 * p + 1] = v[1]; u[3 * p + 2] = v[2];
+}
+
+// ---- out[cols(img)] += sign * sum_{i in chunk} W_i u_p(i): the image-major pass ----------------------------
+// G lanes share one observation (lane a = row a of W_i, one coalesced 24 G-byte read per group), a workgroup
+// walks one chunk of an image's observations and reduces over its groups in LDS: one atomic per (chunk, row).
+template <int G>
+__global__ __launch_bounds__(256) void k_img_wu(const SolveDev d, const ImgChunk* __restrict__ chunks,
+                                                const int4* __restrict__ so, const double* __restrict__ W,
+                                                const double* __restrict__ u, double sign, double* __restrict__ out) {
+  __shared__ double red[256];
+  const ImgChunk ch = chunks[blockIdx.x];
+  const int img = ch.img, cam = d.v.d_image_camera[img];
+  const int dci = d.pose_dim[img] + d.intr_dim[cam];
+  if (dci == 0) return;
+  const int lane_b = threadIdx.x % G, grp = threadIdx.x / G;
+  constexpr int n_grp = 256 / G;
+  double acc = 0.0;
+  for (int64_t o = ch.begin + grp; o < ch.end; o += n_grp) {
+    const int4 s = so[o];                                   // {obs, point, first partner, partners (0 = constant point)}
+    if (s.w == 0 || lane_b >= dci) continue;
+    const double* Wi = W + ((size_t)s.x * d.DC + lane_b) * 3;
+    const double* up = u + 3 * (size_t)s.y;
+    acc += Wi[0] * up[0] + Wi[1] * up[1] + Wi[2] * up[2];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < dci) {
+    double t = 0.0;
+    for (int g = 0; g < n_grp; ++g) t += red[g * G + threadIdx.x];
+    if (t != 0.0) atomicAdd(out + col_index(d, img, cam, threadIdx.x), sign * t);
+  }
+}
+
+// ---- out += U v, U = one dc x dc block per image ------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ublk_matvec(const SolveDev d, const double* __restrict__ Ublk,
+                                                     const double* __restrict__ vec, double* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int img = (int)(t / d.DC), a = (int)(t - (int64_t)img * d.DC);
+  if (img >= d.v.n_images) return;
+  const int cam = d.v.d_image_camera[img];
+  const int dci = d.pose_dim[img] + d.intr_dim[cam];
+  if (a >= dci) return;
+  const double* Ua = Ublk + ((size_t)img * d.DC + a) * d.DC;
+  double acc = 0.0;
+  for (int b = 0; b < dci; ++b) acc += Ua[b] * vec[col_index(d, img, cam, b)];
+  atomicAdd(out + col_index(d, img, cam, a), acc);
+}
+
+// ---- Mloc[img] -= sum_{i in chunk} (W_i T_p) W_i^T: the point part of an image's own diagonal block -------
+template <int G>
+__global__ __launch_bounds__(256) void k_img_block(const SolveDev d, const ImgChunk* __restrict__ chunks,
+                                                   const int4* __restrict__ so, const double* __restrict__ W,
+                                                   const double* __restrict__ T, double* __restrict__ Mloc) {
+  extern __shared__ double red[];                            // [256 / G][G][G]
+  const ImgChunk ch = chunks[blockIdx.x];
+  const int img = ch.img, cam = d.v.d_image_camera[img];
+  const int dci = d.pose_dim[img] + d.intr_dim[cam];
+  if (dci == 0) return;
+  const int lane_b = threadIdx.x % G, grp = threadIdx.x / G;
+  constexpr int n_grp = 256 / G;
+  double acc[G];
+#pragma unroll
+  for (int b = 0; b < G; ++b) acc[b] = 0.0;
+  const int64_t n_it = (ch.end - ch.begin + n_grp - 1) / n_grp;                // uniform trip count: shuffles need every lane
+  for (int64_t it = 0; it < n_it; ++it) {
+    const int64_t o = ch.begin + it * n_grp + grp;
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0, y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    if (o < ch.end) {
+      const int4 s = so[o];
+      if (s.w != 0 && lane_b < dci) {
+        const double* Wi = W + ((size_t)s.x * d.DC + lane_b) * 3;
+        w0 = Wi[0]; w1 = Wi[1]; w2 = Wi[2];
+        const double* Tp = T + 6 * (size_t)s.y;
+        y0 = w0 * Tp[0] + w1 * Tp[1] + w2 * Tp[2];
+        y1 = w0 * Tp[1] + w1 * Tp[3] + w2 * Tp[4];
+        y2 = w0 * Tp[2] + w1 * Tp[4] + w2 * Tp[5];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < G; ++b) {
+      const int src = (threadIdx.x & 63) - lane_b + b;     // lane b of this group (G divides 64)
+      acc[b] += y0 * __shfl(w0, src) + y1 * __shfl(w1, src) + y2 * __shfl(w2, src);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < G; ++b) red[((size_t)grp * G + lane_b) * G + b] = acc[b];
+  __syncthreads();
+  for (int e = threadIdx.x; e < dci * dci; e += blockDim.x) {
+    const int a = e / dci, b = e - a * dci;
+    double t = 0.0;
+    for (int g = 0; g < n_grp; ++g) t += red[((size_t)g * G + a) * G + b];
+    if (t != 0.0) atomicAdd(Mloc + ((size_t)img * d.DC + a) * d.DC + b, -t);
+  }
+}
+
+// ---- preconditioner blocks --------------------------------------------------------------------------------
+// every reduced-system column belongs to exactly one block (col_group[c] = {block, position})
+__global__ __launch_bounds__(256) void k_pre_assemble(const SolveDev d, const int2* __restrict__ col_group,
+                                                      const double* __restrict__ Mloc, double* __restrict__ Gm) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int DC = d.DC;
+  const int img = (int)(t / (DC * DC)), e = (int)(t - (int64_t)img * DC * DC);
+  if (img >= d.v.n_images) return;
+  const int a = e / DC, b = e - a * DC;
+  const int cam = d.v.d_image_camera[img];
+  const int dci = d.pose_dim[img] + d.intr_dim[cam];
+  if (a >= dci || b >= dci) return;
+  const int2 ga = col_group[col_index(d, img, cam, a)], gb = col_group[col_index(d, img, cam, b)];
+  if (ga.x != gb.x) return;
+  const double v = Mloc[((size_t)img * DC + a) * DC + b];
+  if (v != 0.0) atomicAdd(Gm + ((size_t)ga.x * PCG_GS + ga.y) * PCG_GS + gb.y, v);
+}
+
+// One wavefront per block: Gauss-Jordan inversion of the SPD block + damping, lane = row of [A | I].
+__global__ __launch_bounds__(256) void k_pre_invert(int n_groups, const int* __restrict__ group_size,
+                                                    const int* __restrict__ group_cols, const double* __restrict__ damp,
+                                                    double inv_radius, double* __restrict__ Gm, int* __restrict__ fail) {
+  const int g = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (g >= n_groups) return;
+  const int ng = group_size[g];
+  double A[PCG_GS], Iv[PCG_GS];
+  double* Gg = Gm + (size_t)g * PCG_GS * PCG_GS;
+#pragma unroll
+  for (int j = 0; j < PCG_GS; ++j) {
+    A[j] = (lane < ng && j < ng) ? Gg[lane * PCG_GS + j] : 0.0;
+    Iv[j] = (j == lane) ? 1.0 : 0.0;
+  }
+  if (lane < ng) {
+    const double dd = damp[group_cols[g * PCG_GS + lane]] * inv_radius;
+#pragma unroll
+    for (int j = 0; j < PCG_GS; ++j) if (j == lane) A[j] += dd;
+  }
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < PCG_GS; ++k) {
+    if (k < ng) {                                              // uniform over the wavefront
+      const double pivot = __shfl(A[k], k);
+      if (!(pivot > 0.0) || !isfinite(pivot)) bad = true;
+      const double ipiv = 1.0 / pivot;
+      const double f = (lane == k) ? 0.0 : A[k] * ipiv;         // this row's multiplier, taken before column k changes
+#pragma unroll
+      for (int j = 0; j < PCG_GS; ++j) {
+        const double rk = __shfl(A[j], k), ri = __shfl(Iv[j], k);   // pivot row, read before lane k rescales it
+        if (lane == k) { A[j] *= ipiv; Iv[j] *= ipiv; }
+        else { A[j] -= f * rk; Iv[j] -= f * ri; }
+      }
+    }
+  }
+  if (bad && lane == 0) atomicExch(fail, 1);
+  if (lane < ng) {
+#pragma unroll
+    for (int j = 0; j < PCG_GS; ++j) if (j < ng) Gg[lane * PCG_GS + j] = Iv[j];
+  }
+}
+
+// ---- conjugate-gradient vector kernels; device scalars cgs = {rho, rho_prev, p.q, x.b, x.r, r.r, -, -} -------
+__global__ void k_cg_begin(double* __restrict__ cgs) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    cgs[1] = cgs[0];
+    cgs[0] = 0.0; cgs[2] = 0.0; cgs[3] = 0.0; cgs[4] = 0.0; cgs[5] = 0.0;
+  }
+}
+
+// z = M^-1 r, rho = r.z
+__global__ __launch_bounds__(256) void k_pre_apply(int n, const int2* __restrict__ col_group,
+                                                   const int* __restrict__ group_size, const int* __restrict__ group_cols,
+                                                   const double* __restrict__ Ginv, const double* __restrict__ r,
+                                                   double* __restrict__ z, double* __restrict__ cgs) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  double part = 0.0;
+  if (c < n) {
+    const int2 g = col_group[c];
+    const int ng = group_size[g.x];
+    const double* row = Ginv + ((size_t)g.x * PCG_GS + g.y) * PCG_GS;
+    const int* cols = group_cols + (size_t)g.x * PCG_GS;
+    double acc = 0.0;
+    for (int b = 0; b < ng; ++b) acc += row[b] * r[cols[b]];
+    z[c] = acc;
+    part = r[c] * acc;
+  }
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0 && part != 0.0) atomicAdd(cgs + 0, part);
+}
+
+__global__ void k_cg_p_update(int n, int first, const double* __restrict__ z, double* __restrict__ p,
+                              const double* __restrict__ cgs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double beta = first ? 0.0 : cgs[0] / cgs[1];
+  p[i] = first ? z[i] : z[i] + beta * p[i];
+}
+
+// q += D p / radius (after the all-reduce of the partial products), p.q
+__global__ void k_cg_q_finish(int n, const double* __restrict__ damp, double inv_radius, const double* __restrict__ p,
+                              double* __restrict__ q, double* __restrict__ cgs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double part = 0.0;
+  if (i < n) {
+    const double qi = q[i] + damp[i] * inv_radius * p[i];
+    q[i] = qi;
+    part = p[i] * qi;
+  }
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0 && part != 0.0) atomicAdd(cgs + 2, part);
+}
+
+// x += alpha p, r -= alpha q unless the matrix turned out indefinite along p (p.q <= 0: the host stops and keeps x)
+__global__ void k_cg_xr_update(int n, const double* __restrict__ p, const double* __restrict__ q,
+                               const double* __restrict__ b, double* __restrict__ x, double* __restrict__ r,
+                               double* __restrict__ cgs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double pq = cgs[2], rho = cgs[0];
+  const bool ok = pq > 0.0 && isfinite(pq) && rho != 0.0 && isfinite(rho);
+  double xb = 0.0, xr = 0.0, rr = 0.0;
+  if (i < n) {
+    double xi = x[i], ri = r[i];
+    if (ok) {
+      const double alpha = rho / pq;
+      xi += alpha * p[i]; ri -= alpha * q[i];
+      x[i] = xi; r[i] = ri;
+    }
+    xb = xi * b[i]; xr = xi * ri; rr = ri * ri;
+  }
+  xb = wave_sum(xb); xr = wave_sum(xr); rr = wave_sum(rr);
+  if ((threadIdx.x & 63) == 0) { atomicAdd(cgs + 3, xb); atomicAdd(cgs + 4, xr); atomicAdd(cgs + 5, rr); }
+}
+
+__global__ void k_vec_add(int n, const double* __restrict__ a, double* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += a[i];
+}
+
+__global__ void k_dot(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double part = i < n ? a[i] * b[i] : 0.0;
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0 && part != 0.0) atomicAdd(out, part);
+}
+
+// ---- host driver ------------------------------------------------------------------------------------------------
+template <typename F>
+static void launch_by_g(int DC, F&& f) { if (DC <= 8) f(std::integral_constant<int, 8>()); else if (DC <= 16) f(std::integral_constant<int, 16>()); else f(std::integral_constant<int, 32>()); }
+
+int pcg_solve(PcgArgs& a, double inv_radius, const pxr_lm_options* opt, const std::function<int(double*, int64_t)>& ar,
+              PcgResult* res) {
+  hipStream_t st = a.st;
+  const SolveDev& d = a.dv;
+  const int n = d.n_c, DC = d.DC;
+  const int n_img = d.v.n_images;
+  const int64_t n_pts = d.v.n_points;
+  res->iterations = 0; res->ok = false; res->x_dot_r = 0.0;
+  const bool verbose = std::getenv("PXR_VERBOSE") != nullptr;
+
+  // ---- right-hand side b = g_c - sum_i W_i T_p g_p (g_c is already the sum over the ranks) --------------
+  PXR_HIP(hipMemsetAsync(a.b, 0, sizeof(double) * n, st));
+  hipLaunchKernelGGL(k_pt_u, dim3(nblk(n_pts)), dim3(256), 0, st, d, a.pt_ptr, a.part_obs, a.obs_cols, a.W, a.T,
+                     (const double*)nullptr, a.gp, a.u);
+  if (a.n_chunks > 0)
+    launch_by_g(DC, [&](auto G) {
+      hipLaunchKernelGGL(k_img_wu<decltype(G)::value>, dim3((unsigned)a.n_chunks), dim3(256), 0, st, d, a.chunks, a.so, a.W, a.u, -1.0, a.b);
+    });
+  // ---- preconditioner: local blocks = U_img - sum_i Y_i W_i^T, gathered into the column groups ----------
+  PXR_HIP(hipMemcpyAsync(a.Mloc, a.Ublk, sizeof(double) * (size_t)n_img * DC * DC, hipMemcpyDeviceToDevice, st));
+  if (a.n_chunks > 0)
+    launch_by_g(DC, [&](auto G) {
+      constexpr int GG = decltype(G)::value;
+      hipLaunchKernelGGL(k_img_block<GG>, dim3((unsigned)a.n_chunks), dim3(256), sizeof(double) * 256 * GG, st, d, a.chunks, a.so, a.W, a.T, a.Mloc);
+    });
+  PXR_HIP(hipMemsetAsync(a.Gm, 0, sizeof(double) * (size_t)a.n_groups * PCG_GS * PCG_GS, st));
+  hipLaunchKernelGGL(k_pre_assemble, dim3(nblk((int64_t)n_img * DC * DC)), dim3(256), 0, st, d, a.col_group, a.Mloc, a.Gm);
+  RC(hip_check(hipGetLastError(), "pcg set-up kernels"));
+  RC(ar(a.b, n));
+  RC(ar(a.Gm, (int64_t)a.n_groups * PCG_GS * PCG_GS));
+  hipLaunchKernelGGL(k_vec_add, dim3(nblk(n)), dim3(256), 0, st, n, a.gc, a.b);
+  PXR_HIP(hipMemsetAsync(a.d_fail, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_pre_invert, dim3(nblk((int64_t)a.n_groups * 64)), dim3(256), 0, st, a.n_groups, a.group_size, a.group_cols,
+                     a.damp_c, inv_radius, a.Gm, a.d_fail);
+  // ---- x = 0, r = b ------------------------------------------------------------------------------------------
+  PXR_HIP(hipMemsetAsync(a.x, 0, sizeof(double) * n, st));
+  PXR_HIP(hipMemcpyAsync(a.r, a.b, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+  PXR_HIP(hipMemsetAsync(a.cgs, 0, sizeof(double) * 8, st));
+  hipLaunchKernelGGL(k_dot, dim3(nblk(n)), dim3(256), 0, st, n, a.b, a.b, a.cgs + 6);
+  double hs[8];
+  int h_fail = 0;
+  PXR_HIP(hipMemcpyAsync(&h_fail, a.d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+  PXR_HIP(hipMemcpyAsync(hs, a.cgs, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
+  PXR_HIP(hipStreamSynchronize(st));
+  if (h_fail) { if (verbose) fprintf(stderr, "[pxr_ba_solve] pcg: a preconditioner block is not positive definite\n"); return PXR_OK; }
+  const double norm_b = std::sqrt(hs[6]);
+  if (!std::isfinite(norm_b)) return PXR_OK;
+  if (norm_b == 0.0) { res->ok = true; return PXR_OK; }          // x = 0 solves it
+  const double tol_r = opt->linear_r_tolerance > 0.0 ? opt->linear_r_tolerance * norm_b : -1.0;
+  const int max_it = opt->max_linear_solver_iterations > 0 ? opt->max_linear_solver_iterations : 200;
+  double Q0 = 0.0;
+  for (int it = 1; it <= max_it; ++it) {
+    hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(64), 0, st, a.cgs);
+    hipLaunchKernelGGL(k_pre_apply, dim3(nblk(n)), dim3(256), 0, st, n, a.col_group, a.group_size, a.group_cols, a.Gm, a.r, a.z, a.cgs);
+    hipLaunchKernelGGL(k_cg_p_update, dim3(nblk(n)), dim3(256), 0, st, n, it == 1 ? 1 : 0, a.z, a.p, a.cgs);
+    // q = S p (partial over this rank's points)
+    PXR_HIP(hipMemsetAsync(a.q, 0, sizeof(double) * n, st));
+    hipLaunchKernelGGL(k_ublk_matvec, dim3(nblk((int64_t)n_img * DC)), dim3(256), 0, st, d, a.Ublk, a.p, a.q);
+    hipLaunchKernelGGL(k_pt_u, dim3(nblk(n_pts)), dim3(256), 0, st, d, a.pt_ptr, a.part_obs, a.obs_cols, a.W, a.T, a.p,
+                       (const double*)nullptr, a.u);
+    if (a.n_chunks > 0)
+      launch_by_g(DC, [&](auto G) {
+        hipLaunchKernelGGL(k_img_wu<decltype(G)::value>, dim3((unsigned)a.n_chunks), dim3(256), 0, st, d, a.chunks, a.so, a.W, a.u, -1.0, a.q);
+      });
+    RC(hip_check(hipGetLastError(), "pcg matvec kernels"));
+    RC(ar(a.q, n));
+    hipLaunchKernelGGL(k_cg_q_finish, dim3(nblk(n)), dim3(256), 0, st, n, a.damp_c, inv_radius, a.p, a.q, a.cgs);
+    hipLaunchKernelGGL(k_cg_xr_update, dim3(nblk(n)), dim3(256), 0, st, n, a.p, a.q, a.b, a.x, a.r, a.cgs);
+    PXR_HIP(hipMemcpyAsync(hs, a.cgs, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
+    PXR_HIP(hipStreamSynchronize(st));
+    const double rho = hs[0], pq = hs[2], xb = hs[3], xr = hs[4], rr = hs[5];
+    if (!std::isfinite(rho) || rho == 0.0) {                      // [upstream] "Numerical failure. rho = r'z = 0"
+      if (it == 1) return PXR_OK;                                  // res->ok stays false: LINEAR_SOLVER_FAILURE
+      break;
+    }
+    if (!(pq > 0.0) || !std::isfinite(pq)) {                       // [upstream] "Matrix is indefinite": keep the last x
+      if (it == 1) return PXR_OK;
+      break;
+    }
+    res->iterations = it;
+    res->x_dot_r = xr;
+    // Q = x.Sx / 2 - x.b = -(x.b + x.r) / 2 with r = b - S x
+    const double Q1 = -0.5 * (xb + xr);
+    const double zeta = it * (Q1 - Q0) / Q1;
+    if (verbose) fprintf(stderr, "[pxr_ba_solve]   cg %3d |r|/|b| %.3e Q %.9e zeta %.3e\n", it, std::sqrt(rr) / norm_b, Q1, zeta);
+    if (zeta < opt->eta) break;
+    Q0 = Q1;
+    if (tol_r > 0.0 && std::sqrt(rr) <= tol_r) break;
+  }
+  res->ok = res->iterations > 0;
+  return PXR_OK;
+}
+
+// ---- linearisation helpers of the block form of U -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_diag_from_blocks(const SolveDev d, const double* __restrict__ Ublk,
+                                                          double* __restrict__ diag) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int img = (int)(t / d.DC), a = (int)(t - (int64_t)img * d.DC);
+  if (img >= d.v.n_images) return;
+  const int cam = d.v.d_image_camera[img];
+  if (a >= d.pose_dim[img] + d.intr_dim[cam]) return;
+  const double v = Ublk[((size_t)img * d.DC + a) * d.DC + a];
+  if (v != 0.0) atomicAdd(diag + col_index(d, img, cam, a), v);
+}
+
+int pcg_diag_from_blocks(hipStream_t st, const SolveDev& d, const double* Ublk, double* diag) {
+  hipLaunchKernelGGL(k_diag_from_blocks, dim3(nblk((int64_t)d.v.n_images * d.DC)), dim3(256), 0, st, d, Ublk, diag);
+  return hip_check(hipGetLastError(), "k_diag_from_blocks");
+}
+
+}  // namespace pxr

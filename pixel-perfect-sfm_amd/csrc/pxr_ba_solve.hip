@@ -33,24 +33,16 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <vector>
 
+#include "pxr_ba_pcg.h"
+#include "pxr_ba_solve.h"
 #include "pxr_device.h"
 #include "pxr_internal.h"
 
 namespace pxr {
 
-
-struct SolveDev {          // device-side problem description shared by the kernels
-  pxr_ba_view v;           // parameters being linearised (current or candidate)
-  const int* pose_off; const int* pose_dim; const int* tmask;   // per image
-  const int* intr_off; const int* intr_dim; const int* cmask;   // per camera
-  const int* pt_var;                                             // per point
-  const double* scale_c;   // [n_c]   Jacobi scaling, camera side
-  const double* scale_p;   // [n_points][3]
-  int n_c; int DC; int LS; // reduced system size, max camera-side columns, Lrec stride
-  int ldS;                 // leading dimension of the reduced system buffer: n_c + 1 (rhs = last column)
-};
 
 // ---- K_jac ------------------------------------------------------------------------------------
 // The 216-B L record and the 192-B W block of an observation are assembled in LDS (one row per lane)
@@ -169,12 +161,6 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jac(const SolveDev d, const dou
   for (int x = lane; x < n_valid * W3; x += 64) { const int o = x / W3; Wg[x] = Ww[o * WS + (x - o * W3)]; }
 }
 
-// global column index of camera-side column `a` of an observation in image img / camera cam
-__device__ __forceinline__ int col_index(const SolveDev& d, int img, int cam, int a) {
-  const int pd = d.pose_dim[img];
-  return a < pd ? d.pose_off[img] + a : d.intr_off[cam] + (a - pd);
-}
-
 // ---- K_point ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_point(const SolveDev d, const int64_t* __restrict__ pt_ptr,
                                                const int64_t* __restrict__ pt_obs,
@@ -206,14 +192,14 @@ __global__ __launch_bounds__(256) void k_point(const SolveDev d, const int64_t* 
 }
 
 // ---- K_img: U and g_c --------------------------------------------------------------------------
-struct ImgChunk { int img; int64_t begin, end; };
-
 constexpr int IMG_BATCH = 128;   // observations staged in LDS per pass
 
 __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* __restrict__ chunks,
                                              const int64_t* __restrict__ img_obs,
                                              const double* __restrict__ L, double* __restrict__ U,
-                                             double* __restrict__ gc) {
+                                             double* __restrict__ gc, int block_form) {
+  // block_form = 0: U is the dense n_c x n_c matrix (upper triangle), direct solver;
+  // block_form = 1: U is [n_images][DC][DC], the image's full symmetric dc x dc block (iterative solver)
   extern __shared__ double stage[];            // [IMG_BATCH][LS] records, then [256] reduction slots
   const ImgChunk ch = chunks[blockIdx.x];
   const int img = ch.img, cam = d.v.d_image_camera[img];
@@ -256,7 +242,11 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
     for (int s2 = 1; s2 < slices; ++s2) acc += red[s2 * NE + e];
     const int ra = col_index(d, img, cam, a);
     if (is_g) atomicAdd(gc + ra, acc);
-    else atomicAdd(U + (size_t)ra * d.n_c + col_index(d, img, cam, b), acc);
+    else if (block_form) {
+      double* Ub = U + (size_t)img * d.DC * d.DC;
+      atomicAdd(Ub + a * d.DC + b, acc);
+      if (a != b) atomicAdd(Ub + b * d.DC + a, acc);
+    } else atomicAdd(U + (size_t)ra * d.n_c + col_index(d, img, cam, b), acc);
   }
 }
 
@@ -278,17 +268,6 @@ __global__ __launch_bounds__(256) void k_pinv(int64_t n_points, const int* __res
   To[0] = c00 * id; To[1] = c01 * id; To[2] = c02 * id;
   To[3] = (a00 * a22 - a02 * a02) * id; To[4] = (a01 * a02 - a00 * a12) * id;
   To[5] = (a00 * a11 - a01 * a01) * id;
-}
-
-// Y_i = W_i T_p is formed on the fly where it is consumed (row a of observation i)
-__device__ __forceinline__ void y_row(const double* __restrict__ W, const double* __restrict__ T, int64_t i, int a, int DC,
-                                      int64_t pt, double& y0, double& y1, double& y2) {
-  const double* Wi = W + ((size_t)i * DC + a) * 3;
-  const double* Tp = T + 6 * (size_t)pt;
-  const double w0 = Wi[0], w1 = Wi[1], w2 = Wi[2];
-  y0 = w0 * Tp[0] + w1 * Tp[1] + w2 * Tp[2];
-  y1 = w0 * Tp[1] + w1 * Tp[3] + w2 * Tp[4];
-  y2 = w0 * Tp[2] + w1 * Tp[4] + w2 * Tp[5];
 }
 
 // ---- K_schur: S -= Y_i W_j^T (upper), rhs -= Y_i g_p ----------------------------------------------
@@ -482,11 +461,6 @@ __global__ void k_finish_camera_step(int n, const double* __restrict__ x, const 
   if ((threadIdx.x & 63) == 0) atomicAdd(scal_rep + 0, part);
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
-
 // ---- K_backsub: delta_p = -T (g_p + sum_i W_i^T delta_c) ---------------------------------------------
 __global__ __launch_bounds__(256) void k_backsub(const SolveDev d, const int64_t* __restrict__ pt_ptr,
                                                  const int* __restrict__ pj, const int4* __restrict__ pcols,
@@ -616,15 +590,22 @@ __global__ void k_normalize_q(int n, double* __restrict__ q) {
   for (int j = 0; j < 4; ++j) q[4 * i + j] /= nn;   // colmap::Image::NormalizeQvec, bundle_optimizer.h:255
 }
 
-__global__ void k_absmax_unscaled(int64_t n, const double* __restrict__ g, const double* __restrict__ scale,
-                                  double* __restrict__ out) {
+// gradient_tolerance test [upstream: max |g_i| <= tolerance, g in the unscaled variables]: the NUMBER of entries
+// above the tolerance is accumulated instead of the maximum, because a count can be summed over the ranks with the
+// all-reduce(sum) the solver already has (the point gradient is sharded; a rank-local maximum would let the ranks
+// disagree about termination).
+__global__ void k_count_above(int64_t n, const double* __restrict__ g, const double* __restrict__ scale, double tol,
+                              double* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  double v = (i < n) ? fabs(g[i] / scale[i]) : 0.0;
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-  if ((threadIdx.x & 63) == 0) {
-    // non-negative doubles order like their bit patterns
-    atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(v));
-  }
+  double v = (i < n && !(fabs(g[i] / scale[i]) <= tol)) ? 1.0 : 0.0;
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(out, v);
+}
+
+// keep rank 0's copy of a replicated buffer: the other ranks zero theirs before an all-reduce(sum)
+__global__ void k_zero(int64_t n, double* __restrict__ x) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = 0.0;
 }
 
 // ---- host orchestration -----------------------------------------------------------------------------------
@@ -722,6 +703,13 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   const int n_c = off;
   const int DC = std::max(1, dpose_max + dintr_max);
   const int LS = 11 + 2 * DC;
+  // linear solver by image count, like bundle_optimizer.h:180-191 overrides the user's choice
+  PXR_REQUIRE(opt->linear_solver >= PXR_LINEAR_AUTO && opt->linear_solver <= PXR_LINEAR_ITERATIVE,
+              "pxr_ba_solve: unknown linear_solver %d", opt->linear_solver);
+  const bool iterative = n_c > 0 && (opt->linear_solver == PXR_LINEAR_ITERATIVE ||
+                                     (opt->linear_solver == PXR_LINEAR_AUTO && n_img > PXR_MAX_IMAGES_DIRECT));
+  sum->linear_solver = iterative ? PXR_LINEAR_ITERATIVE : PXR_LINEAR_DIRECT;
+  sum->linear_iterations = 0; sum->reserved_ = 0;
   int64_t n_pvar = 0;
   for (int64_t p = 0; p < n_pts; ++p) { pt_var[p] = (!h_point_const[p] && pt_cnt[p + 1] > 0) ? 1 : 0; n_pvar += pt_var[p]; }
   PXR_REQUIRE(n_c > 0 || n_pvar > 0, "pxr_ba_solve: every parameter block is constant");
@@ -758,6 +746,34 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     so_desc[o] = make_int4((int)i, (int)pt, (int)pt_cnt[pt], pt_var[pt] ? (int)(pt_cnt[pt + 1] - pt_cnt[pt]) : 0);
   }
 
+  // preconditioner blocks of the iterative solver: the pose columns of an image and the intrinsics columns of a
+  // camera; one joint block where the camera belongs to a single image (every column in exactly one block)
+  std::vector<int2> col_group;
+  std::vector<int> group_size, group_cols;
+  if (iterative) {
+    PXR_REQUIRE(DC <= PCG_GS, "pxr_ba_solve: %d camera-side columns per observation exceed the preconditioner block size", DC);
+    std::vector<int> cam_users(n_cam, 0);
+    for (int i = 0; i < n_img; ++i) ++cam_users[image_camera[i]];
+    col_group.assign(n_c, make_int2(-1, -1));
+    auto open_group = [&]() { group_size.push_back(0); group_cols.resize(group_cols.size() + PCG_GS, 0); return (int)group_size.size() - 1; };
+    auto add_cols = [&](int g, int first, int count) {
+      for (int a = 0; a < count; ++a) {
+        col_group[first + a] = make_int2(g, group_size[g]);
+        group_cols[(size_t)g * PCG_GS + group_size[g]++] = first + a;
+      }
+    };
+    for (int i = 0; i < n_img; ++i) {
+      const int c = image_camera[i];
+      const bool joint = cam_users[c] == 1 && intr_dim[c] > 0;
+      if (pose_dim[i] == 0 && !joint) continue;
+      const int g = open_group();
+      add_cols(g, pose_off[i], pose_dim[i]);
+      if (joint) add_cols(g, intr_off[c], intr_dim[c]);
+    }
+    for (int c = 0; c < n_cam; ++c)
+      if (cam_users[c] != 1 && intr_dim[c] > 0) add_cols(open_group(), intr_off[c], intr_dim[c]);
+    for (int c = 0; c < n_c; ++c) PXR_REQUIRE(col_group[c].x >= 0, "pxr_ba_solve: internal: column %d in no preconditioner block", c);
+  }
   setup_mark("host structure (CSR, chunks)");
   // ---- device buffers ---------------------------------------------------------------------------
   DevBuf<int> d_pose_off, d_pose_dim, d_tmask, d_intr_off, d_intr_dim, d_cmask, d_pt_var;
@@ -779,7 +795,9 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   RC(Vd0.alloc((size_t)n_pts * 3)); RC(T.alloc((size_t)n_pts * 6));
   RC(W.alloc((size_t)n_obs * DC * 3));
   // S: n_c x (n_c + 1) [S | rhs] + one spare row for the factorisation
-  RC(U.alloc(nc1 * nc1)); RC(S.alloc((nc1 + 1) * (nc1 + 1))); RC(gcd.alloc(2 * nc1)); RC(damp_c.alloc(nc1));
+  // direct solver: dense U and [S | rhs]; iterative solver: one DC x DC block of U per image, nothing quadratic in n_c
+  RC(U.alloc(iterative ? (size_t)n_img * DC * DC : nc1 * nc1)); RC(S.alloc(iterative ? 1 : (nc1 + 1) * (nc1 + 1)));
+  RC(gcd.alloc(2 * nc1)); RC(damp_c.alloc(nc1));
   RC(scale_c.alloc(nc1)); RC(scale_p.alloc((size_t)n_pts * 3)); RC(delta_c.alloc(nc1)); RC(delta_p.alloc((size_t)n_pts * 3));
   RC(rec_a.alloc((size_t)n_obs * PXR_OBS_REC)); RC(rec_b.alloc((size_t)n_obs * PXR_OBS_REC));
   RC(q1.alloc((size_t)n_img * 4)); RC(t1.alloc((size_t)n_img * 3)); RC(k1.alloc((size_t)n_cam * PXR_KPAD)); RC(X1.alloc((size_t)n_pts * 3));
@@ -788,7 +806,15 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   const int ldS = n_c + 1;
   double* rhs = S.p + n_c;          // column n_c of S, stride ldS
   DevBuf<double> xsol, linv;
-  RC(xsol.alloc(nc1)); RC(linv.alloc((size_t)((n_c + 63) / 64 + 1) * 64 * 64));
+  RC(xsol.alloc(nc1)); RC(linv.alloc(iterative ? 1 : (size_t)((n_c + 63) / 64 + 1) * 64 * 64));
+  DevBuf<int2> d_col_group; DevBuf<int> d_group_size, d_group_cols;
+  DevBuf<double> pcg_u, pcg_mloc, pcg_g, pcg_vec, pcg_scal;
+  PcgArgs pcg;
+  if (iterative) {
+    RC(d_col_group.upload(col_group, st)); RC(d_group_size.upload(group_size, st)); RC(d_group_cols.upload(group_cols, st));
+    RC(pcg_u.alloc((size_t)n_pts * 3)); RC(pcg_mloc.alloc((size_t)n_img * DC * DC));
+    RC(pcg_g.alloc(group_size.size() * PCG_GS * PCG_GS)); RC(pcg_vec.alloc(5 * nc1)); RC(pcg_scal.alloc(8));
+  }
   double* diagU = gcd.p; double* gc = gcd.p + nc1;
   DevBuf<int> info_buf;
   RC(info_buf.alloc(1));
@@ -807,13 +833,28 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   pxr_ba_view cand_view = *view;
   cand_view.d_qvec = q1.p; cand_view.d_tvec = t1.p; cand_view.d_cam_params = k1.p; cand_view.d_xyz = X1.p;
 
+  // the collective: the caller's callback if given, else the context's RCCL communicator (pxr_comm_init)
+  const bool multi = allreduce != nullptr || (ctx->comm != nullptr && ctx->nranks > 1);
   auto ar = [&](double* buf, int64_t count) -> int {
-    if (!allreduce) return PXR_OK;
-    if (allreduce(ar_user, buf, count) != 0) return set_error(PXR_EHIP, "pxr_ba_solve: all-reduce callback failed");
-    return PXR_OK;
+    if (allreduce) {
+      if (allreduce(ar_user, buf, count) != 0) return set_error(PXR_EHIP, "pxr_ba_solve: all-reduce callback failed");
+      return PXR_OK;
+    }
+    return comm_allreduce_sum(ctx, buf, count);
+  };
+  // Replicated quantities (camera step, replicated scalars) are computed by every rank from identical inputs, but
+  // with floating-point atomics whose order differs from rank to rank.  To keep the ranks bit-identical -- same
+  // parameters, same accept / reject / terminate decisions, hence the same sequence of collectives -- rank 0's copy
+  // is broadcast: the others zero theirs and join an all-reduce(sum).  Needs the rank (pxr_comm_init / _set_rank).
+  const bool bcast = multi && ctx->nranks > 1;
+  auto from_rank0 = [&](double* buf, int64_t count) -> int {
+    if (!bcast) return PXR_OK;
+    if (ctx->rank != 0) hipLaunchKernelGGL(k_zero, dim3(nblk(count)), dim3(256), 0, st, count, buf);
+    return ar(buf, count);
   };
   auto read_scal = [&](double* h16) -> int {
     RC(ar(scal_sum, 8));
+    RC(from_rank0(scal_rep, 8));
     PXR_HIP(hipMemcpyAsync(h16, scal.p, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
     PXR_HIP(hipStreamSynchronize(st));
     return PXR_OK;
@@ -827,12 +868,13 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     hipLaunchKernelGGL(k_jac, dim3((unsigned)((n_obs + JAC_THREADS - 1) / JAC_THREADS)), dim3(JAC_THREADS),
                        sizeof(double) * (JAC_THREADS / 64) * 64 * (LS + 3 * DC + 1), st, dv, rec, *loss, L.p, W.p);
     hipLaunchKernelGGL(k_point, dim3(nblk(n_pts)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, L.p, V.p, gp.p);
-    PXR_HIP(hipMemsetAsync(U.p, 0, sizeof(double) * nc1 * nc1, st));
+    PXR_HIP(hipMemsetAsync(U.p, 0, sizeof(double) * U.n, st));
     PXR_HIP(hipMemsetAsync(gcd.p, 0, sizeof(double) * 2 * nc1, st));
     if (n_c > 0 && !chunks.empty()) {
       hipLaunchKernelGGL(k_img, dim3((unsigned)chunks.size()), dim3(256), sizeof(double) * ((size_t)IMG_BATCH * LS + 256), st, dv,
-                         d_chunks.p, d_img_obs.p, L.p, U.p, gc);
-      hipLaunchKernelGGL(k_extract_diag, dim3(nblk(n_c)), dim3(256), 0, st, n_c, U.p, diagU);
+                         d_chunks.p, d_img_obs.p, L.p, U.p, gc, iterative ? 1 : 0);
+      if (iterative) RC(pcg_diag_from_blocks(st, dv, U.p, diagU));
+      else hipLaunchKernelGGL(k_extract_diag, dim3(nblk(n_c)), dim3(256), 0, st, n_c, U.p, diagU);
     }
     LAUNCH_CHECK("linearize kernels");
     RC(ar(gcd.p, 2 * (int64_t)nc1));   // global diag(U) and g_c
@@ -843,6 +885,29 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     hipLaunchKernelGGL(k_point_diag, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, V.p, Vd0.p);
     hipLaunchKernelGGL(k_clamp, dim3(nblk(n_pts * 3)), dim3(256), 0, st, n_pts * 3, Vd0.p, opt->min_lm_diagonal, opt->max_lm_diagonal, Vd0.p);
     LAUNCH_CHECK("damping kernels");
+    return PXR_OK;
+  };
+
+  if (iterative) {
+    pcg.st = st; pcg.dv = dv;
+    pcg.chunks = d_schur_chunks.p; pcg.n_chunks = (int)schur_chunks.size(); pcg.so = d_so.p;
+    pcg.pt_ptr = d_pt_ptr.p; pcg.part_obs = d_part_obs.p; pcg.obs_cols = d_obs_cols.p;
+    pcg.W = W.p; pcg.T = T.p; pcg.gp = gp.p; pcg.gc = gc; pcg.damp_c = damp_c.p; pcg.Ublk = U.p;
+    pcg.n_groups = (int)group_size.size(); pcg.col_group = d_col_group.p; pcg.group_size = d_group_size.p;
+    pcg.group_cols = d_group_cols.p;
+    pcg.u = pcg_u.p; pcg.Mloc = pcg_mloc.p; pcg.Gm = pcg_g.p;
+    pcg.x = xsol.p; pcg.r = pcg_vec.p; pcg.p = pcg_vec.p + nc1; pcg.q = pcg_vec.p + 2 * nc1; pcg.z = pcg_vec.p + 3 * nc1;
+    pcg.b = pcg_vec.p + 4 * nc1; pcg.cgs = pcg_scal.p; pcg.d_fail = d_info;
+  }
+  const std::function<int(double*, int64_t)> ar_fn = ar;
+  // gradient_tolerance [upstream]: max-norm of the gradient in the unscaled variables, over ALL ranks
+  auto gradient_below_tolerance = [&](bool* below) -> int {
+    double h[16];
+    PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * 16, st));
+    if (n_c > 0) hipLaunchKernelGGL(k_count_above, dim3(nblk(n_c)), dim3(256), 0, st, (int64_t)n_c, gc, scale_c.p, opt->gradient_tolerance, scal_rep + 4);
+    hipLaunchKernelGGL(k_count_above, dim3(nblk(n_pts * 3)), dim3(256), 0, st, n_pts * 3, gp.p, scale_p.p, opt->gradient_tolerance, scal_sum + 5);
+    RC(read_scal(h));
+    *below = h[5] == 0.0 && h[12] == 0.0;
     return PXR_OK;
   };
 
@@ -895,6 +960,15 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     hipLaunchKernelGGL(k_jacobi_scale, dim3(nblk(n_pts * 3)), dim3(256), 0, st, n_pts * 3, Vd0.p, scale_p.p);
     RC(linearize(rec_cur));
   }
+  if (opt->gradient_tolerance > 0.0) {   // [upstream] the test is also made at iteration 0
+    bool below = false;
+    RC(gradient_below_tolerance(&below));
+    if (below) {
+      sum->termination = PXR_TERM_CONVERGENCE; sum->final_cost = cost; sum->final_radius = opt->initial_radius;
+      sum->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop0).count();
+      return PXR_OK;
+    }
+  }
   double radius = opt->initial_radius, decrease_factor = 2.0;
   int invalid = 0;
   bool reuse_diag = false;
@@ -911,7 +985,21 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     hipLaunchKernelGGL(k_pinv, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, d_pt_var.p, V.p, Vd0.p, inv_radius, T.p);
     PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * 16, st));
     bool ok = true;
-    if (n_c > 0) {
+    double inexact_correction = 0.0;
+    if (n_c > 0 && iterative) {
+      // ITERATIVE_SCHUR: preconditioned conjugate gradients on the implicit Schur complement (pxr_ba_pcg.hip)
+      PcgResult pr;
+      RC(pcg_solve(pcg, inv_radius, opt, ar_fn, &pr));
+      phase(2);
+      sum->linear_iterations += pr.iterations;
+      if (!pr.ok) ok = false;                                 // LINEAR_SOLVER_FAILURE: invalid step
+      // The camera step only approximately solves S x = b; the points are eliminated exactly for that x.  With
+      // e = b - S x:  model cost change = delta.(D^2 delta - g) / 2 + x.e / 2
+      inexact_correction = 0.5 * pr.x_dot_r;
+      PXR_HIP(hipMemsetAsync(d_info, 0, sizeof(int), st));
+      hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, xsol.p, gc, damp_c.p, inv_radius, delta_c.p, scal_rep);
+      RC(from_rank0(delta_c.p, n_c));
+    } else if (n_c > 0) {
       hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, n_c, U.p, (const double*)nullptr, 0.0, (const double*)nullptr, S.p, 1);
       if (use_lds_schur) {
 #define SCHUR_LAUNCH(GG)                                                                                              \
@@ -933,6 +1021,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       RC(chol_factor_solve(st, S.p, n_c, d_info, linv.p, xsol.p));
       phase(2);
       hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, xsol.p, gc, damp_c.p, inv_radius, delta_c.p, scal_rep);
+      RC(from_rank0(delta_c.p, n_c));
     }
     phase(3);
     double model_cost_change = 0, cand_cost = 0, step_norm = 0, x_norm = 0;
@@ -956,12 +1045,15 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       if (n_c > 0 && h_info != 0) ok = false;
       phase(5);
       cand_cost = hs[0];
-      model_cost_change = 0.5 * (hs[1] + hs[8]);     // 0.5 * delta.(D^2 delta - g) == -(J d).(r + J d / 2)
+      model_cost_change = 0.5 * (hs[1] + hs[8]) + inexact_correction;   // 0.5 * delta.(D^2 delta - g) == -(J d).(r + J d / 2)
       step_norm = std::sqrt(hs[2] + hs[9]);
       x_norm = std::sqrt(hs[3] + hs[10]);
-      if (!(model_cost_change > 0.0) || !std::isfinite(model_cost_change) || !std::isfinite(cand_cost)) ok = false;
+      if (!(model_cost_change > 0.0) || !std::isfinite(model_cost_change)) ok = false;
+      // A candidate that cannot be evaluated (check_bounds, a point behind a camera) is NOT an invalid step:
+      // [upstream] sets candidate_cost = DBL_MAX and the step is rejected through the relative decrease.
+      if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
       inner_useful = false;
-      if (ok && do_inner) {
+      if (ok && do_inner && cand_cost < std::numeric_limits<double>::max()) {
         const double cost_before = hs[4];                 // cost at the candidate before the inner iterations
         model_cost_change += cost_before - cand_cost;
         inner_useful = cand_cost < cost;
@@ -996,12 +1088,9 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       radius = std::min(opt->max_radius, radius);
       decrease_factor = 2.0; reuse_diag = false;
       if (opt->gradient_tolerance > 0.0) {
-        PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * 16, st));
-        if (n_c > 0) hipLaunchKernelGGL(k_absmax_unscaled, dim3(nblk(n_c)), dim3(256), 0, st, (int64_t)n_c, gc, scale_c.p, scal_rep + 4);
-        hipLaunchKernelGGL(k_absmax_unscaled, dim3(nblk(n_pts * 3)), dim3(256), 0, st, n_pts * 3, gp.p, scale_p.p, scal_rep + 5);
-        PXR_HIP(hipMemcpyAsync(hs, scal.p, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
-        PXR_HIP(hipStreamSynchronize(st));
-        if (std::max(hs[12], hs[13]) <= opt->gradient_tolerance) { sum->termination = PXR_TERM_CONVERGENCE; break; }
+        bool below = false;
+        RC(gradient_below_tolerance(&below));
+        if (below) { sum->termination = PXR_TERM_CONVERGENCE; break; }
       }
     } else {   // StepRejected
       radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diag = true;

@@ -19,6 +19,8 @@ struct pxr_ctx {
   size_t workspace_bytes = 0;
   void* d_workspace_mat = nullptr;   // grow-only storage of the KA normal-matrix blocks
   size_t workspace_mat_bytes = 0;
+  void* comm = nullptr;          // ncclComm_t of this rank (pxr_comm.cpp), NULL on a single GPU
+  int rank = 0, nranks = 1;
 };
 
 struct pxr_arena {
@@ -39,6 +41,8 @@ inline int hip_check(hipError_t e, const char* what) {
   if (e == hipSuccess) return PXR_OK;
   return set_error(PXR_EHIP, "%s: %s", what, hipGetErrorString(e));
 }
+// in-place all-reduce(sum) on the context's stream through its RCCL communicator (no-op without one)
+int comm_allreduce_sum(pxr_ctx* ctx, double* d_buf, int64_t count, bool even_single_rank = false);
 // pxr_ba_eval with the cost reduction fused into the residual kernel: *d_cost_sum += sum 0.5 rho(|r|^2)
 int ba_eval_with_cost(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
                       int with_jacobian, double* d_rec, double* d_r, double* d_gx, double* d_gy,

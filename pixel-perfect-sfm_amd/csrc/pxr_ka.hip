@@ -424,7 +424,7 @@ __global__ __launch_bounds__(KA_NT) void ka_setup_kernel(const KaArgs a, KaInfo*
   // ---- connected components of the variable nodes (min-label propagation over the edges) ----
   for (int i = tid; i < nloc; i += blockDim.x) {
     const int64_t node = a.v.d_prob_nodes[p.np0 + i];
-    a.label[node] = (a.used[node] && !a.v.d_node_const[node]) ? i : -1;
+    a.label[node] = (a.used[node] && a.v.d_node_const[node] != 1) ? i : -1;
     cnt[i] = 0;
   }
   __syncthreads();
@@ -499,6 +499,9 @@ __global__ __launch_bounds__(KA_NT) void ka_setup_kernel(const KaArgs a, KaInfo*
       if (a.bound > 0.0) {
         ux = fmin(kx + a.bound / sx, ux); uy = fmin(ky + a.bound / sy, uy);
         lx = fmax(kx - a.bound / sx, lx); ly = fmax(ky - a.bound / sy, ly);
+      }
+      if (a.v.d_node_const[node] == 2) {   // a destination keypoint outside nodes_in_problem: ParameterizeKeypoints
+        lx = ly = -INFINITY; ux = uy = INFINITY;   // (keypoint_optimizer.h:117) never visits it -- free, no bounds
       }
       p.lo[v] = lx; p.lo[v + 1] = ly; p.hi[v] = ux; p.hi[v + 1] = uy;
       if (kx < lx || kx > ux || ky < ly || ky > uy) sh_feasible = 0;

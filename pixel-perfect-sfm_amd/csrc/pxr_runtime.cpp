@@ -49,6 +49,7 @@ int pxr_ctx_destroy(pxr_ctx* ctx) {
   // teardown: nothing useful can be done with an error here
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm) (void)pxr_comm_destroy(ctx);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->d_workspace) (void)hipFree(ctx->d_workspace);
   if (ctx->d_workspace_mat) (void)hipFree(ctx->d_workspace_mat);

@@ -44,14 +44,16 @@ class LMOptions(C.Structure):
                 ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
                 ("max_lm_diagonal", C.c_double), ("max_consecutive_invalid_steps", C.c_int32),
                 ("jacobi_scaling", C.c_int32), ("use_inner_iterations", C.c_int32),
-                ("inner_iteration_tolerance", C.c_double)]
+                ("inner_iteration_tolerance", C.c_double), ("linear_solver", C.c_int32),
+                ("max_linear_solver_iterations", C.c_int32), ("eta", C.c_double), ("linear_r_tolerance", C.c_double)]
 
 
 class LMSummary(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("num_successful", C.c_int32), ("termination", C.c_int32),
                 ("num_camera_unknowns", C.c_int32), ("num_point_unknowns", C.c_int64),
                 ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double),
-                ("total_ms", C.c_double), ("setup_ms", C.c_double)]
+                ("total_ms", C.c_double), ("setup_ms", C.c_double), ("linear_solver", C.c_int32),
+                ("reserved_", C.c_int32), ("linear_iterations", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -120,7 +122,15 @@ _SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "pxr_ba_cost": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Loss), C.POINTER(C.c_double)]),
+    "pxr_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "pxr_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "pxr_comm_destroy": (C.c_int, [C.c_void_p]),
+    "pxr_comm_set_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "pxr_comm_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pxr_comm_allreduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
 }
+LINEAR_AUTO, LINEAR_DIRECT, LINEAR_ITERATIVE = 0, 1, 2
+COMM_ID_BYTES = 128
 
 _lib = None
 

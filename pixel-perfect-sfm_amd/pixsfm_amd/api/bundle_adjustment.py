@@ -127,7 +127,12 @@ class _FlatBA:
     AddImageToProblem for every image of the setup, AddPointToProblem for the extra variable / constant
     points (observations in images outside the setup get a constant pose, :299-333)."""
 
-    def __init__(self, reconstruction, setup, feature_view, options=None, point_filter=None):
+    def __init__(self, reconstruction, setup, feature_view, options=None, point_filter=None, extractor=False):
+        """extractor=True: the read-only use by ReferenceExtractor / CostMapExtractor -- the reconstruction is const
+        there (no NormalizeQvec; the rotation normalises q itself) and an observation without a patch is skipped like
+        GetVisibleObservations does (reference_extractor.h:171-213).  extractor=False: the optimiser's SetUp, where a
+        missing patch is an error (feature_view.GetFeaturePatch / references.at throw,
+        feature_reference_bundle_optimizer.h:100-108)."""
         rec = reconstruction
         opt = options or {}
         min_track_length = opt.get('min_track_length', -1)
@@ -146,7 +151,10 @@ class _FlatBA:
         def add_obs(image_id, p2d_idx, point3D_id):
             im = rec.images[image_id]
             if not feature_view.has_fpatch(image_id, p2d_idx):
-                return
+                if extractor:
+                    return
+                raise ValueError("no feature patch for observation (image %d, point2D %d) of point3D %d"
+                                 % (image_id, p2d_idx, point3D_id))
             obs_image.append(idx_of(img_idx, self.image_ids, image_id))
             idx_of(cam_idx, self.camera_ids, im.camera_id)
             obs_point.append(idx_of(pt_idx, self.point_ids, point3D_id))
@@ -156,7 +164,8 @@ class _FlatBA:
 
         for image_id in sorted(setup.image_ids):                          # AddImageToProblem, :247-275
             im = rec.images[image_id]
-            im.qvec = np.asarray(im.qvec, dtype=np.float64) / np.linalg.norm(im.qvec)      # NormalizeQvec :255
+            if not extractor:
+                im.qvec = np.asarray(im.qvec, dtype=np.float64) / np.linalg.norm(im.qvec)  # NormalizeQvec :255
             for p2d_idx, p2d in enumerate(im.points2D):
                 if not p2d.has_point3D():
                     continue
@@ -175,9 +184,21 @@ class _FlatBA:
                     continue
                 self.outside_images.add(el.image_id)
                 add_obs(el.image_id, el.point2D_idx, pid)
-        self.obs_image = np.array(obs_image, np.int32)
-        self.obs_point = np.array(obs_point, np.int32)
-        self.patches = patches
+        # Observation order: point-major, and inside a point the order of Track().Elements() -- what
+        # ComputeReference iterates (reference_extractor.h:239-247: `distances.minCoeff(&ref_idx)` = FIRST minimum in
+        # track order, Reference.observations in track order).  Point-major is also what the residual kernel wants:
+        # consecutive observations share their reference descriptor in L2.
+        track_pos = {}
+        for pid in self.point_ids:
+            for k, el in enumerate(rec.points3D[pid].track.elements):
+                track_pos.setdefault((pid, el.image_id, el.point2D_idx), k)
+        rank = np.array([track_pos.get((self.point_ids[pt], im, p2d), 1 << 30)
+                         for pt, (im, p2d) in zip(obs_point, self.obs_keys)], dtype=np.int64)
+        order = np.lexsort((rank, np.array(obs_point, dtype=np.int64))) if obs_point else np.zeros(0, np.int64)
+        self.obs_image = np.array(obs_image, np.int32)[order]
+        self.obs_point = np.array(obs_point, np.int32)[order]
+        self.patches = [patches[i] for i in order]
+        self.obs_keys = [self.obs_keys[i] for i in order]
         n_img, n_cam, n_pt = len(self.image_ids), len(self.camera_ids), len(self.point_ids)
         self.image_camera = np.array([cam_idx[rec.images[i].camera_id] for i in self.image_ids], np.int32)
         self.qvec = np.array([rec.images[i].qvec for i in self.image_ids], np.float64).reshape(n_img, 4)
@@ -248,7 +269,7 @@ class ReferenceExtractor:
         wanted = {p for p in reconstruction.point3D_ids() if p < len(problem_labels) and problem_labels[p] >= 0}
         setup = BundleAdjustmentSetup()
         setup.add_images(reconstruction.reg_image_ids())
-        flat = _FlatBA(reconstruction, setup, FeatureView(feature_set, reconstruction), point_filter=wanted)
+        flat = _FlatBA(reconstruction, setup, FeatureView(feature_set, reconstruction), point_filter=wanted, extractor=True)
         if len(flat.obs_image) == 0:
             return {}
         arena = features.to_arena(ctx, flat.patches)
@@ -315,7 +336,7 @@ class CostMapExtractor:
         wanted = {p for p in reconstruction.point3D_ids() if p < len(problem_labels) and problem_labels[p] >= 0}
         setup = BundleAdjustmentSetup()
         setup.add_images(reconstruction.reg_image_ids())
-        flat = _FlatBA(reconstruction, setup, FeatureView(feature_set, reconstruction), point_filter=wanted)   # host lists only
+        flat = _FlatBA(reconstruction, setup, FeatureView(feature_set, reconstruction), point_filter=wanted, extractor=True)   # host lists only
         cost_fset = features.FeatureSet(channels=self.get_effective_channels())
         n_obs = len(flat.obs_image)
         if n_obs == 0:

@@ -128,7 +128,7 @@ class FeatureMetricKeypointOptimizer:
         self._summary = None
         self._used = False
 
-    def _run(self, problem_labels, keypoints, graph, track_labels, root_labels, feature_set):
+    def _run(self, problem_labels, keypoints, graph, track_labels, root_labels, feature_set, nodes_in_problem=None):
         if keypoints is None:
             raise ValueError("keypoints cannot be NULL.")                       # topological_keypoint_optimizer.h:73-74
         if self._used:
@@ -139,15 +139,27 @@ class FeatureMetricKeypointOptimizer:
             raise ValueError("label arrays must have one entry per graph node")  # THROW_CHECK_EQ, featuremetric_keypoint_optimizer.h:82-85
         ctx = self.ctx or default_context()
         o = self.options
-        src, dst, w = build_edges(graph, keypoints, track_labels, root_labels, None, o['weight_by_sim'],
+        src, dst, w = build_edges(graph, keypoints, track_labels, root_labels, nodes_in_problem, o['weight_by_sim'],
                                   o['root_edges_only'], o['root_regularize_weight'])
         names = [graph.image_id_to_name[nd.image_id] for nd in graph.nodes]
         kp = np.array([keypoints[nm][nd.feature_idx] for nm, nd in zip(names, graph.nodes)], dtype=np.float64).reshape(-1, 2)
         patches = [feature_set.fmap(nm).fpatch(nd.feature_idx) for nm, nd in zip(names, graph.nodes)]
         arena = features.to_arena(ctx, patches)
         labels = np.zeros(n, np.int32) if problem_labels is None else np.asarray(problem_labels, dtype=np.int32)
-        prob = dict(kp=kp, node_patch=arena.index,
-                    node_const=np.array([self.setup.is_node_constant(nd) for nd in graph.nodes], np.uint8),
+        node_const = np.array([self.setup.is_node_constant(nd) for nd in graph.nodes], np.uint8)
+        if nodes_in_problem is not None:
+            # RunSubset enumerates the out-matches of nodes_in_problem only (topological_keypoint_optimizer.h:108-113) but
+            # a match's destination becomes a parameter block wherever it lies; ParameterizeKeypoints
+            # (keypoint_optimizer.h:117) visits nodes_in_problem only, so such a keypoint is neither held constant nor boxed
+            labels = np.full(n, -1, dtype=np.int32)
+            inside = np.zeros(n, bool)
+            inside[np.fromiter(nodes_in_problem, dtype=np.int64)] = True
+            touched = np.zeros(n, bool)
+            touched[np.asarray(src, dtype=np.int64)] = True
+            touched[np.asarray(dst, dtype=np.int64)] = True
+            labels[inside | touched] = 0
+            node_const[touched & ~inside] = 2
+        prob = dict(kp=kp, node_patch=arena.index, node_const=node_const,
                     node_problem=labels, edge_src=np.array(src, np.int32), edge_dst=np.array(dst, np.int32),
                     edge_w=np.array(w, np.float64))
         ka = KAProblem(ctx, arena, prob)
@@ -167,9 +179,8 @@ class FeatureMetricKeypointOptimizer:
     def run_subset(self, nodes_in_problem, keypoints, graph, track_labels, root_labels, feature_set):
         """RunSubset (featuremetric_keypoint_optimizer.h:116-137): one problem over the given node indices only
         (what ParallelOptimizer hands to each worker); the other keypoints are left untouched."""
-        labels = np.full(len(graph.nodes), -1, dtype=np.int32)
-        labels[np.fromiter(nodes_in_problem, dtype=np.int64)] = 0
-        self._run(labels, keypoints, graph, track_labels, root_labels, feature_set)
+        self._run(None, keypoints, graph, track_labels, root_labels, feature_set,
+                  nodes_in_problem=sorted(int(i) for i in nodes_in_problem))
         return self._summary
 
     def run(self, *args):

@@ -40,6 +40,36 @@ class Context:
             self.lib.pxr_ctx_destroy(self.handle)
             self.handle = None
 
+    # -- multi-GPU ----------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes from rank 0 (ncclGetUniqueId) that every rank passes to comm_init."""
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        check(_lib.load().pxr_comm_unique_id(buf), "pxr_comm_unique_id")
+        return bytes(buf.raw)
+
+    def comm_init(self, unique_id, rank, nranks):
+        """Collective: creates this context's RCCL communicator (ncclCommInitRank on its device)."""
+        assert len(unique_id) == _lib.COMM_ID_BYTES
+        check(self.lib.pxr_comm_init(self.handle, C.c_char_p(bytes(unique_id)), int(rank), int(nranks)), "pxr_comm_init")
+
+    def comm_set_rank(self, rank, nranks):
+        """Rank / size when the collective is a caller-supplied callback (gloo tests, MPI)."""
+        check(self.lib.pxr_comm_set_rank(self.handle, int(rank), int(nranks)), "pxr_comm_set_rank")
+
+    def comm_rank(self):
+        r, n = C.c_int(), C.c_int()
+        check(self.lib.pxr_comm_rank(self.handle, C.byref(r), C.byref(n)), "pxr_comm_rank")
+        return r.value, n.value
+
+    def comm_destroy(self):
+        check(self.lib.pxr_comm_destroy(self.handle), "pxr_comm_destroy")
+
+    def allreduce_sum(self, array):
+        """In-place sum over the ranks of a float64 DeviceArray through the context's communicator."""
+        assert array.dtype == np.float64
+        check(self.lib.pxr_comm_allreduce_sum(self.handle, array.ptr, array.nbytes // 8), "pxr_comm_allreduce_sum")
+
     def __del__(self):
         try:
             self.close()
@@ -259,7 +289,8 @@ def make_loss(name="cauchy", params=(0.25,)):
 def lm_options(max_iterations=100, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0,
                initial_radius=1e4, max_radius=1e16, min_radius=1e-32, min_relative_decrease=1e-3,
                min_lm_diagonal=1e-6, max_lm_diagonal=1e32, max_consecutive_invalid_steps=10, jacobi_scaling=1,
-               use_inner_iterations=False, inner_iteration_tolerance=1e-3, **ignored):
+               use_inner_iterations=False, inner_iteration_tolerance=1e-3, linear_solver="auto",
+               max_linear_solver_iterations=200, eta=0.1, linear_r_tolerance=-1.0, **ignored):
     """Subset of ceres::Solver::Options the engine honours (pixsfm/base/main.py:9-22 +
     bundle_adjustment_options.h:48-64); unknown keys are ignored like pyceres ignores nothing --
     callers should pass only what they need."""
@@ -267,7 +298,22 @@ def lm_options(max_iterations=100, function_tolerance=0.0, gradient_tolerance=0.
                           float(parameter_tolerance), float(initial_radius), float(max_radius), float(min_radius),
                           float(min_relative_decrease), float(min_lm_diagonal), float(max_lm_diagonal),
                           int(max_consecutive_invalid_steps), int(jacobi_scaling), int(bool(use_inner_iterations)),
-                          float(inner_iteration_tolerance))
+                          float(inner_iteration_tolerance), _linear_solver_id(linear_solver),
+                          int(max_linear_solver_iterations), float(eta), float(linear_r_tolerance))
+
+
+def _linear_solver_id(name):
+    """"auto": by image count like bundle_optimizer.h:180-191 (<= 1000 images: Schur complement + Cholesky;
+    more: ITERATIVE_SCHUR).  Ceres' names are accepted: DENSE_SCHUR / SPARSE_SCHUR -> direct, ITERATIVE_SCHUR."""
+    if isinstance(name, int):
+        return int(name)
+    key = str(name).lower()
+    table = {"auto": _lib.LINEAR_AUTO, "direct": _lib.LINEAR_DIRECT, "dense_schur": _lib.LINEAR_DIRECT,
+             "sparse_schur": _lib.LINEAR_DIRECT, "iterative": _lib.LINEAR_ITERATIVE,
+             "iterative_schur": _lib.LINEAR_ITERATIVE}
+    if key not in table:
+        raise ValueError("unknown linear solver %r (auto, direct, iterative)" % (name,))
+    return table[key]
 
 
 class BAProblem:

@@ -1,19 +1,105 @@
 """Multi-GPU partitioning of the hot path: one process per GPU.
 
 BA: points -- with all their observations, patches and reference descriptors -- are
-partitioned over the ranks; images and cameras are replicated.  Each rank forms its partial
-reduced camera system S_r = U_r - sum_p W_p T_p W_p^T and right-hand side; ONE all-reduce
-(sum) of the packed [S | rhs] buffer over RCCL/xGMI per linear solve, plus small all-reduces
-of diag(U)/g_c per linearisation and of 8 scalars per LM attempt.  Every rank then solves
-the (replicated) reduced system and back-substitutes its own points.
-KA: tracks are independent (edges are intra-track only), so problems are simply dealt out
-to ranks and no collective is needed during the solve.
+partitioned over the ranks; images and cameras are replicated.  Direct solver: each rank forms
+its partial reduced camera system S_r = U_r - sum_p W_p T_p W_p^T and right-hand side, ONE
+all-reduce (sum) of the packed [S | rhs] buffer per linear solve; iterative solver (> 1000
+images): one all-reduce of a camera-sized vector per conjugate-gradient iteration.  Plus small
+all-reduces of diag(U) | g_c per linearisation and of 16 scalars per LM attempt.  Every rank
+then holds the (replicated) camera step and back-substitutes its own points.
+KA and reference extraction: sub-problems / points are independent (edges are intra-track only,
+base/src/parallel_optimizer.h:77-211 is the reference's own shape), so they are dealt out to the
+ranks; no collective during the solve, one gather of disjoint rows at the end.
 
-torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" in the CPU tests) is plumbing.
+The collective of the BA path is native: an RCCL communicator owned by the engine's Context
+(pxr_comm_init, ncclAllReduce on the context's stream).  torch.distributed is only the side
+channel that carries the 128-byte communicator id and the host-side gathers -- and, in the CPU
+tests (backend "gloo"), the transport behind the callback form of the collective.
 """
 import numpy as np
 
 
+# ---- process group plumbing ----------------------------------------------------------------
+def world(group=None):
+    """(rank, world size) of torch.distributed, or (0, 1) when it is not initialised."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return 0, 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def init_native_comm(ctx, group=None):
+    """Give `ctx` its RCCL communicator: rank 0 draws the id (ncclGetUniqueId), torch.distributed carries the
+    128 bytes to the other ranks, every rank joins ncclCommInitRank.  Returns (rank, world size)."""
+    import torch.distributed as dist
+    rank, n = world(group)
+    if n == 1:
+        return rank, n
+    box = [ctx.comm_unique_id() if rank == 0 else None]
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast_object_list(box, src=src, group=group)
+    ctx.comm_init(box[0], rank, n)
+    return rank, n
+
+
+class _CudaArrayView:
+    """Wraps a raw device pointer so torch.as_tensor can alias it (no copy)."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 3, "strides": None}
+
+
+def make_allreduce(group=None, ctx=None):
+    """all-reduce(sum) CALLBACK for BAProblem.solve over torch.distributed -- the transport-agnostic form of the
+    collective (gloo in the tests, or any backend torch offers).  On MI355X prefer init_native_comm(): the
+    solver then calls ncclAllReduce itself and no Python runs inside the LM loop.
+
+    nccl backend: the collective is enqueued on torch's current stream, which must be the stream the engine's
+    Context was created on.  gloo backend (several ranks sharing one GPU / CPU transport): the buffer is staged
+    through the host; pass `ctx` so the copies are ordered with the engine's stream."""
+    import torch
+    import torch.distributed as dist
+    backend = dist.get_backend(group)
+
+    def allreduce(ptr, count):
+        t = torch.as_tensor(_CudaArrayView(ptr, count), device="cuda")
+        if backend == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return
+        if ctx is not None:
+            ctx.sync()
+        else:
+            torch.cuda.synchronize()
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        torch.cuda.synchronize()
+
+    return allreduce
+
+
+def allreduce_host(array, group=None):
+    """Sum a host numpy array over the ranks (in place; gathers of disjoint rows are sums with zeros elsewhere)."""
+    import torch
+    import torch.distributed as dist
+    rank, n = world(group)
+    if n == 1:
+        return array
+    t = torch.from_numpy(array)
+    if dist.get_backend(group) == "nccl":
+        d = t.cuda()
+        dist.all_reduce(d, group=group)
+        t.copy_(d.cpu())
+    else:
+        dist.all_reduce(t, group=group)
+    return array
+
+
+# ---- BA: points sharded, cameras replicated ---------------------------------------------------
 def balanced_ranges(weights, world):
     """Contiguous ranges [lo, hi) of items with ~equal total weight (observations per point)."""
     w = np.asarray(weights, dtype=np.int64)
@@ -45,32 +131,22 @@ def shard_ba_problem(problem, rank, world):
         if k in problem and problem[k] is not None:
             shard[k] = np.asarray(problem[k])[patch_ids]
     shard["xyz"] = np.asarray(problem["xyz"])[lo:hi].copy()
-    shard["refs"] = np.asarray(problem["refs"])[lo:hi].copy()
+    if problem.get("refs") is not None:
+        shard["refs"] = np.asarray(problem["refs"])[lo:hi].copy()
+    shard["obs_ids"] = sel
     return shard, pt_ids
 
 
-class _CudaArrayView:
-    """Wraps a raw device pointer so torch.as_tensor can alias it (no copy)."""
-
-    def __init__(self, ptr, count):
-        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False),
-                                         "version": 3, "strides": None}
-
-
-def make_allreduce(group=None):
-    """all-reduce(sum) callback for BAProblem.solve over torch.distributed (RCCL on MI355X).
-    The collective is enqueued on torch's current stream, which must be the stream the
-    engine's Context was created on."""
-    import torch
-    import torch.distributed as dist
-
-    def allreduce(ptr, count):
-        t = torch.as_tensor(_CudaArrayView(ptr, count), device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-
-    return allreduce
+def gather_rows(local_rows, row_ids, n_rows, group=None):
+    """Every rank contributes `local_rows` for the disjoint `row_ids`; returns the (n_rows, ...) array of all ranks'
+    rows on every rank (rows nobody owns stay zero).  One all-reduce(sum) with zeros elsewhere: exact."""
+    local_rows = np.asarray(local_rows)
+    full = np.zeros((int(n_rows),) + local_rows.shape[1:], dtype=local_rows.dtype)
+    full[np.asarray(row_ids, dtype=np.int64)] = local_rows
+    return allreduce_host(full, group)
 
 
+# ---- KA: independent sub-problems dealt to the ranks ---------------------------------------------------
 def assign_problems_to_ranks(problem_sizes, world):
     """KA: longest-processing-time assignment of independent sub-problems (sizes = #edges) to
     ranks; returns rank index per problem."""
@@ -82,3 +158,103 @@ def assign_problems_to_ranks(problem_sizes, world):
         owner[i] = r
         load[r] += int(problem_sizes[i])
     return owner
+
+
+def shard_ka_problem(problem, rank, world):
+    """The sub-problems of a flat KA problem (ka_engine.KAProblem's dict) owned by `rank`, as a flat problem of its
+    own: nodes / edges / patches re-indexed, sub-problems renumbered 0 .. n_local - 1.  Returns
+    (shard dict, global node ids of the shard's nodes).  Nodes outside every sub-problem (label -1) belong to nobody."""
+    node_problem = np.asarray(problem["node_problem"], dtype=np.int64)
+    edge_src = np.asarray(problem["edge_src"], dtype=np.int64)
+    edge_dst = np.asarray(problem["edge_dst"], dtype=np.int64)
+    n_prob = int(node_problem.max()) + 1 if len(node_problem) else 0
+    ep = node_problem[edge_src] if len(edge_src) else np.zeros(0, np.int64)
+    sizes = np.bincount(ep[ep >= 0], minlength=n_prob) if n_prob else np.zeros(0, np.int64)
+    unary_node = problem.get("unary_node")
+    if unary_node is not None and len(unary_node):
+        up = node_problem[np.asarray(unary_node, dtype=np.int64)]
+        sizes = sizes + np.bincount(up[up >= 0], minlength=n_prob)
+    owner = assign_problems_to_ranks(sizes, world)
+    mine = np.nonzero(owner == rank)[0]
+    new_label = np.full(n_prob + 1, -1, dtype=np.int64)
+    new_label[mine] = np.arange(len(mine))
+    node_sel = np.nonzero((node_problem >= 0) & (new_label[node_problem] >= 0))[0]
+    new_node = np.full(len(node_problem), -1, dtype=np.int64)
+    new_node[node_sel] = np.arange(len(node_sel))
+    edge_sel = np.nonzero(new_node[edge_src] >= 0)[0] if len(edge_src) else np.zeros(0, np.int64)
+    node_patch = np.asarray(problem["node_patch"], dtype=np.int64)[node_sel]
+    shard = dict(kp=np.asarray(problem["kp"], dtype=np.float64)[node_sel].copy(),
+                 node_patch=np.arange(len(node_sel), dtype=np.int64),
+                 node_const=np.asarray(problem["node_const"], dtype=np.uint8)[node_sel],
+                 node_problem=new_label[node_problem[node_sel]].astype(np.int32),
+                 edge_src=new_node[edge_src[edge_sel]].astype(np.int32),
+                 edge_dst=new_node[edge_dst[edge_sel]].astype(np.int32),
+                 edge_w=np.asarray(problem["edge_w"], dtype=np.float64)[edge_sel],
+                 patch_ids=node_patch, edge_ids=edge_sel)
+    if len(edge_sel) and (shard["edge_dst"] < 0).any():
+        raise ValueError("an edge connects two different sub-problems")
+    for k in ("patches", "corners", "scales"):
+        if k in problem and problem[k] is not None:
+            shard[k] = np.asarray(problem[k])[node_patch]
+    if unary_node is not None and len(unary_node):
+        usel = np.nonzero(new_node[np.asarray(unary_node, dtype=np.int64)] >= 0)[0]
+        shard["unary_node"] = new_node[np.asarray(unary_node, dtype=np.int64)[usel]].astype(np.int32)
+        shard["unary_ref"] = np.asarray(problem["unary_ref"])[usel]
+        if problem.get("unary_w") is not None:
+            shard["unary_w"] = np.asarray(problem["unary_w"])[usel]
+    return shard, node_sel
+
+
+def ka_solve_sharded(ctx, problem, cfg, loss, bound=4.0, options=None, group=None, arena=None):
+    """KA over the ranks of `group`: this rank solves its share of the sub-problems on its GPU (pxr_ka_solve), then
+    the refined keypoints (disjoint rows) are gathered.  `problem` is the GLOBAL flat problem on every rank (host
+    arrays; `patches` may be omitted when `arena` -- an arena holding this rank's patches in shard order, built by
+    the caller from shard["patch_ids"] -- is given).  Returns (keypoints of all nodes, summed summary dict)."""
+    from .engine import PatchArena
+    from .ka_engine import KAProblem
+    rank, n = world(group)
+    shard, node_ids = shard_ka_problem(problem, rank, n)
+    own_arena = arena is None
+    if own_arena:
+        arena = PatchArena.from_numpy(ctx, shard["patches"], shard["corners"], shard["scales"])
+    kp = np.asarray(problem["kp"], dtype=np.float64).copy()
+    summary = dict(iterations=0, num_successful=0, initial_cost=0.0, final_cost=0.0, total_ms=0.0)
+    if len(node_ids):
+        ka = KAProblem(ctx, arena, shard)
+        total, _ = ka.solve(cfg, loss, bound=bound, options=options)
+        local = ka.keypoints()
+        for k in summary:
+            summary[k] = total[k]
+    else:
+        local = np.zeros((0, 2))
+    if own_arena:
+        arena.close()
+    if n > 1:
+        owned = np.zeros(len(kp), dtype=np.float64)
+        owned[node_ids] = 1.0
+        gathered = gather_rows(local, node_ids, len(kp), group)
+        owned = allreduce_host(owned, group)
+        kp = np.where(owned[:, None] > 0, gathered, kp)
+        s = np.array([summary["iterations"], summary["num_successful"], summary["initial_cost"], summary["final_cost"]],
+                     dtype=np.float64)
+        s = allreduce_host(s, group)
+        t = allreduce_host(np.array([summary["total_ms"]]), group)      # summed device time (AccumulateSummaries)
+        summary.update(iterations=int(s[0]), num_successful=int(s[1]), initial_cost=float(s[2]), final_cost=float(s[3]),
+                       total_ms=float(t[0]))
+    else:
+        kp[node_ids] = local
+    return kp, summary
+
+
+def compute_references_sharded(ctx, arena, shard, pt_ids, n_points, cfg, loss, iters=100, group=None):
+    """Reference extraction on this rank's point shard (pxr_ba_compute_references, independent per point) followed by
+    a gather of the 128-double references, for hosts that need every reference everywhere (the BA itself does not:
+    observations follow their point).  Returns (refs of all points, chosen observation per point as GLOBAL ids)."""
+    from .engine import BAProblem
+    ba = BAProblem(ctx, arena, shard)
+    chosen, _ = ba.compute_references(cfg, loss, iters=iters)
+    refs = ba.d["refs"].download()
+    glob = np.where(chosen >= 0, np.asarray(shard["obs_ids"])[np.maximum(chosen, 0)], -1).astype(np.float64)
+    all_refs = gather_rows(refs, pt_ids, n_points, group)
+    all_obs = gather_rows(glob + 1.0, pt_ids, n_points, group) - 1.0          # rows nobody owns: -1
+    return all_refs, all_obs.astype(np.int64)

@@ -28,8 +28,13 @@ def make_ba_problem_gpu(device, n_cams=200, n_points=200_000, obs_per_point=5, c
     image_camera = np.arange(n_cams, dtype=np.int32)
     X_gt = rng.uniform(-1, 1, (n_points, 3))
     # obs_per_point distinct cameras per point (vectorised: random keys, take the smallest k)
-    keys = rng.random((n_points, n_cams), dtype=np.float32)
-    obs_image_all = np.argpartition(keys, obs_per_point, axis=1)[:, :obs_per_point].astype(np.int32)
+    # (drawn in row blocks -- the same random stream as one (n_points, n_cams) draw, without its memory: 16 GB of keys
+    # at 4000 cameras x 1M points)
+    obs_image_all = np.empty((n_points, obs_per_point), dtype=np.int32)
+    rows = max(1, (1 << 27) // max(1, n_cams))
+    for r0 in range(0, n_points, rows):
+        keys = rng.random((min(rows, n_points - r0), n_cams), dtype=np.float32)
+        obs_image_all[r0:r0 + len(keys)] = np.argpartition(keys, obs_per_point, axis=1)[:, :obs_per_point]
     del keys
     # perturbed initial parameters (identical on all ranks)
     qvec, tvec = q_gt.copy(), t_gt.copy()

@@ -1,0 +1,90 @@
+"""Worker of the multi-rank tests (one process per rank; launched by tests/test_multi_rank_*.py with RANK / WORLD_SIZE /
+MASTER_ADDR / MASTER_PORT in the environment, backend gloo).  Several ranks share ONE GPU in the -m gpu tests: RCCL
+refuses two ranks on one device, so the collective of pxr_ba_solve is the callback form over gloo there; the native
+RCCL path is covered with a one-rank communicator (tests/test_multi_rank_gpu.py) and by bench.py on a multi-GPU node.
+
+    python tests/_multi_rank_worker.py MODE OUT_DIR
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pixel-perfect-sfm_amd"))
+
+
+def ka_problem():
+    from pixsfm_amd import synthetic_ka
+    return synthetic_ka.make_ka_problem(n_tracks=30, track_len=5, seed=12, channels=32, max_kps_per_problem=20, sigma=0.8)
+
+
+def ba_problem(n_cams=10, n_points=240):
+    from pixsfm_amd import synthetic
+    return synthetic.make_ba_problem(n_cams=n_cams, n_points=n_points, obs_per_point=4, seed=23, channels=32)
+
+
+def ba_gauge(prob):
+    n_img, n_pts = len(prob["image_camera"]), len(prob["xyz"])
+    pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
+    tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
+    return pose_const, tmask, np.full(len(prob["cam_model"]), 0b0110, np.uint16), np.zeros(n_pts, np.uint8)
+
+
+def main():
+    mode, out_dir = sys.argv[1], sys.argv[2]
+    import torch.distributed as dist
+    from pixsfm_amd import parallel
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    if mode == "ka_plumbing":
+        # host plumbing only (no GPU): shard -> a stand-in "solve" that moves every variable keypoint of the shard by a
+        # value derived from its GLOBAL node id -> gather.  The real solve is exercised by mode "ka" on the GPU box.
+        prob = ka_problem()
+        shard, node_ids = parallel.shard_ka_problem(prob, rank, world)
+        local = shard["kp"] + (node_ids[:, None] + 1) * np.array([1e-3, -2e-3])
+        kp = parallel.gather_rows(local, node_ids, len(prob["kp"]))
+        owned = parallel.gather_rows(np.ones(len(node_ids)), node_ids, len(prob["kp"]))
+        out = dict(kp=kp, owned=owned, node_ids=node_ids, edge_ids=shard["edge_ids"],
+                   n_local_problems=np.array([int(shard["node_problem"].max()) + 1 if len(node_ids) else 0]))
+    elif mode == "ka":
+        from pixsfm_amd.engine import Context, interp_cfg, lm_options, make_loss
+        ctx = Context(0)
+        prob = ka_problem()
+        kp, summ = parallel.ka_solve_sharded(ctx, prob, interp_cfg(), make_loss("cauchy", [0.25]), 4.0,
+                                             lm_options(parameter_tolerance=1e-5))
+        out = dict(kp=kp, initial_cost=np.array([summ["initial_cost"]]), final_cost=np.array([summ["final_cost"]]))
+    elif mode in ("ba_direct", "ba_iterative", "ba_gradtol"):
+        from pixsfm_amd.engine import BAProblem, Context, PatchArena, interp_cfg, lm_options, make_loss
+        ctx = Context(0)
+        ctx.comm_set_rank(rank, world)
+        prob = ba_problem()
+        gauge = ba_gauge(prob)
+        shard, pt_ids = parallel.shard_ba_problem(prob, rank, world)
+        arena = PatchArena.from_numpy(ctx, shard["patches"], shard["corners"], shard["scales"])
+        ba = BAProblem(ctx, arena, shard)
+        opts = dict(max_iterations=6)
+        if mode == "ba_iterative":
+            opts.update(linear_solver="iterative", eta=0.0, linear_r_tolerance=1e-13, max_linear_solver_iterations=1000)
+        if mode == "ba_gradtol":
+            opts.update(max_iterations=40, gradient_tolerance=2e-4)
+        s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), gauge[0], gauge[1], gauge[2], gauge[3][pt_ids],
+                     options=lm_options(**opts), allreduce=parallel.make_allreduce(ctx=ctx))
+        q, t, k, X = ba.params()
+        xyz = parallel.gather_rows(X, pt_ids, len(prob["xyz"]))
+        refs, ref_obs = parallel.compute_references_sharded(ctx, arena, shard, pt_ids, len(prob["xyz"]), interp_cfg(),
+                                                            make_loss("cauchy", [0.25]))
+        out = dict(q=q, t=t, k=k, xyz=xyz, final_cost=np.array([s["final_cost"]]), initial_cost=np.array([s["initial_cost"]]),
+                   iterations=np.array([s["iterations"]]), successful=np.array([s["num_successful"]]),
+                   termination=np.array([s["termination"]]), linear_iterations=np.array([s["linear_iterations"]]),
+                   refs=refs, ref_obs=ref_obs)
+    else:
+        raise SystemExit("unknown mode " + mode)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -281,6 +281,48 @@ def test_run_subset_only_touches_its_nodes(ctx):
             assert np.array_equal(kp_sub[nm][nd.feature_idx], keypoints[nm][nd.feature_idx])
 
 
+def test_run_subset_not_closed_over_tracks(ctx):
+    """A subset that cuts through tracks: the reference enumerates the out-matches of nodes_in_problem only, the
+    destination of such a match is a parameter block even when it lies outside the subset, and ParameterizeKeypoints
+    visits nodes_in_problem only (topological_keypoint_optimizer.h:108-113, keypoint_optimizer.h:117) -- so the outside
+    keypoint is refined too, without box bounds and without the constant flag.  Against the oracle on the same blocks."""
+    import pxo
+    import pxo_ka
+    from pixsfm_amd.api import FeatureMetricKeypointOptimizer, KeypointAdjustmentSetup, base
+    from pixsfm_amd.api.keypoint_adjustment import build_edges
+    prob, keypoints, graph, fmanager, (img, kid, names) = _ka_inputs(seed=9, n_tracks=8, track_len=5)
+    track_labels = base.compute_track_labels(graph)
+    roots = base.compute_root_labels(graph, track_labels, base.compute_score_labels(graph, track_labels))
+    n = len(graph.nodes)
+    subset = sorted(i for i in range(n) if graph.nodes[i].image_id in (0, 1))     # two of the five images
+    setup = KeypointAdjustmentSetup()
+    setup.set_masked_nodes_constant(graph, roots)
+    kp_sub = {k: v.copy() for k, v in keypoints.items()}
+    summary = FeatureMetricKeypointOptimizer({"solver": {"parameter_tolerance": 1e-5}}, setup, None, ctx=ctx).run_subset(
+        set(subset), kp_sub, graph, track_labels, roots, fmanager.fset(0))
+    assert summary.final_cost < summary.initial_cost
+    src, dst, w = build_edges(graph, keypoints, track_labels, roots, subset)
+    assert len(src) and set(src) <= set(subset) and not set(dst) <= set(subset)
+    touched = set(src) | set(dst)
+    node_of = [int(np.nonzero((img == nd.image_id) & (kid == nd.feature_idx))[0][0]) for nd in graph.nodes]
+    node_const = np.array(roots, np.uint8)
+    node_const[[i for i in touched if i not in set(subset)]] = 2
+    labels = np.full(n, -1, np.int32); labels[sorted(touched | set(subset))] = 0
+    oprob = dict(kp=prob["kp"][node_of], node_patch=np.arange(n, dtype=np.int64), node_const=node_const,
+                 node_problem=np.where(labels < 0, 1, 0).astype(np.int32),        # the oracle wants labels >= 0: untouched nodes = an empty problem 1
+                 edge_src=np.array(src, np.int32), edge_dst=np.array(dst, np.int32), edge_w=np.array(w),
+                 patches=prob["patches"][node_of], corners=prob["corners"][node_of], scales=prob["scales"][node_of])
+    kpo, _ = pxo_ka.ka_solve(oprob, pxo.cfg(), pxo.loss("cauchy", 0.25), 4.0, pxo.lm_options(parameter_tolerance=1e-5))
+    got = np.array([kp_sub[names[nd.image_id]][nd.feature_idx] for nd in graph.nodes])
+    before = np.array([keypoints[names[nd.image_id]][nd.feature_idx] for nd in graph.nodes])
+    assert np.abs(got - kpo).max() < 1e-6                                         # vs oracle (parity unpinned vs Ceres)
+    outside_moved = [i for i in touched if i not in set(subset) and not np.array_equal(got[i], before[i])]
+    assert outside_moved, "destination keypoints outside the subset are parameters of the problem"
+    for i in range(n):
+        if i not in touched:
+            assert np.array_equal(got[i], before[i])
+
+
 def test_bundle_optimizer_set_up_solve_reset(ctx):
     """FeatureReferenceBundleOptimizer.set_up / .problem / .solve_problem / .reset (bindings.cc:36-51): the two-step
     form gives what run() gives; reset() allows a second set_up; a second run() without reset raises."""

@@ -42,8 +42,40 @@ def test_struct_layouts_match_the_header_sizes():
     assert ctypes.sizeof(_lib.Loss) == 16
     assert ctypes.sizeof(_lib.BaView) == 8 * 14
     assert ctypes.sizeof(_lib.KaView) == 8 * 19
-    assert ctypes.sizeof(_lib.LMOptions) == 8 * 13
-    assert ctypes.sizeof(_lib.LMSummary) == 8 * 8
+    assert ctypes.sizeof(_lib.LMOptions) == 8 * 16
+    assert ctypes.sizeof(_lib.LMSummary) == 8 * 10
+
+
+def test_struct_layouts_match_the_c_compiler(tmp_path):
+    """sizeof / offsetof of every struct of include/pixsfm_hip.h as gcc lays them out, against the ctypes mirror."""
+    import shutil
+    import subprocess
+    from pixsfm_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    structs = {"pxr_interp_cfg": _lib.InterpCfg, "pxr_loss": _lib.Loss, "pxr_ba_view": _lib.BaView,
+               "pxr_ka_view": _lib.KaView, "pxr_lm_options": _lib.LMOptions, "pxr_lm_summary": _lib.LMSummary}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pixsfm_hip.h"', 'int main(void) {']
+    for cname, ct in structs.items():
+        lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in ct._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    seen = 0
+    for ln in out:
+        if not ln:
+            continue
+        cname, field, val = ln.split()
+        ct = structs[cname]
+        want = ctypes.sizeof(ct) if field == "sizeof" else getattr(ct, field).offset
+        assert int(val) == want, (cname, field, val, want)
+        seen += 1
+    assert seen > 60
 
 
 def test_no_gpu_means_a_loud_failure_not_a_fallback():

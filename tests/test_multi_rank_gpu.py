@@ -1,0 +1,105 @@
+"""GPU: the multi-rank paths of SURVEY 8e with the real solvers inside.  The GPU box has ONE MI355X and RCCL
+refuses two ranks on one device, so: (a) two PROCESSES share the GPU, each solving its shard with pxr_ka_solve /
+pxr_ba_solve, the BA collective being the callback form over gloo (tests/_multi_rank_worker.py) -- results must
+match the single-process solve of the whole problem; (b) the native RCCL path (pxr_comm_*: dlopen of librccl,
+ncclCommInitRank, ncclAllReduce on the context's stream) runs with a one-rank communicator."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _multi_rank_launch import run_ranks  # noqa: E402
+import _multi_rank_worker as worker  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ka_two_ranks_equal_one(ctx, tmp_path):
+    from pixsfm_amd.engine import PatchArena, interp_cfg, lm_options, make_loss
+    from pixsfm_amd.ka_engine import KAProblem
+    prob = worker.ka_problem()
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ka = KAProblem(ctx, arena, prob)
+    total, _ = ka.solve(interp_cfg(), make_loss("cauchy", [0.25]), bound=4.0, options=lm_options(parameter_tolerance=1e-5))
+    want = ka.keypoints()
+    res = run_ranks("ka", tmp_path, world=2)
+    for r in res:
+        # sub-problems are independent: a rank's solve of its share is the single-process solve of those sub-problems
+        # (the in-kernel reductions use floating-point atomics, hence not bit-identical)
+        assert np.abs(r["kp"] - want).max() < 1e-7
+        assert abs(r["final_cost"][0] - total["final_cost"]) < 1e-9 * total["initial_cost"]
+        assert abs(r["initial_cost"][0] - total["initial_cost"]) < 1e-12 * total["initial_cost"]
+    assert np.array_equal(res[0]["kp"], res[1]["kp"])
+
+
+@pytest.mark.parametrize("mode", ["ba_direct", "ba_iterative"])
+def test_ba_two_ranks_equal_one(ctx, tmp_path, mode):
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    prob = worker.ba_problem()
+    gauge = worker.ba_gauge(prob)
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    opts = dict(max_iterations=6)
+    if mode == "ba_iterative":
+        opts.update(linear_solver="iterative", eta=0.0, linear_r_tolerance=1e-13, max_linear_solver_iterations=1000)
+    s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *gauge, options=lm_options(**opts))
+    q, t, k, X = ba.params()
+    ref_obs, _ = ba.compute_references(interp_cfg(), make_loss("cauchy", [0.25]))
+    refs = ba.d["refs"].download()
+    res = run_ranks(mode, tmp_path, world=2)
+    for r in res:
+        assert int(r["iterations"][0]) == s["iterations"] and int(r["successful"][0]) == s["num_successful"]
+        assert abs(r["final_cost"][0] - s["final_cost"]) < 1e-8 * s["initial_cost"]
+        assert abs(r["initial_cost"][0] - s["initial_cost"]) < 1e-12 * s["initial_cost"]
+        assert np.abs(r["q"] - q).max() < 1e-8 and np.abs(r["t"] - t).max() < 1e-8
+        assert np.abs(r["k"] - k).max() < 1e-6 and np.abs(r["xyz"] - X).max() < 1e-7
+        # reference extraction on the shards (independent per point) + gather = the whole-problem extraction
+        assert np.array_equal(r["ref_obs"], ref_obs)
+        assert np.abs(r["refs"] - refs).max() < 1e-6
+    # replicated parameters are bit-identical on the ranks (rank 0's camera step is broadcast)
+    assert np.array_equal(res[0]["q"], res[1]["q"]) and np.array_equal(res[0]["t"], res[1]["t"])
+    assert np.array_equal(res[0]["k"], res[1]["k"]) and np.array_equal(res[0]["xyz"], res[1]["xyz"])
+    if mode == "ba_iterative":
+        assert int(res[0]["linear_iterations"][0]) == int(res[1]["linear_iterations"][0]) > 0
+
+
+def test_gradient_tolerance_is_decided_globally(ctx, tmp_path):
+    """gradient_tolerance > 0 with sharded points: both ranks must stop at the same iteration (a rank-local
+    max-norm would let one rank leave the loop while the other waits in the next all-reduce)."""
+    res = run_ranks("ba_gradtol", tmp_path, world=2, timeout=300)
+    assert int(res[0]["iterations"][0]) == int(res[1]["iterations"][0])
+    assert int(res[0]["termination"][0]) == int(res[1]["termination"][0]) == 0       # CONVERGENCE by the gradient test
+    assert int(res[0]["iterations"][0]) < 40
+
+
+def test_native_rccl_communicator_single_rank():
+    """pxr_comm_*: librccl resolved at run time, communicator of one rank on the context's device, in-place
+    ncclAllReduce on the context's stream (identity for one rank), BA solve through the native path."""
+    from pixsfm_amd import PixsfmHipError
+    from pixsfm_amd.engine import BAProblem, Context, PatchArena, interp_cfg, lm_options, make_loss
+    c = Context(0)
+    assert c.comm_rank() == (0, 1)
+    uid = Context.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    c.comm_init(uid, 0, 1)
+    assert c.comm_rank() == (0, 1)
+    x = np.arange(1000, dtype=np.float64) * 0.5 - 3.0
+    d = c.to_device(x)
+    c.allreduce_sum(d)
+    c.sync()
+    assert np.array_equal(d.download(), x)
+    with pytest.raises(PixsfmHipError):
+        c.comm_init(uid, 0, 1)                      # a context owns at most one communicator
+    with pytest.raises(PixsfmHipError):
+        c.comm_set_rank(0, 2)                       # its rank is fixed by the communicator
+    prob = worker.ba_problem()
+    arena = PatchArena.from_numpy(c, prob["patches"], prob["corners"], prob["scales"])
+    s = BAProblem(c, arena, prob).solve(interp_cfg(), make_loss("cauchy", [0.25]), *worker.ba_gauge(prob),
+                                        options=lm_options(max_iterations=3))
+    assert s["final_cost"] < s["initial_cost"]
+    c.comm_destroy()
+    assert c.comm_rank() == (0, 1)
+    arena.close()
+    c.close()

@@ -9,9 +9,11 @@ observation owned by the rank: projection, bicubic interpolation of the patch st
 L2-normalisation with analytic gradient, reference subtraction and the six-scalar reduction
 that stands in for the 128 x (10+K) Jacobian block.  Inputs are resident in HBM when the
 timed region starts.  N > 1: points (with all their observations and patches) are
-partitioned over the ranks, no data-path collective in the evaluation; by default every
-rank owns --points points (weak scaling: N x 1M observations in one scene, cameras shared),
---scaling strong shards the 1M-observation problem instead.
+partitioned over the ranks, no data-path collective in the evaluation.  Default = STRONG scaling
+(the target of BASELINE.json: the 1M-observation problem is sharded over the N ranks); --scaling weak lets
+every rank own --points points instead (N x 1M observations in one scene, cameras shared).  The LM loop's
+collective is the native RCCL all-reduce of the engine (pxr_comm_init; falls back to the torch.distributed
+callback if the communicator cannot be created).
 
 Rank 0 prints ONE JSON line; see DESIGN.md section "Measurement" for the roofline and
 cpu_baseline definitions.  Besides the contract's fields it carries `lm` / `lm_no_inner` (LM iterations/s
@@ -79,9 +81,10 @@ def main():
     ap.add_argument("--lm-iters", type=int, default=10, help="LM iterations for the iters/s figure (0 = skip)")
     ap.add_argument("--no-ka", action="store_true", help="skip the keypoint-adjustment half of the metric (BASELINE configs[1])")
     ap.add_argument("--no-costmap", action="store_true", help="skip the cost-map extraction / cost-map BA figures")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: every rank owns --points points (N x the observations, cameras shared); "
-                         "strong: --points points in total, sharded over the ranks")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="strong (default, BASELINE.json's target): --points points in total, sharded over the ranks; "
+                         "weak: every rank owns --points points (N x the observations, cameras shared)")
+    ap.add_argument("--linear-solver", default="auto", help="auto (by image count, bundle_optimizer.h:180-191) | direct | iterative")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,6 +125,19 @@ def main():
                                                       patch_size=PS, seed=2, point_range=(lo, hi))
     n_obs_local = len(prob["obs_image"])
     ctx = Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    collective = "none"
+    if dist_on:
+        from pixsfm_amd import parallel
+        collective = "torch.distributed callback (%s)" % backend
+        if backend == "nccl" and os.environ.get("PXR_BENCH_CALLBACK") != "1":
+            try:
+                if world > 1:
+                    parallel.init_native_comm(ctx)
+                else:
+                    ctx.comm_init(Context.comm_unique_id(), 0, 1)
+                collective = "native ncclAllReduce on the engine's stream (pxr_comm_init)"
+            except Exception as e:  # noqa: BLE001 -- keep the bench alive on the callback path
+                print("native communicator unavailable (%r): using the torch.distributed callback" % (e,), file=sys.stderr)
     arena = PatchArena(ctx, n_obs_local, PS, PS, C, np.float16, device_ptr=patches.data_ptr())
     arena.upload(0, None, prob["corners"], prob["scales"])
     ba = BAProblem(ctx, arena, prob)
@@ -179,8 +195,9 @@ def main():
                 ba.d[name].upload(host)
             barrier()
             lm[key] = ba.solve(cfg, make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,
-                               options=lm_options(max_iterations=args.lm_iters, use_inner_iterations=inner),
-                               allreduce=make_allreduce() if dist_on else None)
+                               options=lm_options(max_iterations=args.lm_iters, use_inner_iterations=inner,
+                                                  linear_solver=args.linear_solver),
+                               allreduce=make_allreduce() if (dist_on and not collective.startswith("native")) else None)
             barrier()
 
     # ---- the reference's low-memory strategy on the same scene: cost-map extraction (one
@@ -236,11 +253,15 @@ def main():
         bpo = algorithmic_bytes_per_obs(C)
         # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of
         # this same command (gpurun refuses/forbids mixing passes) and committed under profiles/.
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r1_ba_eval_pmc.json")
-        if os.path.exists(pmc_path) and world == 1 and n_obs_total == 1_000_000 and not args.float_simd:
-            with open(pmc_path) as fh:
-                traffic = json.load(fh).get("hbm_bytes_per_launch")
+        traffic, traffic_source = None, None
+        for pmc_name in ("r2_ba_eval_pmc.json", "r1_ba_eval_pmc.json"):
+            pmc_path = os.path.join(ROOT, "profiles", pmc_name)
+            if os.path.exists(pmc_path) and world == 1 and n_obs_total == 1_000_000 and not args.float_simd:
+                with open(pmc_path) as fh:
+                    traffic = json.load(fh).get("hbm_bytes_per_launch")
+                traffic_source = "committed profile profiles/%s (separate rocprofv3 --pmc passes of this command; NOT " \
+                                 "measured in this run)" % pmc_name
+                break
         achieved = bpo * n_obs_local / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "featuremetric residuals+Jacobians evaluated/sec (1M obs)",
@@ -262,8 +283,8 @@ def main():
                        "partition": "points sharded, cameras replicated" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "bytes/launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
-                                         "profiles/r1_ba_eval_pmc.json",
+                         "traffic_note": "bytes/launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE",
+                         "traffic_source": traffic_source,
                          "kernel": "ba_eval_kernel<f16,128,jac>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_obs": bpo},
             "initial_cost": cost,
@@ -273,7 +294,10 @@ def main():
                         "successful": v["num_successful"], "ms_per_iter": v["total_ms"] / max(1, v["iterations"]),
                         "setup_ms": v["setup_ms"], "initial_cost": v["initial_cost"], "final_cost": v["final_cost"],
                         "reduced_system": v["num_camera_unknowns"],
-                        "linear_solver": "point Schur complement (LDS-privatised) + hand-written blocked dense Cholesky",
+                        "linear_solver": "point Schur complement (LDS-privatised) + hand-written blocked dense Cholesky"
+                                         if v["linear_solver"] == 1 else
+                                         "implicit Schur complement, block-Jacobi preconditioned CG (ITERATIVE_SCHUR regime)",
+                        "linear_iterations": v["linear_iterations"], "collective": collective,
                         "inner_iterations": key == "lm"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(prob, patches, args.cpu_sample)

@@ -16,12 +16,12 @@ sys.path.insert(0, os.path.join(ROOT, "pixel-perfect-sfm_amd"))
 
 def ka_problem():
     from pixsfm_amd import synthetic_ka
-    return synthetic_ka.make_ka_problem(n_tracks=30, track_len=5, seed=12, channels=32, max_kps_per_problem=20, sigma=0.8)
+    return synthetic_ka.make_ka_problem(n_tracks=30, track_len=5, seed=12, channels=64, max_kps_per_problem=20, sigma=0.8)
 
 
 def ba_problem(n_cams=10, n_points=240):
     from pixsfm_amd import synthetic
-    return synthetic.make_ba_problem(n_cams=n_cams, n_points=n_points, obs_per_point=4, seed=23, channels=32)
+    return synthetic.make_ba_problem(n_cams=n_cams, n_points=n_points, obs_per_point=4, seed=23, channels=64)
 
 
 def ba_gauge(prob):
@@ -69,12 +69,14 @@ def main():
             opts.update(linear_solver="iterative", eta=0.0, linear_r_tolerance=1e-13, max_linear_solver_iterations=1000)
         if mode == "ba_gradtol":
             opts.update(max_iterations=40, gradient_tolerance=2e-4)
+        # reference extraction on the shard at the INITIAL parameters (after the solve the observations of a point
+        # agree to ~1e-8 and "closest to the robust mean" is decided by rounding noise), then the solve
+        refs, ref_obs = parallel.compute_references_sharded(ctx, arena, shard, pt_ids, len(prob["xyz"]), interp_cfg(),
+                                                            make_loss("cauchy", [0.25]))
         s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), gauge[0], gauge[1], gauge[2], gauge[3][pt_ids],
                      options=lm_options(**opts), allreduce=parallel.make_allreduce(ctx=ctx))
         q, t, k, X = ba.params()
         xyz = parallel.gather_rows(X, pt_ids, len(prob["xyz"]))
-        refs, ref_obs = parallel.compute_references_sharded(ctx, arena, shard, pt_ids, len(prob["xyz"]), interp_cfg(),
-                                                            make_loss("cauchy", [0.25]))
         out = dict(q=q, t=t, k=k, xyz=xyz, final_cost=np.array([s["final_cost"]]), initial_cost=np.array([s["initial_cost"]]),
                    iterations=np.array([s["iterations"]]), successful=np.array([s["num_successful"]]),
                    termination=np.array([s["termination"]]), linear_iterations=np.array([s["linear_iterations"]]),

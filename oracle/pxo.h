@@ -221,6 +221,17 @@ int pxo_ba_solve(pxo_ba_batch* b, int n_images, int n_cams, int64_t n_points,
                  const uint8_t* point_const, const pxo_lm_options* opt, pxo_lm_summary* sum);
 
 
+/* ONE LM iteration with Schur elimination, staged and timed the way the reference's CPU path spends it
+ * (pxo_lm_bench.c; OpenMP over observations / points): bench.py's cpu_baseline_lm and an independent check of a
+ * first LM step.  times_ms [6]: Jacobian evaluation, Schur elimination, Cholesky + camera step, back-substitution,
+ * residual-only evaluation, total.  delta_c_out [n_c] / delta_p_out [n_points][3] (tangent, unscaled) may be NULL. */
+int pxo_ba_lm_iteration_schur(const pxo_ba_batch* b, int n_images, int n_cams, int64_t n_points,
+                              const pxo_interp_cfg* cfg, const pxo_loss* loss, const uint8_t* pose_const,
+                              const uint8_t* tvec_const_mask, const uint16_t* cam_const_mask,
+                              const uint8_t* point_const, double radius, double min_diag, double max_diag,
+                              int n_threads, int* n_c_out, double* delta_c_out, double* delta_p_out,
+                              double* times_ms, double* cost_out);
+
 /* ---- KA --------------------------------------------------------------------------------- */
 typedef struct {
   int64_t n_nodes;

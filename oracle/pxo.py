@@ -318,6 +318,33 @@ def ba_solve(problem, config, ls, pose_const, tvec_const_mask, cam_const_mask, p
     return s.as_dict(), prob["qvec"], prob["tvec"], prob["cam_params"], prob["xyz"]
 
 
+def ba_lm_iteration_schur(problem, config, ls, pose_const, tvec_const_mask, cam_const_mask, point_const, radius=1e4,
+                          n_threads=0, want_step=True):
+    """One Schur-complement LM iteration on the host cores (pxo_lm_bench.c).  Returns a dict with the stage times
+    (ms), the costs, the size of the reduced system and -- want_step -- the tangent step (delta_c, delta_p)."""
+    b, keep = ba_batch(problem)
+    n_img, n_cam, n_pts = len(problem["image_camera"]), len(problem["cam_model"]), len(problem["xyz"])
+    pc = np.ascontiguousarray(pose_const, dtype=np.uint8)
+    tm = np.ascontiguousarray(tvec_const_mask, dtype=np.uint8)
+    cm = np.ascontiguousarray(cam_const_mask, dtype=np.uint16)
+    ptc = np.ascontiguousarray(point_const, dtype=np.uint8)
+    n_c = C.c_int()
+    times, cost = np.zeros(6), np.zeros(2)
+    dc = np.zeros(n_img * 6 + n_cam * KPAD) if want_step else None
+    dp = np.zeros((n_pts, 3)) if want_step else None
+    fn = lib().pxo_ba_lm_iteration_schur
+    fn.restype = C.c_int
+    rc = fn(C.byref(b), n_img, n_cam, C.c_int64(n_pts), C.byref(config), C.byref(ls), _p(pc), _p(tm), _p(cm), _p(ptc),
+            C.c_double(radius), C.c_double(1e-6), C.c_double(1e32), int(n_threads), C.byref(n_c), _p(dc), _p(dp),
+            _p(times), _p(cost))
+    names = ("jacobian_eval_ms", "schur_ms", "cholesky_ms", "backsub_ms", "cost_eval_ms", "total_ms")
+    out = dict(zip(names, times.tolist()))
+    out.update(rc=rc, n_c=n_c.value, cost=float(cost[0]), cost_check=float(cost[1]))
+    if want_step:
+        out["delta_c"], out["delta_p"] = dc[:n_c.value], dp
+    return out
+
+
 def nearest_reference(patch, config, kp, candidates):
     """FindNearestReferences for one correspondence (localization/src/nearest_references.h:36-49):
     index of the candidate descriptor with the smallest squared distance to the query descriptor

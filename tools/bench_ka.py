@@ -60,16 +60,42 @@ def make_problem_gpu(dev, n_tracks, track_len, C=128, PS=16, seed=1, sigma=1.0, 
                 corners=corners, scales=np.ones((n, 2)), true_xy=true_xy, n_problems=len(bins)), patches
 
 
-def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None):
-    """Runs the KA benchmark and returns its result dict (bench.py attaches it as "ka")."""
+def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, world=1):
+    """Runs the KA benchmark and returns its result dict (bench.py attaches it as "ka").
+    world > 1 (torch.distributed initialised by the caller): STRONG scaling of BASELINE configs[1] -- the sub-problems
+    are dealt to the ranks (parallel.shard_ka_problem, SURVEY 8e: no collective during the solve), every rank times its
+    share, the figures use the slowest rank, and the refined keypoints are gathered at the end."""
     import types
     args = types.SimpleNamespace(tracks=tracks, track_len=track_len, steps=steps)
+    from pixsfm_amd import parallel
     from pixsfm_amd.engine import Context, PatchArena, interp_cfg, make_loss
     from pixsfm_amd.ka_engine import KAProblem
     dev = "cuda:%d" % device_index
     torch.cuda.set_device(device_index)
     prob, patches = make_problem_gpu(dev, args.tracks, args.track_len)
     ctx = ctx or Context(device_index, stream=torch.cuda.current_stream().cuda_stream)
+    full, node_ids = prob, np.arange(len(prob["kp"]))
+    if world > 1:
+        import torch.distributed as dist
+        prob, node_ids = parallel.shard_ka_problem(full, rank, world)
+        patches = patches[torch.as_tensor(prob["patch_ids"], device=dev)].contiguous()     # this rank's patches only
+        prob["corners"], prob["scales"] = full["corners"][prob["patch_ids"]], full["scales"][prob["patch_ids"]]
+        prob["true_xy"] = full["true_xy"][node_ids]
+        torch.cuda.empty_cache()
+
+    def slowest(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
+
+    def summed(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        return t.item()
     n = len(prob["kp"])
     arena = PatchArena(ctx, n, 16, 16, 128, np.float16, device_ptr=patches.data_ptr())
     arena.upload(0, None, prob["corners"], prob["scales"])
@@ -80,15 +106,29 @@ def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None):
     ctx.timer_start()
     for _ in range(args.steps):
         cost, _, _, _ = ka.eval(cfg, ls)
-    ms = ctx.timer_stop() / args.steps
-    c0 = float(cost.download().sum())
+    ms = slowest(ctx.timer_stop() / args.steps)
+    c0 = summed(float(cost.download().sum()))
     cold, _ = ka.solve(cfg, ls, bound=4.0)          # first call: grows the context workspace
     ka.d["kp"].upload(np.ascontiguousarray(prob["kp"], dtype=np.float64))
     ctx.sync()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     total, _ = ka.solve(cfg, ls, bound=4.0)
-    wall = time.perf_counter() - t0
+    wall = slowest(time.perf_counter() - t0)
     kp = ka.keypoints()
+    n_edges_total, n_problems_total = int(summed(ka.n_edges)), int(summed(ka.n_problems))
+    gather_ms = 0.0
+    if world > 1:                                   # disjoint rows -> every rank holds all refined keypoints
+        t1 = time.perf_counter()
+        kp_all = parallel.gather_rows(kp, node_ids, len(full["kp"]))
+        gather_ms = slowest(time.perf_counter() - t1) * 1e3
+        assert kp_all.shape == full["kp"].shape
+        for k in ("initial_cost", "final_cost"):
+            total[k] = summed(total[k])
+        total["total_ms"], total["setup_ms"] = slowest(total["total_ms"]), slowest(total["setup_ms"])
+        total["num_successful"] = int(summed(total["num_successful"]))
+        kp, prob = kp_all, full
     # expected optimum: true + (root offset)
     tl = args.track_len
     root = prob["node_const"].astype(bool)
@@ -96,9 +136,11 @@ def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None):
     err0 = np.linalg.norm(prob["kp"] - (prob["true_xy"] + off), axis=1)
     err1 = np.linalg.norm(kp - (prob["true_xy"] + off), axis=1)
     out = {"workload": "BASELINE.json configs[1]: %d tracks x %d nodes, %d edges, %d sub-problems, 128-ch fp16 16x16"
-                       % (args.tracks, tl, ka.n_edges, ka.n_problems),
-           "edge_eval": {"edges_per_s": ka.n_edges / (ms * 1e-3), "kernel_ms": ms,
-                         "algorithmic_GBps": 8244 * ka.n_edges / (ms * 1e-3) / 1e9},
+                       % (args.tracks, tl, n_edges_total, n_problems_total),
+           "n_gpus": world, "partition": "sub-problems dealt to the ranks by edge count, no collective in the solve" if world > 1 else "none",
+           "gather_ms": gather_ms,
+           "edge_eval": {"edges_per_s": n_edges_total / (ms * 1e-3), "kernel_ms": ms,
+                         "algorithmic_GBps": 8244 * n_edges_total / (ms * 1e-3) / 1e9},
            "solve": {"wall_ms": wall * 1e3, "first_call_ms": cold["total_ms"], "total_ms": total["total_ms"],
                      "kernel_ms": total["total_ms"] - total["setup_ms"], "lm_iterations_max": total["iterations"],
                      "successful_steps": total["num_successful"], "initial_cost": total["initial_cost"],

@@ -427,7 +427,7 @@ class FeatureReferenceBundleOptimizer:
     .run(reconstruction, feature_view, references) (bindings.cc:36-51,137-141)."""
     option_defaults = {
         'loss': {'name': 'cauchy', 'params': [0.25]},
-        'solver': {**base.solver_default_conf},
+        'solver': {**base.solver_default_conf, 'callbacks': []},
         'print_summary': True,
         'refine_focal_length': True, 'refine_principal_point': False, 'refine_extra_params': True,
         'refine_extrinsics': True, 'min_track_length': -1,

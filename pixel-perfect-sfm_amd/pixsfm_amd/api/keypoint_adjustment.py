@@ -114,7 +114,7 @@ class FeatureMetricKeypointOptimizer:
 
     option_defaults = {
         'loss': {'name': 'cauchy', 'params': [0.25]},
-        'solver': {**base.solver_default_conf, 'parameter_tolerance': 1.0e-4, 'num_threads': 1},
+        'solver': {**base.solver_default_conf, 'parameter_tolerance': 1.0e-4, 'num_threads': 1, 'callbacks': []},
         'print_summary': True, 'bound': 4.0, 'num_threads': -1,
         'root_regularize_weight': -1.0, 'weight_by_sim': True, 'root_edges_only': False,
     }

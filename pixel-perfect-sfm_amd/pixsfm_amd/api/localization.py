@@ -138,7 +138,7 @@ class QueryKeypointOptimizer:
 
     option_defaults = {
         'loss': {'name': 'trivial', 'params': []},
-        'solver': {**base.solver_default_conf, 'parameter_tolerance': 1e-05},
+        'solver': {**base.solver_default_conf, 'parameter_tolerance': 1e-05, 'callbacks': []},
         'print_summary': False, 'bound': 4.0,
     }
 
@@ -305,7 +305,7 @@ class QueryBundleOptimizer:
 
     option_defaults = {
         'loss': {'name': 'cauchy', 'params': [0.25]},
-        'solver': {**base.solver_default_conf},
+        'solver': {**base.solver_default_conf, 'callbacks': []},
         'print_summary': False,
         'refine_focal_length': False, 'refine_principal_point': False, 'refine_extra_params': False,
     }

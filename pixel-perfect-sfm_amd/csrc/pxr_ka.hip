@@ -59,6 +59,15 @@ struct KaArgs {
   pxr_lm_summary* summaries;   // device [n_problems]
 };
 
+// Channel layout of a node over lanes: 8 channels per lane (one 16-byte fp16 load) for the CNN feature sizes, and the
+// whole descriptor in ONE lane for CHANNELS < 8 -- the reference instantiates (128, 1) and (1, 1)
+// (featuremetric_keypoint_optimizer.h:13-17) and takes the scalar all-fp64 [upstream] Ceres bicubic below 8 channels
+// (interpolation.h:222-268), which interp_small restates.
+template <int C> struct KaLay {
+  static constexpr int CPL = C >= 8 ? 8 : C;     // channels per lane
+  static constexpr int LPO = C / CPL;            // lanes per node / edge
+};
+
 template <typename ST, int C, bool WITH_JAC>
 __device__ __forceinline__ void ka_eval_node(const KaArgs& a, int64_t node, const double* kp, int sub, bool fsimd) {
   const int64_t pi = a.v.d_node_patch[node];
@@ -67,25 +76,30 @@ __device__ __forceinline__ void ka_eval_node(const KaArgs& a, int64_t node, cons
   const double u = kp[2 * node] * sx - 0.5 - (double)a.corners[2 * pi];
   const double v = kp[2 * node + 1] * sy - 0.5 - (double)a.corners[2 * pi + 1];
   const ST* patch = reinterpret_cast<const ST*>(a.arena) + (size_t)pi * a.H * a.W * C;
-  double f[8], fr[8], fc[8];
-  if (fsimd) interp8<ST, C / 8, WITH_JAC, true>(patch, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f, fr, fc);
-  else interp8<ST, C / 8, WITH_JAC, false>(patch, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f, fr, fc);
+  constexpr int CPL = KaLay<C>::CPL;
+  double f[CPL], fr[CPL], fc[CPL];
+  if constexpr (C >= 8) {
+    if (fsimd) interp8<ST, C / 8, WITH_JAC, true>(patch, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f, fr, fc);
+    else interp8<ST, C / 8, WITH_JAC, false>(patch, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f, fr, fc);
+  } else {
+    interp_small<ST, C>(patch, a.H, a.W, u, v, a.l2_normalize != 0, f, fr, fc);
+  }
   // InterpolationConfig.check_bounds (patch_interpolator.h:125-135,160-166): outside 0 < u < W, 0 < v < H the
   // functor's evaluation fails; a NaN descriptor makes every cost it enters non-finite, which the line
   // search / step acceptance treat as a failed evaluation
   if (a.check_bounds && !(u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H)) {
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch) f[ch] = __builtin_nan("");
+    for (int ch = 0; ch < CPL; ++ch) f[ch] = __builtin_nan("");
   }
-  double* d = a.desc + (size_t)node * 3 * C + sub * 8;
+  double* d = a.desc + (size_t)node * 3 * C + sub * CPL;
 #pragma unroll
-  for (int ch = 0; ch < 8; ++ch) {
+  for (int ch = 0; ch < CPL; ++ch) {
     d[ch] = f[ch];
     if (WITH_JAC) { d[C + ch] = fc[ch] * sx; d[2 * C + ch] = fr[ch] * sy; }
   }
 }
 
-__device__ __forceinline__ double lpo_sum(double v, int LPO) { return LPO == 16 ? row16_sum(v) : row8_sum(v); }
+__device__ __forceinline__ double lpo_sum(double v, int LPO) { return LPO == 16 ? row16_sum(v) : (LPO == 8 ? row8_sum(v) : v); }
 
 // block-wide sum, result broadcast to every thread (KA_NT threads)
 __device__ __forceinline__ double block_sum(double v, double* sh4) {
@@ -133,7 +147,7 @@ struct KaProb {
 // evaluate all nodes of the problem at keypoints `kp`
 template <typename ST, int C, bool WITH_JAC>
 __device__ void ka_nodes(const KaArgs& a, const KaProb& p, const double* kp, bool fsimd) {
-  constexpr int LPO = C / 8, G = KA_NT / LPO;
+  constexpr int LPO = KaLay<C>::LPO, G = KA_NT / LPO;
   const int grp = threadIdx.x / LPO, sub = threadIdx.x % LPO;
 #pragma nounroll
   for (int64_t i = p.np0 + grp; i < p.np1; i += G) {
@@ -158,19 +172,19 @@ __device__ __forceinline__ double ka_kappa(double s, const double* rho) {
 // and g (unscaled).
 template <int C, bool WITH_JAC>
 __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
-  constexpr int LPO = C / 8, G = KA_NT / LPO;
+  constexpr int LPO = KaLay<C>::LPO, CPL = KaLay<C>::CPL, G = KA_NT / LPO;
   const int grp = threadIdx.x / LPO, sub = threadIdx.x % LPO;
   double cost = 0.0;
 #pragma nounroll
   for (int64_t i = p.ne0 + grp; i < p.ne1; i += G) {
     const int e = a.v.d_prob_edges[i];
     const int n1 = a.v.d_edge_src[e], n2 = a.v.d_edge_dst[e];
-    const double* d1 = a.desc + (size_t)n1 * 3 * C + sub * 8;
-    const double* d2 = a.desc + (size_t)n2 * 3 * C + sub * 8;
-    double r[8];
+    const double* d1 = a.desc + (size_t)n1 * 3 * C + sub * CPL;
+    const double* d2 = a.desc + (size_t)n2 * 3 * C + sub * CPL;
+    double r[CPL];
     double s = 0;
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch) { r[ch] = d1[ch] - d2[ch]; s = fma(r[ch], r[ch], s); }
+    for (int ch = 0; ch < CPL; ++ch) { r[ch] = d1[ch] - d2[ch]; s = fma(r[ch], r[ch], s); }
     s = lpo_sum(s, LPO);
     double rho[3];
     loss_eval(a.loss.type, a.loss.a, a.v.d_edge_w[e], s, rho);
@@ -181,7 +195,7 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
 #pragma unroll
       for (int k = 0; k < 14; ++k) q[k] = 0.0;
 #pragma unroll
-      for (int ch = 0; ch < 8; ++ch) {
+      for (int ch = 0; ch < CPL; ++ch) {
         const double a0 = d1[C + ch], a1 = d1[2 * C + ch], a2 = -d2[C + ch], a3 = -d2[2 * C + ch];
         q[0] = fma(a0, a0, q[0]); q[1] = fma(a0, a1, q[1]); q[2] = fma(a0, a2, q[2]); q[3] = fma(a0, a3, q[3]);
         q[4] = fma(a1, a1, q[4]); q[5] = fma(a1, a2, q[5]); q[6] = fma(a1, a3, q[6]);
@@ -220,12 +234,12 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
   for (int64_t i = p.nu0 + grp; i < p.nu1; i += G) {
     const int u = a.v.d_prob_unary[i];
     const int n1 = a.v.d_unary_node[u];
-    const double* d1 = a.desc + (size_t)n1 * 3 * C + sub * 8;
-    const double* rf = a.v.d_unary_ref + (size_t)u * C + sub * 8;
-    double r[8];
+    const double* d1 = a.desc + (size_t)n1 * 3 * C + sub * CPL;
+    const double* rf = a.v.d_unary_ref + (size_t)u * C + sub * CPL;
+    double r[CPL];
     double s = 0;
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch) { r[ch] = d1[ch] - rf[ch]; s = fma(r[ch], r[ch], s); }
+    for (int ch = 0; ch < CPL; ++ch) { r[ch] = d1[ch] - rf[ch]; s = fma(r[ch], r[ch], s); }
     s = lpo_sum(s, LPO);
     double rho[3];
     loss_eval(a.loss.type, a.loss.a, a.v.d_unary_w ? a.v.d_unary_w[u] : 1.0, s, rho);
@@ -233,7 +247,7 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
     if (WITH_JAC) {
       double q[5] = {0, 0, 0, 0, 0};
 #pragma unroll
-      for (int ch = 0; ch < 8; ++ch) {
+      for (int ch = 0; ch < CPL; ++ch) {
         const double a0 = d1[C + ch], a1 = d1[2 * C + ch];
         q[0] = fma(a0, a0, q[0]); q[1] = fma(a0, a1, q[1]); q[2] = fma(a1, a1, q[2]);
         q[3] = fma(a0, r[ch], q[3]); q[4] = fma(a1, r[ch], q[4]);
@@ -745,12 +759,12 @@ template <typename ST, int C>
 __global__ __launch_bounds__(256) void ka_eval_kernel(const KaArgs a, bool fsimd, double* __restrict__ cost,
                                                       double* __restrict__ out_r, double* __restrict__ out_J1,
                                                       double* __restrict__ out_J2) {
-  constexpr int LPO = C / 8, G = 256 / LPO;
+  constexpr int LPO = KaLay<C>::LPO, CPL = KaLay<C>::CPL, G = 256 / LPO;
   const int grp = threadIdx.x / LPO, sub = threadIdx.x % LPO;
   const int64_t e = (int64_t)blockIdx.x * G + grp;
   if (e >= a.v.n_edges) return;
   const int nn[2] = {a.v.d_edge_src[e], a.v.d_edge_dst[e]};
-  double f[2][8], gx[2][8], gy[2][8];
+  double f[2][CPL], gx[2][CPL], gy[2][CPL];
   bool inside = true;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -760,23 +774,27 @@ __global__ __launch_bounds__(256) void ka_eval_kernel(const KaArgs a, bool fsimd
     const double v = a.v.d_kp[2 * (size_t)nn[k] + 1] * sy - 0.5 - (double)a.corners[2 * pi + 1];
     inside = inside && u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H;
     const ST* patch = reinterpret_cast<const ST*>(a.arena) + (size_t)pi * a.H * a.W * C;
-    double fr[8], fc[8];
-    if (fsimd) interp8<ST, LPO, true, true>(patch, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f[k], fr, fc);
-    else interp8<ST, LPO, true, false>(patch, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f[k], fr, fc);
+    double fr[CPL], fc[CPL];
+    if constexpr (C >= 8) {
+      if (fsimd) interp8<ST, LPO, true, true>(patch, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f[k], fr, fc);
+      else interp8<ST, LPO, true, false>(patch, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f[k], fr, fc);
+    } else {
+      interp_small<ST, C>(patch, a.H, a.W, u, v, a.l2_normalize != 0, f[k], fr, fc);
+    }
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch) { gx[k][ch] = fc[ch] * sx; gy[k][ch] = fr[ch] * sy; }
+    for (int ch = 0; ch < CPL; ++ch) { gx[k][ch] = fc[ch] * sx; gy[k][ch] = fr[ch] * sy; }
   }
   double s = 0;
 #pragma unroll
-  for (int ch = 0; ch < 8; ++ch) { const double r = f[0][ch] - f[1][ch]; s = fma(r, r, s); }
+  for (int ch = 0; ch < CPL; ++ch) { const double r = f[0][ch] - f[1][ch]; s = fma(r, r, s); }
   s = lpo_sum(s, LPO);
   double rho[3];
   loss_eval(a.loss.type, a.loss.a, a.v.d_edge_w[e], s, rho);
   if (sub == 0) cost[e] = (a.check_bounds && !inside) ? __builtin_nan("") : 0.5 * rho[0];   // failed evaluation
   if (out_r) {
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch) {
-      const size_t o = (size_t)e * C + sub * 8 + ch;
+    for (int ch = 0; ch < CPL; ++ch) {
+      const size_t o = (size_t)e * C + sub * CPL + ch;
       out_r[o] = f[0][ch] - f[1][ch];
       if (out_J1) { out_J1[2 * o] = gx[0][ch]; out_J1[2 * o + 1] = gy[0][ch]; }
       if (out_J2) { out_J2[2 * o] = -gx[1][ch]; out_J2[2 * o + 1] = -gy[1][ch]; }
@@ -812,7 +830,7 @@ extern "C" int pxr_ka_eval(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* vi
   fill_args(ctx, arena, view, cfg, loss, a);
   const bool fs = cfg->use_float_simd != 0;
 #define KA_EVAL_LAUNCH(ST, CC)                                                                                   \
-  hipLaunchKernelGGL((ka_eval_kernel<ST, CC>), dim3((unsigned)((view->n_edges + (256 / (CC / 8)) - 1) / (256 / (CC / 8)))), \
+  hipLaunchKernelGGL((ka_eval_kernel<ST, CC>), dim3((unsigned)((view->n_edges + (256 / KaLay<CC>::LPO) - 1) / (256 / KaLay<CC>::LPO))), \
                      dim3(256), 0, ctx->stream, a, fs, d_cost, d_r, d_J1, d_J2)
   if (arena->dtype == PXR_F16 && arena->C == 128) KA_EVAL_LAUNCH(_Float16, 128);
   else if (arena->dtype == PXR_F16 && arena->C == 64) KA_EVAL_LAUNCH(_Float16, 64);
@@ -820,7 +838,10 @@ extern "C" int pxr_ka_eval(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* vi
   else if (arena->dtype == PXR_F32 && arena->C == 64) KA_EVAL_LAUNCH(float, 64);
   else if (arena->dtype == PXR_F64 && arena->C == 128) KA_EVAL_LAUNCH(double, 128);
   else if (arena->dtype == PXR_F64 && arena->C == 64) KA_EVAL_LAUNCH(double, 64);
-  else return set_error(PXR_EUNSUPPORTED, "pxr_ka_eval: CHANNELS=%d not supported (128, 64)", arena->C);
+  else if (arena->dtype == PXR_F16 && arena->C == 1) KA_EVAL_LAUNCH(_Float16, 1);
+  else if (arena->dtype == PXR_F32 && arena->C == 1) KA_EVAL_LAUNCH(float, 1);
+  else if (arena->dtype == PXR_F64 && arena->C == 1) KA_EVAL_LAUNCH(double, 1);
+  else return set_error(PXR_EUNSUPPORTED, "pxr_ka_eval: CHANNELS=%d not supported (128, 64, 1)", arena->C);
 #undef KA_EVAL_LAUNCH
   return hip_check(hipGetLastError(), "ka_eval_kernel launch");
 }
@@ -913,7 +934,10 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   else if (arena->dtype == PXR_F64 && arena->C == 128) KA_SOLVE_LAUNCH(ka_solve_kernel, double, 128);
   else if (arena->dtype == PXR_F32 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, float, 64);
   else if (arena->dtype == PXR_F64 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel, double, 64);
-  else return set_error(PXR_EUNSUPPORTED, "pxr_ka_solve: CHANNELS=%d not supported (128, 64)", arena->C);
+  else if (arena->dtype == PXR_F16 && arena->C == 1) KA_SOLVE_LAUNCH(ka_solve_kernel, _Float16, 1);
+  else if (arena->dtype == PXR_F32 && arena->C == 1) KA_SOLVE_LAUNCH(ka_solve_kernel, float, 1);
+  else if (arena->dtype == PXR_F64 && arena->C == 1) KA_SOLVE_LAUNCH(ka_solve_kernel, double, 1);
+  else return set_error(PXR_EUNSUPPORTED, "pxr_ka_solve: CHANNELS=%d not supported (128, 64, 1)", arena->C);
 #undef KA_SOLVE_LAUNCH
   PXR_HIP(hipGetLastError());
   std::vector<pxr_lm_summary> sums(np);

@@ -272,11 +272,18 @@ class ReferenceExtractor:
         flat = _FlatBA(reconstruction, setup, FeatureView(feature_set, reconstruction), point_filter=wanted, extractor=True)
         if len(flat.obs_image) == 0:
             return {}
-        arena = features.to_arena(ctx, flat.patches)
-        ba = BAProblem(ctx, arena, flat.problem_dict(np.zeros((len(flat.point_ids), arena.C)), arena.index))
-        out = self._references_of(ba, flat)
-        arena.close()
-        return out
+        # several ranks: every rank extracts the references of its share of the points (independent per point,
+        # reference_extractor.h:216-237) from its own patches; the small per-point results are gathered
+        from .. import parallel
+        rank, world = parallel.world()
+        part = flat if world == 1 else _rank_share(flat, rank, world)
+        out = {}
+        if len(part.obs_image):
+            arena = features.to_arena(ctx, part.patches)
+            ba = BAProblem(ctx, arena, part.problem_dict(np.zeros((len(part.point_ids), arena.C)), arena.index))
+            out = self._references_of(ba, part)
+            arena.close()
+        return out if world == 1 else parallel.gather_dicts(out)
 
     def _references_of(self, ba, flat):
         """References of the flat problem `ba` (its device `refs` are filled in place) as {point3D_id: Reference}."""
@@ -402,6 +409,18 @@ class CostMapExtractor:
         return cost_fset, references
 
 
+def _rank_share(flat, rank, world):
+    """This rank's contiguous share of the points of a _FlatBA (balanced by observation count) with all their
+    observations -- the partition of SURVEY 8e: points sharded, images and cameras replicated."""
+    from ..parallel import balanced_ranges
+    counts = np.bincount(flat.obs_point, minlength=len(flat.point_ids))
+    lo, hi = balanced_ranges(counts, world)[rank]
+    obs = np.nonzero((flat.obs_point >= lo) & (flat.obs_point < hi))[0]
+    sub = _PointSubset(flat, list(range(lo, hi)), obs.tolist())
+    sub.lo = lo                     # index (in the parent's point order) of the share's first point
+    return sub
+
+
 class _PointSubset:
     """The observations `obs` (indices into a _FlatBA) of the points `pts` as a flat problem of their own: images and
     cameras stay those of the parent, points and observations are renumbered."""
@@ -467,6 +486,19 @@ class FeatureReferenceBundleOptimizer:
             refs = np.zeros((len(flat.point_ids), C))
             for k, pid in enumerate(flat.point_ids):
                 refs[k] = references[pid].descriptor.reshape(-1)                 # references.at(point3D_id)
+        from .. import parallel
+        rank, world = parallel.world()
+        self._share = None
+        if world > 1:          # points sharded over the ranks, cameras replicated
+            self._share = _rank_share(flat, rank, world)
+            self._share_lo = self._share.lo
+            if len(self._share.obs_image) == 0:
+                raise ValueError("rank %d received no observations: fewer points than ranks" % rank)
+            self._arena = features.to_arena(ctx, self._share.patches)
+            lo, n_loc = self._share_lo, len(self._share.point_ids)
+            self._ba = BAProblem(ctx, self._arena, self._share.problem_dict(None if refs is None else refs[lo:lo + n_loc],
+                                                                           self._arena.index))
+            return
         self._arena = features.to_arena(ctx, flat.patches)
         self._ba = BAProblem(ctx, self._arena, flat.problem_dict(refs, self._arena.index))
 
@@ -488,11 +520,21 @@ class FeatureReferenceBundleOptimizer:
         lm = lm_options(max_iterations=s['max_num_iterations'], function_tolerance=s['function_tolerance'],
                         gradient_tolerance=s['gradient_tolerance'], parameter_tolerance=s['parameter_tolerance'],
                         max_consecutive_invalid_steps=s['max_num_consecutive_invalid_steps'],
-                        use_inner_iterations=s['use_inner_iterations'])
+                        use_inner_iterations=s['use_inner_iterations'],
+                        max_linear_solver_iterations=s['max_linear_solver_iterations'])
+        point_const, allreduce = flat.point_const, self.allreduce
+        if getattr(self, "_share", None) is not None:
+            from .. import parallel
+            lo, n_loc = self._share_lo, len(self._share.point_ids)
+            point_const = flat.point_const[lo:lo + n_loc]
+            if allreduce is None:
+                allreduce = parallel.ensure_collective(ba.ctx)      # native RCCL (None) or the callback form
         summ = ba.solve(self.interpolation.to_engine(), make_loss(self._loss['name'], self._loss['params']),
-                        flat.pose_const, flat.tvec_mask, flat.cam_mask, flat.point_const, options=lm,
-                        allreduce=self.allreduce)
+                        flat.pose_const, flat.tvec_mask, flat.cam_mask, point_const, options=lm,
+                        allreduce=allreduce)
         q, t, k, X = ba.params()
+        if getattr(self, "_share", None) is not None:               # every rank ends up with all refined points
+            X = parallel.gather_rows(X, np.arange(lo, lo + n_loc), len(flat.point_ids))
         for n, i in enumerate(flat.image_ids):       # in place, like feature_reference_bundle_optimizer.h:111-114
             reconstruction.images[i].qvec = q[n].copy()
             reconstruction.images[i].tvec = t[n].copy()

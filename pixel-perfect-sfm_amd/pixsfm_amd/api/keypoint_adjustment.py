@@ -21,9 +21,11 @@ _default_ctx = None
 
 
 def default_context():
+    """The process-wide engine context: device PXR_DEVICE / LOCAL_RANK (one process per GPU), else 0."""
     global _default_ctx
     if _default_ctx is None:
-        _default_ctx = Context(0)
+        from ..parallel import local_device
+        _default_ctx = Context(local_device())
     return _default_ctx
 
 
@@ -144,7 +146,6 @@ class FeatureMetricKeypointOptimizer:
         names = [graph.image_id_to_name[nd.image_id] for nd in graph.nodes]
         kp = np.array([keypoints[nm][nd.feature_idx] for nm, nd in zip(names, graph.nodes)], dtype=np.float64).reshape(-1, 2)
         patches = [feature_set.fmap(nm).fpatch(nd.feature_idx) for nm, nd in zip(names, graph.nodes)]
-        arena = features.to_arena(ctx, patches)
         labels = np.zeros(n, np.int32) if problem_labels is None else np.asarray(problem_labels, dtype=np.int32)
         node_const = np.array([self.setup.is_node_constant(nd) for nd in graph.nodes], np.uint8)
         if nodes_in_problem is not None:
@@ -159,21 +160,43 @@ class FeatureMetricKeypointOptimizer:
             touched[np.asarray(dst, dtype=np.int64)] = True
             labels[inside | touched] = 0
             node_const[touched & ~inside] = 2
-        prob = dict(kp=kp, node_patch=arena.index, node_const=node_const,
+        prob = dict(kp=kp, node_patch=np.arange(n, dtype=np.int64), node_const=node_const,
                     node_problem=labels, edge_src=np.array(src, np.int32), edge_dst=np.array(dst, np.int32),
                     edge_w=np.array(w, np.float64))
-        ka = KAProblem(ctx, arena, prob)
         s = o['solver']
         lm = lm_options(max_iterations=s['max_num_iterations'], function_tolerance=s['function_tolerance'],
                         gradient_tolerance=s['gradient_tolerance'], parameter_tolerance=s['parameter_tolerance'],
                         max_consecutive_invalid_steps=s['max_num_consecutive_invalid_steps'])
-        total, _ = ka.solve(self.interpolation.to_engine(), make_loss(o['loss']['name'], o['loss']['params']),
-                            bound=o['bound'], options=lm)
-        out = ka.keypoints()
+        cfg, loss = self.interpolation.to_engine(), make_loss(o['loss']['name'], o['loss']['params'])
+        # several ranks (torch.distributed initialised, one process per GPU): the sub-problems are dealt to the ranks
+        # -- the reference's ParallelOptimizer over label groups (base/src/parallel_optimizer.h:77-211) with GPUs instead
+        # of threads; every rank uploads only ITS patches and ends up with all refined keypoints
+        from .. import parallel
+        rank, world = parallel.world()
+        shard, node_ids = (prob, np.arange(n)) if world == 1 else parallel.shard_ka_problem(prob, rank, world)
+        channels = patches[0].shape[2]
+        total = dict(iterations=0, num_successful=0, termination=0, initial_cost=0.0, final_cost=0.0, total_ms=0.0)
+        out = kp.copy()
+        if len(node_ids):
+            arena = features.to_arena(ctx, [patches[i] for i in shard["node_patch" if world == 1 else "patch_ids"]])
+            shard = dict(shard, node_patch=arena.index)
+            ka = KAProblem(ctx, arena, shard)
+            total, _ = ka.solve(cfg, loss, bound=o['bound'], options=lm)
+            out[node_ids] = ka.keypoints()
+            arena.close()
+        if world > 1:
+            owned = np.zeros(n); owned[node_ids] = 1.0
+            rows = parallel.gather_rows(out[node_ids], node_ids, n)
+            owned = parallel.allreduce_host(owned)
+            out = np.where(owned[:, None] > 0, rows, kp)
+            acc = parallel.allreduce_host(np.array([total["iterations"], total["num_successful"], total["initial_cost"],
+                                                    total["final_cost"], total["total_ms"],
+                                                    1.0 if total["termination"] == 2 else 0.0], dtype=np.float64))
+            total = dict(total, iterations=int(acc[0]), num_successful=int(acc[1]), initial_cost=float(acc[2]),
+                         final_cost=float(acc[3]), total_ms=float(acc[4]), termination=2 if acc[5] > 0 else total["termination"])
         for nm, nd, xy in zip(names, graph.nodes, out):       # in place, like featuremetric_keypoint_optimizer.h:195-196
             keypoints[nm][nd.feature_idx] = xy
-        self._summary = Summary(total, num_residuals=len(src) * arena.C)
-        arena.close()
+        self._summary = Summary(total, num_residuals=len(src) * channels)
         return True
 
     def run_subset(self, nodes_in_problem, keypoints, graph, track_labels, root_labels, feature_set):

@@ -45,6 +45,47 @@ def init_native_comm(ctx, group=None):
     return rank, n
 
 
+def local_device():
+    """HIP device of this process: PXR_DEVICE if set, else LOCAL_RANK (one process per GPU), else 0."""
+    import os
+    for key in ("PXR_DEVICE", "LOCAL_RANK"):
+        if os.environ.get(key, "") != "":
+            return int(os.environ[key])
+    return 0
+
+
+def ensure_collective(ctx, group=None):
+    """Make `ctx` able to take part in the BA collective of `group`.  Backend nccl (one GPU per rank): the context
+    gets its native RCCL communicator and None is returned (pxr_ba_solve calls ncclAllReduce itself).  Any other
+    backend (gloo: tests, ranks sharing a GPU): the rank is recorded on the context and the all-reduce CALLBACK
+    to pass to BAProblem.solve is returned.  One rank: None."""
+    import torch.distributed as dist
+    rank, n = world(group)
+    if n == 1:
+        return None
+    if dist.get_backend(group) == "nccl":
+        if ctx.comm_rank() != (rank, n):
+            init_native_comm(ctx, group)
+        return None
+    if ctx.comm_rank() != (rank, n):
+        ctx.comm_set_rank(rank, n)
+    return make_allreduce(group, ctx)
+
+
+def gather_dicts(local, group=None):
+    """Union of per-rank dicts with disjoint keys (e.g. {point3D_id: Reference}) on every rank."""
+    import torch.distributed as dist
+    rank, n = world(group)
+    if n == 1:
+        return dict(local)
+    parts = [None] * n
+    dist.all_gather_object(parts, local, group=group)
+    out = {}
+    for part in parts:
+        out.update(part)
+    return out
+
+
 class _CudaArrayView:
     """Wraps a raw device pointer so torch.as_tensor can alias it (no copy)."""
 

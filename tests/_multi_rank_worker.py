@@ -31,6 +31,53 @@ def ba_gauge(prob):
     return pose_const, tmask, np.full(len(prob["cam_model"]), 0b0110, np.uint16), np.zeros(n_pts, np.uint8)
 
 
+def api_inputs():
+    from pixsfm_amd import synthetic, synthetic_ka
+    from pixsfm_amd.api import features
+    from pixsfm_amd.api.keypoint_adjustment import build_matching_graph
+    from pixsfm_amd.api.reconstruction import reconstruction_from_flat
+    kprob = synthetic_ka.make_ka_problem(n_tracks=40, track_len=4, seed=3, directed_both=False, channels=64, max_kps_per_problem=20)
+    n, tl = 160, 4
+    img, kid = np.arange(n) % tl, np.arange(n) // tl
+    names = ["im%d" % k for k in range(tl)]
+    keypoints = {names[k]: kprob["kp"][img == k].copy() for k in range(tl)}
+    fmaps = {names[k]: features.FeatureMap.from_arrays(kprob["patches"][img == k], kid[img == k], kprob["corners"][img == k],
+                                                       (1.0, 1.0)) for k in range(tl)}
+    pairs, matches, scores = [], [], []
+    for a in range(tl):
+        for b in range(a + 1, tl):
+            sel = (img[kprob["edge_src"]] == a) & (img[kprob["edge_dst"]] == b)
+            pairs.append((names[a], names[b]))
+            matches.append(np.stack([kid[kprob["edge_src"][sel]], kid[kprob["edge_dst"][sel]]], 1))
+            scores.append(kprob["edge_w"][sel])
+    graph = build_matching_graph(pairs, matches, scores)
+    ka_in = (keypoints, features.FeatureManager([features.FeatureSet(fmaps)]), graph)
+    prob = synthetic.make_ba_problem(n_cams=6, n_points=90, obs_per_point=3, seed=29, channels=64)
+    rec, patch_of = reconstruction_from_flat(prob)
+    bmaps = {}
+    for (image_id, p2d), pi in patch_of.items():
+        fm = bmaps.setdefault(rec.images[image_id].name, features.FeatureMap())
+        fm.patches[p2d] = features.FeaturePatch(prob["patches"][pi], prob["corners"][pi], prob["scales"][pi])
+    return ka_in, (rec, features.FeatureManager([features.FeatureSet(bmaps)]))
+
+
+def api_run():
+    from pixsfm_amd.api import BundleAdjuster, KeypointAdjuster
+    (keypoints, fmanager, graph), (rec, bmanager) = api_inputs()
+    ka = KeypointAdjuster.create({"strategy": "featuremetric", "max_kps_per_problem": 20})
+    s_ka = ka.refine_multilevel(keypoints, fmanager, graph)["summary"][0]
+    ba = BundleAdjuster.create({"optimizer": {"solver": {"max_num_iterations": 6}}})
+    out = ba.refine_multilevel(rec, bmanager)
+    s_ba, refs = out["summary"][0], out["references"][0]
+    ids = sorted(refs)
+    return dict(kp=np.concatenate([keypoints[k] for k in sorted(keypoints)]),
+                ka_cost=np.array([s_ka.initial_cost, s_ka.final_cost]),
+                ba_cost=np.array([s_ba.initial_cost, s_ba.final_cost]), ba_iters=np.array([s_ba.num_iterations]),
+                xyz=np.array([rec.points3D[p].xyz for p in sorted(rec.points3D)]),
+                qvec=np.array([rec.images[i].qvec for i in sorted(rec.images)]),
+                ref_ids=np.array(ids), ref_desc=np.array([refs[p].descriptor.reshape(-1) for p in ids]))
+
+
 def main():
     mode, out_dir = sys.argv[1], sys.argv[2]
     import torch.distributed as dist
@@ -81,6 +128,10 @@ def main():
                    iterations=np.array([s["iterations"]]), successful=np.array([s["num_successful"]]),
                    termination=np.array([s["termination"]]), linear_iterations=np.array([s["linear_iterations"]]),
                    refs=refs, ref_obs=ref_obs)
+    elif mode == "api":
+        # the pixsfm-shaped API on two ranks: KeypointAdjuster (sub-problems dealt to the ranks), ReferenceExtractor and
+        # FeatureReferenceBundleOptimizer (points sharded, collective chosen by parallel.ensure_collective)
+        out = api_run()
     else:
         raise SystemExit("unknown mode " + mode)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)

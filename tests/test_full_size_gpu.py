@@ -232,3 +232,59 @@ def test_many_cameras_column_tiled_schur_and_long_cholesky(ctx):
     for a_, b_ in zip(p1, p2):
         assert np.abs(a_ - b_).max() < 1e-8 * max(1.0, np.abs(b_).max())
     assert s1["final_cost"] < 0.01 * s1["initial_cost"]
+
+
+def test_ka_full_size_oracle_on_a_sample_of_sub_problems(ctx):
+    """BASELINE configs[1] at FULL size (10 000 tracks x 10 nodes = 100 000 keypoints, 450 000 edges, 2 000
+    sub-problems, 6.5 GB of patches): the whole bounded LM on the GPU, then the oracle on a random sample of the SAME
+    sub-problems (they are independent: a sub-problem's solve does not depend on the others) -- iteration counts, final
+    costs and refined keypoints (1e-6 px; north_star 1e-4; vs the oracle, parity unpinned w.r.t. Ceres), plus the
+    size-independent properties of the full solve."""
+    import os
+    import sys
+    import pxo
+    import pxo_ka
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_ka
+    from pixsfm_amd.engine import PatchArena, interp_cfg, make_loss
+    from pixsfm_amd.ka_engine import KAProblem
+    prob, patches = bench_ka.make_problem_gpu("cuda:0", 10000, 10)
+    n = len(prob["kp"])
+    arena = PatchArena(ctx, n, 16, 16, 128, np.float16, device_ptr=patches.data_ptr())
+    arena.upload(0, None, prob["corners"], prob["scales"])
+    ka = KAProblem(ctx, arena, prob)
+    assert ka.n_edges == 450_000 and ka.n_problems == 2000
+    total, per = ka.solve(interp_cfg(), make_loss("cauchy", [0.25]), bound=4.0, per_problem=True)
+    kp = ka.keypoints()
+    # properties of the whole solve: every sub-problem converged or stopped at a smaller cost, roots did not move,
+    # every keypoint stayed inside its box
+    assert all(p["final_cost"] <= p["initial_cost"] * (1 + 1e-12) for p in per)
+    root = prob["node_const"].astype(bool)
+    assert np.array_equal(kp[root], prob["kp"][root])
+    assert np.abs(kp - prob["kp"]).max() <= 4.0 + 1e-9
+    assert abs(total["final_cost"] - sum(p["final_cost"] for p in per)) < 1e-9 * total["initial_cost"]
+    assert total["final_cost"] < 0.01 * total["initial_cost"]
+    # the oracle on 12 of the 2000 sub-problems
+    rng = np.random.default_rng(3)
+    chosen = np.sort(rng.choice(ka.n_problems, 12, replace=False))
+    node_sel = np.nonzero(np.isin(prob["node_problem"], chosen))[0]
+    renum = np.full(ka.n_problems, -1); renum[chosen] = np.arange(len(chosen))
+    new_node = np.full(n, -1); new_node[node_sel] = np.arange(len(node_sel))
+    edge_sel = np.nonzero(new_node[prob["edge_src"]] >= 0)[0]
+    sub = dict(kp=prob["kp"][node_sel], node_patch=np.arange(len(node_sel), dtype=np.int64), node_const=prob["node_const"][node_sel],
+               node_problem=renum[prob["node_problem"][node_sel]].astype(np.int32),
+               edge_src=new_node[prob["edge_src"][edge_sel]].astype(np.int32),
+               edge_dst=new_node[prob["edge_dst"][edge_sel]].astype(np.int32), edge_w=prob["edge_w"][edge_sel],
+               patches=patches[torch.as_tensor(node_sel, device="cuda:0")].cpu().numpy(),
+               corners=prob["corners"][node_sel], scales=prob["scales"][node_sel])
+    assert len(edge_sel) == sum(ka.problem_sizes[c] for c in chosen)
+    kpo, sums = pxo_ka.ka_solve(sub, pxo.cfg(), pxo.loss("cauchy", 0.25), 4.0, pxo.lm_options(parameter_tolerance=1e-5))
+    for c, o in zip(chosen, sums):
+        g = per[c]
+        assert g["iterations"] == o["iterations"] and g["num_successful"] == o["num_successful"], (c, g, o)
+        assert abs(g["initial_cost"] - o["initial_cost"]) < 1e-10 * o["initial_cost"]
+        assert abs(g["final_cost"] - o["final_cost"]) < 1e-7 * o["initial_cost"]
+    assert np.abs(kp[node_sel] - kpo).max() < 1e-6
+    del ka, arena, patches
+    torch.cuda.empty_cache()

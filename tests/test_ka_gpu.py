@@ -173,3 +173,36 @@ def test_check_bounds_failure_leaves_keypoints_untouched(ctx):
     assert np.array_equal(out[sel], kp[sel])
     assert all(p["termination"] == 0 for i, p in enumerate(per) if i != 1)
     assert total["termination"] == 2
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32, np.float64])
+def test_single_channel_features(ctx, dtype):
+    """CHANNELS = 1 -- the reference instantiates FeatureMetricKeypointOptimizer for (128, 1) and (1, 1)
+    (featuremetric_keypoint_optimizer.h:13-17); below 8 channels it takes the scalar all-fp64 bicubic
+    (interpolation.h:222-268).  Scalar fields, l2_normalize off (a 1-vector normalises to +-1): per-edge residuals and
+    Jacobians and the bounded LM against the oracle."""
+    import pxo
+    import pxo_ka
+    from pixsfm_amd import synthetic_ka
+    from pixsfm_amd.engine import PatchArena, interp_cfg, make_loss
+    from pixsfm_amd.ka_engine import KAProblem
+    prob = synthetic_ka.make_ka_problem(n_tracks=10, track_len=4, seed=21, channels=64, dtype=np.float32, sigma=0.6)
+    prob["patches"] = np.ascontiguousarray((3.0 * prob["patches"][..., 5:6]).astype(dtype))     # one smooth channel
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    assert arena.C == 1
+    ka = KAProblem(ctx, arena, prob)
+    cfg, ls = interp_cfg(l2_normalize=False), make_loss("cauchy", [0.25])
+    cost, r, J1, J2 = ka.eval(cfg, ls, materialize=True)
+    R, J1o, J2o, co = _oracle_edges(prob, dict(l2_normalize=False))
+    rel = lambda a, b: np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+    assert np.abs(R).max() > 1e-3 and np.abs(J1o).max() > 1e-3
+    assert rel(r.download(), R) < 1e-12 and rel(J1.download(), J1o) < 1e-12 and rel(J2.download(), J2o) < 1e-12
+    assert rel(cost.download(), co) < 1e-12
+    total, per = ka.solve(cfg, ls, bound=4.0, per_problem=True)
+    kpo, sums = pxo_ka.ka_solve(prob, pxo.cfg(l2_normalize=False), pxo.loss("cauchy", 0.25), 4.0)
+    for g, o in zip(per, sums):
+        assert g["iterations"] == o["iterations"] and g["num_successful"] == o["num_successful"]
+        assert abs(g["final_cost"] - o["final_cost"]) < 1e-9 * max(o["initial_cost"], 1e-12)
+    assert np.abs(ka.keypoints() - kpo).max() < 1e-6
+    assert total["final_cost"] < total["initial_cost"]
+    arena.close()

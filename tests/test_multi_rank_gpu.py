@@ -104,3 +104,20 @@ def test_native_rccl_communicator_single_rank():
     assert c.comm_rank() == (0, 1)
     arena.close()
     c.close()
+
+
+def test_pixsfm_api_on_two_ranks(ctx, tmp_path, monkeypatch):
+    """KeypointAdjuster / BundleAdjuster through the pixsfm-shaped API with torch.distributed initialised: two ranks
+    (sharing the one GPU of this box, gloo) give what one process gives -- refined keypoints, references of all points,
+    refined poses and points on EVERY rank."""
+    monkeypatch.setenv("PXR_DEVICE", "0")                       # both ranks on the one GPU of this box
+    one = worker.api_run()
+    res = run_ranks("api", tmp_path, world=2)
+    for r in res:
+        assert np.abs(r["kp"] - one["kp"]).max() < 1e-7
+        assert np.abs(r["ka_cost"] - one["ka_cost"]).max() < 1e-9 * one["ka_cost"][0]
+        assert np.array_equal(r["ref_ids"], one["ref_ids"]) and np.abs(r["ref_desc"] - one["ref_desc"]).max() < 1e-12
+        assert int(r["ba_iters"][0]) == int(one["ba_iters"][0])
+        assert np.abs(r["ba_cost"] - one["ba_cost"]).max() < 1e-8 * one["ba_cost"][0]
+        assert np.abs(r["xyz"] - one["xyz"]).max() < 1e-7 and np.abs(r["qvec"] - one["qvec"]).max() < 1e-8
+    assert np.array_equal(res[0]["xyz"], res[1]["xyz"]) and np.array_equal(res[0]["kp"], res[1]["kp"])

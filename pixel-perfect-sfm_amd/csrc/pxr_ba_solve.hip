@@ -34,6 +34,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "pxr_ba_pcg.h"
@@ -720,6 +721,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     std::vector<int64_t> ic(img_cnt.begin(), img_cnt.end() - 1), pc(pt_cnt.begin(), pt_cnt.end() - 1);
     for (int64_t i = 0; i < n_obs; ++i) { img_obs[ic[obs_image[i]]++] = i; pt_obs[pc[obs_point[i]]++] = i; }
   }
+  setup_mark("host CSR (counts, fill)");
   std::vector<ImgChunk> chunks;
   const int64_t CH = 512;    // observations per k_img workgroup (4 LDS batches)
   for (int i = 0; i < n_img; ++i)
@@ -736,14 +738,26 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   PXR_REQUIRE(n_obs < ((int64_t)1 << 31), "pxr_ba_solve: more than 2^31 observations per rank");
   std::vector<int4> obs_cols(n_obs), so_desc(n_obs);   // partner column descriptors in pt_obs order, slots in img_obs order
   std::vector<int> part_obs(n_obs);
-  for (int64_t o = 0; o < n_obs; ++o) {
-    const int64_t j = pt_obs[o];
-    const int im = obs_image[j], cm = image_camera[im];
-    obs_cols[o] = make_int4(pose_off[im], pose_dim[im], intr_off[cm], intr_dim[cm]);
-    part_obs[o] = (int)j;
-    const int64_t i = img_obs[o];
-    const int64_t pt = obs_point[i];
-    so_desc[o] = make_int4((int)i, (int)pt, (int)pt_cnt[pt], pt_var[pt] ? (int)(pt_cnt[pt + 1] - pt_cnt[pt]) : 0);
+  {   // a pure map over the observations (random reads of the index arrays): shared out over a few host threads
+    auto fill = [&](int64_t o0, int64_t o1) {
+      for (int64_t o = o0; o < o1; ++o) {
+        const int64_t j = pt_obs[o];
+        const int im = obs_image[j], cm = image_camera[im];
+        obs_cols[o] = make_int4(pose_off[im], pose_dim[im], intr_off[cm], intr_dim[cm]);
+        part_obs[o] = (int)j;
+        const int64_t i = img_obs[o];
+        const int64_t pt = obs_point[i];
+        so_desc[o] = make_int4((int)i, (int)pt, (int)pt_cnt[pt], pt_var[pt] ? (int)(pt_cnt[pt + 1] - pt_cnt[pt]) : 0);
+      }
+    };
+    const int nth = n_obs < 200000 ? 1 : (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+    if (nth == 1) fill(0, n_obs);
+    else {
+      std::vector<std::thread> pool;
+      const int64_t per = (n_obs + nth - 1) / nth;
+      for (int t = 0; t < nth; ++t) pool.emplace_back(fill, t * per, std::min(n_obs, (t + 1) * per));
+      for (auto& th : pool) th.join();
+    }
   }
 
   // preconditioner blocks of the iterative solver: the pose columns of an image and the intrinsics columns of a

@@ -609,6 +609,29 @@ __global__ void k_zero(int64_t n, double* __restrict__ x) {
   if (i < n) x[i] = 0.0;
 }
 
+// ---- set-up: flattened index chains of the Schur / back-substitution kernels ------------------------------------
+// obs_cols[o] / part_obs[o]: column descriptor and observation id of slot o of the point-ordered list;
+// so[o]: {observation, point, first partner slot, partner count (0 = constant point)} of slot o of the image-ordered list
+__global__ __launch_bounds__(256) void k_build_descriptors(int64_t n_obs, const int32_t* __restrict__ obs_image,
+                                                           const int32_t* __restrict__ obs_point,
+                                                           const int32_t* __restrict__ image_camera,
+                                                           const int64_t* __restrict__ pt_obs, const int64_t* __restrict__ img_obs,
+                                                           const int64_t* __restrict__ pt_ptr, const int* __restrict__ pt_var,
+                                                           const int* __restrict__ pose_off, const int* __restrict__ pose_dim,
+                                                           const int* __restrict__ intr_off, const int* __restrict__ intr_dim,
+                                                           int4* __restrict__ obs_cols, int* __restrict__ part_obs,
+                                                           int4* __restrict__ so) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n_obs) return;
+  const int64_t j = pt_obs[o];
+  const int im = obs_image[j], cm = image_camera[im];
+  obs_cols[o] = make_int4(pose_off[im], pose_dim[im], intr_off[cm], intr_dim[cm]);
+  part_obs[o] = (int)j;
+  const int64_t i = img_obs[o];
+  const int64_t pt = obs_point[i];
+  so[o] = make_int4((int)i, (int)pt, (int)pt_ptr[pt], pt_var[pt] ? (int)(pt_ptr[pt + 1] - pt_ptr[pt]) : 0);
+}
+
 // ---- host orchestration -----------------------------------------------------------------------------------
 template <typename T>
 struct DevBuf {
@@ -736,30 +759,8 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     for (int64_t b = img_cnt[i]; b < img_cnt[i + 1]; b += SCH)
       schur_chunks.push_back({i, b, std::min(img_cnt[i + 1], b + SCH)});
   PXR_REQUIRE(n_obs < ((int64_t)1 << 31), "pxr_ba_solve: more than 2^31 observations per rank");
-  std::vector<int4> obs_cols(n_obs), so_desc(n_obs);   // partner column descriptors in pt_obs order, slots in img_obs order
-  std::vector<int> part_obs(n_obs);
-  {   // a pure map over the observations (random reads of the index arrays): shared out over a few host threads
-    auto fill = [&](int64_t o0, int64_t o1) {
-      for (int64_t o = o0; o < o1; ++o) {
-        const int64_t j = pt_obs[o];
-        const int im = obs_image[j], cm = image_camera[im];
-        obs_cols[o] = make_int4(pose_off[im], pose_dim[im], intr_off[cm], intr_dim[cm]);
-        part_obs[o] = (int)j;
-        const int64_t i = img_obs[o];
-        const int64_t pt = obs_point[i];
-        so_desc[o] = make_int4((int)i, (int)pt, (int)pt_cnt[pt], pt_var[pt] ? (int)(pt_cnt[pt + 1] - pt_cnt[pt]) : 0);
-      }
-    };
-    const int nth = n_obs < 200000 ? 1 : (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
-    if (nth == 1) fill(0, n_obs);
-    else {
-      std::vector<std::thread> pool;
-      const int64_t per = (n_obs + nth - 1) / nth;
-      for (int t = 0; t < nth; ++t) pool.emplace_back(fill, t * per, std::min(n_obs, (t + 1) * per));
-      for (auto& th : pool) th.join();
-    }
-  }
-
+  // (the per-observation descriptors -- partner column descriptors in pt_obs order, slots in img_obs order -- are
+  // filled on the device by k_build_descriptors from the arrays uploaded below)
   // preconditioner blocks of the iterative solver: the pose columns of an image and the intrinsics columns of a
   // camera; one joint block where the camera belongs to a single image (every column in exactly one block)
   std::vector<int2> col_group;
@@ -799,8 +800,12 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   RC(d_intr_off.upload(intr_off, st)); RC(d_intr_dim.upload(intr_dim, st)); RC(d_cmask.upload(cmask, st));
   RC(d_pt_var.upload(pt_var, st)); RC(d_img_obs.upload(img_obs, st)); RC(d_pt_ptr.upload(pt_cnt, st));
   RC(d_pt_obs.upload(pt_obs, st)); RC(d_chunks.upload(chunks, st));
-  RC(d_schur_chunks.upload(schur_chunks, st)); RC(d_obs_cols.upload(obs_cols, st));
-  RC(d_so.upload(so_desc, st)); RC(d_part_obs.upload(part_obs, st));
+  RC(d_schur_chunks.upload(schur_chunks, st));
+  RC(d_obs_cols.alloc(n_obs)); RC(d_so.alloc(n_obs)); RC(d_part_obs.alloc(n_obs));
+  hipLaunchKernelGGL(k_build_descriptors, dim3(nblk(n_obs)), dim3(256), 0, st, n_obs, view->d_obs_image, view->d_obs_point,
+                     view->d_image_camera, d_pt_obs.p, d_img_obs.p, d_pt_ptr.p, d_pt_var.p, d_pose_off.p, d_pose_dim.p,
+                     d_intr_off.p, d_intr_dim.p, d_obs_cols.p, d_part_obs.p, d_so.p);
+  LAUNCH_CHECK("k_build_descriptors");
   setup_mark("index uploads");
   const size_t nc1 = n_c ? n_c : 1;
   DevBuf<double> L, V, gp, Vd0, T, W, U, S /* S | rhs */, gcd /* diagU | g_c */, damp_c, scale_c, scale_p,

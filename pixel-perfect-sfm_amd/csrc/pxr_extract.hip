@@ -8,6 +8,13 @@
 // later back to wherever the optimiser runs.  Here the gather writes straight into the HBM arena the
 // KA / BA kernels read; nothing crosses PCIe.
 //
+// Patch ORDER (round 2): keypoints arrive in detector order, i.e. scattered over the map.  A 128 x 256 x 320 fp32 map
+// is 42 MB -- far beyond the 4 MB L2 of an XCD -- and every map texel is gathered ~300 times by overlapping patches, so
+// in keypoint order nearly every 64-byte row segment came from the Infinity Cache / HBM again (SQ counters: 5 % VALU,
+// 93 % of the wave time parked on memory).  The workgroups therefore walk the patches in MAP-TILE order (a counting
+// sort of the corners by 16 x 16 tile, three tiny kernels): neighbouring workgroups read neighbouring rows, the L2
+// serves the reuse, and the output slot of a patch is still its keypoint index.
+//
 // HBM-bound transposition: one workgroup per patch, one patch row per step.  Reads are the CHW
 // rows (16 contiguous x per channel = 64 B at fp32), staged through a padded LDS tile so that the
 // writes are the arena's channel-fastest texels (256 B per pixel at fp16, 16 B per lane).
@@ -33,10 +40,10 @@ __global__ __launch_bounds__(256) void extract_kernel(const SRC* __restrict__ fm
                                                       const double* __restrict__ kps, double sx, double sy,
                                                       int l2_normalize, DST* __restrict__ out,
                                                       int32_t* __restrict__ corners, double* __restrict__ scales,
-                                                      int64_t first, int ps) {
+                                                      int64_t first, int ps, const int* __restrict__ order) {
   constexpr int PSM = 16, CP = C + 1;           // +1 float of padding: conflict-free column reads
   __shared__ float tile[2 * PSM * CP];
-  const int64_t k = blockIdx.x;
+  const int64_t k = order ? order[blockIdx.x] : blockIdx.x;   // patches in map-tile order, outputs at their own slots
   const int tid = threadIdx.x;
   int x0, y0;
   ex_corner(kps + 2 * k, sx, sy, ps, w, h, x0, y0);
@@ -87,6 +94,38 @@ __global__ __launch_bounds__(256) void extract_kernel(const SRC* __restrict__ fm
   }
 }
 
+// ---- map-tile order of the patches: histogram, scan, scatter ---------------------------------------------------------
+__global__ __launch_bounds__(256) void ex_tile_count(int64_t n, const double* __restrict__ kps, double sx, double sy, int ps,
+                                                     int w, int h, int tiles_x, int* __restrict__ tile_of, int* __restrict__ hist) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  int x0, y0;
+  ex_corner(kps + 2 * k, sx, sy, ps, w, h, x0, y0);
+  const int t = (y0 >> 4) * tiles_x + (x0 >> 4);
+  tile_of[k] = t;
+  atomicAdd(hist + t, 1);
+}
+
+__global__ __launch_bounds__(1024) void ex_tile_scan(int n_tiles, int* __restrict__ hist /* counts -> first slots */) {
+  __shared__ int part[1024];
+  const int per = (n_tiles + 1023) / 1024, t0 = threadIdx.x * per;
+  int s = 0;
+  for (int i = t0; i < min(n_tiles, t0 + per); ++i) s += hist[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = run; run += v; } }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  for (int i = t0; i < min(n_tiles, t0 + per); ++i) { const int v = hist[i]; hist[i] = run; run += v; }
+}
+
+__global__ __launch_bounds__(256) void ex_tile_scatter(int64_t n, const int* __restrict__ tile_of, int* __restrict__ cursor,
+                                                       int* __restrict__ order) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  order[atomicAdd(cursor + tile_of[k], 1)] = (int)k;
+}
+
 }  // namespace pxr
 
 extern "C" int pxr_arena_extract(pxr_ctx* ctx, pxr_arena* a, int64_t first, int64_t n, const void* d_fmap,
@@ -102,10 +141,31 @@ extern "C" int pxr_arena_extract(pxr_ctx* ctx, pxr_arena* a, int64_t first, int6
   if (n == 0) return PXR_OK;
   PXR_HIP(hipSetDevice(ctx->device));
   const double sx = (double)w / image_w, sy = (double)h / image_h;   // extractor.py:177
+  // map-tile order of the patches (worth it once the patches outnumber the tiles a few times over)
+  const int* d_order = nullptr;
+  const int tiles_x = (w + 15) / 16, n_tiles = tiles_x * ((h + 15) / 16);
+  if (n >= 4096 && n < ((int64_t)1 << 31)) {
+    const size_t bytes = sizeof(int) * (2 * (size_t)n + n_tiles) + 768;
+    if (bytes > ctx->workspace_bytes) {
+      PXR_HIP(hipStreamSynchronize(ctx->stream));
+      if (ctx->d_workspace) { PXR_HIP(hipFree(ctx->d_workspace)); ctx->d_workspace = nullptr; ctx->workspace_bytes = 0; }
+      PXR_HIP(hipMalloc(&ctx->d_workspace, bytes));
+      ctx->workspace_bytes = bytes;
+    }
+    int* tile_of = static_cast<int*>(ctx->d_workspace);
+    int* order = tile_of + n;
+    int* hist = order + n;
+    PXR_HIP(hipMemsetAsync(hist, 0, sizeof(int) * n_tiles, ctx->stream));
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(ex_tile_count, dim3(nb), dim3(256), 0, ctx->stream, n, d_keypoints, sx, sy, a->H, w, h, tiles_x, tile_of, hist);
+    hipLaunchKernelGGL(ex_tile_scan, dim3(1), dim3(1024), 0, ctx->stream, n_tiles, hist);
+    hipLaunchKernelGGL(ex_tile_scatter, dim3(nb), dim3(256), 0, ctx->stream, n, tile_of, hist, order);
+    d_order = order;
+  }
 #define EX_LAUNCH(SRC, DST, CC)                                                                              \
   hipLaunchKernelGGL((extract_kernel<SRC, DST, CC>), dim3((unsigned)n), dim3(256), 0, ctx->stream,          \
                      (const SRC*)d_fmap, h, w, d_keypoints, sx, sy, l2_normalize, (DST*)a->d_data,          \
-                     a->d_corners, a->d_scales, first, a->H)
+                     a->d_corners, a->d_scales, first, a->H, d_order)
 #define EX_DST(SRC, CC)                                                   \
   do {                                                                    \
     if (a->dtype == PXR_F16) EX_LAUNCH(SRC, _Float16, CC);                \

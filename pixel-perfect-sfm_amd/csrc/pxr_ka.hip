@@ -744,7 +744,10 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
 // compiler's own budget: capped, they spill ~950 registers.  (A tighter cap of 3 waves/SIMD produced
 // wrong steps on ROCm 7.2 and is not used.)
 template <typename ST, int C>
-__global__ __launch_bounds__(KA_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void ka_solve_kernel_occ2(const KaArgs a, const KaInfo* __restrict__ info) {
+#ifndef PXR_KA_WAVES   // debugging knob of tools/ka_occupancy_probe.sh (the 3-waves build that gave wrong steps)
+#define PXR_KA_WAVES 2
+#endif
+__global__ __launch_bounds__(KA_NT) __attribute__((amdgpu_waves_per_eu(PXR_KA_WAVES, PXR_KA_WAVES))) void ka_solve_kernel_occ2(const KaArgs a, const KaInfo* __restrict__ info) {
   extern __shared__ double sh_A[];      // lds_elems doubles (damped blocks) when the sub-problem fits
   ka_solve_body<ST, C>(a, info, sh_A);
 }

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpixsfm_hip.so")
+LIB_PATH = os.environ.get("PXR_HIP_LIB") or os.path.join(HERE, "libpixsfm_hip.so")   # PXR_HIP_LIB: an alternative build (debugging)
 
 KPAD = 12
 OBS_REC = 8

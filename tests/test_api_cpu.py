@@ -127,6 +127,35 @@ def test_flat_ba_matches_reference_parameterisation():
     assert labels[0] == -1 and labels[1] == 0 and labels[20] == 2
 
 
+def test_flat_ba_observation_order_missing_patches_and_constness():
+    """Observations are point-major and, inside a point, in Track().Elements() order (what ComputeReference iterates,
+    reference_extractor.h:239-247); the optimiser's SetUp raises on a missing patch (GetFeaturePatch / references.at
+    throw), the extractors skip it like GetVisibleObservations and leave the caller's reconstruction untouched."""
+    prob = synthetic.make_ba_problem(n_cams=5, n_points=20, obs_per_point=3, seed=4, channels=8, patch_size=8)
+    rec, patch_of = reconstruction_from_flat(prob)
+    # scramble one track's element order: the flat problem must follow the TRACK, not the image order
+    tr = rec.points3D[7].track
+    tr.elements = tr.elements[::-1]
+    fset = _fset(prob, rec, patch_of)
+    setup = default_problem_setup(rec)
+    flat = _FlatBA(rec, setup, FeatureView(fset, rec), {})
+    assert (np.diff(flat.obs_point) >= 0).all()                               # point-major
+    for k, pid in enumerate(flat.point_ids):
+        keys = [flat.obs_keys[i] for i in np.nonzero(flat.obs_point == k)[0]]
+        assert keys == [(el.image_id, el.point2D_idx) for el in rec.points3D[pid].track.elements], pid
+    # a missing patch: error for the optimiser, skipped by the extractors
+    name, p2d = rec.images[3].name, next(i for i, p in enumerate(rec.images[3].points2D) if p.has_point3D())
+    del fset.fmaps[name].patches[p2d]
+    with pytest.raises(ValueError, match="no feature patch"):
+        _FlatBA(rec, setup, FeatureView(fset, rec), {})
+    q_before = [np.array(rec.images[i].qvec, copy=True) * 1.0 for i in rec.images]
+    for i in rec.images:
+        rec.images[i].qvec = np.asarray(rec.images[i].qvec) * 2.0              # un-normalised on purpose
+    flat_x = _FlatBA(rec, setup, FeatureView(fset, rec), {}, extractor=True)
+    assert len(flat_x.obs_image) == 59
+    assert all(np.array_equal(rec.images[i].qvec, 2.0 * q) for i, q in zip(rec.images, q_before))   # const Reconstruction
+
+
 def test_qka_problem_assembly_and_validation():
     """Host side of the localization QKA mirror: term assembly, inlier masks, argument checks."""
     from pixsfm_amd.api import QueryKeypointAdjuster, features

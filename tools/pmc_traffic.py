@@ -1,0 +1,37 @@
+"""HBM bytes per launch of one kernel from two separate rocprofv3 passes (`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`,
+each with --kernel-trace --output-format csv): the file bench.py reads as `roofline.traffic`.
+
+    python tools/pmc_traffic.py <fetch dir> <write dir> <kernel name pattern> <out.json> "<command the passes ran>"
+
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts KB and reports half of the bytes of 16 B / lane
+coalesced reads, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE (KB) is taken as reported.  Only launches with with_jacobian
+(the bench's step: the ones with the largest grid) are averaged -- pass the mangled template name to pick them."""
+import csv
+import glob
+import json
+import sys
+
+
+def mean_counter(root, pattern, counter):
+    vals = []
+    for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if pattern in r.get("Kernel_Name", "") and r["Counter_Name"] == counter:
+                vals.append(float(r["Counter_Value"]))
+    if not vals:
+        raise SystemExit("no %s samples for %s under %s" % (counter, pattern, root))
+    return sum(vals) / len(vals), len(vals)
+
+
+fetch_dir, write_dir, pattern, out, cmd = sys.argv[1:6]
+f, nf = mean_counter(fetch_dir, pattern, "FETCH_SIZE")
+w, nw = mean_counter(write_dir, pattern, "WRITE_SIZE")
+rd, wr = 2.0 * f * 1024.0, w * 1024.0
+res = {"kernel": pattern, "FETCH_SIZE_KB_per_launch_raw": f, "n_fetch_samples": nf, "WRITE_SIZE_KB_per_launch_raw": w,
+       "n_write_samples": nw,
+       "correction": "gfx950: read bytes = 2 x FETCH_SIZE x 1024 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported",
+       "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+       "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- " + cmd,
+                    "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- " + cmd]}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))

@@ -286,6 +286,25 @@ int pxr_costmap_extract(pxr_ctx* ctx, pxr_arena* features, pxr_arena* costmaps, 
                         const int64_t* d_patch, const int32_t* d_ref_index, const double* d_refs,
                         const pxr_loss* loss, int as_gradientfield, int apply_sqrt);
 
+/* The general form: CostMapConfig.upsampling_factor and compute_cross_derivative (costmap_extractor.h:42-45).  With
+ * upsampling_factor = 1 and no cross derivative this IS pxr_costmap_extract.  Otherwise the reference interpolates
+ * (FillPointCostmap :280-284, :341-345): output texel (y, x) = the features evaluated at the local patch coordinates
+ * (x, y) / upsampling_factor by PatchInterpolator::EvaluateLocal under `cfg` (bicubic; L2 normalisation applies here),
+ * 4 channels [cost, dcost/dr, dcost/dc, d2cost/drdc] with the cross derivative (:304-317).  The `costmaps` arena must be
+ * int(H (f + 1e-6)) x int(W (f + 1e-6)) x {1, 3, 4} (CreateShallowCostmapFSet :385-390, GetEffectiveChannels :52-61) and
+ * receives the upsampling factor (SetUpsamplingFactor :399; pxr_arena_set_upsampling), which the cost-map BA's coordinate
+ * transform u = (x sx - 0.5 - x0) f then honours (featurepatch.h:250-255).  Note that the reference's own
+ * CostMapBundleOptimizer takes 1 or 3 channels only (costmap_bundle_optimizer.h:9-14): 4-channel maps can be produced,
+ * not optimised over -- here too (pxr_ba_eval rejects them). */
+int pxr_costmap_extract_ex(pxr_ctx* ctx, pxr_arena* features, pxr_arena* costmaps, int64_t first_out, int64_t n,
+                           const int64_t* d_patch, const int32_t* d_ref_index, const double* d_refs,
+                           const pxr_loss* loss, int as_gradientfield, int apply_sqrt, const pxr_interp_cfg* cfg,
+                           double upsampling_factor, int compute_cross_derivative);
+/* FeaturePatch::SetUpsamplingFactor / UpsamplingFactor (features/src/featurepatch.h:208-216) for every patch of an arena;
+ * 1 by default.  Only cost-map arenas (1 / 3 channels) may carry another value. */
+int pxr_arena_set_upsampling(pxr_arena* a, double upsampling_factor);
+double pxr_arena_upsampling(pxr_arena* a);
+
 /* PatchInterpolator::Evaluate / InterpolateNodes, batched (A5, features/src/patch_interpolator.h:86-135;
  * `_features.PatchInterpolator(config).interpolate_nodes(fpatch, xy)`, features/bindings.cc): the normalised
  * bicubic descriptor of arena patch d_patch[i] at keypoint d_kp[i] (COLMAP image coordinates) into

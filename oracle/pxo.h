@@ -96,6 +96,8 @@ void pxo_bicubic_ceres(const pxo_patch* p, double r, double c, double* f, double
                        double* dfdc);
 
 /* ---- A3: PixelInterpolator::Evaluate (interpolation.h:642-677) -------------------- */
+void pxo_pixel_interp_cross(const pxo_patch* p, double r, double c, const pxo_interp_cfg* cfg,
+                            double* f, double* dfdr, double* dfdc, double* dfdrc);
 void pxo_pixel_interp(const pxo_patch* p, double r, double c, const pxo_interp_cfg* cfg,
                       double* f, double* dfdr, double* dfdc);
 
@@ -170,6 +172,8 @@ typedef struct {
   const void* arena; int32_t dtype, H, W, C;
   const int32_t* corners;     /* [n_patches][2] */
   const double* scales;       /* [n_patches][2] */
+  double upsampling;          /* FeaturePatch::upsampling_factor_ of every patch (1 for features; cost maps extracted
+                               * with CostMapConfig.upsampling_factor carry it, costmap_extractor.h:399); 0 reads as 1 */
 } pxo_ba_batch;
 
 /* Evaluate residual + materialised 128 x n Jacobian blocks for obs [first, first+count),

@@ -41,7 +41,7 @@ class BaBatch(C.Structure):
                 ("tvec", C.c_void_p), ("cam_model", C.c_void_p), ("cam_params", C.c_void_p),
                 ("xyz", C.c_void_p), ("refs", C.c_void_p), ("arena", C.c_void_p),
                 ("dtype", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
-                ("corners", C.c_void_p), ("scales", C.c_void_p)]
+                ("corners", C.c_void_p), ("scales", C.c_void_p), ("upsampling", C.c_double)]
 
 
 def build(force=False):
@@ -134,6 +134,14 @@ def pixel_interp(patch, r, c, config):
     f, dr, dc = (np.empty(n) for _ in range(3))
     lib().pxo_pixel_interp(C.byref(patch), C.c_double(r), C.c_double(c), C.byref(config), _p(f), _p(dr), _p(dc))
     return f, dr, dc
+
+
+def pixel_interp_cross(patch, r, c, config):
+    """PixelInterpolator::Evaluate with the cross derivative (interpolation.h:642-677): f, df/dr, df/dc, d2f/drdc."""
+    n = patch.C
+    f, dr, dc, drc = (np.empty(n) for _ in range(4))
+    lib().pxo_pixel_interp_cross(C.byref(patch), C.c_double(r), C.c_double(c), C.byref(config), _p(f), _p(dr), _p(dc), _p(drc))
+    return f, dr, dc, drc
 
 
 def patch_eval(patch, xy, config, want_grad=True):
@@ -253,7 +261,8 @@ def ba_batch(problem):
                 arr("obs_patch", np.int64), arr("image_camera", np.int32), arr("qvec", np.float64),
                 arr("tvec", np.float64), arr("cam_model", np.int32), arr("cam_params", np.float64),
                 arr("xyz", np.float64), arr("refs", np.float64) if problem.get("refs") is not None else None, arena.ctypes.data,
-                _NP2DT[arena.dtype], H, W, ch, arr("corners", np.int32), arr("scales", np.float64))
+                _NP2DT[arena.dtype], H, W, ch, arr("corners", np.int32), arr("scales", np.float64),
+                float(problem.get("upsampling", 1.0)))
     return b, keep
 
 

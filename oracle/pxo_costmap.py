@@ -89,6 +89,74 @@ def fill_point_costmap(patch, ref, loss=("trivial", 1.0), as_gradientfield=True,
     return store(np.stack([cost, dr, dc], axis=-1), out_dtype)
 
 
+def cost_patch_shape(H, W, upsampling_factor, channels):
+    """CreateShallowCostmapFSet (costmap_extractor.h:385-390): int(side * (upsampling_factor + 1e-6))."""
+    return int(H * (upsampling_factor + 1.0e-6)), int(W * (upsampling_factor + 1.0e-6)), channels
+
+
+def fill_point_costmap_interpolated(patch, ref, config, loss=("trivial", 1.0), as_gradientfield=True, apply_sqrt=False,
+                                    upsampling_factor=1.0, compute_cross_derivative=False, out_dtype=None):
+    """The branch of FillPointCostmap that INTERPOLATES (costmap_extractor.h:280-284,341-345): taken when the cost
+    patch is not of the feature patch's size (CostMapConfig.upsampling_factor != 1) or compute_cross_derivative is set.
+    Per output texel (y, x): xy = (x, y) / upsampling_factor in LOCAL patch coordinates, PatchInterpolator::EvaluateLocal
+    = PixelInterpolator::Evaluate(r = xy[1], c = xy[0]) with the extractor's InterpolationConfig (l2_normalize applies
+    here, unlike the no-interpolation branch), then the same cost / loss / derivative rules; the cross term follows
+    :304-316.  Statement-by-statement loop over the oracle's C interpolation (small inputs only)."""
+    import pxo
+    patch = np.ascontiguousarray(patch)
+    H, W, C = patch.shape
+    out_dtype = patch.dtype if out_dtype is None else np.dtype(out_dtype)
+    co = (4 if compute_cross_derivative else 3) if as_gradientfield else 1
+    Ho, Wo, _ = cost_patch_shape(H, W, upsampling_factor, co)
+    P = pxo.make_patch(patch)
+    ref = np.asarray(ref, dtype=np.float64)
+    out = np.zeros((Ho, Wo, co))
+    scale = 1.0 / upsampling_factor
+    for y in range(Ho):
+        for x in range(Wo):
+            if as_gradientfield:
+                f, dfdr, dfdc, dfdrc = pxo.pixel_interp_cross(P, y * scale, x * scale, config)
+            else:
+                f = pxo.pixel_interp(P, y * scale, x * scale, config)[0]
+            res = f - ref
+            rho0, rho1 = _rho(loss, np.array([res @ res]))
+            cost = 0.5 * rho0[0]
+            if not as_gradientfield:
+                out[y, x, 0] = np.sqrt(cost) if apply_sqrt else cost
+                continue
+            dr = dc = drc = 0.0
+            if cost > 1.0e-8:
+                dr, dc = rho1[0] * (res @ dfdr), rho1[0] * (res @ dfdc)
+                if compute_cross_derivative:
+                    rho2 = _rho2(loss, res @ res)
+                    drc = rho2 * 2.0 * (res @ dfdr) * (res @ dfdc) + rho1[0] * (dfdr @ dfdc + dfdrc @ res)
+                if apply_sqrt:
+                    cost = np.sqrt(cost)
+                    if compute_cross_derivative:
+                        drc = drc * 0.5 / cost - 0.25 / (cost ** 3) * dr * dc
+                    dr, dc = dr * 0.5 / cost, dc * 0.5 / cost
+            out[y, x, :3] = cost, dr, dc
+            if compute_cross_derivative:
+                out[y, x, 3] = drc
+    return store(out, out_dtype)
+
+
+def _rho2(loss, s):
+    """[upstream ceres/loss_function.cc] rho''(s)."""
+    name, a = loss
+    b = a * a
+    if name == "trivial":
+        return 0.0
+    if name == "cauchy":
+        return -1.0 / (b * (1.0 + s / b) ** 2)
+    if name == "huber":
+        return -(a / np.sqrt(s)) / (2.0 * s) if s > b else 0.0
+    if name == "soft_l1":
+        t = 1.0 + s / b
+        return -1.0 / (2.0 * b * t * np.sqrt(t))
+    raise ValueError(name)
+
+
 def costmaps(patches, obs_patch, obs_point, refs, **kw):
     """One cost map per observation (CostMapExtractor::RunSubset, costmap_extractor.h:192-224):
     observation i -> fill_point_costmap(patches[obs_patch[i]], refs[obs_point[i]])."""

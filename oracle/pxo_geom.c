@@ -403,7 +403,7 @@ static void* ba_worker(void* arg) {
     p.data = (const char*)b->arena + (size_t)pi * b->H * b->W * C * es;
     p.dtype = b->dtype; p.H = b->H; p.W = b->W; p.C = C;
     p.x0 = b->corners[2 * pi]; p.y0 = b->corners[2 * pi + 1];
-    p.sx = b->scales[2 * pi]; p.sy = b->scales[2 * pi + 1]; p.up = 1.0;
+    p.sx = b->scales[2 * pi]; p.sy = b->scales[2 * pi + 1]; p.up = b->upsampling > 0.0 ? b->upsampling : 1.0;
     const int model = b->cam_model[cam];
     const int K = pxo_camera_num_params(model);
     pxo_ba_residual(&p, j->cfg, model, b->qvec + 4 * img, b->tvec + 3 * img, b->xyz + 3 * (int64_t)pt,

@@ -207,15 +207,20 @@ static void get_value_f64(const pxo_patch* p, int r, int c, double* out) {
 
 #define PXO_MAXC 512
 
-/* BiCubicInterpolator::Evaluate (base/src/interpolation.h:220-268 scalar, :177-218 SIMD). */
-void pxo_bicubic(const pxo_patch* p, double r, double c, int use_float_simd, double* f,
-                 double* dfdr, double* dfdc) {
+static void bicubic_ceres_impl(const pxo_patch* p, double r, double c, double* f, double* dfdr, double* dfdc,
+                               double* dfdrc);
+
+/* BiCubicInterpolator::Evaluate (base/src/interpolation.h:220-268 scalar, :177-218 SIMD); dfdrc = the cross
+ * derivative the reference produces when a fourth pointer is passed: the derivative output of the vertical spline over
+ * the row derivatives. */
+static void bicubic_impl(const pxo_patch* p, double r, double c, int use_float_simd, double* f,
+                         double* dfdr, double* dfdc, double* dfdrc) {
   const int C = p->C;
   const int row = (int)floor(r); /* :179 */
   const int col = (int)floor(c);
   double h[4][PXO_MAXC], hd[4][PXO_MAXC];
   if (C < 8) { /* :222-227 falls through to the Ceres scalar path */
-    pxo_bicubic_ceres(p, r, c, f, dfdr, dfdc);
+    bicubic_ceres_impl(p, r, c, f, dfdr, dfdc, dfdrc);
     return;
   }
   const char* base = (const char*)p->data;
@@ -237,19 +242,29 @@ void pxo_bicubic(const pxo_patch* p, double r, double c, int use_float_simd, dou
   }
   if (!use_float_simd) { /* f_k are Eigen::Matrix<double>: vertical pass = double body :210-217 */
     pxo_spline_f64(h[0], h[1], h[2], h[3], C, r - row, f, dfdr);
-    if (dfdc) pxo_spline_f64(hd[0], hd[1], hd[2], hd[3], C, r - row, dfdc, NULL);
+    if (dfdc) pxo_spline_f64(hd[0], hd[1], hd[2], hd[3], C, r - row, dfdc, dfdrc);
   } else { /* f_k are Eigen::Matrix<float>: IN_T = float body, outputs widened into double* f */
     float hf[4][PXO_MAXC], hdf[4][PXO_MAXC];
     for (int j = 0; j < 4; ++j)
       for (int i = 0; i < C; ++i) { hf[j][i] = (float)h[j][i]; hdf[j][i] = (float)hd[j][i]; }
     pxo_spline_lowp(hf[0], hf[1], hf[2], hf[3], PXO_F32, C, r - row, 0, f, dfdr);
-    if (dfdc) pxo_spline_lowp(hdf[0], hdf[1], hdf[2], hdf[3], PXO_F32, C, r - row, 0, dfdc, NULL);
+    if (dfdc) pxo_spline_lowp(hdf[0], hdf[1], hdf[2], hdf[3], PXO_F32, C, r - row, 0, dfdc, dfdrc);
   }
+}
+
+void pxo_bicubic(const pxo_patch* p, double r, double c, int use_float_simd, double* f,
+                 double* dfdr, double* dfdc) {
+  bicubic_impl(p, r, c, use_float_simd, f, dfdr, dfdc, NULL);
 }
 
 /* [upstream] ceres::BiCubicInterpolator::Evaluate == interpolation.h:228-268. */
 void pxo_bicubic_ceres(const pxo_patch* p, double r, double c, double* f, double* dfdr,
                        double* dfdc) {
+  bicubic_ceres_impl(p, r, c, f, dfdr, dfdc, NULL);
+}
+
+static void bicubic_ceres_impl(const pxo_patch* p, double r, double c, double* f, double* dfdr, double* dfdc,
+                               double* dfdrc) {
   const int C = p->C;
   const int row = (int)floor(r);
   const int col = (int)floor(c);
@@ -263,16 +278,23 @@ void pxo_bicubic_ceres(const pxo_patch* p, double r, double c, double* f, double
     pxo_spline_ceres(p0, p1, p2, p3, C, c - col, h[j], hd[j]);
   }
   pxo_spline_ceres(h[0], h[1], h[2], h[3], C, r - row, f, dfdr);
-  if (dfdc) pxo_spline_ceres(hd[0], hd[1], hd[2], hd[3], C, r - row, dfdc, NULL);
+  if (dfdc) pxo_spline_ceres(hd[0], hd[1], hd[2], hd[3], C, r - row, dfdc, dfdrc);
 }
 
 /* PixelInterpolator::Evaluate (base/src/interpolation.h:642-677). */
 void pxo_pixel_interp(const pxo_patch* p, double r, double c, const pxo_interp_cfg* cfg,
                       double* f, double* dfdr, double* dfdc) {
+  pxo_pixel_interp_cross(p, r, c, cfg, f, dfdr, dfdc, NULL);
+}
+
+/* ... with the cross derivative d2f/drdc (:642-646): it comes straight out of the bicubic and is NOT touched by the
+ * L2 normalisation (only f, dfdc and dfdr are, :648-666). */
+void pxo_pixel_interp_cross(const pxo_patch* p, double r, double c, const pxo_interp_cfg* cfg,
+                            double* f, double* dfdr, double* dfdc, double* dfdrc) {
   const int C = p->C;
   double tmp_r[PXO_MAXC];
   /* the reference always computes dfdr (f and dfdr come out of the same spline call) */
-  pxo_bicubic(p, r, c, cfg->use_float_simd, f, dfdr ? dfdr : tmp_r, dfdc);
+  bicubic_impl(p, r, c, cfg->use_float_simd, f, dfdr ? dfdr : tmp_r, dfdc, dfdrc);
   if (cfg->l2_normalize) {
     double ss = 0.0;
     for (int i = 0; i < C; ++i) ss += f[i] * f[i];

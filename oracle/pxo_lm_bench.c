@@ -46,7 +46,7 @@ static pxo_patch patch_of(const pxo_ba_batch* b, int64_t pi) {
   p.data = (const char*)b->arena + (size_t)pi * b->H * b->W * b->C * es;
   p.dtype = b->dtype; p.H = b->H; p.W = b->W; p.C = b->C;
   p.x0 = b->corners[2 * pi]; p.y0 = b->corners[2 * pi + 1];
-  p.sx = b->scales[2 * pi]; p.sy = b->scales[2 * pi + 1]; p.up = 1.0;
+  p.sx = b->scales[2 * pi]; p.sy = b->scales[2 * pi + 1]; p.up = b->upsampling > 0.0 ? b->upsampling : 1.0;
   return p;
 }
 

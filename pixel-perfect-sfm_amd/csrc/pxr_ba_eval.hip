@@ -37,6 +37,7 @@ struct BaEvalArgs {
   const int32_t* corners;
   const double* scales;
   int H, W;
+  double up;          // upsampling_factor_ of the patches (cost maps only; feature patches: 1)
   int l2_normalize;
   int check_bounds;
   pxr_loss loss;      // used when cost_out != NULL
@@ -196,8 +197,9 @@ __global__ __launch_bounds__(256) void ba_eval_small_kernel(const BaEvalArgs a) 
     double x, y;
     world_to_pixel(a.v.d_cam_model[cam], k, q, t, X, x, y);
     const double sx = a.scales[2 * pidx], sy = a.scales[2 * pidx + 1];
-    const double u = x * sx - 0.5 - (double)a.corners[2 * pidx];
-    const double v = y * sy - 0.5 - (double)a.corners[2 * pidx + 1];
+    // FeaturePatch::ToPixelCoordinates (featurepatch.h:250-255) incl. the upsampling factor of cost maps
+    const double u = (x * sx - 0.5 - (double)a.corners[2 * pidx]) * a.up;
+    const double v = (y * sy - 0.5 - (double)a.corners[2 * pidx + 1]) * a.up;
     double f[C], fr[C], fc[C];
     interp_small<ST, C>(reinterpret_cast<const ST*>(a.arena) + (size_t)pidx * a.H * a.W * C, a.H, a.W, u, v,
                         a.l2_normalize != 0, f, fr, fc);
@@ -211,10 +213,10 @@ __global__ __launch_bounds__(256) void ba_eval_small_kernel(const BaEvalArgs a) 
       }
       if (a.out_r) {
         a.out_r[(size_t)i * C + ch] = r;
-        if (WITH_JAC && a.out_gx) { a.out_gx[(size_t)i * C + ch] = fc[ch] * sx; a.out_gy[(size_t)i * C + ch] = fr[ch] * sy; }
+        if (WITH_JAC && a.out_gx) { a.out_gx[(size_t)i * C + ch] = fc[ch] * sx * a.up; a.out_gy[(size_t)i * C + ch] = fr[ch] * sy * a.up; }
       }
     }
-    rec[1] *= sx * sx; rec[2] *= sx * sy; rec[3] *= sy * sy; rec[4] *= sx; rec[5] *= sy;
+    { const double ux = sx * a.up, uy = sy * a.up; rec[1] *= ux * ux; rec[2] *= ux * uy; rec[3] *= uy * uy; rec[4] *= ux; rec[5] *= uy; }
     rec[6] = x; rec[7] = y;
     if (a.check_bounds && !(u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H)) rec[0] = __builtin_nan("");
     double2* o = reinterpret_cast<double2*>(a.rec + (size_t)i * PXR_OBS_REC);
@@ -326,6 +328,7 @@ int pxr::ba_eval_with_cost(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* vi
   PXR_REQUIRE(ctx && arena && view && cfg && d_rec, "pxr_ba_eval: NULL argument");
   PXR_REQUIRE(!d_cost_sum || loss, "pxr_ba_eval: the fused cost needs a loss");
   PXR_REQUIRE(view->n_obs >= 0, "pxr_ba_eval: negative n_obs");
+  PXR_REQUIRE(arena->up == 1.0 || arena->C <= 4, "pxr_ba_eval: an upsampling factor is a property of cost maps (1 / 3 channels)");
   PXR_REQUIRE((d_gx == nullptr) == (d_gy == nullptr), "pxr_ba_eval: d_gx and d_gy must be given together");
   PXR_REQUIRE(!(d_gx && !d_r), "pxr_ba_eval: d_gx/d_gy require d_r");
   if (view->n_obs == 0) return PXR_OK;
@@ -333,7 +336,7 @@ int pxr::ba_eval_with_cost(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* vi
   pxr::BaEvalArgs a;
   a.v = *view;
   a.arena = arena->d_data; a.corners = arena->d_corners; a.scales = arena->d_scales;
-  a.H = arena->H; a.W = arena->W; a.l2_normalize = cfg->l2_normalize; a.check_bounds = cfg->check_bounds;
+  a.H = arena->H; a.W = arena->W; a.up = arena->up; a.l2_normalize = cfg->l2_normalize; a.check_bounds = cfg->check_bounds;
   a.rec = d_rec; a.out_r = d_r; a.out_gx = d_gx; a.out_gy = d_gy;
   a.cost_out = d_cost_sum;
   if (loss) a.loss = *loss; else { a.loss.type = PXR_LOSS_TRIVIAL; a.loss.a = 1.0; }

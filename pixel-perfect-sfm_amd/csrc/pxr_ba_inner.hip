@@ -28,6 +28,7 @@ struct InnerArgs {
   pxr_ba_view v;               // candidate parameters; d_xyz is updated in place
   const void* arena; const int32_t* corners; const double* scales; int H, W;
   int l2_normalize, check_bounds;
+  double up;                   // upsampling_factor_ of the patches (cost maps only; feature patches: 1)
   pxr_loss loss;
   const int64_t* pt_ptr; const int64_t* pt_obs; const int* pt_var;
   double* xyz_out;             // == v.d_xyz (mutable alias)
@@ -132,8 +133,9 @@ __device__ __forceinline__ void inner_points_body(const InnerArgs& a, double (*s
       }
       double x, y, A[2][3], Pq[2][4], PX[2][3], Pk[2][PXR_KPAD];
       world_to_pixel_jac(model, k, q, t, Xc, x, y, A, Pq, PX, Pk);
-      const double u = x * sx - 0.5 - cx;
-      const double v = y * sy - 0.5 - cy;
+      // FeaturePatch::ToPixelCoordinates (featurepatch.h:250-255); cost maps may carry an upsampling factor
+      double u = x * sx - 0.5 - cx, v = y * sy - 0.5 - cy;
+      if constexpr (C < 64) { u *= a.up; v *= a.up; sx *= a.up; sy *= a.up; }   // sx, sy: chain-rule factors from here on
       double f[CH], fr[CH], fc[CH];
       if constexpr (C >= 64)
         interp8<ST, LPO, true, FS>(arena + (size_t)pi * patch_elems, a.H, a.W, C, sub, u, v, a.l2_normalize != 0, f, fr, fc);
@@ -291,7 +293,7 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   InnerArgs a;
   a.v = *view;
   a.arena = arena->d_data; a.corners = arena->d_corners; a.scales = arena->d_scales;
-  a.H = arena->H; a.W = arena->W; a.l2_normalize = cfg->l2_normalize; a.check_bounds = cfg->check_bounds; a.loss = *loss;
+  a.H = arena->H; a.W = arena->W; a.up = arena->up; a.l2_normalize = cfg->l2_normalize; a.check_bounds = cfg->check_bounds; a.loss = *loss;
   a.pt_ptr = d_pt_ptr; a.pt_obs = d_pt_obs; a.pt_var = d_pt_var;
   a.xyz_out = const_cast<double*>(view->d_xyz); a.cost_before = d_cost_before;
   const int ppb = arena->C >= 64 ? 4 : 32;   // points per workgroup (InnerShape)

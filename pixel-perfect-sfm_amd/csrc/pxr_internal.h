@@ -31,6 +31,7 @@ struct pxr_arena {
   bool owns_data = false;
   int32_t* d_corners = nullptr;
   double* d_scales = nullptr;
+  double up = 1.0;               // FeaturePatch::upsampling_factor_ of every patch (cost maps; 1 for feature patches)
   size_t elem_size() const { return dtype == PXR_F16 ? 2 : (dtype == PXR_F32 ? 4 : 8); }
   size_t patch_bytes() const { return (size_t)H * W * C * elem_size(); }
 };

@@ -61,7 +61,9 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 template <typename ST, int LPO, bool WITH_JAC, bool FLOAT_SIMD>
 __device__ __forceinline__ void interp8(const ST* __restrict__ patch, int H, int W, int C, int sub,
                                         double u, double v, bool l2_normalize, double f[8],
-                                        double fr[8], double fc[8]) {
+                                        double fr[8], double fc[8], double* frc = nullptr) {
+  // frc (optional, WITH_JAC only): the cross derivative d2f / dr dc -- the derivative output of the vertical spline over
+  // the row derivatives; the reference leaves it un-normalised (interpolation.h:642-666)
   // BiCubicInterpolator::EvaluateSIMD: r = v (row), c = u (column)
   const double rf = floor(v), cf = floor(u);
   const int row = (int)rf, col = (int)cf;
@@ -115,8 +117,10 @@ __device__ __forceinline__ void interp8(const ST* __restrict__ patch, int H, int
     for (int ch = 0; ch < 8; ++ch) {
       float ff, dd = 0.f, cc = 0.f, dummy = 0.f;
       spline_f32<WITH_JAC>((float)h[0][ch], (float)h[1][ch], (float)h[2][ch], (float)h[3][ch], kv, ff, dd);
-      if (WITH_JAC)
-        spline_f32<false>((float)hd[0][ch], (float)hd[1][ch], (float)hd[2][ch], (float)hd[3][ch], kv, cc, dummy);
+      if (WITH_JAC) {
+        if (frc) { spline_f32<true>((float)hd[0][ch], (float)hd[1][ch], (float)hd[2][ch], (float)hd[3][ch], kv, cc, dummy); frc[ch] = (double)dummy; }
+        else spline_f32<false>((float)hd[0][ch], (float)hd[1][ch], (float)hd[2][ch], (float)hd[3][ch], kv, cc, dummy);
+      }
       f[ch] = (double)ff; fr[ch] = (double)dd; fc[ch] = (double)cc;
     }
   } else {
@@ -125,8 +129,10 @@ __device__ __forceinline__ void interp8(const ST* __restrict__ patch, int H, int
     for (int ch = 0; ch < 8; ++ch) {
       double ff = 0, dd = 0, cc = 0, dummy = 0;
       spline_f64<true, WITH_JAC>((double)h[0][ch], (double)h[1][ch], (double)h[2][ch], (double)h[3][ch], kv, ff, dd);
-      if (WITH_JAC)
-        spline_f64<true, false>((double)hd[0][ch], (double)hd[1][ch], (double)hd[2][ch], (double)hd[3][ch], kv, cc, dummy);
+      if (WITH_JAC) {
+        if (frc) { spline_f64<true, true>((double)hd[0][ch], (double)hd[1][ch], (double)hd[2][ch], (double)hd[3][ch], kv, cc, dummy); frc[ch] = dummy; }
+        else spline_f64<true, false>((double)hd[0][ch], (double)hd[1][ch], (double)hd[2][ch], (double)hd[3][ch], kv, cc, dummy);
+      }
       f[ch] = ff; fr[ch] = dd; fc[ch] = cc;
     }
   }

@@ -185,6 +185,13 @@ int pxr_arena_upload(pxr_arena* a, int64_t first, int64_t count, const void* h_p
   return PXR_OK;
 }
 
+int pxr_arena_set_upsampling(pxr_arena* a, double upsampling_factor) {
+  PXR_REQUIRE(a, "pxr_arena_set_upsampling: arena is NULL");
+  PXR_REQUIRE(upsampling_factor > 0.0, "pxr_arena_set_upsampling: the factor must be positive");
+  a->up = upsampling_factor;
+  return PXR_OK;
+}
+double pxr_arena_upsampling(pxr_arena* a) { return a ? a->up : 1.0; }
 void* pxr_arena_data(pxr_arena* a) { return a ? a->d_data : nullptr; }
 int32_t* pxr_arena_corners(pxr_arena* a) { return a ? a->d_corners : nullptr; }
 double* pxr_arena_scales(pxr_arena* a) { return a ? a->d_scales : nullptr; }

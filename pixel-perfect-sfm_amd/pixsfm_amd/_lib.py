@@ -105,6 +105,10 @@ _SIGNATURES = {
                                             C.POINTER(Loss), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pxr_costmap_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.POINTER(Loss), C.c_int, C.c_int]),
+    "pxr_costmap_extract_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.POINTER(Loss), C.c_int, C.c_int, C.POINTER(InterpCfg), C.c_double, C.c_int]),
+    "pxr_arena_set_upsampling": (C.c_int, [C.c_void_p, C.c_double]),
+    "pxr_arena_upsampling": (C.c_double, [C.c_void_p]),
     "pxr_interpolate": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(InterpCfg), C.c_int64, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "pxr_nearest_references": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(InterpCfg), C.c_int64, C.c_void_p, C.c_void_p,

@@ -325,12 +325,13 @@ class CostMapExtractor:
         ic = interpolation_config
         self.interpolation = ic if isinstance(ic, base.InterpolationConfig) else base.InterpolationConfig(ic)
         self.ctx, self.chunk_bytes = ctx, int(chunk_bytes)
-        if self.config['compute_cross_derivative'] or float(self.config['upsampling_factor']) != 1.0:
-            raise ValueError("compute_cross_derivative / upsampling_factor != 1 are outside the accelerated path "
-                             "(the configuration of pixsfm's CostMapBundleAdjuster, main.py:227-238, is supported)")
+        if float(self.config['upsampling_factor']) <= 0.0:
+            raise ValueError("upsampling_factor must be positive")
 
     def get_effective_channels(self):                                            # costmap_extractor.h:52-61
-        return 3 if self.config['as_gradientfield'] else 1
+        if not self.config['as_gradientfield']:
+            return 1
+        return 4 if self.config['compute_cross_derivative'] else 3
 
     def run(self, problem_labels, reconstruction, feature_set, ref_extractor):
         from ..engine import PatchArena
@@ -357,7 +358,11 @@ class CostMapExtractor:
             if any(p.shape[0] < H or p.shape[1] < W for p in flat.patches):
                 raise ValueError("dense_cut_size exceeds a dense feature map")           # THROW_CHECK_LE, featurepatch.cc:342-343
         dtype = first.arena.dtype if isinstance(first, features.ArenaPatch) else first.data.dtype
-        costmaps = PatchArena(ctx, n_obs, H, W, self.get_effective_channels(), dtype)
+        up = float(self.config['upsampling_factor'])
+        cross = bool(self.config['compute_cross_derivative'])
+        costmaps = PatchArena(ctx, n_obs, int(H * (up + 1.0e-6)), int(W * (up + 1.0e-6)),     # costmap_extractor.h:385-390
+                              self.get_effective_channels(), dtype)
+        costmaps.upsampling_factor = up
         loss = make_loss(self.config['loss']['name'], self.config['loss']['params'])
         # chunks of whole points
         obs_of_point = [[] for _ in flat.point_ids]
@@ -396,7 +401,8 @@ class CostMapExtractor:
                 arena = features.to_arena(ctx, windows)
                 ba = BAProblem(ctx, arena, sub.problem_dict(refs_host, arena.index))
             ba.extract_costmaps(loss, as_gradientfield=self.config['as_gradientfield'], apply_sqrt=self.config['apply_sqrt'],
-                                out=costmaps, first_out=offset)
+                                out=costmaps, first_out=offset, upsampling_factor=up, compute_cross_derivative=cross,
+                                cfg=self.interpolation.to_engine())
             arena.close()                                                        # synchronises the stream first
             map_index[sub.obs] = offset + np.arange(len(sub.obs))
             offset += len(sub.obs)

@@ -221,6 +221,15 @@ class PatchArena:
     def data_ptr(self):
         return self.ctx.lib.pxr_arena_data(self.handle)
 
+    @property
+    def upsampling_factor(self):
+        """FeaturePatch::UpsamplingFactor of every patch of the arena (cost maps; 1 for feature patches)."""
+        return float(self.ctx.lib.pxr_arena_upsampling(self.handle))
+
+    @upsampling_factor.setter
+    def upsampling_factor(self, value):
+        check(self.ctx.lib.pxr_arena_set_upsampling(self.handle, float(value)), "pxr_arena_set_upsampling")
+
     def close(self):
         if getattr(self, "handle", None) and self.ctx.handle:
             self.ctx.lib.pxr_arena_destroy(self.handle)
@@ -356,7 +365,8 @@ class BAProblem:
                       self.n_cameras, d["cam_model"].ptr, d["cam_params"].ptr,
                       self.n_points, d["xyz"].ptr, d["refs"].ptr if d["refs"] is not None else None)
 
-    def extract_costmaps(self, loss, as_gradientfield=True, apply_sqrt=False, dtype=None, out=None, first_out=0):
+    def extract_costmaps(self, loss, as_gradientfield=True, apply_sqrt=False, dtype=None, out=None, first_out=0,
+                         upsampling_factor=1.0, compute_cross_derivative=False, cfg=None):
         """CostMapExtractor (bundle_adjustment/src/costmap_extractor.h:177-358) on the GPU: one cost map per
         observation -- the featuremetric error of every texel of its feature patch against the reference of
         its 3D point (this problem's `refs`, e.g. after compute_references()).  Returns a PatchArena of
@@ -366,11 +376,21 @@ class BAProblem:
         ctx, a = self.ctx, self.arena
         if self.d["refs"] is None:
             raise ValueError("cost maps need reference descriptors")
+        up = float(upsampling_factor)
+        co = (4 if compute_cross_derivative else 3) if as_gradientfield else 1          # GetEffectiveChannels
         if out is None:
-            out = PatchArena(ctx, self.n_obs, a.H, a.W, 3 if as_gradientfield else 1, a.dtype if dtype is None else dtype)
-        check(ctx.lib.pxr_costmap_extract(ctx.handle, a.handle, out.handle, int(first_out), self.n_obs, self.d["obs_patch"].ptr,
-                                          self.d["obs_point"].ptr, self.d["refs"].ptr, C.byref(loss),
-                                          int(bool(as_gradientfield)), int(bool(apply_sqrt))), "pxr_costmap_extract")
+            out = PatchArena(ctx, self.n_obs, int(a.H * (up + 1.0e-6)), int(a.W * (up + 1.0e-6)), co,
+                             a.dtype if dtype is None else dtype)
+        if up == 1.0 and not compute_cross_derivative:
+            check(ctx.lib.pxr_costmap_extract(ctx.handle, a.handle, out.handle, int(first_out), self.n_obs, self.d["obs_patch"].ptr,
+                                              self.d["obs_point"].ptr, self.d["refs"].ptr, C.byref(loss),
+                                              int(bool(as_gradientfield)), int(bool(apply_sqrt))), "pxr_costmap_extract")
+        else:       # CostMapConfig.upsampling_factor / compute_cross_derivative: the interpolating branch, under `cfg`
+            cfg = cfg if cfg is not None else interp_cfg()
+            check(ctx.lib.pxr_costmap_extract_ex(ctx.handle, a.handle, out.handle, int(first_out), self.n_obs,
+                                                 self.d["obs_patch"].ptr, self.d["obs_point"].ptr, self.d["refs"].ptr,
+                                                 C.byref(loss), int(bool(as_gradientfield)), int(bool(apply_sqrt)),
+                                                 C.byref(cfg), up, int(bool(compute_cross_derivative))), "pxr_costmap_extract_ex")
         return out
 
     def costmap_problem(self, costmaps):

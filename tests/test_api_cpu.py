@@ -81,8 +81,9 @@ def test_keypoint_setup_and_confs():
     assert cm.conf["costmaps"]["loss"]["name"] == "trivial" and cm.conf["costmaps"]["as_gradientfield"] is True
     from pixsfm_amd.api import CostMapExtractor
     assert CostMapExtractor({}).get_effective_channels() == 3 and CostMapExtractor({"as_gradientfield": False}).get_effective_channels() == 1
+    assert CostMapExtractor({"compute_cross_derivative": True}).get_effective_channels() == 4       # costmap_extractor.h:52-61
     with pytest.raises(ValueError):
-        CostMapExtractor({"compute_cross_derivative": True})
+        CostMapExtractor({"upsampling_factor": 0.0})
     ba = BundleAdjuster.create({})
     assert ba.conf["optimizer"]["solver"]["use_inner_iterations"] is True and ba.conf["references"]["iters"] == 100
 

@@ -177,7 +177,7 @@ def test_costmap_argument_errors(ctx):
     with pytest.raises(ValueError):
         noref.extract_costmaps(make_loss("trivial", []))
     import ctypes as C
-    wrong = PatchArena(ctx, ba.n_obs, 16, 16, 4)        # compute_cross_derivative layout: not supported
+    wrong = PatchArena(ctx, ba.n_obs, 16, 16, 4)        # the 4-channel (cross derivative) layout belongs to pxr_costmap_extract_ex
     with pytest.raises(PixsfmHipError):
         from pixsfm_amd._lib import check
         check(ctx.lib.pxr_costmap_extract(ctx.handle, arena.handle, wrong.handle, 0, ba.n_obs, ba.d["obs_patch"].ptr,
@@ -444,3 +444,73 @@ def test_costmap_inner_iterations_on_long_tracks(ctx):
     assert s_gpu["iterations"] == s_cpu["iterations"] and s_gpu["num_successful"] == s_cpu["num_successful"]
     assert abs(s_gpu["final_cost"] - s_cpu["final_cost"]) < 1e-6 * s_cpu["final_cost"]
     assert np.abs(X - Xo).max() < 1e-6 and np.abs(q - qo).max() < 1e-6
+
+
+@pytest.mark.parametrize("dtype,channels", [(np.float16, 128), (np.float32, 64)])
+@pytest.mark.parametrize("up,grad,cross,sqrt_,loss", [(2.0, True, False, False, ("trivial", [])),
+                                                    (1.0, True, True, False, ("cauchy", [0.25])),
+                                                    (1.0, True, True, True, ("cauchy", [0.25])),
+                                                    (1.5, False, False, True, ("trivial", [])),
+                                                    (2.0, True, True, False, ("huber", [0.3]))])
+def test_interpolated_costmaps_match_oracle(ctx, dtype, channels, up, grad, cross, sqrt_, loss):
+    """CostMapConfig.upsampling_factor / compute_cross_derivative: the INTERPOLATING branch of FillPointCostmap
+    (costmap_extractor.h:280-284, 304-317, 341-345) -- bicubic evaluation at (x, y) / upsampling_factor under the
+    extractor's InterpolationConfig (L2 normalisation on), 4 channels with the cross derivative -- against the oracle's
+    statement-by-statement loop (vs the oracle: parity unpinned, the reference has no cost-map test)."""
+    import pxo
+    import pxo_costmap
+    from pixsfm_amd.engine import interp_cfg, make_loss
+    prob, arena, ba = _setup(ctx, n_cams=3, n_points=4, obs_per_point=2, seed=91, dtype=dtype, channels=channels, patch_size=8)
+    cm = ba.extract_costmaps(make_loss(*loss), as_gradientfield=grad, apply_sqrt=sqrt_, upsampling_factor=up,
+                             compute_cross_derivative=cross, cfg=interp_cfg())
+    co = (4 if cross else 3) if grad else 1
+    assert (cm.H, cm.W, cm.C) == (int(8 * (up + 1e-6)), int(8 * (up + 1e-6)), co) and cm.upsampling_factor == up
+    got, corners, scales = cm.download()
+    assert np.array_equal(corners, prob["corners"][prob["obs_patch"]])
+    for i in range(len(got)):
+        want = pxo_costmap.fill_point_costmap_interpolated(
+            prob["patches"][prob["obs_patch"][i]], prob["refs"][prob["obs_point"][i]], pxo.cfg(),
+            loss=(loss[0], loss[1][0] if loss[1] else 1.0), as_gradientfield=grad, apply_sqrt=sqrt_, upsampling_factor=up,
+            compute_cross_derivative=cross)
+        assert want.shape == got[i].shape and want.dtype == got[i].dtype
+        scale = np.abs(want.astype(np.float64)).max(axis=(0, 1), keepdims=True) + 1e-30
+        err = np.abs(got[i].astype(np.float64) - want.astype(np.float64)) / scale
+        tol = {2: 2e-3, 4: 1e-6}[got.dtype.itemsize]               # storage rounding of values near zero (relative to the channel's range)
+        assert err.max() < tol, (i, err.max())
+
+
+def test_costmap_ba_on_upsampled_maps_matches_oracle(ctx):
+    """Cost maps extracted with upsampling_factor = 2 carry that factor (SetUpsamplingFactor, costmap_extractor.h:399);
+    the cost-map residual then interpolates at u = (x sx - 0.5 - x0) * 2 (featurepatch.h:250-255).  Residuals, Jacobians,
+    cost and a short solve against the oracle on the same maps."""
+    import pxo
+    from pixsfm_amd.engine import interp_cfg, lm_options, make_loss
+    prob, arena, ba = _setup(ctx, n_cams=5, n_points=40, obs_per_point=3, seed=93, dtype=np.float16, patch_size=8)
+    cm = ba.extract_costmaps(make_loss("trivial", []), upsampling_factor=2.0, cfg=interp_cfg())
+    assert cm.H == 16 and cm.upsampling_factor == 2.0
+    cba = ba.costmap_problem(cm)
+    rec, r, gx, gy = cba.eval(interp_cfg(l2_normalize=False), with_jacobian=True, materialize=True)
+    P = cba.projection_jacobian().download()
+    oprob = _costmap_problem(prob, cm.download()[0])
+    oprob["upsampling"] = 2.0
+    cost_o, r_o, J_o = pxo.ba_eval_batch(oprob, pxo.cfg(l2_normalize=False), pxo.loss("cauchy", 0.25), want_r=True, want_J=True)
+    rel = lambda a, b: np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+    assert rel(r.download(), r_o) < 1e-10
+    J = gx.download()[:, :, None] * P[:, None, 0, :] + gy.download()[:, :, None] * P[:, None, 1, :]
+    assert rel(J, J_o) < 1e-10
+    assert abs(cba.cost(make_loss("cauchy", [0.25])) - cost_o) < 1e-10 * abs(cost_o)
+    n_img = 5
+    pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
+    tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
+    gauge = (pose_const, tmask, np.full(n_img, 0b1111, np.uint16), np.zeros(40, np.uint8))
+    for inner in (False, True):
+        for name in ("qvec", "tvec", "xyz"):
+            ba.d[name].upload(prob[name])
+        s = cba.solve(interp_cfg(l2_normalize=False), make_loss("cauchy", [0.25]), *gauge,
+                      options=lm_options(max_iterations=4, use_inner_iterations=inner))
+        so, qo, to, ko, Xo = pxo.ba_solve(oprob, pxo.cfg(l2_normalize=False), pxo.loss("cauchy", 0.25), *gauge,
+                                          pxo.lm_options(max_iterations=4, use_inner_iterations=int(inner)))
+        q, t, k, X = cba.params()
+        assert s["iterations"] == so["iterations"] and s["num_successful"] == so["num_successful"]
+        assert abs(s["final_cost"] - so["final_cost"]) < 1e-6 * so["initial_cost"]
+        assert np.abs(X - Xo).max() < 1e-6 and np.abs(q - qo).max() < 1e-6

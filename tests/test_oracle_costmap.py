@@ -153,3 +153,35 @@ def test_reference_free_residual_block_finite_differences(channels):
             rm = pxo.ba_residual(patch, cfg, 2, args[3], args[1], args[0], args[2], None, jac=False)[0]
             fd = (rp - rm) / (2 * h)
             assert np.abs(fd - J[:, j]).max() < 1e-5 * max(1.0, np.abs(J[:, j]).max())
+
+
+def test_cross_derivative_and_interpolated_branch_by_finite_differences():
+    """The oracle's cross derivative d2f/drdc (the fourth output of PixelInterpolator::Evaluate, interpolation.h:642-646;
+    not touched by the L2 normalisation) and the cost-map cross term (costmap_extractor.h:304-308) against central
+    differences of the quantities they differentiate."""
+    import pxo
+    import pxo_costmap
+    rng = np.random.default_rng(8)
+    patch = rng.normal(0, 1, (8, 8, 16)).astype(np.float64)
+    P = pxo.make_patch(patch)
+    cfg = pxo.cfg(l2_normalize=False)
+    h = 1e-5
+    for r, c in ((3.3, 4.7), (2.05, 2.9), (5.5, 1.25)):
+        f, dr, dc, drc = pxo.pixel_interp_cross(P, r, c, cfg)
+        fd = (pxo.pixel_interp_cross(P, r, c + h, cfg)[1] - pxo.pixel_interp_cross(P, r, c - h, cfg)[1]) / (2 * h)
+        assert np.abs(drc - fd).max() < 1e-6 * max(1.0, np.abs(fd).max())
+        f2, dr2, dc2 = pxo.pixel_interp(P, r, c, cfg)
+        assert np.array_equal(f, f2) and np.array_equal(dr, dr2) and np.array_equal(dc, dc2)
+    # cost-map cross term: d/dc of dcost/dr, evaluated through an upsampled grid (texel spacing 1/64)
+    ref = rng.normal(0, 1, 16)
+    up = 64.0
+    cm = pxo_costmap.fill_point_costmap_interpolated(patch[:3, :3].copy(), ref, cfg, loss=("cauchy", 0.5), upsampling_factor=up,
+                                                     compute_cross_derivative=True, out_dtype=np.float64)
+    assert cm.shape == (192, 192, 4)
+    y, x = 70, 90
+    fd_r = (cm[y + 1, x, 0] - cm[y - 1, x, 0]) * up / 2            # dcost/dr by differences of the cost channel
+    fd_c = (cm[y, x + 1, 0] - cm[y, x - 1, 0]) * up / 2
+    fd_rc = (cm[y, x + 1, 1] - cm[y, x - 1, 1]) * up / 2           # d/dc of the dcost/dr channel
+    assert abs(cm[y, x, 1] - fd_r) < 1e-3 * max(1.0, abs(fd_r)) and abs(cm[y, x, 2] - fd_c) < 1e-3 * max(1.0, abs(fd_c))
+    assert abs(cm[y, x, 3] - fd_rc) < 2e-3 * max(1.0, abs(fd_rc))
+    assert pxo_costmap.cost_patch_shape(16, 16, 1.5, 3) == (24, 24, 3) and pxo_costmap.cost_patch_shape(12, 12, 1.0, 1) == (12, 12, 1)

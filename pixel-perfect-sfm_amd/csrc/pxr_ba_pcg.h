@@ -25,6 +25,7 @@ struct PcgArgs {
   double* Gm;                        // [n_groups][PCG_GS][PCG_GS]
   double *x, *r, *p, *q, *z, *b;     // [n_c]
   double* cgs;                       // [8] scalars
+  double* cg_part;                   // [8][ceil(n_c / 256)] per-block partial sums of the dot products
   int* d_fail;
 };
 

@@ -219,7 +219,29 @@ __global__ __launch_bounds__(256) void k_pre_invert(int n_groups, const int* __r
   }
 }
 
-// ---- conjugate-gradient vector kernels; device scalars cgs = {rho, rho_prev, p.q, x.b, x.r, r.r, -, -} -------
+// ---- conjugate-gradient vector kernels; device scalars cgs = {rho, rho_prev, p.q, x.b, x.r, r.r, |b|^2, -} -------
+// The dot products are DETERMINISTIC: every 256-thread block reduces in a fixed tree and writes its partial sum to
+// part[slot][block]; k_cg_finalize adds the partials in block order.  All CG vectors are replicated over the ranks and
+// built from all-reduced (hence bit-identical) data, so with order-fixed reductions alpha, beta and every stopping
+// decision of the host loop are bit-identical on all ranks -- a rank leaving the loop one iteration early would leave
+// the others waiting in the next all-reduce.  (Floating-point atomics would make the last bits rank-dependent.)
+constexpr int CG_SLOTS = 8;
+
+__device__ __forceinline__ void block_partial(double v, double* __restrict__ part, int slot, int nb) {   // 256 threads
+  __shared__ double sh[CG_SLOTS][4];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[slot][threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(size_t)slot * nb + blockIdx.x] = (sh[slot][0] + sh[slot][1]) + (sh[slot][2] + sh[slot][3]);
+}
+
+__global__ void k_cg_finalize(const double* __restrict__ part, int nb, unsigned slot_mask, double* __restrict__ cgs) {
+  const int s = threadIdx.x;
+  if (s >= CG_SLOTS || !((slot_mask >> s) & 1u)) return;
+  double t = 0.0;
+  for (int b = 0; b < nb; ++b) t += part[(size_t)s * nb + b];
+  cgs[s] = t;
+}
 __global__ void k_cg_begin(double* __restrict__ cgs) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     cgs[1] = cgs[0];
@@ -231,9 +253,9 @@ __global__ void k_cg_begin(double* __restrict__ cgs) {
 __global__ __launch_bounds__(256) void k_pre_apply(int n, const int2* __restrict__ col_group,
                                                    const int* __restrict__ group_size, const int* __restrict__ group_cols,
                                                    const double* __restrict__ Ginv, const double* __restrict__ r,
-                                                   double* __restrict__ z, double* __restrict__ cgs) {
+                                                   double* __restrict__ z, double* __restrict__ part) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  double part = 0.0;
+  double v = 0.0;
   if (c < n) {
     const int2 g = col_group[c];
     const int ng = group_size[g.x];
@@ -242,10 +264,9 @@ __global__ __launch_bounds__(256) void k_pre_apply(int n, const int2* __restrict
     double acc = 0.0;
     for (int b = 0; b < ng; ++b) acc += row[b] * r[cols[b]];
     z[c] = acc;
-    part = r[c] * acc;
+    v = r[c] * acc;
   }
-  part = wave_sum(part);
-  if ((threadIdx.x & 63) == 0 && part != 0.0) atomicAdd(cgs + 0, part);
+  block_partial(v, part, 0, gridDim.x);
 }
 
 __global__ void k_cg_p_update(int n, int first, const double* __restrict__ z, double* __restrict__ p,
@@ -257,23 +278,24 @@ __global__ void k_cg_p_update(int n, int first, const double* __restrict__ z, do
 }
 
 // q += D p / radius (after the all-reduce of the partial products), p.q
-__global__ void k_cg_q_finish(int n, const double* __restrict__ damp, double inv_radius, const double* __restrict__ p,
-                              double* __restrict__ q, double* __restrict__ cgs) {
+__global__ __launch_bounds__(256) void k_cg_q_finish(int n, const double* __restrict__ damp, double inv_radius,
+                                                     const double* __restrict__ p, double* __restrict__ q,
+                                                     double* __restrict__ part) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  double part = 0.0;
+  double v = 0.0;
   if (i < n) {
     const double qi = q[i] + damp[i] * inv_radius * p[i];
     q[i] = qi;
-    part = p[i] * qi;
+    v = p[i] * qi;
   }
-  part = wave_sum(part);
-  if ((threadIdx.x & 63) == 0 && part != 0.0) atomicAdd(cgs + 2, part);
+  block_partial(v, part, 2, gridDim.x);
 }
 
 // x += alpha p, r -= alpha q unless the matrix turned out indefinite along p (p.q <= 0: the host stops and keeps x)
-__global__ void k_cg_xr_update(int n, const double* __restrict__ p, const double* __restrict__ q,
-                               const double* __restrict__ b, double* __restrict__ x, double* __restrict__ r,
-                               double* __restrict__ cgs) {
+__global__ __launch_bounds__(256) void k_cg_xr_update(int n, const double* __restrict__ p, const double* __restrict__ q,
+                                                      const double* __restrict__ b, double* __restrict__ x,
+                                                      double* __restrict__ r, const double* __restrict__ cgs,
+                                                      double* __restrict__ part) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const double pq = cgs[2], rho = cgs[0];
   const bool ok = pq > 0.0 && isfinite(pq) && rho != 0.0 && isfinite(rho);
@@ -287,8 +309,9 @@ __global__ void k_cg_xr_update(int n, const double* __restrict__ p, const double
     }
     xb = xi * b[i]; xr = xi * ri; rr = ri * ri;
   }
-  xb = wave_sum(xb); xr = wave_sum(xr); rr = wave_sum(rr);
-  if ((threadIdx.x & 63) == 0) { atomicAdd(cgs + 3, xb); atomicAdd(cgs + 4, xr); atomicAdd(cgs + 5, rr); }
+  block_partial(xb, part, 3, gridDim.x);
+  block_partial(xr, part, 4, gridDim.x);
+  block_partial(rr, part, 5, gridDim.x);
 }
 
 __global__ void k_vec_add(int n, const double* __restrict__ a, double* __restrict__ y) {
@@ -296,11 +319,10 @@ __global__ void k_vec_add(int n, const double* __restrict__ a, double* __restric
   if (i < n) y[i] += a[i];
 }
 
-__global__ void k_dot(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_dot(int n, const double* __restrict__ a, const double* __restrict__ b,
+                                             double* __restrict__ part, int slot) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  double part = i < n ? a[i] * b[i] : 0.0;
-  part = wave_sum(part);
-  if ((threadIdx.x & 63) == 0 && part != 0.0) atomicAdd(out, part);
+  block_partial(i < n ? a[i] * b[i] : 0.0, part, slot, gridDim.x);
 }
 
 // ---- host driver ------------------------------------------------------------------------------------------------
@@ -345,7 +367,9 @@ int pcg_solve(PcgArgs& a, double inv_radius, const pxr_lm_options* opt, const st
   PXR_HIP(hipMemsetAsync(a.x, 0, sizeof(double) * n, st));
   PXR_HIP(hipMemcpyAsync(a.r, a.b, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
   PXR_HIP(hipMemsetAsync(a.cgs, 0, sizeof(double) * 8, st));
-  hipLaunchKernelGGL(k_dot, dim3(nblk(n)), dim3(256), 0, st, n, a.b, a.b, a.cgs + 6);
+  const int nb = (int)nblk(n);
+  hipLaunchKernelGGL(k_dot, dim3(nb), dim3(256), 0, st, n, a.b, a.b, a.cg_part, 6);
+  hipLaunchKernelGGL(k_cg_finalize, dim3(1), dim3(64), 0, st, a.cg_part, nb, 1u << 6, a.cgs);
   double hs[8];
   int h_fail = 0;
   PXR_HIP(hipMemcpyAsync(&h_fail, a.d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -360,7 +384,8 @@ int pcg_solve(PcgArgs& a, double inv_radius, const pxr_lm_options* opt, const st
   double Q0 = 0.0;
   for (int it = 1; it <= max_it; ++it) {
     hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(64), 0, st, a.cgs);
-    hipLaunchKernelGGL(k_pre_apply, dim3(nblk(n)), dim3(256), 0, st, n, a.col_group, a.group_size, a.group_cols, a.Gm, a.r, a.z, a.cgs);
+    hipLaunchKernelGGL(k_pre_apply, dim3(nb), dim3(256), 0, st, n, a.col_group, a.group_size, a.group_cols, a.Gm, a.r, a.z, a.cg_part);
+    hipLaunchKernelGGL(k_cg_finalize, dim3(1), dim3(64), 0, st, a.cg_part, nb, 1u << 0, a.cgs);
     hipLaunchKernelGGL(k_cg_p_update, dim3(nblk(n)), dim3(256), 0, st, n, it == 1 ? 1 : 0, a.z, a.p, a.cgs);
     // q = S p (partial over this rank's points)
     PXR_HIP(hipMemsetAsync(a.q, 0, sizeof(double) * n, st));
@@ -373,8 +398,10 @@ int pcg_solve(PcgArgs& a, double inv_radius, const pxr_lm_options* opt, const st
       });
     RC(hip_check(hipGetLastError(), "pcg matvec kernels"));
     RC(ar(a.q, n));
-    hipLaunchKernelGGL(k_cg_q_finish, dim3(nblk(n)), dim3(256), 0, st, n, a.damp_c, inv_radius, a.p, a.q, a.cgs);
-    hipLaunchKernelGGL(k_cg_xr_update, dim3(nblk(n)), dim3(256), 0, st, n, a.p, a.q, a.b, a.x, a.r, a.cgs);
+    hipLaunchKernelGGL(k_cg_q_finish, dim3(nb), dim3(256), 0, st, n, a.damp_c, inv_radius, a.p, a.q, a.cg_part);
+    hipLaunchKernelGGL(k_cg_finalize, dim3(1), dim3(64), 0, st, a.cg_part, nb, 1u << 2, a.cgs);
+    hipLaunchKernelGGL(k_cg_xr_update, dim3(nb), dim3(256), 0, st, n, a.p, a.q, a.b, a.x, a.r, a.cgs, a.cg_part);
+    hipLaunchKernelGGL(k_cg_finalize, dim3(1), dim3(64), 0, st, a.cg_part, nb, (1u << 3) | (1u << 4) | (1u << 5), a.cgs);
     PXR_HIP(hipMemcpyAsync(hs, a.cgs, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
     PXR_HIP(hipStreamSynchronize(st));
     const double rho = hs[0], pq = hs[2], xb = hs[3], xr = hs[4], rr = hs[5];

@@ -832,7 +832,8 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   if (iterative) {
     RC(d_col_group.upload(col_group, st)); RC(d_group_size.upload(group_size, st)); RC(d_group_cols.upload(group_cols, st));
     RC(pcg_u.alloc((size_t)n_pts * 3)); RC(pcg_mloc.alloc((size_t)n_img * DC * DC));
-    RC(pcg_g.alloc(group_size.size() * PCG_GS * PCG_GS)); RC(pcg_vec.alloc(5 * nc1)); RC(pcg_scal.alloc(8));
+    RC(pcg_g.alloc(group_size.size() * PCG_GS * PCG_GS)); RC(pcg_vec.alloc(5 * nc1));
+    RC(pcg_scal.alloc(8 + 8 * ((nc1 + 255) / 256)));
   }
   double* diagU = gcd.p; double* gc = gcd.p + nc1;
   DevBuf<int> info_buf;
@@ -916,7 +917,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     pcg.group_cols = d_group_cols.p;
     pcg.u = pcg_u.p; pcg.Mloc = pcg_mloc.p; pcg.Gm = pcg_g.p;
     pcg.x = xsol.p; pcg.r = pcg_vec.p; pcg.p = pcg_vec.p + nc1; pcg.q = pcg_vec.p + 2 * nc1; pcg.z = pcg_vec.p + 3 * nc1;
-    pcg.b = pcg_vec.p + 4 * nc1; pcg.cgs = pcg_scal.p; pcg.d_fail = d_info;
+    pcg.b = pcg_vec.p + 4 * nc1; pcg.cgs = pcg_scal.p; pcg.cg_part = pcg_scal.p + 8; pcg.d_fail = d_info;
   }
   const std::function<int(double*, int64_t)> ar_fn = ar;
   // gradient_tolerance [upstream]: max-norm of the gradient in the unscaled variables, over ALL ranks

@@ -312,6 +312,95 @@ __global__ __launch_bounds__(PS * 16) __attribute__((amdgpu_waves_per_eu(2, 2)))
   __shared__ uint4 sh[GRAD ? PS * PS * 16 : 1];
   costmap_f16_body<OT, PS, GRAD, true>(a, n, sh);
 }
+// ---- the INTERPOLATING branch of FillPointCostmap (costmap_extractor.h:280-284,341-345) --------------------------------
+// Taken by the reference when the cost patch is not of the feature patch's size (CostMapConfig.upsampling_factor != 1) or
+// compute_cross_derivative is set: per output texel (y, x) the features are interpolated at the LOCAL patch coordinates
+// (x, y) / upsampling_factor with the extractor's InterpolationConfig (PatchInterpolator::EvaluateLocal: bicubic, L2
+// normalisation with its chain rule -- unlike the branch above, which reads raw texels), then
+//   cost = 0.5 rho(|res|^2)[0];  where cost > 1e-8:  dcost/dr = rho' <res, df/dr>, dcost/dc likewise,
+//   d2cost/drdc = 2 rho'' <res, df/dr> <res, df/dc> + rho' (<df/dr, df/dc> + <d2f/drdc, res>)      (:304-308)
+// and the sqrt variants (:309-317).  A rarely used configuration (neither pixsfm's default_conf nor low_memory.yaml
+// sets it): one workgroup per patch, a group of C / 8 lanes per output texel, the 64 KiB patch served by L1 / L2.
+template <typename ST, typename OT, int C, bool FS>
+__global__ __launch_bounds__(256) void costmap_interp_kernel(const CostmapArgs a, int Ho, int Wo, double inv_up, int grad, int cross,
+                                                             int l2_normalize) {
+  constexpr int LPO = C / 8, G = 256 / LPO;
+  const int grp = threadIdx.x / LPO, sub = threadIdx.x % LPO;
+  const int64_t i = blockIdx.x;
+  const int64_t pi = a.patch[i];
+  const ST* P = reinterpret_cast<const ST*>(a.fin) + (size_t)pi * a.H * a.W * C;
+  if (threadIdx.x == 0) {
+    const int64_t o = a.first_out + i;
+    a.cout[2 * o] = a.cin[2 * pi]; a.cout[2 * o + 1] = a.cin[2 * pi + 1];
+    a.sout[2 * o] = a.sin[2 * pi]; a.sout[2 * o + 1] = a.sin[2 * pi + 1];
+  }
+  double ref[8];
+  {
+    const double* rp = a.refs + (size_t)a.ref_index[i] * C + sub * 8;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) ref[ch] = rp[ch];
+  }
+  OT* out = reinterpret_cast<OT*>(a.fout) + (size_t)(a.first_out + i) * Ho * Wo * a.CO;
+  auto rsum = [](double v) { return LPO == 16 ? row16_sum(v) : row8_sum(v); };
+  const int n_it = (Ho * Wo + G - 1) / G;                 // uniform trip count: the row reductions need whole groups
+  for (int it = 0; it < n_it; ++it) {
+    const int t = min(it * G + grp, Ho * Wo - 1);
+    const int y = t / Wo, x = t - y * Wo;
+    double f[8], fr[8], fc[8], frc[8];
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) frc[ch] = 0.0;
+    if (grad) interp8<ST, LPO, true, FS>(P, a.H, a.W, C, sub, x * inv_up, y * inv_up, l2_normalize != 0, f, fr, fc, cross ? frc : nullptr);
+    else interp8<ST, LPO, false, FS>(P, a.H, a.W, C, sub, x * inv_up, y * inv_up, l2_normalize != 0, f, fr, fc);
+    double s = 0.0, br = 0.0, bc = 0.0, rc = 0.0, xr = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+      const double res = f[ch] - ref[ch];
+      s = fma(res, res, s);
+      if (grad) { br = fma(res, fr[ch], br); bc = fma(res, fc[ch], bc); rc = fma(fr[ch], fc[ch], rc); xr = fma(frc[ch], res, xr); }
+    }
+    s = rsum(s);
+    if (grad) { br = rsum(br); bc = rsum(bc); if (cross) { rc = rsum(rc); xr = rsum(xr); } }
+    if (sub == 0 && it * G + grp < Ho * Wo) {
+      double rho[3];
+      loss_eval(a.loss.type, a.loss.a, 1.0, s, rho);
+      double cost = 0.5 * rho[0];
+      OT* o = out + (size_t)t * a.CO;
+      if (grad) {
+        double dcr = 0.0, dcc = 0.0, dcrc = 0.0;
+        if (cost > 1.0e-8) {
+          dcr = rho[1] * br; dcc = rho[1] * bc;
+          if (cross) dcrc = rho[2] * 2.0 * br * bc + rho[1] * (rc + xr);
+          if (a.apply_sqrt) {
+            cost = sqrt(cost);
+            if (cross) { dcrc *= 0.5 / cost; dcrc += -0.5 * 0.5 / (cost * cost * cost) * dcr * dcc; }
+            dcr *= 0.5 / cost; dcc *= 0.5 / cost;
+          }
+        }
+        o[0] = store_cast<OT>(cost); o[1] = store_cast<OT>(dcr); o[2] = store_cast<OT>(dcc);
+        if (cross) o[3] = store_cast<OT>(dcrc);
+      } else {
+        if (a.apply_sqrt) cost = sqrt(cost);
+        o[0] = store_cast<OT>(cost);
+      }
+    }
+  }
+}
+
+template <typename ST, int C>
+static int launch_costmap_interp(pxr_ctx* ctx, int out_dtype, const CostmapArgs& a, int64_t n, int Ho, int Wo, double up,
+                                 bool grad, bool cross, const pxr_interp_cfg* cfg) {
+  const dim3 grid((unsigned)n), block(256);
+#define CMI(OT, FS) hipLaunchKernelGGL((costmap_interp_kernel<ST, OT, C, FS>), grid, block, 0, ctx->stream, a, Ho, Wo, 1.0 / up, \
+                                       grad ? 1 : 0, cross ? 1 : 0, cfg->l2_normalize)
+  if (cfg->use_float_simd) {
+    if (out_dtype == PXR_F16) CMI(_Float16, true); else if (out_dtype == PXR_F32) CMI(float, true); else CMI(double, true);
+  } else {
+    if (out_dtype == PXR_F16) CMI(_Float16, false); else if (out_dtype == PXR_F32) CMI(float, false); else CMI(double, false);
+  }
+#undef CMI
+  return hip_check(hipGetLastError(), "costmap_interp_kernel launch");
+}
+
 template <typename OT>
 static int launch_costmap_f16(pxr_ctx* ctx, const CostmapArgs& a, int64_t n, bool grad) {
   hipDeviceProp_t prop;

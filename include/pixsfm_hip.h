@@ -389,6 +389,13 @@ int pxr_graph_score_labels(int64_t n_nodes, int64_t n_edges, const int64_t* edge
                            double* scores /* [n_nodes] */);
 int pxr_graph_root_labels(int64_t n_nodes, const int64_t* track_labels, const double* scores,
                           uint8_t* is_root /* [n_nodes] */);
+/* The same three labellings ON THE DEVICE for a flat graph that already lives in HBM (csrc/pxr_graph_gpu.hip): connected
+ * components by label hooking, one wavefront per component replaying the reference's ordered, image-constrained
+ * union-find, scores summed in the reference's order (bit-identical), roots by per-track maximum.  All arrays are device
+ * pointers; matches in Graph order (ascending source node); d_scores / d_is_root may be NULL (roots need scores). */
+int pxr_graph_labels_device(pxr_ctx* ctx, int64_t n_nodes, const int32_t* d_node_image, int64_t n_edges,
+                            const int64_t* d_edge_src, const int64_t* d_edge_dst, const double* d_edge_sim,
+                            int64_t* d_track_labels, double* d_scores, uint8_t* d_is_root, int64_t* h_n_tracks);
 /* Residual-block selection of TopologicalKeypointOptimizer::SetUp + AddIntraResiduals (A12,
  * topological_keypoint_optimizer.h:97-175, featuremetric_keypoint_optimizer.h:158-202): intra-track matches,
  * minus keypoint aliases, optionally root edges only, plus root-regularisation blocks; weights = similarity

@@ -122,6 +122,8 @@ _SIGNATURES = {
                                          C.POINTER(C.c_int64)]),
     "pxr_graph_score_labels": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pxr_graph_root_labels": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pxr_graph_labels_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "pxr_ka_build_edges": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),

@@ -155,6 +155,25 @@ def compute_track_labels(graph):
     return labels.tolist()
 
 
+def compute_labels_on_device(graph, ctx=None):
+    """Track labels, score labels and root labels in one call on the GPU (pxr_graph_labels_device): the flat graph is
+    uploaded once, the three results come back as (track_labels list, scores array, root_labels list of bool) --
+    identical to compute_track_labels / compute_score_labels / compute_root_labels."""
+    import ctypes as C
+    from .. import _lib
+    from .keypoint_adjustment import default_context
+    ctx = ctx or default_context()
+    node_image, src, dst, sim = _flat_graph(graph)
+    n = len(node_image)
+    d_img, d_src, d_dst, d_sim = (ctx.to_device(a, dt) for a, dt in ((node_image, np.int32), (src, np.int64), (dst, np.int64),
+                                                                    (sim, np.float64)))
+    labels, scores, roots = ctx.empty((max(n, 1),), np.int64), ctx.empty((max(n, 1),), np.float64), ctx.empty((max(n, 1),), np.uint8)
+    n_tracks = C.c_int64()
+    _lib.check(ctx.lib.pxr_graph_labels_device(ctx.handle, n, d_img.ptr, len(src), d_src.ptr, d_dst.ptr, d_sim.ptr, labels.ptr,
+                                               scores.ptr, roots.ptr, C.byref(n_tracks)), "pxr_graph_labels_device")
+    return labels.download()[:n].tolist(), scores.download()[:n], [bool(r) for r in roots.download()[:n]]
+
+
 def compute_score_labels(graph, track_labels):                       # graph.cc:208-223
     from .. import _lib
     lib = _lib.load()

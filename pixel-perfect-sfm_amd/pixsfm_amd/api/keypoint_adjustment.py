@@ -257,6 +257,10 @@ class KeypointAdjuster:
 
     def refine_multilevel(self, keypoints_dict, feature_manager, graph, track_labels=None, root_labels=None,
                           problem_setup=None):
+        if track_labels is None and root_labels is None:
+            # main.py:111-118 calls the three labellings one after the other on the host; here one call on the device
+            # the solve runs on anyway (pxr_graph_labels_device: identical labels, scores and roots)
+            track_labels, _, root_labels = base.compute_labels_on_device(graph)
         if track_labels is None:
             track_labels = base.compute_track_labels(graph)
         if root_labels is None:

@@ -1,0 +1,81 @@
+"""GPU: match-graph labelling on the device (pxr_graph_labels_device) against the vectors produced by the
+reference's own graph.cc (tests/golden/graph_ref.npz) and, at size, against the native host implementation (which is
+itself pinned to those vectors): track labels, scores (bit-identical: same summation order), roots."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_graph_golden import _build, _gen  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_device_labelling_matches_the_reference_vectors(ctx):
+    from pixsfm_amd.api import base
+    gen = _gen()
+    gold = np.load(os.path.join(HERE, "golden", "graph_ref.npz"))
+    for name, pairs, mm in gen.cases():
+        g = _build(base, pairs, mm)
+        labels, scores, roots = base.compute_labels_on_device(g, ctx)
+        assert labels == gold[name + "_labels"].tolist(), name
+        assert np.array_equal(scores, gold[name + "_scores"]), name
+        assert [int(r) for r in roots] == gold[name + "_roots"].tolist(), name
+
+
+def _flat_random_graph(rng, n_groups, per, n_img, n_matches, n_cross):
+    n = n_groups * per
+    node_image = rng.integers(0, n_img, n).astype(np.int32)
+    grp = rng.integers(0, n_groups, n_matches)
+    src = (grp * per + rng.integers(0, per, n_matches)).astype(np.int64)
+    dst = (grp * per + rng.integers(0, per, n_matches)).astype(np.int64)
+    src = np.concatenate([src, rng.integers(0, n, n_cross)])          # a few matches between groups: larger components
+    dst = np.concatenate([dst, rng.integers(0, n, n_cross)])
+    keep = node_image[src] != node_image[dst]
+    keep[:50] = True                                                  # keep some same-image / self matches: refused merges
+    src, dst = src[keep], dst[keep]
+    order = np.argsort(src, kind="stable")                            # Graph order: grouped by ascending source node
+    src, dst = src[order], dst[order]
+    sim = np.round(rng.uniform(0.1, 1.0, len(src)), 2)                # coarse similarities: ties everywhere
+    dup = rng.integers(0, len(src), 200)                              # duplicated matches (identical tuples)
+    src, dst, sim = np.concatenate([src, src[dup]]), np.concatenate([dst, dst[dup]]), np.concatenate([sim, sim[dup]])
+    order = np.argsort(src, kind="stable")
+    return node_image, src[order], dst[order], sim[order]
+
+
+@pytest.mark.parametrize("n_groups,per,n_matches", [(1500, 12, 60000), (40, 150, 30000)])
+def test_device_labelling_equals_host_labelling_at_size(ctx, n_groups, per, n_matches):
+    """Many small components (the KA regime) and a few large ones (hundreds of nodes, thousands of matches per
+    component: the wavefront's rank sort and the sequential merge run long)."""
+    from pixsfm_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(n_groups)
+    node_image, src, dst, sim = _flat_random_graph(rng, n_groups, per, 40, n_matches, 300)
+    n, m = len(node_image), len(src)
+    want_l, want_s, want_r = np.empty(n, np.int64), np.empty(n, np.float64), np.empty(n, np.uint8)
+    ntr = C.c_int64()
+    _lib.check(lib.pxr_graph_track_labels(n, node_image.ctypes.data, m, src.ctypes.data, dst.ctypes.data, sim.ctypes.data,
+                                          want_l.ctypes.data, C.byref(ntr)), "host labels")
+    _lib.check(lib.pxr_graph_score_labels(n, m, src.ctypes.data, dst.ctypes.data, sim.ctypes.data, want_l.ctypes.data,
+                                          want_s.ctypes.data), "host scores")
+    _lib.check(lib.pxr_graph_root_labels(n, want_l.ctypes.data, want_s.ctypes.data, want_r.ctypes.data), "host roots")
+    d = [ctx.to_device(a, dt) for a, dt in ((node_image, np.int32), (src, np.int64), (dst, np.int64), (sim, np.float64))]
+    got_l, got_s, got_r = ctx.empty((n,), np.int64), ctx.empty((n,), np.float64), ctx.empty((n,), np.uint8)
+    ntr_d = C.c_int64()
+    _lib.check(lib.pxr_graph_labels_device(ctx.handle, n, d[0].ptr, m, d[1].ptr, d[2].ptr, d[3].ptr, got_l.ptr, got_s.ptr,
+                                           got_r.ptr, C.byref(ntr_d)), "device labels")
+    assert ntr_d.value == ntr.value
+    assert np.array_equal(got_l.download(), want_l)
+    assert np.array_equal(got_s.download(), want_s)
+    assert np.array_equal(got_r.download(), want_r)
+    # labels only (scores / roots optional), and the argument checks
+    only = ctx.empty((n,), np.int64)
+    _lib.check(lib.pxr_graph_labels_device(ctx.handle, n, d[0].ptr, m, d[1].ptr, d[2].ptr, d[3].ptr, only.ptr, None, None, None), "labels only")
+    assert np.array_equal(only.download(), want_l)
+    bad = ctx.to_device(src[::-1].copy(), np.int64)                   # not in Graph order
+    with pytest.raises(_lib.PixsfmHipError):
+        _lib.check(lib.pxr_graph_labels_device(ctx.handle, n, d[0].ptr, m, bad.ptr, d[2].ptr, d[3].ptr, only.ptr, None, None, None), "order")

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256) void costmap_kernel(const CostmapArgs a) {
   }
 }
 
-// ---- the hot configuration: fp16 features, C = 128, square patches of 16 (default) or 8 (low_memory.yaml) ------
+// ---- fp16 features, C = 128, square patches: 8 x 8 (low_memory.yaml) and the cost-only 16 x 16 maps --------------------
+// (16 x 16 with gradients, the default, has its own kernel further down: costmap_kernel_f16_split)
 // The generic kernel above is ALU-bound (fp64 channel math + a 16-lane all-reduce and a one-lane epilogue per
 // texel: 0.34 of the HBM peak).  This one
 //   * is persistent (two workgroups per CU) and prefetches the NEXT patch's column into registers while the
@@ -312,6 +313,172 @@ __global__ __launch_bounds__(PS * 16) __attribute__((amdgpu_waves_per_eu(2, 2)))
   __shared__ uint4 sh[GRAD ? PS * PS * 16 : 1];
   costmap_f16_body<OT, PS, GRAD, true>(a, n, sh);
 }
+// ---- 16 x 16 patches with gradients (the default cost-map configuration): the CHANNELS are split over the wavefronts ------
+// Wavefront w owns channels [32 w, 32 w + 32): lane = (k, x), k = lane >> 4 the 8-channel group, x = lane & 15 the texel
+// COLUMN, whose 16 rows sit in registers.  So
+//   * the left / right neighbours are the adjacent lanes of the DPP row (row_shr:1 / row_shl:1 with the lane's own value as
+//     the out-of-range fill = the reference's clamped index): no LDS copy of the patch, no barrier around it;
+//   * the channel sums of four rows are reduce-scattered over the four 16-lane rows of the wavefront with the gfx950 half /
+//     row exchanges (v_permlane32_swap, v_permlane16_swap: 2 exchanges + 1 add per fp64 pair), DPP-row k ends up with
+//     texel row 4 g + k;
+//   * the four wavefronts' partial sums (3 x 256 doubles each) meet in 24 KB of LDS (double-buffered: ONE barrier per patch)
+//     and thread t finishes texel t: loss, `cost > 1e-8` branch, sqrt and the stores run on all 256 lanes;
+//   * ROLLING REFILL: a row register is reloaded with the NEXT patch's row right after its last use (the rows above
+//     4 g + 3 once row group g is done), so sixteen 16-byte loads per lane are always in flight (s_waitcnt vmcnt(13..18))
+//     and every load has a whole patch period to land, without a second set of registers.  For the counter waits to be
+//     exact the memory side of the loop is branch-free (indices past the end are clamped), the loads are pinned where
+//     they are written (sched_barrier) and nothing else uses the vector-memory counter in the loop body: the patch index
+//     and the reference descriptor are fetched two patches ahead, the descriptor goes through LDS, the corner / scale
+//     copy has its own tiny kernel.  The patch base lives in a buffer descriptor (SGPRs), the lane offset in one VGPR.
+// Measured on MI355X (200k maps, back to back): 3.10 ms against 3.89 ms for the LDS-staged kernel above = 4.4 TB/s
+// algorithmic, 0.55 of the HBM peak.  What bounds it is the vector ALU at the POWER limit: ~1800 vector instructions per
+// lane and patch (43 % of them the two-step half -> float -> double conversions of the reference's contract), every one
+// of which issues in 4 cycles (tools/valu_rate_probe.hip: fp64 fma / add / cvt, packed fp16 and DPP moves all 4 cycles
+// per wavefront, only plain fp32 runs at 2), and the package sits at 1366 W with the shader clock throttled from 2.39 to
+// 2.10 GHz while it runs (profiles/r2_costmap_clock_power.txt): 4 waves x ~8200 cycles per patch and CU / 2.10 GHz =
+// 3.9 us, x 781 patches per CU = 3.05 ms.  Without the loads the same arithmetic takes 2.84 ms, the loads alone 2.72 ms.
+__device__ __forceinline__ double swap_sum32(double A, double B) {   // lanes < 32: A + A(lane + 32); lanes >= 32: B + B(lane - 32)
+  union { double d; unsigned u[2]; } a, b;
+  a.d = A; b.d = B;
+  const auto r0 = __builtin_amdgcn_permlane32_swap(a.u[0], b.u[0], false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap(a.u[1], b.u[1], false, false);
+  a.u[0] = r0[0]; b.u[0] = r0[1]; a.u[1] = r1[0]; b.u[1] = r1[1];
+  return a.d + b.d;
+}
+__device__ __forceinline__ double swap_sum16(double A, double B) {   // even rows: A + A(row + 1); odd rows: B + B(row - 1)
+  union { double d; unsigned u[2]; } a, b;
+  a.d = A; b.d = B;
+  const auto r0 = __builtin_amdgcn_permlane16_swap(a.u[0], b.u[0], false, false);
+  const auto r1 = __builtin_amdgcn_permlane16_swap(a.u[1], b.u[1], false, false);
+  a.u[0] = r0[0]; b.u[0] = r0[1]; a.u[1] = r1[0]; b.u[1] = r1[1];
+  return a.d + b.d;
+}
+
+// CreateShallowCostmapFSet, costmap_extractor.h:382-399: corner and scale of a cost map are the feature patch's
+__global__ void costmap_meta_kernel(const CostmapArgs a, const int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t p = a.patch[i], o = a.first_out + i;
+  a.cout[2 * o] = a.cin[2 * p]; a.cout[2 * o + 1] = a.cin[2 * p + 1];
+  a.sout[2 * o] = a.sin[2 * p]; a.sout[2 * o + 1] = a.sin[2 * p + 1];
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: an array of these is split into registers
+
+template <typename OT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void costmap_kernel_f16_split(const CostmapArgs a, const int64_t n) {
+  constexpr int PS = 16, C = 128;
+  constexpr int ROW_BYTES = PS * C * (int)sizeof(_Float16), PATCH_BYTES = PS * ROW_BYTES;
+  __shared__ double part[2][4][3][PS * PS];
+  __shared__ double refsh[2][C];
+  const int tid = threadIdx.x, w = tid >> 6, k = (tid >> 4) & 3, x = tid & 15;
+  const _Float16* fin = reinterpret_cast<const _Float16*>(a.fin);
+  const unsigned lane_off = (unsigned)((x * C + 32 * w + 8 * k) * sizeof(_Float16));   // bytes; uniform base + 32-bit lane offset
+  const int64_t G = gridDim.x;
+  u32x4 col[PS];
+  double ref[8];
+  auto tex = [](const u32x4& v) { Texel8<_Float16> t; t.raw = make_uint4(v.x, v.y, v.z, v.w); return t; };
+  // The loop body is branch-free on the memory side (indices past the end are clamped to the last patch: one redundant
+  // patch load per workgroup at the very end), so the vector-memory counter waits are exact: loads return in order, and a
+  // branch around a load would force the compiler to wait for ALL outstanding loads at the next use.
+  auto uniform64 = [](int64_t v) {   // the index is the same in every lane: keep it (and the addresses made of it) in SGPRs
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+  };
+  int64_t i = blockIdx.x;
+  if (i >= n) return;
+  auto at = [&](int64_t j) { return j < n ? j : n - 1; };
+  int64_t p1 = uniform64(a.patch[at(i + G)]);
+  int r1 = __builtin_amdgcn_readfirstlane(a.ref_index[at(i + G)]);
+  {
+    // same issue order as in the loop (rows 0 .. 15, then the next reference): the wait counts the compiler derives at the
+    // loop head are the minimum over both ways into it
+    const double* rp = a.refs + (size_t)a.ref_index[i] * C + 32 * w + 8 * k;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) ref[ch] = rp[ch];
+    const auto P = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(fin + (size_t)uniform64(a.patch[i]) * PS * PS * C), 0, PATCH_BYTES, 0x00020000);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int y = 0; y < PS; ++y) {
+      col[y] = __builtin_amdgcn_raw_buffer_load_b128(P, lane_off, y * ROW_BYTES, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  double rnext = a.refs[(size_t)r1 * C + (tid & (C - 1))];      // reference descriptor of patch i + G, handed on through LDS
+  __builtin_amdgcn_sched_barrier(0);
+  int buf = 0;
+  for (; i < n; i += G, buf ^= 1) {
+    // indices two patches ahead (consumed at the end of this iteration, when they are the OLDEST loads in flight)
+    const int64_t i2 = at(i + 2 * G);
+    const int64_t p2v = a.patch[i2];
+    const int r2v = a.ref_index[i2];
+    // the NEXT patch: its rows replace this patch's rows in the registers as soon as the arithmetic below has used them
+    // for the last time, so every row load has a whole patch period to land
+    // buffer addressing: the patch base lives in four SGPRs, the lane's offset in ONE VGPR for all sixteen rows
+    const auto Pn = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(fin + (size_t)p1 * PS * PS * C), 0, PATCH_BYTES, 0x00020000);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      double s[4], br[4], bc[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int y = 4 * g + r;
+        const u32x4 cu = col[y];
+        u32x4 lf, rt;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // clamped horizontal neighbours: a lane without a source keeps its own texel
+          lf[q] = (unsigned)__builtin_amdgcn_update_dpp((int)cu[q], (int)cu[q], 0x111, 0xf, 0xf, false);   // row_shr:1 -> x - 1
+          rt[q] = (unsigned)__builtin_amdgcn_update_dpp((int)cu[q], (int)cu[q], 0x101, 0xf, 0xf, false);   // row_shl:1 -> x + 1
+        }
+        double f[8], dr[8], dc[8];
+        widen8<_Float16>(tex(cu), f);
+        StorageDiff<_Float16>::run(tex(col[y < PS - 1 ? y + 1 : PS - 1]), tex(col[y > 0 ? y - 1 : 0]), dr);
+        StorageDiff<_Float16>::run(tex(rt), tex(lf), dc);
+        double ss = 0.0, sr = 0.0, sc = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+          const double res = f[ch] - ref[ch];
+          ss = fma(res, res, ss); sr = fma(res, dr[ch], sr); sc = fma(res, dc[ch], sc);
+        }
+        s[r] = ss; br[r] = sr; bc[r] = sc;
+      }
+      // rows 4g + 3 and 4g + 4 are still neighbours of the next group; everything above them is dead
+      __builtin_amdgcn_sched_barrier(0);                // keep the refill HERE: the scheduler otherwise sinks it to the end
+#pragma unroll
+      for (int y = (g == 0 ? 0 : 4 * g - 1); y < (g == 3 ? PS : 4 * g + 3); ++y) {
+        col[y] = __builtin_amdgcn_raw_buffer_load_b128(Pn, lane_off, y * ROW_BYTES, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // rows (0, 2) and (1, 3) over the half-waves, then the two results over the row pairs: DPP-row k holds texel row 4 g + k
+      const int t = (4 * g + k) * PS + x;
+      part[buf][w][0][t] = swap_sum16(swap_sum32(s[0], s[2]), swap_sum32(s[1], s[3]));
+      part[buf][w][1][t] = swap_sum16(swap_sum32(br[0], br[2]), swap_sum32(br[1], br[3]));
+      part[buf][w][2][t] = swap_sum16(swap_sum32(bc[0], bc[2]), swap_sum32(bc[1], bc[3]));
+    }
+    if (tid < C) refsh[buf][tid] = rnext;
+    const int64_t p2 = uniform64(p2v);
+    const int r2 = __builtin_amdgcn_readfirstlane(r2v);
+    rnext = a.refs[(size_t)r2 * C + (tid & (C - 1))];
+    __syncthreads();
+    double v[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) v[q] = (part[buf][0][q][tid] + part[buf][1][q][tid]) + (part[buf][2][q][tid] + part[buf][3][q][tid]);
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) ref[ch] = refsh[buf][32 * w + 8 * k + ch];
+    const int64_t o_idx = a.first_out + i;
+    p1 = p2;
+    double rho[3];
+    loss_eval(a.loss.type, a.loss.a, 1.0, v[0], rho);
+    double cost = 0.5 * rho[0], dcr = 0.0, dcc = 0.0;
+    if (cost > 1.0e-8) {                               // costmap_extractor.h:300-318
+      dcr = rho[1] * (0.5 * v[1]); dcc = rho[1] * (0.5 * v[2]);   // sum(res * 0.5 d) == 0.5 * sum(res * d), exactly
+      if (a.apply_sqrt) { cost = sqrt(cost); dcr *= 0.5 / cost; dcc *= 0.5 / cost; }
+    }
+    OT* o = reinterpret_cast<OT*>(a.fout) + ((size_t)o_idx * PS * PS + tid) * 3;
+    o[0] = store_cast<OT>(cost); o[1] = store_cast<OT>(dcr); o[2] = store_cast<OT>(dcc);
+  }
+}
+
 // ---- the INTERPOLATING branch of FillPointCostmap (costmap_extractor.h:280-284,341-345) --------------------------------
 // Taken by the reference when the cost patch is not of the feature patch's size (CostMapConfig.upsampling_factor != 1) or
 // compute_cross_derivative is set: per output texel (y, x) the features are interpolated at the LOCAL patch coordinates
@@ -408,8 +575,12 @@ static int launch_costmap_f16(pxr_ctx* ctx, const CostmapArgs& a, int64_t n, boo
   const int64_t resident = (int64_t)prop.multiProcessorCount * (a.H == 16 ? 2 : 8);
   const dim3 grid((unsigned)(n < resident ? n : resident)), block((unsigned)(a.H * 16));
   if (a.H == 16) {
-    if (grad) hipLaunchKernelGGL((costmap_kernel_f16<OT, 16, true>), grid, block, 0, ctx->stream, a, n);
-    else hipLaunchKernelGGL((costmap_kernel_f16<OT, 16, false>), grid, block, 0, ctx->stream, a, n);
+    if (grad) {   // the channel-split kernel: three workgroups per CU (168 VGPRs, 49 KB of LDS each)
+      const int64_t res3 = (int64_t)prop.multiProcessorCount * 3;
+      const dim3 g3((unsigned)(n < res3 ? n : res3));
+      hipLaunchKernelGGL(costmap_meta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, n);
+      hipLaunchKernelGGL((costmap_kernel_f16_split<OT>), g3, dim3(256), 0, ctx->stream, a, n);
+    } else hipLaunchKernelGGL((costmap_kernel_f16<OT, 16, false>), grid, block, 0, ctx->stream, a, n);
   } else {
     if (grad) hipLaunchKernelGGL((costmap_kernel_f16<OT, 8, true>), grid, block, 0, ctx->stream, a, n);
     else hipLaunchKernelGGL((costmap_kernel_f16<OT, 8, false>), grid, block, 0, ctx->stream, a, n);

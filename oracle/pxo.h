@@ -10,13 +10,18 @@
  * [upstream] marks formulas that live in un-vendored third-party code (Ceres >= 2.1,
  * COLMAP 3.8) and are restated from their published algorithms.
  *
- * Parity status: the spline + grid arithmetic (A2) is pinned bit-exactly against the
- * reference's own cubic_hermite_spline_simd.h / grid2d.h compiled in place
- * (oracle/_ref, see oracle/Makefile) and against the reference's interpolation test
- * cases.  The residual functors (A7-A10), the LM solvers and the reference extraction
- * have no golden vectors in the reference and cannot be run here (Ceres/COLMAP absent):
- * for those rows "parity unpinned" -- they are validated by finite differences and
- * closed-form properties only.
+ * Parity status: pinned against reference code compiled in place (oracle/_ref, recipes in
+ * oracle/Makefile, committed vectors under tests/golden/): the spline + grid arithmetic (A2,
+ * bit-exact); the image->patch coordinates, bounds check, L2 normalisation with its chain rule
+ * and the Jet bridge (A1, A3-A5: features/src/featurepatch.h, patch_interpolator.h,
+ * base/src/interpolation.h); the residual functors and WorldToPixel (A7-A10:
+ * residuals/src/featuremetric.h, feature_reference.h, base/src/projection.h), differentiated
+ * with one dual number per parameter -- with the quaternion rotation and the camera models
+ * under them restated from the published Ceres / COLMAP definitions; the match-graph
+ * labelling (base/src/graph.cc, bit-exact) and the IRLS loop (base/src/irls_optim.h).
+ * "Parity unpinned" (Ceres / COLMAP absent, no golden vectors in the reference): the camera
+ * models themselves (A6), the loss functions and corrector (A20) and the trust-region
+ * solvers (A14, A18) -- validated by finite differences and closed-form properties only.
  */
 #ifndef PXO_H_
 #define PXO_H_

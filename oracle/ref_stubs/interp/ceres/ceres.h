@@ -1,0 +1,65 @@
+// Stub for <ceres/ceres.h>: glog's CHECK_* macros, ceres::sqrt, the Jet type's NAME (the shim differentiates with the
+// reference's analytic derivative path, Jets are never instantiated), and the two Ceres interpolation entry points the
+// reference falls back to below 8 channels / in CERES_BICUBIC mode (declared, aborting: not on the tested path).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include "Eigen/Core"
+#define PXO_STUB_CHECK(cond) do { if (!(cond)) { std::fprintf(stderr, "CHECK failed: %s\n", #cond); std::abort(); } } while (0)
+#define CHECK_GE(a, b) PXO_STUB_CHECK((a) >= (b))
+#define CHECK_LT(a, b) PXO_STUB_CHECK((a) < (b))
+#define CHECK_EQ(a, b) PXO_STUB_CHECK((a) == (b))
+#define CHECK_NOTNULL(a) (a)
+namespace ceres {
+using std::sqrt;
+// A forward-mode dual number standing in for ceres::Jet ([upstream Ceres 2.x] jet.h semantics: value a, derivative vector v;
+// product / quotient / sqrt rules), enough for the reference's coordinate transform, bounds check, projection and Jet bridge.
+template <typename T, int N> struct Jet {
+  T a; Eigen::Matrix<T, N, 1> v;
+  Jet() : a(T(0)) { for (int i = 0; i < N; ++i) v[i] = T(0); }
+  Jet(const T& x) : a(x) { for (int i = 0; i < N; ++i) v[i] = T(0); }     // NOLINT: T(1.0) literals in the reference's templates
+  Jet(const T& x, int k) : a(x) { for (int i = 0; i < N; ++i) v[i] = T(i == k ? 1 : 0); }
+  Jet& operator+=(const Jet& y) { a += y.a; v += y.v; return *this; }
+  Jet& operator-=(const Jet& y) { a -= y.a; v -= y.v; return *this; }
+  Jet& operator*=(const Jet& y) { *this = *this * y; return *this; }
+  Jet& operator/=(const Jet& y) { *this = *this / y; return *this; }
+};
+template <typename T, int N> Jet<T, N> operator-(const Jet<T, N>& x) { Jet<T, N> o; o.a = -x.a; o.v = x.v * T(-1); return o; }
+template <typename T, int N> Jet<T, N> operator+(const Jet<T, N>& x, const Jet<T, N>& y) { Jet<T, N> o; o.a = x.a + y.a; o.v = x.v + y.v; return o; }
+template <typename T, int N> Jet<T, N> operator-(const Jet<T, N>& x, const Jet<T, N>& y) { Jet<T, N> o; o.a = x.a - y.a; o.v = x.v - y.v; return o; }
+template <typename T, int N> Jet<T, N> operator*(const Jet<T, N>& x, const Jet<T, N>& y) { Jet<T, N> o; o.a = x.a * y.a; o.v = y.a * x.v + x.a * y.v; return o; }
+template <typename T, int N> Jet<T, N> operator/(const Jet<T, N>& x, const Jet<T, N>& y) {
+  Jet<T, N> o; const T inv = T(1) / y.a, q = x.a * inv; o.a = q; o.v = (x.v - q * y.v) * inv; return o;
+}
+template <typename T, int N> Jet<T, N> operator+(const Jet<T, N>& x, const T& s) { Jet<T, N> o(x); o.a = x.a + s; return o; }
+template <typename T, int N> Jet<T, N> operator+(const T& s, const Jet<T, N>& x) { return x + s; }
+template <typename T, int N> Jet<T, N> operator-(const Jet<T, N>& x, const T& s) { Jet<T, N> o(x); o.a = x.a - s; return o; }
+template <typename T, int N> Jet<T, N> operator-(const T& s, const Jet<T, N>& x) { Jet<T, N> o = -x; o.a = s - x.a; return o; }
+template <typename T, int N> Jet<T, N> operator*(const Jet<T, N>& x, const T& s) { Jet<T, N> o; o.a = x.a * s; o.v = x.v * s; return o; }
+template <typename T, int N> Jet<T, N> operator*(const T& s, const Jet<T, N>& x) { return x * s; }
+template <typename T, int N> Jet<T, N> operator/(const Jet<T, N>& x, const T& s) { Jet<T, N> o; const T inv = T(1) / s; o.a = x.a * inv; o.v = x.v * inv; return o; }
+template <typename T, int N> Jet<T, N> operator/(const T& s, const Jet<T, N>& x) { return Jet<T, N>(s) / x; }
+template <typename T, int N> bool operator>(const Jet<T, N>& x, const T& s) { return x.a > s; }
+template <typename T, int N> bool operator<(const Jet<T, N>& x, const T& s) { return x.a < s; }
+template <typename T, int N> bool operator<(const Jet<T, N>& x, const Jet<T, N>& y) { return x.a < y.a; }
+template <typename T, int N> bool operator>(const Jet<T, N>& x, const Jet<T, N>& y) { return x.a > y.a; }
+template <typename T, int N> Jet<T, N> sqrt(const Jet<T, N>& x) { Jet<T, N> o; o.a = std::sqrt(x.a); o.v = x.v * (T(1) / (T(2) * o.a)); return o; }
+template <typename T, int N> Jet<T, N> abs(const Jet<T, N>& x) { return x.a < T(0) ? -x : x; }
+using std::abs;
+// the factory plumbing the residual headers name in their static Create() members (never called by the shims)
+class CostFunction { public: virtual ~CostFunction() {} };
+class LossFunction;
+template <typename Functor, int kNumResiduals, int... Ns>
+class AutoDiffCostFunction : public CostFunction { public: explicit AutoDiffCostFunction(Functor* f) : f_(f) {} private: std::unique_ptr<Functor> f_; };
+template <int kDataDimension, typename... A>
+void CubicHermiteSpline(const A&...) { Eigen::stub_unreachable("ceres::CubicHermiteSpline"); }
+template <typename Grid>
+class BiCubicInterpolator {
+ public:
+  explicit BiCubicInterpolator(const Grid&) {}
+  void Evaluate(double, double, double*, double*, double*) const { Eigen::stub_unreachable("ceres::BiCubicInterpolator"); }
+};
+}  // namespace ceres

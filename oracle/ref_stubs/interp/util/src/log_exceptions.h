@@ -1,0 +1,13 @@
+// Shadows the reference's util/src/log_exceptions.h (pybind11 exception plumbing): the check macros as plain aborts.
+#pragma once
+#include <stdexcept>
+#include <string>
+#include "ceres/ceres.h"
+#define THROW_CHECK(c) PXO_STUB_CHECK(c)
+#define THROW_CHECK_NE(a, b) PXO_STUB_CHECK((a) != (b))
+#define THROW_CHECK_EQ(a, b) PXO_STUB_CHECK((a) == (b))
+#define THROW_CHECK_GE(a, b) PXO_STUB_CHECK((a) >= (b))
+#define THROW_CHECK_LT(a, b) PXO_STUB_CHECK((a) < (b))
+#define THROW_CHECK_MSG(c, m) PXO_STUB_CHECK(c)
+#define THROW_CUSTOM_CHECK_MSG(c, e, m) PXO_STUB_CHECK(c)
+#define THROW_EXCEPTION(exception, msg) throw exception(msg)

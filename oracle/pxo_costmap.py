@@ -18,8 +18,9 @@ derivative, :253-279 / :330-340): per texel (y, x)
     for half that is half(float(value)) -- half.hpp has no constructor from double -- i.e. TWO roundings).
 
 The cost patch copies corner and scale of the feature patch (CreateShallowCostmapFSet, :382-399).
-"parity unpinned": the reference has no test or golden vector for cost maps; the two storage-type rounding
-rules above are pinned against the reference's vendored half.hpp (oracle/_ref, tests/test_oracle_costmap.py).
+Parity: pinned against the reference's own FillPointCostmap compiled in place (oracle/ref_costmap_shim.cc ->
+tests/golden/costmap_ref.npz, tests/test_costmap_golden.py: fp16 maps bit for bit) and, for the two storage-type rounding
+rules above, against the reference's vendored half.hpp (oracle/_ref, tests/test_oracle_costmap.py).
 """
 import numpy as np
 

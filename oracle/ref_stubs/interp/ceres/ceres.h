@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <limits>
 #include <memory>
 #include "Eigen/Core"
 #define PXO_STUB_CHECK(cond) do { if (!(cond)) { std::fprintf(stderr, "CHECK failed: %s\n", #cond); std::abort(); } } while (0)
@@ -51,7 +52,44 @@ template <typename T, int N> Jet<T, N> abs(const Jet<T, N>& x) { return x.a < T(
 using std::abs;
 // the factory plumbing the residual headers name in their static Create() members (never called by the shims)
 class CostFunction { public: virtual ~CostFunction() {} };
-class LossFunction;
+// [upstream Ceres 2.1 loss_function.cc]: the rho formulas restated (what a build of the reference's cost-map extraction pins is
+// its own arithmetic around them, not Ceres' robustifiers)
+class LossFunction {
+ public:
+  virtual ~LossFunction() {}
+  virtual void Evaluate(double sq_norm, double out[3]) const = 0;
+};
+class TrivialLoss : public LossFunction {
+ public:
+  void Evaluate(double s, double rho[3]) const override { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
+};
+class CauchyLoss : public LossFunction {
+ public:
+  explicit CauchyLoss(double a) : b_(a * a), c_(1 / b_) {}
+  void Evaluate(double s, double rho[3]) const override {
+    const double sum = 1.0 + s * c_;
+    const double inv = 1.0 / sum;
+    rho[0] = b_ * std::log(sum);
+    rho[1] = std::fmax(std::numeric_limits<double>::min(), inv);
+    rho[2] = -c_ * (inv * inv);
+  }
+ private:
+  const double b_, c_;
+};
+class HuberLoss : public LossFunction {
+ public:
+  explicit HuberLoss(double a) : a_(a), b_(a * a) {}
+  void Evaluate(double s, double rho[3]) const override {
+    if (s > b_) {
+      const double r = std::sqrt(s);
+      rho[0] = 2.0 * a_ * r - b_;
+      rho[1] = std::fmax(std::numeric_limits<double>::min(), a_ / r);
+      rho[2] = -rho[1] / (2.0 * s);
+    } else { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
+  }
+ private:
+  const double a_, b_;
+};
 template <typename Functor, int kNumResiduals, int... Ns>
 class AutoDiffCostFunction : public CostFunction { public: explicit AutoDiffCostFunction(Functor* f) : f_(f) {} private: std::unique_ptr<Functor> f_; };
 template <int kDataDimension, typename... A>

@@ -3,11 +3,13 @@
 #include <stdexcept>
 #include <string>
 #include "ceres/ceres.h"
-#define THROW_CHECK(c) PXO_STUB_CHECK(c)
-#define THROW_CHECK_NE(a, b) PXO_STUB_CHECK((a) != (b))
-#define THROW_CHECK_EQ(a, b) PXO_STUB_CHECK((a) == (b))
-#define THROW_CHECK_GE(a, b) PXO_STUB_CHECK((a) >= (b))
-#define THROW_CHECK_LT(a, b) PXO_STUB_CHECK((a) < (b))
-#define THROW_CHECK_MSG(c, m) PXO_STUB_CHECK(c)
-#define THROW_CUSTOM_CHECK_MSG(c, e, m) PXO_STUB_CHECK(c)
+// complete statements (the reference uses some of them without a trailing semicolon, costmap_extractor.h:235)
+#define PXO_STUB_THROW_CHECK(cond) { if (!(cond)) { std::fprintf(stderr, "THROW_CHECK failed: %s\n", #cond); std::abort(); } }
+#define THROW_CHECK(c) PXO_STUB_THROW_CHECK(c)
+#define THROW_CHECK_NE(a, b) PXO_STUB_THROW_CHECK((a) != (b))
+#define THROW_CHECK_EQ(a, b) PXO_STUB_THROW_CHECK((a) == (b))
+#define THROW_CHECK_GE(a, b) PXO_STUB_THROW_CHECK((a) >= (b))
+#define THROW_CHECK_LT(a, b) PXO_STUB_THROW_CHECK((a) < (b))
+#define THROW_CHECK_MSG(c, m) PXO_STUB_THROW_CHECK(c)
+#define THROW_CUSTOM_CHECK_MSG(c, e, m) PXO_STUB_THROW_CHECK(c)
 #define THROW_EXCEPTION(exception, msg) throw exception(msg)

@@ -13,4 +13,5 @@ template <int n_nodes, int channels> using DescriptorMatrixd = Eigen::Matrix<dou
 using DescriptorMatrixXd = DescriptorMatrixd<Eigen::Dynamic, Eigen::Dynamic>;
 template <int n_nodes> using OffsetMatrix3d = Eigen::Matrix<double, n_nodes, 3, Eigen::RowMajor>;
 template <int rows> using VectorNd = Eigen::Matrix<double, rows, 1>;
+const colmap::point2D_t kDensePatchId = 1000000;
 }  // namespace pixsfm

@@ -5,7 +5,8 @@ Tolerances: the cost maps are STORED in the features' dtype, so the bar is the s
 bits except where the fp64 summation order (16-lane tree here, numpy's einsum there) moves a value across a
 rounding boundary -- at most 1 ulp, on a small fraction of the entries; fp64 maps within 1e-12.  Residuals /
 Jacobians within 1e-10 relative (north_star: 1e-5), refined parameters within 1e-6 (north_star: 1e-4).
-PARITY UNPINNED w.r.t. the real reference: it has no golden vectors for cost maps.
+The extraction is additionally pinned against the reference's own FillPointCostmap run in place: tests/test_costmap_golden.py.
+The cost-map BA (a trust-region solve) is compared with the oracle only.
 """
 import numpy as np
 import pytest

@@ -18,7 +18,9 @@
  * residuals/src/featuremetric.h, feature_reference.h, base/src/projection.h), differentiated
  * with one dual number per parameter -- with the quaternion rotation and the camera models
  * under them restated from the published Ceres / COLMAP definitions; the match-graph
- * labelling (base/src/graph.cc, bit-exact) and the IRLS loop (base/src/irls_optim.h).
+ * labelling (base/src/graph.cc, bit-exact), the IRLS loop (base/src/irls_optim.h), the cost-map
+ * kernel (costmap_extractor.h FillPointCostmap) and the KA problem construction (edges, weights,
+ * constants, bounds: topological_keypoint_optimizer.h, keypoint_optimizer.h via a recording Problem).
  * "Parity unpinned" (Ceres / COLMAP absent, no golden vectors in the reference): the camera
  * models themselves (A6), the loss functions and corrector (A20) and the trust-region
  * solvers (A14, A18) -- validated by finite differences and closed-form properties only.
@@ -275,6 +277,10 @@ int pxo_ka_solve_problem(pxo_ka_batch* b, const int32_t* nodes, int nn, const in
 int pxo_ka_solve_problem_u(pxo_ka_batch* b, const int32_t* nodes, int nn, const int32_t* edges, int m,
                            const int32_t* unary, int nu, const pxo_interp_cfg* cfg, const pxo_loss* loss,
                            double bound, const pxo_lm_options* opt, pxo_lm_summary* sum);
+
+/* The box bounds of one node: lower / upper (x, y) as KeypointOptimizerBase::ParameterizeKeypoints sets them
+ * (keypoint_adjustment/src/keypoint_optimizer.h:124-152). */
+void pxo_ka_node_bounds(const pxo_ka_batch* b, int64_t node, double bound, double lo[2], double hi[2]);
 
 #ifdef __cplusplus
 }

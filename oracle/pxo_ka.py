@@ -56,3 +56,22 @@ def ka_solve(problem, config, ls, bound=4.0, opts=None):
         assert rc == 0
         summaries.append(s.as_dict())
     return kp, summaries
+
+
+def node_bounds(kp, corners, scales, H, W, bound):
+    """Box bounds (n, 4) = lower x, lower y, upper x, upper y of every keypoint, KeypointOptimizerBase::ParameterizeKeypoints
+    (keypoint_optimizer.h:124-152): the patch extent in image pixels, intersected with +- bound / scale around the keypoint."""
+    kp = np.ascontiguousarray(kp, dtype=np.float64)
+    n = len(kp)
+    corners = np.ascontiguousarray(corners, dtype=np.int32)
+    scales = np.ascontiguousarray(scales, dtype=np.float64)
+    node_patch = np.arange(n, dtype=np.int64)
+    b = KaBatch(n, kp.ctypes.data, node_patch.ctypes.data, None, 0, None, None, None, None, 0, H, W, 128, corners.ctypes.data,
+                scales.ctypes.data, 0, None, None, None)
+    out = np.empty((n, 4))
+    lo, hi = (C.c_double * 2)(), (C.c_double * 2)()
+    lib = pxo.lib()
+    for i in range(n):
+        lib.pxo_ka_node_bounds(C.byref(b), C.c_int64(i), C.c_double(bound), lo, hi)
+        out[i] = (lo[0], lo[1], hi[0], hi[1])
+    return out

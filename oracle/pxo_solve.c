@@ -542,6 +542,11 @@ static void ka_bounds(const pxo_ka_batch* b, int64_t node, double bound, double 
   }
 }
 
+/* the box ParameterizeKeypoints puts around a variable keypoint (keypoint_optimizer.h:124-152), for the parity tests */
+void pxo_ka_node_bounds(const pxo_ka_batch* b, int64_t node, double bound, double lo[2], double hi[2]) {
+  ka_bounds(b, node, bound, lo, hi);
+}
+
 typedef struct {
   const pxo_ka_batch* b; const pxo_interp_cfg* cfg; const pxo_loss* loss;
   const int32_t* edges; int m;    /* edge ids of this problem */

@@ -8,7 +8,10 @@
 #include <cstdlib>
 #include <limits>
 #include <memory>
+#include <string>
+#include <vector>
 #include "Eigen/Core"
+#define CERES_VERSION_MAJOR 2
 #define PXO_STUB_CHECK(cond) do { if (!(cond)) { std::fprintf(stderr, "CHECK failed: %s\n", #cond); std::abort(); } } while (0)
 #define CHECK_GE(a, b) PXO_STUB_CHECK((a) >= (b))
 #define CHECK_LT(a, b) PXO_STUB_CHECK((a) < (b))
@@ -100,4 +103,53 @@ class BiCubicInterpolator {
   explicit BiCubicInterpolator(const Grid&) {}
   void Evaluate(double, double, double*, double*, double*) const { Eigen::stub_unreachable("ceres::BiCubicInterpolator"); }
 };
+
+// ---- a RECORDING ceres::Problem / Solver: what the reference's problem set-up code hands to Ceres is kept for inspection,
+// nothing is solved ([upstream Ceres] API names only)
+enum Ownership { DO_NOT_TAKE_OWNERSHIP, TAKE_OWNERSHIP };
+enum LinearSolverType { DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR };
+enum LoggingType { SILENT, PER_MINIMIZER_ITERATION };
+enum CallbackReturnType { SOLVER_CONTINUE, SOLVER_ABORT, SOLVER_TERMINATE_SUCCESSFULLY };
+class ScaledLoss : public LossFunction {
+ public:
+  ScaledLoss(const LossFunction* rho, double a, Ownership) : rho_(rho), a_(a) {}
+  void Evaluate(double s, double out[3]) const override {
+    if (!rho_) { out[0] = a_ * s; out[1] = a_; out[2] = 0.0; return; }
+    rho_->Evaluate(s, out); out[0] *= a_; out[1] *= a_; out[2] *= a_;
+  }
+  const LossFunction* rho_; double a_;
+};
+struct IterationSummary {
+  int iteration = 0; double cost = 0, cost_change = 0, gradient_max_norm = 0, step_norm = 0, trust_region_radius = 0;
+  int linear_solver_iterations = 0; double iteration_time_in_seconds = 0, cumulative_time_in_seconds = 0;
+};
+class IterationCallback { public: virtual ~IterationCallback() {} virtual CallbackReturnType operator()(const IterationSummary&) { return SOLVER_CONTINUE; } };
+typedef void* ResidualBlockId;
+class Problem {
+ public:
+  struct Options { Ownership loss_function_ownership = TAKE_OWNERSHIP, cost_function_ownership = TAKE_OWNERSHIP; };
+  struct Block { CostFunction* cost; LossFunction* loss; std::vector<double*> params; };
+  struct Bound { double* p; int index; double value; bool upper; };
+  Problem() {}
+  explicit Problem(const Options&) {}
+  template <typename... Ps>
+  ResidualBlockId AddResidualBlock(CostFunction* c, LossFunction* l, Ps*... ps) { blocks.push_back(Block{c, l, {ps...}}); return nullptr; }
+  void SetParameterBlockConstant(double* p) { constant.push_back(p); }
+  void SetParameterLowerBound(double* p, int i, double v) { bounds.push_back(Bound{p, i, v, false}); }
+  void SetParameterUpperBound(double* p, int i, double v) { bounds.push_back(Bound{p, i, v, true}); }
+  std::vector<Block> blocks; std::vector<double*> constant; std::vector<Bound> bounds;
+};
+class Solver {
+ public:
+  struct Options {
+    LinearSolverType linear_solver_type = SPARSE_NORMAL_CHOLESKY; int max_num_iterations = 50; bool minimizer_progress_to_stdout = false;
+    int max_num_consecutive_invalid_steps = 5; double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    int num_threads = 1; LoggingType logging_type = PER_MINIMIZER_ITERATION; std::vector<IterationCallback*> callbacks;
+    bool IsValid(std::string*) const { return true; }
+  };
+  struct Summary {
+    double initial_cost = 0, final_cost = 0, total_time_in_seconds = 0; int num_residuals_reduced = 1; std::vector<IterationSummary> iterations;
+  };
+};
+inline void Solve(const Solver::Options&, Problem*, Solver::Summary*) {}
 }  // namespace ceres

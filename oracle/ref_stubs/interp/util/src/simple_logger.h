@@ -3,11 +3,13 @@
 #pragma once
 #include <ostream>
 namespace pixsfm {
+enum headless { CERR = 2, COUT };
 enum typelog { DEBUG = 0, INFO, WARN, ERROR };
 class STDLOG {
  public:
   STDLOG() {}
   explicit STDLOG(typelog) {}
+  explicit STDLOG(headless) {}
   template <typename T>
   STDLOG& operator<<(const T&) { return *this; }
   STDLOG& operator<<(std::ostream& (*)(std::ostream&)) { return *this; }

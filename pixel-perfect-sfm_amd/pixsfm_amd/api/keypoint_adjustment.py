@@ -109,6 +109,25 @@ def build_edges(graph, keypoints, track_labels, root_labels, nodes_in_problem=No
     return o_src[:k].tolist(), o_dst[:k].tolist(), o_w[:k].tolist()
 
 
+def node_roles(setup, graph, src, dst, nodes_in_problem=None):
+    """KeypointOptimizerBase::ParameterizeKeypoints (keypoint_optimizer.h:110-157) as per-node codes for pxr_ka_view.d_node_const:
+    1 = held constant (KeypointAdjustmentSetup), 0 = variable inside its box bounds, 2 = variable WITHOUT bounds.
+    RunSubset enumerates the out-matches of nodes_in_problem only (topological_keypoint_optimizer.h:108-113) but a match's
+    destination becomes a parameter block wherever it lies; ParameterizeKeypoints visits nodes_in_problem only, so such a
+    keypoint is neither held constant nor boxed.  Also returns the mask of the nodes that take part in this solve."""
+    n = len(graph.nodes)
+    node_const = np.array([setup.is_node_constant(nd) for nd in graph.nodes], np.uint8)
+    if nodes_in_problem is None:
+        return node_const, np.ones(n, bool)
+    inside = np.zeros(n, bool)
+    inside[np.fromiter(nodes_in_problem, dtype=np.int64)] = True
+    touched = np.zeros(n, bool)
+    touched[np.asarray(src, dtype=np.int64)] = True
+    touched[np.asarray(dst, dtype=np.int64)] = True
+    node_const[touched & ~inside] = 2
+    return node_const, inside | touched
+
+
 class FeatureMetricKeypointOptimizer:
     """_keypoint_adjustment.FeatureMetricKeypointOptimizer (bindings.cc:77-81):
     ctor (options, setup, interpolation_config); run(problem_labels, keypoints, graph, track_labels,
@@ -147,19 +166,9 @@ class FeatureMetricKeypointOptimizer:
         kp = np.array([keypoints[nm][nd.feature_idx] for nm, nd in zip(names, graph.nodes)], dtype=np.float64).reshape(-1, 2)
         patches = [feature_set.fmap(nm).fpatch(nd.feature_idx) for nm, nd in zip(names, graph.nodes)]
         labels = np.zeros(n, np.int32) if problem_labels is None else np.asarray(problem_labels, dtype=np.int32)
-        node_const = np.array([self.setup.is_node_constant(nd) for nd in graph.nodes], np.uint8)
+        node_const, in_solve = node_roles(self.setup, graph, src, dst, nodes_in_problem)
         if nodes_in_problem is not None:
-            # RunSubset enumerates the out-matches of nodes_in_problem only (topological_keypoint_optimizer.h:108-113) but
-            # a match's destination becomes a parameter block wherever it lies; ParameterizeKeypoints
-            # (keypoint_optimizer.h:117) visits nodes_in_problem only, so such a keypoint is neither held constant nor boxed
-            labels = np.full(n, -1, dtype=np.int32)
-            inside = np.zeros(n, bool)
-            inside[np.fromiter(nodes_in_problem, dtype=np.int64)] = True
-            touched = np.zeros(n, bool)
-            touched[np.asarray(src, dtype=np.int64)] = True
-            touched[np.asarray(dst, dtype=np.int64)] = True
-            labels[inside | touched] = 0
-            node_const[touched & ~inside] = 2
+            labels = np.where(in_solve, 0, -1).astype(np.int32)
         prob = dict(kp=kp, node_patch=np.arange(n, dtype=np.int64), node_const=node_const,
                     node_problem=labels, edge_src=np.array(src, np.int32), edge_dst=np.array(dst, np.int32),
                     edge_w=np.array(w, np.float64))

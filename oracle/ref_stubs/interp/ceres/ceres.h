@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
+#include <iostream>
 #include <memory>
+#include <utility>
 #include <string>
 #include <vector>
 #include "Eigen/Core"
@@ -17,6 +19,8 @@
 #define CHECK_LT(a, b) PXO_STUB_CHECK((a) < (b))
 #define CHECK_EQ(a, b) PXO_STUB_CHECK((a) == (b))
 #define CHECK_NOTNULL(a) (a)
+namespace pxo_stub { struct CheckStream { explicit CheckStream(bool ok) { if (!ok) { std::fprintf(stderr, "CHECK failed\n"); std::abort(); } } template <typename T> CheckStream& operator<<(const T&) { return *this; } }; }
+#define CHECK(c) pxo_stub::CheckStream(static_cast<bool>(c))
 namespace ceres {
 using std::sqrt;
 // A forward-mode dual number standing in for ceres::Jet ([upstream Ceres 2.x] jet.h semantics: value a, derivative vector v;
@@ -109,6 +113,8 @@ class BiCubicInterpolator {
 enum Ownership { DO_NOT_TAKE_OWNERSHIP, TAKE_OWNERSHIP };
 enum LinearSolverType { DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR };
 enum LoggingType { SILENT, PER_MINIMIZER_ITERATION };
+enum PreconditionerType { IDENTITY, JACOBI, SCHUR_JACOBI, CLUSTER_JACOBI, CLUSTER_TRIDIAGONAL };
+class ParameterBlockOrdering { public: void AddElementToGroup(double* p, int g) { elements.push_back(std::make_pair(p, g)); } std::vector<std::pair<double*, int>> elements; };
 enum CallbackReturnType { SOLVER_CONTINUE, SOLVER_ABORT, SOLVER_TERMINATE_SUCCESSFULLY };
 class ScaledLoss : public LossFunction {
  public:
@@ -130,6 +136,9 @@ class Problem {
   struct Options { Ownership loss_function_ownership = TAKE_OWNERSHIP, cost_function_ownership = TAKE_OWNERSHIP; };
   struct Block { CostFunction* cost; LossFunction* loss; std::vector<double*> params; };
   struct Bound { double* p; int index; double value; bool upper; };
+  struct Subset { double* p; int size; std::vector<int> constant; };
+  std::vector<double*> quaternion_manifold; std::vector<Subset> subset_manifold;
+  int NumResiduals() const { return (int)blocks.size(); }
   Problem() {}
   explicit Problem(const Options&) {}
   template <typename... Ps>
@@ -145,11 +154,15 @@ class Solver {
     LinearSolverType linear_solver_type = SPARSE_NORMAL_CHOLESKY; int max_num_iterations = 50; bool minimizer_progress_to_stdout = false;
     int max_num_consecutive_invalid_steps = 5; double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
     int num_threads = 1; LoggingType logging_type = PER_MINIMIZER_ITERATION; std::vector<IterationCallback*> callbacks;
+    bool use_inner_iterations = false; std::shared_ptr<ParameterBlockOrdering> inner_iteration_ordering;
+    PreconditionerType preconditioner_type = JACOBI; int max_linear_solver_iterations = 500, max_consecutive_nonmonotonic_steps = 5;
     bool IsValid(std::string*) const { return true; }
   };
   struct Summary {
     double initial_cost = 0, final_cost = 0, total_time_in_seconds = 0; int num_residuals_reduced = 1; std::vector<IterationSummary> iterations;
   };
 };
-inline void Solve(const Solver::Options&, Problem*, Solver::Summary*) {}
+// the options the reference finally hands to the solver (linear solver / preconditioner selection) are kept for inspection
+inline Solver::Options& LastSolveOptions() { static Solver::Options o; return o; }
+inline void Solve(const Solver::Options& o, Problem*, Solver::Summary*) { LastSolveOptions() = o; }
 }  // namespace ceres

@@ -61,6 +61,15 @@ class Camera {
   const double* ParamsData() const { return params_.data(); }
   double* ParamsData() { return params_.data(); }
   const std::vector<double>& Params() const { return params_; }
+  size_t NumParams() const { return params_.size(); }
+  void SetModelId(int m) { model_ = m; }
+  void SetParams(const std::vector<double>& p) { params_ = p; }
+  // [upstream COLMAP 3.8 camera_models.h] parameter groups: focal length(s), principal point, extra (distortion) parameters
+  std::vector<size_t> FocalLengthIdxs() const { return (model_ == 1 || model_ == 4) ? std::vector<size_t>{0, 1} : std::vector<size_t>{0}; }
+  std::vector<size_t> PrincipalPointIdxs() const { return (model_ == 1 || model_ == 4) ? std::vector<size_t>{2, 3} : std::vector<size_t>{1, 2}; }
+  std::vector<size_t> ExtraParamsIdxs() const {
+    switch (model_) { case 2: return {3}; case 3: return {3, 4}; case 4: return {4, 5, 6, 7}; default: return {}; }
+  }
  private:
   int model_ = 0; std::vector<double> params_;
 };

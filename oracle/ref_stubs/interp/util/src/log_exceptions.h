@@ -10,6 +10,8 @@
 #define THROW_CHECK_EQ(a, b) PXO_STUB_THROW_CHECK((a) == (b))
 #define THROW_CHECK_GE(a, b) PXO_STUB_THROW_CHECK((a) >= (b))
 #define THROW_CHECK_LT(a, b) PXO_STUB_THROW_CHECK((a) < (b))
+#define THROW_CHECK_GT(a, b) PXO_STUB_THROW_CHECK((a) > (b))
+#define THROW_CHECK_LE(a, b) PXO_STUB_THROW_CHECK((a) <= (b))
 #define THROW_CHECK_MSG(c, m) PXO_STUB_THROW_CHECK(c)
 #define THROW_CUSTOM_CHECK_MSG(c, e, m) PXO_STUB_THROW_CHECK(c)
 #define THROW_EXCEPTION(exception, msg) throw exception(msg)

@@ -6,6 +6,8 @@
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
+#include <utility>
+#include <vector>
 #include "base/src/graph.h"
 #include "features/src/featurepatch.h"
 namespace pixsfm {
@@ -30,8 +32,15 @@ class FeatureView {
  public:
   FeatureView() {}
   FeatureView(FeatureSet<dtype>*, const Graph*, const std::unordered_set<size_t>&) {}
+  int Channels() const { return channels; }
+  int channels = 128;
   FeatureMap<dtype>& GetFeatureMap(colmap::image_t image_id) { return maps.at(image_id); }
-  FeaturePatch<dtype>& GetFeaturePatch(colmap::image_t image_id, colmap::point2D_t idx) { return maps.at(image_id).GetFeaturePatch(idx); }
+  // every residual the set-up code adds fetches its patch here first: the call log tells which observation a block is for
+  FeaturePatch<dtype>& GetFeaturePatch(colmap::image_t image_id, colmap::point2D_t idx) {
+    calls.emplace_back(image_id, idx);
+    return maps.at(image_id).GetFeaturePatch(idx);
+  }
+  std::vector<std::pair<colmap::image_t, colmap::point2D_t>> calls;
   std::map<colmap::image_t, FeatureMap<dtype>> maps;
 };
 }  // namespace pixsfm

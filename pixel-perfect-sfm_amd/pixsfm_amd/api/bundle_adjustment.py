@@ -122,6 +122,17 @@ class FeatureView:
         return self.feature_set.channels
 
 
+def linear_solver_for(num_images):
+    """SolveProblem's choice (bundle_optimizer.h:180-191), by the number of images OF THE SETUP (images that enter through
+    AddPointToProblem do not count): DENSE_SCHUR up to 50, SPARSE_SCHUR up to 1000, ITERATIVE_SCHUR + SCHUR_JACOBI above.
+    The two direct variants are the same algebra here (Schur complement + Cholesky)."""
+    if num_images <= 50:
+        return "DENSE_SCHUR"
+    if num_images <= 1000:
+        return "SPARSE_SCHUR"
+    return "ITERATIVE_SCHUR"
+
+
 class _FlatBA:
     """Flat arrays of the residual blocks BundleOptimizer::SetUp would add (bundle_optimizer.h:139-165):
     AddImageToProblem for every image of the setup, AddPointToProblem for the extra variable / constant
@@ -527,7 +538,8 @@ class FeatureReferenceBundleOptimizer:
                         gradient_tolerance=s['gradient_tolerance'], parameter_tolerance=s['parameter_tolerance'],
                         max_consecutive_invalid_steps=s['max_num_consecutive_invalid_steps'],
                         use_inner_iterations=s['use_inner_iterations'],
-                        max_linear_solver_iterations=s['max_linear_solver_iterations'])
+                        max_linear_solver_iterations=s['max_linear_solver_iterations'],
+                        linear_solver=linear_solver_for(self.setup.num_images()))
         point_const, allreduce = flat.point_const, self.allreduce
         if getattr(self, "_share", None) is not None:
             from .. import parallel

@@ -479,6 +479,118 @@ void costmap_kernel_f16_split(const CostmapArgs a, const int64_t n) {
   }
 }
 
+// ---- 8 x 8 patches with gradients: what the reference's only `strategy: costmaps` configuration uses (configs/low_memory.yaml,
+// patch_size 8).  Same channel split over the four wavefronts; a wavefront's 16-lane row now holds the 8 columns x the two
+// HALVES of the patch: lane = 16 k + 2 x + yh, four rows (4 yh .. 4 yh + 3) of column x per lane.  Horizontal neighbours are
+// two lanes away (row_shr:2 / row_shl:2: the row ends clamp by themselves), the rows across the half boundary come from the
+// partner lane (quad_perm [1,0,3,2]) once per patch; one reduce-scatter group per patch leaves DPP-row k with texel row
+// 4 yh + k.  Only 16 data registers per lane, so the next patch is simply loaded a whole iteration ahead into a second set.
+// Measured on MI355X (200k maps back to back): 0.88 ms against 1.14 ms for the LDS-staged kernel = 4.0 TB/s algorithmic,
+// 0.50 of the HBM peak (the per-patch barrier and epilogue weigh four times more than at 16 x 16).
+template <typename OT>
+__global__ __launch_bounds__(256) void costmap_kernel_f16_split8(const CostmapArgs a, const int64_t n) {
+  constexpr int PS = 8, C = 128, RPL = 4;
+  constexpr int ROW_BYTES = PS * C * (int)sizeof(_Float16), PATCH_BYTES = PS * ROW_BYTES;
+  __shared__ double part[2][4][3][PS * PS];
+  __shared__ double refsh[2][C];
+  const int tid = threadIdx.x, w = tid >> 6, k = (tid >> 4) & 3, x = (tid >> 1) & 7, yh = tid & 1;
+  const _Float16* fin = reinterpret_cast<const _Float16*>(a.fin);
+  const unsigned lane_off = (unsigned)(((4 * yh * PS + x) * C + 32 * w + 8 * k) * sizeof(_Float16));
+  const int64_t G = gridDim.x;
+  auto tex = [](const u32x4& v) { Texel8<_Float16> t; t.raw = make_uint4(v.x, v.y, v.z, v.w); return t; };
+  auto uniform64 = [](int64_t v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+  };
+  int64_t i = blockIdx.x;
+  if (i >= n) return;
+  auto at = [&](int64_t j) { return j < n ? j : n - 1; };
+  auto load_rows = [&](int64_t p, u32x4* c) {
+    const auto P = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(fin + (size_t)p * PS * PS * C), 0, PATCH_BYTES, 0x00020000);
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) c[r] = __builtin_amdgcn_raw_buffer_load_b128(P, lane_off, r * ROW_BYTES, 0);
+  };
+  u32x4 col[RPL], nxt[RPL];
+  double ref[8];
+  {
+    const double* rp = a.refs + (size_t)a.ref_index[i] * C + 32 * w + 8 * k;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) ref[ch] = rp[ch];
+  }
+  load_rows(uniform64(a.patch[i]), col);
+  int64_t p1 = uniform64(a.patch[at(i + G)]);
+  int r1 = __builtin_amdgcn_readfirstlane(a.ref_index[at(i + G)]);
+  double rnext = a.refs[(size_t)r1 * C + (tid & (C - 1))];
+  int buf = 0;
+  for (; i < n; i += G, buf ^= 1) {
+    const int64_t i2 = at(i + 2 * G);
+    const int64_t p2v = a.patch[i2];
+    const int r2v = a.ref_index[i2];
+    load_rows(p1, nxt);                                // the next patch: a whole iteration to land
+    // the rows across the half boundary: the partner lane's bottom row (for the upper half: its top row)
+    u32x4 edge;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int mine = yh ? (int)col[0][q] : (int)col[RPL - 1][q];          // what the partner needs from this lane
+      edge[q] = (unsigned)__builtin_amdgcn_update_dpp(0, mine, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    }
+    double s[RPL], br[RPL], bc[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      const u32x4 cu = col[r];
+      u32x4 lf, rt;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {   // clamped horizontal neighbours, two lanes away
+        lf[q] = (unsigned)__builtin_amdgcn_update_dpp((int)cu[q], (int)cu[q], 0x112, 0xf, 0xf, false);   // row_shr:2 -> x - 1
+        rt[q] = (unsigned)__builtin_amdgcn_update_dpp((int)cu[q], (int)cu[q], 0x102, 0xf, 0xf, false);   // row_shl:2 -> x + 1
+      }
+      // vertical neighbours: inside the lane, across the half boundary from the partner, clamped at the patch border
+      u32x4 up = r > 0 ? col[r - 1] : col[0], dn = r < RPL - 1 ? col[r + 1] : col[RPL - 1];
+      if (r == 0) { for (int q = 0; q < 4; ++q) up[q] = yh ? edge[q] : up[q]; }
+      if (r == RPL - 1) { for (int q = 0; q < 4; ++q) dn[q] = yh ? dn[q] : edge[q]; }
+      double f[8], dr[8], dc[8];
+      widen8<_Float16>(tex(cu), f);
+      StorageDiff<_Float16>::run(tex(dn), tex(up), dr);
+      StorageDiff<_Float16>::run(tex(rt), tex(lf), dc);
+      double ss = 0.0, sr = 0.0, sc = 0.0;
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        const double res = f[ch] - ref[ch];
+        ss = fma(res, res, ss); sr = fma(res, dr[ch], sr); sc = fma(res, dc[ch], sc);
+      }
+      s[r] = ss; br[r] = sr; bc[r] = sc;
+    }
+    const int t = (4 * yh + k) * PS + x;
+    part[buf][w][0][t] = swap_sum16(swap_sum32(s[0], s[2]), swap_sum32(s[1], s[3]));
+    part[buf][w][1][t] = swap_sum16(swap_sum32(br[0], br[2]), swap_sum32(br[1], br[3]));
+    part[buf][w][2][t] = swap_sum16(swap_sum32(bc[0], bc[2]), swap_sum32(bc[1], bc[3]));
+    if (tid < C) refsh[buf][tid] = rnext;
+    const int64_t p2 = uniform64(p2v);
+    const int r2 = __builtin_amdgcn_readfirstlane(r2v);
+    rnext = a.refs[(size_t)r2 * C + (tid & (C - 1))];
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) ref[ch] = refsh[buf][32 * w + 8 * k + ch];
+    if (tid < PS * PS) {
+      double v[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) v[q] = (part[buf][0][q][tid] + part[buf][1][q][tid]) + (part[buf][2][q][tid] + part[buf][3][q][tid]);
+      double rho[3];
+      loss_eval(a.loss.type, a.loss.a, 1.0, v[0], rho);
+      double cost = 0.5 * rho[0], dcr = 0.0, dcc = 0.0;
+      if (cost > 1.0e-8) {                               // costmap_extractor.h:300-318
+        dcr = rho[1] * (0.5 * v[1]); dcc = rho[1] * (0.5 * v[2]);
+        if (a.apply_sqrt) { cost = sqrt(cost); dcr *= 0.5 / cost; dcc *= 0.5 / cost; }
+      }
+      OT* o = reinterpret_cast<OT*>(a.fout) + ((size_t)(a.first_out + i) * PS * PS + tid) * 3;
+      o[0] = store_cast<OT>(cost); o[1] = store_cast<OT>(dcr); o[2] = store_cast<OT>(dcc);
+    }
+    p1 = p2;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) col[r] = nxt[r];
+  }
+}
+
 // ---- the INTERPOLATING branch of FillPointCostmap (costmap_extractor.h:280-284,341-345) --------------------------------
 // Taken by the reference when the cost patch is not of the feature patch's size (CostMapConfig.upsampling_factor != 1) or
 // compute_cross_derivative is set: per output texel (y, x) the features are interpolated at the LOCAL patch coordinates
@@ -582,8 +694,12 @@ static int launch_costmap_f16(pxr_ctx* ctx, const CostmapArgs& a, int64_t n, boo
       hipLaunchKernelGGL((costmap_kernel_f16_split<OT>), g3, dim3(256), 0, ctx->stream, a, n);
     } else hipLaunchKernelGGL((costmap_kernel_f16<OT, 16, false>), grid, block, 0, ctx->stream, a, n);
   } else {
-    if (grad) hipLaunchKernelGGL((costmap_kernel_f16<OT, 8, true>), grid, block, 0, ctx->stream, a, n);
-    else hipLaunchKernelGGL((costmap_kernel_f16<OT, 8, false>), grid, block, 0, ctx->stream, a, n);
+    if (grad) {   // 124 VGPRs: four workgroups per CU resident; twice that many in the grid evens out the tail
+      const int64_t res8 = (int64_t)prop.multiProcessorCount * 8;
+      const dim3 g8((unsigned)(n < res8 ? n : res8));
+      hipLaunchKernelGGL(costmap_meta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, n);
+      hipLaunchKernelGGL((costmap_kernel_f16_split8<OT>), g8, dim3(256), 0, ctx->stream, a, n);
+    } else hipLaunchKernelGGL((costmap_kernel_f16<OT, 8, false>), grid, block, 0, ctx->stream, a, n);
   }
   return hip_check(hipGetLastError(), "costmap_kernel_f16 launch");
 }

@@ -56,10 +56,14 @@ typedef struct pxr_arena pxr_arena;
 typedef struct {
   int32_t l2_normalize;   /* default 1 */
   int32_t use_float_simd; /* default 0: fp32 horizontal pass, fp64 vertical pass */
-  int32_t check_bounds;   /* default 0.  1: an evaluation outside 0 < u < W, 0 < v < H of its patch FAILS
-                           * (patch_interpolator.h:125-135,160-166): the block's cost / squared norm is NaN,
-                           * the solvers treat a non-finite trial cost as an invalid step and a non-finite
-                           * initial cost as PXR_TERM_FAILURE, like Ceres does when Evaluate returns false */
+  int32_t check_bounds;   /* default 0.  1: PatchInterpolator::Evaluate reports whether 0 < u < W, 0 < v < H
+                           * (patch_interpolator.h:125-135,160-166).  Like in the reference this FAILS an evaluation
+                           * only where the functor passes it on: the BA functor WITHOUT a reference descriptor, i.e.
+                           * the cost-map BA (feature_reference.h:128-130) -- the block's squared norm is NaN, the
+                           * solvers reject a non-finite trial cost and report PXR_TERM_FAILURE for a non-finite
+                           * initial cost, like Ceres when Evaluate returns false.  With a reference descriptor
+                           * (feature_reference.h:132-136) and in keypoint adjustment (featuremetric.h:61,
+                           * feature_reference.h:59) the functors return true regardless: no effect. */
 } pxr_interp_cfg;
 
 typedef struct {

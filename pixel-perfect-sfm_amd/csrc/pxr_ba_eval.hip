@@ -148,9 +148,11 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(const BaEvalArgs a) {
     // Jet bridge: d/dx = dfdc * sx, d/dy = dfdr * sy  (interpolation.h:130-140 + featurepatch.h:250-255)
     rec[1] *= sx * sx; rec[2] *= sx * sy; rec[3] *= sy * sy; rec[4] *= sx; rec[5] *= sy;
     // InterpolationConfig.check_bounds (patch_interpolator.h:125-135,160-166): outside 0 < u < W, 0 < v < H the
-    // functor returns false, i.e. the evaluation fails; here the block's squared norm becomes NaN, which makes
-    // the cost non-finite -> the solver treats the step as invalid (FAILURE at the initial point), like Ceres
-    if (a.check_bounds && !(my_u > 0.0 && my_u < (double)a.W && my_v > 0.0 && my_v < (double)a.H)) rec[0] = __builtin_nan("");
+    // interpolator reports `false` -- which FeatureReferenceCostFunctor passes on ONLY when it has no reference
+    // descriptor (`if (!ref_descriptor_) return is_inside; ... return true;`, feature_reference.h:128-136: the cost-map
+    // functor); with a reference the evaluation succeeds regardless.  A failed evaluation: the block's squared norm
+    // becomes NaN, the cost non-finite -> the solver rejects the step (FAILURE at the initial point), like Ceres
+    if (a.check_bounds && !a.v.d_refs && !(my_u > 0.0 && my_u < (double)a.W && my_v > 0.0 && my_v < (double)a.H)) rec[0] = __builtin_nan("");
     double2* o = reinterpret_cast<double2*>(a.rec + (size_t)mine * PXR_OBS_REC);
     o[0] = make_double2(rec[0], rec[1]);
     o[1] = make_double2(rec[2], rec[3]);
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256) void ba_eval_small_kernel(const BaEvalArgs a) 
     }
     { const double ux = sx * a.up, uy = sy * a.up; rec[1] *= ux * ux; rec[2] *= ux * uy; rec[3] *= uy * uy; rec[4] *= ux; rec[5] *= uy; }
     rec[6] = x; rec[7] = y;
-    if (a.check_bounds && !(u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H)) rec[0] = __builtin_nan("");
+    if (a.check_bounds && !a.v.d_refs && !(u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H)) rec[0] = __builtin_nan("");   // no reference: the cost-map functor
     double2* o = reinterpret_cast<double2*>(a.rec + (size_t)i * PXR_OBS_REC);
     o[0] = make_double2(rec[0], rec[1]);
     o[1] = make_double2(rec[2], rec[3]);

@@ -153,8 +153,9 @@ __device__ __forceinline__ void inner_points_body(const InnerArgs& a, double (*s
       double rho[3];
       loss_eval(a.loss.type, a.loss.a, 1.0, s, rho);
       if (valid) cost += 0.5 * rho[0];
-      // check_bounds: a projection outside its patch fails the evaluation -> non-finite cost -> the step is rejected
-      if (valid && a.check_bounds && !(u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H)) cost = __builtin_nan("");
+      // check_bounds: without a reference descriptor (cost maps) a projection outside its patch fails the evaluation
+      // (feature_reference.h:128-130) -> non-finite cost -> the step is rejected
+      if (valid && a.check_bounds && !a.v.d_refs && !(u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H)) cost = __builtin_nan("");
       if (with_jac) {
         gcc = rsum(gcc) * sx * sx; gcr = rsum(gcr) * sx * sy; grr = rsum(grr) * sy * sy;
         bc = rsum(bc) * sx; br = rsum(br) * sy;

@@ -84,13 +84,10 @@ __device__ __forceinline__ void ka_eval_node(const KaArgs& a, int64_t node, cons
   } else {
     interp_small<ST, C>(patch, a.H, a.W, u, v, a.l2_normalize != 0, f, fr, fc);
   }
-  // InterpolationConfig.check_bounds (patch_interpolator.h:125-135,160-166): outside 0 < u < W, 0 < v < H the
-  // functor's evaluation fails; a NaN descriptor makes every cost it enters non-finite, which the line
-  // search / step acceptance treat as a failed evaluation
-  if (a.check_bounds && !(u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H)) {
-#pragma unroll
-    for (int ch = 0; ch < CPL; ++ch) f[ch] = __builtin_nan("");
-  }
+  // InterpolationConfig.check_bounds has NO effect on keypoint adjustment: PatchInterpolator::Evaluate returns the bounds
+  // check (patch_interpolator.h:125-135), but FeatureMetric2DCostFunctor and FeatureReference2DCostFunctor ignore it and
+  // return true (featuremetric.h:44-63, feature_reference.h:44-60); the box bounds of ParameterizeKeypoints keep the
+  // keypoints inside their patches instead.
   double* d = a.desc + (size_t)node * 3 * C + sub * CPL;
 #pragma unroll
   for (int ch = 0; ch < CPL; ++ch) {
@@ -600,7 +597,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   double cost = linearize(true);
   sm.initial_cost = cost;
   if (!inf.feasible || !isfinite(cost)) {   // [upstream] Program::IsFeasible fails / the initial evaluation fails
-                                            // (check_bounds): FAILURE, parameters untouched
+                                            // (non-finite input): FAILURE, parameters untouched
     sm.final_cost = cost; sm.termination = PXR_TERM_FAILURE;
     if (tid == 0) a.summaries[prob] = sm;
     return;
@@ -768,14 +765,12 @@ __global__ __launch_bounds__(256) void ka_eval_kernel(const KaArgs a, bool fsimd
   if (e >= a.v.n_edges) return;
   const int nn[2] = {a.v.d_edge_src[e], a.v.d_edge_dst[e]};
   double f[2][CPL], gx[2][CPL], gy[2][CPL];
-  bool inside = true;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int64_t pi = a.v.d_node_patch[nn[k]];
     const double sx = a.scales[2 * pi], sy = a.scales[2 * pi + 1];
     const double u = a.v.d_kp[2 * (size_t)nn[k]] * sx - 0.5 - (double)a.corners[2 * pi];
     const double v = a.v.d_kp[2 * (size_t)nn[k] + 1] * sy - 0.5 - (double)a.corners[2 * pi + 1];
-    inside = inside && u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H;
     const ST* patch = reinterpret_cast<const ST*>(a.arena) + (size_t)pi * a.H * a.W * C;
     double fr[CPL], fc[CPL];
     if constexpr (C >= 8) {
@@ -793,7 +788,7 @@ __global__ __launch_bounds__(256) void ka_eval_kernel(const KaArgs a, bool fsimd
   s = lpo_sum(s, LPO);
   double rho[3];
   loss_eval(a.loss.type, a.loss.a, a.v.d_edge_w[e], s, rho);
-  if (sub == 0) cost[e] = (a.check_bounds && !inside) ? __builtin_nan("") : 0.5 * rho[0];   // failed evaluation
+  if (sub == 0) cost[e] = 0.5 * rho[0];   // (check_bounds does not fail a KA residual: the functor returns true, featuremetric.h:61)
   if (out_r) {
 #pragma unroll
     for (int ch = 0; ch < CPL; ++ch) {

@@ -154,11 +154,12 @@ def test_linearity_in_reference_full_size_property(ctx):
     assert np.abs((r0 ** 2).sum(1) - 1.0).max() < 1e-12   # unit-norm descriptors (interpolation_test.cc:187-207)
 
 
-def test_check_bounds_marks_failed_evaluations(ctx):
-    """InterpolationConfig.check_bounds (patch_interpolator.h:125-135,160-166): observations that project outside
-    0 < u < W, 0 < v < H fail to evaluate -- their record's squared norm is NaN (all other fields as usual);
-    which observations fail is checked against the oracle's is_inside; the BA solver reports FAILURE when the
-    initial evaluation fails, and without the option the same problem evaluates normally."""
+def test_check_bounds_has_no_effect_with_reference_descriptors(ctx):
+    """InterpolationConfig.check_bounds: PatchInterpolator::Evaluate reports whether the projection lies inside its patch
+    (patch_interpolator.h:125-135,160-166), but FeatureReferenceCostFunctor passes that on only when it has NO reference
+    descriptor (`if (!ref_descriptor_) return is_inside; ... return true;`, feature_reference.h:128-136 -- the cost-map
+    functor, tests/test_costmap_gpu.py::test_costmap_ba_check_bounds).  With references the evaluation is the border-clamped
+    one regardless: records, cost and solve are those of check_bounds = False, and equal the oracle's."""
     import pxo
     from pixsfm_amd import synthetic
     from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
@@ -172,16 +173,24 @@ def test_check_bounds_marks_failed_evaluations(ctx):
     inside = []
     for i in range(len(prob["obs_image"])):
         p = pxo.make_patch(prob["patches"][i], prob["corners"][i], prob["scales"][i])
-        xy = rec_off[i, 6:8]
-        inside.append(pxo.patch_eval(p, xy, pxo.cfg(check_bounds=True))[3] == 1)
-    inside = np.array(inside)
-    assert 0 < (~inside).sum() < len(inside)
-    assert np.array_equal(np.isnan(rec_on[:, 0]), ~inside)
-    assert np.array_equal(rec_on[inside], rec_off[inside]) and np.array_equal(rec_on[:, 1:], rec_off[:, 1:])
-    assert np.isfinite(rec_off).all()
+        inside.append(pxo.patch_eval(p, rec_off[i, 6:8], pxo.cfg(check_bounds=True))[3] == 1)
+    assert 0 < (~np.array(inside)).sum() < len(inside)            # some observations ARE outside their patches
+    assert np.isfinite(rec_on).all() and np.array_equal(rec_on, rec_off)
+    cost_o, _, _ = pxo.ba_eval_batch(prob, pxo.cfg(check_bounds=True), pxo.loss("cauchy", 0.25))
+    cost = ba.cost(make_loss("cauchy", [0.25]))
+    assert abs(cost - cost_o) < 1e-10 * cost_o
     gauge = (np.array([1, 0, 0, 0], np.uint8), np.array([0, 1, 0, 0], np.uint8), np.full(4, 0b0110, np.uint16),
              np.zeros(40, np.uint8))
-    s = ba.solve(interp_cfg(check_bounds=True), make_loss("cauchy", [0.25]), *gauge, options=lm_options(max_iterations=5))
-    assert s["termination"] == 2 and s["iterations"] == 0 and np.isnan(s["initial_cost"])     # PXR_TERM_FAILURE
-    s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *gauge, options=lm_options(max_iterations=2))
-    assert s["termination"] != 2 and np.isfinite(s["final_cost"])
+    for inner in (False, True):
+        for name in ("qvec", "tvec", "xyz", "cam_params"):
+            ba.d[name].upload(prob[name])
+        s_on = ba.solve(interp_cfg(check_bounds=True), make_loss("cauchy", [0.25]), *gauge,
+                        options=lm_options(max_iterations=3, use_inner_iterations=inner))
+        p_on = [a.copy() for a in ba.params()]
+        for name in ("qvec", "tvec", "xyz", "cam_params"):
+            ba.d[name].upload(prob[name])
+        s_off = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *gauge, options=lm_options(max_iterations=3, use_inner_iterations=inner))
+        assert s_on["termination"] != 2 and s_on["iterations"] == s_off["iterations"], (s_on, s_off)
+        # (the two solves are separate runs: their reductions agree to rounding, not bit for bit)
+        assert abs(s_on["final_cost"] - s_off["final_cost"]) <= 1e-9 * abs(s_off["final_cost"]), (s_on, s_off)
+        assert all(np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max()) for a, b in zip(p_on, ba.params()))

@@ -43,7 +43,7 @@ int64_t pxo_ref_ba_setup(int n_images, const int32_t* image_camera, const int64_
                          const uint8_t* const_camera, int refine_focal, int refine_pp, int refine_extra, int refine_extrinsics,
                          int min_track_length, int use_inner, int64_t max_blocks, int32_t* blk_image, int32_t* blk_p2d,
                          uint8_t* blk_const_pose, int8_t* image_role, uint8_t* tvec_mask_out, int32_t* camera_mask,
-                         int8_t* point_role, uint8_t* inner_group, int32_t* solver) {
+                         int8_t* point_role, uint8_t* inner_group, int32_t* solver) try {
   using namespace pixsfm;
   static const int kNumParams[5] = {3, 4, 4, 5, 8};
   colmap::Reconstruction rec;
@@ -101,7 +101,13 @@ int64_t pxo_ref_ba_setup(int n_images, const int32_t* image_camera, const int64_
   options.print_summary = false;
   InterpolationConfig icfg;
   FeatureReferenceBundleOptimizer opt(options, setup, icfg);
-  opt.Run(&rec, fview, references);
+  ceres::LastSolveOptions() = ceres::Solver::Options();   // SolveProblem returns before the solver when there are no residuals
+  try {
+    opt.Run(&rec, fview, references);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "pxo_ref_ba_setup: the reference threw: %s\n", e.what());
+    return -4;
+  }
 
   ceres::Problem* pr = opt.Problem();
   if ((int64_t)pr->blocks.size() > max_blocks) return -1;
@@ -152,6 +158,9 @@ int64_t pxo_ref_ba_setup(int n_images, const int32_t* image_camera, const int64_
     for (const auto& e : so.inner_iteration_ordering->elements) if (e.second == 0) inner_group[point_of.at(e.first)] = 1;
   solver[0] = (int)so.linear_solver_type; solver[1] = (int)so.preconditioner_type;
   return (int64_t)pr->blocks.size();
+} catch (const std::exception& e) {
+  std::fprintf(stderr, "pxo_ref_ba_setup: %s\n", e.what());
+  return -5;
 }
 
 }  // extern "C"

@@ -56,7 +56,7 @@ int64_t pxo_ref_ka_setup(int64_t n_pairs, const int32_t* pairs, const int64_t* m
                          const int32_t* node_corner, const double* node_scale, const int64_t* nodes_in_problem, int64_t n_in,
                          const int32_t* const_images, int n_const, int const_roots, int weight_by_sim, int root_edges_only,
                          double root_regularize_weight, double bound, int64_t max_blocks, int64_t* blk_src, int64_t* blk_dst,
-                         double* blk_w, uint8_t* node_const, double* node_bounds) {
+                         double* blk_w, uint8_t* node_const, double* node_bounds) try {
   using namespace pixsfm;
   Graph graph;
   for (int64_t p = 0; p < n_pairs; ++p) {
@@ -92,7 +92,10 @@ int64_t pxo_ref_ka_setup(int64_t n_pairs, const int32_t* pairs, const int64_t* m
   }
 
   auto setup = std::make_shared<KeypointAdjustmentSetup>();
-  for (int c = 0; c < n_const; ++c) setup->SetImageConstant(graph.image_name_to_id.at("im" + std::to_string(const_images[c])));
+  for (int c = 0; c < n_const; ++c) {
+    const auto it = graph.image_name_to_id.find("im" + std::to_string(const_images[c]));
+    if (it != graph.image_name_to_id.end()) setup->SetImageConstant(it->second);   // an image without matches is not in the graph
+  }
   if (const_roots) setup->SetMaskedNodesConstant(&graph, roots);
 
   FeatureMetricKeypointOptimizer::Options options;
@@ -128,6 +131,9 @@ int64_t pxo_ref_ka_setup(int64_t n_pairs, const int32_t* pairs, const int64_t* m
   for (double* p : pr->constant) node_const[node_of.at(p)] = 1;
   for (const auto& bd : pr->bounds) node_bounds[4 * node_of.at(bd.p) + (bd.upper ? 2 : 0) + bd.index] = bd.value;
   return (int64_t)pr->blocks.size();
+} catch (const std::exception& e) {
+  std::fprintf(stderr, "pxo_ref_ka_setup: %s\n", e.what());
+  return -5;
 }
 
 }  // extern "C"

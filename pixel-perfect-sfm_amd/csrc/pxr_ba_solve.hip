@@ -632,6 +632,78 @@ __global__ __launch_bounds__(256) void k_build_descriptors(int64_t n_obs, const 
   so[o] = make_int4((int)i, (int)pt, (int)pt_ptr[pt], pt_var[pt] ? (int)(pt_ptr[pt + 1] - pt_ptr[pt]) : 0);
 }
 
+// ---- observation lists on the device (set-up) -------------------------------------------------------------------------
+// counts per image / per point, index range check, and whether the observations are ordered by point (then the
+// point-ordered list is the identity); flags[0] = out-of-range index seen, flags[1] = a point index decreases
+__global__ __launch_bounds__(256) void k_count_indices(int64_t n_obs, const int32_t* __restrict__ obs_image,
+                                                       const int32_t* __restrict__ obs_point, int n_img, int64_t n_pts,
+                                                       unsigned long long* __restrict__ img_cnt, unsigned long long* __restrict__ pt_cnt,
+                                                       int* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_obs) return;
+  const int im = obs_image[i], pt = obs_point[i];
+  if (im < 0 || im >= n_img || pt < 0 || pt >= n_pts) { atomicOr(&flags[0], 1); return; }
+  atomicAdd(&img_cnt[im + 1], 1ull);
+  atomicAdd(&pt_cnt[pt + 1], 1ull);
+  if (i > 0 && obs_point[i - 1] > pt) atomicOr(&flags[1], 1);
+}
+__global__ void k_iota(int64_t n, int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = i;
+}
+// STABLE counting sort of the observation ids by image (the order the host fill produces: ascending observation id inside
+// an image -- the summation order of k_img and of the Schur contraction, which must not depend on the run):
+//   k_sort_hist     a workgroup counts the images of its contiguous chunk of SORT_CHUNK observations,
+//   k_sort_offsets  per image, an exclusive scan of those counts over the chunks on top of the image's first slot,
+//   k_sort_scatter  the workgroup walks its chunk in order, 256 observations a round: slot = running offset of the image +
+//                   number of EARLIER observations of the round with the same image.
+constexpr int SORT_CHUNK = 4096, SORT_MAX_IMAGES = 8192;
+__global__ __launch_bounds__(256) void k_sort_hist(int64_t n_obs, const int32_t* __restrict__ obs_image, int n_img,
+                                                   int* __restrict__ hist) {
+  extern __shared__ int sh_cnt[];
+  for (int k = threadIdx.x; k < n_img; k += blockDim.x) sh_cnt[k] = 0;
+  __syncthreads();
+  const int64_t b0 = (int64_t)blockIdx.x * SORT_CHUNK, b1 = min(n_obs, b0 + SORT_CHUNK);
+  for (int64_t i = b0 + threadIdx.x; i < b1; i += blockDim.x) atomicAdd(&sh_cnt[obs_image[i]], 1);
+  __syncthreads();
+  for (int k = threadIdx.x; k < n_img; k += blockDim.x) hist[(size_t)blockIdx.x * n_img + k] = sh_cnt[k];
+}
+__global__ void k_sort_offsets(int n_img, int n_chunks, const int64_t* __restrict__ img_ptr, int* __restrict__ hist) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_img) return;
+  int run = (int)img_ptr[k];
+  for (int b = 0; b < n_chunks; ++b) {
+    const int c = hist[(size_t)b * n_img + k];
+    hist[(size_t)b * n_img + k] = run;
+    run += c;
+  }
+}
+__global__ __launch_bounds__(256) void k_sort_scatter(int64_t n_obs, const int32_t* __restrict__ obs_image, int n_img,
+                                                      const int* __restrict__ hist, int64_t* __restrict__ img_obs) {
+  extern __shared__ int sh_off[];          // [n_img] running offsets, then [256] the keys of the round
+  int* keys = sh_off + n_img;
+  for (int k = threadIdx.x; k < n_img; k += blockDim.x) sh_off[k] = hist[(size_t)blockIdx.x * n_img + k];
+  const int64_t b0 = (int64_t)blockIdx.x * SORT_CHUNK, b1 = min(n_obs, b0 + SORT_CHUNK);
+  for (int64_t r0 = b0; r0 < b1; r0 += 256) {
+    const int64_t i = r0 + threadIdx.x;
+    const int key = i < b1 ? obs_image[i] : -1;
+    __syncthreads();                       // offsets initialised / updated by the previous round
+    keys[threadIdx.x] = key;
+    __syncthreads();
+    int before = 0, after = 0;
+    if (key >= 0) {
+      for (int t = 0; t < 256; ++t) {
+        const int same = keys[t] == key;
+        before += same & (t < (int)threadIdx.x);
+        after += same & (t > (int)threadIdx.x);
+      }
+      img_obs[sh_off[key] + before] = i;
+    }
+    __syncthreads();                       // every slot of the round is computed from the old offsets
+    if (key >= 0 && after == 0) sh_off[key] += before + 1;
+  }
+}
+
 // ---- host orchestration -----------------------------------------------------------------------------------
 template <typename T>
 struct DevBuf {
@@ -688,23 +760,53 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   const int64_t n_obs = view->n_obs, n_pts = view->n_points;
   const int n_img = view->n_images, n_cam = view->n_cameras;
 
-  // ---- host-side structure: which blocks are in the program, offsets, CSR lists ------------
-  std::vector<int32_t> obs_image(n_obs), obs_point(n_obs), image_camera(n_img), cam_model(n_cam);
-  PXR_HIP(hipMemcpyAsync(obs_image.data(), view->d_obs_image, 4 * n_obs, hipMemcpyDeviceToHost, st));
-  PXR_HIP(hipMemcpyAsync(obs_point.data(), view->d_obs_point, 4 * n_obs, hipMemcpyDeviceToHost, st));
+  // ---- structure: which blocks are in the program, offsets, observation lists per image and per point -----------------
+  // Fast path (observations ordered by point -- what every caller of this library produces -- and at most
+  // SORT_MAX_IMAGES images): the 2 x n_obs index arrays never leave the device; only the per-image / per-point COUNTS come
+  // to the host, the lists are built by a stable counting sort on the device.  Otherwise (and with PXR_BA_SETUP_HOST=1,
+  // for the equivalence test) the lists are built on the host from a copy of the index arrays.
+  std::vector<int32_t> obs_image, obs_point, image_camera(n_img), cam_model(n_cam);
+  std::vector<int64_t> img_cnt(n_img + 1, 0), pt_cnt(n_pts + 1, 0);
+  DevBuf<unsigned long long> d_cnt;
+  DevBuf<int> d_flags;
+  bool device_lists = n_img <= SORT_MAX_IMAGES && std::getenv("PXR_BA_SETUP_HOST") == nullptr;
   PXR_HIP(hipMemcpyAsync(image_camera.data(), view->d_image_camera, 4 * n_img, hipMemcpyDeviceToHost, st));
   PXR_HIP(hipMemcpyAsync(cam_model.data(), view->d_cam_model, 4 * n_cam, hipMemcpyDeviceToHost, st));
+  if (device_lists) {
+    int h_flags[2] = {0, 0};
+    RC(d_cnt.alloc((size_t)n_img + 1 + (size_t)n_pts + 1)); RC(d_flags.alloc(2));
+    PXR_HIP(hipMemsetAsync(d_cnt.p, 0, sizeof(unsigned long long) * d_cnt.n, st));
+    PXR_HIP(hipMemsetAsync(d_flags.p, 0, sizeof(int) * 2, st));
+    hipLaunchKernelGGL(k_count_indices, dim3((unsigned)((n_obs + 255) / 256)), dim3(256), 0, st, n_obs, view->d_obs_image,
+                       view->d_obs_point, n_img, n_pts, d_cnt.p, d_cnt.p + n_img + 1, d_flags.p);
+    static_assert(sizeof(unsigned long long) == sizeof(int64_t), "counter width");
+    PXR_HIP(hipMemcpyAsync(img_cnt.data(), d_cnt.p, sizeof(int64_t) * (n_img + 1), hipMemcpyDeviceToHost, st));
+    PXR_HIP(hipMemcpyAsync(pt_cnt.data(), d_cnt.p + n_img + 1, sizeof(int64_t) * (n_pts + 1), hipMemcpyDeviceToHost, st));
+    PXR_HIP(hipMemcpyAsync(h_flags, d_flags.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+    PXR_HIP(hipStreamSynchronize(st));
+    PXR_REQUIRE(h_flags[0] == 0, "pxr_ba_solve: an observation references an image / point out of range");
+    if (h_flags[1]) {                       // not ordered by point: the general host path
+      device_lists = false;
+      std::fill(img_cnt.begin(), img_cnt.end(), 0); std::fill(pt_cnt.begin(), pt_cnt.end(), 0);
+    }
+  }
+  if (!device_lists) {
+    obs_image.resize(n_obs); obs_point.resize(n_obs);
+    PXR_HIP(hipMemcpyAsync(obs_image.data(), view->d_obs_image, 4 * n_obs, hipMemcpyDeviceToHost, st));
+    PXR_HIP(hipMemcpyAsync(obs_point.data(), view->d_obs_point, 4 * n_obs, hipMemcpyDeviceToHost, st));
+  }
   PXR_HIP(hipStreamSynchronize(st));
-  setup_mark("index arrays on the host");
+  setup_mark(device_lists ? "counts on the host" : "index arrays on the host");
   static const int kNumParams[11] = {3, 4, 4, 5, 8, 8, 12, 5, 4, 5, 12};   // [upstream COLMAP 3.8] kNumParams by model id
   for (int c = 0; c < n_cam; ++c)
     PXR_REQUIRE(cam_model[c] >= 0 && cam_model[c] <= 10, "pxr_ba_solve: unsupported camera model id %d", cam_model[c]);
-  std::vector<int64_t> img_cnt(n_img + 1, 0), pt_cnt(n_pts + 1, 0);
-  for (int64_t i = 0; i < n_obs; ++i) {
-    PXR_REQUIRE(obs_image[i] >= 0 && obs_image[i] < n_img && obs_point[i] >= 0 && obs_point[i] < n_pts,
-                "pxr_ba_solve: observation %lld references image %d / point %d out of range", (long long)i,
-                obs_image[i], obs_point[i]);
-    ++img_cnt[obs_image[i] + 1]; ++pt_cnt[obs_point[i] + 1];
+  if (!device_lists) {
+    for (int64_t i = 0; i < n_obs; ++i) {
+      PXR_REQUIRE(obs_image[i] >= 0 && obs_image[i] < n_img && obs_point[i] >= 0 && obs_point[i] < n_pts,
+                  "pxr_ba_solve: observation %lld references image %d / point %d out of range", (long long)i,
+                  obs_image[i], obs_point[i]);
+      ++img_cnt[obs_image[i] + 1]; ++pt_cnt[obs_point[i] + 1];
+    }
   }
   // With several ranks a camera-side block may have no local observation but still be part of the
   // (global) program: the caller marks unused blocks constant, we keep every non-constant block.
@@ -739,12 +841,13 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   PXR_REQUIRE(n_c > 0 || n_pvar > 0, "pxr_ba_solve: every parameter block is constant");
   for (int i = 0; i < n_img; ++i) img_cnt[i + 1] += img_cnt[i];
   for (int64_t p = 0; p < n_pts; ++p) pt_cnt[p + 1] += pt_cnt[p];
-  std::vector<int64_t> img_obs(n_obs), pt_obs(n_obs);
-  {
+  std::vector<int64_t> img_obs, pt_obs;
+  if (!device_lists) {
+    img_obs.resize(n_obs); pt_obs.resize(n_obs);
     std::vector<int64_t> ic(img_cnt.begin(), img_cnt.end() - 1), pc(pt_cnt.begin(), pt_cnt.end() - 1);
     for (int64_t i = 0; i < n_obs; ++i) { img_obs[ic[obs_image[i]]++] = i; pt_obs[pc[obs_point[i]]++] = i; }
   }
-  setup_mark("host CSR (counts, fill)");
+  setup_mark(device_lists ? "host prefix sums" : "host CSR (counts, fill)");
   std::vector<ImgChunk> chunks;
   const int64_t CH = 512;    // observations per k_img workgroup (4 LDS batches)
   for (int i = 0; i < n_img; ++i)
@@ -798,8 +901,23 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   DevBuf<int> d_part_obs;
   RC(d_pose_off.upload(pose_off, st)); RC(d_pose_dim.upload(pose_dim, st)); RC(d_tmask.upload(tmask, st));
   RC(d_intr_off.upload(intr_off, st)); RC(d_intr_dim.upload(intr_dim, st)); RC(d_cmask.upload(cmask, st));
-  RC(d_pt_var.upload(pt_var, st)); RC(d_img_obs.upload(img_obs, st)); RC(d_pt_ptr.upload(pt_cnt, st));
-  RC(d_pt_obs.upload(pt_obs, st)); RC(d_chunks.upload(chunks, st));
+  RC(d_pt_var.upload(pt_var, st)); RC(d_pt_ptr.upload(pt_cnt, st)); RC(d_chunks.upload(chunks, st));
+  if (device_lists) {
+    RC(d_img_obs.alloc(n_obs)); RC(d_pt_obs.alloc(n_obs));
+    hipLaunchKernelGGL(k_iota, dim3(nblk(n_obs)), dim3(256), 0, st, n_obs, d_pt_obs.p);     // ordered by point already
+    DevBuf<int64_t> d_img_ptr;
+    DevBuf<int> d_hist;
+    const int n_chunks = (int)((n_obs + SORT_CHUNK - 1) / SORT_CHUNK);
+    RC(d_img_ptr.upload(img_cnt, st)); RC(d_hist.alloc((size_t)n_chunks * n_img));
+    hipLaunchKernelGGL(k_sort_hist, dim3(n_chunks), dim3(256), sizeof(int) * n_img, st, n_obs, view->d_obs_image, n_img, d_hist.p);
+    hipLaunchKernelGGL(k_sort_offsets, dim3((n_img + 255) / 256), dim3(256), 0, st, n_img, n_chunks, d_img_ptr.p, d_hist.p);
+    hipLaunchKernelGGL(k_sort_scatter, dim3(n_chunks), dim3(256), sizeof(int) * (n_img + 256), st, n_obs, view->d_obs_image, n_img,
+                       d_hist.p, d_img_obs.p);
+    LAUNCH_CHECK("observation-list kernels");
+    PXR_HIP(hipStreamSynchronize(st));      // d_img_ptr / d_hist go out of scope
+  } else {
+    RC(d_img_obs.upload(img_obs, st)); RC(d_pt_obs.upload(pt_obs, st));
+  }
   RC(d_schur_chunks.upload(schur_chunks, st));
   RC(d_obs_cols.alloc(n_obs)); RC(d_so.alloc(n_obs)); RC(d_part_obs.alloc(n_obs));
   hipLaunchKernelGGL(k_build_descriptors, dim3(nblk(n_obs)), dim3(256), 0, st, n_obs, view->d_obs_image, view->d_obs_point,

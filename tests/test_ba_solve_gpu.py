@@ -149,3 +149,32 @@ def test_two_rank_partition_on_one_gpu(ctx):
         assert np.abs(q - ref[0]).max() < 1e-9 and np.abs(t - ref[1]).max() < 1e-9
         assert np.abs(k - ref[2]).max() < 1e-7
         assert np.abs(X - ref[3][pt_ids]).max() < 1e-9
+
+
+def test_device_built_observation_lists_equal_the_host_ones(ctx, monkeypatch):
+    """Set-up: the per-image / per-point observation lists are built on the device (stable counting sort by image) when the
+    observations are ordered by point; PXR_BA_SETUP_HOST=1 forces the host construction, an input that is NOT ordered by
+    point takes it by itself.  Same lists -> the same summation orders -> the solves agree to the reduction noise of
+    two separate runs, and a permuted input reproduces the ordered one."""
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    prob = synthetic.make_ba_problem(n_cams=9, n_points=700, obs_per_point=5, seed=123, shared_camera=True)
+    gauge = _gauge(prob)
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+
+    def solve(p):
+        ba = BAProblem(ctx, arena, p)
+        s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *gauge, options=lm_options(max_iterations=4, use_inner_iterations=True))
+        return s, ba.params()
+
+    s_dev, p_dev = solve(prob)
+    monkeypatch.setenv("PXR_BA_SETUP_HOST", "1")
+    s_host, p_host = solve(prob)
+    monkeypatch.delenv("PXR_BA_SETUP_HOST")
+    perm = np.random.default_rng(5).permutation(len(prob["obs_image"]))      # not ordered by point any more
+    shuffled = dict(prob, obs_image=prob["obs_image"][perm], obs_point=prob["obs_point"][perm], obs_patch=prob["obs_patch"][perm])
+    s_perm, p_perm = solve(shuffled)
+    for s_, p_ in ((s_host, p_host), (s_perm, p_perm)):
+        assert s_["iterations"] == s_dev["iterations"] and s_["num_successful"] == s_dev["num_successful"]
+        assert abs(s_["final_cost"] - s_dev["final_cost"]) <= 1e-9 * abs(s_dev["final_cost"])
+        assert all(np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max()) for a, b in zip(p_, p_dev))

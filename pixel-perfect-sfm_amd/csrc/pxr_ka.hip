@@ -37,7 +37,7 @@
 namespace pxr {
 
 constexpr int KA_NT = 256;     // threads per sub-problem workgroup
-constexpr int KA_NLDS = 100;   // LDS budget for the damped blocks: KA_NLDS^2 doubles (78 KiB: two workgroups per CU)
+constexpr int KA_NLDS = 88;    // LDS budget for the damped blocks: KA_NLDS^2 doubles (61 KiB + 17 KiB of metadata caches: two workgroups per CU)
 
 struct KaArgs {
   pxr_ka_view v;
@@ -68,13 +68,31 @@ template <int C> struct KaLay {
   static constexpr int LPO = C / CPL;            // lanes per node / edge
 };
 
+// per-problem metadata the solve kernel keeps in LDS for its whole LM loop: every evaluation walks the same nodes and
+// residual blocks, and the chains node -> patch -> scale / corner and slot -> edge -> endpoints -> unknowns were two to
+// three dependent global loads in front of every interpolation / block (the kernel is latency-bound: one workgroup per
+// sub-problem, ~18 % vector-ALU utilisation)
+constexpr int KA_NODE_CACHE = 96, KA_EDGE_CACHE = 512;
+struct KaNodeMeta { int64_t node, pi; double sx, sy, cx, cy; int64_t id; int v; };     // node < 0: not touched by a residual block; id: the node, v: its first unknown or -1
+struct KaEdgeMeta { int n1, n2, v1, v2; double w; };
+
+template <typename ST, int C, bool WITH_JAC>
+__device__ __forceinline__ void ka_eval_node_at(const KaArgs& a, int64_t node, int64_t pi, double sx, double sy, double cx,
+                                                double cy, const double* kp, int sub, bool fsimd);
+
 template <typename ST, int C, bool WITH_JAC>
 __device__ __forceinline__ void ka_eval_node(const KaArgs& a, int64_t node, const double* kp, int sub, bool fsimd) {
   const int64_t pi = a.v.d_node_patch[node];
-  const double sx = a.scales[2 * pi], sy = a.scales[2 * pi + 1];
+  ka_eval_node_at<ST, C, WITH_JAC>(a, node, pi, a.scales[2 * pi], a.scales[2 * pi + 1], (double)a.corners[2 * pi],
+                                   (double)a.corners[2 * pi + 1], kp, sub, fsimd);
+}
+
+template <typename ST, int C, bool WITH_JAC>
+__device__ __forceinline__ void ka_eval_node_at(const KaArgs& a, int64_t node, int64_t pi, double sx, double sy, double cx,
+                                                double cy, const double* kp, int sub, bool fsimd) {
   // FeaturePatch::ToPixelCoordinates, features/src/featurepatch.h:250-255
-  const double u = kp[2 * node] * sx - 0.5 - (double)a.corners[2 * pi];
-  const double v = kp[2 * node + 1] * sy - 0.5 - (double)a.corners[2 * pi + 1];
+  const double u = kp[2 * node] * sx - 0.5 - cx;
+  const double v = kp[2 * node + 1] * sy - 0.5 - cy;
   const ST* patch = reinterpret_cast<const ST*>(a.arena) + (size_t)pi * a.H * a.W * C;
   constexpr int CPL = KaLay<C>::CPL;
   double f[CPL], fr[CPL], fc[CPL];
@@ -139,6 +157,9 @@ struct KaProb {
   double *g, *gun, *scale, *diag, *step, *delta, *lo, *hi, *rhs;
   int *row_off, *row_v0, *row_nc, *comp_v0;
   double* Hm;            // block-diagonal normal matrix: one dense nc x nc block per component
+  const KaNodeMeta* cnode = nullptr;   // LDS: metadata of the first KA_NODE_CACHE nodes / KA_EDGE_CACHE edges of the problem
+  const KaEdgeMeta* cedge = nullptr;   // (solve kernel only; the rest, and every other caller, reads global memory)
+  double* csq = nullptr;               // LDS: squared residual norms of the cached edges (cost-only pass)
 };
 
 // evaluate all nodes of the problem at keypoints `kp`
@@ -148,6 +169,12 @@ __device__ void ka_nodes(const KaArgs& a, const KaProb& p, const double* kp, boo
   const int grp = threadIdx.x / LPO, sub = threadIdx.x % LPO;
 #pragma nounroll
   for (int64_t i = p.np0 + grp; i < p.np1; i += G) {
+    if (p.cnode && i - p.np0 < KA_NODE_CACHE) {
+      const KaNodeMeta m = p.cnode[i - p.np0];
+      if (m.node < 0) continue;
+      ka_eval_node_at<ST, C, WITH_JAC>(a, m.node, m.pi, m.sx, m.sy, m.cx, m.cy, kp, sub, fsimd);
+      continue;
+    }
     const int64_t node = a.v.d_prob_nodes[i];
     if (!a.used[node]) continue;
     ka_eval_node<ST, C, WITH_JAC>(a, node, kp, sub, fsimd);
@@ -172,10 +199,44 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
   constexpr int LPO = KaLay<C>::LPO, CPL = KaLay<C>::CPL, G = KA_NT / LPO;
   const int grp = threadIdx.x / LPO, sub = threadIdx.x % LPO;
   double cost = 0.0;
+  int64_t i_first = p.ne0 + grp;
+  if constexpr (!WITH_JAC) {
+    // cost only (the line-search probes: half of the solve's wall time).  The robust loss -- an fp64 log for Cauchy -- is
+    // evaluated by ONE lane of a 16-lane group per residual block, yet costs the whole wavefront its ~150 instructions:
+    // the groups only form the squared norms here and park them in LDS, then every lane evaluates the loss of a
+    // different block.
+    if (p.cedge && p.csq) {
+      const int64_t ncached = min((int64_t)KA_EDGE_CACHE, p.ne1 - p.ne0);
+      for (; i_first - p.ne0 < ncached; i_first += G) {
+        const KaEdgeMeta m = p.cedge[i_first - p.ne0];
+        const double* d1 = a.desc + (size_t)m.n1 * 3 * C + sub * CPL;
+        const double* d2 = a.desc + (size_t)m.n2 * 3 * C + sub * CPL;
+        double sq = 0;
+#pragma unroll
+        for (int ch = 0; ch < CPL; ++ch) { const double r = d1[ch] - d2[ch]; sq = fma(r, r, sq); }
+        sq = lpo_sum(sq, LPO);
+        if (sub == 0) p.csq[i_first - p.ne0] = sq;
+      }
+      __syncthreads();
+      for (int64_t k = threadIdx.x; k < ncached; k += blockDim.x) {
+        double rho[3];
+        loss_eval(a.loss.type, a.loss.a, p.cedge[k].w, p.csq[k], rho);
+        cost += 0.5 * rho[0];
+      }
+    }
+  }
 #pragma nounroll
-  for (int64_t i = p.ne0 + grp; i < p.ne1; i += G) {
-    const int e = a.v.d_prob_edges[i];
-    const int n1 = a.v.d_edge_src[e], n2 = a.v.d_edge_dst[e];
+  for (int64_t i = i_first; i < p.ne1; i += G) {
+    int n1, n2, v1c = 0, v2c = 0;
+    double we;
+    const bool cached = p.cedge && i - p.ne0 < KA_EDGE_CACHE;
+    if (cached) {
+      const KaEdgeMeta m = p.cedge[i - p.ne0];
+      n1 = m.n1; n2 = m.n2; v1c = m.v1; v2c = m.v2; we = m.w;
+    } else {
+      const int e = a.v.d_prob_edges[i];
+      n1 = a.v.d_edge_src[e]; n2 = a.v.d_edge_dst[e]; we = a.v.d_edge_w[e];
+    }
     const double* d1 = a.desc + (size_t)n1 * 3 * C + sub * CPL;
     const double* d2 = a.desc + (size_t)n2 * 3 * C + sub * CPL;
     double r[CPL];
@@ -184,7 +245,7 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
     for (int ch = 0; ch < CPL; ++ch) { r[ch] = d1[ch] - d2[ch]; s = fma(r[ch], r[ch], s); }
     s = lpo_sum(s, LPO);
     double rho[3];
-    loss_eval(a.loss.type, a.loss.a, a.v.d_edge_w[e], s, rho);
+    loss_eval(a.loss.type, a.loss.a, we, s, rho);
     if (sub == 0) cost += 0.5 * rho[0];
     if (WITH_JAC) {
       // J = [g1x g1y -g2x -g2y]; 10 entries of J^T J and 4 of J^T r
@@ -204,7 +265,7 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
       for (int k = 0; k < 14; ++k) q[k] = lpo_sum(q[k], LPO);
       if (sub == 0) {
         const double kappa = ka_kappa(s, rho);
-        const int v1 = a.var_of_node[n1], v2 = a.var_of_node[n2];
+        const int v1 = cached ? v1c : a.var_of_node[n1], v2 = cached ? v2c : a.var_of_node[n2];
         // both variable endpoints of an edge lie in the same component: one block, one column origin
         const int vv = v1 >= 0 ? v1 : v2;
         if (vv >= 0) {
@@ -307,8 +368,9 @@ __device__ double ka_interp_step(double f0, double g0, bool have_prev, double xp
 // candidate = P(x + alpha * delta) for the problem's variable nodes (ParameterBlock::Plus [upstream])
 __device__ void ka_plus(const KaArgs& a, const KaProb& p, double alpha) {
   for (int64_t i = p.np0 + threadIdx.x; i < p.np1; i += blockDim.x) {
-    const int64_t node = a.v.d_prob_nodes[i];
-    const int v = a.var_of_node[node];
+    const bool cached = p.cnode && i - p.np0 < KA_NODE_CACHE;
+    const int64_t node = cached ? p.cnode[i - p.np0].id : a.v.d_prob_nodes[i];
+    const int v = cached ? p.cnode[i - p.np0].v : a.var_of_node[node];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       double val = a.v.d_kp[2 * node + c];
@@ -528,8 +590,18 @@ __global__ __launch_bounds__(KA_NT) void ka_setup_kernel(const KaArgs a, KaInfo*
 }
 
 
+// -DPXR_KA_PROFILE: workgroup 0 prints how its wall time splits over the phases of the LM loop (tools/ka_phase_probe.sh)
+#ifdef PXR_KA_PROFILE
+#define KA_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = wall_clock64(); ka_prof[k] += t_ - ka_t0; ka_t0 = t_; } } while (0)
+#else
+#define KA_T(k) do { } while (0)
+#endif
+
 template <typename ST, int C>
 __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __restrict__ info, double* sh_A) {
+#ifdef PXR_KA_PROFILE
+  long long ka_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ka_t0 = wall_clock64();
+#endif
   __shared__ double sh4[KA_NT / 64];
   __shared__ int sh_ok;
   const int prob = blockIdx.x, tid = threadIdx.x;
@@ -551,6 +623,26 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   sm.num_camera_unknowns = 0; sm.num_point_unknowns = 0; sm.initial_cost = 0; sm.final_cost = 0;
   sm.final_radius = 0; sm.total_ms = 0; sm.setup_ms = 0;
 
+  __shared__ KaNodeMeta sh_nodes[KA_NODE_CACHE];
+  __shared__ KaEdgeMeta sh_edges[KA_EDGE_CACHE];
+  __shared__ double sh_sq[KA_EDGE_CACHE];
+  for (int64_t i = p.np0 + tid; i < p.np1 && i - p.np0 < KA_NODE_CACHE; i += blockDim.x) {
+    const int64_t node = a.v.d_prob_nodes[i];
+    const int64_t pi = a.v.d_node_patch[node];
+    KaNodeMeta m;
+    m.node = a.used[node] ? node : -1; m.pi = pi; m.id = node; m.v = a.var_of_node[node];
+    m.sx = a.scales[2 * pi]; m.sy = a.scales[2 * pi + 1]; m.cx = (double)a.corners[2 * pi]; m.cy = (double)a.corners[2 * pi + 1];
+    sh_nodes[i - p.np0] = m;
+  }
+  for (int64_t i = p.ne0 + tid; i < p.ne1 && i - p.ne0 < KA_EDGE_CACHE; i += blockDim.x) {
+    const int e = a.v.d_prob_edges[i];
+    KaEdgeMeta m;
+    m.n1 = a.v.d_edge_src[e]; m.n2 = a.v.d_edge_dst[e]; m.v1 = a.var_of_node[m.n1]; m.v2 = a.var_of_node[m.n2]; m.w = a.v.d_edge_w[e];
+    sh_edges[i - p.ne0] = m;
+  }
+  p.cnode = sh_nodes; p.cedge = sh_edges; p.csq = sh_sq;
+  __syncthreads();
+
   const KaInfo inf = info[prob];
   const int n = inf.n, hsz = inf.hsz, maxnc = inf.maxnc;
   p.n = n; p.ncomp = inf.ncomp;
@@ -563,9 +655,12 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = 0.0;
     for (int e = tid; e < n; e += blockDim.x) p.g[e] = 0.0;
     __syncthreads();
+    KA_T(7);
     ka_nodes<ST, C, true>(a, p, a.v.d_kp, fsimd);
+    KA_T(0);
     const double c = ka_terms<C, true>(a, p, sh4);
     __syncthreads();
+    KA_T(1);
     for (int e = tid; e < n; e += blockDim.x) {
       p.gun[e] = p.g[e];
       if (compute_scale) p.scale[e] = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(p.Hm[p.row_off[e] + e - p.row_v0[e]])) : 1.0;
@@ -580,11 +675,16 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       p.g[e] *= se;
     }
     __syncthreads();
+    KA_T(2);
     return c;
   };
   auto cost_at_candidate = [&]() -> double {
+    KA_T(7);
     ka_nodes<ST, C, false>(a, p, a.kp_cand, fsimd);
-    return ka_terms<C, false>(a, p, sh4);
+    KA_T(3);
+    const double c = ka_terms<C, false>(a, p, sh4);
+    KA_T(4);
+    return c;
   };
 
   if (n == 0 || (p.ne1 == p.ne0 && p.nu1 == p.nu0)) {
@@ -640,6 +740,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       }
       __syncthreads();
     }
+    KA_T(5);
     bool ok = sh_ok != 0;
     // model cost change = -d.g - 0.5 d.H.d
     double part = 0.0;
@@ -667,6 +768,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       g0p += p.gun[e] * dl;
     }
     const double g0 = block_sum(g0p, sh4);
+    KA_T(6);
     // DoLineSearch [upstream trust_region_minimizer.cc]: projected Armijo search along delta.  The
     // accepted probe IS the candidate point P(x + delta): its cost is reused instead of re-evaluated.
     double cand;
@@ -703,8 +805,9 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     }
     double s2 = 0.0, x2 = 0.0;
     for (int64_t i = p.np0 + tid; i < p.np1; i += blockDim.x) {
-      const int64_t node = a.v.d_prob_nodes[i];
-      if (a.var_of_node[node] < 0) continue;
+      const bool cached = i - p.np0 < KA_NODE_CACHE;
+      const int64_t node = cached ? sh_nodes[i - p.np0].id : a.v.d_prob_nodes[i];
+      if ((cached ? sh_nodes[i - p.np0].v : a.var_of_node[node]) < 0) continue;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const double x0 = a.v.d_kp[2 * node + c], d = a.kp_cand[2 * node + c] - x0;
@@ -718,7 +821,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     const double rel = cost_change / model_cost_change;
     if (rel > opt.min_relative_decrease) {
       for (int64_t i = p.np0 + tid; i < p.np1; i += blockDim.x) {
-        const int64_t node = a.v.d_prob_nodes[i];
+        const int64_t node = i - p.np0 < KA_NODE_CACHE ? sh_nodes[i - p.np0].id : a.v.d_prob_nodes[i];
         a.v.d_kp[2 * node] = a.kp_cand[2 * node]; a.v.d_kp[2 * node + 1] = a.kp_cand[2 * node + 1];
       }
       __syncthreads();
@@ -733,6 +836,13 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   }
   sm.final_cost = cost; sm.final_radius = radius;
   if (tid == 0) a.summaries[prob] = sm;
+#ifdef PXR_KA_PROFILE
+  KA_T(7);
+  if (blockIdx.x == 0 && tid == 0)
+    printf("[ka profile, workgroup 0, 10 ns ticks] nodes+J %lld  terms+J %lld  scale %lld  nodes(cost) %lld  terms(cost) %lld  "
+           "damp+cholesky %lld  model change %lld  other %lld  | iterations %d unknowns %d\n", ka_prof[0], ka_prof[1], ka_prof[2],
+           ka_prof[3], ka_prof[4], ka_prof[5], ka_prof[6], ka_prof[7], sm.iterations, n);
+#endif
 }
 
 // Two entry points over the same body.  The fp16 / fp32 instantiations need ~284 VGPRs unconstrained,

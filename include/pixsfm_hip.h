@@ -400,6 +400,35 @@ int pxr_graph_root_labels(int64_t n_nodes, const int64_t* track_labels, const do
 int pxr_graph_labels_device(pxr_ctx* ctx, int64_t n_nodes, const int32_t* d_node_image, int64_t n_edges,
                             const int64_t* d_edge_src, const int64_t* d_edge_dst, const double* d_edge_sim,
                             int64_t* d_track_labels, double* d_scores, uint8_t* d_is_root, int64_t* h_n_tracks);
+/* ---- BA problem construction (host code; A16, A17) ----------------------------------------------------------
+ * BundleOptimizer::SetUp on a flat scene (bundle_adjustment/src/bundle_optimizer.h:139-165): AddImageToProblem for the
+ * images of the setup (:247-275, incl. the min_track_length filter), AddPointToProblem for the extra variable /
+ * constant points (:279-317: their observations in images OUTSIDE the setup, whose cameras become constant unless
+ * residuals of setup images use them), FeatureReferenceBundleOptimizer::AddResiduals
+ * (feature_reference_bundle_optimizer.h:90-149), then ParameterizePoints / Images / Cameras (:335-453).
+ * Scene (HOST arrays, what a binding reads off colmap::Reconstruction): images 0 .. n_images-1 with their camera and
+ * their points2D (rows p2d_ptr[i] .. p2d_ptr[i+1] of p2d_point3D; -1 = no 3D point), cameras (COLMAP model id), points
+ * 0 .. n_points-1 with their tracks in Track().Elements() order (track_ptr / track_image / track_p2d);
+ * has_patch [n_p2d] (NULL: every observation has a feature patch; a missing one is an error unless
+ * skip_missing_patches -- the extractors' GetVisibleObservations, reference_extractor.h:171-213).
+ * Setup (BundleAdjustmentSetup, bundle_adjustment_options.h:28-42): in_setup / const_pose / tvec_mask (bit a = tvec[a]
+ * constant) per image, variable_point / constant_point per point, constant_camera per camera; the four refine_* flags
+ * and min_track_length of BundleOptimizerOptions (:66-90).
+ * Outputs: the residual blocks (capacity n_p2d) as (image, point2D index, point3D), ordered by point and inside a point
+ * like its track; per image whether it takes part, whether its pose is constant, its constant translation components;
+ * per camera -1 (not in the problem) or the bit mask of constant parameters (all bits: the block is constant); per
+ * point -1 (no residual block), 0 variable, 1 constant.  With inner iterations every variable point is in group 0
+ * (:350-355).  The linear solver follows the number of images IN THE SETUP (:180-191), see pxr_lm_options. */
+int pxr_ba_build_problem(int32_t n_images, const int32_t* image_camera, const int64_t* p2d_ptr, const int64_t* p2d_point3D,
+                         int32_t n_cameras, const int32_t* cam_model, int64_t n_points, const int64_t* track_ptr,
+                         const int32_t* track_image, const int32_t* track_p2d, const uint8_t* has_patch,
+                         const uint8_t* in_setup, const uint8_t* const_pose, const uint8_t* tvec_mask,
+                         const uint8_t* variable_point, const uint8_t* constant_point, const uint8_t* constant_camera,
+                         int refine_focal_length, int refine_principal_point, int refine_extra_params, int refine_extrinsics,
+                         int min_track_length, int skip_missing_patches, int64_t* n_obs, int32_t* obs_image, int32_t* obs_p2d,
+                         int64_t* obs_point, uint8_t* image_in_problem, uint8_t* pose_is_const, uint8_t* tvec_mask_out,
+                         int32_t* camera_mask, int8_t* point_role);
+
 /* Residual-block selection of TopologicalKeypointOptimizer::SetUp + AddIntraResiduals (A12,
  * topological_keypoint_optimizer.h:97-175, featuremetric_keypoint_optimizer.h:158-202): intra-track matches,
  * minus keypoint aliases, optionally root edges only, plus root-regularisation blocks; weights = similarity

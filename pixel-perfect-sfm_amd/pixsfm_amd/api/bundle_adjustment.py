@@ -9,10 +9,12 @@ the Ceres solve is replaced by pxr_ba_solve on the GPU.
 `use_inner_iterations` (default True, bundle_adjustment/main.py:43) is honoured: every variable point is
 re-optimised on its own after each trust-region step (pxr_ba_inner.hip).
 """
+import ctypes as C
 from copy import deepcopy
 
 import numpy as np
 
+from .. import _lib
 from ..engine import BAProblem, lm_options, make_loss
 from . import base, features
 from .keypoint_adjustment import Summary, default_context
@@ -133,124 +135,121 @@ def linear_solver_for(num_images):
     return "ITERATIVE_SCHUR"
 
 
+def build_problem(image_camera, p2d_ptr, p2d_point3D, cam_model, n_points, track_ptr, track_image, track_p2d, in_setup, const_pose,
+                  tvec_mask, variable_point, constant_point, constant_camera, refine_focal_length=True, refine_principal_point=False,
+                  refine_extra_params=True, refine_extrinsics=True, min_track_length=-1, has_patch=None, skip_missing_patches=False):
+    """BundleOptimizer::SetUp + Parameterize* on a flat scene -- native host code (pxr_ba_build_problem, csrc/pxr_ba_setup.cpp;
+    arrays as documented in include/pixsfm_hip.h).  Returns a dict: obs_image / obs_p2d / obs_point (scene ids, ordered by point
+    and inside a point like its track), image_in_problem, pose_const, tvec_mask, camera_mask (-1 = not in the problem),
+    point_role (-1 / 0 variable / 1 constant)."""
+    lib = _lib.load()
+    a = lambda x, dt: np.ascontiguousarray(x, dtype=dt)
+    image_camera, p2d_ptr, p2d_point3D = a(image_camera, np.int32), a(p2d_ptr, np.int64), a(p2d_point3D, np.int64)
+    cam_model, track_ptr, track_image, track_p2d = a(cam_model, np.int32), a(track_ptr, np.int64), a(track_image, np.int32), a(track_p2d, np.int32)
+    in_setup, const_pose, tvec_mask = a(in_setup, np.uint8), a(const_pose, np.uint8), a(tvec_mask, np.uint8)
+    variable_point, constant_point, constant_camera = a(variable_point, np.uint8), a(constant_point, np.uint8), a(constant_camera, np.uint8)
+    hp = None if has_patch is None else a(has_patch, np.uint8)
+    n_img, n_cam, n_p2d = len(image_camera), len(cam_model), len(p2d_point3D)
+    o_img, o_p2d, o_pt = np.empty(n_p2d, np.int32), np.empty(n_p2d, np.int32), np.empty(n_p2d, np.int64)
+    in_prob, pose_c, tm = np.empty(n_img, np.uint8), np.empty(n_img, np.uint8), np.empty(n_img, np.uint8)
+    cmask, role = np.empty(n_cam, np.int32), np.empty(int(n_points), np.int8)
+    n = C.c_int64()
+    p = lambda x: None if x is None else x.ctypes.data
+    _lib.check(lib.pxr_ba_build_problem(n_img, p(image_camera), p(p2d_ptr), p(p2d_point3D), n_cam, p(cam_model), int(n_points), p(track_ptr),
+                                        p(track_image), p(track_p2d), p(hp), p(in_setup), p(const_pose), p(tvec_mask), p(variable_point),
+                                        p(constant_point), p(constant_camera), int(bool(refine_focal_length)), int(bool(refine_principal_point)),
+                                        int(bool(refine_extra_params)), int(bool(refine_extrinsics)), int(min_track_length),
+                                        int(bool(skip_missing_patches)), C.byref(n), p(o_img), p(o_p2d), p(o_pt), p(in_prob), p(pose_c), p(tm),
+                                        p(cmask), p(role)), "pxr_ba_build_problem")
+    k = n.value
+    return dict(obs_image=o_img[:k], obs_p2d=o_p2d[:k], obs_point=o_pt[:k], image_in_problem=in_prob, pose_const=pose_c, tvec_mask=tm,
+                camera_mask=cmask, point_role=role)
+
+
 class _FlatBA:
-    """Flat arrays of the residual blocks BundleOptimizer::SetUp would add (bundle_optimizer.h:139-165):
-    AddImageToProblem for every image of the setup, AddPointToProblem for the extra variable / constant
-    points (observations in images outside the setup get a constant pose, :299-333)."""
+    """Flat arrays of the residual blocks BundleOptimizer::SetUp would add (bundle_optimizer.h:139-165) and of the
+    parameterisation (:335-453).  The walk over the scene is native host code (build_problem -> pxr_ba_build_problem); this
+    class dumps the pycolmap-style objects into the flat scene arrays it takes and compacts its answer into the arrays of
+    pxr_ba_view (images / cameras / points that take part, in ascending id)."""
 
     def __init__(self, reconstruction, setup, feature_view, options=None, point_filter=None, extractor=False):
         """extractor=True: the read-only use by ReferenceExtractor / CostMapExtractor -- the reconstruction is const
         there (no NormalizeQvec; the rotation normalises q itself) and an observation without a patch is skipped like
         GetVisibleObservations does (reference_extractor.h:171-213).  extractor=False: the optimiser's SetUp, where a
         missing patch is an error (feature_view.GetFeaturePatch / references.at throw,
-        feature_reference_bundle_optimizer.h:100-108)."""
+        feature_reference_bundle_optimizer.h:100-108).  point_filter: only these points' observations are walked."""
         rec = reconstruction
         opt = options or {}
-        min_track_length = opt.get('min_track_length', -1)
-        refine_extrinsics = opt.get('refine_extrinsics', True)
-        self.image_ids, self.camera_ids, self.point_ids = [], [], []
-        img_idx, cam_idx, pt_idx = {}, {}, {}
-        obs_image, obs_point, patches, self.obs_keys = [], [], [], []
-        reg_count = {}
-
-        def idx_of(table, lst, key):
-            if key not in table:
-                table[key] = len(lst)
-                lst.append(key)
-            return table[key]
-
-        def add_obs(image_id, p2d_idx, point3D_id):
-            im = rec.images[image_id]
-            if not feature_view.has_fpatch(image_id, p2d_idx):
-                if extractor:
-                    return
-                raise ValueError("no feature patch for observation (image %d, point2D %d) of point3D %d"
-                                 % (image_id, p2d_idx, point3D_id))
-            obs_image.append(idx_of(img_idx, self.image_ids, image_id))
-            idx_of(cam_idx, self.camera_ids, im.camera_id)
-            obs_point.append(idx_of(pt_idx, self.point_ids, point3D_id))
-            patches.append(feature_view.fpatch(image_id, p2d_idx))
-            self.obs_keys.append((image_id, p2d_idx))
-            reg_count[point3D_id] = reg_count.get(point3D_id, 0) + 1
-
-        for image_id in sorted(setup.image_ids):                          # AddImageToProblem, :247-275
-            im = rec.images[image_id]
-            if not extractor:
-                im.qvec = np.asarray(im.qvec, dtype=np.float64) / np.linalg.norm(im.qvec)  # NormalizeQvec :255
-            for p2d_idx, p2d in enumerate(im.points2D):
-                if not p2d.has_point3D():
-                    continue
-                if point_filter is not None and p2d.point3D_id not in point_filter:
-                    continue
-                if rec.points3D[p2d.point3D_id].track.length() < min_track_length:
-                    continue
-                add_obs(image_id, p2d_idx, p2d.point3D_id)
-        self.outside_images = set()
-        for pid in list(sorted(setup.variable_points)) + list(sorted(setup.constant_points)):   # AddPointToProblem
-            p = rec.points3D[pid]
-            if reg_count.get(pid, 0) == p.track.length():
-                continue
-            for el in p.track.elements:
-                if setup.has_image(el.image_id):
-                    continue
-                self.outside_images.add(el.image_id)
-                add_obs(el.image_id, el.point2D_idx, pid)
-        # Observation order: point-major, and inside a point the order of Track().Elements() -- what
-        # ComputeReference iterates (reference_extractor.h:239-247: `distances.minCoeff(&ref_idx)` = FIRST minimum in
-        # track order, Reference.observations in track order).  Point-major is also what the residual kernel wants:
-        # consecutive observations share their reference descriptor in L2.
-        track_pos = {}
-        for pid in self.point_ids:
-            for k, el in enumerate(rec.points3D[pid].track.elements):
-                track_pos.setdefault((pid, el.image_id, el.point2D_idx), k)
-        rank = np.array([track_pos.get((self.point_ids[pt], im, p2d), 1 << 30)
-                         for pt, (im, p2d) in zip(obs_point, self.obs_keys)], dtype=np.int64)
-        order = np.lexsort((rank, np.array(obs_point, dtype=np.int64))) if obs_point else np.zeros(0, np.int64)
-        self.obs_image = np.array(obs_image, np.int32)[order]
-        self.obs_point = np.array(obs_point, np.int32)[order]
-        self.patches = [patches[i] for i in order]
-        self.obs_keys = [self.obs_keys[i] for i in order]
-        n_img, n_cam, n_pt = len(self.image_ids), len(self.camera_ids), len(self.point_ids)
-        self.image_camera = np.array([cam_idx[rec.images[i].camera_id] for i in self.image_ids], np.int32)
-        self.qvec = np.array([rec.images[i].qvec for i in self.image_ids], np.float64).reshape(n_img, 4)
-        self.tvec = np.array([rec.images[i].tvec for i in self.image_ids], np.float64).reshape(n_img, 3)
-        self.cam_model = np.array([rec.cameras[c].model_id for c in self.camera_ids], np.int32)
-        self.cam_params = np.zeros((n_cam, 12))
+        img_ids, cam_ids, pt_ids = sorted(rec.images), sorted(rec.cameras), sorted(rec.points3D)
+        img_of = {i: k for k, i in enumerate(img_ids)}
+        cam_of = {c: k for k, c in enumerate(cam_ids)}
+        pt_of = {p: k for k, p in enumerate(pt_ids)}
+        image_camera = np.array([cam_of[rec.images[i].camera_id] for i in img_ids], np.int32)
+        counts = [len(rec.images[i].points2D) for i in img_ids]
+        p2d_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        filt = None if point_filter is None else set(point_filter)
+        p2d_point3D = np.array([pt_of[q.point3D_id] if (q.has_point3D() and (filt is None or q.point3D_id in filt)) else -1
+                                for i in img_ids for q in rec.images[i].points2D], np.int64).reshape(-1)
+        tl = [rec.points3D[p].track.length() for p in pt_ids]
+        track_ptr = np.concatenate([[0], np.cumsum(tl)]).astype(np.int64)
+        track_image = np.array([img_of[e.image_id] for p in pt_ids for e in rec.points3D[p].track.elements], np.int32).reshape(-1)
+        track_p2d = np.array([e.point2D_idx for p in pt_ids for e in rec.points3D[p].track.elements], np.int32).reshape(-1)
+        n_img, n_cam, n_pt = len(img_ids), len(cam_ids), len(pt_ids)
+        in_setup = np.array([setup.has_image(i) for i in img_ids], np.uint8)
+        const_pose = np.array([setup.has_constant_pose(i) for i in img_ids], np.uint8)
+        tvm = np.array([sum(1 << a for a in setup.constant_tvec(i)) if setup.has_constant_tvec(i) else 0 for i in img_ids], np.uint8)
+        var_pt = np.zeros(n_pt, np.uint8); const_pt = np.zeros(n_pt, np.uint8)
+        for p in setup.variable_points:
+            var_pt[pt_of[p]] = 1
+        for p in setup.constant_points:
+            const_pt[pt_of[p]] = 1
+        const_cam = np.array([setup.is_constant_camera(c) for c in cam_ids], np.uint8)
+        cam_model = np.array([rec.cameras[c].model_id for c in cam_ids], np.int32)
+        # which observations have a feature patch (only those that can enter the problem are asked)
+        has_patch = np.ones(len(p2d_point3D), np.uint8)
+        for k, i in enumerate(img_ids):
+            for j in range(counts[k]):
+                if p2d_point3D[p2d_ptr[k] + j] >= 0 and not feature_view.has_fpatch(i, j):
+                    has_patch[p2d_ptr[k] + j] = 0
+        try:
+            r = build_problem(image_camera, p2d_ptr, p2d_point3D, cam_model, n_pt, track_ptr, track_image, track_p2d, in_setup, const_pose, tvm,
+                              var_pt, const_pt, const_cam, opt.get('refine_focal_length', True), opt.get('refine_principal_point', False),
+                              opt.get('refine_extra_params', True), opt.get('refine_extrinsics', True), opt.get('min_track_length', -1),
+                              has_patch, skip_missing_patches=extractor)
+        except _lib.PixsfmHipError as e:
+            raise ValueError(str(e).replace("pxr_ba_build_problem: ", "")) from None
+        if not extractor:                                                # NormalizeQvec in AddImageToProblem, :255
+            for i in setup.image_ids:
+                im = rec.images[i]
+                im.qvec = np.asarray(im.qvec, dtype=np.float64) / np.linalg.norm(im.qvec)
+        # ---- compact: the images / cameras / points that take part, in ascending id --------------------------------------------
+        used_img = np.flatnonzero(r["image_in_problem"])
+        used_cam = np.flatnonzero(r["camera_mask"] >= 0)
+        used_pt = np.flatnonzero(r["point_role"] >= 0)
+        img_new = np.full(n_img, -1, np.int32); img_new[used_img] = np.arange(len(used_img), dtype=np.int32)
+        cam_new = np.full(n_cam, -1, np.int32); cam_new[used_cam] = np.arange(len(used_cam), dtype=np.int32)
+        pt_new = np.full(n_pt, -1, np.int32); pt_new[used_pt] = np.arange(len(used_pt), dtype=np.int32)
+        self.image_ids = [img_ids[k] for k in used_img]
+        self.camera_ids = [cam_ids[k] for k in used_cam]
+        self.point_ids = [pt_ids[k] for k in used_pt]
+        self.outside_images = {img_ids[k] for k in used_img if not in_setup[k]}
+        self.obs_image = img_new[r["obs_image"]]
+        self.obs_point = pt_new[r["obs_point"]]
+        self.obs_keys = [(img_ids[a], int(b)) for a, b in zip(r["obs_image"].tolist(), r["obs_p2d"].tolist())]
+        self.patches = [feature_view.fpatch(i, j) for i, j in self.obs_keys]
+        n_i, n_c, n_p = len(used_img), len(used_cam), len(used_pt)
+        self.image_camera = cam_new[image_camera[used_img]]
+        self.qvec = np.array([rec.images[i].qvec for i in self.image_ids], np.float64).reshape(n_i, 4)
+        self.tvec = np.array([rec.images[i].tvec for i in self.image_ids], np.float64).reshape(n_i, 3)
+        self.cam_model = cam_model[used_cam]
+        self.cam_params = np.zeros((n_c, 12))
         for k, c in enumerate(self.camera_ids):
             self.cam_params[k, :len(rec.cameras[c].params)] = rec.cameras[c].params
-        self.xyz = np.array([rec.points3D[p].xyz for p in self.point_ids], np.float64).reshape(n_pt, 3)
-        # ---- parameterisation (Parameterize*, :335-453) ----------------------------------------------
-        self.pose_const = np.zeros(n_img, np.uint8)
-        self.tvec_mask = np.zeros(n_img, np.uint8)
-        for k, i in enumerate(self.image_ids):
-            if (not refine_extrinsics) or setup.has_constant_pose(i) or (not setup.has_image(i)):
-                self.pose_const[k] = 1
-            elif setup.has_constant_tvec(i):
-                self.tvec_mask[k] = sum(1 << a for a in setup.constant_tvec(i))
-        const_camera = not (opt.get('refine_focal_length', True) or opt.get('refine_principal_point', False)
-                            or opt.get('refine_extra_params', True))
-        cams_with_inside_obs = {rec.images[i].camera_id for i in self.image_ids if setup.has_image(i)}
-        self.cam_mask = np.zeros(n_cam, np.uint16)
-        for k, c in enumerate(self.camera_ids):
-            cam = rec.cameras[c]
-            K = CAMERA_MODELS[cam.model_id][1]
-            if const_camera or setup.is_constant_camera(c) or c not in cams_with_inside_obs:   # :320-322, :405-409
-                self.cam_mask[k] = (1 << K) - 1
-                continue
-            const = []
-            if not opt.get('refine_focal_length', True):
-                const += cam.focal_length_idxs()
-            if not opt.get('refine_principal_point', False):
-                const += cam.principal_point_idxs()
-            if not opt.get('refine_extra_params', True):
-                const += cam.extra_params_idxs()
-            self.cam_mask[k] = sum(1 << a for a in const)
-        self.point_const = np.zeros(n_pt, np.uint8)
-        for k, pid in enumerate(self.point_ids):                            # ParameterizePoints :335-364
-            tl = rec.points3D[pid].track.length()
-            need = min(min_track_length, tl) if min_track_length > 0 else tl
-            if need > reg_count.get(pid, 0) or pid in setup.constant_points:
-                self.point_const[k] = 1
+        self.xyz = np.array([rec.points3D[p].xyz for p in self.point_ids], np.float64).reshape(n_p, 3)
+        self.pose_const = r["pose_const"][used_img].astype(np.uint8)
+        self.tvec_mask = r["tvec_mask"][used_img].astype(np.uint8)
+        self.cam_mask = r["camera_mask"][used_cam].astype(np.uint16)
+        self.point_const = r["point_role"][used_pt].astype(np.uint8)
 
     def problem_dict(self, refs, patch_index=None):
         """patch_index: arena patch of each observation (features.to_arena(...).index); default 0 .. n_obs - 1."""

@@ -124,6 +124,36 @@ def test_flattened_problem_matches_the_reference_vectors():
     assert seen["tvec"] > 3 and seen["cam_partial"] > 10 and seen["cam_const"] > 5, seen
 
 
+def test_native_builder_through_the_c_abi_matches_the_reference_vectors():
+    """pxr_ba_build_problem on the flat scene arrays directly (no Python scene objects in between)."""
+    from pixsfm_amd.api.bundle_adjustment import build_problem
+    gen = _gen()
+    gold = np.load(os.path.join(HERE, "golden", "ba_setup_ref.npz"))
+    for c in gen.cases():
+        g = {k: gold[c["name"] + "_" + k] for k in ("blk_image", "blk_p2d", "image_role", "tvec_mask_out", "camera_mask", "point_role")}
+        n_img, n_pt = len(c["image_camera"]), int(c["n_points"])
+        tracks = [[] for _ in range(n_pt)]                     # Track().Elements() order = the shim's: by image, then point2D
+        for i in range(n_img):
+            for j, p in enumerate(c["p2d_point3D"][c["p2d_ptr"][i]:c["p2d_ptr"][i + 1]]):
+                if p >= 0:
+                    tracks[p].append((i, j))
+        track_ptr = np.concatenate([[0], np.cumsum([len(t) for t in tracks])]).astype(np.int64)
+        flat = [e for t in tracks for e in t]
+        r = build_problem(c["image_camera"], c["p2d_ptr"], c["p2d_point3D"], c["cam_model"], n_pt, track_ptr,
+                          [e[0] for e in flat], [e[1] for e in flat], c["in_problem"], c["const_pose"], c["tvec_mask"], c["var_point"],
+                          c["const_point"], c["const_camera"], c["refine_focal"], c["refine_pp"], c["refine_extra"], c["refine_extrinsics"],
+                          c["min_track_length"])
+        assert sorted(zip(r["obs_image"].tolist(), r["obs_p2d"].tolist())) == sorted(zip(g["blk_image"].tolist(), g["blk_p2d"].tolist())), c["name"]
+        assert np.all(np.diff(r["obs_point"]) >= 0)                                       # ordered by point
+        assert np.array_equal(r["camera_mask"], g["camera_mask"]), c["name"]
+        assert np.array_equal(r["point_role"], g["point_role"]), c["name"]
+        for i in np.flatnonzero(r["image_in_problem"]):
+            if g["image_role"][i] == 2:
+                assert r["pose_const"][i] == 0 and r["tvec_mask"][i] == g["tvec_mask_out"][i], (c["name"], i)
+            else:
+                assert r["pose_const"][i] == 1, (c["name"], i)
+
+
 def test_reference_run_live_when_present():
     gen = _gen()
     if not os.path.exists(gen.LIB):

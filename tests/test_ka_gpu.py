@@ -213,3 +213,19 @@ def test_single_channel_features(ctx, dtype):
     assert np.abs(ka.keypoints() - kpo).max() < 1e-6
     assert total["final_cost"] < total["initial_cost"]
     arena.close()
+
+
+def test_sub_problem_larger_than_the_lds_metadata_caches(ctx):
+    """One sub-problem of 270 nodes / 1350 residual blocks: the solve kernel keeps the metadata of the first 96 nodes and 512
+    blocks in LDS and reads the rest from global memory -- both paths in one solve, against the oracle."""
+    import pxo
+    import pxo_ka
+    from pixsfm_amd.engine import interp_cfg, lm_options, make_loss
+    prob, arena, ka = _setup(ctx, n_tracks=45, track_len=6, seed=77, max_kps_per_problem=100000)
+    assert prob["n_problems"] == 1 and len(prob["kp"]) > 96 and len(prob["edge_src"]) > 512
+    opts = dict(max_iterations=6, parameter_tolerance=1e-5)
+    total, per = ka.solve(interp_cfg(), make_loss("cauchy", [0.25]), bound=4.0, per_problem=True, options=lm_options(**opts))
+    kpo, sums = pxo_ka.ka_solve(prob, pxo.cfg(), pxo.loss("cauchy", 0.25), 4.0, pxo.lm_options(**opts))
+    assert per[0]["iterations"] == sums[0]["iterations"] and per[0]["num_successful"] == sums[0]["num_successful"]
+    assert abs(per[0]["final_cost"] - sums[0]["final_cost"]) < 1e-8 * sums[0]["final_cost"]
+    assert np.abs(ka.keypoints() - kpo).max() < 1e-6

@@ -77,8 +77,9 @@ for trial in range(n_trials):
             sg["initial_cost"], sg["final_cost"], so["iterations"], so["num_successful"], so["termination"], so["initial_cost"], so["final_cost"], err))
     arena.close()
     # ---- KA ----
-    kprob = synthetic_ka.make_ka_problem(n_tracks=int(rng.integers(3, 12)), track_len=int(rng.integers(2, 7)), seed=int(rng.integers(1 << 30)),
-                                         dtype=dt, channels=ch, sigma=float(rng.uniform(0.3, 1.5)), max_kps_per_problem=int(rng.integers(6, 40)),
+    big = rng.integers(4) == 0          # one large sub-problem: beyond the solve kernel's LDS metadata caches (96 nodes / 512 blocks)
+    kprob = synthetic_ka.make_ka_problem(n_tracks=int(rng.integers(30, 60)) if big else int(rng.integers(3, 12)), track_len=int(rng.integers(2, 7)), seed=int(rng.integers(1 << 30)),
+                                         dtype=dt, channels=ch, sigma=float(rng.uniform(0.3, 1.5)), max_kps_per_problem=100000 if big else int(rng.integers(6, 40)),
                                          scale=(1.0, 1.0) if rng.integers(2) else (0.5, 0.25))
     kprob["node_const"] = np.where(rng.random(len(kprob["kp"])) < 0.2, 1, kprob["node_const"]).astype(np.uint8)
     kprob["edge_w"] = rng.uniform(0.2, 1.0, len(kprob["edge_w"]))

@@ -228,11 +228,11 @@ class FeatureMetricKeypointOptimizer:
 
 
 class TopologicalReferenceKeypointOptimizer(FeatureMetricKeypointOptimizer):
-    """Option preset (topological_reference_keypoint_optimizer.h:8-15): star graph to the root."""
+    """Option preset (topological_reference_keypoint_optimizer.h:8-15): star graph to the root.  The three values are the
+    DEFAULTS of its Options struct -- keys the caller sets explicitly still win, as they do through the pybind constructor."""
 
     def __init__(self, options=None, setup=None, interpolation_config=None, ctx=None):
-        options = dict(options or {})
-        options.update(weight_by_sim=False, root_regularize_weight=1.0, root_edges_only=True)
+        options = {'weight_by_sim': False, 'root_regularize_weight': 1.0, 'root_edges_only': True, **dict(options or {})}
         super().__init__(options, setup, interpolation_config, ctx)
 
 

@@ -672,8 +672,7 @@ class CostMapBundleAdjuster(BundleAdjuster):
         **deepcopy(BundleAdjuster.default_conf),
         'costmaps': {'loss': {'name': 'trivial', 'params': []}, 'as_gradientfield': True,
                      'compute_cross_derivative': False, 'num_threads': -1},
-        'strategy': 'costmaps',
-    }
+    }   # ('strategy' stays the inherited 'feature_reference', like in the reference: the key only steers create())
 
     def __init__(self, conf):
         self.conf = base.merge_adjuster_conf(self.default_conf, conf)

@@ -123,13 +123,13 @@ def _write_dataset(loc, name, data, chunks=None):
     return d
 
 
-def write_featuremap_cache(group, keypoint_ids, patches, corners, scales, metadata, cache_format="chunked"):
-    """store_features.py:74-91."""
+def write_featuremap_cache(group, keypoint_ids, patches, corners, scales, metadata, cache_format="chunked", format_override=None):
+    """store_features.py:74-91.  format_override: write another value into the "format" attribute (malformed-file tests)."""
     lib = _lib()
     assert "is_sparse" in metadata
     keypoint_ids = [int(k) for k in keypoint_ids]
     if cache_format == "chunked":                                # :42-71
-        _write_attr(group, "format", 2)
+        _write_attr(group, "format", 2 if format_override is None else format_override)
         for k, v in metadata.items():
             _write_attr(group, k, int(v) if k == "is_sparse" else v)
         chunks = [1, *patches.shape[1:]]
@@ -141,7 +141,7 @@ def write_featuremap_cache(group, keypoint_ids, patches, corners, scales, metada
         lib.H5Dclose(_write_dataset(group, "scales", np.asarray(scales, np.float64)))
     elif cache_format == "grouped":                              # :17-39
         _write_attr(group, "shape", list(patches.shape[1:]))
-        _write_attr(group, "format", 1)
+        _write_attr(group, "format", 1 if format_override is None else format_override)
         for k, v in metadata.items():
             _write_attr(group, k, int(v) if k == "is_sparse" else v)
         for i, pid in enumerate(keypoint_ids):                   # write_patch_cache, :5-14
@@ -153,13 +153,13 @@ def write_featuremap_cache(group, keypoint_ids, patches, corners, scales, metada
         raise RuntimeError("Unknown cache_format %s to write." % cache_format)
 
 
-def write_cache(path, levels, dtype_name="half", cache_format="chunked", level_prefix=""):
+def write_cache(path, levels, dtype_name="half", cache_format="chunked", level_prefix="", channels_per_level=None, format_override=None):
     """extract.py:98-127.  levels: list (one entry per feature level) of {image name: dict(keypoint_ids, patches,
-    corners, scales, metadata)}."""
+    corners, scales, metadata)}.  channels_per_level / format_override: deliberately inconsistent files for the error tests."""
     lib = _lib()
     f = _check(lib.H5Fcreate(str(path).encode(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT), "H5Fcreate")
     channels = [next(iter(level.values()))["patches"].shape[-1] for level in levels]
-    _write_attr(f, "channels_per_level", channels)
+    _write_attr(f, "channels_per_level", channels if channels_per_level is None else channels_per_level)
     _write_attr(f, "dtype", dtype_name)
     lcpl = lib.H5Pcreate(_g("H5P_CLS_LINK_CREATE_ID_g"))
     lib.H5Pset_create_intermediate_group(lcpl, 1)                # h5py creates the parents of "dir/im.jpg" too
@@ -167,7 +167,7 @@ def write_cache(path, levels, dtype_name="half", cache_format="chunked", level_p
         lg = _check(lib.H5Gcreate2(f, (level_prefix + str(l)).encode(), H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT), "H5Gcreate2")
         for image_name, fm in level.items():
             g = _check(lib.H5Gcreate2(lg, image_name.encode(), lcpl, H5P_DEFAULT, H5P_DEFAULT), "H5Gcreate2 " + image_name)
-            write_featuremap_cache(g, fm["keypoint_ids"], fm["patches"], fm["corners"], fm["scales"], fm["metadata"], cache_format)
+            write_featuremap_cache(g, fm["keypoint_ids"], fm["patches"], fm["corners"], fm["scales"], fm["metadata"], cache_format, format_override)
             lib.H5Gclose(g)
         lib.H5Gclose(lg)
     lib.H5Pclose(lcpl)

@@ -49,6 +49,9 @@ class Image {
   std::vector<class Point2D>& Points2D() { return points2D_; }
   Eigen::Vector4d& Qvec() { return qvec_; }
   Eigen::Vector3d& Tvec() { return tvec_; }
+  const Eigen::Vector4d& Qvec() const { return qvec_; }
+  const Eigen::Vector3d& Tvec() const { return tvec_; }
+  Eigen::Matrix3d RotationMatrix() const { Eigen::stub_unreachable("Image::RotationMatrix"); }
   const std::string& Name() const { return name_; }
   Eigen::Matrix<double, 3, 4> ProjectionMatrix() const { return Eigen::Matrix<double, 3, 4>(); }
  private:

@@ -2,6 +2,8 @@
 // restated from their published definitions ([upstream COLMAP 3.8] src/base/camera_models.h).  NOT reference code: parity
 // of a projection rests on this stub as far as the camera model itself goes (SURVEY 8a row A6 stays unpinned).
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <cstddef>
 #include <vector>
 namespace colmap {
@@ -64,6 +66,7 @@ class Camera {
   size_t NumParams() const { return params_.size(); }
   void SetModelId(int m) { model_ = m; }
   void SetParams(const std::vector<double>& p) { params_ = p; }
+  template <typename V> V ImageToWorld(const V&) const { std::fprintf(stderr, "colmap stub: Camera::ImageToWorld is not available\n"); std::abort(); }
   // [upstream COLMAP 3.8 camera_models.h] parameter groups: focal length(s), principal point, extra (distortion) parameters
   std::vector<size_t> FocalLengthIdxs() const { return (model_ == 1 || model_ == 4) ? std::vector<size_t>{0, 1} : std::vector<size_t>{0}; }
   std::vector<size_t> PrincipalPointIdxs() const { return (model_ == 1 || model_ == 4) ? std::vector<size_t>{2, 3} : std::vector<size_t>{1, 2}; }

@@ -40,6 +40,10 @@ class FeatureView {
     calls.emplace_back(image_id, idx);
     return maps.at(image_id).GetFeaturePatch(idx);
   }
+  bool HasFeaturePatch(colmap::image_t image_id, colmap::point2D_t idx) const {
+    auto it = maps.find(image_id);
+    return it != maps.end() && it->second.patches.count(idx) > 0;
+  }
   std::vector<std::pair<colmap::image_t, colmap::point2D_t>> calls;
   std::map<colmap::image_t, FeatureMap<dtype>> maps;
 };

@@ -207,14 +207,32 @@ def main():
         from pixsfm_amd import parallel
         collective = "torch.distributed callback (%s)" % backend
         if backend == "nccl" and os.environ.get("PXR_BENCH_CALLBACK") != "1":
+            ok = 1
             try:
                 if world > 1:
                     parallel.init_native_comm(ctx)
                 else:
                     ctx.comm_init(Context.comm_unique_id(), 0, 1)
-                collective = "native ncclAllReduce on the engine's stream (pxr_comm_init)"
+                probe = ctx.to_device(np.full(4, float(rank + 1)), np.float64)      # one real all-reduce before relying on it
+                ctx.allreduce_sum(probe)
+                ctx.sync()
+                if not np.array_equal(probe.download(), np.full(4, world * (world + 1) / 2.0)):
+                    raise RuntimeError("native all-reduce returned %r" % (probe.download(),))
             except Exception as e:  # noqa: BLE001 -- keep the bench alive on the callback path
-                print("native communicator unavailable (%r): using the torch.distributed callback" % (e,), file=sys.stderr)
+                ok = 0
+                print("rank %d: native communicator unavailable (%r)" % (rank, e), file=sys.stderr)
+            # every rank must take the same path: one rank on the callback while the others wait in ncclAllReduce would hang
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                collective = "native ncclAllReduce on the engine's stream (pxr_comm_init)"
+            else:
+                if ok:
+                    ctx.comm_destroy()
+                if world > 1:
+                    ctx.comm_set_rank(rank, world)
+                if rank == 0:
+                    print("using the torch.distributed callback on every rank", file=sys.stderr)
     arena = PatchArena(ctx, n_obs_local, PS, PS, C, np.float16, device_ptr=patches.data_ptr())
     arena.upload(0, None, prob["corners"], prob["scales"])
     ba = BAProblem(ctx, arena, prob)

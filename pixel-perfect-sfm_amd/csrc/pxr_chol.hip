@@ -9,7 +9,7 @@
 // a right-looking Cholesky that treats row n like any other sub-diagonal row performs the forward
 // substitution L y = b for free (row n of the factor is y^T).
 //   k_chol_panel   every workgroup factors the 64x64 diagonal block AND inverts its triangular
-//                  factor in one 64-step sweep on 4x4 register tiles (one barrier per step, finished
+//                  factor in one sweep over column PAIRS on 4x4 register tiles (one barrier per pair, finished
 //                  columns of L / rows of inv(L) exported to LDS so the updates need no masks);
 //                  WG 0 writes L_kk and inv(L_kk) back, WG b >= 1 computes its 128 panel rows
 //                  X = B inv(L_kk)^T as an LDS-tiled GEMM (8x4 register micro-tiles).
@@ -28,12 +28,22 @@ constexpr int PROWS = 128;   // panel rows per workgroup in the TRSM part
 // n_rows = rows of the (augmented) matrix, n_cols = columns to factor, k = first column of the panel.
 __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ a, int n_rows, int n_cols, int lda, int k,
                                                     int* __restrict__ info, double* __restrict__ linv_out) {
-  __shared__ double Lt[CNB][CNB];         // Lt[m][j] = inv(L_kk)[j][m]
+  __shared__ double Lt[CNB][CNB + 2];     // Lt[m][j] = inv(L_kk)[j][m]; padded: a column write touches 16 rows, one bank group each
   __shared__ double Bs[CNB][PROWS];       // panel tile, Bs[m][row]
-  __shared__ double colb[2][CNB], rowb[2][CNB];
+  __shared__ double cola[2][CNB], colc[2][CNB], rowa[2][CNB], rowc[2][CNB];
   const int tid = threadIdx.x;
   const int ti = tid >> 4, tj = tid & 15;
   const int nb = min(CNB, n_cols - k);
+#ifdef PXR_CHOL_PROFILE   // -DPXR_CHOL_PROFILE: workgroups 0 and 1 of the first panel print their phase times (100 MHz ticks)
+  long long cp_t[6], cp_c[6]; int cp_n = 0;
+  __shared__ long long cp_pair[33];
+#define CHOL_PAIR() do { if (tid == 255) cp_pair[j >> 1] = clock64(); } while (0)   // thread 255: last wavefront, live to the end
+#define CHOL_T() do { if (tid == 0) { cp_c[cp_n] = clock64(); cp_t[cp_n++] = wall_clock64(); } } while (0)
+  CHOL_T();
+#else
+#define CHOL_T() do { } while (0)
+#define CHOL_PAIR() do { } while (0)
+#endif
   const bool is_panel_wg = blockIdx.x > 0;
   const int r0 = k + nb + ((int)blockIdx.x - 1) * PROWS;
   // issue the panel-tile loads first: they fly while the diagonal block is factored
@@ -57,61 +67,91 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ a, int 
       Xt[u][w] = (R == Cc) ? 1.0 : 0.0;
     }
   int bad = 0;
-  // 64-step sweep:  L[i][j] = D[i][j] / sqrt(D[j][j]);  D[i][c] -= L[i][j] L[c][j];
-  //                 X[j][:] /= L[j][j];  X[i][:] -= L[i][j] X[j][:]      (X: I -> inv(L))
-#pragma unroll 4
-  for (int j = 0; j < CNB; ++j) {
-    const int jb = j >> 2, jo = j & 3, buf = j & 1;
-    if (tj == jb) {                                          // owners of column j of D
+  CHOL_T();
+  // 32-step sweep over column PAIRS (j, j+1), one barrier per pair:
+  //   L[:,j]   = D[:,j] / sqrt(D[j][j]);
+  //   L[:,j+1] = (D[:,j+1] - L[:,j] L[j+1][j]) / sqrt(D[j+1][j+1] - L[j+1][j]^2);
+  //   D       -= L[:,j] L[:,j]^T + L[:,j+1] L[:,j+1]^T;
+  //   X[j]    /= L[j][j];  X[j+1] = (X[j+1] - L[j+1][j] X[j]) / L[j+1][j+1];  X -= L[:,j] X[j] + L[:,j+1] X[j+1]   (X: I -> inv(L))
+#pragma unroll 2
+  for (int j = 0; j < CNB; j += 2) {
+    const int jb = j >> 2, jo = j & 3, buf = (j >> 1) & 1;   // jo is 0 or 2: both columns sit in the same 4-wide tile
+    // a wavefront holds the tile rows 4 w .. 4 w + 3: once they are all finished (rows < j) it has nothing left to
+    // export or update and only keeps the barrier company -- the sweep is bound by the LDS reads of the live ones
+    const bool live = 4 * (tid >> 6) + 3 >= jb;
+    CHOL_PAIR();
+    if (live && tj == jb) {                                  // owners of columns j, j+1 of D
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        double v = Dt[u][0];
-        if (jo == 1) v = Dt[u][1]; else if (jo == 2) v = Dt[u][2]; else if (jo == 3) v = Dt[u][3];
-        colb[buf][4 * ti + u] = v;
+        cola[buf][4 * ti + u] = jo == 0 ? Dt[u][0] : Dt[u][2];
+        colc[buf][4 * ti + u] = jo == 0 ? Dt[u][1] : Dt[u][3];
       }
     }
-    if (ti == jb) {                                          // owners of row j of X
+    if (ti == jb) {                                          // owners of rows j, j+1 of X
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        double v = Xt[0][w];
-        if (jo == 1) v = Xt[1][w]; else if (jo == 2) v = Xt[2][w]; else if (jo == 3) v = Xt[3][w];
-        rowb[buf][4 * tj + w] = v;
+        rowa[buf][4 * tj + w] = jo == 0 ? Xt[0][w] : Xt[2][w];
+        rowc[buf][4 * tj + w] = jo == 0 ? Xt[1][w] : Xt[3][w];
       }
     }
     __syncthreads();
-    // all 13 LDS reads are issued unconditionally, back to back (one wait), and masked in registers:
-    // conditional loads made the compiler emit a branch + wait per value (13 serialized LDS round trips)
-    const double djj = colb[buf][j];
-    double cu[4], cw[4], rw[4];
+    if (live) {
+      // all LDS reads are issued unconditionally, back to back (one wait), and masked in registers:
+      // conditional loads made the compiler emit a branch + wait per value
+      const double d00 = cola[buf][j], d10 = cola[buf][j + 1], d11 = colc[buf][j + 1];
+      double ua[4], wa[4], uc[4], wc[4], ra[4], rc[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { cu[u] = colb[buf][4 * ti + u]; cw[u] = colb[buf][4 * tj + u]; rw[u] = rowb[buf][4 * tj + u]; }
-    if (!(djj > 0.0) && bad == 0) bad = j + 1;
-    const double inv = djj > 0.0 ? rsqrt(djj) : 1.0;
-    // No masks: once column j of L and row j of inv(L) have been exported to LDS (below), the
-    // register entries of finished rows / columns are dead -- they are never read again, so the
-    // rank-1 updates may overwrite them with garbage.
-    double li[4], lc[4], xr[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { li[u] = cu[u] * inv; lc[u] = cw[u] * inv; xr[u] = rw[u] * inv; }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        Dt[u][w] = fma(-li[u], lc[w], Dt[u][w]);
-        Xt[u][w] = fma(-li[u], xr[w], Xt[u][w]);
+      for (int u = 0; u < 4; ++u) {
+        ua[u] = cola[buf][4 * ti + u]; wa[u] = cola[buf][4 * tj + u];
+        uc[u] = colc[buf][4 * ti + u]; wc[u] = colc[buf][4 * tj + u];
+        ra[u] = rowa[buf][4 * tj + u]; rc[u] = rowc[buf][4 * tj + u];
       }
-    if (tj == jb && !is_panel_wg) {                          // column j of L (rows >= j are meaningful)
+      // the two pivots from INDEPENDENT reciprocal square roots:  1 / sqrt(d11 - d10^2 / d00) = sqrt(d00) / sqrt(d00 d11 - d10^2)
+      const double det = fma(d00, d11, -(d10 * d10));
+      if (!(d00 > 0.0) && bad == 0) bad = j + 1;
+      if (!(det > 0.0) && bad == 0) bad = j + 2;
+      const double inv0 = d00 > 0.0 ? rsqrt(d00) : 1.0;
+      const double rdet = det > 0.0 ? rsqrt(det) : 1.0;
+      const double l10 = d10 * inv0;
+      const double inv1 = det > 0.0 ? rdet * (d00 * inv0) : 1.0;
+      // No masks: once columns j, j+1 of L and rows j, j+1 of inv(L) have been exported to LDS (below), the
+      // register entries of finished rows / columns are dead -- they are never read again, so the
+      // rank-2 updates may overwrite them with garbage.
+      double lia[4], lca[4], xra[4], lic[4], lcc[4], xrc[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) Bs[j][4 * ti + u] = li[u];
-    }
-    if (ti == jb) {                                          // row j of inv(L): Lt[m][j] = inv(L)[j][m], zero for m > j
+      for (int u = 0; u < 4; ++u) {
+        lia[u] = ua[u] * inv0; lca[u] = wa[u] * inv0; xra[u] = ra[u] * inv0;
+        lic[u] = fma(-lia[u], l10, uc[u]) * inv1;
+        lcc[u] = fma(-lca[u], l10, wc[u]) * inv1;
+        xrc[u] = fma(-l10, xra[u], rc[u]) * inv1;
+      }
 #pragma unroll
-      for (int w = 0; w < 4; ++w) Lt[4 * tj + w][j] = (4 * tj + w <= j) ? xr[w] : 0.0;
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          Dt[u][w] = fma(-lic[u], lcc[w], fma(-lia[u], lca[w], Dt[u][w]));
+          Xt[u][w] = fma(-lic[u], xrc[w], fma(-lia[u], xra[w], Xt[u][w]));
+        }
+      if (tj == jb && !is_panel_wg) {                        // columns j, j+1 of L (rows >= j / j+1 are meaningful)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { Bs[j][4 * ti + u] = lia[u]; Bs[j + 1][4 * ti + u] = lic[u]; }
+      }
+      if (ti == jb) {                                        // rows j, j+1 of inv(L): Lt[m][j] = inv(L)[j][m], zero for m > j
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          Lt[4 * tj + w][j] = (4 * tj + w <= j) ? xra[w] : 0.0;
+          Lt[4 * tj + w][j + 1] = (4 * tj + w <= j + 1) ? xrc[w] : 0.0;
+        }
+      }
     }
   }
+#ifdef PXR_CHOL_PROFILE
+  if (tid == 255) cp_pair[32] = clock64();
+#endif
   __syncthreads();
+  CHOL_T();
   if (!is_panel_wg) {
-    if (bad && bad <= nb && tid == 0) atomicCAS(info, 0, k + bad);
+    if (bad && bad <= nb && tid == 255) atomicCAS(info, 0, k + bad);   // the last wavefront is live (and tracks `bad`) to the end
     double* lo = linv_out + (size_t)(k / CNB) * CNB * CNB;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -121,6 +161,15 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ a, int 
         if (R < nb && Cc < nb && R >= Cc) a[(size_t)(k + R) + (size_t)(k + Cc) * lda] = Bs[Cc][R];
         lo[R * CNB + Cc] = Lt[Cc][R];                        // inv(L_kk), row-major
       }
+#ifdef PXR_CHOL_PROFILE
+    CHOL_T();
+    if (tid == 0 && k == 0) printf("chol panel wg0: loads %lld sweep %lld writeback %lld (x10 ns); sweep %lld shader cycles\n", cp_t[1] - cp_t[0], cp_t[2] - cp_t[1], cp_t[3] - cp_t[2], cp_c[2] - cp_c[1]);
+    if (tid == 0 && k == 0) {
+      printf("chol pairs (cycles):");
+      for (int q = 0; q < 32; ++q) printf(" %lld", cp_pair[q + 1] - cp_pair[q]);
+      printf("\n");
+    }
+#endif
     return;
   }
 #pragma unroll
@@ -129,6 +178,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ a, int 
     Bs[e / PROWS][e % PROWS] = breg[q];
   }
   __syncthreads();
+  CHOL_T();
   // X = B inv(L)^T for this workgroup's PROWS rows: x[row][j] = sum_m Bs[m][row] Lt[m][j]
   const int tx = tid & 15, ty = tid >> 4;   // ty: 8 rows, tx: 4 columns
   double acc[8][4];
@@ -148,6 +198,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ a, int 
 #pragma unroll
       for (int w = 0; w < 4; ++w) acc[u][w] = fma(bv[u], lv[w], acc[u][w]);
   }
+  CHOL_T();
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
     const int j = 4 * tx + w;
@@ -158,6 +209,12 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ a, int 
       if (r < n_rows) a[(size_t)r + (size_t)(k + j) * lda] = acc[u][w];
     }
   }
+#ifdef PXR_CHOL_PROFILE
+  CHOL_T();
+  if (tid == 0 && k == 0 && blockIdx.x == 1)
+    printf("chol panel wg1: loads %lld sweep %lld stage %lld gemm %lld store %lld (x10 ns)\n", cp_t[1] - cp_t[0], cp_t[2] - cp_t[1], cp_t[3] - cp_t[2],
+           cp_t[4] - cp_t[3], cp_t[5] - cp_t[4]);
+#endif
 }
 
 // A22 -= P P^T on 64 x 64 tiles (lower tiles only); P = A(k+nb : n_rows, k : k+nb).  The one GEMM-shaped

@@ -26,10 +26,21 @@ def test_spd_solve_matches_numpy(ctx, n):
     assert np.abs(L @ L.T - A).max() < 1e-10 * np.abs(A).max()
 
 
-def test_not_positive_definite_is_reported(ctx):
+@pytest.mark.parametrize("pivot", [70, 71, 0, 63, 64, 99])      # the panel sweeps column PAIRS: first and second of a pair
+def test_not_positive_definite_is_reported(ctx, pivot):
     n = 100
-    A = np.eye(n); A[70, 70] = -1.0
+    A = np.eye(n); A[pivot, pivot] = -1.0
     dA, db = ctx.to_device(A), ctx.to_device(np.ones(n))
     info = C.c_int(0)
     ctx.lib.pxr_dense_spd_solve(ctx.handle, dA.ptr, n, db.ptr, C.byref(info))
-    assert info.value == 71
+    assert info.value == pivot + 1
+
+
+def test_pivot_that_turns_negative_only_after_elimination(ctx):
+    """positive diagonal, indefinite matrix: the failing pivot is the SECOND column of a pair (d11 - l10^2 <= 0)"""
+    n = 40
+    A = np.eye(n); A[6, 7] = A[7, 6] = 2.0
+    dA, db = ctx.to_device(np.triu(A)), ctx.to_device(np.ones(n))
+    info = C.c_int(0)
+    ctx.lib.pxr_dense_spd_solve(ctx.handle, dA.ptr, n, db.ptr, C.byref(info))
+    assert info.value == 8

@@ -44,13 +44,25 @@ class BaBatch(C.Structure):
                 ("corners", C.c_void_p), ("scales", C.c_void_p), ("upsampling", C.c_double)]
 
 
+def _newest(paths):
+    return max((os.path.getmtime(p) for p in paths), default=0.0)
+
+
 def build(force=False):
-    """Compile liboracle.so (and _ref when /root/reference is present)."""
+    """Compile liboracle.so, and the in-place builds of the reference under _ref/ when /root/reference is present and one of
+    them is missing or older than the shim sources / stub headers (oracle/Makefile)."""
     so = os.path.join(HERE, "liboracle.so")
-    srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".c", ".h", ".cc"))]
-    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
-    if force or stale:
-        subprocess.check_call(["make", "-C", HERE, "-s"], stdout=subprocess.DEVNULL)
+    srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(so) or _newest(srcs) > os.path.getmtime(so):
+        subprocess.check_call(["make", "-C", HERE, "-s", "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/pixsfm"):
+        shims = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.startswith("ref_") and f.endswith(".cc")]
+        stubs = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(HERE, "ref_stubs")) for f in fs]
+        ref_dir = os.path.join(HERE, "_ref")
+        built = [os.path.join(ref_dir, f) for f in os.listdir(ref_dir)] if os.path.isdir(ref_dir) else []
+        expected = len(shims)            # one library per shim (ref_shim.cc -> libpxo_ref.so, ref_x_shim.cc -> libpxo_ref_x.so)
+        if force or len(built) < expected or min(os.path.getmtime(b) for b in built) < _newest(shims + stubs + [os.path.join(HERE, "Makefile")]):
+            subprocess.check_call(["make", "-C", HERE, "-s", "ref"], stdout=subprocess.DEVNULL)
     return so
 
 

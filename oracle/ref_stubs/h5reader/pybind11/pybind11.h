@@ -21,11 +21,12 @@ struct dict : object {
   object operator[](const char*) const { stub_unreachable("dict[]"); }
   bool contains(const char*) const { return false; }
 };
-struct buffer_info { void* ptr = nullptr; ssize_t size = 0; std::vector<ssize_t> shape; std::vector<ssize_t> strides; };
+struct buffer_info { void* ptr = nullptr; ssize_t size = 0; ssize_t ndim = 0; std::vector<ssize_t> shape; std::vector<ssize_t> strides; };
 struct array : object { enum { c_style = 1, f_style = 2 }; };
 template <typename T, int Flags = 0> class array_t : public array {
  public:
   array_t() {}
+  template <int F2> array_t(const array_t<T, F2>&) {}       // c_style <-> default flags
   template <typename S1, typename S2>
   array_t(std::initializer_list<S1>, std::initializer_list<S2>, const T*, handle = handle()) { stub_unreachable("array_t(shape, strides, ptr, base)"); }
   buffer_info request() const { stub_unreachable("array_t::request"); }

@@ -58,7 +58,14 @@ template <typename T, int N> Jet<T, N> sqrt(const Jet<T, N>& x) { Jet<T, N> o; o
 template <typename T, int N> Jet<T, N> abs(const Jet<T, N>& x) { return x.a < T(0) ? -x : x; }
 using std::abs;
 // the factory plumbing the residual headers name in their static Create() members (never called by the shims)
-class CostFunction { public: virtual ~CostFunction() {} };
+class CostFunction {
+ public:
+  virtual ~CostFunction() {}
+#ifdef PXO_STUB_EVALUABLE_COST   // shims that identify a recorded residual block by evaluating it on plain doubles
+  virtual int NumResiduals() const { return 0; }
+  virtual bool EvaluateValues(double const* const*, double*) const { return false; }
+#endif
+};
 // [upstream Ceres 2.1 loss_function.cc]: the rho formulas restated (what a build of the reference's cost-map extraction pins is
 // its own arithmetic around them, not Ceres' robustifiers)
 class LossFunction {
@@ -98,7 +105,18 @@ class HuberLoss : public LossFunction {
   const double a_, b_;
 };
 template <typename Functor, int kNumResiduals, int... Ns>
-class AutoDiffCostFunction : public CostFunction { public: explicit AutoDiffCostFunction(Functor* f) : f_(f) {} private: std::unique_ptr<Functor> f_; };
+class AutoDiffCostFunction : public CostFunction {
+ public:
+  explicit AutoDiffCostFunction(Functor* f) : f_(f) {}
+#ifdef PXO_STUB_EVALUABLE_COST
+  int NumResiduals() const override { return kNumResiduals; }
+  bool EvaluateValues(double const* const* p, double* r) const override { return Call(p, r, std::make_index_sequence<sizeof...(Ns)>()); }
+ private:
+  template <size_t... I> bool Call(double const* const* p, double* r, std::index_sequence<I...>) const { return (*f_)(p[I]..., r); }
+#endif
+ private:
+  std::unique_ptr<Functor> f_;
+};
 template <int kDataDimension, typename... A>
 void CubicHermiteSpline(const A&...) { Eigen::stub_unreachable("ceres::CubicHermiteSpline"); }
 template <typename Grid>
@@ -164,5 +182,10 @@ class Solver {
 };
 // the options the reference finally hands to the solver (linear solver / preconditioner selection) are kept for inspection
 inline Solver::Options& LastSolveOptions() { static Solver::Options o; return o; }
+#ifdef PXO_STUB_EVALUABLE_COST
+void PxoSolveHook(Problem* p);   // defined by the shim: looks at the problem while it is still alive
+inline void Solve(const Solver::Options& o, Problem* p, Solver::Summary*) { LastSolveOptions() = o; PxoSolveHook(p); }
+#else
 inline void Solve(const Solver::Options& o, Problem*, Solver::Summary*) { LastSolveOptions() = o; }
+#endif
 }  // namespace ceres

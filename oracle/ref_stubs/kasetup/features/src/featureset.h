@@ -15,6 +15,8 @@ template <typename dtype>
 class FeatureMap {
  public:
   bool IsSparse() const { return sparse; }
+  int Channels() const { return channels; }
+  int channels = 128;
   FeaturePatch<dtype>& GetFeaturePatch(colmap::point2D_t idx) { return *patches.at(idx); }
   std::unordered_map<colmap::point2D_t, FeaturePatch<dtype>*> patches;
   bool sparse = true;

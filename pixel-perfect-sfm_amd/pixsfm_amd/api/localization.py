@@ -67,7 +67,8 @@ def _build_problem(keypoints, fmap, references, patch_idxs, inliers, per_keypoin
                 node_problem=np.arange(m, dtype=np.int32) if per_keypoint_problems else np.zeros(m, np.int32),
                 edge_src=np.zeros(0, np.int32), edge_dst=np.zeros(0, np.int32), edge_w=np.zeros(0),
                 unary_node=np.asarray(unary_node, dtype=np.int32),
-                unary_ref=np.asarray(unary_ref, dtype=np.float64).reshape(len(unary_node), -1), unary_w=None)
+                unary_ref=(np.asarray(unary_ref, dtype=np.float64).reshape(len(unary_node), -1) if unary_node else np.zeros((0, 0))),
+                unary_w=None)      # no residual at all (every correspondence an outlier): the callers return False
     return rows, patches, prob
 
 
@@ -298,6 +299,37 @@ class QueryKeypointAdjuster:
             pnp_points2D[i] = unique_kps[old_to_new[i]]
 
 
+def _qba_observations(points3D, fmap, references, inliers, patch_idxs):
+    """The residual blocks of a query BA (single_query_bundle_optimizer.h:92-221): one per correspondence and reference
+    descriptor, inlier correspondences only, in that order.  -> (correspondence index, patch, xyz, descriptor) lists."""
+    rows, patches, xyz, refs = [], [], [], []
+    for idx in range(len(points3D)):
+        if inliers is not None and not inliers[idx]:
+            continue
+        patch = fmap.fpatch(idx if patch_idxs is None else patch_idxs[idx])
+        for d in _reference_descriptors(references[idx]):
+            rows.append(idx)
+            patches.append(patch)
+            xyz.append(np.asarray(points3D[idx], dtype=np.float64).reshape(3))
+            refs.append(d.reshape(-1))
+    return rows, patches, xyz, refs
+
+
+def _qba_camera_mask(camera, options):
+    """ParameterizeQuery (query_bundle_optimizer.h:113-146): bit mask of the camera parameters held constant."""
+    K = len(camera.params)
+    if not (options['refine_focal_length'] or options['refine_principal_point'] or options['refine_extra_params']):
+        return (1 << K) - 1                                                   # :121-126
+    const = []
+    if not options['refine_focal_length']:
+        const += camera.focal_length_idxs()
+    if not options['refine_principal_point']:
+        const += camera.principal_point_idxs()
+    if not options['refine_extra_params']:
+        const += camera.extra_params_idxs()
+    return sum(1 << a for a in const)
+
+
 class QueryBundleOptimizer:
     """_localization.QueryBundleOptimizer: ctor (options, interpolation_config);
     run(qvec, tvec, camera, points3D, fmap, references, inliers=None, patch_idxs=None) refines qvec,
@@ -328,15 +360,7 @@ class QueryBundleOptimizer:
         for name, v, k in (("qvec", qvec, 4), ("tvec", tvec, 3)):
             if not isinstance(v, np.ndarray) or v.dtype != np.float64 or v.size != k:
                 raise ValueError("%s must be a float64 numpy array of %d values (refined in place)" % (name, k))
-        patches, xyz, refs = [], [], []
-        for idx in range(n):
-            if inliers is not None and not inliers[idx]:
-                continue
-            patch = fmap.fpatch(idx if patch_idxs is None else patch_idxs[idx])
-            for d in _reference_descriptors(references[idx]):
-                patches.append(patch)
-                xyz.append(np.asarray(points3D[idx], dtype=np.float64).reshape(3))
-                refs.append(d.reshape(-1))
+        rows, patches, xyz, refs = _qba_observations(points3D, fmap, references, inliers, patch_idxs)
         if not patches:
             return False
         ctx = self.ctx or default_context()
@@ -353,17 +377,7 @@ class QueryBundleOptimizer:
                     xyz=np.array(xyz), refs=np.array(refs))
         ba = BAProblem(ctx, arena, prob)
         K = len(camera.params)
-        if not (o['refine_focal_length'] or o['refine_principal_point'] or o['refine_extra_params']):
-            cam_mask = (1 << K) - 1                                           # query_bundle_optimizer.h:121-126
-        else:
-            const = []
-            if not o['refine_focal_length']:
-                const += camera.focal_length_idxs()
-            if not o['refine_principal_point']:
-                const += camera.principal_point_idxs()
-            if not o['refine_extra_params']:
-                const += camera.extra_params_idxs()
-            cam_mask = sum(1 << a for a in const)
+        cam_mask = _qba_camera_mask(camera, o)
         lm = lm_options(max_iterations=s['max_num_iterations'], function_tolerance=s['function_tolerance'],
                         gradient_tolerance=s['gradient_tolerance'], parameter_tolerance=s['parameter_tolerance'],
                         max_consecutive_invalid_steps=s['max_num_consecutive_invalid_steps'],

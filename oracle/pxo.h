@@ -21,7 +21,9 @@
  * labelling (base/src/graph.cc, bit-exact), the IRLS loop (base/src/irls_optim.h), the cost-map
  * kernel (costmap_extractor.h FillPointCostmap) and the KA problem construction (edges, weights,
  * constants, bounds: topological_keypoint_optimizer.h, keypoint_optimizer.h via a recording Problem)
- * and the BA problem construction (bundle_optimizer.h, feature_reference_bundle_optimizer.h, same way).
+ * and the BA problem construction (bundle_optimizer.h, feature_reference_bundle_optimizer.h, same way);
+ * the whole reference extraction (A19: reference_extractor.h RunSubset / ComputeReference over irls_optim.h), the query
+ * refinements' problem construction and FindNearestReferences (localization/src/*.h).
  * "Parity unpinned" (Ceres / COLMAP absent, no golden vectors in the reference): the camera
  * models themselves (A6), the loss functions and corrector (A20) and the trust-region
  * solvers (A14, A18) -- validated by finite differences and closed-form properties only.

@@ -268,7 +268,9 @@ int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const 
  * `loss` (ReferenceConfig.loss, Cauchy(0.25)) and `iters` (100) iterations, reference = the
  * observation descriptor closest to the robust mean.  Outputs (device): d_refs_out
  * [n_points][C], d_ref_obs_out [n_points] (index of the chosen observation, -1 if the point has
- * none), optional d_robust_mean_out [n_points][C]. */
+ * none), optional d_robust_mean_out [n_points][C].  Channels: 128, 64, and 3 / 1 (image intensities; the registered
+ * FeatureReferenceBundleOptimizer cases (128,1) (64,1) (3,1) (1,1), feature_reference_bundle_optimizer.h:13-16 -- below 8
+ * channels the interpolation is the scalar Ceres bicubic the reference falls back to, interpolation.h:222-268). */
 int pxr_ba_compute_references(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view,
                               const pxr_interp_cfg* cfg, const pxr_loss* loss, int iters,
                               double* d_refs_out, int64_t* d_ref_obs_out, double* d_robust_mean_out,
@@ -312,7 +314,8 @@ double pxr_arena_upsampling(pxr_arena* a);
 /* PatchInterpolator::Evaluate / InterpolateNodes, batched (A5, features/src/patch_interpolator.h:86-135;
  * `_features.PatchInterpolator(config).interpolate_nodes(fpatch, xy)`, features/bindings.cc): the normalised
  * bicubic descriptor of arena patch d_patch[i] at keypoint d_kp[i] (COLMAP image coordinates) into
- * d_desc [n][C], and optionally its Jacobian with respect to the keypoint, d_J [n][C][2] (d/dx, d/dy). */
+ * d_desc [n][C], and optionally its Jacobian with respect to the keypoint, d_J [n][C][2] (d/dx, d/dy).
+ * Channels 128, 64, 3, 1 (pxr_nearest_references below: the same). */
 int pxr_interpolate(pxr_ctx* ctx, pxr_arena* arena, const pxr_interp_cfg* cfg, int64_t n, const double* d_kp,
                     const int64_t* d_patch, double* d_desc, double* d_J /* may be NULL */);
 

@@ -227,6 +227,133 @@ __global__ __launch_bounds__(256) void k_interpolate(int64_t n, const ST* __rest
   }
 }
 
+// ---- few-channel patches (C = 3 or 1: image intensities; FeatureReferenceBundleOptimizer registers (3, 1) and (1, 1),
+// feature_reference_bundle_optimizer.h:13-16) ---------------------------------------------------------------------------
+// Below 8 channels the reference interpolates with the scalar [upstream] ceres::BiCubicInterpolator (interp_small); one lane
+// holds the whole descriptor, so a point / correspondence / keypoint is ONE lane here and nothing crosses lanes.
+template <int C>
+__global__ __launch_bounds__(256) void k_irls_small(int64_t n_points, const int64_t* __restrict__ pt_ptr,
+                                                    const int64_t* __restrict__ pt_obs, const double* __restrict__ desc,
+                                                    pxr_loss loss, int iters, int l2_normalize, double* __restrict__ wbuf,
+                                                    double* __restrict__ refs, int64_t* __restrict__ ref_obs,
+                                                    double* __restrict__ robust_mean) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_points) return;
+  const int64_t o0 = pt_ptr[p];
+  const int n = (int)(pt_ptr[p + 1] - o0);
+  if (n == 0) { ref_obs[p] = -1; return; }
+  double* w = wbuf + o0;
+  for (int i = 0; i < n; ++i) w[i] = 1.0;
+  double mu[C];
+  int early = -1;
+  for (int k = 0; k < iters && early < 0; ++k) {
+    double sw = 0.0;
+    for (int i = 0; i < n; ++i) sw += w[i];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) mu[ch] = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const double wi = w[i] / sw;                           // irls_optim.h:44
+      w[i] = wi;
+      const double* di = desc + (size_t)pt_obs[o0 + i] * C;
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) mu[ch] += di[ch] * wi;  // :46-48
+    }
+    if (l2_normalize) {                                      // :54-58
+      double ss = 0.0;
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) ss = fma(mu[ch], mu[ch], ss);
+      const double nrm = sqrt(ss);
+      if (nrm > 0.0) {
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) mu[ch] /= nrm;
+      }
+    }
+    for (int i = 0; i < n && early < 0; ++i) {               // :60-69
+      const double* di = desc + (size_t)pt_obs[o0 + i] * C;
+      double s = 0.0;
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) { const double df = di[ch] - mu[ch]; s = fma(df, df, s); }
+      double rho[3];
+      loss_eval(loss.type, loss.a, 1.0, s, rho);
+      if (rho[0] > 0.0) w[i] = 1.0 / rho[0];
+      else {
+        early = i;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) mu[ch] = di[ch];
+      }
+    }
+  }
+  int best = 0;                                              // ComputeReference: first minimum, like Eigen's minCoeff
+  double bestd = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double* di = desc + (size_t)pt_obs[o0 + i] * C;
+    double s = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) { const double df = di[ch] - mu[ch]; s = fma(df, df, s); }
+    if (i == 0 || s < bestd) { bestd = s; best = i; }
+  }
+  const int64_t bo = pt_obs[o0 + best];
+#pragma unroll
+  for (int ch = 0; ch < C; ++ch) {
+    refs[(size_t)p * C + ch] = desc[(size_t)bo * C + ch];
+    if (robust_mean) robust_mean[(size_t)p * C + ch] = mu[ch];
+  }
+  ref_obs[p] = bo;
+}
+
+template <typename ST, int C>
+__global__ __launch_bounds__(256) void k_nearest_small(int64_t n, const ST* __restrict__ arena, const int32_t* __restrict__ corners,
+                                                       const double* __restrict__ scales, int H, int W, int l2_normalize,
+                                                       const double* __restrict__ kp, const int64_t* __restrict__ patch,
+                                                       const int64_t* __restrict__ cand_ptr, const int64_t* __restrict__ cand_index,
+                                                       const double* __restrict__ cand_desc, int64_t* __restrict__ best,
+                                                       double* __restrict__ best_dist, double* __restrict__ out_desc) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t pi = patch[i];
+  const double u = kp[2 * i] * scales[2 * pi] - 0.5 - (double)corners[2 * pi];
+  const double v = kp[2 * i + 1] * scales[2 * pi + 1] - 0.5 - (double)corners[2 * pi + 1];
+  double f[C], fr[C], fc[C];
+  interp_small<ST, C>(arena + (size_t)pi * H * W * C, H, W, u, v, l2_normalize != 0, f, fr, fc);
+  double dmin = 1.7976931348623157e308;
+  int64_t bi = -1;
+  for (int64_t o = cand_ptr[i]; o < cand_ptr[i + 1]; ++o) {
+    const int64_t row = cand_index ? cand_index[o] : o;
+    const double* d = cand_desc + (size_t)row * C;
+    double s = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) { const double e = d[ch] - f[ch]; s = fma(e, e, s); }
+    if (s < dmin) { dmin = s; bi = row; }
+  }
+  best[i] = bi;
+  if (best_dist) best_dist[i] = dmin;
+  if (out_desc && bi >= 0) {
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) out_desc[(size_t)i * C + ch] = cand_desc[(size_t)bi * C + ch];
+  }
+}
+
+template <typename ST, int C>
+__global__ __launch_bounds__(256) void k_interpolate_small(int64_t n, const ST* __restrict__ arena, const int32_t* __restrict__ corners,
+                                                           const double* __restrict__ scales, int H, int W, int l2_normalize,
+                                                           const double* __restrict__ kp, const int64_t* __restrict__ patch,
+                                                           double* __restrict__ out_f, double* __restrict__ out_J) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t pi = patch[i];
+  const double sx = scales[2 * pi], sy = scales[2 * pi + 1];
+  const double u = kp[2 * i] * sx - 0.5 - (double)corners[2 * pi];
+  const double v = kp[2 * i + 1] * sy - 0.5 - (double)corners[2 * pi + 1];
+  double f[C], fr[C], fc[C];
+  interp_small<ST, C>(arena + (size_t)pi * H * W * C, H, W, u, v, l2_normalize != 0, f, fr, fc);
+#pragma unroll
+  for (int ch = 0; ch < C; ++ch) {
+    const size_t o = (size_t)i * C + ch;
+    out_f[o] = f[ch];
+    if (out_J) { out_J[2 * o] = fc[ch] * sx; out_J[2 * o + 1] = fr[ch] * sy; }
+  }
+}
+
 }  // namespace pxr
 
 extern "C" int pxr_interpolate(pxr_ctx* ctx, pxr_arena* arena, const pxr_interp_cfg* cfg, int64_t n, const double* d_kp,
@@ -245,7 +372,18 @@ extern "C" int pxr_interpolate(pxr_ctx* ctx, pxr_arena* arena, const pxr_interp_
   else if (arena->dtype == PXR_F32 && arena->C == 64) INTERP_LAUNCH(float, 64);
   else if (arena->dtype == PXR_F64 && arena->C == 128) INTERP_LAUNCH(double, 128);
   else if (arena->dtype == PXR_F64 && arena->C == 64) INTERP_LAUNCH(double, 64);
-  else return set_error(PXR_EUNSUPPORTED, "pxr_interpolate: CHANNELS=%d not supported (128, 64)", arena->C);
+#define INTERP_SMALL(ST, CC)                                                                                       \
+  hipLaunchKernelGGL((k_interpolate_small<ST, CC>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n,   \
+                     (const ST*)arena->d_data, arena->d_corners, arena->d_scales, arena->H, arena->W, cfg->l2_normalize, \
+                     d_kp, d_patch, d_desc, d_J)
+  else if (arena->dtype == PXR_F16 && arena->C == 3) INTERP_SMALL(_Float16, 3);
+  else if (arena->dtype == PXR_F16 && arena->C == 1) INTERP_SMALL(_Float16, 1);
+  else if (arena->dtype == PXR_F32 && arena->C == 3) INTERP_SMALL(float, 3);
+  else if (arena->dtype == PXR_F32 && arena->C == 1) INTERP_SMALL(float, 1);
+  else if (arena->dtype == PXR_F64 && arena->C == 3) INTERP_SMALL(double, 3);
+  else if (arena->dtype == PXR_F64 && arena->C == 1) INTERP_SMALL(double, 1);
+  else return set_error(PXR_EUNSUPPORTED, "pxr_interpolate: CHANNELS=%d not supported (128, 64, 3, 1)", arena->C);
+#undef INTERP_SMALL
 #undef INTERP_LAUNCH
   return hip_check(hipGetLastError(), "k_interpolate launch");
 }
@@ -269,7 +407,18 @@ extern "C" int pxr_nearest_references(pxr_ctx* ctx, pxr_arena* arena, const pxr_
   else if (arena->dtype == PXR_F32 && arena->C == 64) NEAREST_LAUNCH(float, 64);
   else if (arena->dtype == PXR_F64 && arena->C == 128) NEAREST_LAUNCH(double, 128);
   else if (arena->dtype == PXR_F64 && arena->C == 64) NEAREST_LAUNCH(double, 64);
-  else return set_error(PXR_EUNSUPPORTED, "pxr_nearest_references: CHANNELS=%d not supported (128, 64)", arena->C);
+#define NEAREST_SMALL(ST, CC)                                                                                      \
+  hipLaunchKernelGGL((k_nearest_small<ST, CC>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n,       \
+                     (const ST*)arena->d_data, arena->d_corners, arena->d_scales, arena->H, arena->W, cfg->l2_normalize, \
+                     d_kp, d_patch, d_cand_ptr, d_cand_index, d_cand_desc, d_best, d_best_dist, d_out_desc)
+  else if (arena->dtype == PXR_F16 && arena->C == 3) NEAREST_SMALL(_Float16, 3);
+  else if (arena->dtype == PXR_F16 && arena->C == 1) NEAREST_SMALL(_Float16, 1);
+  else if (arena->dtype == PXR_F32 && arena->C == 3) NEAREST_SMALL(float, 3);
+  else if (arena->dtype == PXR_F32 && arena->C == 1) NEAREST_SMALL(float, 1);
+  else if (arena->dtype == PXR_F64 && arena->C == 3) NEAREST_SMALL(double, 3);
+  else if (arena->dtype == PXR_F64 && arena->C == 1) NEAREST_SMALL(double, 1);
+  else return set_error(PXR_EUNSUPPORTED, "pxr_nearest_references: CHANNELS=%d not supported (128, 64, 3, 1)", arena->C);
+#undef NEAREST_SMALL
 #undef NEAREST_LAUNCH
   return hip_check(hipGetLastError(), "k_nearest launch");
 }
@@ -280,7 +429,8 @@ extern "C" int pxr_ba_compute_references(pxr_ctx* ctx, pxr_arena* arena, const p
                                          double* d_obs_desc_out) {
   using namespace pxr;
   PXR_REQUIRE(ctx && arena && view && cfg && loss && d_refs_out && d_ref_obs_out, "pxr_ba_compute_references: NULL argument");
-  PXR_REQUIRE(arena->C == 128 || arena->C == 64, "pxr_ba_compute_references: CHANNELS=%d not supported (128, 64)", arena->C);
+  PXR_REQUIRE(arena->C == 128 || arena->C == 64 || arena->C == 3 || arena->C == 1,
+              "pxr_ba_compute_references: CHANNELS=%d not supported (128, 64, 3, 1)", arena->C);
   PXR_REQUIRE(iters >= 0, "pxr_ba_compute_references: negative iteration count");
   PXR_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -324,9 +474,15 @@ extern "C" int pxr_ba_compute_references(pxr_ctx* ctx, pxr_arena* arena, const p
     rc = pxr_ba_eval(ctx, arena, &v, cfg, 0, d_rec, d_desc, nullptr, nullptr);
   }
   if (!rc) {
-    const int G = 256 / (C / 8);
+    const int G = C >= 64 ? 256 / (C / 8) : 256;
     const unsigned blocks = (unsigned)((n_pts + G - 1) / G);
-    if (C == 128)
+    if (C == 3)
+      hipLaunchKernelGGL((k_irls_small<3>), dim3(blocks), dim3(256), 0, st, n_pts, d_ptr, d_lst, d_desc, *loss, iters,
+                         cfg->l2_normalize, d_w, d_refs_out, d_ref_obs_out, d_robust_mean_out);
+    else if (C == 1)
+      hipLaunchKernelGGL((k_irls_small<1>), dim3(blocks), dim3(256), 0, st, n_pts, d_ptr, d_lst, d_desc, *loss, iters,
+                         cfg->l2_normalize, d_w, d_refs_out, d_ref_obs_out, d_robust_mean_out);
+    else if (C == 128)
       hipLaunchKernelGGL((k_irls<128>), dim3(blocks), dim3(256), 0, st, n_pts, d_ptr, d_lst, d_desc, *loss, iters,
                          cfg->l2_normalize, d_w, d_refs_out, d_ref_obs_out, d_robust_mean_out);
     else

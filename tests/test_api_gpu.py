@@ -524,3 +524,37 @@ def test_feature_cache_to_device_flow_equals_host_flow(ctx, tmp_path):
         assert np.abs(rec_h.images[i].qvec - rec_d.images[i].qvec).max() < 1e-9
     for p in rec_h.points3D:
         assert np.abs(rec_h.points3D[p].xyz - rec_d.points3D[p].xyz).max() < 1e-9
+
+
+@pytest.mark.parametrize("channels", [3, 1])
+def test_bundle_adjuster_on_image_intensity_features(ctx, channels):
+    """BundleAdjuster (strategy feature_reference) on 3- / 1-channel maps without L2 normalisation, the "image" dense features
+    of pixsfm (features/models/image.py; FeatureReferenceBundleOptimizer (3, 1), (1, 1)): references extracted and the BA
+    solved through the same API objects; equal to the low-level engine on the same scene."""
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.api import BundleAdjuster, features
+    from pixsfm_amd.api.reconstruction import reconstruction_from_flat
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    prob = synthetic.make_ba_problem(n_cams=6, n_points=50, obs_per_point=4, seed=31 + channels, noise=0.02, channels=channels)
+    rec, patch_of = reconstruction_from_flat(prob)
+    fmaps = {}
+    for (image_id, p2d), pi in patch_of.items():
+        fm = fmaps.setdefault(rec.images[image_id].name, features.FeatureMap())
+        fm.patches[p2d] = features.FeaturePatch(prob["patches"][pi], prob["corners"][pi], prob["scales"][pi])
+    fmanager = features.FeatureManager([features.FeatureSet(fmaps)])
+    conf = {"optimizer": {"solver": {"max_num_iterations": 6}}, "interpolation": {"l2_normalize": False}}
+    out = BundleAdjuster.create(conf).refine_multilevel(rec, fmanager)
+    summary, references = out["summary"][0], out["references"][0]
+    assert len(references) == 50 and all(r.descriptor.shape == (1, channels) for r in references.values())
+    assert summary.final_cost < summary.initial_cost
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    cfg = interp_cfg(l2_normalize=False)
+    ba.compute_references(cfg, make_loss("cauchy", [0.25]), iters=100)
+    pose_const = np.zeros(6, np.uint8); pose_const[0] = 1
+    tmask = np.zeros(6, np.uint8); tmask[1] = 1
+    s = ba.solve(cfg, make_loss("cauchy", [0.25]), pose_const, tmask, np.full(6, 0b0110, np.uint16), np.zeros(50, np.uint8),
+                 options=lm_options(max_iterations=6, use_inner_iterations=True))
+    q, t, k, X = ba.params()
+    assert abs(s["final_cost"] - summary.final_cost) < 1e-4 * max(s["final_cost"], 1e-12)
+    assert np.abs(np.array([rec.points3D[p + 1].xyz for p in range(50)]) - X).max() < 1e-4

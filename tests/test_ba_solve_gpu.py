@@ -178,3 +178,22 @@ def test_device_built_observation_lists_equal_the_host_ones(ctx, monkeypatch):
         assert s_["iterations"] == s_dev["iterations"] and s_["num_successful"] == s_dev["num_successful"]
         assert abs(s_["final_cost"] - s_dev["final_cost"]) <= 1e-9 * abs(s_dev["final_cost"])
         assert all(np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max()) for a, b in zip(p_, p_dev))
+
+
+@pytest.mark.parametrize("channels,inner", [(3, False), (3, True), (1, False)])
+def test_feature_reference_ba_on_image_intensities(ctx, channels, inner):
+    """dense_features.model.name = "image": 3- or 1-channel maps, references subtracted, no L2 normalisation --
+    FeatureReferenceBundleOptimizer's (3, 1) and (1, 1) cases (feature_reference_bundle_optimizer.h:13-16).  Same LM
+    trajectory as the oracle; the point-only inner iterations run on the few-channel kernel with references."""
+    import pxo
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    prob = synthetic.make_ba_problem(n_cams=6, n_points=60, obs_per_point=4, seed=70 + channels, channels=channels, noise=0.02)
+    gauge = _gauge(prob)
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    kw = dict(max_iterations=6, use_inner_iterations=inner)
+    s_gpu = ba.solve(interp_cfg(l2_normalize=False), make_loss("cauchy", [0.25]), *gauge, options=lm_options(**kw))
+    s_cpu, qo, to, ko, Xo = pxo.ba_solve(prob, pxo.cfg(l2_normalize=False), pxo.loss("cauchy", 0.25), *gauge, pxo.lm_options(**kw))
+    _assert_same(s_gpu, ba.params(), s_cpu, (qo, to, ko, Xo))
+    assert s_gpu["final_cost"] < s_gpu["initial_cost"]

@@ -109,3 +109,59 @@ def test_keep_observations_and_nearest_references(ctx):
         assert best[i] == rows[b] and abs(dist[i] - d) <= 1e-12 * max(d, 1e-12)
         assert np.array_equal(win[i], desc[best[i]])
     assert all(best[i] in cand_index[cand_ptr[i]:cand_ptr[i + 1]] for i in range(n_obs))
+
+
+@pytest.mark.parametrize("channels,dtype,l2", [(3, np.float16, False), (3, np.float32, True), (1, np.float16, False), (1, np.float64, False)])
+def test_few_channel_references_interpolation_and_nearest(ctx, channels, dtype, l2):
+    """Image-intensity features (dense_features.model.name = "image": 3 or 1 channels): FeatureReferenceBundleOptimizer
+    registers (3, 1) and (1, 1) (feature_reference_bundle_optimizer.h:13-16) and ReferenceExtractor runs on any channel
+    count through the dynamic interpolator (reference_extractor.h:139-143), which below 8 channels is the scalar Ceres
+    bicubic (interpolation.h:222-268).  Reference extraction, batched interpolation with Jacobians, nearest references and
+    the residual blocks of the feature-reference BA against the oracle."""
+    import pxo
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, interpolate, make_loss, nearest_references
+    prob = synthetic.make_ba_problem(n_cams=7, n_points=40, obs_per_point=5, seed=channels + 10, noise=0.3, channels=channels, dtype=dtype)
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    cfg_g, cfg_o = interp_cfg(l2_normalize=l2), pxo.cfg(l2_normalize=l2)
+    chosen, mean = ba.compute_references(cfg_g, make_loss("cauchy", [0.25]), iters=30, keep_mean=True, keep_observations=True)
+    refs, desc = ba.d["refs"].download(), ba.obs_desc.download()
+    ls = pxo.loss("cauchy", 0.25)
+    n_obs = len(prob["obs_image"])
+    od = np.zeros((n_obs, channels))
+    for i in range(n_obs):
+        img, pt = prob["obs_image"][i], prob["obs_point"][i]
+        cam = prob["image_camera"][img]
+        patch = pxo.make_patch(prob["patches"][i], prob["corners"][i], prob["scales"][i])
+        K = pxo.lib().pxo_camera_num_params(int(prob["cam_model"][cam]))
+        od[i] = pxo.ba_residual(patch, cfg_o, int(prob["cam_model"][cam]), prob["qvec"][img], prob["tvec"][img], prob["xyz"][pt],
+                                prob["cam_params"][cam][:K], None, jac=False)[0]
+    assert np.abs(desc - od).max() < 1e-12
+    for p in range(len(prob["xyz"])):
+        obs = np.nonzero(prob["obs_point"] == p)[0]
+        idx, ref, mu = pxo.compute_reference(od[obs], ls, 30, l2)
+        assert chosen[p] == obs[idx]
+        assert np.abs(refs[p] - ref).max() < 1e-12 and np.abs(mean[p] - mu).max() < 1e-12
+    # the residual blocks of the feature-reference BA on these features (the Schur solver only sees the six-scalar record)
+    rec, r, gx, gy = ba.eval(cfg_g, with_jacobian=True, materialize=True)
+    r = r.download()
+    assert np.abs(r - (od - refs[prob["obs_point"]])).max() < 1e-12
+    # batched interpolation with Jacobians, and nearest references, at perturbed keypoints
+    rng = np.random.default_rng(1)
+    kps = prob["centers"] + rng.normal(0, 0.4, (n_obs, 2))
+    f, J = interpolate(ctx, arena, cfg_g, kps, np.arange(n_obs), jacobian=True)
+    for i in range(0, n_obs, 9):
+        patch = pxo.make_patch(prob["patches"][i], prob["corners"][i], prob["scales"][i])
+        fo, gxo, gyo, _ = pxo.patch_eval(patch, kps[i], cfg_o)
+        assert np.abs(f[i] - fo).max() < 1e-12
+        assert np.abs(J[i] - np.stack([gxo, gyo], 1)).max() < 1e-9 * max(1.0, np.abs(gxo).max(), np.abs(gyo).max())
+    ptr = np.arange(0, n_obs + 1, 5)
+    cand_ptr = np.concatenate([[0], np.cumsum(np.full(n_obs, 5))])
+    cand_index = np.concatenate([np.arange(ptr[p], ptr[p + 1]) for p in prob["obs_point"]])
+    best, dist, win = nearest_references(ctx, arena, cfg_g, kps, np.arange(n_obs), cand_ptr, od, cand_index=cand_index, want_desc=True)
+    for i in range(0, n_obs, 9):
+        patch = pxo.make_patch(prob["patches"][i], prob["corners"][i], prob["scales"][i])
+        rows = cand_index[cand_ptr[i]:cand_ptr[i + 1]]
+        b, d = pxo.nearest_reference(patch, cfg_o, kps[i], od[rows])
+        assert best[i] == rows[b] and abs(dist[i] - d) <= 1e-12 * max(d, 1e-12) and np.array_equal(win[i], od[best[i]])

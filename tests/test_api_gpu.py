@@ -558,3 +558,38 @@ def test_bundle_adjuster_on_image_intensity_features(ctx, channels):
     q, t, k, X = ba.params()
     assert abs(s["final_cost"] - summary.final_cost) < 1e-4 * max(s["final_cost"], 1e-12)
     assert np.abs(np.array([rec.points3D[p + 1].xyz for p in range(50)]) - X).max() < 1e-4
+
+
+def test_query_bundle_adjuster_on_single_channel_features(ctx):
+    """QueryBundleOptimizer's (1, 1) case (query_bundle_optimizer.h:33-34): a grayscale map, no L2 normalisation."""
+    import pxo
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.api import QueryBundleAdjuster, features
+    from pixsfm_amd.api.reconstruction import Camera
+    full = synthetic.make_ba_problem(n_cams=4, n_points=90, obs_per_point=3, seed=5, model=2, rot_deg=0.2, trans=0.01, channels=1)
+    sel = np.nonzero(full["obs_image"] == 0)[0]
+    pts, n = full["obs_point"][sel], len(sel)
+    points3D = [full["gt_xyz"][p].copy() for p in pts]
+    # references: the unnormalised intensities at the true projections
+    cfg = pxo.cfg(l2_normalize=False)
+    refs = []
+    for i, p in zip(sel, pts):
+        patch = pxo.make_patch(full["patches"][i], full["corners"][i], full["scales"][i])
+        refs.append(pxo.ba_residual(patch, cfg, 2, full["gt_qvec"][0], full["gt_tvec"][0], full["gt_xyz"][p],
+                                    full["cam_params"][full["image_camera"][0]][:4], None, jac=False)[0])
+    fmap = features.FeatureMap.from_arrays(full["patches"][sel], np.arange(n), full["corners"][sel], (1.0, 1.0))
+    cam = Camera(1, 2, 1000, 1000, full["cam_params"][full["image_camera"][0], :4].copy())
+    qvec, tvec = full["qvec"][0].copy(), full["tvec"][0].copy()
+    adj = QueryBundleAdjuster({"interpolation": {"l2_normalize": False}}, ctx=ctx)
+    assert adj.refine(qvec, tvec, cam, points3D, fmap, refs)
+    flat = dict(obs_image=np.zeros(n, np.int32), obs_point=np.arange(n, dtype=np.int32), obs_patch=np.arange(n, dtype=np.int64),
+                image_camera=np.zeros(1, np.int32), qvec=full["qvec"][:1].copy(), tvec=full["tvec"][:1].copy(),
+                cam_model=np.array([2], np.int32), cam_params=full["cam_params"][full["image_camera"][0]][None].copy(),
+                xyz=np.array(points3D), refs=np.array(refs), patches=np.ascontiguousarray(full["patches"][sel]),
+                corners=full["corners"][sel], scales=full["scales"][sel])
+    so, qo, to, co, _ = pxo.ba_solve(flat, cfg, pxo.loss("cauchy", 0.25), [0], [0], [0b1111], np.ones(n, np.uint8), pxo.lm_options())
+    s = adj.solver.last_summary
+    assert abs(s["initial_cost"] - so["initial_cost"]) < 1e-10 * so["initial_cost"]
+    assert abs(s["final_cost"] - so["final_cost"]) < 1e-6 * so["initial_cost"]
+    assert np.abs(qvec - qo[0]).max() < 1e-6 and np.abs(tvec - to[0]).max() < 1e-6
+    assert s["final_cost"] < 0.5 * s["initial_cost"]

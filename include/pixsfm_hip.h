@@ -287,7 +287,9 @@ int pxr_ba_compute_references(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view*
  * differences in the storage type, optional sqrt (CostMapConfig.apply_sqrt); corner and scale are copied from
  * the feature patch.  The cost-map BA (CostMapBundleOptimizer, costmap_bundle_optimizer.h) is then
  * pxr_ba_solve on the `costmaps` arena with view->d_refs = NULL and cfg->l2_normalize = 0
- * (bundle_adjustment/main.py:270): the residual block is the interpolated 3- (or 1-) channel texel. */
+ * (bundle_adjustment/main.py:270): the residual block is the interpolated 3- (or 1-) channel texel. 
+ * Feature channels: 128, 64, and 3 / 1 (image intensities; costmap_extractor.h:35-37 registers 128 and 3) -- one lane per
+ * texel there.  pxr_costmap_extract_ex's interpolating branch (upsampling_factor != 1, cross derivative) takes 128 / 64 only. */
 int pxr_costmap_extract(pxr_ctx* ctx, pxr_arena* features, pxr_arena* costmaps, int64_t first_out, int64_t n,
                         const int64_t* d_patch, const int32_t* d_ref_index, const double* d_refs,
                         const pxr_loss* loss, int as_gradientfield, int apply_sqrt);

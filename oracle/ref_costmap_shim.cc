@@ -30,14 +30,14 @@ struct ViewPatch : public FeaturePatch<dtype> {
 
 struct Filler : public CostMapExtractor {
   using CostMapExtractor::CostMapExtractor;
-  template <typename dtype_o, typename dtype>
+  template <int CHANNELS, typename dtype_o, typename dtype>
   void Fill(void* feat, int H, int W, const double* ref, void* out, int Ho, int Wo, int CO) {
-    ViewPatch<dtype> fpatch(feat, H, W, 128);
+    ViewPatch<dtype> fpatch(feat, H, W, CHANNELS);
     ViewPatch<dtype_o> cost(out, Ho, Wo, CO);
     Reference reference;
-    reference.descriptor = DescriptorMatrixXd(1, 128);
-    for (int i = 0; i < 128; ++i) reference.descriptor.data()[i] = ref[i];
-    this->template FillPointCostmap<128, dtype_o, dtype>(fpatch, reference, cost);
+    reference.descriptor = DescriptorMatrixXd(1, CHANNELS);
+    for (int i = 0; i < CHANNELS; ++i) reference.descriptor.data()[i] = ref[i];
+    this->template FillPointCostmap<CHANNELS, dtype_o, dtype>(fpatch, reference, cost);
   }
 };
 }  // namespace pixsfm
@@ -60,12 +60,35 @@ int pxo_ref_fill_point_costmap(void* feat, int dtype, int H, int W, const double
   icfg.l2_normalize = l2_normalize != 0;
   pixsfm::Filler filler(cfg, icfg);
   const int CO = cfg.GetEffectiveChannels();
-#define FILL(DO, DI) { filler.Fill<DO, DI>(feat, H, W, ref, out, Ho, Wo, CO); return 0; }
-  if (dtype == 0 && out_dtype == 0) FILL(half, half)
-  if (dtype == 0 && out_dtype == 1) FILL(float, half)
-  if (dtype == 0 && out_dtype == 2) FILL(double, half)
-  if (dtype == 1 && out_dtype == 1) FILL(float, float)
-  if (dtype == 2 && out_dtype == 2) FILL(double, double)
+#define FILL(CH, DO, DI) { filler.Fill<CH, DO, DI>(feat, H, W, ref, out, Ho, Wo, CO); return 0; }
+  if (dtype == 0 && out_dtype == 0) FILL(128, half, half)
+  if (dtype == 0 && out_dtype == 1) FILL(128, float, half)
+  if (dtype == 0 && out_dtype == 2) FILL(128, double, half)
+  if (dtype == 1 && out_dtype == 1) FILL(128, float, float)
+  if (dtype == 2 && out_dtype == 2) FILL(128, double, double)
+  return -1;
+}
+
+// The extractor's other registered case, CHANNELS = 3 (costmap_extractor.h:35-37: image intensities): feat is H x W x 3.  Only
+// the branch WITHOUT interpolation (cost map of the patch's size, no cross derivative) -- below 8 channels the interpolating
+// branch runs on ceres::BiCubicInterpolator, which is not available here.
+int pxo_ref_fill_point_costmap3(void* feat, int dtype, int H, int W, const double* ref, void* out, int out_dtype, int as_gradientfield,
+                                int apply_sqrt, int loss_type, double a) {
+  pixsfm::CostMapConfig cfg;
+  cfg.as_gradientfield = as_gradientfield != 0;
+  cfg.apply_sqrt = apply_sqrt != 0;
+  if (loss_type == 1) cfg.loss.reset(new ceres::CauchyLoss(a));
+  else if (loss_type == 2) cfg.loss.reset(new ceres::HuberLoss(a));
+  pixsfm::InterpolationConfig icfg;
+  icfg.l2_normalize = false;
+  pixsfm::Filler filler(cfg, icfg);
+  const int CO = cfg.GetEffectiveChannels();
+  const int Ho = H, Wo = W;
+  if (dtype == 0 && out_dtype == 0) FILL(3, half, half)
+  if (dtype == 0 && out_dtype == 1) FILL(3, float, half)
+  if (dtype == 0 && out_dtype == 2) FILL(3, double, half)
+  if (dtype == 1 && out_dtype == 1) FILL(3, float, float)
+  if (dtype == 2 && out_dtype == 2) FILL(3, double, double)
 #undef FILL
   return -1;
 }

@@ -148,6 +148,67 @@ __global__ __launch_bounds__(256) void costmap_kernel(const CostmapArgs a) {
   }
 }
 
+// ---- few-channel features (CHANNELS = 3: the extractor's other registered case, costmap_extractor.h:35-37; 1 alike) -----
+// Image intensities: a texel is 3 (or 1) values, so one lane does a whole texel -- residual, storage-type central
+// differences of its four neighbours, loss, gate, sqrt, cast -- and nothing crosses lanes.  Workgroup = one cost map.
+template <typename ST> __device__ __forceinline__ double storage_diff1(ST a, ST b);
+template <> __device__ __forceinline__ double storage_diff1<_Float16>(_Float16 a, _Float16 b) { return (double)(_Float16)(a - b); }
+template <> __device__ __forceinline__ double storage_diff1<float>(float a, float b) { return (double)__fsub_rn(a, b); }
+template <> __device__ __forceinline__ double storage_diff1<double>(double a, double b) { return __dsub_rn(a, b); }
+
+template <typename ST, typename OT, int C, bool GRAD>
+__global__ __launch_bounds__(256) void costmap_small_kernel(const CostmapArgs a) {
+  const int64_t i = blockIdx.x;
+  const int64_t pi = a.patch[i];
+  const int H = a.H, W = a.W;
+  const ST* P = reinterpret_cast<const ST*>(a.fin) + (size_t)pi * H * W * C;
+  if (threadIdx.x == 0) {   // CreateShallowCostmapFSet, costmap_extractor.h:382-399
+    const int64_t o = a.first_out + i;
+    a.cout[2 * o] = a.cin[2 * pi]; a.cout[2 * o + 1] = a.cin[2 * pi + 1];
+    a.sout[2 * o] = a.sin[2 * pi]; a.sout[2 * o + 1] = a.sin[2 * pi + 1];
+  }
+  double ref[C];
+#pragma unroll
+  for (int ch = 0; ch < C; ++ch) ref[ch] = a.refs[(size_t)a.ref_index[i] * C + ch];
+  OT* out = reinterpret_cast<OT*>(a.fout) + (size_t)(a.first_out + i) * H * W * a.CO;
+  for (int t = threadIdx.x; t < H * W; t += blockDim.x) {
+    const int y = t / W, x = t - y * W;
+    const ST* c = P + (size_t)t * C;
+    double s = 0.0, br = 0.0, bc = 0.0;
+    if (GRAD) {
+      const ST* up = P + (size_t)((y > 0 ? y - 1 : 0) * W + x) * C;
+      const ST* dn = P + (size_t)((y < H - 1 ? y + 1 : H - 1) * W + x) * C;
+      const ST* lf = P + (size_t)(y * W + (x > 0 ? x - 1 : 0)) * C;
+      const ST* rt = P + (size_t)(y * W + (x < W - 1 ? x + 1 : W - 1)) * C;
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) {
+        const double res = (double)c[ch] - ref[ch];
+        s = fma(res, res, s);
+        br = fma(res, 0.5 * storage_diff1<ST>(dn[ch], up[ch]), br);
+        bc = fma(res, 0.5 * storage_diff1<ST>(rt[ch], lf[ch]), bc);
+      }
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) { const double res = (double)c[ch] - ref[ch]; s = fma(res, res, s); }
+    }
+    double rho[3];
+    loss_eval(a.loss.type, a.loss.a, 1.0, s, rho);
+    double cost = 0.5 * rho[0];
+    OT* o = out + (size_t)t * a.CO;
+    if (GRAD) {
+      double dcr = 0.0, dcc = 0.0;
+      if (cost > 1.0e-8) {   // costmap_extractor.h:300-318
+        dcr = rho[1] * br; dcc = rho[1] * bc;
+        if (a.apply_sqrt) { cost = sqrt(cost); dcr *= 0.5 / cost; dcc *= 0.5 / cost; }
+      }
+      o[0] = store_cast<OT>(cost); o[1] = store_cast<OT>(dcr); o[2] = store_cast<OT>(dcc);
+    } else {
+      if (a.apply_sqrt) cost = sqrt(cost);   // :351-353
+      o[0] = store_cast<OT>(cost);
+    }
+  }
+}
+
 // ---- fp16 features, C = 128, square patches: 8 x 8 (low_memory.yaml) and the cost-only 16 x 16 maps --------------------
 // (16 x 16 with gradients, the default, has its own kernel further down: costmap_kernel_f16_split)
 // The generic kernel above is ALU-bound (fp64 channel math + a 16-lane all-reduce and a one-lane epilogue per
@@ -715,6 +776,21 @@ static int launch_costmap(pxr_ctx* ctx, const CostmapArgs& a, int64_t n, bool gr
   return hip_check(hipGetLastError(), "costmap_kernel launch");
 }
 
+template <typename ST, typename OT, int C>
+static int launch_costmap_small(pxr_ctx* ctx, const CostmapArgs& a, int64_t n, bool grad) {
+  if (grad) hipLaunchKernelGGL((costmap_small_kernel<ST, OT, C, true>), dim3((unsigned)n), dim3(256), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((costmap_small_kernel<ST, OT, C, false>), dim3((unsigned)n), dim3(256), 0, ctx->stream, a);
+  return hip_check(hipGetLastError(), "costmap_small_kernel launch");
+}
+template <typename ST, int C>
+static int launch_costmap_small_o(pxr_ctx* ctx, int out_dtype, const CostmapArgs& a, int64_t n, bool grad) {
+  switch (out_dtype) {
+    case PXR_F16: return launch_costmap_small<ST, _Float16, C>(ctx, a, n, grad);
+    case PXR_F32: return launch_costmap_small<ST, float, C>(ctx, a, n, grad);
+    default: return launch_costmap_small<ST, double, C>(ctx, a, n, grad);
+  }
+}
+
 template <typename ST, int C>
 static int launch_costmap_o(pxr_ctx* ctx, int out_dtype, const CostmapArgs& a, int64_t n, bool grad) {
   switch (out_dtype) {
@@ -739,9 +815,10 @@ extern "C" int pxr_costmap_extract(pxr_ctx* ctx, pxr_arena* features, pxr_arena*
   PXR_REQUIRE(costmaps->C == (as_gradientfield ? 3 : 1),
               "pxr_costmap_extract: %d cost-map channels, CostMapConfig needs %d (compute_cross_derivative is not supported)",
               costmaps->C, as_gradientfield ? 3 : 1);
-  if (features->C != 128 && features->C != 64)
-    return pxr::set_error(PXR_EUNSUPPORTED, "pxr_costmap_extract: CHANNELS=%d not supported (128, 64)", features->C);
-  if (features->W * (features->C / 8) > 256)
+  const bool few = features->C == 3 || features->C == 1;
+  if (features->C != 128 && features->C != 64 && !few)
+    return pxr::set_error(PXR_EUNSUPPORTED, "pxr_costmap_extract: CHANNELS=%d not supported (128, 64, 3, 1)", features->C);
+  if (!few && features->W * (features->C / 8) > 256)
     return pxr::set_error(PXR_EUNSUPPORTED, "pxr_costmap_extract: patches wider than %d texels are not supported "
                           "(dense maps: slice dense_cut_size windows with pxr_arena_extract first)", 256 / (features->C / 8));
   if (n == 0) return PXR_OK;
@@ -754,6 +831,11 @@ extern "C" int pxr_costmap_extract(pxr_ctx* ctx, pxr_arena* features, pxr_arena*
   a.first_out = first_out; a.patch = d_patch; a.ref_index = d_ref_index; a.refs = d_refs; a.loss = *loss;
   const bool grad = as_gradientfield != 0;
   const int od = costmaps->dtype;
+  if (few) {
+    if (features->dtype == PXR_F16) return features->C == 3 ? pxr::launch_costmap_small_o<_Float16, 3>(ctx, od, a, n, grad) : pxr::launch_costmap_small_o<_Float16, 1>(ctx, od, a, n, grad);
+    if (features->dtype == PXR_F32) return features->C == 3 ? pxr::launch_costmap_small_o<float, 3>(ctx, od, a, n, grad) : pxr::launch_costmap_small_o<float, 1>(ctx, od, a, n, grad);
+    return features->C == 3 ? pxr::launch_costmap_small_o<double, 3>(ctx, od, a, n, grad) : pxr::launch_costmap_small_o<double, 1>(ctx, od, a, n, grad);
+  }
   if (features->dtype == PXR_F16 && features->C == 128) return pxr::launch_costmap_o<_Float16, 128>(ctx, od, a, n, grad);
   if (features->dtype == PXR_F16) return pxr::launch_costmap_o<_Float16, 64>(ctx, od, a, n, grad);
   if (features->dtype == PXR_F32 && features->C == 128) return pxr::launch_costmap_o<float, 128>(ctx, od, a, n, grad);
@@ -784,7 +866,8 @@ extern "C" int pxr_costmap_extract_ex(pxr_ctx* ctx, pxr_arena* features, pxr_are
               costmaps->W, costmaps->C, Ho, Wo, CO);
   PXR_REQUIRE(Ho >= 1 && Wo >= 1, "pxr_costmap_extract_ex: empty cost maps");
   if (features->C != 128 && features->C != 64)
-    return pxr::set_error(PXR_EUNSUPPORTED, "pxr_costmap_extract_ex: CHANNELS=%d not supported (128, 64)", features->C);
+    return pxr::set_error(PXR_EUNSUPPORTED, "pxr_costmap_extract_ex: CHANNELS=%d not supported by the interpolating branch (128, 64; "
+                          "3 / 1 channels: only cost maps of the patch size without the cross derivative)", features->C);
   costmaps->up = upsampling_factor;                      // SetUpsamplingFactor, :399
   if (n == 0) return PXR_OK;
   PXR_REQUIRE(d_patch && d_ref_index && d_refs, "pxr_costmap_extract_ex: NULL argument");

@@ -48,6 +48,18 @@ def cases():
             up = 2.0
         out.append(dict(name="ci%02d" % k, patch=patch, ref=ref, loss=[("trivial", 1.0), ("cauchy", 0.25)][k % 2], grad=grad,
                         sqrt=bool(k % 2), out_dtype=np.dtype(np.float64 if k % 4 else dt), up=up, cross=cross, l2=bool(k % 3)))
+    rng3 = np.random.default_rng(299792)                  # CHANNELS = 3, the extractor's other registered case (raw-texel branch)
+    for k in range(18):
+        dt = [np.float16, np.float32, np.float64][k % 3]
+        H, W = [(16, 16), (8, 8), (9, 13)][(k // 3) % 3]
+        base = rng3.uniform(0.1, 0.9, 3)
+        patch = (base + rng3.normal(0, [0.2, 0.03][k % 2], (H, W, 3))).astype(dt)
+        if k % 4 == 0:
+            patch[1, 2] = base.astype(dt)
+        out.append(dict(name="c3_%02d" % k, patch=patch, ref=(base.astype(dt).astype(np.float64) if k % 4 == 0 else base.copy()),
+                        loss=[("trivial", 1.0), ("cauchy", 0.25), ("huber", 0.1)][(k // 2) % 3], grad=bool(k % 6 != 5),
+                        sqrt=bool((k // 3) % 2), out_dtype=np.dtype(dt if k % 7 or dt is not np.float16 else np.float32),
+                        up=1.0, cross=False, l2=False))
     return out
 
 
@@ -63,9 +75,13 @@ def run_reference(c):
     Ho, Wo, co = out_shape(c)
     out = np.zeros((Ho, Wo, co), c["out_dtype"])
     patch = np.ascontiguousarray(c["patch"])
-    rc = lib.pxo_ref_fill_point_costmap(_p(patch), DT[patch.dtype], H, W, _p(c["ref"]), _p(out), DT[out.dtype], Ho, Wo,
-                                        C.c_double(c["up"]), int(c["grad"]), int(c["cross"]), int(c["sqrt"]), LOSS[c["loss"][0]],
-                                        C.c_double(c["loss"][1]), int(c["l2"]))
+    if patch.shape[2] == 3:
+        rc = lib.pxo_ref_fill_point_costmap3(_p(patch), DT[patch.dtype], H, W, _p(c["ref"]), _p(out), DT[out.dtype], int(c["grad"]),
+                                             int(c["sqrt"]), LOSS[c["loss"][0]], C.c_double(c["loss"][1]))
+    else:
+        rc = lib.pxo_ref_fill_point_costmap(_p(patch), DT[patch.dtype], H, W, _p(c["ref"]), _p(out), DT[out.dtype], Ho, Wo,
+                                            C.c_double(c["up"]), int(c["grad"]), int(c["cross"]), int(c["sqrt"]), LOSS[c["loss"][0]],
+                                            C.c_double(c["loss"][1]), int(c["l2"]))
     assert rc == 0, (patch.dtype, out.dtype)
     return out
 

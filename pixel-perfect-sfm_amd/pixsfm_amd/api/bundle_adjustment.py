@@ -263,8 +263,10 @@ class _FlatBA:
 class ReferenceExtractor:
     """_bundle_adjustment.ReferenceExtractor(ref_conf, interp_conf).run(problem_labels, reconstruction,
     feature_set) -> {point3D_id: Reference} (bindings.cc:28-34,172-177; reference_extractor.h:125-162)."""
-    default_conf = {'loss': {'name': 'cauchy', 'params': [0.25]}, 'iters': 100, 'keep_observations': False,
-                    'compute_offsets3D': False, 'num_threads': -1}
+    # ReferenceConfig's own defaults (reference_extractor.h:55-67: TEN IRLS iterations); BundleAdjuster.default_conf['references']
+    # carries the Python-level ones (iters 100) and passes them in full
+    default_conf = {'loss': {'name': 'cauchy', 'params': [0.25]}, 'iters': 10, 'keep_observations': False,
+                    'compute_offsets3D': False, 'num_threads': -1}     # (closest_to_robust_mean is not exposed by bindings.cc:69-78: always true)
 
     def __init__(self, config=None, interpolation_config=None, ctx=None):
         self.config = base.merge_conf(self.default_conf, config)

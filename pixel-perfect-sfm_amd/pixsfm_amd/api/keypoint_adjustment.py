@@ -136,7 +136,7 @@ class FeatureMetricKeypointOptimizer:
     option_defaults = {
         'loss': {'name': 'cauchy', 'params': [0.25]},
         'solver': {**base.solver_default_conf, 'parameter_tolerance': 1.0e-4, 'num_threads': 1, 'callbacks': []},
-        'print_summary': True, 'bound': 4.0, 'num_threads': -1,
+        'print_summary': True, 'bound': -1.0, 'num_threads': -1,      # KeypointOptimizerOptions' own defaults (keypoint_adjustment_options.h:46-80); KeypointAdjuster.default_conf passes bound 4
         'root_regularize_weight': -1.0, 'weight_by_sim': True, 'root_edges_only': False,
     }
 

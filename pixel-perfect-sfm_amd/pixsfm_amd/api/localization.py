@@ -137,10 +137,12 @@ class QueryKeypointOptimizer:
     run(keypoints, fmap, references, patch_idxs=None, inliers=None) refines `keypoints` in place and
     returns False when the problem has no residuals (query_keypoint_optimizer.h:56-59)."""
 
+    # the C++ struct's own defaults (query_refinement_options.h:60-95); QueryKeypointAdjuster.default_conf carries the
+    # Python-level ones (bound 4, parameter_tolerance 1e-5) and always passes them in full
     option_defaults = {
         'loss': {'name': 'trivial', 'params': []},
-        'solver': {**base.solver_default_conf, 'parameter_tolerance': 1e-05, 'callbacks': []},
-        'print_summary': False, 'bound': 4.0,
+        'solver': {**base.solver_default_conf, 'parameter_tolerance': 1e-04, 'callbacks': []},
+        'print_summary': True, 'bound': -1.0,
     }
 
     def __init__(self, options=None, interpolation_config=None, ctx=None):
@@ -335,10 +337,11 @@ class QueryBundleOptimizer:
     run(qvec, tvec, camera, points3D, fmap, references, inliers=None, patch_idxs=None) refines qvec,
     tvec (numpy arrays) and camera.params in place; False when no residual was added."""
 
+    # the C++ struct's own defaults (query_refinement_options.h:8-57)
     option_defaults = {
         'loss': {'name': 'cauchy', 'params': [0.25]},
-        'solver': {**base.solver_default_conf, 'callbacks': []},
-        'print_summary': False,
+        'solver': {**base.solver_default_conf, 'parameter_tolerance': 1e-05, 'callbacks': []},
+        'print_summary': True,
         'refine_focal_length': False, 'refine_principal_point': False, 'refine_extra_params': False,
     }
 

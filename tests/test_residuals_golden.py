@@ -142,3 +142,42 @@ def test_hip_ba_residuals_match_the_reference_vectors():
             assert np.all(J[i][:, 10 + K:] == 0.0)
             n_checked += 1
     assert n_checked == len(gen.ba_cases())
+
+
+@pytest.mark.gpu
+def test_single_block_cost_functions_of_the_shim_match_the_reference_vectors():
+    """`_pixsfm._residuals.FeatureReferenceCostFunctor / FeatureReferenceConstantPoseCostFunctor` (residuals/bindings.cc:14-30):
+    one residual block with the ceres::CostFunction surface, residuals and per-block Jacobians against the vectors of the
+    reference's functors.  The first factory ignores its reference descriptor like the reference's binding does
+    (feature_reference.h:267-271), so its residual is the golden residual PLUS the reference."""
+    from pixsfm_amd._pixsfm import _residuals
+    from pixsfm_amd.api import features
+    from pixsfm_amd.engine import Context
+    gen, gold = _gen(), _gold()
+    ctx = Context(0)
+    n = 0
+    for c in gen.ba_cases():
+        if c["check_bounds"] or c["d"].shape[2] != 128:
+            continue
+        name = c["name"]
+        K = len(c["params"])
+        patch = features.FeaturePatch(c["d"], c["c"], c["s"])
+        icfg = {"l2_normalize": c["l2"]}
+        f = _residuals.FeatureReferenceCostFunctor(c["model"], patch, c["ref"].reshape(1, -1), icfg, ctx=ctx)
+        assert f.num_residuals() == 128 and f.parameter_block_sizes() == [4, 3, 3, K]
+        ok, r, J = f.evaluate(c["q"], c["t"], c["X"], c["params"])
+        assert ok and _rel(r, gold[name + "_r"] + c["ref"]) < 1e-10
+        assert [b.shape for b in J] == [(128, 4), (128, 3), (128, 3), (128, K)]
+        assert _rel(np.hstack(J), gold[name + "_J"]) < 1e-9
+        g = _residuals.FeatureReferenceConstantPoseCostFunctor(c["model"], c["q"], c["t"], patch, c["ref"].reshape(1, -1), icfg, ctx=ctx)
+        assert g.parameter_block_sizes() == [3, K]
+        ok, r, J = g.evaluate(c["X"], c["params"])
+        assert ok and _rel(r, gold[name + "_r"]) < 1e-10 and _rel(np.hstack(J), gold[name + "_J"][:, 7:]) < 1e-9
+        n += 1
+        if n >= 12:
+            break
+    assert n >= 6
+    with pytest.raises(ValueError, match="Unsupported dimensions"):
+        _residuals.FeatureReferenceCostFunctor(0, features.FeaturePatch(np.zeros((4, 4, 64), np.float16), (0, 0), (1.0, 1.0)), np.zeros((1, 64)), {}, ctx=ctx)
+    with pytest.raises(NotImplementedError):
+        _residuals.GeometricCostFunctor(0, np.zeros(2))

@@ -219,6 +219,25 @@ typedef struct {
   int64_t linear_iterations; /* conjugate-gradient iterations summed over the LM attempts (iterative solver)   */
 } pxr_lm_summary;
 
+/* ceres::IterationCallback of the BA solve (the `solver.callbacks` of pixsfm's option dicts, base/src/callbacks.h; the
+ * reference also keeps Ctrl-C responsive this way, util/src/py_interrupt.h): called on the host by pxr_ba_solve after the
+ * initial evaluation (iteration 0) and after every LM iteration.  Return 0 to continue, 1 to abort (SOLVER_ABORT: the solve
+ * ends with PXR_TERM_FAILURE, parameters as of the last accepted step), 2 to stop as converged (SOLVER_TERMINATE_SUCCESSFULLY).
+ * With several ranks every rank calls its own callback and all must return the same value.  pxr_ka_solve runs its LM loops
+ * inside one kernel and does not call back. */
+typedef struct {
+  int32_t iteration;            /* 0 = the initial evaluation                                            */
+  int32_t step_is_valid;        /* the linear solve succeeded and the model cost decreased              */
+  int32_t step_is_successful;   /* the step was accepted                                                */
+  double cost;                  /* cost after this iteration (unchanged when the step was not accepted) */
+  double cost_change;           /* cost before - candidate cost (0 for iteration 0 / invalid steps)     */
+  double relative_decrease;     /* cost_change / model cost change                                      */
+  double trust_region_radius;   /* radius the NEXT iteration starts with                                */
+  double step_norm;
+} pxr_iteration_summary;
+typedef int (*pxr_iteration_callback)(const pxr_iteration_summary* summary, void* user);
+int pxr_set_iteration_callback(pxr_ctx* ctx, pxr_iteration_callback fn /* NULL removes it */, void* user);
+
 /* ---- multi-GPU: one process per GPU ---------------------------------------------
  * With N ranks every rank holds ALL images and cameras (replicated) and a disjoint shard of the points with
  * all their observations, patches and references; the only exchange of the BA path is an in-place

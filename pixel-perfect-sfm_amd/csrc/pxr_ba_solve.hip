@@ -1111,6 +1111,24 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   int invalid = 0;
   bool reuse_diag = false;
   bool inner_enabled = opt->use_inner_iterations != 0, inner_useful = false;
+  // ceres::IterationCallback (pxr_set_iteration_callback): 1 = SOLVER_ABORT, 2 = SOLVER_TERMINATE_SUCCESSFULLY
+  auto notify = [&](int iteration, bool valid, bool successful, double cost_now, double change, double rel, double radius_next, double step) -> int {
+    if (!ctx->iter_cb) return 0;
+    pxr_iteration_summary is;
+    is.iteration = iteration; is.step_is_valid = valid; is.step_is_successful = successful; is.cost = cost_now; is.cost_change = change;
+    is.relative_decrease = rel; is.trust_region_radius = radius_next; is.step_norm = step;
+    return ctx->iter_cb(&is, ctx->iter_user);
+  };
+  auto user_stop = [&](int rc) {   // true: leave the loop
+    if (rc == 1) { sum->termination = PXR_TERM_FAILURE; return true; }
+    if (rc == 2) { sum->termination = PXR_TERM_CONVERGENCE; return true; }
+    return false;
+  };
+  if (user_stop(notify(0, false, false, cost, 0.0, 0.0, radius, 0.0))) {
+    sum->final_cost = cost; sum->final_radius = radius;
+    sum->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop0).count();
+    return PXR_OK;
+  }
 
   while (true) {
     if (sum->iterations >= opt->max_iterations) { sum->termination = PXR_TERM_NO_CONVERGENCE; break; }
@@ -1204,6 +1222,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     if (!ok) {   // HandleInvalidStep
       if (++invalid >= opt->max_consecutive_invalid_steps) { sum->termination = PXR_TERM_FAILURE; break; }
       radius *= 0.5; reuse_diag = true;
+      if (user_stop(notify(sum->iterations, false, false, cost, 0.0, 0.0, radius, step_norm))) break;
       continue;
     }
     invalid = 0;
@@ -1230,8 +1249,10 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
         RC(gradient_below_tolerance(&below));
         if (below) { sum->termination = PXR_TERM_CONVERGENCE; break; }
       }
+      if (user_stop(notify(sum->iterations, true, true, cost, cost_change, rel, radius, step_norm))) break;
     } else {   // StepRejected
       radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diag = true;
+      if (user_stop(notify(sum->iterations, true, false, cost, cost_change, rel, radius, step_norm))) break;
     }
   }
   PXR_HIP(hipStreamSynchronize(st));

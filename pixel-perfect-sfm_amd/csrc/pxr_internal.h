@@ -21,6 +21,8 @@ struct pxr_ctx {
   size_t workspace_mat_bytes = 0;
   void* comm = nullptr;          // ncclComm_t of this rank (pxr_comm.cpp), NULL on a single GPU
   int rank = 0, nranks = 1;
+  pxr_iteration_callback iter_cb = nullptr;   // pxr_set_iteration_callback
+  void* iter_user = nullptr;
 };
 
 struct pxr_arena {

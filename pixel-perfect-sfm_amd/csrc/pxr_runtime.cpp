@@ -197,4 +197,11 @@ int32_t* pxr_arena_corners(pxr_arena* a) { return a ? a->d_corners : nullptr; }
 double* pxr_arena_scales(pxr_arena* a) { return a ? a->d_scales : nullptr; }
 int64_t pxr_arena_size(pxr_arena* a) { return a ? a->n : 0; }
 
+int pxr_set_iteration_callback(pxr_ctx* ctx, pxr_iteration_callback fn, void* user) {
+  PXR_REQUIRE(ctx, "pxr_set_iteration_callback: NULL context");
+  ctx->iter_cb = fn;
+  ctx->iter_user = fn ? user : nullptr;
+  return PXR_OK;
+}
+
 }  // extern "C"

@@ -135,6 +135,7 @@ _SIGNATURES = {
     "pxr_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pxr_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "pxr_comm_destroy": (C.c_int, [C.c_void_p]),
+    "pxr_set_iteration_callback": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pxr_comm_set_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pxr_comm_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pxr_comm_allreduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
@@ -143,6 +144,15 @@ LINEAR_AUTO, LINEAR_DIRECT, LINEAR_ITERATIVE = 0, 1, 2
 COMM_ID_BYTES = 128
 
 _lib = None
+
+
+class IterationSummary(C.Structure):
+    """pxr_iteration_summary"""
+    _fields_ = [("iteration", C.c_int32), ("step_is_valid", C.c_int32), ("step_is_successful", C.c_int32), ("cost", C.c_double),
+                ("cost_change", C.c_double), ("relative_decrease", C.c_double), ("trust_region_radius", C.c_double), ("step_norm", C.c_double)]
+
+
+ITERATION_CALLBACK = C.CFUNCTYPE(C.c_int, C.POINTER(IterationSummary), C.c_void_p)
 
 
 def declared_symbols():

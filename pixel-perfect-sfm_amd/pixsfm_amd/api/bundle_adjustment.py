@@ -548,9 +548,16 @@ class FeatureReferenceBundleOptimizer:
             point_const = flat.point_const[lo:lo + n_loc]
             if allreduce is None:
                 allreduce = parallel.ensure_collective(ba.ctx)      # native RCCL (None) or the callback form
-        summ = ba.solve(self.interpolation.to_engine(), make_loss(self._loss['name'], self._loss['params']),
-                        flat.pose_const, flat.tvec_mask, flat.cam_mask, point_const, options=lm,
-                        allreduce=allreduce)
+        callbacks = list(s.get('callbacks') or [])                  # solver.callbacks (base/src/callbacks.h): one call per LM iteration
+        if callbacks:
+            ba.ctx.set_iteration_callbacks(callbacks)
+        try:
+            summ = ba.solve(self.interpolation.to_engine(), make_loss(self._loss['name'], self._loss['params']),
+                            flat.pose_const, flat.tvec_mask, flat.cam_mask, point_const, options=lm,
+                            allreduce=allreduce)
+        finally:
+            if callbacks:
+                ba.ctx.set_iteration_callbacks(None)
         q, t, k, X = ba.params()
         if getattr(self, "_share", None) is not None:               # every rank ends up with all refined points
             X = parallel.gather_rows(X, np.arange(lo, lo + n_loc), len(flat.point_ids))

@@ -385,9 +385,16 @@ class QueryBundleOptimizer:
                         gradient_tolerance=s['gradient_tolerance'], parameter_tolerance=s['parameter_tolerance'],
                         max_consecutive_invalid_steps=s['max_num_consecutive_invalid_steps'],
                         use_inner_iterations=False)     # every point is constant: nothing for inner iterations
-        summary = ba.solve(self.interpolation.to_engine(), make_loss(o['loss']['name'], o['loss']['params']),
-                           np.zeros(1, np.uint8), np.zeros(1, np.uint8), np.array([cam_mask], np.uint16),
-                           np.ones(m, np.uint8), options=lm)
+        callbacks = list(s.get('callbacks') or [])
+        if callbacks:
+            ctx.set_iteration_callbacks(callbacks)
+        try:
+            summary = ba.solve(self.interpolation.to_engine(), make_loss(o['loss']['name'], o['loss']['params']),
+                               np.zeros(1, np.uint8), np.zeros(1, np.uint8), np.array([cam_mask], np.uint16),
+                               np.ones(m, np.uint8), options=lm)
+        finally:
+            if callbacks:
+                ctx.set_iteration_callbacks(None)
         q_out, t_out, cam_out, _ = ba.params()
         qvec.reshape(4)[:] = q_out[0]
         tvec.reshape(3)[:] = t_out[0]

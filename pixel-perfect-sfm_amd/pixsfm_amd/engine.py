@@ -62,6 +62,26 @@ class Context:
         check(self.lib.pxr_comm_rank(self.handle, C.byref(r), C.byref(n)), "pxr_comm_rank")
         return r.value, n.value
 
+    def set_iteration_callbacks(self, callbacks):
+        """ceres::IterationCallback objects for the BA solves of this context (pxr_set_iteration_callback): each callable gets
+        the iteration summary (attributes iteration, step_is_valid, step_is_successful, cost, cost_change, relative_decrease,
+        trust_region_radius, step_norm) and returns None / 0 to continue, 1 to abort, 2 to terminate successfully; the largest
+        answer wins.  An empty list removes the hook."""
+        callbacks = list(callbacks or [])
+        if not callbacks:
+            check(self.lib.pxr_set_iteration_callback(self.handle, None, None), "pxr_set_iteration_callback")
+            self._iter_cb = None
+            return
+
+        def hook(summary, _user):
+            rc = 0
+            for cb in callbacks:
+                ans = cb(summary.contents)
+                rc = max(rc, int(getattr(ans, "value", ans) or 0))
+            return rc
+        self._iter_cb = _lib.ITERATION_CALLBACK(hook)            # kept alive as long as it is installed
+        check(self.lib.pxr_set_iteration_callback(self.handle, C.cast(self._iter_cb, C.c_void_p), None), "pxr_set_iteration_callback")
+
     def comm_destroy(self):
         check(self.lib.pxr_comm_destroy(self.handle), "pxr_comm_destroy")
 

@@ -593,3 +593,44 @@ def test_query_bundle_adjuster_on_single_channel_features(ctx):
     assert abs(s["final_cost"] - so["final_cost"]) < 1e-6 * so["initial_cost"]
     assert np.abs(qvec - qo[0]).max() < 1e-6 and np.abs(tvec - to[0]).max() < 1e-6
     assert s["final_cost"] < 0.5 * s["initial_cost"]
+
+
+def test_iteration_callbacks_of_the_bundle_adjustment(ctx):
+    """`solver.callbacks` (base/src/callbacks.h; pyceres IterationCallback objects in the reference): called after the initial
+    evaluation and after every LM iteration with the iteration summary; SOLVER_ABORT (1) / SOLVER_TERMINATE_SUCCESSFULLY (2)
+    end the solve like in Ceres."""
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    prob = synthetic.make_ba_problem(n_cams=5, n_points=40, obs_per_point=4, seed=3)
+    n_img = 5
+    gauge = (np.r_[1, np.zeros(n_img - 1)].astype(np.uint8), np.r_[0, 1, np.zeros(n_img - 2)].astype(np.uint8), np.full(n_img, 0b0110, np.uint16), np.zeros(40, np.uint8))
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+
+    def run(callbacks, max_it=6):
+        ba = BAProblem(ctx, arena, prob)
+        ctx.set_iteration_callbacks(callbacks)
+        try:
+            return ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *gauge, options=lm_options(max_iterations=max_it))
+        finally:
+            ctx.set_iteration_callbacks(None)
+
+    plain = run(None)
+    seen = []
+    s = run([lambda it: seen.append((it.iteration, it.step_is_valid, it.step_is_successful, it.cost, it.cost_change, it.trust_region_radius))])
+    # observing changes nothing (the Schur sums use floating-point atomics: run-to-run equality holds to rounding only)
+    assert abs(s["final_cost"] - plain["final_cost"]) <= 1e-10 * plain["final_cost"] and s["iterations"] == plain["iterations"]
+    assert [x[0] for x in seen] == list(range(0, s["iterations"] + 1))
+    assert seen[0][1:3] == (0, 0) and seen[0][3] == s["initial_cost"] and seen[-1][3] == s["final_cost"]
+    assert sum(x[2] for x in seen) == s["num_successful"]
+    for prev, cur in zip(seen, seen[1:]):
+        if cur[2]:
+            assert abs((prev[3] - cur[3]) - cur[4]) <= 1e-12 * prev[3] and cur[3] < prev[3]
+        else:
+            assert cur[3] == prev[3]
+    # abort after the second iteration / declare success after the first
+    s_abort = run([lambda it: 1 if it.iteration == 2 else 0])
+    assert s_abort["iterations"] == 2 and s_abort["termination"] == 2                                  # PXR_TERM_FAILURE
+    s_ok = run([lambda it: None, lambda it: 2 if it.iteration == 1 else 0])
+    assert s_ok["iterations"] == 1 and s_ok["termination"] == 0 and abs(s_ok["final_cost"] - seen[1][3]) <= 1e-10 * seen[1][3]
+    s0 = run([lambda it: 2])
+    assert s0["iterations"] == 0 and s0["final_cost"] == s0["initial_cost"]

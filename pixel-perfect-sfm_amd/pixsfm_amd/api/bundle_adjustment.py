@@ -548,16 +548,20 @@ class FeatureReferenceBundleOptimizer:
             point_const = flat.point_const[lo:lo + n_loc]
             if allreduce is None:
                 allreduce = parallel.ensure_collective(ba.ctx)      # native RCCL (None) or the callback form
-        callbacks = list(s.get('callbacks') or [])                  # solver.callbacks (base/src/callbacks.h): one call per LM iteration
-        if callbacks:
-            ba.ctx.set_iteration_callbacks(callbacks)
+        # solver.callbacks (base/src/callbacks.h): one call per LM iteration; the first hook records Summary::iterations
+        from types import SimpleNamespace
+        history = []
+        fields = ("iteration", "step_is_valid", "step_is_successful", "cost", "cost_change", "relative_decrease", "trust_region_radius", "step_norm")
+
+        def record(it):
+            history.append(SimpleNamespace(**{f: getattr(it, f) for f in fields}))
+        ba.ctx.set_iteration_callbacks([record] + list(s.get('callbacks') or []))
         try:
             summ = ba.solve(self.interpolation.to_engine(), make_loss(self._loss['name'], self._loss['params']),
                             flat.pose_const, flat.tvec_mask, flat.cam_mask, point_const, options=lm,
                             allreduce=allreduce)
         finally:
-            if callbacks:
-                ba.ctx.set_iteration_callbacks(None)
+            ba.ctx.set_iteration_callbacks(None)
         q, t, k, X = ba.params()
         if getattr(self, "_share", None) is not None:               # every rank ends up with all refined points
             X = parallel.gather_rows(X, np.arange(lo, lo + n_loc), len(flat.point_ids))
@@ -570,6 +574,7 @@ class FeatureReferenceBundleOptimizer:
         for n, pid in enumerate(flat.point_ids):
             reconstruction.points3D[pid].xyz = X[n].copy()
         self._summary = Summary(summ, num_residuals=len(flat.obs_image) * C)
+        self._summary.iterations = history
         return True
 
     def reset(self):

@@ -75,6 +75,9 @@ class Summary:
         self.total_time_in_seconds = d["total_ms"] * 1e-3
         self.num_residuals_reduced = num_residuals
         self.raw = d
+        # ceres::Solver::Summary::iterations: per-iteration records of the BA solves (filled by the bundle optimizers through
+        # pxr_set_iteration_callback); the keypoint adjustments run their LM loops inside one kernel and leave it empty
+        self.iterations = []
 
     def BriefReport(self):
         return "pixsfm_amd: iterations %d, initial cost %e, final cost %e, termination %s" % (

@@ -88,6 +88,9 @@ def test_bundle_adjuster_like_pixsfm(ctx):
     conf = {"optimizer": {"solver": {"max_num_iterations": 8}}}
     out = BundleAdjuster.create(conf).refine_multilevel(rec, fmanager)
     summary, references = out["summary"][0], out["references"][0]
+    # ceres::Solver::Summary::iterations: iteration 0 = the initial evaluation, then one record per LM iteration
+    assert [it.iteration for it in summary.iterations] == list(range(summary.num_iterations + 1))
+    assert summary.iterations[0].cost == summary.initial_cost and summary.iterations[-1].cost == summary.final_cost
     # (per-image feature noise + references taken at the perturbed projections leave a cost floor)
     assert len(references) == 70 and summary.final_cost < 0.5 * summary.initial_cost
     # the same thing through the low-level engine: references by the GPU extractor, default gauge

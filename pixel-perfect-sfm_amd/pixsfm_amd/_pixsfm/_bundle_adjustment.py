@@ -3,16 +3,23 @@ from ..api.bundle_adjustment import (BundleAdjustmentSetup, CostMapBundleOptimiz
                                      FeatureReferenceBundleOptimizer, ReferenceExtractor)
 
 
-class BundleOptimizerOptions(dict):
-    """Dict-constructible option struct of the reference; the optimizers take the dict itself."""
+from ._options import struct
+
+BundleOptimizerOptions = struct("BundleOptimizerOptions", FeatureReferenceBundleOptimizer.option_defaults,
+                                "BundleOptimizerOptions (bundle_adjustment_options.h:44-96; bindings.cc:113-135).")
+ReferenceConfig = struct("ReferenceConfig", ReferenceExtractor.default_conf, "ReferenceConfig (reference_extractor.h:55-67; bindings.cc:69-79).")
 
 
-class ReferenceConfig(dict):
-    pass
+def _effective_channels(self):
+    """GetEffectiveChannels (costmap_extractor.h:52-61)."""
+    return (4 if self["compute_cross_derivative"] else 3) if self["as_gradientfield"] else 1
 
 
-class CostMapConfig(dict):
-    pass
+CostMapConfig = struct("CostMapConfig", CostMapExtractor.default_conf, "CostMapConfig (costmap_extractor.h:38-62; bindings.cc:53-67).",
+                       extra={"get_effective_channels": _effective_channels})
+PatchWarpBundleOptimizerOptions = struct(
+    "PatchWarpBundleOptimizerOptions", {**FeatureReferenceBundleOptimizer.option_defaults, "regularize_source": False},
+    "Named by the bindings; its optimizer is outside the accelerated path.", base=BundleOptimizerOptions)
 
 
 def _outside(name, why):

@@ -15,3 +15,6 @@ for _sfx in ("_f16", "_f32", "_f64"):
 
 class Map_IdReference(dict):
     """Opaque std::unordered_map<point3D_t, Reference> of the reference: a dict here."""
+
+
+from ..api.features import _PatchStatus as PatchStatus  # noqa: E402,F401

@@ -2,5 +2,9 @@
 from ..api.localization import QueryBundleOptimizer, QueryKeypointOptimizer, find_nearest_references  # noqa: F401
 
 
-class QueryBundleOptimizerOptions(dict):
-    pass
+from ._options import struct
+
+QueryBundleOptimizerOptions = struct("QueryBundleOptimizerOptions", QueryBundleOptimizer.option_defaults,
+                                     "QueryBundleOptimizerOptions (query_refinement_options.h:8-57).")
+QueryKeypointOptimizerOptions = struct("QueryKeypointOptimizerOptions", QueryKeypointOptimizer.option_defaults,
+                                       "QueryKeypointOptimizerOptions (query_refinement_options.h:60-95).")

@@ -79,8 +79,10 @@ class InterpolationConfig:
 class Match:
     __slots__ = ("node_idx", "sim")
 
-    def __init__(self, node_idx, sim):
-        self.node_idx, self.sim = int(node_idx), float(sim)
+    def __init__(self, node_idx, similarity=None, sim=None):         # base/bindings.cc:46-55: (node_idx, similarity)
+        self.node_idx, self.sim = int(node_idx), float(similarity if similarity is not None else sim)
+
+    similarity = property(lambda self: self.sim, lambda self, v: setattr(self, "sim", float(v)))
 
 
 class FeatureNode:
@@ -111,6 +113,33 @@ class Graph:
             self.node_map[key] = node.node_idx
             return node
         return self.nodes[idx]
+
+    def add_node(self, image, feature_idx):                          # graph.cc:98-113 (both overloads)
+        """Appends a node WITHOUT registering it in the (image, keypoint) lookup of find_or_create_node -- like the
+        reference's AddNode; `image` is an image name (registered on first use) or an image id.  Returns the node index."""
+        if isinstance(image, str):
+            image_id = self.image_name_to_id.setdefault(image, len(self.image_name_to_id))
+            self.image_id_to_name.setdefault(image_id, image)
+        else:
+            image_id = int(image)
+        node = FeatureNode(image_id, feature_idx)
+        node.node_idx = len(self.nodes)
+        self.nodes.append(node)
+        return node.node_idx
+
+    def degrees(self):                                               # graph.cc:5-14
+        d = [0] * len(self.nodes)
+        for n in self.nodes:
+            d[n.node_idx] += len(n.out_matches)
+            for m in n.out_matches:
+                d[m.node_idx] += 1
+        return d
+
+    def scores(self):                                                # graph.cc:16-25 (the bound name; get_scores: same)
+        return [float(x) for x in self.get_scores()]
+
+    def edges(self):                                                 # graph.cc:27-36
+        return [(n.node_idx, m.node_idx, m.sim) for n in self.nodes for m in n.out_matches]
 
     def add_edge(self, node1, node2, sim):                           # graph.cc:59-64
         node1.out_matches.append(Match(node2.node_idx, sim))

@@ -123,6 +123,33 @@ class FeatureView:
     def channels(self):
         return self.feature_set.channels
 
+    # -- the rest of the pybind surface (features/bindings.cc:163-190) --
+    def mapping(self):                           # image id -> image name of the images with 3D points (featureview.cc:66-75)
+        rec = self.reconstruction
+        return {i: rec.images[i].name for i in rec.reg_image_ids() if any(p.has_point3D() for p in rec.images[i].points2D)}
+
+    def find_image_id(self, image_name):         # featureview.cc:316-323
+        for i, name in self.mapping().items():
+            if name == image_name:
+                return i
+        raise ValueError("image_name not found")
+
+    def fmap(self, image):                       # by image id or by name
+        return self.feature_set.fmap(image if isinstance(image, str) else self.reconstruction.images[image].name)
+
+    def reserved_memory(self):                   # featureview.cc:294-313: the patches this view requires
+        total = 0
+        for i, name in self.mapping().items():
+            if not self.feature_set.has_fmap(name):
+                continue
+            fm = self.feature_set.fmap(name)
+            if fm.is_sparse:
+                total += sum(fm.fpatch(k).num_bytes() for k, p in enumerate(self.reconstruction.images[i].points2D)
+                             if p.has_point3D() and fm.has_fpatch(k))
+            else:
+                total += fm.num_bytes()
+        return total
+
 
 def linear_solver_for(num_images):
     """SolveProblem's choice (bundle_optimizer.h:180-191), by the number of images OF THE SETUP (images that enter through
@@ -300,9 +327,9 @@ class ReferenceExtractor:
     def _references_of(self, ba, flat):
         """References of the flat problem `ba` (its device `refs` are filled in place) as {point3D_id: Reference}."""
         keep = bool(self.config['keep_observations'])
-        chosen, _ = ba.compute_references(self.interpolation.to_engine(),
-                                          make_loss(self.config['loss']['name'], self.config['loss']['params']),
-                                          iters=self.config['iters'], keep_observations=keep)
+        chosen, mean = ba.compute_references(self.interpolation.to_engine(),
+                                             make_loss(self.config['loss']['name'], self.config['loss']['params']),
+                                             iters=self.config['iters'], keep_observations=keep, keep_mean=keep)
         refs = ba.d["refs"].download()
         obs_desc = ba.obs_desc.download() if keep else None                 # reference_extractor.h:259-265
         obs_of_point = {}
@@ -315,6 +342,9 @@ class ReferenceExtractor:
                 image_id, p2d_idx = flat.obs_keys[int(chosen[k])]
                 out[pid] = features.Reference(image_id, p2d_idx, refs[k],
                                               observations=[obs_desc[i] for i in obs_of_point[k]] if keep else None)
+                if keep:   # ReferenceData (reference_extractor.h:256-265): the visible track and each observation's distance to the robust mean
+                    out[pid].track = [flat.obs_keys[i] for i in obs_of_point[k]]
+                    out[pid].costs = [float(((obs_desc[i] - mean[k]) ** 2).sum()) for i in obs_of_point[k]]
         return out
 
 

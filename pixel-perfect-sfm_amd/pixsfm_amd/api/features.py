@@ -10,6 +10,18 @@ import numpy as np
 kDenseId = 1000000      # util/src/types.h:33
 
 
+class _PatchStatus:
+    """features/src/featurepatch.h PatchStatus (bindings.cc:260-262)."""
+
+    def __init__(self, is_locked=True, reference_count=1):
+        self.is_locked, self.reference_count = bool(is_locked), int(reference_count)
+
+
+class _CallableList(list):
+    def __call__(self):
+        return self
+
+
 class FeaturePatch:
     """features/src/featurepatch.h:40-156: HWC data + corner (x0, y0) + scale (sx, sy)."""
 
@@ -26,6 +38,65 @@ class FeaturePatch:
     @property
     def shape(self):
         return self.data.shape
+
+    # -- the read-only properties / helpers of the pybind class (features/bindings.cc:47-76) --
+    height = property(lambda self: int(self.data.shape[0]))
+    width = property(lambda self: int(self.data.shape[1]))
+    channels = property(lambda self: int(self.data.shape[2]))
+    size = property(lambda self: int(self.data.size))
+
+    @property
+    def status(self):
+        """PatchStatus of a patch built from numpy: locked, one reference (featurepatch.cc:41-43); nothing is ever unloaded."""
+        return _PatchStatus(True, 1)
+
+    @property
+    def upsampling_factor(self):                 # featurepatch.h: 1 unless a cost-map extractor set it
+        return getattr(self, "_upsampling_factor", 1.0)
+
+    @upsampling_factor.setter
+    def upsampling_factor(self, value):
+        self._upsampling_factor = float(value)
+
+    def get_entry(self, y, x, c):                # featurepatch.cc GetEntry: data[(y W + x) C + c]
+        return self.data[int(y), int(x), int(c)]
+
+    def is_reference(self):                      # a view of caller memory (featurepatch.cc:45), never an owned copy
+        return True
+
+    def has_data(self):
+        return True
+
+    def data_ptr(self):
+        return self.data.ctypes.data
+
+    def num_bytes(self):                         # Size() * sizeof(dtype)
+        return int(self.data.nbytes)
+
+    def current_memory(self):                    # featurepatch.cc CurrentMemory: NumBytes() while data is held
+        return self.num_bytes()
+
+    def lock(self):
+        pass
+
+    def flush(self):                             # locked / referenced patches free nothing
+        return 0
+
+    def get_pixel_coords(self, xy):              # GetPixelCoordinatesVec
+        return self.to_pixel_coordinates(np.asarray(xy, dtype=np.float64).reshape(2))
+
+    def to_corner(self, xy, patch_size):         # featurepatch.cc:322-334
+        o = patch_size / 2.0
+        corner = np.trunc(self.get_pixel_coords(xy) - o).astype(np.int32)          # Eigen cast<int>: towards zero
+        corner = np.maximum(corner, 0)
+        return np.minimum(corner, np.array([self.width - patch_size, self.height - patch_size], np.int32))
+
+    def slice(self, xy, patch_size):             # featurepatch.cc:336-357: a patch_size window of a (dense) patch, copied
+        patch_size = int(patch_size)
+        if patch_size > self.width or patch_size > self.height:
+            raise ValueError("patch_size exceeds the patch")                    # THROW_CHECK_LE
+        c = self.to_corner(xy, patch_size)
+        return FeaturePatch(self.data[c[1]:c[1] + patch_size, c[0]:c[0] + patch_size].copy(), c, self.scale)
 
     def to_pixel_coordinates(self, xy):          # featurepatch.h:250-255
         return np.asarray(xy) * self.scale - 0.5 - self.corner
@@ -65,6 +136,44 @@ class FeatureMap:
     def keys(self):
         return list(self.patches.keys())
 
+    # -- the rest of the pybind surface (features/bindings.cc:89-113) --
+    fpatches = property(lambda self: self.patches)
+
+    def add_fpatch(self, point2D_idx, patch):    # featuremap.h:120-129
+        self.patches[int(point2D_idx)] = patch
+
+    def num_fpatches(self):
+        return len(self.patches)
+
+    @property
+    def channels(self):
+        for p in self.patches.values():
+            return p.shape[2]
+        return -1                                # FeatureMap(): channels_(-1)
+
+    def shape(self):                             # featuremap.h:136-156: [n, H, W, C]
+        out = [len(self.patches), 0, 0, self.channels]
+        for p in self.patches.values():
+            out[1] = out[1] or p.shape[0]
+            out[2] = out[2] or p.shape[1]
+        return out
+
+    @property
+    def size(self):
+        return sum(p.data.size for p in self.patches.values())
+
+    def num_bytes(self):
+        return sum(p.data.nbytes for p in self.patches.values())
+
+    def current_memory(self):
+        return self.num_bytes()
+
+    def lock(self):
+        pass
+
+    def flush(self):
+        return 0
+
 
 class FeatureSet:
     """One feature level: image name -> FeatureMap (features/src/featureset.h)."""
@@ -87,6 +196,35 @@ class FeatureSet:
                     return p.shape[2]
         return self._channels
 
+    # -- the rest of the pybind surface (features/bindings.cc:126-147); the cache bookkeeping of H5-backed sets has nothing
+    # to do here: everything is resident --
+    def keys(self):
+        return list(self.fmaps.keys())
+
+    def add_fmap(self, name, fmap):              # featureset.h AddFeatureMap
+        self.fmaps[name] = fmap
+
+    def emplace(self, name, fmap):
+        self.fmaps.setdefault(name, fmap)
+
+    def num_bytes(self):
+        return sum(fm.num_bytes() for fm in self.fmaps.values())
+
+    def current_memory(self):
+        return self.num_bytes()
+
+    def lock(self):
+        pass
+
+    def flush(self):
+        return 0
+
+    def flush_every_n(self, n):
+        pass
+
+    def use_parallel_io(self, do_parallel):
+        pass
+
     def _first_patch(self):
         for fm in self.fmaps.values():
             for p in fm.patches.values():
@@ -98,7 +236,7 @@ class FeatureManager:
     """features/src/featuremanager.h: one FeatureSet per feature level."""
 
     def __init__(self, fsets):
-        self.fsets = list(fsets)
+        self.fsets = _CallableList(fsets)        # `.fsets` here, `.fsets()` in the pybind class: both work
 
     @property
     def num_levels(self):
@@ -106,6 +244,15 @@ class FeatureManager:
 
     def fset(self, level_index):
         return self.fsets[level_index]
+
+    def num_bytes(self):
+        return sum(fs.num_bytes() for fs in self.fsets)
+
+    def current_memory(self):
+        return self.num_bytes()
+
+    def lock(self):
+        pass
 
 
 class Reference:
@@ -116,6 +263,11 @@ class Reference:
         self.descriptor = np.asarray(descriptor, dtype=np.float64).reshape(1, -1)
         # per-observation descriptors (references.h:52-60), used by "all"-reference localization
         self.observations = [np.asarray(o, dtype=np.float64).reshape(1, -1) for o in (observations or [])]
+        self.costs = []          # per-observation squared distances to the robust mean (reference_extractor.h:259-265)
+        self.track = []          # the visible track the observations belong to, as (image_id, point2D_idx)
+
+    channels = property(lambda self: int(self.descriptor.shape[1]))
+    n_nodes = property(lambda self: int(self.descriptor.shape[0]))
 
     def has_observations(self):
         return len(self.observations) > 0
@@ -225,6 +377,12 @@ class PatchInterpolator:
 
     def interpolate(self, fpatch, xy):
         return self.interpolate_nodes(fpatch, xy).reshape(-1)
+
+    def interpolate_local(self, fpatch, xy):
+        """InterpolateLocal (dynamic_patch_interpolator.h:125-132): `xy` in the patch's own pixel coordinates (column, row), no
+        image -> patch transform."""
+        local = FeaturePatch(fpatch.data, (0, 0), (1.0, 1.0))
+        return self.interpolate(local, np.asarray(xy, dtype=np.float64).reshape(2) + 0.5)
 
 
 def load_features_from_cache(cache_path, fill=True, level_prefix="", ctx=None, device=False, required=None):

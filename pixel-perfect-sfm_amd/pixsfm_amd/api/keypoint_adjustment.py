@@ -155,9 +155,10 @@ class FeatureMetricKeypointOptimizer:
     def _run(self, problem_labels, keypoints, graph, track_labels, root_labels, feature_set, nodes_in_problem=None):
         if keypoints is None:
             raise ValueError("keypoints cannot be NULL.")                       # topological_keypoint_optimizer.h:73-74
-        if self._used:
+        if self._used and not getattr(self, "_resolving", False):
             raise ValueError("Cannot use the same KeypointOptimizer multiple times")   # :75-77
         self._used = True
+        self._last = (problem_labels, keypoints, graph, track_labels, root_labels, feature_set, nodes_in_problem)
         n = len(graph.nodes)
         if len(track_labels) != n or len(root_labels) != n or (problem_labels is not None and len(problem_labels) != n):
             raise ValueError("label arrays must have one entry per graph node")  # THROW_CHECK_EQ, featuremetric_keypoint_optimizer.h:82-85
@@ -228,6 +229,17 @@ class FeatureMetricKeypointOptimizer:
 
     def summary(self):
         return self._summary
+
+    def solve_problem(self):
+        """SolveProblem (keypoint_optimizer.h:77-107, bindings.cc:32): solve the problem of the last run() / run_subset() again,
+        starting from the keypoints as they are now."""
+        if getattr(self, "_last", None) is None:
+            raise ValueError("no problem has been set up: call run() first")
+        self._resolving = True
+        try:
+            return self._run(*self._last)
+        finally:
+            self._resolving = False
 
 
 class TopologicalReferenceKeypointOptimizer(FeatureMetricKeypointOptimizer):

@@ -240,6 +240,10 @@ def test_reference_extractor_keep_observations_and_find_nearest(ctx):
         assert r.has_observations() and len(r.observations) == rec.points3D[pid].track.length()
         d = np.array([np.linalg.norm(o - r.descriptor) for o in r.observations])
         assert d.min() < 1e-12                              # the reference IS one of the observations (closest to the mean)
+        # ReferenceData (reference_extractor.h:256-265): the visible track and each observation's squared distance to the robust
+        # mean; the chosen observation is the one with the smallest cost, and it is the source
+        assert r.track == [(e.image_id, e.point2D_idx) for e in rec.points3D[pid].track.elements] and len(r.costs) == len(r.track)
+        assert r.track[int(np.argmin(r.costs))] == r.source and int(np.argmin(r.costs)) == int(np.argmin(d))
     # query = observations of image 0, keypoints at their detections
     im = rec.images[min(rec.images)]
     idxs = [k for k, p in enumerate(im.points2D) if p.has_point3D()]
@@ -637,3 +641,19 @@ def test_iteration_callbacks_of_the_bundle_adjustment(ctx):
     assert s_ok["iterations"] == 1 and s_ok["termination"] == 0 and abs(s_ok["final_cost"] - seen[1][3]) <= 1e-10 * seen[1][3]
     s0 = run([lambda it: 2])
     assert s0["iterations"] == 0 and s0["final_cost"] == s0["initial_cost"]
+
+
+def test_patch_interpolator_local_coordinates(ctx):
+    """PatchInterpolator.interpolate_local (dynamic_patch_interpolator.h:125-132): the keypoint in the patch's own pixel
+    coordinates (column, row) -- PixelInterpolator::Evaluate(r = xy[1], c = xy[0]) without the image -> patch transform."""
+    import pxo
+    from pixsfm_amd.api import features
+    rng = np.random.default_rng(8)
+    data = rng.normal(size=(16, 16, 128)).astype(np.float16)
+    fpatch = features.FeaturePatch(data, (37, 91), (0.5, 0.25))            # corner and scale must not matter
+    interp = features.PatchInterpolator({"l2_normalize": True}, ctx=ctx)
+    patch = pxo.make_patch(data, (37, 91), (0.5, 0.25))
+    for xy in ([7.3, 4.9], [0.2, 14.6], [11.0, 3.0]):
+        got = interp.interpolate_local(fpatch, xy)
+        want = pxo.pixel_interp(patch, xy[1], xy[0], pxo.cfg())[0]
+        assert got.shape == (128,) and np.abs(got - want).max() < 1e-12

@@ -74,9 +74,18 @@ def reference_pixsfm():
         @staticmethod
         def to_container(cfg, resolve=False):
             return _Cfg.unwrap(cfg)
+
+        @staticmethod
+        def resolve(cfg):
+            pass
     om.OmegaConf, om.DictConfig = OmegaConf, _Cfg
+    om_sub = types.ModuleType("omegaconf.omegaconf")
+    om_sub.OmegaConf, om_sub.DictConfig = OmegaConf, _Cfg
+    om.omegaconf = om_sub
+    sys.modules["omegaconf.omegaconf"] = om_sub
     pyceres = types.ModuleType("pyceres")
     pyceres.ListIterationCallback = list
+    pyceres.IterationCallback = object
     from pixsfm_amd.api import reconstruction as rec_mod
     pycolmap = types.ModuleType("pycolmap")
     pycolmap.Reconstruction = rec_mod.Reconstruction
@@ -93,7 +102,7 @@ def reference_pixsfm():
     pkg.features = feats
     yield importlib.import_module
     for k in list(sys.modules):                 # only what this fixture registered (never torch & co.)
-        if k == "pixsfm" or k.startswith("pixsfm.") or k in ("omegaconf", "pyceres", "pycolmap"):
+        if k == "pixsfm" or k.startswith("pixsfm.") or k in ("omegaconf", "omegaconf.omegaconf", "pyceres", "pycolmap"):
             if k in saved:
                 sys.modules[k] = saved[k]
             else:
@@ -198,3 +207,54 @@ def test_reference_bundle_adjuster_runs_on_the_adapter(reference_pixsfm):
             adjuster.refine_multilevel(rec, fmanager)
     with pytest.raises(NotImplementedError):
         ba_main.BundleAdjuster.create(OmegaConf.create({"strategy": "geometric"})).refine(rec, fmanager.fset(0))
+
+
+
+def test_reference_query_adjusters_run_on_the_adapter(reference_pixsfm):
+    """pixsfm/localization/main.py, unmodified: QueryKeypointAdjuster / QueryBundleAdjuster construct the adapter's optimizers
+    from their own default_conf (every key of it must be a field of the option structs) and drive them; the file's pure-Python
+    helpers run as they are.  The CNN extractor, the cache loader and the config lookup it imports are outside the path
+    (stubbed); QueryLocalizer's PnP needs pycolmap."""
+    import torch
+    from pixsfm_amd import PixsfmHipError, synthetic, synthetic_ka
+    from pixsfm_amd.api import features
+    for name, attrs in (("pixsfm.features.extractor", {"FeatureExtractor": type("FeatureExtractor", (), {"default_conf": {}})}),
+                        ("pixsfm.extract", {"features_from_reconstruction": None, "load_features_from_cache": None}),
+                        ("pixsfm.configs", {"parse_config_path": lambda p: p})):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+    sys.modules["pixsfm.features"].FeatureManager = features.FeatureManager
+    sys.modules["pycolmap"].Camera = object
+    loc_main = reference_pixsfm("pixsfm.localization.main")                 # the reference's file, unmodified
+    assert loc_main.__file__.startswith(REF)
+    # pure-Python helpers of the file
+    assert loc_main.find_unique_inliers([3, 3, 5, 3], [True, False, True, True]) == [True, False, True, False]
+    assert loc_main.find_unique_min_by_group([0.5, 0.2, 0.9, 0.1], [7, 7, 8, 8]) == [False, True, False, True]
+    # QKA: one keypoint per track of a small KA scene, references = descriptors at the true positions
+    base_ = synthetic_ka.make_ka_problem(n_tracks=8, track_len=2, seed=5, sigma=0.5, channels=128)
+    q = np.arange(0, 16, 2)
+    fmap = features.FeatureMap.from_arrays(base_["patches"][q], np.arange(8), base_["corners"][q], (1.0, 1.0))
+    refs = [np.full((1, 128), 1.0 / np.sqrt(128.0)) for _ in q]
+    qka = loc_main.QueryKeypointAdjuster({"optimizer": {"bound": 2.0}})
+    assert qka.conf.optimizer.bound == 2.0 and qka.conf.optimizer.solver.parameter_tolerance == 1e-05
+    assert type(qka.solver).__name__ == "QueryKeypointOptimizer" and qka.solver.options["bound"] == 2.0
+    kp = base_["kp"][q].copy()
+    # QBA: image 0 of a small BA scene
+    full = synthetic.make_ba_problem(n_cams=3, n_points=30, obs_per_point=2, seed=6, model=2)
+    sel = np.nonzero(full["obs_image"] == 0)[0]
+    from pixsfm_amd.api.reconstruction import Camera
+    cam = Camera(1, 2, 1000, 1000, full["cam_params"][full["image_camera"][0], :4].copy())
+    qfmap = features.FeatureMap.from_arrays(full["patches"][sel], np.arange(len(sel)), full["corners"][sel], (1.0, 1.0))
+    qba = loc_main.QueryBundleAdjuster({"optimizer": {"refine_focal_length": True}})
+    assert qba.solver.options["refine_focal_length"] is True and qba.solver.options["loss"]["name"] == "cauchy"
+    args = (full["qvec"][0].copy(), full["tvec"][0].copy(), cam, [full["gt_xyz"][p].copy() for p in full["obs_point"][sel]], qfmap,
+            [full["refs"][p].copy() for p in full["obs_point"][sel]])
+    if torch.cuda.is_available():
+        qka.refine(kp, fmap, refs)
+        assert qba.refine(*args)
+    else:
+        with pytest.raises(PixsfmHipError, match="pxr_ctx_create"):
+            qka.refine(kp, fmap, refs)
+        with pytest.raises(PixsfmHipError, match="pxr_ctx_create"):
+            qba.refine(*args)

@@ -66,18 +66,27 @@ class Context:
         """ceres::IterationCallback objects for the BA solves of this context (pxr_set_iteration_callback): each callable gets
         the iteration summary (attributes iteration, step_is_valid, step_is_successful, cost, cost_change, relative_decrease,
         trust_region_radius, step_norm) and returns None / 0 to continue, 1 to abort, 2 to terminate successfully; the largest
-        answer wins.  An empty list removes the hook."""
+        answer wins.  An empty list removes the hook -- and re-raises an exception a callback raised during the solve (which
+        was aborted at that iteration)."""
         callbacks = list(callbacks or [])
         if not callbacks:
             check(self.lib.pxr_set_iteration_callback(self.handle, None, None), "pxr_set_iteration_callback")
             self._iter_cb = None
+            pending, self._iter_exc = getattr(self, "_iter_exc", None), None
+            if pending is not None:          # an exception raised inside a callback aborted the solve: it surfaces here
+                raise pending
             return
+        self._iter_exc = None
 
         def hook(summary, _user):
             rc = 0
-            for cb in callbacks:
-                ans = cb(summary.contents)
-                rc = max(rc, int(getattr(ans, "value", ans) or 0))
+            try:
+                for cb in callbacks:
+                    ans = cb(summary.contents)
+                    rc = max(rc, int(getattr(ans, "value", ans) or 0))
+            except BaseException as e:       # noqa: BLE001 -- ctypes would print and swallow it; abort the solve instead
+                self._iter_exc = e
+                return 1
             return rc
         self._iter_cb = _lib.ITERATION_CALLBACK(hook)            # kept alive as long as it is installed
         check(self.lib.pxr_set_iteration_callback(self.handle, C.cast(self._iter_cb, C.c_void_p), None), "pxr_set_iteration_callback")

@@ -642,6 +642,13 @@ def test_iteration_callbacks_of_the_bundle_adjustment(ctx):
     s0 = run([lambda it: 2])
     assert s0["iterations"] == 0 and s0["final_cost"] == s0["initial_cost"]
 
+    # an exception inside a callback aborts the solve at that iteration and surfaces when the hook is removed
+    def boom(it):
+        if it.iteration == 1:
+            raise KeyError("from the callback")
+    with pytest.raises(KeyError, match="from the callback"):
+        run([boom])
+
 
 def test_patch_interpolator_local_coordinates(ctx):
     """PatchInterpolator.interpolate_local (dynamic_patch_interpolator.h:125-132): the keypoint in the patch's own pixel

@@ -183,3 +183,30 @@ def test_shard_ba_problem_partitions_points_and_replicates_cameras():
     owner = assign_problems_to_ranks([9, 1, 8, 2, 7, 3], 2)
     load = [sum(s for s, o in zip([9, 1, 8, 2, 7, 3], owner) if o == r) for r in range(2)]
     assert abs(load[0] - load[1]) <= 2
+
+
+def test_iteration_callback_hook_logic_without_a_gpu():
+    """Context.set_iteration_callbacks: the largest answer of the callbacks wins, None counts as continue, an exception inside a
+    callback becomes SOLVER_ABORT and is re-raised when the hook is removed (ctypes alone would print it and return garbage)."""
+    import ctypes as C
+    from pixsfm_amd import _lib, engine
+
+    class FakeLib:
+        def pxr_set_iteration_callback(self, handle, fn, user):
+            return 0
+    ctx = engine.Context.__new__(engine.Context)
+    ctx.lib, ctx.handle = FakeLib(), None
+    summary = _lib.IterationSummary(iteration=3, cost=2.5)
+    seen = []
+    ctx.set_iteration_callbacks([lambda it: seen.append((it.iteration, it.cost)), lambda it: 2 if it.iteration == 3 else 0])
+    assert ctx._iter_cb(C.pointer(summary), None) == 2 and seen == [(3, 2.5)]
+    ctx.set_iteration_callbacks(None)
+
+    def bad(it):
+        raise KeyError("boom")
+    ctx.set_iteration_callbacks([bad])
+    assert ctx._iter_cb(C.pointer(summary), None) == 1
+    with pytest.raises(KeyError, match="boom"):
+        ctx.set_iteration_callbacks(None)
+    ctx.set_iteration_callbacks(None)                       # nothing pending any more
+    ctx.handle = None

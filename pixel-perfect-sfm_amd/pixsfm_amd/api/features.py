@@ -22,11 +22,35 @@ class _CallableList(list):
         return self
 
 
+class TrackElementTuple(tuple):
+    """colmap::TrackElement as the reference exposes it (.image_id, .point2D_idx) that also IS the (image_id, point2D_idx)
+    tuple this package used before."""
+
+    def __new__(cls, image_id, point2D_idx):
+        return super().__new__(cls, (int(image_id), int(point2D_idx)))
+
+    image_id = property(lambda self: self[0])
+    point2D_idx = property(lambda self: self[1])
+
+
+class TrackList(list):
+    """colmap::Track surface (.elements, .length()) over a list of track elements."""
+
+    elements = property(lambda self: list(self))
+
+    def length(self):
+        return len(self)
+
+
 class FeaturePatch:
     """features/src/featurepatch.h:40-156: HWC data + corner (x0, y0) + scale (sx, sy)."""
 
-    def __init__(self, data, corner=(0, 0), scale=(1.0, 1.0)):
-        data = np.asarray(data)
+    def __init__(self, inarray=None, offset=(0, 0), scale=(1.0, 1.0), do_copy=False, data=None, corner=None):
+        """(inarray, offset, scale, do_copy) like the pybind constructor (features/bindings.cc:47-53: `offset` is the corner
+        (x0, y0)); `data` / `corner` are this package's own names for the first two."""
+        data = inarray if data is None else data
+        corner = offset if corner is None else corner
+        data = np.array(data) if do_copy else np.asarray(data)
         if data.ndim != 3:
             raise ValueError("FeaturePatch expects an H x W x C array")
         if data.dtype not in (np.float16, np.float32, np.float64):
@@ -108,7 +132,21 @@ class FeaturePatch:
 class FeatureMap:
     """Patches of one image keyed by keypoint index (features/src/featuremap.h:104-118)."""
 
-    def __init__(self, patches=None, is_sparse=True):
+    def __init__(self, patches=None, point2D_ids=None, corners=None, metadata=None, is_sparse=True):
+        """FeatureMap({keypoint id: FeaturePatch}, is_sparse=...), or the reference's numpy constructor
+        FeatureMap(patches [N][H][W][C], point2D_ids, corners, metadata) (featuremap.cc:8-45; extract.py:131-139): patch i is a
+        view of patches[i] at corners[i] with metadata['scale']; a dense map (metadata['is_sparse'] false) holds ONE patch
+        under kDenseId."""
+        if isinstance(patches, np.ndarray):
+            if patches.ndim != 4:
+                raise ValueError("patches must be N x H x W x C")                   # THROW_CHECK_EQ(shape.size(), 4)
+            self.is_sparse = bool(metadata["is_sparse"])
+            if not self.is_sparse and len(patches) != 1:
+                raise ValueError("a dense feature map holds exactly one patch")     # THROW_CHECK(is_sparse_ || n_patches == 1)
+            scale = np.asarray(metadata["scale"], dtype=np.float64).reshape(2)
+            self.patches = {(int(point2D_ids[i]) if self.is_sparse else kDenseId): FeaturePatch(patches[i], corners[i], scale)
+                            for i in range(len(patches))}
+            return
         self.patches = dict(patches or {})
         self.is_sparse = is_sparse
 
@@ -178,8 +216,11 @@ class FeatureMap:
 class FeatureSet:
     """One feature level: image name -> FeatureMap (features/src/featureset.h)."""
 
-    def __init__(self, fmaps=None, channels=None):
-        self.fmaps = dict(fmaps or {})
+    def __init__(self, feature_dict=None, channels=None, fmaps=None):
+        """FeatureSet(feature_dict, channels) / FeatureSet(channels) like the pybind constructors (features/bindings.cc:127-130)."""
+        if isinstance(feature_dict, (int, np.integer)) and channels is None:
+            feature_dict, channels = None, int(feature_dict)
+        self.fmaps = dict(fmaps if fmaps is not None else (feature_dict or {}))
         self._channels = channels
 
     def fmap(self, image_name):
@@ -235,7 +276,15 @@ class FeatureSet:
 class FeatureManager:
     """features/src/featuremanager.h: one FeatureSet per feature level."""
 
-    def __init__(self, fsets):
+    def __init__(self, fsets, dummy=None, level_prefix=""):
+        """FeatureManager([FeatureSet, ...]); or like the pybind constructors (features/bindings.cc:235-237):
+        FeatureManager(channels_per_level, dtype_array) -> empty sets to emplace() maps into (extract.py:95-96), and
+        FeatureManager(h5_path, fill, level_prefix) -> the cache reader (load_features_from_cache)."""
+        if isinstance(fsets, (str, bytes)) or hasattr(fsets, "__fspath__"):
+            loaded = load_features_from_cache(fsets, fill=True if dummy is None else bool(dummy), level_prefix=level_prefix)
+            fsets = list(loaded.fsets)
+        elif len(fsets) and all(isinstance(c, (int, np.integer)) for c in fsets):
+            fsets = [FeatureSet(channels=int(c)) for c in fsets]
         self.fsets = _CallableList(fsets)        # `.fsets` here, `.fsets()` in the pybind class: both work
 
     @property
@@ -258,13 +307,28 @@ class FeatureManager:
 class Reference:
     """features/src/references.h:29-72 (N_NODES = 1): source observation + 1 x C descriptor."""
 
-    def __init__(self, image_id, point2D_idx, descriptor, observations=None):
-        self.source = (int(image_id), int(point2D_idx))
-        self.descriptor = np.asarray(descriptor, dtype=np.float64).reshape(1, -1)
+    def __init__(self, image_id=0, point2D_idx=0, descriptor=None, observations=None, costs=None, source=None, track=None):
+        """Reference(image_id, point2D_idx, descriptor, observations), or by keyword like the pybind struct (features/bindings.cc:
+        264-274; store_references.py:45-53): Reference(descriptor=, observations=, costs=, source=TrackElement, track=Track)."""
+        if source is not None:
+            image_id, point2D_idx = source.image_id, source.point2D_idx
+        self.source = TrackElementTuple(int(image_id), int(point2D_idx))
+        self.descriptor = np.zeros((1, 0)) if descriptor is None else np.asarray(descriptor, dtype=np.float64).reshape(1, -1)
         # per-observation descriptors (references.h:52-60), used by "all"-reference localization
-        self.observations = [np.asarray(o, dtype=np.float64).reshape(1, -1) for o in (observations or [])]
-        self.costs = []          # per-observation squared distances to the robust mean (reference_extractor.h:259-265)
-        self.track = []          # the visible track the observations belong to, as (image_id, point2D_idx)
+        self.observations = [np.asarray(o, dtype=np.float64).reshape(1, -1) for o in (observations if observations is not None else [])]
+        # per-observation squared distances to the robust mean, and the visible track they belong to (reference_extractor.h:259-265)
+        self.costs = [float(c) for c in (costs if costs is not None else [])]
+        self.track = track if track is not None else []
+
+    @property
+    def track(self):
+        return self._track
+
+    @track.setter
+    def track(self, value):
+        elems = getattr(value, "elements", value)
+        self._track = TrackList(TrackElementTuple(int(e.image_id), int(e.point2D_idx)) if hasattr(e, "image_id")
+                                else TrackElementTuple(int(e[0]), int(e[1])) for e in elems)
 
     channels = property(lambda self: int(self.descriptor.shape[1]))
     n_nodes = property(lambda self: int(self.descriptor.shape[0]))

@@ -165,3 +165,36 @@ def test_option_structs_behave_like_make_dataclass():
     # the optimizers take the structs as they take dicts
     opt = ka.FeatureMetricKeypointOptimizer(f, None, None)
     assert opt.options["bound"] == 4.0 and opt.options["solver"]["max_num_iterations"] == 7
+
+
+def test_containers_accept_the_pybind_constructor_forms():
+    """How the reference's own Python builds them: FeatureManager(channels_per_level, dtype_array) + fset(l).emplace(name,
+    FeatureMap(patches, keypoint_ids, corners, metadata)) (extract.py:95-139), FeaturePatch(inarray, offset, scale, do_copy)
+    (features/bindings.cc:47-53), Reference(descriptor=, observations=, costs=, source=, track=) (store_references.py:45-53)."""
+    from pixsfm_amd._pixsfm import _features as ft
+    from pixsfm_amd.api.reconstruction import Track, TrackElement
+    rng = np.random.default_rng(0)
+    patches = rng.normal(size=(3, 4, 4, 8)).astype(np.float16)
+    corners = np.array([[1, 2], [3, 4], [5, 6]])
+    meta = {"is_sparse": True, "scale": np.array([0.5, 0.25]), "patch_size": 4}
+    mgr = ft.FeatureManager([8, 8], np.array([0], np.float16))
+    assert mgr.num_levels == 2 and mgr.fset(1).channels == 8 and mgr.fset(0).keys() == []
+    mgr.fset(0).emplace("a.jpg", ft.FeatureMap(patches, [10, 20, 30], corners, meta))
+    fm = mgr.fset(0).fmap("a.jpg")
+    assert fm.is_sparse and sorted(fm.keys()) == [10, 20, 30] and fm.shape() == [3, 4, 4, 8]
+    p = fm.fpatch(20)
+    assert np.array_equal(p.data, patches[1]) and np.array_equal(p.corner, [3, 4]) and np.array_equal(p.scale, [0.5, 0.25])
+    assert np.shares_memory(p.data, patches)                      # a view, like the reference's numpy-backed patches
+    dense = ft.FeatureMap(patches[:1], [7], corners[:1], {"is_sparse": False, "scale": np.ones(2)})
+    assert not dense.is_sparse and dense.keys() == [ft.kDenseId] and dense.fpatch(123) is dense.fpatch(0)
+    with pytest.raises(ValueError):
+        ft.FeatureMap(patches, [1, 2, 3], corners, {"is_sparse": False, "scale": np.ones(2)})
+    q = ft.FeaturePatch(inarray=patches[0], offset=np.array([9, 8]), scale=np.array([2.0, 2.0]), do_copy=True)
+    assert np.array_equal(q.corner, [9, 8]) and not np.shares_memory(q.data, patches)
+    fs = ft.FeatureSet(feature_dict={"a.jpg": fm}, channels=8)
+    assert fs.has_fmap("a.jpg") and ft.FeatureSet(8).channels == 8
+    r = ft.Reference(descriptor=np.ones((1, 8)), observations=[np.zeros((1, 8)), np.ones((1, 8))], costs=[8.0, 0.0],
+                     source=TrackElement(3, 5), track=Track([TrackElement(3, 5), TrackElement(4, 1)]))
+    assert (r.source.image_id, r.source.point2D_idx) == (3, 5) and r.source == (3, 5) and r.has_observations()
+    assert [(e.image_id, e.point2D_idx) for e in r.track.elements] == [(3, 5), (4, 1)] and r.track.length() == 2 and r.costs == [8.0, 0.0]
+    assert ft.Reference().channels == 0 and not ft.Reference().has_observations()

@@ -39,7 +39,11 @@ Rccl* rccl() {
     }
     const char* paths[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (size_t i = 0; !r.handle && i < sizeof(paths) / sizeof(paths[0]); ++i) r.handle = dlopen(paths[i], RTLD_NOW | RTLD_GLOBAL);
-    if (!r.handle) { r.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
+    if (!r.handle) {
+      const char* why = dlerror();             // ONE call: dlerror() clears the message it returns
+      r.error = std::string("librccl not found: ") + (why ? why : "?");
+      return;
+    }
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");

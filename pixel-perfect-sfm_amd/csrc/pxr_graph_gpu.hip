@@ -76,6 +76,12 @@ __global__ void g_scatter(int64_t m, const int64_t* __restrict__ key_node, const
   out[atomicAdd(cursor + k, 1)] = (int)e;
 }
 
+constexpr int kMaxComponentMatches = 32768;   // ~0.3 s of one wavefront; beyond it the host is faster
+__global__ void g_max(int n, const int* __restrict__ cnt, int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && cnt[i] > 0) atomicMax(out, cnt[i]);
+}
+
 // exclusive scan of a[0..n) in place, a[n] = total: one workgroup, every thread a contiguous chunk
 __global__ __launch_bounds__(1024) void g_scan(int n, int* __restrict__ a) {
   __shared__ int part[1024];
@@ -258,7 +264,8 @@ extern "C" int pxr_graph_labels_device(pxr_ctx* ctx, int64_t n_nodes, const int3
   PXR_REQUIRE(!(h_flag[0] & 2), "pxr_graph_labels_device: matches must be in Graph order (grouped by ascending source node)");
   // 1. components
   hipLaunchKernelGGL(g_iota, dim3(gblk(n)), dim3(256), 0, st, n, comp);
-  for (int round = 0; m > 0 && round < 64; ++round) {
+  for (int64_t round = 0; m > 0; ++round) {             // until no label moves (hook + full pointer jumping: O(log n) rounds)
+    PXR_REQUIRE(round <= (int64_t)n + 1, "pxr_graph_labels_device: the component labelling did not converge");
     PXR_HIP(hipMemsetAsync(flag + 1, 0, 4, st));
     hipLaunchKernelGGL(g_hook, dim3(gblk(m)), dim3(256), 0, st, m, d_edge_src, d_edge_dst, comp, flag + 1);
     hipLaunchKernelGGL(g_jump, dim3(gblk(n)), dim3(256), 0, st, n, comp, flag + 1);
@@ -269,6 +276,17 @@ extern "C" int pxr_graph_labels_device(pxr_ctx* ctx, int64_t n_nodes, const int3
   // 2. buckets of edges per component (keyed by the component of the source node)
   PXR_HIP(hipMemsetAsync(ptr, 0, sizeof(int) * ((size_t)n + 1), st));
   if (m > 0) hipLaunchKernelGGL(g_count, dim3(gblk(m)), dim3(256), 0, st, m, d_edge_src, (const int*)comp, ptr);
+  if (m > 0) {
+    // g_component orders a component's matches with an O(m_c^2) rank sort in ONE wavefront: fine for tracks-sized
+    // components, quadratic when bad matches chain a scene into one giant component -- refuse those (the caller
+    // falls back to the host labelling, pxr_graph_track_labels) instead of running a single wave for minutes
+    hipLaunchKernelGGL(g_max, dim3(gblk(n)), dim3(256), 0, st, n, (const int*)ptr, flag + 2);
+    PXR_HIP(hipMemcpyAsync(h_flag, flag + 2, 4, hipMemcpyDeviceToHost, st));
+    PXR_HIP(hipStreamSynchronize(st));
+    if (h_flag[0] > kMaxComponentMatches)
+      return set_error(PXR_EUNSUPPORTED, "pxr_graph_labels_device: a connected component holds %d matches (limit %d): label on the host",
+                       h_flag[0], kMaxComponentMatches);
+  }
   hipLaunchKernelGGL(g_scan, dim3(1), dim3(1024), 0, st, n, ptr);
   PXR_HIP(hipMemcpyAsync(cursor, ptr, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToDevice, st));
   if (m > 0) hipLaunchKernelGGL(g_scatter, dim3(gblk(m)), dim3(256), 0, st, m, d_edge_src, (const int*)comp, cursor, bucket);

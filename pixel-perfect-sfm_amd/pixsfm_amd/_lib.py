@@ -18,7 +18,10 @@ LOSS_IDS = {"trivial": 0, "cauchy": 1, "huber": 2, "soft_l1": 3}
 
 
 class PixsfmHipError(RuntimeError):
-    pass
+    code = 0
+
+
+PXR_EUNSUPPORTED = -4
 
 
 class InterpCfg(C.Structure):
@@ -186,4 +189,6 @@ def load():
 def check(rc, what=""):
     if rc != 0:
         msg = load().pxr_last_error()
-        raise PixsfmHipError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
+        err = PixsfmHipError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
+        err.code = int(rc)
+        raise err

@@ -198,8 +198,17 @@ def compute_labels_on_device(graph, ctx=None):
                                                                     (sim, np.float64)))
     labels, scores, roots = ctx.empty((max(n, 1),), np.int64), ctx.empty((max(n, 1),), np.float64), ctx.empty((max(n, 1),), np.uint8)
     n_tracks = C.c_int64()
-    _lib.check(ctx.lib.pxr_graph_labels_device(ctx.handle, n, d_img.ptr, len(src), d_src.ptr, d_dst.ptr, d_sim.ptr, labels.ptr,
-                                               scores.ptr, roots.ptr, C.byref(n_tracks)), "pxr_graph_labels_device")
+    try:
+        _lib.check(ctx.lib.pxr_graph_labels_device(ctx.handle, n, d_img.ptr, len(src), d_src.ptr, d_dst.ptr, d_sim.ptr, labels.ptr,
+                                                   scores.ptr, roots.ptr, C.byref(n_tracks)), "pxr_graph_labels_device")
+    except _lib.PixsfmHipError as e:
+        if e.code != _lib.PXR_EUNSUPPORTED:
+            raise
+        # one giant connected component (bad matches chaining tracks): the device kernel's per-component rank sort is
+        # quadratic in ONE wavefront there -- the native host labelling (the reference's own shape, graph.cc) takes over
+        track_labels = compute_track_labels(graph)
+        score_labels = compute_score_labels(graph, track_labels)
+        return track_labels, np.asarray(score_labels), compute_root_labels(graph, track_labels, score_labels)
     return labels.download()[:n].tolist(), scores.download()[:n], [bool(r) for r in roots.download()[:n]]
 
 

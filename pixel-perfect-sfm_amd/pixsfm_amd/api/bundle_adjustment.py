@@ -322,7 +322,7 @@ class ReferenceExtractor:
             ba = BAProblem(ctx, arena, part.problem_dict(np.zeros((len(part.point_ids), arena.C)), arena.index))
             out = self._references_of(ba, part)
             arena.close()
-        return out if world == 1 else parallel.gather_dicts(out)
+        return out if world == 1 else parallel.gather_references(out)
 
     def _references_of(self, ba, flat):
         """References of the flat problem `ba` (its device `refs` are filled in place) as {point3D_id: Reference}."""

@@ -29,6 +29,9 @@ class TrackElementTuple(tuple):
     def __new__(cls, image_id, point2D_idx):
         return super().__new__(cls, (int(image_id), int(point2D_idx)))
 
+    def __getnewargs__(self):                    # pickle / copy re-create through __new__(cls, image_id, point2D_idx)
+        return (self[0], self[1])
+
     image_id = property(lambda self: self[0])
     point2D_idx = property(lambda self: self[1])
 

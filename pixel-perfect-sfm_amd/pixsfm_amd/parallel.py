@@ -72,17 +72,62 @@ def ensure_collective(ctx, group=None):
     return make_allreduce(group, ctx)
 
 
-def gather_dicts(local, group=None):
-    """Union of per-rank dicts with disjoint keys (e.g. {point3D_id: Reference}) on every rank."""
+def allgather_rows(array, group=None):
+    """Every rank contributes an (n_r, ...) array (n_r may differ, trailing shape and dtype agree); returns the list of
+    all ranks' arrays on every rank.  Two tensor collectives (row counts, rows padded to the longest) -- no pickling."""
+    import torch
     import torch.distributed as dist
+    rank, n = world(group)
+    array = np.ascontiguousarray(array)
+    if n == 1:
+        return [array]
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(n)]
+    dist.all_gather(counts, torch.tensor([array.shape[0]], dtype=torch.int64, device=dev), group=group)
+    counts = [int(c.item()) for c in counts]
+    longest = max(counts)
+    if longest == 0:
+        return [array[:0].copy() for _ in range(n)]
+    padded = np.zeros((longest,) + array.shape[1:], dtype=array.dtype)
+    padded[:array.shape[0]] = array
+    mine = torch.from_numpy(padded).to(dev)
+    parts = [torch.empty_like(mine) for _ in range(n)]
+    dist.all_gather(parts, mine, group=group)
+    return [parts[r][:counts[r]].cpu().numpy() for r in range(n)]
+
+
+def gather_references(local, group=None):
+    """Union of per-rank {point3D_id: Reference} dicts with disjoint keys on every rank.  What a Reference carries
+    (features/src/references.h:29-72: source observation, 1 x C descriptor, optionally the per-observation descriptors,
+    their costs and the visible track) travels as flat arrays -- ids, descriptor rows, per-reference lengths and the
+    concatenated variable-length parts -- through allgather_rows; the objects are rebuilt locally."""
+    from .api.features import Reference
     rank, n = world(group)
     if n == 1:
         return dict(local)
-    parts = [None] * n
-    dist.all_gather_object(parts, local, group=group)
+    ids = sorted(local)
+    refs = [local[p] for p in ids]
+    # channel count agreed over the ranks (a rank may hold no reference at all)
+    chan = int(allreduce_host(np.array([max([r.channels for r in refs], default=0)], dtype=np.int64), group, op="max")[0])
+    head = np.zeros((len(ids), 6), dtype=np.int64)          # id, image_id, point2D_idx, #observations, #costs, #track
+    desc = np.zeros((len(ids), chan), dtype=np.float64)
+    for k, (p, r) in enumerate(zip(ids, refs)):
+        head[k] = (p, r.source[0], r.source[1], len(r.observations), len(r.costs), len(r.track))
+        desc[k] = r.descriptor.reshape(-1)
+    obs = np.concatenate([np.asarray(o, dtype=np.float64).reshape(1, chan) for r in refs for o in r.observations]
+                         or [np.zeros((0, chan))])
+    costs = np.array([c for r in refs for c in r.costs], dtype=np.float64)
+    track = np.array([tuple(e) for r in refs for e in r.track], dtype=np.int64).reshape(-1, 2)
     out = {}
-    for part in parts:
-        out.update(part)
+    for h, d, o, c, t in zip(*[allgather_rows(a, group) for a in (head, desc, obs, costs, track)]):
+        o_at = np.concatenate([[0], np.cumsum(h[:, 3])])
+        c_at = np.concatenate([[0], np.cumsum(h[:, 4])])
+        t_at = np.concatenate([[0], np.cumsum(h[:, 5])])
+        for k in range(len(h)):
+            out[int(h[k, 0])] = Reference(int(h[k, 1]), int(h[k, 2]), d[k].copy(),
+                                          observations=[o[i].copy() for i in range(o_at[k], o_at[k + 1])],
+                                          costs=c[c_at[k]:c_at[k + 1]].tolist(),
+                                          track=[(int(a), int(b)) for a, b in t[t_at[k]:t_at[k + 1]]])
     return out
 
 
@@ -123,20 +168,21 @@ def make_allreduce(group=None, ctx=None):
     return allreduce
 
 
-def allreduce_host(array, group=None):
-    """Sum a host numpy array over the ranks (in place; gathers of disjoint rows are sums with zeros elsewhere)."""
+def allreduce_host(array, group=None, op="sum"):
+    """Reduce a host numpy array over the ranks (in place; gathers of disjoint rows are sums with zeros elsewhere)."""
     import torch
     import torch.distributed as dist
     rank, n = world(group)
     if n == 1:
         return array
+    rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX}[op]
     t = torch.from_numpy(array)
     if dist.get_backend(group) == "nccl":
         d = t.cuda()
-        dist.all_reduce(d, group=group)
+        dist.all_reduce(d, op=rop, group=group)
         t.copy_(d.cpu())
     else:
-        dist.all_reduce(t, group=group)
+        dist.all_reduce(t, op=rop, group=group)
     return array
 
 

@@ -1,7 +1,7 @@
 """Worker of the multi-rank tests (one process per rank; launched by tests/test_multi_rank_*.py with RANK / WORLD_SIZE /
 MASTER_ADDR / MASTER_PORT in the environment, backend gloo).  Several ranks share ONE GPU in the -m gpu tests: RCCL
 refuses two ranks on one device, so the collective of pxr_ba_solve is the callback form over gloo there; the native
-RCCL path is covered with a one-rank communicator (tests/test_multi_rank_gpu.py) and by bench.py on a multi-GPU node.
+RCCL path is covered with a one-rank communicator (tests/test_zz_multi_rank_gpu.py) and by bench.py on a multi-GPU node.
 
     python tests/_multi_rank_worker.py MODE OUT_DIR
 """
@@ -59,6 +59,33 @@ def api_inputs():
         fm = bmaps.setdefault(rec.images[image_id].name, features.FeatureMap())
         fm.patches[p2d] = features.FeaturePatch(prob["patches"][pi], prob["corners"][pi], prob["scales"][pi])
     return ka_in, (rec, features.FeatureManager([features.FeatureSet(bmaps)]))
+
+
+def make_references(n=23, channels=16, seed=5):
+    """{point3D_id: Reference} with every field a Reference can carry; every third one has no observations kept."""
+    from pixsfm_amd.api import features
+    rng = np.random.default_rng(seed)
+    out = {}
+    for k in range(n):
+        pid = 7 + 3 * k
+        m = 0 if k % 3 == 0 else 2 + k % 4
+        track = [(int(rng.integers(1, 50)), int(rng.integers(0, 900))) for _ in range(m)]
+        out[pid] = features.Reference(descriptor=rng.normal(size=channels), observations=rng.normal(size=(m, channels)),
+                                      costs=rng.random(m), source=features.TrackElementTuple(k + 1, 10 * k), track=track)
+    return out
+
+
+def pack_references(refs):
+    ids = sorted(refs)
+    cat = lambda rows, width: np.array(rows, dtype=np.float64).reshape(-1, width)
+    return dict(ids=np.array(ids), source=np.array([tuple(refs[p].source) for p in ids]).reshape(-1, 2),
+                desc=cat([refs[p].descriptor.reshape(-1) for p in ids], refs[ids[0]].channels if ids else 1),
+                n_obs=np.array([len(refs[p].observations) for p in ids]),
+                obs=cat([o.reshape(-1) for p in ids for o in refs[p].observations], refs[ids[0]].channels if ids else 1),
+                costs=np.array([c for p in ids for c in refs[p].costs]),
+                track=np.array([tuple(e) for p in ids for e in refs[p].track]).reshape(-1, 2),
+                typed=np.array([all(hasattr(e, "image_id") for e in refs[p].track) and hasattr(refs[p].source, "point2D_idx")
+                                and hasattr(refs[p].track, "elements") for p in ids]))
 
 
 def api_run():
@@ -128,6 +155,12 @@ def main():
                    iterations=np.array([s["iterations"]]), successful=np.array([s["num_successful"]]),
                    termination=np.array([s["termination"]]), linear_iterations=np.array([s["linear_iterations"]]),
                    refs=refs, ref_obs=ref_obs)
+    elif mode == "refs_gather":
+        # host plumbing only: real Reference objects (source, descriptor, observations, costs, track) of this rank's points
+        # through parallel.gather_references; rank 1 of 3 deliberately holds none
+        local = {p: r for p, r in make_references().items() if (p % world == rank and not (world == 3 and rank == 1))}
+        got = parallel.gather_references(local)
+        out = pack_references(got)
     elif mode == "api":
         # the pixsfm-shaped API on two ranks: KeypointAdjuster (sub-problems dealt to the ranks), ReferenceExtractor and
         # FeatureReferenceBundleOptimizer (points sharded, collective chosen by parallel.ensure_collective)

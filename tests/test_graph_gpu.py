@@ -79,3 +79,32 @@ def test_device_labelling_equals_host_labelling_at_size(ctx, n_groups, per, n_ma
     bad = ctx.to_device(src[::-1].copy(), np.int64)                   # not in Graph order
     with pytest.raises(_lib.PixsfmHipError):
         _lib.check(lib.pxr_graph_labels_device(ctx.handle, n, d[0].ptr, m, bad.ptr, d[2].ptr, d[3].ptr, only.ptr, None, None, None), "order")
+
+
+def test_a_giant_component_is_refused_by_the_device_and_labelled_on_the_host(ctx):
+    """One connected component with more matches than the device kernel's per-component rank sort takes: the C entry
+    point answers PXR_EUNSUPPORTED (no silent wrong labels, no minutes-long single wavefront) and
+    base.compute_labels_on_device falls back to the native host labelling -- same three results."""
+    from pixsfm_amd import _lib
+    from pixsfm_amd.api import base
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    n, m = 3000, 40000
+    node_image = rng.integers(0, 60, n).astype(np.int32)
+    src = np.sort(rng.integers(0, n, m)).astype(np.int64)
+    dst = rng.integers(0, n, m).astype(np.int64)
+    sim = np.round(rng.uniform(0.1, 1.0, m), 3)
+    d = [ctx.to_device(a, dt) for a, dt in ((node_image, np.int32), (src, np.int64), (dst, np.int64), (sim, np.float64))]
+    out = ctx.empty((n,), np.int64)
+    rc = lib.pxr_graph_labels_device(ctx.handle, n, d[0].ptr, m, d[1].ptr, d[2].ptr, d[3].ptr, out.ptr, None, None, None)
+    assert rc == _lib.PXR_EUNSUPPORTED
+    g = base.Graph()
+    for i in range(n):
+        g.add_node(int(node_image[i]), i)
+    for a, b, s in zip(src.tolist(), dst.tolist(), sim.tolist()):
+        g.add_edge(g.nodes[a], g.nodes[b], s)
+    labels, scores, roots = base.compute_labels_on_device(g, ctx)
+    want = base.compute_track_labels(g)
+    assert labels == want
+    assert np.array_equal(scores, np.asarray(base.compute_score_labels(g, want)))
+    assert roots == base.compute_root_labels(g, want, scores)

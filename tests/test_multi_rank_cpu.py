@@ -1,5 +1,5 @@
 """CPU, world_size 2 over gloo: the host side of the multi-GPU paths -- the real sharding and gather
-code of pixsfm_amd.parallel run in two processes.  The solves themselves need the GPU: tests/test_multi_rank_gpu.py
+code of pixsfm_amd.parallel run in two processes.  The solves themselves need the GPU: tests/test_zz_multi_rank_gpu.py
 runs the same worker with pxr_ka_solve / pxr_ba_solve inside."""
 import os
 import sys
@@ -47,3 +47,41 @@ def test_ba_point_shards_cover_all_observations():
         assert np.array_equal(shard["qvec"], prob["qvec"]) and len(shard["image_camera"]) == len(prob["image_camera"])
         seen.append(shard["obs_ids"])
     assert np.array_equal(np.sort(np.concatenate(seen)), np.arange(len(prob["obs_image"])))
+
+
+def test_references_gather_over_two_and_three_ranks(tmp_path):
+    """Real Reference objects (source / track / observations / costs) through parallel.gather_references on gloo: every
+    rank ends with the union, field for field (the round-2 regression: un-pickling TrackElementTuple in all_gather_object)."""
+    want = worker.pack_references(worker.make_references())
+    for world in (2, 3):
+        d = tmp_path / ("w%d" % world)
+        d.mkdir()
+        res = run_ranks("refs_gather", d, world=world)
+        keep = want["ids"] % world != 1 if world == 3 else np.ones(len(want["ids"]), bool)      # rank 1 of 3 contributed nothing
+        full = worker.make_references()
+        expect = worker.pack_references({p: full[p] for p in want["ids"][keep]})
+        for r in res:
+            for k in expect:
+                assert np.array_equal(r[k], expect[k]), k
+            assert r["typed"].all()
+
+
+def test_api_containers_survive_pickle_and_deepcopy():
+    import copy
+    import pickle
+    from pixsfm_amd.api import features
+    refs = worker.make_references()
+    for clone in (pickle.loads(pickle.dumps(refs)), copy.deepcopy(refs)):
+        a, b = worker.pack_references(refs), worker.pack_references(clone)
+        assert all(np.array_equal(a[k], b[k]) for k in a) and b["typed"].all()
+    e = pickle.loads(pickle.dumps(features.TrackElementTuple(3, 4)))
+    assert (e.image_id, e.point2D_idx) == (3, 4) and e == (3, 4) and isinstance(e, features.TrackElementTuple)
+    t = copy.deepcopy(features.TrackList([features.TrackElementTuple(1, 2)]))
+    assert t.length() == 1 and t.elements[0].image_id == 1
+    patch = features.FeaturePatch(np.arange(2 * 3 * 4, dtype=np.float32).reshape(2, 3, 4), (5, 6), (0.5, 0.25))
+    fmap = features.FeatureMap(); fmap.patches[9] = patch
+    fset = features.FeatureSet({"a.jpg": fmap})
+    man = pickle.loads(pickle.dumps(features.FeatureManager([fset])))
+    got = man.fsets[0].fmaps["a.jpg"].patches[9] if hasattr(man, "fsets") else None
+    if got is not None:
+        assert np.array_equal(got.data, patch.data) and np.array_equal(got.corner, patch.corner) and np.array_equal(got.scale, patch.scale)

@@ -8,243 +8,64 @@
 // triangle A(i,j) = a[i + j*ld], i >= j, plus one extra ROW i = n holding the right-hand side:
 // a right-looking Cholesky that treats row n like any other sub-diagonal row performs the forward
 // substitution L y = b for free (row n of the factor is y^T).
-//   k_chol_panel   every workgroup factors the 64x64 diagonal block AND inverts its triangular
-//                  factor in one sweep over column PAIRS on 4x4 register tiles (one barrier per pair, finished
-//                  columns of L / rows of inv(L) exported to LDS so the updates need no masks);
-//                  WG 0 writes L_kk and inv(L_kk) back, WG b >= 1 computes its 128 panel rows
-//                  X = B inv(L_kk)^T as an LDS-tiled GEMM (8x4 register micro-tiles).
-//   k_chol_syrk    trailing update A22 -= P P^T on 64x64 tiles (lower tiles only), fp64 MFMA.
-//   k_chol_backsolve L^T x = y in one launch: a workgroup per block column, solution blocks handed on
-//                  through flags; x_k = inv(L_kk)^T z_k, z_c -= L(k-block, c-block)^T x_k.
+//
+// ONE launch per 64-column block step s (k_chol_step), look-ahead built into the launch:
+//   panel workgroups   (8 wavefronts; 48 rows each) first apply step s - 1's rank-64 update to THEIR part of block
+//                      column s -- the 64 x 64 diagonal tile (every panel workgroup redundantly: no hop between
+//                      workgroups on the critical path) and their own rows below it -- on fp64 MFMA accumulators
+//                      that never leave the registers, then factor the tile and solve their rows in the same sweep
+//                      (pxr_chol_core.h: lane = row pivot chain on v_readlane, rank-8 MFMA updates, two barriers per 8
+//                      columns).  The first 64 "rows" are identity rows: they come out as inv(L_ss)^T for the
+//                      back-substitution;
+//   update workgroups  apply step s - 1's update to the tiles RIGHT of block column s (64 x 64 MFMA tiles), off the
+//                      critical path of the step.
+// So step s needs only what step s - 1 wrote, the trailing update never delays the next pivot chain, and the chain
+// itself is ~300 shader cycles per pivot instead of ~1000 (profiles/r3_chol_*).
+//   k_chol_backsolve   L^T x = y in one launch: a workgroup per block column, solution blocks handed on
+//                      through flags; x_k = inv(L_kk)^T z_k, z_c -= L(k-block, c-block)^T x_k.
 #include <hip/hip_runtime.h>
 
+#include "pxr_chol_core.h"
 #include "pxr_internal.h"
 
 namespace pxr {
 
 constexpr int CNB = 64;
-constexpr int PROWS = 128;   // panel rows per workgroup in the TRSM part
-
-// n_rows = rows of the (augmented) matrix, n_cols = columns to factor, k = first column of the panel.
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ a, int n_rows, int n_cols, int lda, int k,
-                                                    int* __restrict__ info, double* __restrict__ linv_out) {
-  __shared__ double Lt[CNB][CNB + 2];     // Lt[m][j] = inv(L_kk)[j][m]; padded: a column write touches 16 rows, one bank group each
-  __shared__ double Bs[CNB][PROWS];       // panel tile, Bs[m][row]
-  __shared__ double cola[2][CNB], colc[2][CNB], rowa[2][CNB], rowc[2][CNB];
-  const int tid = threadIdx.x;
-  const int ti = tid >> 4, tj = tid & 15;
-  const int nb = min(CNB, n_cols - k);
-#ifdef PXR_CHOL_PROFILE   // -DPXR_CHOL_PROFILE: workgroups 0 and 1 of the first panel print their phase times (100 MHz ticks)
-  long long cp_t[6], cp_c[6]; int cp_n = 0;
-  __shared__ long long cp_pair[33];
-#define CHOL_PAIR() do { if (tid == 255) cp_pair[j >> 1] = clock64(); } while (0)   // thread 255: last wavefront, live to the end
-#define CHOL_T() do { if (tid == 0) { cp_c[cp_n] = clock64(); cp_t[cp_n++] = wall_clock64(); } } while (0)
-  CHOL_T();
-#else
-#define CHOL_T() do { } while (0)
-#define CHOL_PAIR() do { } while (0)
-#endif
-  const bool is_panel_wg = blockIdx.x > 0;
-  const int r0 = k + nb + ((int)blockIdx.x - 1) * PROWS;
-  // issue the panel-tile loads first: they fly while the diagonal block is factored
-  double breg[CNB * PROWS / 256];
-  if (is_panel_wg) {
-#pragma unroll
-    for (int q = 0; q < CNB * PROWS / 256; ++q) {
-      const int e = tid + q * 256, i = e % PROWS, m = e / PROWS;
-      breg[q] = (r0 + i < n_rows && m < nb) ? a[(size_t)(r0 + i) + (size_t)(k + m) * lda] : 0.0;
-    }
-  }
-  double Dt[4][4], Xt[4][4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const int R = 4 * ti + u, Cc = 4 * tj + w;
-      double v = (R == Cc) ? 1.0 : 0.0;                     // identity padding beyond nb
-      if (R < nb && Cc < nb && R >= Cc) v = a[(size_t)(k + R) + (size_t)(k + Cc) * lda];
-      Dt[u][w] = v;
-      Xt[u][w] = (R == Cc) ? 1.0 : 0.0;
-    }
-  int bad = 0;
-  CHOL_T();
-  // 32-step sweep over column PAIRS (j, j+1), one barrier per pair:
-  //   L[:,j]   = D[:,j] / sqrt(D[j][j]);
-  //   L[:,j+1] = (D[:,j+1] - L[:,j] L[j+1][j]) / sqrt(D[j+1][j+1] - L[j+1][j]^2);
-  //   D       -= L[:,j] L[:,j]^T + L[:,j+1] L[:,j+1]^T;
-  //   X[j]    /= L[j][j];  X[j+1] = (X[j+1] - L[j+1][j] X[j]) / L[j+1][j+1];  X -= L[:,j] X[j] + L[:,j+1] X[j+1]   (X: I -> inv(L))
-#pragma unroll 2
-  for (int j = 0; j < CNB; j += 2) {
-    const int jb = j >> 2, jo = j & 3, buf = (j >> 1) & 1;   // jo is 0 or 2: both columns sit in the same 4-wide tile
-    // a wavefront holds the tile rows 4 w .. 4 w + 3: once they are all finished (rows < j) it has nothing left to
-    // export or update and only keeps the barrier company -- the sweep is bound by the LDS reads of the live ones
-    const bool live = 4 * (tid >> 6) + 3 >= jb;
-    CHOL_PAIR();
-    if (live && tj == jb) {                                  // owners of columns j, j+1 of D
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        cola[buf][4 * ti + u] = jo == 0 ? Dt[u][0] : Dt[u][2];
-        colc[buf][4 * ti + u] = jo == 0 ? Dt[u][1] : Dt[u][3];
-      }
-    }
-    if (ti == jb) {                                          // owners of rows j, j+1 of X
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        rowa[buf][4 * tj + w] = jo == 0 ? Xt[0][w] : Xt[2][w];
-        rowc[buf][4 * tj + w] = jo == 0 ? Xt[1][w] : Xt[3][w];
-      }
-    }
-    __syncthreads();
-    if (live) {
-      // all LDS reads are issued unconditionally, back to back (one wait), and masked in registers:
-      // conditional loads made the compiler emit a branch + wait per value
-      const double d00 = cola[buf][j], d10 = cola[buf][j + 1], d11 = colc[buf][j + 1];
-      double ua[4], wa[4], uc[4], wc[4], ra[4], rc[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        ua[u] = cola[buf][4 * ti + u]; wa[u] = cola[buf][4 * tj + u];
-        uc[u] = colc[buf][4 * ti + u]; wc[u] = colc[buf][4 * tj + u];
-        ra[u] = rowa[buf][4 * tj + u]; rc[u] = rowc[buf][4 * tj + u];
-      }
-      // the two pivots from INDEPENDENT reciprocal square roots:  1 / sqrt(d11 - d10^2 / d00) = sqrt(d00) / sqrt(d00 d11 - d10^2)
-      const double det = fma(d00, d11, -(d10 * d10));
-      if (!(d00 > 0.0) && bad == 0) bad = j + 1;
-      if (!(det > 0.0) && bad == 0) bad = j + 2;
-      const double inv0 = d00 > 0.0 ? rsqrt(d00) : 1.0;
-      const double rdet = det > 0.0 ? rsqrt(det) : 1.0;
-      const double l10 = d10 * inv0;
-      const double inv1 = det > 0.0 ? rdet * (d00 * inv0) : 1.0;
-      // No masks: once columns j, j+1 of L and rows j, j+1 of inv(L) have been exported to LDS (below), the
-      // register entries of finished rows / columns are dead -- they are never read again, so the
-      // rank-2 updates may overwrite them with garbage.
-      double lia[4], lca[4], xra[4], lic[4], lcc[4], xrc[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        lia[u] = ua[u] * inv0; lca[u] = wa[u] * inv0; xra[u] = ra[u] * inv0;
-        lic[u] = fma(-lia[u], l10, uc[u]) * inv1;
-        lcc[u] = fma(-lca[u], l10, wc[u]) * inv1;
-        xrc[u] = fma(-l10, xra[u], rc[u]) * inv1;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          Dt[u][w] = fma(-lic[u], lcc[w], fma(-lia[u], lca[w], Dt[u][w]));
-          Xt[u][w] = fma(-lic[u], xrc[w], fma(-lia[u], xra[w], Xt[u][w]));
-        }
-      if (tj == jb && !is_panel_wg) {                        // columns j, j+1 of L (rows >= j / j+1 are meaningful)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { Bs[j][4 * ti + u] = lia[u]; Bs[j + 1][4 * ti + u] = lic[u]; }
-      }
-      if (ti == jb) {                                        // rows j, j+1 of inv(L): Lt[m][j] = inv(L)[j][m], zero for m > j
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          Lt[4 * tj + w][j] = (4 * tj + w <= j) ? xra[w] : 0.0;
-          Lt[4 * tj + w][j + 1] = (4 * tj + w <= j + 1) ? xrc[w] : 0.0;
-        }
-      }
-    }
-  }
-#ifdef PXR_CHOL_PROFILE
-  if (tid == 255) cp_pair[32] = clock64();
-#endif
-  __syncthreads();
-  CHOL_T();
-  if (!is_panel_wg) {
-    if (bad && bad <= nb && tid == 255) atomicCAS(info, 0, k + bad);   // the last wavefront is live (and tracks `bad`) to the end
-    double* lo = linv_out + (size_t)(k / CNB) * CNB * CNB;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const int R = 4 * ti + u, Cc = 4 * tj + w;
-        if (R < nb && Cc < nb && R >= Cc) a[(size_t)(k + R) + (size_t)(k + Cc) * lda] = Bs[Cc][R];
-        lo[R * CNB + Cc] = Lt[Cc][R];                        // inv(L_kk), row-major
-      }
-#ifdef PXR_CHOL_PROFILE
-    CHOL_T();
-    if (tid == 0 && k == 0) printf("chol panel wg0: loads %lld sweep %lld writeback %lld (x10 ns); sweep %lld shader cycles\n", cp_t[1] - cp_t[0], cp_t[2] - cp_t[1], cp_t[3] - cp_t[2], cp_c[2] - cp_c[1]);
-    if (tid == 0 && k == 0) {
-      printf("chol pairs (cycles):");
-      for (int q = 0; q < 32; ++q) printf(" %lld", cp_pair[q + 1] - cp_pair[q]);
-      printf("\n");
-    }
-#endif
-    return;
-  }
-#pragma unroll
-  for (int q = 0; q < CNB * PROWS / 256; ++q) {
-    const int e = tid + q * 256;
-    Bs[e / PROWS][e % PROWS] = breg[q];
-  }
-  __syncthreads();
-  CHOL_T();
-  // X = B inv(L)^T for this workgroup's PROWS rows: x[row][j] = sum_m Bs[m][row] Lt[m][j]
-  const int tx = tid & 15, ty = tid >> 4;   // ty: 8 rows, tx: 4 columns
-  double acc[8][4];
-#pragma unroll
-  for (int u = 0; u < 8; ++u)
-#pragma unroll
-    for (int w = 0; w < 4; ++w) acc[u][w] = 0.0;
-#pragma unroll 4
-  for (int m = 0; m < CNB; ++m) {
-    double bv[8], lv[4];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) bv[u] = Bs[m][8 * ty + u];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) lv[w] = Lt[m][4 * tx + w];
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-      for (int w = 0; w < 4; ++w) acc[u][w] = fma(bv[u], lv[w], acc[u][w]);
-  }
-  CHOL_T();
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const int j = 4 * tx + w;
-    if (j >= nb) continue;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int r = r0 + 8 * ty + u;
-      if (r < n_rows) a[(size_t)r + (size_t)(k + j) * lda] = acc[u][w];
-    }
-  }
-#ifdef PXR_CHOL_PROFILE
-  CHOL_T();
-  if (tid == 0 && k == 0 && blockIdx.x == 1)
-    printf("chol panel wg1: loads %lld sweep %lld stage %lld gemm %lld store %lld (x10 ns)\n", cp_t[1] - cp_t[0], cp_t[2] - cp_t[1], cp_t[3] - cp_t[2],
-           cp_t[4] - cp_t[3], cp_t[5] - cp_t[4]);
-#endif
-}
-
-// A22 -= P P^T on 64 x 64 tiles (lower tiles only); P = A(k+nb : n_rows, k : k+nb).  The one GEMM-shaped
-// piece of the path: fp64 MFMA (v_mfma_f64_16x16x4_f64).  Each of the four wavefronts owns a 32 x 32
-// quarter = 2 x 2 MFMA blocks, K = 64 in 16 steps.  Operands come from the LDS-staged panel rows
-// (Pt[m][row]: lane l feeds row l % 16, k = l / 16 for A and for B alike).  The product is formed
-// TRANSPOSED (A <- rows of the column tile, B <- rows of the row tile) so that the accumulator's
-// lane index (col = lane & 15) runs along the matrix ROWS, which are contiguous in memory:
-// C/D layout of the f64 MFMA is col = lane & 15, row = (lane >> 4) + 4 * reg.
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
-constexpr int SPAD = CNB + 8;   // LDS row stride: spreads the four k-rows of a step over the banks
+constexpr int SPAD = CNB + 8;   // LDS row stride of the update tiles: spreads the four k-rows of a step over the banks
 
-__global__ __launch_bounds__(256) void k_chol_syrk(double* __restrict__ a, int n_rows, int lda, int k, int nb) {
-  const int ti = blockIdx.y, tj = blockIdx.x;
-  if (tj > ti) return;
-  __shared__ double Pi[CNB][SPAD];   // [m][row of the row tile]
-  __shared__ double Pj[CNB][SPAD];   // [m][row of the column tile]
-  const int r0 = k + nb;
+// LDS of a panel workgroup: the sweep's buffers + step s - 1's columns of the tile rows (64) and of the workgroup's own
+// rows (48), in operand order U[k][row]
+struct PanelLds {
+  cholcore::FactorLds f;
+  double U[CNB][CNB + 16 * cholcore::ROW_WAVES];
+};
+struct UpdateLds {
+  double Pi[CNB][SPAD];   // [m][row of the row tile]
+  double Pj[CNB][SPAD];   // [m][row of the column tile]
+};
+constexpr size_t kStepLds = sizeof(PanelLds) > sizeof(UpdateLds) ? sizeof(PanelLds) : sizeof(UpdateLds);
+
+// trailing tile (ti, tj) of the matrix below / right of block column s - 1:  A(ti, tj) -= P_ti P_tj^T with
+// P = A(:, 64 (s - 1) .. 64 s) -- fp64 MFMA (v_mfma_f64_16x16x4_f64), four wavefronts, each a 32 x 32 quarter = 2 x 2 MFMA
+// blocks, K = 64 in 16 steps.  Operands come from the LDS-staged panel rows (P[m][row]: lane l feeds row l % 16,
+// k = l / 16 for A and for B alike).  The product is formed TRANSPOSED (A <- rows of the column tile, B <- rows of the row
+// tile) so that the accumulator's lane index (col = lane & 15) runs along the matrix ROWS, which are contiguous in memory:
+// C/D layout of the f64 MFMA is col = lane & 15, row = (lane >> 4) + 4 * reg.
+__device__ __forceinline__ void update_tile(UpdateLds& lds, double* __restrict__ a, int n_rows, int lda, int k, int r0, int ti, int tj) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int q = 0; q < CNB * CNB / 256; ++q) {
-    const int e = tid + q * 256, i = e % CNB, m = e / CNB;
+  for (int q = 0; q < CNB * CNB / 512; ++q) {
+    const int e = tid + q * 512, i = e % CNB, m = e / CNB;
     const int gi = r0 + ti * CNB + i, gj = r0 + tj * CNB + i;
     // clamped address + select (a conditional load costs a branch and a wait per element)
-    const size_t col = (size_t)(k + min(m, nb - 1)) * lda;
+    const size_t col = (size_t)(k + m) * lda;
     const double vi = a[(size_t)min(gi, n_rows - 1) + col], vj = a[(size_t)min(gj, n_rows - 1) + col];
-    Pi[m][i] = (gi < n_rows && m < nb) ? vi : 0.0;
-    Pj[m][i] = (gj < n_rows && m < nb) ? vj : 0.0;
+    lds.Pi[m][i] = gi < n_rows ? vi : 0.0;
+    lds.Pj[m][i] = gj < n_rows ? vj : 0.0;
   }
   __syncthreads();
+  if (tid >= 256) return;
   const int lane = tid & 63, w = tid >> 6, wi = w >> 1, wj = w & 1;
   const int lr = lane & 15, lk = lane >> 4;
   mfma_d4 acc[2][2];
@@ -255,8 +76,8 @@ __global__ __launch_bounds__(256) void k_chol_syrk(double* __restrict__ a, int n
 #pragma unroll 4
   for (int s = 0; s < CNB / 4; ++s) {
     const int m = 4 * s + lk;
-    const double aj0 = Pj[m][32 * wj + lr], aj1 = Pj[m][32 * wj + 16 + lr];       // A: column-tile rows
-    const double bi0 = Pi[m][32 * wi + lr], bi1 = Pi[m][32 * wi + 16 + lr];       // B: row-tile rows
+    const double aj0 = lds.Pj[m][32 * wj + lr], aj1 = lds.Pj[m][32 * wj + 16 + lr];       // A: column-tile rows
+    const double bi0 = lds.Pi[m][32 * wi + lr], bi1 = lds.Pi[m][32 * wi + 16 + lr];       // B: row-tile rows
     acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj0, bi0, acc[0][0], 0, 0, 0);
     acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj0, bi1, acc[0][1], 0, 0, 0);
     acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj1, bi0, acc[1][0], 0, 0, 0);
@@ -274,6 +95,83 @@ __global__ __launch_bounds__(256) void k_chol_syrk(double* __restrict__ a, int n
         const int gi = r0 + ti * CNB + 32 * wi + 16 * y + lr;
         if (gi < n_rows && gj < n_rows && gi >= gj) a[(size_t)gi + (size_t)gj * lda] -= acc[x][y][r];
       }
+}
+
+// block step s: n_rows = rows of the (augmented) matrix, n_cols = columns to factor.  Grid: n_panel panel workgroups, then
+// the update workgroups of the tiles (ti, tj), 1 <= tj <= ti, of the matrix from block row s on (s >= 1 only).
+__global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ a, int n_rows, int n_cols, int lda, int s, int n_panel,
+                                                   int* __restrict__ info, double* __restrict__ linv_out) {
+  using namespace cholcore;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int k0 = s * CNB, nb = min(CNB, n_cols - k0);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if ((int)blockIdx.x >= n_panel) {                                   // ---- an update workgroup
+    int t = (int)blockIdx.x - n_panel, ti = 1;
+    while (t >= ti) { t -= ti; ++ti; }                                 // tile t of row ti: (ti, 1 + t), at most ~25 rows
+    update_tile(*reinterpret_cast<UpdateLds*>(smem), a, n_rows, lda, k0 - CNB, k0, ti, 1 + t);
+    return;
+  }
+  // ---- a panel workgroup
+  PanelLds& lds = *reinterpret_cast<PanelLds*>(smem);
+  const int i = lane & 15, g = lane >> 4;
+  // the 16-row block this wavefront carries through the sweep: blocks 0..3 are identity rows (-> inv(L_ss)), then the rows
+  // below the tile
+  const int v = wave - ROW_WAVE0, vb = ROW_WAVES * (int)blockIdx.x + v;
+  const int r0 = k0 + nb + 16 * (vb - 4);                              // first matrix row of a real row block
+  const bool real_rows = wave >= ROW_WAVE0 && vb >= 4 && r0 < n_rows;
+  RowSink sink;
+  sink.l_diag = blockIdx.x == 0 ? a + (size_t)k0 + (size_t)k0 * lda : nullptr;
+  sink.ld = lda; sink.nb = nb; sink.rows_valid = 16; sink.rows_out = nullptr; sink.mode = RowSink::kNone;
+  d4 acc[4];
+  if (wave < 4) {
+    load_diag_blocks(acc, a + (size_t)k0 + (size_t)k0 * lda, lda, nb, wave, lane);
+  } else if (wave >= ROW_WAVE0 && vb < 4) {
+    identity_rows(acc, vb, lane);
+    sink.mode = RowSink::kInverse; sink.rows_out = linv_out + (size_t)s * CNB * CNB + 16 * vb;
+  } else if (real_rows) {
+    sink.mode = RowSink::kPanel; sink.rows_out = a + (size_t)r0 + (size_t)k0 * lda; sink.rows_valid = min(16, n_rows - r0);
+    load_rows(acc, sink.rows_out, lda, nb, sink.rows_valid, lane);
+  }
+  if (s > 0) {
+    // step s - 1's rank-64 update of this workgroup's part of block column s.  Stage L(tile rows, s-1) and
+    // L(own rows, s-1) as U[k][row] (rows contiguous in memory: coalesced), then MFMA from LDS.
+    const int kp = k0 - CNB;
+    const int first_real = k0 + nb + 16 * (ROW_WAVES * (int)blockIdx.x - 4);   // row of this workgroup's row block v = 0
+    // thread t: row t % 128 of the 112 staged rows (tile rows, then this workgroup's 48), columns t / 128 + 4 q -- all 16
+    // loads are issued before the first LDS store (a load -> store loop pays the memory latency once per trip)
+    {
+      const int r = tid & 127, m0 = tid >> 7;
+      int gr = -1;
+      if (r < CNB) { if (r < nb) gr = k0 + r; }
+      else if (r < CNB + 16 * ROW_WAVES) {
+        const int vbb = ROW_WAVES * (int)blockIdx.x + ((r - CNB) >> 4);
+        if (vbb >= 4) gr = first_real + (r - CNB);
+      }
+      const bool live = gr >= 0 && gr < n_rows;
+      const double* src = a + (size_t)(live ? gr : 0) + (size_t)(kp + m0) * lda;
+      double u[CNB / 4];
+#pragma unroll
+      for (int q = 0; q < CNB / 4; ++q) u[q] = src[(size_t)(4 * q) * lda];
+      if (r < CNB + 16 * ROW_WAVES) {
+#pragma unroll
+        for (int q = 0; q < CNB / 4; ++q) lds.U[m0 + 4 * q][r] = live ? u[q] : 0.0;
+      }
+    }
+    __syncthreads();
+    if (wave < 4 || real_rows) {
+      const int rrow = wave < 4 ? 16 * wave + i : CNB + 16 * v + i;    // this lane's row of the B (row) operand
+      const int ncb = wave < 4 ? wave + 1 : 4;
+#pragma unroll 4
+      for (int ks = 0; ks < CNB / 4; ++ks) {
+        const double br = lds.U[4 * ks + g][rrow];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          if (cb < ncb) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lds.U[4 * ks + g][16 * cb + i], br, acc[cb], 0, 0, 0);
+      }
+    }
+  }
+  const int bad = factor_tile(lds.f, acc, wave, lane, sink);
+  if (blockIdx.x == 0 && tid == 0 && bad && bad <= nb) atomicCAS(info, 0, k0 + bad);
 }
 
 // L^T x = y in ONE launch: workgroup b owns block column c = nblk - 1 - b (64 unknowns) and keeps its
@@ -334,14 +232,17 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
 
 int chol_factor_solve(hipStream_t st, double* a, int n, int* d_info, double* linv_ws, double* x_out) {
   const int lda = n + 1, n_rows = n + 1;
+  // > 64 KiB of dynamic LDS needs the opt-in, per device (one process may hold contexts on several devices)
+  if (int rc = hip_check(hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStepLds), "LDS size")) return rc;
   if (int rc = hip_check(hipMemsetAsync(d_info, 0, sizeof(int), st), "memset info")) return rc;
-  for (int k = 0; k < n; k += CNB) {
+  const int rows_per_wg = 16 * cholcore::ROW_WAVES;
+  for (int s = 0, k = 0; k < n; ++s, k += CNB) {
     const int nb = (n - k < CNB) ? n - k : CNB;
-    const int rem = n_rows - k - nb;   // rows below the diagonal block (>= 1: the rhs row)
-    const int wgs = 1 + (rem + PROWS - 1) / PROWS;
-    hipLaunchKernelGGL(k_chol_panel, dim3(wgs), dim3(256), 0, st, a, n_rows, n, lda, k, d_info, linv_ws);
-    const int T = (rem + CNB - 1) / CNB;
-    hipLaunchKernelGGL(k_chol_syrk, dim3(T, T), dim3(256), 0, st, a, n_rows, lda, k, nb);
+    const int rem = n_rows - k - nb;                      // rows below the diagonal tile (>= 1: the rhs row)
+    const int n_panel = (CNB + rem + rows_per_wg - 1) / rows_per_wg;   // 64 identity rows + the rows below
+    const int T = (n_rows - k + CNB - 1) / CNB;           // row tiles from block row s on; tiles (ti, tj), 1 <= tj <= ti < T
+    const int n_update = s > 0 ? T * (T - 1) / 2 : 0;
+    hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_update), dim3(512), kStepLds, st, a, n_rows, n, lda, s, n_panel, d_info, linv_ws);
   }
   const int nblk = (n + CNB - 1) / CNB;
   int* flags = reinterpret_cast<int*>(linv_ws + (size_t)nblk * CNB * CNB);   // spare block of the workspace

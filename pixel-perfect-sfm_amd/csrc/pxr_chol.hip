@@ -39,12 +39,17 @@ constexpr int SPAD = CNB + 8;   // LDS row stride of the update tiles: spreads t
 struct PanelLds {
   cholcore::FactorLds f;
   double U[CNB][CNB + 16 * cholcore::ROW_WAVES];
+  double H[3][4][CNB];    // the three tile blocks wavefront 4 updates on behalf of wavefronts 3, 3, 2 (accumulator order)
 };
 struct UpdateLds {
   double Pi[CNB][SPAD];   // [m][row of the row tile]
   double Pj[CNB][SPAD];   // [m][row of the column tile]
 };
-constexpr size_t kStepLds = sizeof(PanelLds) > sizeof(UpdateLds) ? sizeof(PanelLds) : sizeof(UpdateLds);
+// ONE workgroup per CU: a panel workgroup that shares its CU with an update workgroup shares its MFMA and LDS pipes, and
+// its pivot chain is the critical path of the step -- asking for more than half of the CU's 160 KiB keeps a second
+// workgroup out; when a step has more than 256 workgroups the surplus update tiles run as a short second round
+constexpr size_t kStepLdsNeed = sizeof(PanelLds) > sizeof(UpdateLds) ? sizeof(PanelLds) : sizeof(UpdateLds);
+constexpr size_t kStepLds = kStepLdsNeed > 96 * 1024 ? kStepLdsNeed : 96 * 1024;
 
 // trailing tile (ti, tj) of the matrix below / right of block column s - 1:  A(ti, tj) -= P_ti P_tj^T with
 // P = A(:, 64 (s - 1) .. 64 s) -- fp64 MFMA (v_mfma_f64_16x16x4_f64), four wavefronts, each a 32 x 32 quarter = 2 x 2 MFMA
@@ -64,27 +69,11 @@ __device__ __forceinline__ void update_tile(UpdateLds& lds, double* __restrict__
     lds.Pi[m][i] = gi < n_rows ? vi : 0.0;
     lds.Pj[m][i] = gj < n_rows ? vj : 0.0;
   }
-  __syncthreads();
-  if (tid >= 256) return;
-  const int lane = tid & 63, w = tid >> 6, wi = w >> 1, wj = w & 1;
+  // the tile itself goes INTO the accumulators before the products (loads in flight behind the staging; a read-modify-write
+  // after the MFMAs serialised 16 load -> wait -> store trips per lane)
+  const int lane = tid & 63, w = (tid >> 6) & 3, wi = w >> 1, wj = w & 1;
   const int lr = lane & 15, lk = lane >> 4;
   mfma_d4 acc[2][2];
-#pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int y = 0; y < 2; ++y) acc[x][y] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-  for (int s = 0; s < CNB / 4; ++s) {
-    const int m = 4 * s + lk;
-    const double aj0 = lds.Pj[m][32 * wj + lr], aj1 = lds.Pj[m][32 * wj + 16 + lr];       // A: column-tile rows
-    const double bi0 = lds.Pi[m][32 * wi + lr], bi1 = lds.Pi[m][32 * wi + 16 + lr];       // B: row-tile rows
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj0, bi0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj0, bi1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj1, bi0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj1, bi1, acc[1][1], 0, 0, 0);
-  }
-  // acc[x][y][r] = sum_m P[gj][m] P[gi][m]  with  gj = column-tile row 32 wj + 16 x + (lane >> 4) + 4 r,
-  //                                               gi = row-tile row    32 wi + 16 y + (lane & 15)
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -93,8 +82,47 @@ __device__ __forceinline__ void update_tile(UpdateLds& lds, double* __restrict__
       for (int r = 0; r < 4; ++r) {
         const int gj = r0 + tj * CNB + 32 * wj + 16 * x + lk + 4 * r;
         const int gi = r0 + ti * CNB + 32 * wi + 16 * y + lr;
-        if (gi < n_rows && gj < n_rows && gi >= gj) a[(size_t)gi + (size_t)gj * lda] -= acc[x][y][r];
+        const double c = a[(size_t)min(gi, n_rows - 1) + (size_t)min(gj, n_rows - 1) * lda];     // clamped address + select
+        acc[x][y][r] = (gi < n_rows && gj < n_rows && gi >= gj) ? c : 0.0;
       }
+  __syncthreads();
+  if (tid >= 256) return;
+#pragma unroll 4
+  for (int s = 0; s < CNB / 4; ++s) {
+    const int m = 4 * s + lk;
+    const double aj0 = -lds.Pj[m][32 * wj + lr], aj1 = -lds.Pj[m][32 * wj + 16 + lr];     // A: column-tile rows (negated: acc -= P P^T)
+    const double bi0 = lds.Pi[m][32 * wi + lr], bi1 = lds.Pi[m][32 * wi + 16 + lr];       // B: row-tile rows
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj0, bi0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj0, bi1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj1, bi0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aj1, bi1, acc[1][1], 0, 0, 0);
+  }
+  // acc[x][y][r] = A[gi][gj] - sum_m P[gj][m] P[gi][m]  with  gj = column-tile row 32 wj + 16 x + (lane >> 4) + 4 r,
+  //                                                           gi = row-tile row    32 wi + 16 y + (lane & 15)
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gj = r0 + tj * CNB + 32 * wj + 16 * x + lk + 4 * r;
+        const int gi = r0 + ti * CNB + 32 * wi + 16 * y + lr;
+        // write-through (sc1) stores: the ~9 MB of updated tiles leave the L2 while the panel workgroups are still busy,
+        // instead of as one write-back of dirty lines at the end of the launch (which the next step waits for)
+        if (gi < n_rows && gj < n_rows && gi >= gj)
+          __hip_atomic_store(&a[(size_t)gi + (size_t)gj * lda], acc[x][y][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+}
+
+// acc[cb] -= U_rows U_cols(cb)^T over the 64 columns of the previous block step, blocks CB0 <= cb < CB1
+template <int CB0, int CB1>
+__device__ __forceinline__ void rank64_update(cholcore::d4 (&acc)[4], const double (&U)[CNB][CNB + 16 * cholcore::ROW_WAVES], int rrow, int i, int g) {
+#pragma unroll 4
+  for (int ks = 0; ks < CNB / 4; ++ks) {
+    const double br = U[4 * ks + g][rrow];
+#pragma unroll
+    for (int cb = CB0; cb < CB1; ++cb) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[4 * ks + g][16 * cb + i], br, acc[cb], 0, 0, 0);
+  }
 }
 
 // block step s: n_rows = rows of the (augmented) matrix, n_cols = columns to factor.  Grid: n_panel panel workgroups, then
@@ -158,16 +186,37 @@ __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ a, int n
       }
     }
     __syncthreads();
+    // MFMA balance over the four SIMDs: wavefront w and row wavefront w + 4 share SIMD w; block row 3 (4 blocks) and a row
+    // wavefront (4 blocks) would put 128 MFMAs on SIMD 3 against 16 on SIMD 0, so the otherwise idle wavefront 4 (SIMD 0)
+    // takes blocks (3,0), (3,1), (2,0) and hands its sums over through LDS: 96 per SIMD at most
     if (wave < 4 || real_rows) {
       const int rrow = wave < 4 ? 16 * wave + i : CNB + 16 * v + i;    // this lane's row of the B (row) operand
-      const int ncb = wave < 4 ? wave + 1 : 4;
+      // one clean loop per role (a run-time block range inside ONE loop made the compiler branch around every MFMA)
+      if (wave == 0) rank64_update<0, 1>(acc, lds.U, rrow, i, g);
+      else if (wave == 1) rank64_update<0, 2>(acc, lds.U, rrow, i, g);
+      else if (wave == 2) rank64_update<1, 3>(acc, lds.U, rrow, i, g);
+      else if (wave == 3) rank64_update<2, 4>(acc, lds.U, rrow, i, g);
+      else rank64_update<0, 4>(acc, lds.U, rrow, i, g);
+    } else if (wave == 4) {
+      d4 h0 = d4{0.0, 0.0, 0.0, 0.0}, h1 = h0, h2 = h0;
 #pragma unroll 4
       for (int ks = 0; ks < CNB / 4; ++ks) {
-        const double br = lds.U[4 * ks + g][rrow];
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-          if (cb < ncb) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lds.U[4 * ks + g][16 * cb + i], br, acc[cb], 0, 0, 0);
+        const double br3 = lds.U[4 * ks + g][48 + i], br2 = lds.U[4 * ks + g][32 + i];
+        const double a0 = -lds.U[4 * ks + g][i], a1 = -lds.U[4 * ks + g][16 + i];
+        h0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, br3, h0, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, br3, h1, 0, 0, 0);
+        h2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, br2, h2, 0, 0, 0);
       }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { lds.H[0][t][lane] = h0[t]; lds.H[1][t][lane] = h1[t]; lds.H[2][t][lane] = h2[t]; }
+    }
+    __syncthreads();
+    if (wave == 3) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { acc[0][t] += lds.H[0][t][lane]; acc[1][t] += lds.H[1][t][lane]; }
+    } else if (wave == 2) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[0][t] += lds.H[2][t][lane];
     }
   }
   const int bad = factor_tile(lds.f, acc, wave, lane, sink);

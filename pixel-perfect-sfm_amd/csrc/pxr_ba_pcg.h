@@ -24,7 +24,7 @@ struct PcgArgs {
   double* Mloc;                      // [n_images][DC][DC]
   double* Gm;                        // [n_groups][PCG_GS][PCG_GS]
   double *x, *r, *p, *q, *z, *b;     // [n_c]
-  double* cgs;                       // [8] scalars
+  double* cgs;                       // [8] scalars + [8] control block of the device-resident loop
   double* cg_part;                   // [8][ceil(n_c / 256)] per-block partial sums of the dot products
   int* d_fail;
 };

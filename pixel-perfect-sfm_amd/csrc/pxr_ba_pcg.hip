@@ -30,39 +30,55 @@
 namespace pxr {
 
 static inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
+
+// device-resident control block of the conjugate-gradient loop (doubles, right behind the eight scalars of `cgs`): the loop's
+// stopping decisions are taken ON the device (k_cg_decide) and every kernel of an iteration returns at once when STOP is
+// set, so the host enqueues iterations without waiting for any of them and looks at the block only every few iterations
+enum { CTL_STOP = 0, CTL_ITERS = 1, CTL_Q0 = 2, CTL_XR = 3, CTL_TOL_R = 4, CTL_ETA = 5, CTL_NORM_B = 6, CTL_SIZE = 8 };
 #define RC(call) do { int _rc = (call); if (_rc != PXR_OK) return _rc; } while (0)
 
 // ---- u_p = T_p (g_p + sum_j W_j^T v_j): the point-major pass ---------------------------------------------
+// G lanes share one POINT: lane a walks row a of the W block of each of the point's observations (one coalesced 24 G-byte
+// read per observation and group -- a thread per point read 24 doubles at a stride of the whole track: 125 us per pass at
+// 1M observations against 50 us for the same bytes in k_img_wu), the three partial sums are reduced over the group with
+// DPP-free shuffles in a fixed order (deterministic), lane 0 applies T_p.
+template <int G>
 __global__ __launch_bounds__(256) void k_pt_u(const SolveDev d, const int64_t* __restrict__ pt_ptr,
                                               const int* __restrict__ pj, const int4* __restrict__ pcols,
                                               const double* __restrict__ W, const double* __restrict__ T,
                                               const double* __restrict__ vec /* [n_c] or NULL */,
                                               const double* __restrict__ gp /* [n_points][3] or NULL */,
-                                              double* __restrict__ u) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= d.v.n_points) return;
-  double v[3] = {0, 0, 0};
-  if (d.pt_var[p]) {
-    if (gp) { v[0] = gp[3 * p]; v[1] = gp[3 * p + 1]; v[2] = gp[3 * p + 2]; }
-    if (vec) {
-      for (int64_t o = pt_ptr[p]; o < pt_ptr[p + 1]; ++o) {
-        const int64_t i = pj[o];
-        const int4 ci = pcols[o];                     // {pose_off, pose_dim, intr_off, intr_dim}
-        const int dci = ci.y + ci.w;
-        const double* Wi = W + (size_t)i * d.DC * 3;
-        for (int a = 0; a < dci; ++a) {
-          const double x = vec[a < ci.y ? ci.x + a : ci.z + (a - ci.y)];
-          v[0] += Wi[3 * a] * x; v[1] += Wi[3 * a + 1] * x; v[2] += Wi[3 * a + 2] * x;
-        }
+                                              double* __restrict__ u, const double* __restrict__ ctl /* or NULL */) {
+  if (ctl && ctl[CTL_STOP] != 0.0) return;
+  const int lane_a = threadIdx.x % G;
+  const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const bool live = p < d.v.n_points;                      // whole groups are live or not: the shuffles below stay inside a group
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+  const bool var = live && d.pt_var[p];
+  if (var && vec) {
+    for (int64_t o = pt_ptr[p]; o < pt_ptr[p + 1]; ++o) {
+      const int4 ci = pcols[o];                       // {pose_off, pose_dim, intr_off, intr_dim}
+      if (lane_a < ci.y + ci.w) {
+        const double* Wi = W + ((size_t)pj[o] * d.DC + lane_a) * 3;
+        const double x = vec[lane_a < ci.y ? ci.x + lane_a : ci.z + (lane_a - ci.y)];
+        v0 += Wi[0] * x; v1 += Wi[1] * x; v2 += Wi[2] * x;
       }
     }
-    const double* Tp = T + 6 * p;
-    const double t0 = Tp[0] * v[0] + Tp[1] * v[1] + Tp[2] * v[2];
-    const double t1 = Tp[1] * v[0] + Tp[3] * v[1] + Tp[4] * v[2];
-    const double t2 = Tp[2] * v[0] + Tp[4] * v[1] + Tp[5] * v[2];
-    v[0] = t0; v[1] = t1; v[2] = t2;
   }
-  u[3 * p] = v[0]; u[3 * p + 1] = v[1]; u[3 * p + 2] = v[2];
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) {              // fixed butterfly inside the G-lane group
+    v0 += __shfl_xor(v0, off); v1 += __shfl_xor(v1, off); v2 += __shfl_xor(v2, off);
+  }
+  if (!live || lane_a != 0) return;
+  if (var) {
+    if (gp) { v0 += gp[3 * p]; v1 += gp[3 * p + 1]; v2 += gp[3 * p + 2]; }
+    const double* Tp = T + 6 * p;
+    const double t0 = Tp[0] * v0 + Tp[1] * v1 + Tp[2] * v2;
+    const double t1 = Tp[1] * v0 + Tp[3] * v1 + Tp[4] * v2;
+    const double t2 = Tp[2] * v0 + Tp[4] * v1 + Tp[5] * v2;
+    v0 = t0; v1 = t1; v2 = t2;
+  }
+  u[3 * p] = v0; u[3 * p + 1] = v1; u[3 * p + 2] = v2;
 }
 
 // ---- out[cols(img)] += sign * sum_{i in chunk} W_i u_p(i): the image-major pass ----------------------------
@@ -71,8 +87,10 @@ __global__ __launch_bounds__(256) void k_pt_u(const SolveDev d, const int64_t* _
 template <int G>
 __global__ __launch_bounds__(256) void k_img_wu(const SolveDev d, const ImgChunk* __restrict__ chunks,
                                                 const int4* __restrict__ so, const double* __restrict__ W,
-                                                const double* __restrict__ u, double sign, double* __restrict__ out) {
+                                                const double* __restrict__ u, double sign, double* __restrict__ out,
+                                                const double* __restrict__ ctl /* or NULL */) {
   __shared__ double red[256];
+  if (ctl && ctl[CTL_STOP] != 0.0) return;
   const ImgChunk ch = chunks[blockIdx.x];
   const int img = ch.img, cam = d.v.d_image_camera[img];
   const int dci = d.pose_dim[img] + d.intr_dim[cam];
@@ -98,10 +116,11 @@ __global__ __launch_bounds__(256) void k_img_wu(const SolveDev d, const ImgChunk
 
 // ---- out += U v, U = one dc x dc block per image ------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ublk_matvec(const SolveDev d, const double* __restrict__ Ublk,
-                                                     const double* __restrict__ vec, double* __restrict__ out) {
+                                                     const double* __restrict__ vec, double* __restrict__ out,
+                                                     const double* __restrict__ ctl) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int img = (int)(t / d.DC), a = (int)(t - (int64_t)img * d.DC);
-  if (img >= d.v.n_images) return;
+  if (img >= d.v.n_images || ctl[CTL_STOP] != 0.0) return;
   const int cam = d.v.d_image_camera[img];
   const int dci = d.pose_dim[img] + d.intr_dim[cam];
   if (a >= dci) return;
@@ -234,26 +253,44 @@ __device__ __forceinline__ void block_partial(double v, double* __restrict__ par
   __syncthreads();
   if (threadIdx.x == 0) part[(size_t)slot * nb + blockIdx.x] = (sh[slot][0] + sh[slot][1]) + (sh[slot][2] + sh[slot][3]);
 }
-
-__global__ void k_cg_finalize(const double* __restrict__ part, int nb, unsigned slot_mask, double* __restrict__ cgs) {
-  const int s = threadIdx.x;
-  if (s >= CG_SLOTS || !((slot_mask >> s) & 1u)) return;
-  double t = 0.0;
-  for (int b = 0; b < nb; ++b) t += part[(size_t)s * nb + b];
-  cgs[s] = t;
-}
-__global__ void k_cg_begin(double* __restrict__ cgs) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    cgs[1] = cgs[0];
-    cgs[0] = 0.0; cgs[2] = 0.0; cgs[3] = 0.0; cgs[4] = 0.0; cgs[5] = 0.0;
+// the sum of a slot's partials, formed by every block of a consumer kernel for itself instead of waiting for a one-thread
+// "finalize" launch: lane l of the block's first wavefront adds partials l, l + 64, ... in order, then a fixed butterfly --
+// the same order in every block and on every rank, hence the same bits everywhere.  All threads of the block must call it.
+__device__ __forceinline__ double slot_sum(const double* __restrict__ part, int slot, int nb) {
+  __shared__ double total[CG_SLOTS];
+  if (threadIdx.x < 64) {
+    double t = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 64) t += part[(size_t)slot * nb + b];
+    t = wave_sum(t);
+    if (threadIdx.x == 0) total[slot] = t;
   }
+  __syncthreads();
+  return total[slot];
 }
 
-// z = M^-1 r, rho = r.z
+__global__ void k_cg_finalize(const double* __restrict__ part, int nb, unsigned slot_mask, double* __restrict__ cgs) {   // 64 threads
+  for (int s = 0; s < CG_SLOTS; ++s)
+    if ((slot_mask >> s) & 1u) { const double t = slot_sum(part, s, nb); if (threadIdx.x == 0) cgs[s] = t; }
+}
+
+// set-up of the loop's control block: |b|, the tolerances, "not stopped"; |b| = 0 or not finite stops before the first iteration
+__global__ void k_cg_init(double* __restrict__ cgs, double* __restrict__ ctl, double r_tolerance, double eta, const int* __restrict__ fail) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double norm_b = sqrt(cgs[6]);
+  ctl[CTL_NORM_B] = norm_b;
+  ctl[CTL_TOL_R] = r_tolerance > 0.0 ? r_tolerance * norm_b : -1.0;
+  ctl[CTL_ETA] = eta;
+  ctl[CTL_ITERS] = 0.0; ctl[CTL_Q0] = 0.0; ctl[CTL_XR] = 0.0;
+  ctl[CTL_STOP] = (*fail != 0 || !isfinite(norm_b) || norm_b == 0.0) ? 1.0 : 0.0;
+  cgs[0] = 0.0; cgs[1] = 0.0;
+}
+
+// z = M^-1 r, partials of rho = r.z
 __global__ __launch_bounds__(256) void k_pre_apply(int n, const int2* __restrict__ col_group,
                                                    const int* __restrict__ group_size, const int* __restrict__ group_cols,
                                                    const double* __restrict__ Ginv, const double* __restrict__ r,
-                                                   double* __restrict__ z, double* __restrict__ part) {
+                                                   double* __restrict__ z, double* __restrict__ part, const double* __restrict__ ctl) {
+  if (ctl[CTL_STOP] != 0.0) return;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   double v = 0.0;
   if (c < n) {
@@ -269,18 +306,26 @@ __global__ __launch_bounds__(256) void k_pre_apply(int n, const int2* __restrict
   block_partial(v, part, 0, gridDim.x);
 }
 
-__global__ void k_cg_p_update(int n, int first, const double* __restrict__ z, double* __restrict__ p,
-                              const double* __restrict__ cgs) {
+// rho from its partials; p = z + (rho / rho_prev) p; q = 0 for the products that follow
+__global__ __launch_bounds__(256) void k_cg_p_update(int n, int first, const double* __restrict__ z, double* __restrict__ p,
+                                                     double* __restrict__ q, const double* __restrict__ part, int nb,
+                                                     double* __restrict__ cgs, const double* __restrict__ ctl) {
+  if (ctl[CTL_STOP] != 0.0) return;
+  const double rho = slot_sum(part, 0, nb);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double beta = first ? 0.0 : cgs[0] / cgs[1];
-  p[i] = first ? z[i] : z[i] + beta * p[i];
+  if (i < n) {
+    const double beta = first ? 0.0 : rho / cgs[1];
+    p[i] = first ? z[i] : z[i] + beta * p[i];
+    q[i] = 0.0;
+  }
+  if (i == 0) cgs[0] = rho;
 }
 
-// q += D p / radius (after the all-reduce of the partial products), p.q
+// q += D p / radius (after the all-reduce of the partial products), partials of p.q
 __global__ __launch_bounds__(256) void k_cg_q_finish(int n, const double* __restrict__ damp, double inv_radius,
                                                      const double* __restrict__ p, double* __restrict__ q,
-                                                     double* __restrict__ part) {
+                                                     double* __restrict__ part, const double* __restrict__ ctl) {
+  if (ctl[CTL_STOP] != 0.0) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double v = 0.0;
   if (i < n) {
@@ -291,13 +336,15 @@ __global__ __launch_bounds__(256) void k_cg_q_finish(int n, const double* __rest
   block_partial(v, part, 2, gridDim.x);
 }
 
-// x += alpha p, r -= alpha q unless the matrix turned out indefinite along p (p.q <= 0: the host stops and keeps x)
+// p.q from its partials; x += alpha p, r -= alpha q unless the matrix turned out indefinite along p (p.q <= 0: the loop
+// stops and keeps x); partials of x.b, x.r, r.r
 __global__ __launch_bounds__(256) void k_cg_xr_update(int n, const double* __restrict__ p, const double* __restrict__ q,
                                                       const double* __restrict__ b, double* __restrict__ x,
-                                                      double* __restrict__ r, const double* __restrict__ cgs,
-                                                      double* __restrict__ part) {
+                                                      double* __restrict__ r, double* __restrict__ cgs,
+                                                      double* __restrict__ part, int nb, const double* __restrict__ ctl) {
+  if (ctl[CTL_STOP] != 0.0) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const double pq = cgs[2], rho = cgs[0];
+  const double pq = slot_sum(part, 2, nb), rho = cgs[0];
   const bool ok = pq > 0.0 && isfinite(pq) && rho != 0.0 && isfinite(rho);
   double xb = 0.0, xr = 0.0, rr = 0.0;
   if (i < n) {
@@ -309,9 +356,30 @@ __global__ __launch_bounds__(256) void k_cg_xr_update(int n, const double* __res
     }
     xb = xi * b[i]; xr = xi * ri; rr = ri * ri;
   }
+  if (i == 0) cgs[2] = pq;
   block_partial(xb, part, 3, gridDim.x);
   block_partial(xr, part, 4, gridDim.x);
   block_partial(rr, part, 5, gridDim.x);
+}
+
+// the end of iteration `it`: Ceres' tests ([upstream] conjugate_gradients_solver.cc) on the device
+__global__ void k_cg_decide(int it, const double* __restrict__ part, int nb, double* __restrict__ cgs, double* __restrict__ ctl) {
+  if (blockIdx.x != 0 || ctl[CTL_STOP] != 0.0) return;                 // one block of 64 threads
+  const double xb = slot_sum(part, 3, nb), xr = slot_sum(part, 4, nb), rr = slot_sum(part, 5, nb);
+  if (threadIdx.x != 0) return;
+  const double rho = cgs[0], pq = cgs[2];
+  cgs[3] = xb; cgs[4] = xr; cgs[5] = rr;
+  cgs[1] = rho;                                                    // rho_prev of the next iteration
+  if (!isfinite(rho) || rho == 0.0) { ctl[CTL_STOP] = 1.0; return; }   // "Numerical failure. rho = r'z = 0": iteration not counted
+  if (!(pq > 0.0) || !isfinite(pq)) { ctl[CTL_STOP] = 1.0; return; }   // "Matrix is indefinite": the last x is kept
+  ctl[CTL_ITERS] = (double)it;
+  ctl[CTL_XR] = xr;
+  // Q = x.Sx / 2 - x.b = -(x.b + x.r) / 2 with r = b - S x
+  const double Q1 = -0.5 * (xb + xr);
+  const double zeta = it * (Q1 - ctl[CTL_Q0]) / Q1;
+  if (zeta < ctl[CTL_ETA]) { ctl[CTL_STOP] = 1.0; return; }
+  ctl[CTL_Q0] = Q1;
+  if (ctl[CTL_TOL_R] > 0.0 && sqrt(rr) <= ctl[CTL_TOL_R]) ctl[CTL_STOP] = 1.0;
 }
 
 __global__ void k_vec_add(int n, const double* __restrict__ a, double* __restrict__ y) {
@@ -341,11 +409,15 @@ int pcg_solve(PcgArgs& a, double inv_radius, const pxr_lm_options* opt, const st
 
   // ---- right-hand side b = g_c - sum_i W_i T_p g_p (g_c is already the sum over the ranks) --------------
   PXR_HIP(hipMemsetAsync(a.b, 0, sizeof(double) * n, st));
-  hipLaunchKernelGGL(k_pt_u, dim3(nblk(n_pts)), dim3(256), 0, st, d, a.pt_ptr, a.part_obs, a.obs_cols, a.W, a.T,
-                     (const double*)nullptr, a.gp, a.u);
+  launch_by_g(DC, [&](auto G) {
+    constexpr int GG = decltype(G)::value;
+    hipLaunchKernelGGL(k_pt_u<GG>, dim3(nblk(n_pts * GG)), dim3(256), 0, st, d, a.pt_ptr, a.part_obs, a.obs_cols, a.W, a.T,
+                       (const double*)nullptr, a.gp, a.u, (const double*)nullptr);
+  });
   if (a.n_chunks > 0)
     launch_by_g(DC, [&](auto G) {
-      hipLaunchKernelGGL(k_img_wu<decltype(G)::value>, dim3((unsigned)a.n_chunks), dim3(256), 0, st, d, a.chunks, a.so, a.W, a.u, -1.0, a.b);
+      hipLaunchKernelGGL(k_img_wu<decltype(G)::value>, dim3((unsigned)a.n_chunks), dim3(256), 0, st, d, a.chunks, a.so, a.W, a.u, -1.0, a.b,
+                         (const double*)nullptr);
     });
   // ---- preconditioner: local blocks = U_img - sum_i Y_i W_i^T, gathered into the column groups ----------
   PXR_HIP(hipMemcpyAsync(a.Mloc, a.Ublk, sizeof(double) * (size_t)n_img * DC * DC, hipMemcpyDeviceToDevice, st));
@@ -366,63 +438,51 @@ int pcg_solve(PcgArgs& a, double inv_radius, const pxr_lm_options* opt, const st
   // ---- x = 0, r = b ------------------------------------------------------------------------------------------
   PXR_HIP(hipMemsetAsync(a.x, 0, sizeof(double) * n, st));
   PXR_HIP(hipMemcpyAsync(a.r, a.b, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
-  PXR_HIP(hipMemsetAsync(a.cgs, 0, sizeof(double) * 8, st));
+  PXR_HIP(hipMemsetAsync(a.cgs, 0, sizeof(double) * (8 + CTL_SIZE), st));
   const int nb = (int)nblk(n);
+  double* ctl = a.cgs + 8;
   hipLaunchKernelGGL(k_dot, dim3(nb), dim3(256), 0, st, n, a.b, a.b, a.cg_part, 6);
   hipLaunchKernelGGL(k_cg_finalize, dim3(1), dim3(64), 0, st, a.cg_part, nb, 1u << 6, a.cgs);
-  double hs[8];
-  int h_fail = 0;
-  PXR_HIP(hipMemcpyAsync(&h_fail, a.d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
-  PXR_HIP(hipMemcpyAsync(hs, a.cgs, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
-  PXR_HIP(hipStreamSynchronize(st));
-  if (h_fail) { if (verbose) fprintf(stderr, "[pxr_ba_solve] pcg: a preconditioner block is not positive definite\n"); return PXR_OK; }
-  const double norm_b = std::sqrt(hs[6]);
-  if (!std::isfinite(norm_b)) return PXR_OK;
-  if (norm_b == 0.0) { res->ok = true; return PXR_OK; }          // x = 0 solves it
-  const double tol_r = opt->linear_r_tolerance > 0.0 ? opt->linear_r_tolerance * norm_b : -1.0;
+  hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(64), 0, st, a.cgs, ctl, opt->linear_r_tolerance, opt->eta, a.d_fail);
+  // ---- the loop: no host round trip inside an iteration.  The control block comes to the host after iteration 2 (where
+  // Ceres' Q test usually ends a well-preconditioned solve) and then after every fourth; iterations enqueued past the
+  // stop are a handful of kernels that return at their first instruction.
   const int max_it = opt->max_linear_solver_iterations > 0 ? opt->max_linear_solver_iterations : 200;
-  double Q0 = 0.0;
+  struct { double cgs[8]; double ctl[CTL_SIZE]; } h;
+  int h_fail = 0;
   for (int it = 1; it <= max_it; ++it) {
-    hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(64), 0, st, a.cgs);
-    hipLaunchKernelGGL(k_pre_apply, dim3(nb), dim3(256), 0, st, n, a.col_group, a.group_size, a.group_cols, a.Gm, a.r, a.z, a.cg_part);
-    hipLaunchKernelGGL(k_cg_finalize, dim3(1), dim3(64), 0, st, a.cg_part, nb, 1u << 0, a.cgs);
-    hipLaunchKernelGGL(k_cg_p_update, dim3(nblk(n)), dim3(256), 0, st, n, it == 1 ? 1 : 0, a.z, a.p, a.cgs);
+    hipLaunchKernelGGL(k_pre_apply, dim3(nb), dim3(256), 0, st, n, a.col_group, a.group_size, a.group_cols, a.Gm, a.r, a.z, a.cg_part, ctl);
+    hipLaunchKernelGGL(k_cg_p_update, dim3(nb), dim3(256), 0, st, n, it == 1 ? 1 : 0, a.z, a.p, a.q, a.cg_part, nb, a.cgs, ctl);
     // q = S p (partial over this rank's points)
-    PXR_HIP(hipMemsetAsync(a.q, 0, sizeof(double) * n, st));
-    hipLaunchKernelGGL(k_ublk_matvec, dim3(nblk((int64_t)n_img * DC)), dim3(256), 0, st, d, a.Ublk, a.p, a.q);
-    hipLaunchKernelGGL(k_pt_u, dim3(nblk(n_pts)), dim3(256), 0, st, d, a.pt_ptr, a.part_obs, a.obs_cols, a.W, a.T, a.p,
-                       (const double*)nullptr, a.u);
+    hipLaunchKernelGGL(k_ublk_matvec, dim3(nblk((int64_t)n_img * DC)), dim3(256), 0, st, d, a.Ublk, a.p, a.q, ctl);
+    launch_by_g(DC, [&](auto G) {
+      constexpr int GG = decltype(G)::value;
+      hipLaunchKernelGGL(k_pt_u<GG>, dim3(nblk(n_pts * GG)), dim3(256), 0, st, d, a.pt_ptr, a.part_obs, a.obs_cols, a.W, a.T, a.p,
+                         (const double*)nullptr, a.u, ctl);
+    });
     if (a.n_chunks > 0)
       launch_by_g(DC, [&](auto G) {
-        hipLaunchKernelGGL(k_img_wu<decltype(G)::value>, dim3((unsigned)a.n_chunks), dim3(256), 0, st, d, a.chunks, a.so, a.W, a.u, -1.0, a.q);
+        hipLaunchKernelGGL(k_img_wu<decltype(G)::value>, dim3((unsigned)a.n_chunks), dim3(256), 0, st, d, a.chunks, a.so, a.W, a.u, -1.0, a.q, ctl);
       });
     RC(hip_check(hipGetLastError(), "pcg matvec kernels"));
-    RC(ar(a.q, n));
-    hipLaunchKernelGGL(k_cg_q_finish, dim3(nb), dim3(256), 0, st, n, a.damp_c, inv_radius, a.p, a.q, a.cg_part);
-    hipLaunchKernelGGL(k_cg_finalize, dim3(1), dim3(64), 0, st, a.cg_part, nb, 1u << 2, a.cgs);
-    hipLaunchKernelGGL(k_cg_xr_update, dim3(nb), dim3(256), 0, st, n, a.p, a.q, a.b, a.x, a.r, a.cgs, a.cg_part);
-    hipLaunchKernelGGL(k_cg_finalize, dim3(1), dim3(64), 0, st, a.cg_part, nb, (1u << 3) | (1u << 4) | (1u << 5), a.cgs);
-    PXR_HIP(hipMemcpyAsync(hs, a.cgs, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
-    PXR_HIP(hipStreamSynchronize(st));
-    const double rho = hs[0], pq = hs[2], xb = hs[3], xr = hs[4], rr = hs[5];
-    if (!std::isfinite(rho) || rho == 0.0) {                      // [upstream] "Numerical failure. rho = r'z = 0"
-      if (it == 1) return PXR_OK;                                  // res->ok stays false: LINEAR_SOLVER_FAILURE
-      break;
+    RC(ar(a.q, n));                   // (past the stop: every rank reduces the same stale vector -- the ranks stay in step)
+    hipLaunchKernelGGL(k_cg_q_finish, dim3(nb), dim3(256), 0, st, n, a.damp_c, inv_radius, a.p, a.q, a.cg_part, ctl);
+    hipLaunchKernelGGL(k_cg_xr_update, dim3(nb), dim3(256), 0, st, n, a.p, a.q, a.b, a.x, a.r, a.cgs, a.cg_part, nb, ctl);
+    hipLaunchKernelGGL(k_cg_decide, dim3(1), dim3(64), 0, st, it, a.cg_part, nb, a.cgs, ctl);
+    if (verbose || it == 2 || it % 4 == 0 || it == max_it) {
+      PXR_HIP(hipMemcpyAsync(&h, a.cgs, sizeof(h), hipMemcpyDeviceToHost, st));
+      PXR_HIP(hipMemcpyAsync(&h_fail, a.d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+      PXR_HIP(hipStreamSynchronize(st));
+      if (verbose && (int)h.ctl[CTL_ITERS] == it)
+        fprintf(stderr, "[pxr_ba_solve]   cg %3d |r|/|b| %.3e Q %.9e\n", it, std::sqrt(h.cgs[5]) / h.ctl[CTL_NORM_B], -0.5 * (h.cgs[3] + h.cgs[4]));
+      if (h.ctl[CTL_STOP] != 0.0) break;
     }
-    if (!(pq > 0.0) || !std::isfinite(pq)) {                       // [upstream] "Matrix is indefinite": keep the last x
-      if (it == 1) return PXR_OK;
-      break;
-    }
-    res->iterations = it;
-    res->x_dot_r = xr;
-    // Q = x.Sx / 2 - x.b = -(x.b + x.r) / 2 with r = b - S x
-    const double Q1 = -0.5 * (xb + xr);
-    const double zeta = it * (Q1 - Q0) / Q1;
-    if (verbose) fprintf(stderr, "[pxr_ba_solve]   cg %3d |r|/|b| %.3e Q %.9e zeta %.3e\n", it, std::sqrt(rr) / norm_b, Q1, zeta);
-    if (zeta < opt->eta) break;
-    Q0 = Q1;
-    if (tol_r > 0.0 && std::sqrt(rr) <= tol_r) break;
   }
+  if (h_fail) { if (verbose) fprintf(stderr, "[pxr_ba_solve] pcg: a preconditioner block is not positive definite\n"); return PXR_OK; }
+  if (!std::isfinite(h.ctl[CTL_NORM_B])) return PXR_OK;
+  if (h.ctl[CTL_NORM_B] == 0.0) { res->ok = true; return PXR_OK; }          // x = 0 solves it
+  res->iterations = (int)h.ctl[CTL_ITERS];
+  res->x_dot_r = h.ctl[CTL_XR];
   res->ok = res->iterations > 0;
   return PXR_OK;
 }

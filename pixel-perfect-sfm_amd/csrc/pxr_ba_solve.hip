@@ -725,6 +725,7 @@ struct DevBuf {
 // pxr_chol.hip: factor the n x n SPD system stored row-major (upper) in the n x (n + 1) buffer `a` whose last
 // column is the right-hand side (forward substitution is fused into the factorisation), then back-substitute.
 int chol_factor_solve(hipStream_t st, double* a, int n, int* d_info, double* linv_ws, double* x_out);
+size_t chol_workspace_doubles(int n);
 
 // pxr_ba_inner.hip
 int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
@@ -943,7 +944,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   const int ldS = n_c + 1;
   double* rhs = S.p + n_c;          // column n_c of S, stride ldS
   DevBuf<double> xsol, linv;
-  RC(xsol.alloc(nc1)); RC(linv.alloc(iterative ? 1 : (size_t)((n_c + 63) / 64 + 1) * 64 * 64));
+  RC(xsol.alloc(nc1)); RC(linv.alloc(iterative ? 1 : chol_workspace_doubles(n_c)));
   DevBuf<int2> d_col_group; DevBuf<int> d_group_size, d_group_cols;
   DevBuf<double> pcg_u, pcg_mloc, pcg_g, pcg_vec, pcg_scal;
   PcgArgs pcg;
@@ -951,7 +952,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     RC(d_col_group.upload(col_group, st)); RC(d_group_size.upload(group_size, st)); RC(d_group_cols.upload(group_cols, st));
     RC(pcg_u.alloc((size_t)n_pts * 3)); RC(pcg_mloc.alloc((size_t)n_img * DC * DC));
     RC(pcg_g.alloc(group_size.size() * PCG_GS * PCG_GS)); RC(pcg_vec.alloc(5 * nc1));
-    RC(pcg_scal.alloc(8 + 8 * ((nc1 + 255) / 256)));
+    RC(pcg_scal.alloc(16 + 8 * ((nc1 + 255) / 256)));   // 8 scalars + the loop's control block + the dot-product partials
   }
   double* diagU = gcd.p; double* gc = gcd.p + nc1;
   DevBuf<int> info_buf;
@@ -1035,7 +1036,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     pcg.group_cols = d_group_cols.p;
     pcg.u = pcg_u.p; pcg.Mloc = pcg_mloc.p; pcg.Gm = pcg_g.p;
     pcg.x = xsol.p; pcg.r = pcg_vec.p; pcg.p = pcg_vec.p + nc1; pcg.q = pcg_vec.p + 2 * nc1; pcg.z = pcg_vec.p + 3 * nc1;
-    pcg.b = pcg_vec.p + 4 * nc1; pcg.cgs = pcg_scal.p; pcg.cg_part = pcg_scal.p + 8; pcg.d_fail = d_info;
+    pcg.b = pcg_vec.p + 4 * nc1; pcg.cgs = pcg_scal.p; pcg.cg_part = pcg_scal.p + 16; pcg.d_fail = d_info;
   }
   const std::function<int(double*, int64_t)> ar_fn = ar;
   // gradient_tolerance [upstream]: max-norm of the gradient in the unscaled variables, over ALL ranks

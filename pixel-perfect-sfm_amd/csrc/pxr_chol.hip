@@ -128,7 +128,7 @@ __device__ __forceinline__ void rank64_update(cholcore::d4 (&acc)[4], const doub
 // block step s: n_rows = rows of the (augmented) matrix, n_cols = columns to factor.  Grid: n_panel panel workgroups, then
 // the update workgroups of the tiles (ti, tj), 1 <= tj <= ti, of the matrix from block row s on (s >= 1 only).
 __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ a, int n_rows, int n_cols, int lda, int s, int n_panel,
-                                                   int* __restrict__ info, double* __restrict__ linv_out) {
+                                                   int* __restrict__ info, double* __restrict__ linv_out, double* __restrict__ ldiag_out) {
   using namespace cholcore;
   extern __shared__ __align__(16) unsigned char smem[];
   const int k0 = s * CNB, nb = min(CNB, n_cols - k0);
@@ -148,7 +148,9 @@ __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ a, int n
   const int r0 = k0 + nb + 16 * (vb - 4);                              // first matrix row of a real row block
   const bool real_rows = wave >= ROW_WAVE0 && vb >= 4 && r0 < n_rows;
   RowSink sink;
-  sink.l_diag = blockIdx.x == 0 ? a + (size_t)k0 + (size_t)k0 * lda : nullptr;
+  // L_ss goes to the workspace, NOT over the tile: the other panel workgroups read the tile when they start, and with more
+  // panel workgroups than CUs (n > ~12000) the late ones start after workgroup 0 has finished
+  sink.l_diag = blockIdx.x == 0 ? ldiag_out + (size_t)s * CNB * CNB : nullptr;
   sink.ld = lda; sink.nb = nb; sink.rows_valid = 16; sink.rows_out = nullptr; sink.mode = RowSink::kNone;
   d4 acc[4];
   if (wave < 4) {
@@ -279,8 +281,14 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
   }
 }
 
+// linv_ws: (2 nblk + 1) x 64 x 64 doubles, nblk = ceil(n / 64): [0, nblk) the inverses of the diagonal tiles' factors,
+// [nblk] the back-substitution's flags, [nblk + 1, 2 nblk + 1) the diagonal tiles' factors L_ss (column-major 64 x 64; in
+// `a` the diagonal tiles keep their INPUT values, see k_chol_step)
+size_t chol_workspace_doubles(int n) { return (size_t)(2 * ((n + CNB - 1) / CNB) + 1) * CNB * CNB; }
+
 int chol_factor_solve(hipStream_t st, double* a, int n, int* d_info, double* linv_ws, double* x_out) {
   const int lda = n + 1, n_rows = n + 1;
+  const int nblk = (n + CNB - 1) / CNB;
   // > 64 KiB of dynamic LDS needs the opt-in, per device (one process may hold contexts on several devices)
   if (int rc = hip_check(hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStepLds), "LDS size")) return rc;
   if (int rc = hip_check(hipMemsetAsync(d_info, 0, sizeof(int), st), "memset info")) return rc;
@@ -291,9 +299,9 @@ int chol_factor_solve(hipStream_t st, double* a, int n, int* d_info, double* lin
     const int n_panel = (CNB + rem + rows_per_wg - 1) / rows_per_wg;   // 64 identity rows + the rows below
     const int T = (n_rows - k + CNB - 1) / CNB;           // row tiles from block row s on; tiles (ti, tj), 1 <= tj <= ti < T
     const int n_update = s > 0 ? T * (T - 1) / 2 : 0;
-    hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_update), dim3(512), kStepLds, st, a, n_rows, n, lda, s, n_panel, d_info, linv_ws);
+    hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_update), dim3(512), kStepLds, st, a, n_rows, n, lda, s, n_panel, d_info, linv_ws,
+                       linv_ws + (size_t)(nblk + 1) * CNB * CNB);
   }
-  const int nblk = (n + CNB - 1) / CNB;
   int* flags = reinterpret_cast<int*>(linv_ws + (size_t)nblk * CNB * CNB);   // spare block of the workspace
   if (int rc = hip_check(hipMemsetAsync(flags, 0, sizeof(int) * nblk, st), "memset flags")) return rc;
   hipLaunchKernelGGL(k_chol_backsolve, dim3(nblk), dim3(256), 0, st, a, n, lda, linv_ws, x_out, flags, nblk);
@@ -310,11 +318,12 @@ __global__ void k_aug_pack(int n, const double* __restrict__ a, const double* __
   if (r < n) v = (c == n) ? b[r] : (r <= c ? a[(size_t)r * n + c] : 0.0);
   aug[t] = v;
 }
-__global__ void k_aug_unpack(int n, const double* __restrict__ aug, double* __restrict__ a) {
+__global__ void k_aug_unpack(int n, const double* __restrict__ aug, const double* __restrict__ ldiag, double* __restrict__ a) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)n * n) return;
   const int r = (int)(t / n), c = (int)(t % n);
-  if (r <= c) a[t] = aug[(size_t)r * (n + 1) + c];
+  // row-major upper (r, c) = column-major lower element (row c, column r); the diagonal tiles' factors live in the workspace
+  if (r <= c) a[t] = (r / CNB == c / CNB) ? ldiag[(size_t)(r / CNB) * CNB * CNB + (c % CNB) + (r % CNB) * CNB] : aug[(size_t)r * (n + 1) + c];
 }
 
 }  // namespace pxr
@@ -328,7 +337,7 @@ extern "C" int pxr_dense_spd_solve(pxr_ctx* ctx, double* d_a, int n, double* d_b
   PXR_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   double *aug = nullptr, *linv = nullptr;
-  const size_t na = (size_t)(n + 1) * (n + 1), nl = (size_t)((n + 63) / 64 + 1) * 64 * 64;
+  const size_t na = (size_t)(n + 1) * (n + 1), nl = chol_workspace_doubles(n);
   if (hipMalloc((void**)&aug, sizeof(double) * na) != hipSuccess || hipMalloc((void**)&linv, sizeof(double) * nl) != hipSuccess) {
     (void)hipFree(aug); (void)hipFree(linv);
     return set_error(PXR_ENOMEM, "pxr_dense_spd_solve: workspace allocation failed");
@@ -337,7 +346,8 @@ extern "C" int pxr_dense_spd_solve(pxr_ctx* ctx, double* d_a, int n, double* d_b
   hipLaunchKernelGGL(k_aug_pack, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, st, n, d_a, d_b, aug);
   int rc = chol_factor_solve(st, aug, n, d_info, linv, d_b);
   if (!rc) {
-    hipLaunchKernelGGL(k_aug_unpack, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, n, aug, d_a);
+    hipLaunchKernelGGL(k_aug_unpack, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, n, aug,
+                       linv + (size_t)((n + CNB - 1) / CNB + 1) * CNB * CNB, d_a);
     rc = hip_check(hipMemcpyAsync(h_info, d_info, sizeof(int), hipMemcpyDeviceToHost, st), "D2H info");
   }
   if (!rc) rc = hip_check(hipStreamSynchronize(st), "sync");

@@ -39,7 +39,7 @@ struct FactorLds {
 
 struct RowSink {                  // where a wavefront's results go (wave-uniform)
   enum { kNone = 0, kInverse = 1, kPanel = 2 };
-  double* l_diag;     // wavefront 1 writes L (rows >= column, both < nb) here when non-null: l_diag[row + col * ld]
+  double* l_diag;     // wavefront 1 writes L (rows >= column, both < nb) here when non-null: l_diag[row + col * 64]
   double* rows_out;   // kInverse: rows_out[col * 64 + row] (row-major inv(L): the extra rows are identity rows);
   int mode;           // kPanel:   rows_out[row + col * ld] for row < rows_valid, col < nb
   int ld, rows_valid, nb;
@@ -171,10 +171,10 @@ __device__ __forceinline__ int factor_panel(FactorLds& lds, int p, int lane, int
 // wavefront 1, one panel behind: panel p of L out of the LDS copy
 __device__ __forceinline__ void store_diag_panel(const FactorLds& lds, int p, int lane, const RowSink& sink) {
   if (!sink.l_diag || lane < PW * p || lane >= sink.nb) return;           // one exec-mask branch; rows above the panel's diagonal block hold zeros
-  double* out = sink.l_diag + (size_t)lane + (size_t)(PW * p) * sink.ld;
+  double* out = sink.l_diag + lane + (PW * p) * NB;
 #pragma unroll
   for (int k = 0; k < PW; ++k)
-    if (PW * p + k < sink.nb) out[(size_t)k * sink.ld] = lds.P[p & 1][k][lane];   // wave-uniform test; entries above the diagonal inside the
+    if (PW * p + k < sink.nb) out[k * NB] = lds.P[p & 1][k][lane];   // wave-uniform test; entries above the diagonal inside the
                                                                                   // 8 x 8 block are stored as the zeros P holds (upper part: never read)
 }
 

@@ -44,3 +44,22 @@ def test_pivot_that_turns_negative_only_after_elimination(ctx):
     info = C.c_int(0)
     ctx.lib.pxr_dense_spd_solve(ctx.handle, dA.ptr, n, db.ptr, C.byref(info))
     assert info.value == 8
+
+
+def test_more_panel_workgroups_than_compute_units(ctx):
+    """n > 48 * 256: the first block steps have more panel workgroups than the GPU has CUs, so some of them start after
+    workgroup 0 has finished its tile -- they must still find the tile's INPUT values (the factor of a diagonal tile goes
+    to the workspace, not over the tile).  Checked through the residual of the solve."""
+    n = 12352
+    rng = np.random.default_rng(5)
+    M = rng.normal(size=(n, 64))
+    A = M @ M.T + np.diag(rng.uniform(50.0, 100.0, n))
+    b = rng.normal(size=n)
+    info = C.c_int(-1)
+    dA, db = ctx.to_device(np.triu(A)), ctx.to_device(b)
+    assert ctx.lib.pxr_dense_spd_solve(ctx.handle, dA.ptr, n, db.ptr, C.byref(info)) == 0 and info.value == 0
+    x = db.download()
+    assert np.linalg.norm(A @ x - b) <= 1e-10 * np.linalg.norm(b)
+    L = np.triu(dA.download()).T                      # the returned factor, diagonal tiles included
+    rows = rng.integers(0, n, 40)
+    assert np.allclose((L[rows] @ L.T), A[rows], rtol=0, atol=1e-9 * np.abs(A).max())

@@ -103,6 +103,11 @@ int pxr_arena_destroy(pxr_arena* a);
  * scales double[count][2].  h_patches may be NULL to only set metadata. */
 int pxr_arena_upload(pxr_arena* a, int64_t first, int64_t count, const void* h_patches,
                      const int32_t* h_corners, const double* h_scales);
+/* The same from `count` SEPARATE host patches (h_patch_ptrs[i]: H*W*C elements, HWC) -- the FeaturePatch objects a
+ * FeatureView hands out one by one (features/src/featureview.cc:44-55, featurepatch.h:40-156): gathered by all host cores
+ * into pinned staging buffers and uploaded double-buffered, without a stacked host copy of the set. */
+int pxr_arena_upload_gather(pxr_arena* a, int64_t first, int64_t count, const void* const* h_patch_ptrs,
+                            const int32_t* h_corners, const double* h_scales);
 /* Sparse patch producer on the device: replaces FeatureExtractor.tensor_to_fmap's
  * sparse branch + extract_patches_torch/_numpy (pixsfm/features/extractor.py:152-199,
  * features/extract_patches.py:13-44) and the GPU -> CPU -> optimiser copies behind them.

@@ -10,6 +10,7 @@
 // tests/test_ba_setup_golden.py, tools/fuzz_setup_vs_reference.py).
 #include <algorithm>
 #include <cstdint>
+#include <thread>
 #include <vector>
 
 #include "pxr_internal.h"
@@ -116,25 +117,61 @@ extern "C" int pxr_ba_build_problem(int32_t n_images, const int32_t* image_camer
   // ---- observation order: point-major, inside a point the order of Track().Elements() -- what ComputeReference iterates
   // (reference_extractor.h:239-247: the FIRST minimum in track order) and what keeps a point's reference descriptor in L2
   // across its observations in the residual kernel
-  std::vector<int64_t> rank(obs.size());
+  // Linear time: a stable counting sort by point (registered[] is the bucket size), then inside every point's short bucket an
+  // insertion sort by the position in the track -- the buckets are independent, so the second step runs on all cores
+  // (a comparison sort of the 1M observations of BASELINE configs[2] on one core took 0.12 s, twelve LM iterations).
+  const size_t n_o = obs.size();
+  std::vector<int64_t> first((size_t)n_points + 1, 0);
+  for (int64_t p = 0; p < n_points; ++p) first[(size_t)p + 1] = first[(size_t)p] + registered[(size_t)p];
   {
-    // position of (image, p2d) inside its point's track: tracks are short, a linear scan per observation is cheap
-    for (size_t o = 0; o < obs.size(); ++o) {
-      const int64_t p = obs[o].point;
-      int64_t r = (int64_t)1 << 40;
-      for (int64_t e = track_ptr[p]; e < track_ptr[p + 1]; ++e)
-        if (track_image[e] == obs[o].image && track_p2d[e] == obs[o].p2d) { r = e - track_ptr[p]; break; }
-      rank[o] = r;
+    std::vector<int64_t> cursor(first.begin(), first.end() - 1);
+    for (size_t o = 0; o < n_o; ++o) {                              // insertion order inside a bucket = the order of `obs`
+      const int64_t at = cursor[(size_t)obs[o].point]++;
+      obs_image[at] = obs[o].image; obs_p2d[at] = obs[o].p2d; obs_point[at] = obs[o].point;
     }
   }
-  std::vector<size_t> order(obs.size());
-  for (size_t o = 0; o < obs.size(); ++o) order[o] = o;
-  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
-    if (obs[a].point != obs[b].point) return obs[a].point < obs[b].point;
-    return rank[a] < rank[b];
-  });
-  for (size_t o = 0; o < obs.size(); ++o) {
-    obs_image[o] = obs[order[o]].image; obs_p2d[o] = obs[order[o]].p2d; obs_point[o] = obs[order[o]].point;
+  auto order_points = [&](int64_t p0, int64_t p1) {
+    std::vector<int64_t> rk;
+    for (int64_t p = p0; p < p1; ++p) {
+      const int64_t b = first[(size_t)p], e = first[(size_t)p + 1];
+      if (e - b < 2) continue;
+      rk.resize((size_t)(e - b));
+      for (int64_t o = b; o < e; ++o) {                             // position of (image, p2d) inside the point's track
+        int64_t r = (int64_t)1 << 40;
+        for (int64_t t = track_ptr[p]; t < track_ptr[p + 1]; ++t)
+          if (track_image[t] == obs_image[o] && track_p2d[t] == obs_p2d[o]) { r = t - track_ptr[p]; break; }
+        rk[(size_t)(o - b)] = r;
+      }
+      for (int64_t o = b + 1; o < e; ++o) {                         // stable insertion sort by rank
+        const int64_t r = rk[(size_t)(o - b)];
+        const int32_t im = obs_image[o], k2 = obs_p2d[o];
+        int64_t q = o - 1;
+        while (q >= b && rk[(size_t)(q - b)] > r) {
+          rk[(size_t)(q + 1 - b)] = rk[(size_t)(q - b)]; obs_image[q + 1] = obs_image[q]; obs_p2d[q + 1] = obs_p2d[q];
+          --q;
+        }
+        rk[(size_t)(q + 1 - b)] = r; obs_image[q + 1] = im; obs_p2d[q + 1] = k2;
+      }
+    }
+  };
+  {
+    unsigned n_thr = std::thread::hardware_concurrency();
+    n_thr = std::max(1u, std::min(n_thr, 32u));
+    if (n_o < 65536 || n_thr == 1) {
+      order_points(0, n_points);
+    } else {
+      // ranges of ~equal numbers of observations
+      std::vector<std::thread> pool;
+      int64_t p_lo = 0;
+      for (unsigned t = 0; t < n_thr; ++t) {
+        const int64_t want = (int64_t)((n_o * (size_t)(t + 1)) / n_thr);
+        const int64_t p_hi = t + 1 == n_thr ? n_points
+                                            : (int64_t)(std::upper_bound(first.begin(), first.end(), want) - first.begin()) - 1;
+        if (p_hi > p_lo) pool.emplace_back(order_points, p_lo, p_hi);
+        p_lo = std::max(p_lo, p_hi);
+      }
+      for (auto& th : pool) th.join();
+    }
   }
   *n_obs_out = (int64_t)obs.size();
   return PXR_OK;

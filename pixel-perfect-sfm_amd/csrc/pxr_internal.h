@@ -23,6 +23,9 @@ struct pxr_ctx {
   int rank = 0, nranks = 1;
   pxr_iteration_callback iter_cb = nullptr;   // pxr_set_iteration_callback
   void* iter_user = nullptr;
+  void* h_stage[2] = {nullptr, nullptr};      // pinned staging buffers of the patch uploads (pxr_arena_upload*), lazily allocated
+  hipEvent_t ev_stage[2] = {nullptr, nullptr};
+  size_t stage_bytes = 0;
 };
 
 struct pxr_arena {

@@ -1,5 +1,7 @@
 // pxr_runtime.cpp -- context, error reporting, device-memory plumbing and the patch arena.
+#include <algorithm>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "pxr_internal.h"
@@ -55,6 +57,10 @@ int pxr_ctx_destroy(pxr_ctx* ctx) {
   if (ctx->d_workspace_mat) (void)hipFree(ctx->d_workspace_mat);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  for (int b = 0; b < 2; ++b) {
+    if (ctx->h_stage[b]) (void)hipHostFree(ctx->h_stage[b]);
+    if (ctx->ev_stage[b]) (void)hipEventDestroy(ctx->ev_stage[b]);
+  }
   delete ctx;
   return PXR_OK;
 }
@@ -164,6 +170,64 @@ int pxr_arena_destroy(pxr_arena* a) {
   return PXR_OK;
 }
 
+// Host patches -> arena through two pinned staging buffers: while the DMA engine drains one, all host cores gather the next
+// chunk into the other (from ONE contiguous block, or from `count` separate 64 KB patches -- the FeaturePatch objects of a
+// FeatureManager: no stacked host copy of the whole set first).  A pageable hipMemcpyAsync is staged by the runtime one
+// small buffer at a time on one thread; this keeps the link busy instead.
+static int upload_staged(pxr_arena* a, int64_t first, int64_t count, const void* h_contig, const void* const* h_ptrs) {
+  pxr_ctx* ctx = a->ctx;
+  hipStream_t s = ctx->stream;
+  const size_t pb = a->patch_bytes();
+  constexpr size_t kStage = (size_t)128 << 20;
+  if (!ctx->h_stage[0]) {
+    for (int b = 0; b < 2; ++b) {
+      if (hipHostMalloc(&ctx->h_stage[b], kStage, hipHostMallocDefault) != hipSuccess) {
+        for (int q = 0; q < 2; ++q) { if (ctx->h_stage[q]) (void)hipHostFree(ctx->h_stage[q]); ctx->h_stage[q] = nullptr; }
+        return pxr::set_error(PXR_ENOMEM, "pxr_arena_upload: no pinned staging memory");
+      }
+      PXR_HIP(hipEventCreateWithFlags(&ctx->ev_stage[b], hipEventDisableTiming));
+    }
+    ctx->stage_bytes = kStage;
+  }
+  const int64_t per = std::max<int64_t>(1, (int64_t)(ctx->stage_bytes / pb));
+  unsigned n_thr = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+  bool used[2] = {false, false};
+  int b = 0;
+  for (int64_t c0 = 0; c0 < count; c0 += per, b ^= 1) {
+    const int64_t n = std::min(per, count - c0);
+    if (used[b]) PXR_HIP(hipEventSynchronize(ctx->ev_stage[b]));            // the previous upload out of this buffer is done
+    char* dst = static_cast<char*>(ctx->h_stage[b]);
+    auto gather = [&](int64_t i0, int64_t i1) {
+      for (int64_t i = i0; i < i1; ++i)
+        std::memcpy(dst + (size_t)i * pb, h_ptrs ? h_ptrs[c0 + i] : static_cast<const char*>(h_contig) + (size_t)(c0 + i) * pb, pb);
+    };
+    if ((size_t)n * pb < ((size_t)4 << 20) || n_thr == 1) {
+      gather(0, n);
+    } else {
+      std::vector<std::thread> pool;
+      for (unsigned t = 0; t < n_thr; ++t) {
+        const int64_t i0 = n * t / n_thr, i1 = n * (t + 1) / n_thr;
+        if (i1 > i0) pool.emplace_back(gather, i0, i1);
+      }
+      for (auto& th : pool) th.join();
+    }
+    PXR_HIP(hipMemcpyAsync((char*)a->d_data + pb * (size_t)(first + c0), dst, pb * (size_t)n, hipMemcpyHostToDevice, s));
+    PXR_HIP(hipEventRecord(ctx->ev_stage[b], s));
+    used[b] = true;
+  }
+  return PXR_OK;
+}
+
+static int upload_meta(pxr_arena* a, int64_t first, int64_t count, const int32_t* h_corners, const double* h_scales) {
+  hipStream_t s = a->ctx->stream;
+  if (h_corners)
+    PXR_HIP(hipMemcpyAsync(a->d_corners + 2 * first, h_corners, sizeof(int32_t) * 2 * count, hipMemcpyHostToDevice, s));
+  if (h_scales)
+    PXR_HIP(hipMemcpyAsync(a->d_scales + 2 * first, h_scales, sizeof(double) * 2 * count, hipMemcpyHostToDevice, s));
+  PXR_HIP(hipStreamSynchronize(s));
+  return PXR_OK;
+}
+
 int pxr_arena_upload(pxr_arena* a, int64_t first, int64_t count, const void* h_patches,
                      const int32_t* h_corners, const double* h_scales) {
   PXR_REQUIRE(a, "pxr_arena_upload: arena is NULL");
@@ -171,18 +235,24 @@ int pxr_arena_upload(pxr_arena* a, int64_t first, int64_t count, const void* h_p
               "pxr_arena_upload: range [%lld, %lld) outside arena of %lld patches", (long long)first,
               (long long)(first + count), (long long)a->n);
   if (count == 0) return PXR_OK;
-  hipStream_t s = a->ctx->stream;
-  if (h_patches)
-    PXR_HIP(hipMemcpyAsync((char*)a->d_data + a->patch_bytes() * (size_t)first, h_patches,
-                           a->patch_bytes() * (size_t)count, hipMemcpyHostToDevice, s));
-  if (h_corners)
-    PXR_HIP(hipMemcpyAsync(a->d_corners + 2 * first, h_corners, sizeof(int32_t) * 2 * count,
-                           hipMemcpyHostToDevice, s));
-  if (h_scales)
-    PXR_HIP(hipMemcpyAsync(a->d_scales + 2 * first, h_scales, sizeof(double) * 2 * count,
-                           hipMemcpyHostToDevice, s));
-  PXR_HIP(hipStreamSynchronize(s));
-  return PXR_OK;
+  PXR_HIP(hipSetDevice(a->ctx->device));
+  if (h_patches) {
+    if (int rc = upload_staged(a, first, count, h_patches, nullptr)) return rc;
+  }
+  return upload_meta(a, first, count, h_corners, h_scales);
+}
+
+int pxr_arena_upload_gather(pxr_arena* a, int64_t first, int64_t count, const void* const* h_patch_ptrs,
+                            const int32_t* h_corners, const double* h_scales) {
+  PXR_REQUIRE(a && h_patch_ptrs, "pxr_arena_upload_gather: NULL argument");
+  PXR_REQUIRE(first >= 0 && count >= 0 && first + count <= a->n,
+              "pxr_arena_upload_gather: range [%lld, %lld) outside arena of %lld patches", (long long)first,
+              (long long)(first + count), (long long)a->n);
+  if (count == 0) return PXR_OK;
+  for (int64_t i = 0; i < count; ++i) PXR_REQUIRE(h_patch_ptrs[i], "pxr_arena_upload_gather: patch %lld is NULL", (long long)i);
+  PXR_HIP(hipSetDevice(a->ctx->device));
+  if (int rc = upload_staged(a, first, count, nullptr, h_patch_ptrs)) return rc;
+  return upload_meta(a, first, count, h_corners, h_scales);
 }
 
 int pxr_arena_set_upsampling(pxr_arena* a, double upsampling_factor) {

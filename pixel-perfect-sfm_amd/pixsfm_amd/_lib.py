@@ -92,6 +92,7 @@ _SIGNATURES = {
                                    C.POINTER(C.c_void_p)]),
     "pxr_arena_destroy": (C.c_int, [C.c_void_p]),
     "pxr_arena_upload": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pxr_arena_upload_gather": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pxr_arena_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_double, C.c_double, C.c_int]),
     "pxr_arena_data": (C.c_void_p, [C.c_void_p]),

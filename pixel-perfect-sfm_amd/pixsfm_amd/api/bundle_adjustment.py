@@ -193,34 +193,123 @@ def build_problem(image_camera, p2d_ptr, p2d_point3D, cam_model, n_points, track
                 camera_mask=cmask, point_role=role)
 
 
+class _SceneDump:
+    """The Python objects of a scene read ONCE into flat arrays: images / cameras / points in ascending id, every point2D's
+    point index, the tracks, and which (image, point2D) has a feature patch.  Independent of the BundleAdjustmentSetup and
+    of the extractor / optimiser role, so BundleAdjuster.refine hands the same dump to the reference extraction and to the
+    optimiser (the dump is the per-observation Python work of the drop-in path; pxr_ba_build_problem is native)."""
+
+    def __init__(self, reconstruction, feature_view):
+        rec = reconstruction
+        self.reconstruction, self.feature_view = rec, feature_view
+        self.img_ids, self.cam_ids, self.pt_ids = sorted(rec.images), sorted(rec.cameras), sorted(rec.points3D)
+        img_ids, pt_ids = self.img_ids, self.pt_ids
+        self.img_of = {i: k for k, i in enumerate(img_ids)}
+        self.cam_of = {c: k for k, c in enumerate(self.cam_ids)}
+        self.pt_of = pt_of = {p: k for k, p in enumerate(pt_ids)}
+        images = [rec.images[i] for i in img_ids]
+        self.image_camera = np.array([self.cam_of[im.camera_id] for im in images], np.int32)
+        self.counts = counts = [len(im.points2D) for im in images]
+        self.p2d_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        try:        # the attribute alone (-1 = no 3D point here); pycolmap marks it with 2^64 - 1, which does not fit: ask has_point3D()
+            ids = np.fromiter((q.point3D_id for im in images for q in im.points2D), dtype=np.int64, count=int(self.p2d_ptr[-1]))
+        except OverflowError:
+            ids = np.fromiter((q.point3D_id if q.has_point3D() else -1 for im in images for q in im.points2D), dtype=np.int64,
+                              count=int(self.p2d_ptr[-1]))
+        # point3D id -> index in ascending-id order (ids are arbitrary integers: binary search in the sorted id list)
+        pt_arr = np.asarray(pt_ids, dtype=np.int64)
+        pos = np.searchsorted(pt_arr, np.maximum(ids, 0)) if len(pt_arr) else np.zeros(len(ids), np.int64)
+        pos = np.minimum(pos, max(len(pt_arr) - 1, 0))
+        known = (ids >= 0) & (pt_arr[pos] == ids) if len(pt_arr) else np.zeros(len(ids), bool)
+        if ((ids >= 0) & ~known).any():
+            raise KeyError(int(ids[(ids >= 0) & ~known][0]))           # a point2D refers to a point3D the reconstruction lacks
+        self.p2d_point3D = np.where(known, pos, -1).astype(np.int64)
+        points = [rec.points3D[p] for p in pt_ids]
+        tl = [pt.track.length() for pt in points]
+        self.track_ptr = np.concatenate([[0], np.cumsum(tl)]).astype(np.int64)
+        n_el = int(self.track_ptr[-1])
+        img_of = self.img_of
+        self.track_image = np.fromiter((img_of[e.image_id] for pt in points for e in pt.track.elements), dtype=np.int32, count=n_el)
+        self.track_p2d = np.fromiter((e.point2D_idx for pt in points for e in pt.track.elements), dtype=np.int32, count=n_el)
+        self.cam_model = np.array([rec.cameras[c].model_id for c in self.cam_ids], np.int32)
+        # which observations have a feature patch -- per image one set lookup over its keypoint ids, not one call per point2D
+        fs = getattr(feature_view, "feature_set", None)
+        self.has_patch = np.zeros(len(ids), np.uint8)
+        self._patch_dicts = []
+        if fs is None:                           # any object with has_fpatch / fpatch (image_id, point2D_idx): asked one by one
+            self._patch_dicts = None
+            for k, i in enumerate(img_ids):
+                for j in range(counts[k]):
+                    at = int(self.p2d_ptr[k]) + j
+                    self.has_patch[at] = 1 if (self.p2d_point3D[at] < 0 or feature_view.has_fpatch(i, j)) else 0
+            images = []
+        for k, im in enumerate(images):
+            lo, hi = int(self.p2d_ptr[k]), int(self.p2d_ptr[k + 1])
+            fm = fs.fmap(im.name) if fs.has_fmap(im.name) else None
+            self._patch_dicts.append(fm)
+            if fm is None or hi == lo:
+                continue
+            if fm.is_sparse:
+                keys = np.fromiter(fm.patches.keys(), dtype=np.int64, count=len(fm.patches))
+                self.has_patch[lo:hi] = np.isin(np.arange(hi - lo, dtype=np.int64), keys)
+            else:
+                self.has_patch[lo:hi] = 1 if fm.has_fpatch(0) else 0
+        self.has_patch[self.p2d_point3D < 0] = 1                        # never asked (only observations of 3D points are)
+
+    def patches_of(self, obs_image_idx, obs_p2d):
+        """The FeaturePatch / ArenaPatch of each (image index, point2D index), image by image (one dict per image)."""
+        if self._patch_dicts is None:
+            return [self.feature_view.fpatch(self.img_ids[a], b) for a, b in zip(obs_image_idx.tolist(), obs_p2d.tolist())]
+        out = np.empty(len(obs_image_idx), dtype=object)
+        order = np.argsort(obs_image_idx, kind="stable")
+        bounds = np.searchsorted(obs_image_idx[order], np.arange(len(self.img_ids) + 1))
+        for k in range(len(self.img_ids)):
+            sel = order[bounds[k]:bounds[k + 1]]
+            if len(sel) == 0:
+                continue
+            fm = self._patch_dicts[k]
+            if fm is None:
+                raise KeyError(self.reconstruction.images[self.img_ids[k]].name)
+            if fm.is_sparse:
+                pd = fm.patches
+                out[sel] = [pd[j] for j in obs_p2d[sel].tolist()]
+            else:
+                out[sel] = fm.fpatch(0)
+        return out.tolist()
+
+
 class _FlatBA:
     """Flat arrays of the residual blocks BundleOptimizer::SetUp would add (bundle_optimizer.h:139-165) and of the
     parameterisation (:335-453).  The walk over the scene is native host code (build_problem -> pxr_ba_build_problem); this
     class dumps the pycolmap-style objects into the flat scene arrays it takes and compacts its answer into the arrays of
     pxr_ba_view (images / cameras / points that take part, in ascending id)."""
 
-    def __init__(self, reconstruction, setup, feature_view, options=None, point_filter=None, extractor=False):
+    def __init__(self, reconstruction, setup, feature_view, options=None, point_filter=None, extractor=False, scene=None):
         """extractor=True: the read-only use by ReferenceExtractor / CostMapExtractor -- the reconstruction is const
         there (no NormalizeQvec; the rotation normalises q itself) and an observation without a patch is skipped like
         GetVisibleObservations does (reference_extractor.h:171-213).  extractor=False: the optimiser's SetUp, where a
         missing patch is an error (feature_view.GetFeaturePatch / references.at throw,
-        feature_reference_bundle_optimizer.h:100-108).  point_filter: only these points' observations are walked."""
+        feature_reference_bundle_optimizer.h:100-108).  point_filter: only these points' observations are walked.
+        scene: a _SceneDump of (reconstruction, feature_view) made earlier (BundleAdjuster.refine shares one)."""
+        from ._timing import phase
+        self._phase = phase
+        with phase("dump"):
+            if scene is None or scene.reconstruction is not reconstruction:
+                scene = _SceneDump(reconstruction, feature_view)
+            self._dump(reconstruction, setup, scene, options, point_filter, extractor)
+
+    def _dump(self, reconstruction, setup, scene, options, point_filter, extractor):
+        phase = self._phase
         rec = reconstruction
         opt = options or {}
-        img_ids, cam_ids, pt_ids = sorted(rec.images), sorted(rec.cameras), sorted(rec.points3D)
-        img_of = {i: k for k, i in enumerate(img_ids)}
-        cam_of = {c: k for k, c in enumerate(cam_ids)}
-        pt_of = {p: k for k, p in enumerate(pt_ids)}
-        image_camera = np.array([cam_of[rec.images[i].camera_id] for i in img_ids], np.int32)
-        counts = [len(rec.images[i].points2D) for i in img_ids]
-        p2d_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-        filt = None if point_filter is None else set(point_filter)
-        p2d_point3D = np.array([pt_of[q.point3D_id] if (q.has_point3D() and (filt is None or q.point3D_id in filt)) else -1
-                                for i in img_ids for q in rec.images[i].points2D], np.int64).reshape(-1)
-        tl = [rec.points3D[p].track.length() for p in pt_ids]
-        track_ptr = np.concatenate([[0], np.cumsum(tl)]).astype(np.int64)
-        track_image = np.array([img_of[e.image_id] for p in pt_ids for e in rec.points3D[p].track.elements], np.int32).reshape(-1)
-        track_p2d = np.array([e.point2D_idx for p in pt_ids for e in rec.points3D[p].track.elements], np.int32).reshape(-1)
+        img_ids, cam_ids, pt_ids, pt_of = scene.img_ids, scene.cam_ids, scene.pt_ids, scene.pt_of
+        image_camera, p2d_ptr, cam_model = scene.image_camera, scene.p2d_ptr, scene.cam_model
+        track_ptr, track_image, track_p2d = scene.track_ptr, scene.track_image, scene.track_p2d
+        p2d_point3D = scene.p2d_point3D
+        if point_filter is not None:
+            keep = np.zeros(len(pt_ids) + 1, bool)
+            keep[[pt_of[p] for p in point_filter if p in pt_of]] = True
+            p2d_point3D = np.where(keep[p2d_point3D], p2d_point3D, -1)      # (index -1 reads the spare False slot)
         n_img, n_cam, n_pt = len(img_ids), len(cam_ids), len(pt_ids)
         in_setup = np.array([setup.has_image(i) for i in img_ids], np.uint8)
         const_pose = np.array([setup.has_constant_pose(i) for i in img_ids], np.uint8)
@@ -231,18 +320,14 @@ class _FlatBA:
         for p in setup.constant_points:
             const_pt[pt_of[p]] = 1
         const_cam = np.array([setup.is_constant_camera(c) for c in cam_ids], np.uint8)
-        cam_model = np.array([rec.cameras[c].model_id for c in cam_ids], np.int32)
         # which observations have a feature patch (only those that can enter the problem are asked)
-        has_patch = np.ones(len(p2d_point3D), np.uint8)
-        for k, i in enumerate(img_ids):
-            for j in range(counts[k]):
-                if p2d_point3D[p2d_ptr[k] + j] >= 0 and not feature_view.has_fpatch(i, j):
-                    has_patch[p2d_ptr[k] + j] = 0
+        has_patch = np.where(p2d_point3D >= 0, scene.has_patch, 1).astype(np.uint8)
         try:
-            r = build_problem(image_camera, p2d_ptr, p2d_point3D, cam_model, n_pt, track_ptr, track_image, track_p2d, in_setup, const_pose, tvm,
-                              var_pt, const_pt, const_cam, opt.get('refine_focal_length', True), opt.get('refine_principal_point', False),
-                              opt.get('refine_extra_params', True), opt.get('refine_extrinsics', True), opt.get('min_track_length', -1),
-                              has_patch, skip_missing_patches=extractor)
+            with phase("build_problem"):         # (nested in "dump": subtracted by the report)
+                r = build_problem(image_camera, p2d_ptr, p2d_point3D, cam_model, n_pt, track_ptr, track_image, track_p2d, in_setup, const_pose, tvm,
+                                  var_pt, const_pt, const_cam, opt.get('refine_focal_length', True), opt.get('refine_principal_point', False),
+                                  opt.get('refine_extra_params', True), opt.get('refine_extrinsics', True), opt.get('min_track_length', -1),
+                                  has_patch, skip_missing_patches=extractor)
         except _lib.PixsfmHipError as e:
             raise ValueError(str(e).replace("pxr_ba_build_problem: ", "")) from None
         if not extractor:                                                # NormalizeQvec in AddImageToProblem, :255
@@ -262,8 +347,8 @@ class _FlatBA:
         self.outside_images = {img_ids[k] for k in used_img if not in_setup[k]}
         self.obs_image = img_new[r["obs_image"]]
         self.obs_point = pt_new[r["obs_point"]]
-        self.obs_keys = [(img_ids[a], int(b)) for a, b in zip(r["obs_image"].tolist(), r["obs_p2d"].tolist())]
-        self.patches = [feature_view.fpatch(i, j) for i, j in self.obs_keys]
+        self.obs_keys = [(img_ids[a], b) for a, b in zip(r["obs_image"].tolist(), r["obs_p2d"].tolist())]
+        self.patches = scene.patches_of(r["obs_image"], r["obs_p2d"])
         n_i, n_c, n_p = len(used_img), len(used_cam), len(used_pt)
         self.image_camera = cam_new[image_camera[used_img]]
         self.qvec = np.array([rec.images[i].qvec for i in self.image_ids], np.float64).reshape(n_i, 4)
@@ -303,12 +388,15 @@ class ReferenceExtractor:
         if self.config['compute_offsets3D']:
             raise ValueError("compute_offsets3D is outside the accelerated path (N_NODES = 1: offsets are zero)")
 
-    def run(self, problem_labels, reconstruction, feature_set):
+    def run(self, problem_labels, reconstruction, feature_set, arena_cache=None, scene=None):
+        """arena_cache: a features.SharedArena -- the patches uploaded here stay on the device for the optimiser that follows;
+        scene: a _SceneDump of (reconstruction, FeatureView(feature_set)) shared with it."""
         ctx = self.ctx or default_context()
         wanted = {p for p in reconstruction.point3D_ids() if p < len(problem_labels) and problem_labels[p] >= 0}
         setup = BundleAdjustmentSetup()
         setup.add_images(reconstruction.reg_image_ids())
-        flat = _FlatBA(reconstruction, setup, FeatureView(feature_set, reconstruction), point_filter=wanted, extractor=True)
+        flat = _FlatBA(reconstruction, setup, scene.feature_view if scene is not None else FeatureView(feature_set, reconstruction),
+                       point_filter=wanted, extractor=True, scene=scene)
         if len(flat.obs_image) == 0:
             return {}
         # several ranks: every rank extracts the references of its share of the points (independent per point,
@@ -318,9 +406,12 @@ class ReferenceExtractor:
         part = flat if world == 1 else _rank_share(flat, rank, world)
         out = {}
         if len(part.obs_image):
-            arena = features.to_arena(ctx, part.patches)
-            ba = BAProblem(ctx, arena, part.problem_dict(np.zeros((len(part.point_ids), arena.C)), arena.index))
-            out = self._references_of(ba, part)
+            from ._timing import phase
+            with phase("upload"):
+                arena = features.to_arena(ctx, part.patches, cache=arena_cache)
+            with phase("references"):
+                ba = BAProblem(ctx, arena, part.problem_dict(np.zeros((len(part.point_ids), arena.C)), arena.index))
+                out = self._references_of(ba, part)
             arena.close()
         return out if world == 1 else parallel.gather_references(out)
 
@@ -336,6 +427,10 @@ class ReferenceExtractor:
         if keep:
             for i, k in enumerate(flat.obs_point):
                 obs_of_point.setdefault(int(k), []).append(i)
+        if not keep:        # the default: ids + source observation + descriptor row per point, objects on demand
+            sel = np.flatnonzero(chosen >= 0)
+            keys = [flat.obs_keys[int(c)] for c in chosen[sel]]
+            return features.ReferenceMap([flat.point_ids[k] for k in sel], np.array(keys, dtype=np.int64).reshape(len(sel), 2), refs[sel])
         out = {}
         for k, pid in enumerate(flat.point_ids):
             if chosen[k] >= 0:
@@ -524,13 +619,15 @@ class FeatureReferenceBundleOptimizer:
         if isinstance(feature_view, features.FeatureSet):
             feature_view = FeatureView(feature_view, reconstruction)
         self._loss = loss_function or self.options['loss']
-        flat = _FlatBA(reconstruction, self.setup, feature_view, self.options)
+        flat = _FlatBA(reconstruction, self.setup, feature_view, self.options, scene=getattr(self, "scene", None))
         self._flat, self._ba, self._arena = flat, None, None
         if len(flat.obs_image) == 0:
             return
         C = flat.patches[0].shape[2]
         refs = None                                                              # cost maps: "just minimize"
-        if references is not None:
+        if isinstance(references, features.ReferenceMap):
+            refs = references.descriptor_matrix(flat.point_ids)                  # references.at(point3D_id), all rows at once
+        elif references is not None:
             refs = np.zeros((len(flat.point_ids), C))
             for k, pid in enumerate(flat.point_ids):
                 refs[k] = references[pid].descriptor.reshape(-1)                 # references.at(point3D_id)
@@ -542,13 +639,16 @@ class FeatureReferenceBundleOptimizer:
             self._share_lo = self._share.lo
             if len(self._share.obs_image) == 0:
                 raise ValueError("rank %d received no observations: fewer points than ranks" % rank)
-            self._arena = features.to_arena(ctx, self._share.patches)
+            self._arena = features.to_arena(ctx, self._share.patches, cache=getattr(self, "arena_cache", None))
             lo, n_loc = self._share_lo, len(self._share.point_ids)
             self._ba = BAProblem(ctx, self._arena, self._share.problem_dict(None if refs is None else refs[lo:lo + n_loc],
                                                                            self._arena.index))
             return
-        self._arena = features.to_arena(ctx, flat.patches)
-        self._ba = BAProblem(ctx, self._arena, flat.problem_dict(refs, self._arena.index))
+        from ._timing import phase
+        with phase("upload"):
+            self._arena = features.to_arena(ctx, flat.patches, cache=getattr(self, "arena_cache", None))
+        with phase("problem_to_device"):
+            self._ba = BAProblem(ctx, self._arena, flat.problem_dict(refs, self._arena.index))
 
     @property
     def problem(self):
@@ -586,14 +686,25 @@ class FeatureReferenceBundleOptimizer:
         def record(it):
             history.append(SimpleNamespace(**{f: getattr(it, f) for f in fields}))
         ba.ctx.set_iteration_callbacks([record] + list(s.get('callbacks') or []))
+        from ._timing import phase
         try:
-            summ = ba.solve(self.interpolation.to_engine(), make_loss(self._loss['name'], self._loss['params']),
-                            flat.pose_const, flat.tvec_mask, flat.cam_mask, point_const, options=lm,
-                            allreduce=allreduce)
+            with phase("solve"):
+                summ = ba.solve(self.interpolation.to_engine(), make_loss(self._loss['name'], self._loss['params']),
+                                flat.pose_const, flat.tvec_mask, flat.cam_mask, point_const, options=lm,
+                                allreduce=allreduce)
         finally:
             ba.ctx.set_iteration_callbacks(None)
+        with phase("write_back"):
+            self._write_back(reconstruction, flat, ba, lo if getattr(self, "_share", None) is not None else None,
+                             n_loc if getattr(self, "_share", None) is not None else None)
+        self._summary = Summary(summ, num_residuals=len(flat.obs_image) * C)
+        self._summary.iterations = history
+        return True
+
+    def _write_back(self, reconstruction, flat, ba, lo, n_loc):
         q, t, k, X = ba.params()
-        if getattr(self, "_share", None) is not None:               # every rank ends up with all refined points
+        if lo is not None:                                          # every rank ends up with all refined points
+            from .. import parallel
             X = parallel.gather_rows(X, np.arange(lo, lo + n_loc), len(flat.point_ids))
         for n, i in enumerate(flat.image_ids):       # in place, like feature_reference_bundle_optimizer.h:111-114
             reconstruction.images[i].qvec = q[n].copy()
@@ -603,9 +714,6 @@ class FeatureReferenceBundleOptimizer:
             cam.params = k[n, :len(cam.params)].copy()
         for n, pid in enumerate(flat.point_ids):
             reconstruction.points3D[pid].xyz = X[n].copy()
-        self._summary = Summary(summ, num_residuals=len(flat.obs_image) * C)
-        self._summary.iterations = history
-        return True
 
     def reset(self):
         """Reset (bundle_optimizer.h:124-129): drop the problem; the optimizer can be set up again."""
@@ -699,12 +807,18 @@ class FeatureReferenceBundleAdjuster(BundleAdjuster):
         if problem_setup is None:
             problem_setup = default_problem_setup(reconstruction)
         feature_view = FeatureView(feature_set, reconstruction)
-        problem_labels = find_problem_labels(reconstruction, self.conf['max_tracks_per_problem'])
+        from ._timing import phase
+        with phase("problem_labels"):
+            problem_labels = find_problem_labels(reconstruction, self.conf['max_tracks_per_problem'])
         ref_extractor = ReferenceExtractor(deepcopy(self.conf['references']), self.conf['interpolation'])
-        references = ref_extractor.run(problem_labels, reconstruction, feature_set)
-        solver = FeatureReferenceBundleOptimizer(deepcopy(self.conf['optimizer']), problem_setup,
-                                                 self.conf['interpolation'])
-        solver.run(reconstruction, feature_view, references)
+        with phase("dump"):
+            scene = _SceneDump(reconstruction, feature_view)      # the Python objects are read once for both steps
+        with features.SharedArena() as shared:       # host patches cross PCIe once for the extraction AND the optimiser
+            references = ref_extractor.run(problem_labels, reconstruction, feature_set, arena_cache=shared, scene=scene)
+            solver = FeatureReferenceBundleOptimizer(deepcopy(self.conf['optimizer']), problem_setup,
+                                                     self.conf['interpolation'])
+            solver.arena_cache, solver.scene = shared, scene
+            solver.run(reconstruction, feature_view, references)
         return {"references": references, "summary": solver.summary()}
 
 

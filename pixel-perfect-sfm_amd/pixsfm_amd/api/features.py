@@ -5,6 +5,8 @@ views (the reference's patches built from numpy are non-owning views too,
 features/src/featurepatch.cc:45); the hot path consumes the flat HBM arena built from them
 (`to_arena`).  HDF5 loading / caching is out of scope.
 """
+from collections.abc import Mapping as _Mapping
+
 import numpy as np
 
 kDenseId = 1000000      # util/src/types.h:33
@@ -59,6 +61,7 @@ class FeaturePatch:
         if data.dtype not in (np.float16, np.float32, np.float64):
             raise ValueError("FeaturePatch dtype must be float16/32/64")     # featurepatch.cc:365-367
         self.data = np.ascontiguousarray(data)
+        self._ptr = self.data.ctypes.data            # cached: to_arena reads it once per patch
         self.corner = np.asarray(corner, dtype=np.int32).reshape(2)
         self.scale = np.asarray(scale, dtype=np.float64).reshape(2)
 
@@ -95,7 +98,11 @@ class FeaturePatch:
         return True
 
     def data_ptr(self):
-        return self.data.ctypes.data
+        return self._ptr
+
+    def __setstate__(self, state):               # a copy / unpickled patch owns new memory: the cached address moves with it
+        self.__dict__.update(state)
+        self._ptr = self.data.ctypes.data
 
     def num_bytes(self):                         # Size() * sizeof(dtype)
         return int(self.data.nbytes)
@@ -340,6 +347,72 @@ class Reference:
         return len(self.observations) > 0
 
 
+class ReferenceMap(_Mapping):
+    """{point3D_id: Reference} as ReferenceExtractor.run returns it, held as three arrays (ids, source observations,
+    descriptors) -- a Reference OBJECT is made when somebody asks for one (references[pid], .items(), ...) and kept.  The
+    bundle optimiser takes the descriptor rows straight from the array: at BASELINE configs[2] (200k points) building and
+    re-reading 200k Python objects cost 2.4 s around a 60 ms solve.  Assignment (references[pid] = Reference(...)) works."""
+
+    def __init__(self, ids, sources, descriptors):
+        self._ids = [int(p) for p in ids]
+        self._row = {p: k for k, p in enumerate(self._ids)}
+        self._src = np.asarray(sources, dtype=np.int64).reshape(len(self._ids), 2)
+        d = np.ascontiguousarray(descriptors, dtype=np.float64)
+        self._desc = d.reshape(len(self._ids), -1) if len(self._ids) else np.zeros((0, d.shape[-1] if d.ndim == 2 else 0))
+        self._objs = {}
+
+    def __len__(self):
+        return len(self._row)
+
+    def __iter__(self):
+        return iter(self._ids)
+
+    def __contains__(self, pid):
+        return pid in self._row
+
+    def __getitem__(self, pid):
+        obj = self._objs.get(pid)
+        if obj is None:
+            k = self._row[pid]                    # KeyError like dict / references.at()
+            obj = self._objs[pid] = Reference(int(self._src[k, 0]), int(self._src[k, 1]), self._desc[k])
+        return obj
+
+    def __setitem__(self, pid, ref):
+        pid = int(pid)
+        if pid not in self._row:
+            self._row[pid] = len(self._ids)
+            self._ids.append(pid)
+            self._src = np.concatenate([self._src, [[ref.source[0], ref.source[1]]]])
+            self._desc = np.concatenate([self._desc, ref.descriptor.reshape(1, -1)]) if self._desc.size else ref.descriptor.reshape(1, -1).copy()
+        self._objs[pid] = ref
+
+    @property
+    def channels(self):
+        return int(self._desc.shape[1])
+
+    def descriptor_matrix(self, point_ids):
+        """(len(point_ids), C) reference descriptors; objects handed out (and possibly edited) or assigned win over the arrays."""
+        rows = np.fromiter((self._row[p] for p in point_ids), dtype=np.int64, count=len(point_ids))
+        out = self._desc[rows]
+        if self._objs:
+            at = {p: k for k, p in enumerate(point_ids)}
+            for p, ref in self._objs.items():
+                if p in at:
+                    out[at[p]] = ref.descriptor.reshape(-1)
+        return out
+
+    def arrays(self):
+        """(ids, sources, descriptors) with the handed-out objects' current values folded in; None if an object carries
+        observations / costs / a track (then only the objects describe the map)."""
+        if any(r.observations or r.costs or len(r.track) for r in self._objs.values()):
+            return None
+        desc, src = self._desc.copy(), self._src.copy()
+        for p, ref in self._objs.items():
+            desc[self._row[p]] = ref.descriptor.reshape(-1)
+            src[self._row[p]] = (ref.source[0], ref.source[1])
+        return np.asarray(self._ids, dtype=np.int64), src, desc
+
+
 class ArenaPatch:
     """A patch that already lives in a device arena (written by tensor_to_arena / pxr_arena_extract, or adopted
     from a torch tensor): the FeaturePatch of the GPU-resident flow.  FeatureMap / FeatureSet hold these like
@@ -368,12 +441,37 @@ class ArenaRef:
             self._arena.close()
 
 
-def to_arena(ctx, patch_list):
+class SharedArena:
+    """One upload for several consumers of the same host patches: BundleAdjuster.refine runs the reference extraction and
+    the optimiser on the same FeatureSet -- the second to_arena(..., cache=this) finds its patches in the arena the first
+    one built instead of sending 64 KB per observation over PCIe again.  A context manager: the arena is freed on exit."""
+
+    def __init__(self):
+        self.arena, self.slot = None, {}
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def close(self):
+        if self.arena is not None:
+            self.arena.close()
+        self.arena, self.slot = None, {}
+
+
+def to_arena(ctx, patch_list, cache=None):
     """FeaturePatch objects (identical H, W, C, dtype) are stacked into a new HBM arena; ArenaPatch objects
-    of one arena are used where they are (no copy)."""
+    of one arena are used where they are (no copy).  cache: a SharedArena that keeps / provides the upload."""
     from ..engine import PatchArena
     if not patch_list:
         raise ValueError("no patches")
+    if cache is not None and cache.arena is not None:
+        try:
+            return ArenaRef(cache.arena, [cache.slot[id(p)] for p in patch_list], owned=False)
+        except KeyError:
+            cache = None                         # a patch the shared arena does not hold: an arena of this call's own
     on_device = [isinstance(p, ArenaPatch) for p in patch_list]
     if all(on_device):
         arena = patch_list[0].arena
@@ -394,10 +492,15 @@ def to_arena(ctx, patch_list):
         if p.shape != shape or p.data.dtype != dtype:
             raise ValueError("the accelerated path needs patches of identical shape and dtype (sparse patches of one "
                              "patch_size, pixsfm/features/extractor.py:33-51, or dense maps of equal size)")
-    data = np.stack([p.data for p in uniq])
-    corners = np.stack([p.corner for p in uniq])
-    scales = np.stack([p.scale for p in uniq])
-    return ArenaRef(PatchArena.from_numpy(ctx, data, corners, scales), index, owned=True)
+    corners = np.array([p.corner for p in uniq], dtype=np.int32).reshape(len(uniq), 2)
+    scales = np.array([p.scale for p in uniq], dtype=np.float64).reshape(len(uniq), 2)
+    pointers = np.fromiter((p.data_ptr() for p in uniq), dtype=np.uint64, count=len(uniq))
+    # the patches go up one by one through pinned staging buffers (no np.stack of the set: 65 GB at BASELINE configs[2])
+    arena = PatchArena.from_patch_pointers(ctx, pointers, shape, dtype, corners, scales)
+    if cache is not None:
+        cache.arena, cache.slot = arena, slot
+        return ArenaRef(arena, index, owned=False)
+    return ArenaRef(arena, index, owned=True)
 
 
 def tensor_to_arena(arena, first, featuremap, image_size, keypoints, l2_normalize=True):

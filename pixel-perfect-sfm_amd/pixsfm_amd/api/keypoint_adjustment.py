@@ -164,8 +164,12 @@ class FeatureMetricKeypointOptimizer:
             raise ValueError("label arrays must have one entry per graph node")  # THROW_CHECK_EQ, featuremetric_keypoint_optimizer.h:82-85
         ctx = self.ctx or default_context()
         o = self.options
-        src, dst, w = build_edges(graph, keypoints, track_labels, root_labels, nodes_in_problem, o['weight_by_sim'],
-                                  o['root_edges_only'], o['root_regularize_weight'])
+        from ._timing import phase
+        with phase("build_edges"):
+            src, dst, w = build_edges(graph, keypoints, track_labels, root_labels, nodes_in_problem, o['weight_by_sim'],
+                                      o['root_edges_only'], o['root_regularize_weight'])
+        t_dump = phase("dump")
+        t_dump.__enter__()
         names = [graph.image_id_to_name[nd.image_id] for nd in graph.nodes]
         kp = np.array([keypoints[nm][nd.feature_idx] for nm, nd in zip(names, graph.nodes)], dtype=np.float64).reshape(-1, 2)
         patches = [feature_set.fmap(nm).fpatch(nd.feature_idx) for nm, nd in zip(names, graph.nodes)]
@@ -190,12 +194,16 @@ class FeatureMetricKeypointOptimizer:
         channels = patches[0].shape[2]
         total = dict(iterations=0, num_successful=0, termination=0, initial_cost=0.0, final_cost=0.0, total_ms=0.0)
         out = kp.copy()
+        t_dump.__exit__(None, None, None)
         if len(node_ids):
-            arena = features.to_arena(ctx, [patches[i] for i in shard["node_patch" if world == 1 else "patch_ids"]])
-            shard = dict(shard, node_patch=arena.index)
-            ka = KAProblem(ctx, arena, shard)
-            total, _ = ka.solve(cfg, loss, bound=o['bound'], options=lm)
-            out[node_ids] = ka.keypoints()
+            with phase("upload"):
+                arena = features.to_arena(ctx, [patches[i] for i in shard["node_patch" if world == 1 else "patch_ids"]])
+            with phase("problem_to_device"):
+                shard = dict(shard, node_patch=arena.index)
+                ka = KAProblem(ctx, arena, shard)
+            with phase("solve"):
+                total, _ = ka.solve(cfg, loss, bound=o['bound'], options=lm)
+                out[node_ids] = ka.keypoints()
             arena.close()
         if world > 1:
             owned = np.zeros(n); owned[node_ids] = 1.0
@@ -207,8 +215,9 @@ class FeatureMetricKeypointOptimizer:
                                                     1.0 if total["termination"] == 2 else 0.0], dtype=np.float64))
             total = dict(total, iterations=int(acc[0]), num_successful=int(acc[1]), initial_cost=float(acc[2]),
                          final_cost=float(acc[3]), total_ms=float(acc[4]), termination=2 if acc[5] > 0 else total["termination"])
-        for nm, nd, xy in zip(names, graph.nodes, out):       # in place, like featuremetric_keypoint_optimizer.h:195-196
-            keypoints[nm][nd.feature_idx] = xy
+        with phase("write_back"):
+            for nm, nd, xy in zip(names, graph.nodes, out):       # in place, like featuremetric_keypoint_optimizer.h:195-196
+                keypoints[nm][nd.feature_idx] = xy
         self._summary = Summary(total, num_residuals=len(src) * channels)
         return True
 
@@ -281,10 +290,12 @@ class KeypointAdjuster:
 
     def refine_multilevel(self, keypoints_dict, feature_manager, graph, track_labels=None, root_labels=None,
                           problem_setup=None):
+        from ._timing import phase
         if track_labels is None and root_labels is None:
             # main.py:111-118 calls the three labellings one after the other on the host; here one call on the device
             # the solve runs on anyway (pxr_graph_labels_device: identical labels, scores and roots)
-            track_labels, _, root_labels = base.compute_labels_on_device(graph)
+            with phase("labelling"):
+                track_labels, _, root_labels = base.compute_labels_on_device(graph)
         if track_labels is None:
             track_labels = base.compute_track_labels(graph)
         if root_labels is None:

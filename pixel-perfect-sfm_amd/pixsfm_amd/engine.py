@@ -196,6 +196,20 @@ class PatchArena:
             None if corners is None else corners.ctypes.data,
             None if scales is None else scales.ctypes.data), "pxr_arena_upload")
 
+    @classmethod
+    def from_patch_pointers(cls, ctx, pointers, shape, dtype, corners, scales):
+        """An arena filled from SEPARATE host patches (pointers[i]: address of patch i, `shape` = (H, W, C) elements of
+        `dtype`): pxr_arena_upload_gather -- all host cores gather into pinned staging buffers, the upload is
+        double-buffered; no stacked host copy of the whole set.  The caller keeps the patches alive during the call."""
+        pointers = np.ascontiguousarray(pointers, dtype=np.uint64)
+        n = len(pointers)
+        a = cls(ctx, n, shape[0], shape[1], shape[2], dtype)
+        corners = np.ascontiguousarray(corners, dtype=np.int32).reshape(n, 2)
+        scales = np.ascontiguousarray(scales, dtype=np.float64).reshape(n, 2)
+        check(ctx.lib.pxr_arena_upload_gather(a.handle, 0, n, pointers.ctypes.data, corners.ctypes.data, scales.ctypes.data),
+              "pxr_arena_upload_gather")
+        return a
+
     def extract(self, first, fmap, keypoints, image_size, l2_normalize=True):
         """Fill patches [first, first + len(keypoints)) from ONE image's dense feature map that is
         already on the device (FeatureExtractor.tensor_to_fmap sparse branch, extractor.py:152-199,

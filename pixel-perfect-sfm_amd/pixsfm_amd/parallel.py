@@ -97,29 +97,49 @@ def allgather_rows(array, group=None):
 
 
 def gather_references(local, group=None):
-    """Union of per-rank {point3D_id: Reference} dicts with disjoint keys on every rank.  What a Reference carries
+    """Union of per-rank {point3D_id: Reference} maps with disjoint keys on every rank.  What a Reference carries
     (features/src/references.h:29-72: source observation, 1 x C descriptor, optionally the per-observation descriptors,
     their costs and the visible track) travels as flat arrays -- ids, descriptor rows, per-reference lengths and the
-    concatenated variable-length parts -- through allgather_rows; the objects are rebuilt locally."""
-    from .api.features import Reference
+    concatenated variable-length parts -- through allgather_rows (the same collectives whatever form a rank holds); the result
+    is a features.ReferenceMap (arrays, objects on demand) when no reference carries variable-length parts, else a dict."""
+    from .api.features import ReferenceMap
     rank, n = world(group)
     if n == 1:
-        return dict(local)
-    ids = sorted(local)
-    refs = [local[p] for p in ids]
+        return local if isinstance(local, ReferenceMap) else dict(local)
+    packed = local.arrays() if isinstance(local, ReferenceMap) else None
+    if packed is not None:                       # the extractor's array form: nothing to flatten
+        ids, refs, my_chan = packed[0], None, (packed[2].shape[1] if len(packed[0]) else 0)
+    else:
+        ids = sorted(local)
+        refs = [local[p] for p in ids]
+        my_chan = max([r.channels for r in refs], default=0)
     # channel count agreed over the ranks (a rank may hold no reference at all)
-    chan = int(allreduce_host(np.array([max([r.channels for r in refs], default=0)], dtype=np.int64), group, op="max")[0])
+    chan = int(allreduce_host(np.array([my_chan], dtype=np.int64), group, op="max")[0])
     head = np.zeros((len(ids), 6), dtype=np.int64)          # id, image_id, point2D_idx, #observations, #costs, #track
     desc = np.zeros((len(ids), chan), dtype=np.float64)
-    for k, (p, r) in enumerate(zip(ids, refs)):
-        head[k] = (p, r.source[0], r.source[1], len(r.observations), len(r.costs), len(r.track))
-        desc[k] = r.descriptor.reshape(-1)
-    obs = np.concatenate([np.asarray(o, dtype=np.float64).reshape(1, chan) for r in refs for o in r.observations]
-                         or [np.zeros((0, chan))])
-    costs = np.array([c for r in refs for c in r.costs], dtype=np.float64)
-    track = np.array([tuple(e) for r in refs for e in r.track], dtype=np.int64).reshape(-1, 2)
+    obs, costs, track = np.zeros((0, chan)), np.zeros(0), np.zeros((0, 2), np.int64)
+    if refs is None:
+        if len(ids):
+            head[:, 0], head[:, 1:3], desc[:] = packed[0], packed[1], packed[2]
+    else:
+        for k, (p, r) in enumerate(zip(ids, refs)):
+            head[k] = (p, r.source[0], r.source[1], len(r.observations), len(r.costs), len(r.track))
+            desc[k] = r.descriptor.reshape(-1)
+        obs = np.concatenate([np.asarray(o, dtype=np.float64).reshape(1, chan) for r in refs for o in r.observations]
+                             or [np.zeros((0, chan))])
+        costs = np.array([c for r in refs for c in r.costs], dtype=np.float64)
+        track = np.array([tuple(e) for r in refs for e in r.track], dtype=np.int64).reshape(-1, 2)
+    parts = [allgather_rows(a, group) for a in (head, desc, obs, costs, track)]
+    if all(h[:, 3:].sum() == 0 for h in parts[0]):
+        h, d = np.concatenate(parts[0]), np.concatenate(parts[1])
+        return ReferenceMap(h[:, 0], h[:, 1:3], d)
+    return _unpack_references(parts)
+
+
+def _unpack_references(parts):
+    from .api.features import Reference
     out = {}
-    for h, d, o, c, t in zip(*[allgather_rows(a, group) for a in (head, desc, obs, costs, track)]):
+    for h, d, o, c, t in zip(*parts):
         o_at = np.concatenate([[0], np.cumsum(h[:, 3])])
         c_at = np.concatenate([[0], np.cumsum(h[:, 4])])
         t_at = np.concatenate([[0], np.cumsum(h[:, 5])])

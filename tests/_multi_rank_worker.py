@@ -158,9 +158,18 @@ def main():
     elif mode == "refs_gather":
         # host plumbing only: real Reference objects (source, descriptor, observations, costs, track) of this rank's points
         # through parallel.gather_references; rank 1 of 3 deliberately holds none
-        local = {p: r for p, r in make_references().items() if (p % world == rank and not (world == 3 and rank == 1))}
+        local = {p: r for k, (p, r) in enumerate(sorted(make_references().items())) if (k % world == rank and not (world == 3 and rank == 1))}
         got = parallel.gather_references(local)
         out = pack_references(got)
+    elif mode == "refmap_gather":
+        from pixsfm_amd.api import features
+        ids = np.arange(3, 3 + 11)
+        mine = np.flatnonzero(np.arange(11) % world == rank)
+        local = features.ReferenceMap(ids[mine], np.stack([mine + 1, 7 * mine], 1), np.arange(11 * 4, dtype=np.float64).reshape(11, 4)[mine])
+        got = parallel.gather_references(local)
+        a = got.arrays()
+        order = np.argsort(a[0])
+        out = dict(is_map=np.array([int(isinstance(got, features.ReferenceMap))]), ids=a[0][order], src=a[1][order], desc=a[2][order])
     elif mode == "api":
         # the pixsfm-shaped API on two ranks: KeypointAdjuster (sub-problems dealt to the ranks), ReferenceExtractor and
         # FeatureReferenceBundleOptimizer (points sharded, collective chosen by parallel.ensure_collective)

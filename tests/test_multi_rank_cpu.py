@@ -5,6 +5,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _multi_rank_launch import run_ranks  # noqa: E402
@@ -57,7 +58,7 @@ def test_references_gather_over_two_and_three_ranks(tmp_path):
         d = tmp_path / ("w%d" % world)
         d.mkdir()
         res = run_ranks("refs_gather", d, world=world)
-        keep = want["ids"] % world != 1 if world == 3 else np.ones(len(want["ids"]), bool)      # rank 1 of 3 contributed nothing
+        keep = np.arange(len(want["ids"])) % world != 1 if world == 3 else np.ones(len(want["ids"]), bool)      # rank 1 of 3 contributed nothing
         full = worker.make_references()
         expect = worker.pack_references({p: full[p] for p in want["ids"][keep]})
         for r in res:
@@ -85,3 +86,36 @@ def test_api_containers_survive_pickle_and_deepcopy():
     got = man.fsets[0].fmaps["a.jpg"].patches[9] if hasattr(man, "fsets") else None
     if got is not None:
         assert np.array_equal(got.data, patch.data) and np.array_equal(got.corner, patch.corner) and np.array_equal(got.scale, patch.scale)
+
+
+def test_reference_map_is_a_lazy_dict_of_references():
+    """features.ReferenceMap (what ReferenceExtractor.run returns by default): dict behaviour, objects on demand, edits and
+    assignments visible to descriptor_matrix (what the optimiser reads), pickle round trip."""
+    import pickle
+    from pixsfm_amd.api import features
+    rng = np.random.default_rng(0)
+    ids, src, desc = [5, 9, 12], np.array([[1, 10], [2, 20], [3, 30]]), rng.normal(size=(3, 8))
+    m = features.ReferenceMap(ids, src, desc)
+    assert len(m) == 3 and sorted(m) == ids and 9 in m and 7 not in m and list(m.keys()) == ids
+    r = m[9]
+    assert isinstance(r, features.Reference) and tuple(r.source) == (2, 20) and np.array_equal(r.descriptor.reshape(-1), desc[1]) and m[9] is r
+    with pytest.raises(KeyError):
+        m[7]
+    assert np.array_equal(m.descriptor_matrix([12, 5]), desc[[2, 0]])
+    r.descriptor = np.full((1, 8), 2.0)                       # an edited object wins
+    m[40] = features.Reference(4, 44, np.arange(8.0))         # so does an assigned one, also under a new key
+    assert np.array_equal(m.descriptor_matrix([9, 40]), np.stack([np.full(8, 2.0), np.arange(8.0)])) and len(m) == 4
+    a = m.arrays()
+    assert a[0].tolist() == [5, 9, 12, 40] and np.array_equal(a[2][1], np.full(8, 2.0)) and a[1][3].tolist() == [4, 44]
+    m2 = pickle.loads(pickle.dumps(m))
+    assert sorted(m2) == sorted(m) and np.array_equal(m2.descriptor_matrix([9, 40, 5]), m.descriptor_matrix([9, 40, 5]))
+    assert {k: v.channels for k, v in m.items()} == {5: 8, 9: 8, 12: 8, 40: 8}
+    assert len(features.ReferenceMap([], np.zeros((0, 2)), np.zeros((0, 8)))) == 0
+
+
+def test_array_form_references_gather_as_a_reference_map(tmp_path):
+    """ReferenceMap on every rank (the extractor's default output) -> gather_references -> one ReferenceMap with all rows."""
+    res = run_ranks("refmap_gather", tmp_path, world=2)
+    for r in res:
+        assert r["is_map"][0] == 1 and r["ids"].tolist() == list(range(3, 3 + 11))
+        assert np.array_equal(r["desc"], np.arange(11 * 4, dtype=np.float64).reshape(11, 4)) and np.array_equal(r["src"][:, 1], 7 * np.arange(11))

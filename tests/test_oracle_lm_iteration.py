@@ -1,4 +1,4 @@
-"""The oracle's Schur-complement LM iteration (oracle/pxo_lm_bench.c: what bench.py times as `cpu_baseline_lm`)
+"""The oracle's Schur-complement LM iteration (oracle/pxo_lm_bench.c: what bench.py times as `cpu_baseline_lm_projected`)
 against the oracle's dense LM (oracle/pxo_solve.c, all unknowns in one normal matrix): the same first step."""
 import numpy as np
 

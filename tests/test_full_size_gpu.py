@@ -288,3 +288,77 @@ def test_ka_full_size_oracle_on_a_sample_of_sub_problems(ctx):
     assert np.abs(kp[node_sel] - kpo).max() < 1e-6
     del ka, arena, patches
     torch.cuda.empty_cache()
+
+
+def _quat_plus(q, d):
+    """[upstream Ceres QuaternionManifold::Plus] q_delta = [cos |d|, sin |d| / |d| d], result = q_delta * q (w first)."""
+    nd = np.linalg.norm(d, axis=1, keepdims=True)
+    s = np.where(nd > 0, np.sin(nd) / np.where(nd > 0, nd, 1.0), 1.0)
+    w0, v0 = np.cos(nd[:, 0]), s * d
+    w1, v1 = q[:, 0], q[:, 1:]
+    return np.concatenate([(w0 * w1 - (v0 * v1).sum(1))[:, None], w0[:, None] * v1 + w1[:, None] * v0 + np.cross(v0, v1)], 1)
+
+
+@pytest.mark.parametrize("solver", ["direct", "iterative"])
+def test_one_lm_step_at_scale_equals_the_oracles(ctx, big, solver):
+    """ONE Levenberg-Marquardt step on the first 131 075 observations of configs[2] (26 215 whole points, all 200
+    cameras: what bench.py's cpu_baseline_lm_projected times) against the oracle's Schur iteration
+    (oracle/pxo_lm_bench.c, OpenMP on the host cores): the cost at the linearisation point, the camera step
+    (translations, intrinsics, rotations through the manifold), the point step and the cost of the candidate -- the
+    solver's output at scale tied to something other than itself.  Direct: Cholesky of the 1593 x 1593 reduced system;
+    iterative: the implicit-Schur conjugate gradients driven to 1e-12."""
+    import os
+    import pxo
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    prob, patches, ba_full = big
+    n_img = 200
+    n_pts = int(prob["obs_point"][131072 - 1]) + 1                       # whole points (observations are point-sorted)
+    n_obs = int(np.searchsorted(prob["obs_point"], n_pts, side="left"))
+    sub = dict(prob)
+    for k in ("obs_image", "obs_point", "obs_patch", "corners", "scales"):
+        sub[k] = prob[k][:n_obs]
+    sub["xyz"], sub["refs"] = prob["xyz"][:n_pts].copy(), prob["refs"][:n_pts].copy()
+    pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
+    tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
+    cmask, ptc = np.full(n_img, 0b0110, np.uint16), np.zeros(n_pts, np.uint8)
+    # ---- the GPU step
+    arena = PatchArena(ctx, n_obs, 16, 16, 128, np.float16, device_ptr=patches.data_ptr())     # the first n_obs patches of the big arena
+    arena.upload(0, None, sub["corners"], sub["scales"])
+    ba = BAProblem(ctx, arena, sub)
+    extra = {} if solver == "direct" else dict(eta=0.0, linear_r_tolerance=1e-12, max_linear_solver_iterations=4000)
+    s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,
+                 options=lm_options(max_iterations=1, jacobi_scaling=0, use_inner_iterations=False, initial_radius=1e4,
+                                    linear_solver=solver, **extra))
+    assert s["iterations"] == 1 and s["num_successful"] == 1 and s["num_camera_unknowns"] == 8 * n_img - 7
+    q1, t1, k1, X1 = ba.params()
+    # ---- the oracle's step on the host cores
+    sub["patches"] = patches[:n_obs].cpu().numpy()
+    cfg, ls = pxo.cfg(), pxo.loss("cauchy", 0.25)
+    out = pxo.ba_lm_iteration_schur(sub, cfg, ls, pose_const, tmask, cmask, ptc, radius=1e4, n_threads=os.cpu_count() or 1)
+    assert out["rc"] == 0 and out["n_c"] == s["num_camera_unknowns"]
+    tol = 1e-8 if solver == "direct" else 1e-7
+    assert abs(s["initial_cost"] - out["cost"]) < 1e-10 * out["cost"]
+    dp = out["delta_p"]
+    assert np.abs((X1 - sub["xyz"]) - dp).max() < tol * np.abs(dp).max()
+    dc, col = out["delta_c"], 0
+    rot = np.zeros((n_img, 3))
+    worst_t, worst_k = 0.0, 0.0
+    for i in range(n_img):
+        if pose_const[i]:
+            continue
+        rot[i] = dc[col:col + 3]; col += 3
+        for a in range(3):
+            if (tmask[i] >> a) & 1:
+                continue
+            worst_t = max(worst_t, abs((t1[i, a] - prob["tvec"][i, a]) - dc[col])); col += 1
+    for c in range(n_img):
+        for a in (0, 3):                                                  # SIMPLE_RADIAL: f and k free
+            worst_k = max(worst_k, abs((k1[c, a] - prob["cam_params"][c, a]) - dc[col]) / max(1e-12, abs(dc[col]))); col += 1
+    assert col == out["n_c"]
+    assert worst_t < tol * np.abs(dc).max() and worst_k < 1e-6
+    assert np.abs(q1 - _quat_plus(prob["qvec"], rot)).max() < tol
+    # ---- the candidate's cost: the oracle evaluates the parameters the GPU step produced
+    cand = dict(sub, qvec=q1, tvec=t1, cam_params=k1[:, :prob["cam_params"].shape[1]], xyz=X1)
+    cost_c, _, _ = pxo.ba_eval_batch(cand, cfg, ls, n_threads=os.cpu_count() or 1)
+    assert abs(s["final_cost"] - cost_c) < 1e-9 * cost_c and s["final_cost"] < 0.5 * s["initial_cost"]
+    arena.close()

@@ -161,10 +161,18 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="strong (default, BASELINE.json's target): --points points in total, sharded over the ranks; "
                          "weak: every rank owns --points points (N x the observations, cameras shared)")
+    ap.add_argument("--patch-size", type=int, default=16, help="side of the square fp16 patches (16: pixsfm's default; 8: low_memory.yaml)")
+    ap.add_argument("--preset", choices=("aachen",), default=None,
+                    help="aachen: BASELINE.json configs[4]-shaped scene on ONE GPU -- 4000 cameras, 1M points, 5M observations, 8 x 8 "
+                         "fp16 patches (82 GB; the reference runs Aachen with configs/low_memory.yaml: patch_size 8), iterative "
+                         "solver by image count, cost-map strategy beside it; KA / CPU legs / API timing are skipped")
     ap.add_argument("--no-api-e2e", action="store_true",
                     help="skip the end-to-end timing of the drop-in API calls on host-resident inputs (tools/bench_api_e2e.py)")
     ap.add_argument("--linear-solver", default="auto", help="auto (by image count, bundle_optimizer.h:180-191) | direct | iterative")
     args = ap.parse_args()
+    if args.preset == "aachen":
+        args.cams, args.points, args.obs_per_point, args.patch_size = 4000, 1_000_000, 5, 8
+        args.no_ka = args.no_api_e2e = args.no_cpu_baseline = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -193,7 +201,7 @@ def main():
     from pixsfm_amd import synthetic_gpu
     from pixsfm_amd.engine import BAProblem, Context, PatchArena, interp_cfg, make_loss
 
-    C, PS = 128, 16
+    C, PS = 128, args.patch_size
     # points (with their observations, patches and references) are the sharded unit; cameras and poses
     # are replicated.  weak: the scene grows with the ranks, strong: it is split.
     total_points = args.points * world if args.scaling == "weak" else args.points
@@ -201,7 +209,9 @@ def main():
     lo, hi = rank * per, min(total_points, (rank + 1) * per)
     prob, patches = synthetic_gpu.make_ba_problem_gpu(dev, n_cams=args.cams, n_points=total_points,
                                                       obs_per_point=args.obs_per_point, channels=C,
-                                                      patch_size=PS, seed=2, point_range=(lo, hi))
+                                                      patch_size=PS, seed=2, point_range=(lo, hi),
+                                                      # 8 x 8 patches leave +-2 px around the stencil: ~1 px initial errors
+                                                      **(dict(rot_deg=0.04, trans=0.003, pt_sigma=0.003) if PS < 16 else {}))
     n_obs_local = len(prob["obs_image"])
     ctx = Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
     collective = "none"
@@ -358,7 +368,7 @@ def main():
         costmap = {"extract_ms": ex_ms, "maps_per_sec": n_obs_local / (ex_ms * 1e-3),
                    "extract_GBps": ex_bytes * n_obs_local / (ex_ms * 1e-3) / 1e9,
                    "extract_frac_of_peak": ex_bytes * n_obs_local / (ex_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                   "extract_bytes_per_map": ex_bytes, "kernel": "costmap_kernel_f16_split<f16> (16x16x128, gradients)",
+                   "extract_bytes_per_map": ex_bytes, "kernel": "costmap_kernel_f16_split%s<f16> (%dx%dx128, gradients)" % ("8" if PS == 8 else "", PS, PS),
                    "map_arena_GB": n_obs_local * PS * PS * 3 * 2 / 1e9,
                    "extract_bound": "vector ALU at the package power limit: ~1800 4-cycle vector instructions per lane and map "
                                     "(the reference's double accumulation and half -> double conversions), 1366 W / shader clock "
@@ -435,10 +445,11 @@ def main():
             "dtype": "f32 horizontal / f64 vertical+normalisation on f16 patches"
                      if not args.float_simd else "f32 splines / f64 normalisation on f16 patches",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: synthetic %d cams / %d points / %d obs "
+            "config": {"workload": "BASELINE.json %s: synthetic %d cams / %d points / %d obs "
                                    "featuremetric BA residual+Jacobian evaluation, %d-ch fp16 %dx%d patches, "
                                    "SIMPLE_RADIAL, fused six-scalar Jacobian reduction"
-                                   % (args.cams, total_points, n_obs_total, C, PS, PS),
+                                   % ("configs[4] shape (Aachen scale) on one GPU" if args.preset == "aachen" else "configs[2]",
+                                      args.cams, total_points, n_obs_total, C, PS, PS),
                        "n_obs": n_obs_total, "channels": C, "patch": PS,
                        "arena_GB": n_obs_total * PS * PS * C * 2 / 1e9,
                        "obs_per_gpu": n_obs_local,

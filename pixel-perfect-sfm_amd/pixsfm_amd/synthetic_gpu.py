@@ -80,7 +80,7 @@ def make_ba_problem_gpu(device, n_cams=200, n_points=200_000, obs_per_point=5, c
         val = val / val.norm(dim=-1, keepdim=True)
         patches[s:e] = val.reshape(e - s, patch_size, patch_size, channels).half()
     ph0 = torch.cos(th)[None, :]
-    refs = torch.einsum("k,nck->nc", ph0[0], A.float()).double()
+    refs = (A.float() * ph0[0]).sum(-1).double()     # (not einsum: its batched-GEMM path fails at n_loc * channels = 1.28e8 rows)
     refs = refs / refs.norm(dim=-1, keepdim=True)
     torch.cuda.synchronize(dev)
     prob = dict(obs_image=obs_image, obs_point=obs_point, obs_patch=np.arange(n_obs, dtype=np.int64),

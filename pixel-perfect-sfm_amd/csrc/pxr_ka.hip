@@ -43,6 +43,7 @@ struct KaArgs {
   pxr_ka_view v;
   const void* arena; const int32_t* corners; const double* scales; int H, W;
   int l2_normalize; int float_simd; int check_bounds; int lds_elems;   // lds_elems: doubles of dynamic LDS for the damped blocks
+  int lds_state_n;       // > 0: the whole LM state of a sub-problem lives in LDS too (normal matrix + 8 vectors + 4 index arrays of this many unknowns)
   pxr_loss loss; double bound; pxr_lm_options opt;
   // scratch
   double* desc;          // [n_nodes][3][C]: f, df/dx, df/dy
@@ -450,6 +451,64 @@ __device__ bool ka_chol_wave(double* A, int n, double* b) {
   return ok;
 }
 
+// one wavefront, 2 < n <= KA_NREG: the block in REGISTERS, lane = row.  Lane r holds row r of the lower triangle; pivot j
+// is read from lane j with v_readlane, every lane scales its own entry of column j, and the multipliers of the trailing
+// update (the scaled entries of the other rows) come in with v_readlane again -- no LDS read-modify-write chains, no
+// division: a track of 10 keypoints (18 unknowns) factors in ~5 k cycles against ~38 k for the LDS form above, which was
+// a quarter of an LM iteration of the sub-problem.  The solves run on the registers too; the solution goes to b.
+constexpr int KA_NREG = 24;
+__device__ __forceinline__ double ka_readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ bool ka_chol_wave_reg(const double* A, int n, double* b) {
+  const int lane = threadIdx.x & 63;
+  double row[KA_NREG], inv[KA_NREG];
+#pragma unroll
+  for (int c = 0; c < KA_NREG; ++c) row[c] = (lane < n && c <= lane && c < n) ? A[lane * n + c] : 0.0;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < KA_NREG; ++j) {
+    if (j < n) {                                              // wave-uniform
+      const double d = ka_readlane_f64(row[j], j);
+      const bool good = d > 0.0 && isfinite(d);
+      ok = ok && good;
+      inv[j] = good ? rsqrt(d) : 1.0;                         // 1 / L[j][j]
+      const double l = row[j] * inv[j];                       // lane r >= j: L[r][j]  (lane j: sqrt(d))
+      row[j] = l;
+#pragma unroll
+      for (int c = j + 1; c < KA_NREG; ++c)
+        if (c < n) row[c] = fma(-l, ka_readlane_f64(l, c), row[c]);   // rows r >= c use it; the others hold dead entries
+    } else {
+      inv[j] = 1.0;
+    }
+  }
+  double bi = lane < n ? b[lane] : 0.0;
+#pragma unroll
+  for (int j = 0; j < KA_NREG; ++j) {                         // L y = b
+    if (j < n) {
+      const double yj = ka_readlane_f64(bi, j) * inv[j];
+      bi = lane == j ? yj : (lane > j ? fma(-row[j], yj, bi) : bi);
+    }
+  }
+  // L^T x = y: step j needs L[j][r] in lane r -- lane j's row, one entry per lane: through the block's own storage
+  // (A is scratch of the iteration: overwritten with the factor's rows)
+  double* Aw = const_cast<double*>(A);
+  if (lane < n) {
+#pragma unroll
+    for (int c = 0; c < KA_NREG; ++c) if (c <= lane && c < n) Aw[lane * n + c] = row[c];
+  }
+  wave_sync();
+#pragma unroll
+  for (int j = KA_NREG - 1; j >= 0; --j) {
+    if (j < n) {
+      const double xj = ka_readlane_f64(bi, j) * inv[j];
+      bi = lane == j ? xj : (lane < j ? fma(-Aw[j * n + lane], xj, bi) : bi);
+    }
+  }
+  if (lane < n) b[lane] = bi;
+  return ok;
+}
+
 // one thread, n == 2 (a keypoint that is alone in its component)
 __device__ __forceinline__ bool ka_chol_2x2(const double* A, double* b) {
   const double a00 = A[0], a10 = A[2], a11 = A[3];
@@ -648,6 +707,26 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   p.n = n; p.ncomp = inf.ncomp;
   sm.num_camera_unknowns = n;
   double* A = (hsz <= a.lds_elems) ? sh_A : (a.Abuf + a.prob_h_ptr[prob]);
+  if (a.lds_state_n > 0) {
+    // The LM state of the sub-problem in LDS for the whole solve: the normal matrix the residual blocks are accumulated
+    // into (20 atomics per block went to L2 before) and the vectors / index arrays every short phase of an iteration
+    // walks -- each phase paid an L2 round trip for a few hundred bytes.  Launch-time decision: every sub-problem fits.
+    const int nm = a.lds_state_n;
+    double* base = sh_A + a.lds_elems;
+    p.Hm = base; base += a.lds_elems;
+    double* const lo_g = p.lo; double* const hi_g = p.hi;
+    const int *ro_g = p.row_off, *rv_g = p.row_v0, *rn_g = p.row_nc, *cv_g = p.comp_v0;
+    p.g = base; p.gun = base + nm; p.scale = base + 2 * nm; p.diag = base + 3 * nm; p.step = base + 4 * nm;
+    p.delta = base + 5 * nm; p.lo = base + 6 * nm; p.hi = base + 7 * nm;
+    int* ib = reinterpret_cast<int*>(base + 8 * nm);
+    p.row_off = ib; p.row_v0 = ib + nm; p.row_nc = ib + 2 * nm; p.comp_v0 = ib + 3 * nm;
+    for (int e = tid; e < n; e += blockDim.x) {
+      p.lo[e] = lo_g[e]; p.hi[e] = hi_g[e];
+      p.row_off[e] = ro_g[e]; p.row_v0[e] = rv_g[e]; p.row_nc[e] = rn_g[e];
+    }
+    for (int c = tid; c < inf.ncomp; c += blockDim.x) p.comp_v0[c] = cv_g[c];
+    __syncthreads();
+  }
   const pxr_lm_options& opt = a.opt;
 
   // evaluate cost + normal equations at the CURRENT keypoints, then scale: H <- S H S, g <- S g
@@ -729,7 +808,8 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     if (maxnc > 2) {
       for (int c = tid >> 6; c < p.ncomp; c += KA_NT / 64) {
         const int v0 = p.comp_v0[c], nc = p.row_nc[v0];
-        if (nc > 2 && nc <= 64 && !ka_chol_wave(A + p.row_off[v0], nc, p.step + v0)) sh_ok = 0;
+        if (nc > 2 && nc <= KA_NREG) { if (!ka_chol_wave_reg(A + p.row_off[v0], nc, p.step + v0)) sh_ok = 0; }
+        else if (nc > 2 && nc <= 64 && !ka_chol_wave(A + p.row_off[v0], nc, p.step + v0)) sh_ok = 0;
       }
     }
     __syncthreads();
@@ -1026,8 +1106,14 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   a.Hbuf = (double*)ctx->d_workspace_mat;
   a.Abuf = need_aglob ? (double*)((char*)ctx->d_workspace_mat + hbytes) : a.Hbuf;
   a.lds_elems = lds_elems;
+  // the whole LM state in LDS when EVERY sub-problem fits next to the static metadata caches at two workgroups per CU
+  int n_max = 1;
+  for (int i = 0; i < np; ++i) n_max = std::max(n_max, infos[i].n);
+  n_max = (n_max + 1) & ~1;                                           // the int arrays start 8-byte aligned
+  const size_t state_bytes = sizeof(double) * ((size_t)2 * lds_elems + (size_t)8 * n_max) + sizeof(int) * (size_t)4 * n_max;
+  a.lds_state_n = (!need_aglob && state_bytes <= (size_t)56 * 1024) ? n_max : 0;
   PXR_HIP(hipMemcpyAsync(d_hptr, h_ptr.data(), sizeof(int64_t) * (np + 1), hipMemcpyHostToDevice, st));
-  const size_t shmem = sizeof(double) * (size_t)lds_elems;
+  const size_t shmem = a.lds_state_n > 0 ? state_bytes : sizeof(double) * (size_t)lds_elems;
 #define KA_SOLVE_LAUNCH(KERNEL, ST, CC)                                                                      \
   do {                                                                                                       \
     PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<ST, CC>),                               \

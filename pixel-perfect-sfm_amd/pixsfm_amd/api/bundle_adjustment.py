@@ -193,13 +193,27 @@ def build_problem(image_camera, p2d_ptr, p2d_point3D, cam_model, n_points, track
                 camera_mask=cmask, point_role=role)
 
 
+_HOST = []
+
+
+def _host_module():
+    """pixsfm_amd._pxr_host, the compiled (pybind11) scene dump, or None where it was not built (csrc/Makefile target `host`)."""
+    if not _HOST:
+        try:
+            from .. import _pxr_host
+            _HOST.append(_pxr_host)
+        except ImportError:
+            _HOST.append(None)
+    return _HOST[0]
+
+
 class _SceneDump:
     """The Python objects of a scene read ONCE into flat arrays: images / cameras / points in ascending id, every point2D's
     point index, the tracks, and which (image, point2D) has a feature patch.  Independent of the BundleAdjustmentSetup and
     of the extractor / optimiser role, so BundleAdjuster.refine hands the same dump to the reference extraction and to the
     optimiser (the dump is the per-observation Python work of the drop-in path; pxr_ba_build_problem is native)."""
 
-    def __init__(self, reconstruction, feature_view):
+    def __init__(self, reconstruction, feature_view, use_compiled=True):
         rec = reconstruction
         self.reconstruction, self.feature_view = rec, feature_view
         self.img_ids, self.cam_ids, self.pt_ids = sorted(rec.images), sorted(rec.cameras), sorted(rec.points3D)
@@ -211,11 +225,26 @@ class _SceneDump:
         self.image_camera = np.array([self.cam_of[im.camera_id] for im in images], np.int32)
         self.counts = counts = [len(im.points2D) for im in images]
         self.p2d_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-        try:        # the attribute alone (-1 = no 3D point here); pycolmap marks it with 2^64 - 1, which does not fit: ask has_point3D()
-            ids = np.fromiter((q.point3D_id for im in images for q in im.points2D), dtype=np.int64, count=int(self.p2d_ptr[-1]))
-        except OverflowError:
-            ids = np.fromiter((q.point3D_id if q.has_point3D() else -1 for im in images for q in im.points2D), dtype=np.int64,
-                              count=int(self.p2d_ptr[-1]))
+        host = _host_module() if use_compiled else None
+        self.compiled = host is not None
+        if host is not None:         # the per-observation walk in C++ (csrc/pybind/pxr_host.cpp)
+            points = [rec.points3D[p] for p in pt_ids]
+            p2d_ptr, ids, self.track_ptr, self.track_image, self.track_p2d = host.scene_arrays(images, points, self.img_of)
+            assert np.array_equal(p2d_ptr, self.p2d_ptr)
+        else:
+            try:    # the attribute alone (-1 = no 3D point here); pycolmap marks it with 2^64 - 1, which does not fit: ask has_point3D()
+                ids = np.fromiter((q.point3D_id for im in images for q in im.points2D), dtype=np.int64, count=int(self.p2d_ptr[-1]))
+            except OverflowError:
+                ids = np.fromiter((q.point3D_id if q.has_point3D() else -1 for im in images for q in im.points2D), dtype=np.int64,
+                                  count=int(self.p2d_ptr[-1]))
+            ids = np.where(ids < 0, -1, ids)
+            points = [rec.points3D[p] for p in pt_ids]
+            tl = [pt.track.length() for pt in points]
+            self.track_ptr = np.concatenate([[0], np.cumsum(tl)]).astype(np.int64)
+            n_el = int(self.track_ptr[-1])
+            img_of = self.img_of
+            self.track_image = np.fromiter((img_of[e.image_id] for pt in points for e in pt.track.elements), dtype=np.int32, count=n_el)
+            self.track_p2d = np.fromiter((e.point2D_idx for pt in points for e in pt.track.elements), dtype=np.int32, count=n_el)
         # point3D id -> index in ascending-id order (ids are arbitrary integers: binary search in the sorted id list)
         pt_arr = np.asarray(pt_ids, dtype=np.int64)
         pos = np.searchsorted(pt_arr, np.maximum(ids, 0)) if len(pt_arr) else np.zeros(len(ids), np.int64)
@@ -224,13 +253,6 @@ class _SceneDump:
         if ((ids >= 0) & ~known).any():
             raise KeyError(int(ids[(ids >= 0) & ~known][0]))           # a point2D refers to a point3D the reconstruction lacks
         self.p2d_point3D = np.where(known, pos, -1).astype(np.int64)
-        points = [rec.points3D[p] for p in pt_ids]
-        tl = [pt.track.length() for pt in points]
-        self.track_ptr = np.concatenate([[0], np.cumsum(tl)]).astype(np.int64)
-        n_el = int(self.track_ptr[-1])
-        img_of = self.img_of
-        self.track_image = np.fromiter((img_of[e.image_id] for pt in points for e in pt.track.elements), dtype=np.int32, count=n_el)
-        self.track_p2d = np.fromiter((e.point2D_idx for pt in points for e in pt.track.elements), dtype=np.int32, count=n_el)
         self.cam_model = np.array([rec.cameras[c].model_id for c in self.cam_ids], np.int32)
         # which observations have a feature patch -- per image one set lookup over its keypoint ids, not one call per point2D
         fs = getattr(feature_view, "feature_set", None)
@@ -260,6 +282,14 @@ class _SceneDump:
         """The FeaturePatch / ArenaPatch of each (image index, point2D index), image by image (one dict per image)."""
         if self._patch_dicts is None:
             return [self.feature_view.fpatch(self.img_ids[a], b) for a, b in zip(obs_image_idx.tolist(), obs_p2d.tolist())]
+        if self.compiled:
+            dicts = [None if fm is None else (fm.patches if fm.is_sparse else fm.fpatch(0)) for fm in self._patch_dicts]
+            dense = [fm is not None and not fm.is_sparse for fm in self._patch_dicts]
+            try:
+                return _host_module().patches_of(dicts, dense, np.ascontiguousarray(obs_image_idx, dtype=np.int32),
+                                                 np.ascontiguousarray(obs_p2d, dtype=np.int32))[0]
+            except KeyError:
+                pass                     # the pure-Python walk below names the missing image / patch
         out = np.empty(len(obs_image_idx), dtype=object)
         order = np.argsort(obs_image_idx, kind="stable")
         bounds = np.searchsorted(obs_image_idx[order], np.arange(len(self.img_ids) + 1))
@@ -347,7 +377,9 @@ class _FlatBA:
         self.outside_images = {img_ids[k] for k in used_img if not in_setup[k]}
         self.obs_image = img_new[r["obs_image"]]
         self.obs_point = pt_new[r["obs_point"]]
-        self.obs_keys = [(img_ids[a], b) for a, b in zip(r["obs_image"].tolist(), r["obs_p2d"].tolist())]
+        self._key_image = np.asarray(img_ids, dtype=np.int64)[r["obs_image"]] if len(img_ids) else np.zeros(0, np.int64)
+        self._key_p2d = r["obs_p2d"]                 # obs_keys (a list of 1M tuples at configs[2]) is built only when somebody asks
+        self._obs_keys = None
         self.patches = scene.patches_of(r["obs_image"], r["obs_p2d"])
         n_i, n_c, n_p = len(used_img), len(used_cam), len(used_pt)
         self.image_camera = cam_new[image_camera[used_img]]
@@ -362,6 +394,18 @@ class _FlatBA:
         self.tvec_mask = r["tvec_mask"][used_img].astype(np.uint8)
         self.cam_mask = r["camera_mask"][used_cam].astype(np.uint16)
         self.point_const = r["point_role"][used_pt].astype(np.uint8)
+
+    @property
+    def obs_keys(self):
+        """(image_id, point2D_idx) of every residual block."""
+        if self._obs_keys is None:
+            self._obs_keys = list(zip(self._key_image.tolist(), self._key_p2d.tolist()))
+        return self._obs_keys
+
+    def key_arrays(self, obs):
+        """(len(obs), 2) int64: image_id, point2D_idx of the given residual blocks -- without the list of tuples."""
+        obs = np.asarray(obs, dtype=np.int64)
+        return np.stack([self._key_image[obs], self._key_p2d[obs].astype(np.int64)], 1)
 
     def problem_dict(self, refs, patch_index=None):
         """patch_index: arena patch of each observation (features.to_arena(...).index); default 0 .. n_obs - 1."""
@@ -429,8 +473,7 @@ class ReferenceExtractor:
                 obs_of_point.setdefault(int(k), []).append(i)
         if not keep:        # the default: ids + source observation + descriptor row per point, objects on demand
             sel = np.flatnonzero(chosen >= 0)
-            keys = [flat.obs_keys[int(c)] for c in chosen[sel]]
-            return features.ReferenceMap([flat.point_ids[k] for k in sel], np.array(keys, dtype=np.int64).reshape(len(sel), 2), refs[sel])
+            return features.ReferenceMap([flat.point_ids[k] for k in sel], flat.key_arrays(chosen[sel]), refs[sel])
         out = {}
         for k, pid in enumerate(flat.point_ids):
             if chosen[k] >= 0:
@@ -577,6 +620,9 @@ class _PointSubset:
         self.obs_point = np.array([local[int(flat.obs_point[i])] for i in obs], np.int32)
         self.patches = [flat.patches[i] for i in obs]
         self.xyz = flat.xyz[np.asarray(pts, dtype=np.int64)]
+
+    def key_arrays(self, obs):
+        return self.flat.key_arrays(self.obs[np.asarray(obs, dtype=np.int64)])
 
     def problem_dict(self, refs, patch_index):
         f = self.flat

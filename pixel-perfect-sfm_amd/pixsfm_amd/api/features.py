@@ -64,6 +64,9 @@ class FeaturePatch:
         self._ptr = self.data.ctypes.data            # cached: to_arena reads it once per patch
         self.corner = np.asarray(corner, dtype=np.int32).reshape(2)
         self.scale = np.asarray(scale, dtype=np.float64).reshape(2)
+        self.corner.setflags(write=False); self.scale.setflags(write=False)     # read-only like the pybind properties (features/bindings.cc:55-58)
+        self._meta = (self._ptr, int(self.corner[0]), int(self.corner[1]), float(self.scale[0]), float(self.scale[1]),
+                      self.data.shape + (self.data.dtype.str,))
 
     @property
     def shape(self):
@@ -103,6 +106,7 @@ class FeaturePatch:
     def __setstate__(self, state):               # a copy / unpickled patch owns new memory: the cached address moves with it
         self.__dict__.update(state)
         self._ptr = self.data.ctypes.data
+        self._meta = (self._ptr,) + tuple(self._meta[1:])
 
     def num_bytes(self):                         # Size() * sizeof(dtype)
         return int(self.data.nbytes)
@@ -441,6 +445,20 @@ class ArenaRef:
             self._arena.close()
 
 
+_HOST = []
+
+
+def _host_module():
+    """pixsfm_amd._pxr_host (the compiled host binding), or None where it was not built."""
+    if not _HOST:
+        try:
+            from .. import _pxr_host
+            _HOST.append(_pxr_host)
+        except ImportError:
+            _HOST.append(None)
+    return _HOST[0]
+
+
 class SharedArena:
     """One upload for several consumers of the same host patches: BundleAdjuster.refine runs the reference extraction and
     the optimiser on the same FeatureSet -- the second to_arena(..., cache=this) finds its patches in the arena the first
@@ -481,24 +499,33 @@ def to_arena(ctx, patch_list, cache=None):
     if any(on_device):
         raise ValueError("cannot mix host FeaturePatch and device ArenaPatch objects in one problem")
     # one arena entry per DISTINCT patch object: in dense mode all keypoints of an image share one (large) patch
-    slot, uniq, index = {}, [], np.empty(len(patch_list), dtype=np.int64)
-    for k, p in enumerate(patch_list):
-        if id(p) not in slot:
-            slot[id(p)] = len(uniq)
-            uniq.append(p)
-        index[k] = slot[id(p)]
+    host = _host_module()
+    mixed = "the accelerated path needs patches of identical shape and dtype (sparse patches of one patch_size, " \
+            "pixsfm/features/extractor.py:33-51, or dense maps of equal size)"
+    if host is not None:             # compiled walk over the patch objects (csrc/pybind/pxr_host.cpp)
+        try:
+            index, uniq, pointers, corners, scales = host.gather_patches(list(patch_list))
+        except ValueError:
+            raise ValueError(mixed) from None
+        slot = None
+    else:
+        slot, uniq, index = {}, [], np.empty(len(patch_list), dtype=np.int64)
+        for k, p in enumerate(patch_list):
+            if id(p) not in slot:
+                slot[id(p)] = len(uniq)
+                uniq.append(p)
+            index[k] = slot[id(p)]
+        corners = np.array([p.corner for p in uniq], dtype=np.int32).reshape(len(uniq), 2)
+        scales = np.array([p.scale for p in uniq], dtype=np.float64).reshape(len(uniq), 2)
+        pointers = np.fromiter((p.data_ptr() for p in uniq), dtype=np.uint64, count=len(uniq))
+        if len({p._meta[5] for p in uniq}) != 1:
+            raise ValueError(mixed)
     shape, dtype = uniq[0].shape, uniq[0].data.dtype
-    for p in uniq:
-        if p.shape != shape or p.data.dtype != dtype:
-            raise ValueError("the accelerated path needs patches of identical shape and dtype (sparse patches of one "
-                             "patch_size, pixsfm/features/extractor.py:33-51, or dense maps of equal size)")
-    corners = np.array([p.corner for p in uniq], dtype=np.int32).reshape(len(uniq), 2)
-    scales = np.array([p.scale for p in uniq], dtype=np.float64).reshape(len(uniq), 2)
-    pointers = np.fromiter((p.data_ptr() for p in uniq), dtype=np.uint64, count=len(uniq))
     # the patches go up one by one through pinned staging buffers (no np.stack of the set: 65 GB at BASELINE configs[2])
     arena = PatchArena.from_patch_pointers(ctx, pointers, shape, dtype, corners, scales)
     if cache is not None:
-        cache.arena, cache.slot = arena, slot
+        cache.arena = arena
+        cache.slot = slot if slot is not None else {id(p): k for k, p in enumerate(uniq)}
         return ArenaRef(arena, index, owned=False)
     return ArenaRef(arena, index, owned=True)
 

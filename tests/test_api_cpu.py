@@ -274,3 +274,104 @@ def test_native_edge_construction_matches_the_python_restatement(weight_by_sim, 
         want = pxo_graph.build_edges(g, None, tl, roots, subset, weight_by_sim, root_edges_only, reg)
         assert got[0] == list(want[0]) and got[1] == list(want[1]) and np.array_equal(got[2], want[2])
         assert len(got[0]) > 0
+
+
+def test_compiled_scene_dump_equals_the_python_walk():
+    """pixsfm_amd._pxr_host (pybind11, csrc/pybind/pxr_host.cpp) reads the pycolmap-style objects in C++; _SceneDump must give the
+    same arrays and the same patch objects with and without it -- on the stand-in classes, with point2Ds without a 3D point in
+    both spellings (-1 here, 2^64 - 1 in pycolmap), observations without a patch, a dense map and a missing feature map."""
+    import pytest
+    from pixsfm_amd.api import bundle_adjustment as B, features
+    from pixsfm_amd.api.reconstruction import Camera, Image, Point2D, Point3D, Reconstruction
+    if B._host_module() is None:
+        pytest.skip("_pxr_host was not built (no pybind11 / Python headers)")
+
+    class PycolmapStylePoint2D:                      # kInvalidPoint3DId = 2^64 - 1
+        def __init__(self, pid):
+            self.point3D_id = pid if pid >= 0 else 2 ** 64 - 1
+
+        def has_point3D(self):
+            return self.point3D_id != 2 ** 64 - 1
+
+    rng = np.random.default_rng(3)
+    rec = Reconstruction()
+    rec.add_camera(Camera(7, "SIMPLE_RADIAL", 100, 100, [50.0, 50, 50, 0]))
+    n_img, n_pts = 6, 40
+    images = [Image(10 + 3 * i, "im%d.jpg" % i, 7, [1, 0, 0, 0], [0, 0, 0]) for i in range(n_img)]
+    for p in range(n_pts):
+        rec.add_point3D(100 + 7 * p, Point3D(rng.normal(size=3)))
+    for p in range(n_pts):
+        for i in rng.choice(n_img, 3, replace=False):
+            im = images[i]
+            cls = PycolmapStylePoint2D if i % 2 else (lambda pid: Point2D([0, 0], pid))
+            if rng.random() < 0.2:
+                im.points2D.append(cls(-1))          # a keypoint without a 3D point
+            im.points2D.append(cls(100 + 7 * p))
+            rec.points3D[100 + 7 * p].track.add_element(im.image_id, len(im.points2D) - 1)
+    for im in images:
+        rec.add_image(im)
+    fmaps = {}
+    for k, im in enumerate(images):
+        if k == 4:
+            continue                                  # no feature map at all for this image
+        if k == 2:
+            fmaps[im.name] = features.FeatureMap.dense(np.zeros((4, 4, 8), np.float16), (1.0, 1.0))
+            continue
+        fm = features.FeatureMap()
+        for j in range(len(im.points2D)):
+            if rng.random() < 0.9:
+                fm.patches[j] = features.FeaturePatch(np.zeros((2, 2, 8), np.float16) + j, (j, k), (1.0, 1.0))
+        fmaps[im.name] = fm
+    fv = B.FeatureView(features.FeatureSet(fmaps), rec)
+    a, b = B._SceneDump(rec, fv, use_compiled=True), B._SceneDump(rec, fv, use_compiled=False)
+    assert a.compiled and not b.compiled
+    for name in ("p2d_ptr", "p2d_point3D", "track_ptr", "track_image", "track_p2d", "has_patch", "image_camera", "cam_model"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+        assert getattr(a, name).dtype == getattr(b, name).dtype, name
+    # patch lookup on the observations that do have one
+    at = np.flatnonzero((a.p2d_point3D >= 0) & (a.has_patch == 1))
+    oi = (np.searchsorted(a.p2d_ptr, at, side="right") - 1).astype(np.int32)
+    oj = (at - a.p2d_ptr[oi]).astype(np.int32)
+    keep = oi != 4
+    pa, pb = a.patches_of(oi[keep], oj[keep]), b.patches_of(oi[keep], oj[keep])
+    assert len(pa) == keep.sum() and all(x is y for x, y in zip(pa, pb))
+    with pytest.raises(KeyError):
+        a.patches_of(np.array([4], np.int32), np.array([0], np.int32))
+    # and the whole flat problem through both
+    setup = B.default_problem_setup(rec)
+    fa = B._FlatBA(rec, setup, fv, {}, extractor=True, scene=a)
+    fb = B._FlatBA(rec, setup, fv, {}, extractor=True, scene=b)
+    assert np.array_equal(fa.obs_image, fb.obs_image) and np.array_equal(fa.obs_point, fb.obs_point) and fa.obs_keys == fb.obs_keys
+    assert all(x is y for x, y in zip(fa.patches, fb.patches))
+
+
+def test_compiled_patch_gather_equals_the_python_walk():
+    """_pxr_host.gather_patches: slots per DISTINCT patch object (a dense map is shared by all its keypoints), buffer addresses,
+    corners, scales -- what features.to_arena hands to pxr_arena_upload_gather; mixed layouts are refused."""
+    import pytest
+    from pixsfm_amd.api import features
+    host = features._host_module()
+    if host is None:
+        pytest.skip("_pxr_host was not built")
+    rng = np.random.default_rng(1)
+    base = [features.FeaturePatch(rng.normal(size=(4, 4, 8)).astype(np.float16), (3 * k, -k), (1.0 + k, 0.5)) for k in range(7)]
+    order = rng.integers(0, 7, 40)
+    plist = [base[k] for k in order]
+    index, uniq, ptrs, corners, scales = host.gather_patches(plist)
+    first = {}
+    for k in order.tolist():
+        first.setdefault(k, len(first))
+    assert index.tolist() == [first[k] for k in order.tolist()] and index.dtype == np.int64
+    want = [base[k] for k in sorted(first, key=first.get)]
+    assert len(uniq) == len(want) and all(a is b for a, b in zip(uniq, want))
+    assert ptrs.tolist() == [p.data.ctypes.data for p in want] and ptrs.dtype == np.uint64
+    assert np.array_equal(corners, np.array([p.corner for p in want], np.int32)) and corners.dtype == np.int32
+    assert np.array_equal(scales, np.array([p.scale for p in want], np.float64))
+    with pytest.raises(ValueError):
+        host.gather_patches(plist + [features.FeaturePatch(np.zeros((4, 4, 8), np.float32), (0, 0), (1.0, 1.0))])
+    with pytest.raises(ValueError):
+        host.gather_patches(plist + [features.FeaturePatch(np.zeros((2, 4, 8), np.float16), (0, 0), (1.0, 1.0))])
+    import copy
+    import pickle
+    for clone in (pickle.loads(pickle.dumps(base[2])), copy.deepcopy(base[2])):     # a copy owns new memory: its address moved with it
+        assert clone._meta[0] == clone.data.ctypes.data and clone._meta[1:] == base[2]._meta[1:]

@@ -178,7 +178,7 @@ static int upload_staged(pxr_arena* a, int64_t first, int64_t count, const void*
   pxr_ctx* ctx = a->ctx;
   hipStream_t s = ctx->stream;
   const size_t pb = a->patch_bytes();
-  constexpr size_t kStage = (size_t)128 << 20;
+  constexpr size_t kStage = (size_t)256 << 20;
   if (!ctx->h_stage[0]) {
     for (int b = 0; b < 2; ++b) {
       if (hipHostMalloc(&ctx->h_stage[b], kStage, hipHostMallocDefault) != hipSuccess) {
@@ -190,7 +190,7 @@ static int upload_staged(pxr_arena* a, int64_t first, int64_t count, const void*
     ctx->stage_bytes = kStage;
   }
   const int64_t per = std::max<int64_t>(1, (int64_t)(ctx->stage_bytes / pb));
-  unsigned n_thr = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+  unsigned n_thr = std::max(1u, std::min(std::thread::hardware_concurrency() / 2, 32u));   // the gather is the slower side of the pipeline
   bool used[2] = {false, false};
   int b = 0;
   for (int64_t c0 = 0; c0 < count; c0 += per, b ^= 1) {

@@ -164,6 +164,85 @@ __device__ __forceinline__ void interp8(const ST* __restrict__ patch, int H, int
   }
 }
 
+// ---- value only, TWO 8-channel chunks per lane (channels 8 sub .. and 64 + 8 sub ..): a 128-channel descriptor on 8 lanes ----
+// For passes that are chains of memory round trips rather than arithmetic (the line-search probes of the keypoint adjustment):
+// 32 nodes per 256-thread trip instead of 16.  Same per-channel arithmetic as interp8; the L2 norm is summed over the 8 lanes.
+template <typename ST, bool FLOAT_SIMD>
+__device__ __forceinline__ void interp8x2_value(const ST* __restrict__ patch, int H, int W, int sub, double u, double v,
+                                                bool l2_normalize, double fa[8], double fb[8]) {
+  constexpr int C = 128;
+  const double rf = floor(v), cf = floor(u);
+  const int row = (int)rf, col = (int)cf;
+  const double dy = v - rf, dx = u - cf;
+  int ro[4], co[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    ro[j] = clampi(row - 1 + j, 0, H - 1) * W;
+    co[j] = clampi(col - 1 + j, 0, W - 1);
+  }
+  typedef typename Texel8<ST>::work_t HT;
+#pragma unroll
+  for (int part = 0; part < 2; ++part) {
+    double* f = part ? fb : fa;
+    Texel8<ST> tx[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tx[j][i].load(patch + (size_t)(ro[j] + co[i]) * C + part * 64 + sub * 8);
+    HT h[4][8];
+    if constexpr (sizeof(HT) == 4) {
+      const SplineCoefF32 kh(dx);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float p0[8], p1[8], p2[8], p3[8];
+        tx[j][0].unpack(p0); tx[j][1].unpack(p1); tx[j][2].unpack(p2); tx[j][3].unpack(p3);
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) { float dd = 0.f; spline_f32<false>(p0[ch], p1[ch], p2[ch], p3[ch], kh, h[j][ch], dd); }
+      }
+    } else {
+      const SplineCoefF64 kh(dx);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double p0[8], p1[8], p2[8], p3[8];
+        tx[j][0].unpack(p0); tx[j][1].unpack(p1); tx[j][2].unpack(p2); tx[j][3].unpack(p3);
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+          double ff = 0, dd = 0;
+          spline_f64<true, false>(p0[ch], p1[ch], p2[ch], p3[ch], kh, ff, dd);
+          if (FLOAT_SIMD) ff = (double)(float)ff;
+          h[j][ch] = ff;
+        }
+      }
+    }
+    if constexpr (FLOAT_SIMD) {
+      const SplineCoefF32 kv(dy);
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        float ff, dd = 0.f;
+        spline_f32<false>((float)h[0][ch], (float)h[1][ch], (float)h[2][ch], (float)h[3][ch], kv, ff, dd);
+        f[ch] = (double)ff;
+      }
+    } else {
+      const SplineCoefF64 kv(dy);
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        double ff = 0, dd = 0;
+        spline_f64<true, false>((double)h[0][ch], (double)h[1][ch], (double)h[2][ch], (double)h[3][ch], kv, ff, dd);
+        f[ch] = ff;
+      }
+    }
+  }
+  if (l2_normalize) {
+    double ss = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) ss = fma(fa[ch], fa[ch], fma(fb[ch], fb[ch], ss));
+    ss = row8_sum(ss);
+    const double ninv = 1.0 / sqrt(ss);
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) { fa[ch] *= ninv; fb[ch] *= ninv; }
+  }
+}
+
 // ---- few-channel patches (cost maps: C = 1 or 3) ---------------------------------------------
 // With fewer than 8 channels the reference leaves its SIMD path (base/src/interpolation.h:222-227) and runs
 // [upstream] ceres::BiCubicInterpolator on doubles (:240-266): per row the Catmull-Rom spline

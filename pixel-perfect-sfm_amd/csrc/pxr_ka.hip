@@ -165,9 +165,37 @@ struct KaProb {
 
 // evaluate all nodes of the problem at keypoints `kp`
 template <typename ST, int C, bool WITH_JAC>
-__device__ void ka_nodes(const KaArgs& a, const KaProb& p, const double* kp, bool fsimd) {
+__device__ void ka_nodes(const KaArgs& a, const KaProb& p, const double* kp, bool fsimd, bool moving_only = false) {
   constexpr int LPO = KaLay<C>::LPO, G = KA_NT / LPO;
   const int grp = threadIdx.x / LPO, sub = threadIdx.x % LPO;
+  if constexpr (!WITH_JAC && C == 128 && sizeof(ST) <= 4) {
+    // value-only pass over the cached nodes (the line-search probes): EIGHT lanes per node, two 8-channel chunks each -- 32
+    // nodes per trip instead of 16 -- and, for a probe (moving_only), only the nodes that MOVE: a constant keypoint (a track's
+    // root) keeps the descriptor the linearisation wrote
+    if (p.cnode) {
+      const int qgrp = threadIdx.x / 8, qsub = threadIdx.x % 8;
+      const int64_t ncached = min((int64_t)KA_NODE_CACHE, p.np1 - p.np0);
+#pragma nounroll
+      for (int64_t i = p.np0 + qgrp; i - p.np0 < ncached; i += KA_NT / 8) {
+        const KaNodeMeta m = p.cnode[i - p.np0];
+        if (m.node < 0 || (moving_only && m.v < 0)) continue;
+        const double u = kp[2 * m.node] * m.sx - 0.5 - m.cx, v = kp[2 * m.node + 1] * m.sy - 0.5 - m.cy;
+        const ST* patch = reinterpret_cast<const ST*>(a.arena) + (size_t)m.pi * a.H * a.W * C;
+        double fa[8], fb[8];
+        if (fsimd) interp8x2_value<ST, true>(patch, a.H, a.W, qsub, u, v, a.l2_normalize != 0, fa, fb);
+        else interp8x2_value<ST, false>(patch, a.H, a.W, qsub, u, v, a.l2_normalize != 0, fa, fb);
+        double* d = a.desc + (size_t)m.node * 3 * C + qsub * 8;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) { d[ch] = fa[ch]; d[64 + ch] = fb[ch]; }
+      }
+      for (int64_t i = p.np0 + KA_NODE_CACHE + grp; i < p.np1; i += G) {       // nodes beyond the cache: the general form
+        const int64_t node = a.v.d_prob_nodes[i];
+        if (a.used[node]) ka_eval_node<ST, C, WITH_JAC>(a, node, kp, sub, fsimd);
+      }
+      __syncthreads();
+      return;
+    }
+  }
 #pragma nounroll
   for (int64_t i = p.np0 + grp; i < p.np1; i += G) {
     if (p.cnode && i - p.np0 < KA_NODE_CACHE) {
@@ -208,15 +236,42 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
     // different block.
     if (p.cedge && p.csq) {
       const int64_t ncached = min((int64_t)KA_EDGE_CACHE, p.ne1 - p.ne0);
-      for (; i_first - p.ne0 < ncached; i_first += G) {
-        const KaEdgeMeta m = p.cedge[i_first - p.ne0];
-        const double* d1 = a.desc + (size_t)m.n1 * 3 * C + sub * CPL;
-        const double* d2 = a.desc + (size_t)m.n2 * 3 * C + sub * CPL;
-        double sq = 0;
+      if constexpr (C >= 32) {
+        // FOUR lanes per residual block here (C / 4 channels each, streamed): the pass is a chain of L2 round trips, not
+        // arithmetic -- 64 blocks per trip instead of 16 cuts the trips of a 225-block sub-problem from 15 to 4
+        constexpr int QL = 4, QG = KA_NT / QL, QC = C / QL;
+        const int qgrp = threadIdx.x / QL, qsub = threadIdx.x % QL;
+        for (int64_t i = p.ne0 + qgrp; i - p.ne0 < ncached; i += QG) {
+          const KaEdgeMeta m = p.cedge[i - p.ne0];
+          // lane q of the group takes channels 2 q + 8 k, 2 q + 8 k + 1: the four lanes read 64 consecutive bytes per load
+          const double2* d1 = reinterpret_cast<const double2*>(a.desc + (size_t)m.n1 * 3 * C) + qsub;
+          const double2* d2 = reinterpret_cast<const double2*>(a.desc + (size_t)m.n2 * 3 * C) + qsub;
+          double2 x1[QC / 2], x2[QC / 2];
 #pragma unroll
-        for (int ch = 0; ch < CPL; ++ch) { const double r = d1[ch] - d2[ch]; sq = fma(r, r, sq); }
-        sq = lpo_sum(sq, LPO);
-        if (sub == 0) p.csq[i_first - p.ne0] = sq;
+          for (int k = 0; k < QC / 2; ++k) { x1[k] = d1[QL * k]; x2[k] = d2[QL * k]; }
+          double sq0 = 0, sq1 = 0;
+#pragma unroll
+          for (int k = 0; k < QC / 2; ++k) {
+            const double r0 = x1[k].x - x2[k].x, r1 = x1[k].y - x2[k].y;
+            sq0 = fma(r0, r0, sq0); sq1 = fma(r1, r1, sq1);
+          }
+          double sq = sq0 + sq1;
+          sq += dpp_f64<0xB1>(sq);   // quad_perm [1,0,3,2]
+          sq += dpp_f64<0x4E>(sq);   // quad_perm [2,3,0,1]
+          if (qsub == 0) p.csq[i - p.ne0] = sq;
+        }
+        i_first = p.ne0 + ncached + grp;
+      } else {
+        for (; i_first - p.ne0 < ncached; i_first += G) {
+          const KaEdgeMeta m = p.cedge[i_first - p.ne0];
+          const double* d1 = a.desc + (size_t)m.n1 * 3 * C + sub * CPL;
+          const double* d2 = a.desc + (size_t)m.n2 * 3 * C + sub * CPL;
+          double sq = 0;
+#pragma unroll
+          for (int ch = 0; ch < CPL; ++ch) { const double r = d1[ch] - d2[ch]; sq = fma(r, r, sq); }
+          sq = lpo_sum(sq, LPO);
+          if (sub == 0) p.csq[i_first - p.ne0] = sq;
+        }
       }
       __syncthreads();
       for (int64_t k = threadIdx.x; k < ncached; k += blockDim.x) {
@@ -224,6 +279,67 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
         loss_eval(a.loss.type, a.loss.a, p.cedge[k].w, p.csq[k], rho);
         cost += 0.5 * rho[0];
       }
+    }
+  }
+  if constexpr (WITH_JAC && C >= 64) {
+    // linearisation, cached residual blocks: EIGHT lanes per block (C / 8 channels each as interleaved pairs: the eight lanes
+    // read 128 consecutive bytes per load), 32 blocks per trip instead of 16 -- the trips are chains of L2 round trips
+    if (p.cedge) {
+      constexpr int QL = 8, QG = KA_NT / QL, QP = C / (2 * QL);       // QP channel pairs per lane
+      const int qgrp = threadIdx.x / QL, qsub = threadIdx.x % QL;
+      const int64_t ncached = min((int64_t)KA_EDGE_CACHE, p.ne1 - p.ne0);
+#pragma nounroll
+      for (int64_t i = p.ne0 + qgrp; i - p.ne0 < ncached; i += QG) {
+        const KaEdgeMeta m = p.cedge[i - p.ne0];
+        const double2* d1 = reinterpret_cast<const double2*>(a.desc + (size_t)m.n1 * 3 * C) + qsub;
+        const double2* d2 = reinterpret_cast<const double2*>(a.desc + (size_t)m.n2 * 3 * C) + qsub;
+        double q[14], s = 0;
+#pragma unroll
+        for (int k = 0; k < 14; ++k) q[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < QP; ++k) {
+          const double2 f1 = d1[QL * k], f2 = d2[QL * k];
+          const double2 gx1 = d1[C / 2 + QL * k], gy1 = d1[C + QL * k], gx2 = d2[C / 2 + QL * k], gy2 = d2[C + QL * k];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const double r = h ? f1.y - f2.y : f1.x - f2.x;
+            const double a0 = h ? gx1.y : gx1.x, a1 = h ? gy1.y : gy1.x, a2 = -(h ? gx2.y : gx2.x), a3 = -(h ? gy2.y : gy2.x);
+            s = fma(r, r, s);
+            q[0] = fma(a0, a0, q[0]); q[1] = fma(a0, a1, q[1]); q[2] = fma(a0, a2, q[2]); q[3] = fma(a0, a3, q[3]);
+            q[4] = fma(a1, a1, q[4]); q[5] = fma(a1, a2, q[5]); q[6] = fma(a1, a3, q[6]);
+            q[7] = fma(a2, a2, q[7]); q[8] = fma(a2, a3, q[8]); q[9] = fma(a3, a3, q[9]);
+            q[10] = fma(a0, r, q[10]); q[11] = fma(a1, r, q[11]); q[12] = fma(a2, r, q[12]); q[13] = fma(a3, r, q[13]);
+          }
+        }
+        s = row8_sum(s);
+#pragma unroll
+        for (int k = 0; k < 14; ++k) q[k] = row8_sum(q[k]);
+        double rho[3];
+        loss_eval(a.loss.type, a.loss.a, m.w, s, rho);
+        if (qsub == 0) {
+          cost += 0.5 * rho[0];
+          const double kappa = ka_kappa(s, rho);
+          const int v1 = m.v1, v2 = m.v2;
+          const int vv = v1 >= 0 ? v1 : v2;
+          if (vv >= 0) {
+            const int nc = p.row_nc[vv], c0 = p.row_v0[vv];
+            const int idx[4] = {v1, v1 + 1, v2, v2 + 1};
+            const bool var[4] = {v1 >= 0, v1 >= 0, v2 >= 0, v2 >= 0};
+            const double b[4] = {q[10], q[11], q[12], q[13]};
+            const double mm[4][4] = {{q[0], q[1], q[2], q[3]}, {q[1], q[4], q[5], q[6]}, {q[2], q[5], q[7], q[8]}, {q[3], q[6], q[8], q[9]}};
+            double* blk = p.Hm + (p.row_off[vv] - (vv - c0) * nc);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              if (!var[x]) continue;
+              atomicAdd(p.g + idx[x], rho[1] * b[x]);
+#pragma unroll
+              for (int y = 0; y < 4; ++y)
+                if (var[y]) atomicAdd(blk + (size_t)(idx[x] - c0) * nc + (idx[y] - c0), rho[1] * (mm[x][y] - kappa * b[x] * b[y]));
+            }
+          }
+        }
+      }
+      i_first = p.ne0 + ncached + grp;
     }
   }
 #pragma nounroll
@@ -759,7 +875,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   };
   auto cost_at_candidate = [&]() -> double {
     KA_T(7);
-    ka_nodes<ST, C, false>(a, p, a.kp_cand, fsimd);
+    ka_nodes<ST, C, false>(a, p, a.kp_cand, fsimd, true);
     KA_T(3);
     const double c = ka_terms<C, false>(a, p, sh4);
     KA_T(4);

@@ -229,3 +229,26 @@ def test_sub_problem_larger_than_the_lds_metadata_caches(ctx):
     assert per[0]["iterations"] == sums[0]["iterations"] and per[0]["num_successful"] == sums[0]["num_successful"]
     assert abs(per[0]["final_cost"] - sums[0]["final_cost"]) < 1e-8 * sums[0]["final_cost"]
     assert np.abs(ka.keypoints() - kpo).max() < 1e-6
+
+
+def test_all_constant_sub_problem_reports_its_cost(ctx):
+    """Every keypoint of one sub-problem held constant (n = 0 unknowns): nothing to solve, but the summary's initial / final
+    cost is the cost of its residual blocks -- evaluated on ALL nodes (the value-only pass of the line-search probes skips
+    constant nodes; this path must not)."""
+    import pxo
+    import pxo_ka
+    from pixsfm_amd.engine import PatchArena, interp_cfg, make_loss
+    from pixsfm_amd.ka_engine import KAProblem
+    from pixsfm_amd import synthetic_ka
+    prob = synthetic_ka.make_ka_problem(n_tracks=6, track_len=4, seed=9, max_kps_per_problem=8)
+    frozen = int(prob["node_problem"].max())
+    prob["node_const"] = np.where(prob["node_problem"] == frozen, 1, prob["node_const"]).astype(np.uint8)
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ka = KAProblem(ctx, arena, prob)
+    total, per = ka.solve(interp_cfg(), make_loss(), per_problem=True)
+    kpo, sums = pxo_ka.ka_solve(prob, pxo.cfg(), pxo.loss(), 4.0)
+    assert per[frozen]["num_camera_unknowns"] == 0 and per[frozen]["initial_cost"] > 0
+    assert abs(per[frozen]["initial_cost"] - sums[frozen]["initial_cost"]) < 1e-10 * sums[frozen]["initial_cost"]
+    assert per[frozen]["final_cost"] == per[frozen]["initial_cost"]
+    assert np.array_equal(ka.keypoints()[prob["node_problem"] == frozen], prob["kp"][prob["node_problem"] == frozen])
+    assert np.abs(ka.keypoints() - kpo).max() < 1e-6

@@ -27,8 +27,9 @@ namespace pxr {
 
 // corner of keypoint k in map texels (extractor.py:192-193): C-style truncation like astype(np.int32)
 __device__ __forceinline__ void ex_corner(const double* kp, double sx, double sy, int ps, int w, int h, int& x0, int& y0) {
-  x0 = (int)(kp[0] * sx - ps / 2.0);
-  y0 = (int)(kp[1] * sy - ps / 2.0);
+  // clamped as doubles first: the conversion of a value outside int's range is undefined (NaN lands on 0)
+  x0 = (int)fmin(fmax(kp[0] * sx - ps / 2.0, -1.0), (double)w);
+  y0 = (int)fmin(fmax(kp[1] * sy - ps / 2.0, -1.0), (double)h);
   x0 = min(max(x0, 0), w - ps - 1);
   y0 = min(max(y0, 0), h - ps - 1);
 }

@@ -56,6 +56,14 @@ struct Texel8<double> {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// floor(coordinate) as an int for the 4 x 4 stencil.  A coordinate far outside the patch (a diverging solver step: |x| > 2^31)
+// makes the plain conversion undefined -- the compiled code then indexed memory with the garbage and the GPU raised a memory
+// fault.  Every index below -3 selects the same clamped texels as -3, every index above n + 1 the same as n + 1 (Grid2D's
+// clamping, grid2d.h:64-73), so the conversion is made on the clamped value; NaN lands on -3.
+__device__ __forceinline__ int texel_index(double floored, int n) {
+  return (int)fmin(fmax(floored, -3.0), (double)n + 1.0);
+}
+
 // Normalised descriptor + gradients of 8 channels of one observation, all lanes of the
 // observation's lane group cooperating.  LPO = lanes per observation (C / 8).
 template <typename ST, int LPO, bool WITH_JAC, bool FLOAT_SIMD>
@@ -66,7 +74,7 @@ __device__ __forceinline__ void interp8(const ST* __restrict__ patch, int H, int
   // the row derivatives; the reference leaves it un-normalised (interpolation.h:642-666)
   // BiCubicInterpolator::EvaluateSIMD: r = v (row), c = u (column)
   const double rf = floor(v), cf = floor(u);
-  const int row = (int)rf, col = (int)cf;
+  const int row = texel_index(rf, H), col = texel_index(cf, W);
   const double dy = v - rf, dx = u - cf;
   int ro[4], co[4];
 #pragma unroll
@@ -172,7 +180,7 @@ __device__ __forceinline__ void interp8x2_value(const ST* __restrict__ patch, in
                                                 bool l2_normalize, double fa[8], double fb[8]) {
   constexpr int C = 128;
   const double rf = floor(v), cf = floor(u);
-  const int row = (int)rf, col = (int)cf;
+  const int row = texel_index(rf, H), col = texel_index(cf, W);
   const double dy = v - rf, dx = u - cf;
   int ro[4], co[4];
 #pragma unroll
@@ -263,7 +271,7 @@ template <typename ST, int C>
 __device__ __forceinline__ void interp_small(const ST* __restrict__ patch, int H, int W, double u, double v,
                                              bool l2_normalize, double f[C], double fr[C], double fc[C]) {
   const double rf = floor(v), cf = floor(u);
-  const int row = (int)rf, col = (int)cf;
+  const int row = texel_index(rf, H), col = texel_index(cf, W);
   const double dy = v - rf, dx = u - cf;
   int co[4];
 #pragma unroll

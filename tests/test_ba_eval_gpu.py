@@ -194,3 +194,27 @@ def test_check_bounds_has_no_effect_with_reference_descriptors(ctx):
         # (the two solves are separate runs: their reductions agree to rounding, not bit for bit)
         assert abs(s_on["final_cost"] - s_off["final_cost"]) <= 1e-9 * abs(s_off["final_cost"]), (s_on, s_off)
         assert all(np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max()) for a, b in zip(p_on, ba.params()))
+
+
+@pytest.mark.parametrize("wild", [3e9, 1e12, 1e30, float("inf"), float("nan")])
+def test_projections_beyond_int_range_stay_inside_the_patch(ctx, wild):
+    """A diverging camera can project observations billions of texels away from their patch.  The texel index is clamped
+    to the border like Grid2D does (grid2d.h:64-73) BEFORE the double -> int conversion (undefined beyond int's range:
+    the kernel used to fault there); the observations of the other cameras are not disturbed."""
+    from pixsfm_amd.engine import interp_cfg
+    prob, arena, ba = _setup(ctx, n_cams=6, n_points=120, obs_per_point=4, seed=12)
+    rec0, r0, gx0, _ = ba.eval(interp_cfg(), with_jacobian=True, materialize=True)
+    rec0, r0, gx0 = rec0.download(), r0.download(), gx0.download()
+    cams = np.zeros((6, 12))
+    cams[:, :prob["cam_params"].shape[1]] = prob["cam_params"]
+    cams[::2, 0] = wild                                    # focal length of every other camera
+    ba.d["cam_params"].upload(cams)
+    rec, r, gx, _ = ba.eval(interp_cfg(), with_jacobian=True, materialize=True)
+    ctx.sync()
+    rec, r, gx = rec.download(), r.download(), gx.download()
+    hit = prob["image_camera"][prob["obs_image"]] % 2 == 0
+    assert hit.any() and (~hit).any()
+    np.testing.assert_array_equal(r[~hit], r0[~hit])
+    np.testing.assert_array_equal(gx[~hit], gx0[~hit])
+    if np.isfinite(wild):
+        assert np.isfinite(r[hit]).all()                   # border texels, normalised

@@ -64,15 +64,14 @@ __device__ __forceinline__ int texel_index(double floored, int n) {
   return (int)fmin(fmax(floored, -3.0), (double)n + 1.0);
 }
 
-// Normalised descriptor + gradients of 8 channels of one observation, all lanes of the
-// observation's lane group cooperating.  LPO = lanes per observation (C / 8).
-template <typename ST, int LPO, bool WITH_JAC, bool FLOAT_SIMD>
-__device__ __forceinline__ void interp8(const ST* __restrict__ patch, int H, int W, int C, int sub,
-                                        double u, double v, bool l2_normalize, double f[8],
-                                        double fr[8], double fc[8], double* frc = nullptr) {
-  // frc (optional, WITH_JAC only): the cross derivative d2f / dr dc -- the derivative output of the vertical spline over
-  // the row derivatives; the reference leaves it un-normalised (interpolation.h:642-666)
-  // BiCubicInterpolator::EvaluateSIMD: r = v (row), c = u (column)
+// Interpolated value + gradients of the 8 channels chan0 .. chan0 + 7 of one patch at (u, v), NOT normalised:
+// BiCubicInterpolator::EvaluateSIMD (interpolation.h:177-218), r = v (row), c = u (column).
+// frc (optional, WITH_JAC only): the cross derivative d2f / dr dc -- the derivative output of the vertical spline over
+// the row derivatives; the reference leaves it un-normalised (interpolation.h:642-666)
+template <typename ST, bool WITH_JAC, bool FLOAT_SIMD>
+__device__ __forceinline__ void interp8_raw(const ST* __restrict__ patch, int H, int W, int C, int chan0,
+                                            double u, double v, double f[8], double fr[8], double fc[8],
+                                            double* frc = nullptr) {
   const double rf = floor(v), cf = floor(u);
   const int row = texel_index(rf, H), col = texel_index(cf, W);
   const double dy = v - rf, dx = u - cf;
@@ -86,7 +85,7 @@ __device__ __forceinline__ void interp8(const ST* __restrict__ patch, int H, int
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tx[j][i].load(patch + (size_t)(ro[j] + co[i]) * C + sub * 8);
+    for (int i = 0; i < 4; ++i) tx[j][i].load(patch + (size_t)(ro[j] + co[i]) * C + chan0);
 
   typedef typename Texel8<ST>::work_t HT;  // horizontal-pass arithmetic type
   HT h[4][8], hd[4][8];
@@ -144,6 +143,15 @@ __device__ __forceinline__ void interp8(const ST* __restrict__ patch, int H, int
       f[ch] = ff; fr[ch] = dd; fc[ch] = cc;
     }
   }
+}
+
+// Normalised descriptor + gradients of 8 channels of one observation, all lanes of the
+// observation's lane group cooperating.  LPO = lanes per observation (C / 8).
+template <typename ST, int LPO, bool WITH_JAC, bool FLOAT_SIMD>
+__device__ __forceinline__ void interp8(const ST* __restrict__ patch, int H, int W, int C, int sub,
+                                        double u, double v, bool l2_normalize, double f[8],
+                                        double fr[8], double fc[8], double* frc = nullptr) {
+  interp8_raw<ST, WITH_JAC, FLOAT_SIMD>(patch, H, W, C, sub * 8, u, v, f, fr, fc, frc);
   // PixelInterpolator::Evaluate L2 normalisation + chain rule, interpolation.h:648-666
   if (l2_normalize) {
     double ss = 0.0;

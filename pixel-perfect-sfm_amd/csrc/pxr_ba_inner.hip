@@ -9,13 +9,11 @@
 // function / gradient / parameter tolerance 1e-6 / 1e-10 / 1e-8, initial radius 1e4, Jacobi
 // scaling, <= 5 consecutive invalid steps).
 //
-// Mapping: one wave per point, its rows of C/8 lanes (four at C = 128, eight at C = 64) evaluate that many
-// observations at a time with
-// the same interpolation core as the fused BA kernel; the per-observation 2x2 / 2-vector blocks
-// are folded with d(x,y)/dX into the point's 3x3 normal matrix and reduced across the rows with
-// two shuffles.  The whole nested LM runs in registers; consecutive evaluations re-read the same
-// 4 KiB stencils from L2.  The kernel also returns the cost at the (unrefined) candidate, so the
-// outer loop needs no separate evaluation for Ceres' inner-iteration bookkeeping.
+// Two mappings.  fp16 / fp32 feature patches (C = 64, 128): k_inner_packed -- 16 observations per wavefront trip, four
+// lanes each, the points of a wavefront in lockstep (described at the kernel).  fp64 storage and cost maps (C = 1, 3):
+// k_inner_points -- one point per wavefront (eight for cost maps), an observation per row of C / 8 lanes, the whole
+// nested LM in registers.  Both return the cost at the (unrefined) candidate, so the outer loop needs no separate
+// evaluation for Ceres' inner-iteration bookkeeping.
 #include <hip/hip_runtime.h>
 
 #include "pxr_device.h"
@@ -273,14 +271,7 @@ __device__ __forceinline__ void inner_points_body(const InnerArgs& a, double (*s
   if (lane == 0) { a.xyz_out[3 * p] = X[0]; a.xyz_out[3 * p + 1] = X[1]; a.xyz_out[3 * p + 2] = X[2]; }
 }
 
-// Two entry points over the same body: the fp16 / fp32 instantiations are capped at 256 VGPRs (two
-// wavefronts per SIMD; unconstrained they take ~330 and run one), the fp64-storage ones keep the
-// compiler's budget (capped they would spill several hundred registers).
-template <typename ST, int C, bool FS>
-__global__ __launch_bounds__(64 * InnerShape<C>::WPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_inner_points_occ2(const InnerArgs a) {
-  __shared__ double sh_obs[InnerShape<C>::WPB * InnerShape<C>::PPW][InnerShape<C>::MAXO][26];   // per point: q(4) t(3) k(12) sx sy corner(2) model patch
-  inner_points_body<ST, C, FS>(a, sh_obs);
-}
+// fp64 storage and the cost maps' few channels (the fp16 / fp32 feature patches take k_inner_packed below)
 template <typename ST, int C, bool FS>
 __global__ __launch_bounds__(64 * InnerShape<C>::WPB) void k_inner_points(const InnerArgs a) {
   __shared__ double sh_obs[InnerShape<C>::WPB * InnerShape<C>::PPW][InnerShape<C>::MAXO][26];
@@ -304,17 +295,36 @@ __global__ __launch_bounds__(64 * InnerShape<C>::WPB) void k_inner_points(const 
 //   Jc = (fc - f (f.fc) / N^2) / N   Jc.Jc = (fc.fc - (f.fc)^2 / N^2) / N^2   Jc.r = -(fc.d - (f.d)(f.fc) / N^2) / N
 // -- the same quantities as PixelInterpolator's normalise-then-subtract (interpolation.h:648-666) up to rounding
 // (1e-13 relative on r.r at the residual sizes of a converging problem; r.r is clamped at 0).
-constexpr int IP_SLOTS = 16, IP_MAXPTS = 4, IP_MAXQ = 32, IP_OBS = 26;
+constexpr int IP_MAXPTS = 4, IP_MAXQ = 32, IP_OBS = 30;
 
-template <int C>
+// Nested-LM state of one point.  It lives in LDS: the owner lane works on it for a few hundred cycles per round, and as
+// registers it was what the compiler spilled to scratch around every evaluation (101 VGPRs; the reloads sat on the round's
+// critical path).
+struct InnerOwner {
+  double X[3], Xc[3], cost, H[6], g[3], sc[3], radius, decrease_factor, diag[3], mcc, r2;
+  int invalid, it, reuse_diag, live;
+};
+
+template <int C, int IP_SLOTS>
 struct PackedLds {
   double ref[IP_MAXPTS][C];          // reference descriptors of the wavefront's points
-  double obs[IP_MAXQ][IP_OBS];       // per observation: q(4) t(3) k(12) sx sy corner(2) model patch
+  double obs[IP_MAXQ][IP_OBS];       // per observation: R (9, row-major) t (3) k (12) sx sy corner (2) model patch
   double res[IP_SLOTS][10];          // per slot of the current trip: cost, H (6), g (3)
-  double Xc[IP_MAXPTS][4];           // candidate position per point; [3] = d.d of its reference
-  double cost0[IP_MAXPTS];
-  int live[IP_MAXPTS];               // point still iterating (or first round): its slots are evaluated
+  InnerOwner own[IP_MAXPTS];
 };
+
+// 1 / sqrt(x) for finite x > 0 (v_rsq_f64 + one second-order correction); x <= 0 gives NaN / inf, which the callers test for
+__device__ __forceinline__ double inner_rsqrt(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(x * y0), y0, 1.0);
+  return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
+// 1 / x (v_rcp_f64 + two Newton steps, < 1 ulp for normal x): the IEEE division sequence is three times as long a chain
+__device__ __forceinline__ double inner_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return fma(fma(-x, y, 1.0), y, y);
+}
 
 __device__ __forceinline__ double quad_sum(double v) {
   v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
@@ -322,12 +332,49 @@ __device__ __forceinline__ double quad_sum(double v) {
   return v;
 }
 
-template <typename ST, int C, bool FS>
+// rho(s) = {rho, rho', rho''} like loss_eval (pxr_device.h) with reciprocals for the divisions
+__device__ __forceinline__ void inner_loss(int type, double a, double s, double rho[3]) {
+  const double b = a * a;
+  const double tiny = 2.2250738585072014e-308;
+  switch (type) {
+    case PXR_LOSS_CAUCHY: {
+      const double c = inner_rcp(b), sum = 1.0 + s * c, inv = inner_rcp(sum);
+      rho[0] = b * log(sum); rho[1] = fmax(tiny, inv); rho[2] = -c * (inv * inv);
+      break;
+    }
+    case PXR_LOSS_HUBER:
+      if (s > b) {
+        const double ir = inner_rsqrt(s), r = s * ir;
+        rho[0] = 2.0 * a * r - b; rho[1] = fmax(tiny, a * ir); rho[2] = -rho[1] * (0.5 * ir * ir);
+      } else {
+        rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+      }
+      break;
+    case PXR_LOSS_SOFTL1: {
+      const double c = inner_rcp(b), sum = 1.0 + s * c, it = inner_rsqrt(sum), tmp = sum * it;
+      rho[0] = 2.0 * b * (tmp - 1.0); rho[1] = fmax(tiny, it);
+      rho[2] = -(c * rho[1]) * (0.5 * it * it);
+      break;
+    }
+    default:
+      rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+  }
+}
+
+template <typename ST, int C, bool FS, int LPO>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_inner_packed(const InnerArgs a, const int ppw) {
-  static_assert(C == 128 || C == 64, "four lanes per observation, C / 32 chunks of 8 channels per lane");
-  constexpr int NCHUNK = C / 32;
-  __shared__ PackedLds<C> lds;
-  const int lane = threadIdx.x, sidx = lane >> 2, sub = lane & 3;
+  static_assert(C == 128 || C == 64, "LPO lanes per observation, C / (8 LPO) chunks of 8 channels per lane");
+  constexpr int NCHUNK = C / (8 * LPO), IP_SLOTS = 64 / LPO;
+  __shared__ PackedLds<C, IP_SLOTS> lds;
+  const int lane = threadIdx.x, sidx = lane / LPO, sub = lane % LPO;
+#ifdef PXR_INNER_PROFILE   // tools/inner_phase_probe.sh: two wavefronts print how their shader-clock cycles split over the phases
+  long long pf_t = __builtin_amdgcn_s_memtime(), pf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int pf_rounds = 0;
+#define PF_MARK(k) do { const long long n_ = __builtin_amdgcn_s_memtime(); pf_acc[k] += n_ - pf_t; pf_t = n_; } while (0)
+#else
+#define PF_MARK(k) do { } while (0)
+#endif
+  auto lanes_sum = [](double v) { return LPO == 4 ? quad_sum(v) : row8_sum(v); };
   const int64_t P0 = (int64_t)blockIdx.x * ppw;
   const int npts = (int)((a.v.n_points - P0) < (int64_t)ppw ? (a.v.n_points - P0) : (int64_t)ppw);
   // the observations of points P0 .. P0 + npts - 1 are entries [o0, o0 + L) of pt_obs; point j starts at st_j
@@ -339,13 +386,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const bool owner = lane < npts;
   const int64_t myp = P0 + (owner ? lane : 0);
   const int my_b = owner ? (int)(a.pt_ptr[myp] - o0) : 0, my_e = owner ? (int)(a.pt_ptr[myp + 1] - o0) : 0;
-  bool active = owner && my_e > my_b && a.pt_var[myp] != 0;
-  double X[3] = {a.v.d_xyz[3 * myp], a.v.d_xyz[3 * myp + 1], a.v.d_xyz[3 * myp + 2]};
+  const bool variable = owner && my_e > my_b && a.pt_var[myp] != 0;
+  bool active = variable, first = true;
   const ST* arena = reinterpret_cast<const ST*>(a.arena);
   const size_t patch_elems = (size_t)a.H * a.W * C;
   const bool l2 = a.l2_normalize != 0;
 
-  // ---- staging: references, observation records ----
+  // ---- staging: references, observation records (rotation matrix of the unit quaternion instead of the quaternion) ----
   for (int j = 0; j < npts; ++j)
     for (int ch = lane; ch < C; ch += 64) lds.ref[j][ch] = a.v.d_refs ? a.v.d_refs[(size_t)(P0 + j) * C + ch] : 0.0;
   for (int q = sidx; q < L && q < IP_MAXQ; q += IP_SLOTS) {
@@ -354,152 +401,168 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int img = a.v.d_obs_image[i], cam = a.v.d_image_camera[img];
     const int64_t pi = a.v.d_obs_patch[i];
     if (sub == 0) {
+      double R[9];
+      quat_to_rotation(a.v.d_qvec + 4 * (size_t)img, R);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ob[j] = a.v.d_qvec[4 * (size_t)img + j];
+      for (int m = 0; m < 9; ++m) ob[m] = R[m];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) ob[4 + j] = a.v.d_tvec[3 * (size_t)img + j];
+      for (int m = 0; m < 3; ++m) ob[9 + m] = a.v.d_tvec[3 * (size_t)img + m];
     } else if (sub == 1) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) ob[7 + j] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + j];
+      for (int m = 0; m < 6; ++m) ob[12 + m] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + m];
     } else if (sub == 2) {
 #pragma unroll
-      for (int j = 6; j < PXR_KPAD; ++j) ob[7 + j] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + j];
-    } else {
-      ob[19] = a.scales[2 * pi]; ob[20] = a.scales[2 * pi + 1];
-      ob[21] = (double)a.corners[2 * pi]; ob[22] = (double)a.corners[2 * pi + 1];
-      ob[23] = (double)a.v.d_cam_model[cam]; ob[24] = (double)pi;
+      for (int m = 6; m < PXR_KPAD; ++m) ob[12 + m] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + m];
+    } else if (sub == 3) {
+      ob[24] = a.scales[2 * pi]; ob[25] = a.scales[2 * pi + 1];
+      ob[26] = (double)a.corners[2 * pi]; ob[27] = (double)a.corners[2 * pi + 1];
+      ob[28] = (double)a.v.d_cam_model[cam]; ob[29] = (double)pi;
     }
   }
-  __syncthreads();
   if (owner) {
-    double r2 = 0.0;
-    if (l2)
-      for (int ch = 0; ch < C; ++ch) r2 = fma(lds.ref[lane][ch], lds.ref[lane][ch], r2);
-    lds.Xc[lane][3] = r2;
+    InnerOwner& S = lds.own[lane];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { S.X[m] = a.v.d_xyz[3 * myp + m]; S.Xc[m] = S.X[m]; }
+    S.live = 1; S.radius = 1e4; S.decrease_factor = 2.0; S.invalid = 0; S.it = 0; S.reuse_diag = 0; S.mcc = 0.0;
   }
+  __syncthreads();
+  for (int j = 0; j < npts; ++j) {   // d.d of every reference, all lanes
+    double r2 = 0.0;
+    for (int ch = lane; ch < C; ch += 64) r2 = fma(lds.ref[j][ch], lds.ref[j][ch], r2);
+    r2 = rows_sum<16>(row16_sum(r2));
+    if (lane == 0) lds.own[j].r2 = r2;
+  }
+  PF_MARK(0);
 
   // ---- the nested LMs of the wavefront's points, one evaluation (all points) per round ----
-  double cost = 0.0, H[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, sc[3] = {1, 1, 1};
-  double radius = 1e4, decrease_factor = 2.0, diag[3] = {0, 0, 0}, mcc = 0.0;
-  double Xc[3] = {X[0], X[1], X[2]};
-  int invalid = 0, it = 0;
-  bool reuse_diag = false, first = true;
   while (true) {
-    // a point that has finished keeps its slots but they skip the evaluation: the wavefront's rounds are those of its slowest
-    // point, the texel traffic (the kernel moves ~4 KB per observation and round through an L2 it does not fit) only that of
-    // the points still iterating
-    if (owner) { lds.Xc[lane][0] = Xc[0]; lds.Xc[lane][1] = Xc[1]; lds.Xc[lane][2] = Xc[2]; lds.live[lane] = (first || active) ? 1 : 0; }
     __syncthreads();
     // -- evaluation: cost, H (xx xy xz yy yz zz), g of every point at its candidate --
+    // A point that has finished keeps its slots but they skip the evaluation: the wavefront's rounds are those of its slowest
+    // point, the texel traffic (~4 KB per observation and round through an L2 it does not fit) only that of the points
+    // still iterating.
     double cand = 0.0, Hc[6] = {0, 0, 0, 0, 0, 0}, gc[3] = {0, 0, 0};
     for (int base = 0; base < L; base += IP_SLOTS) {
       const int q = base + sidx;
-      const bool valid = q < L;
-      const int qc = valid ? q : L - 1;
+      const int qc = q < L ? q : L - 1;
       const int j = (qc >= st1) + (qc >= st2) + (qc >= st3);
-      if (valid && lds.live[j]) {
-      double qv[4], t[3], k[PXR_KPAD], sx, sy, cx, cy;
-      int model;
-      int64_t pi;
-      if (qc < IP_MAXQ) {
-        const double* ob = lds.obs[qc];
+      if (q < L && lds.own[j].live) {
+        double R[9], t[3], k[PXR_KPAD], sx, sy, cx, cy;
+        int model;
+        int64_t pi;
+        if (q < IP_MAXQ) {
+          const double* ob = lds.obs[q];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) qv[m] = ob[m];
+          for (int m = 0; m < 9; ++m) R[m] = ob[m];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) t[m] = ob[4 + m];
+          for (int m = 0; m < 3; ++m) t[m] = ob[9 + m];
 #pragma unroll
-        for (int m = 0; m < PXR_KPAD; ++m) k[m] = ob[7 + m];
-        sx = ob[19]; sy = ob[20]; cx = ob[21]; cy = ob[22];
-        model = (int)ob[23]; pi = (int64_t)ob[24];
-      } else {   // long tracks: the tail of the list comes from global memory
-        const int64_t i = a.pt_obs[o0 + qc];
-        const int img = a.v.d_obs_image[i], cam = a.v.d_image_camera[img];
-        pi = a.v.d_obs_patch[i];
+          for (int m = 0; m < PXR_KPAD; ++m) k[m] = ob[12 + m];
+          sx = ob[24]; sy = ob[25]; cx = ob[26]; cy = ob[27];
+          model = (int)ob[28]; pi = (int64_t)ob[29];
+        } else {   // long tracks: the tail of the list comes from global memory
+          const int64_t i = a.pt_obs[o0 + q];
+          const int img = a.v.d_obs_image[i], cam = a.v.d_image_camera[img];
+          pi = a.v.d_obs_patch[i];
+          quat_to_rotation(a.v.d_qvec + 4 * (size_t)img, R);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) qv[m] = a.v.d_qvec[4 * (size_t)img + m];
+          for (int m = 0; m < 3; ++m) t[m] = a.v.d_tvec[3 * (size_t)img + m];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) t[m] = a.v.d_tvec[3 * (size_t)img + m];
+          for (int m = 0; m < PXR_KPAD; ++m) k[m] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + m];
+          model = a.v.d_cam_model[cam];
+          sx = a.scales[2 * pi]; sy = a.scales[2 * pi + 1];
+          cx = (double)a.corners[2 * pi]; cy = (double)a.corners[2 * pi + 1];
+        }
+        // WorldToPixel (base/src/projection.h:60-75) and d(x,y)/dX = d(x,y)/d(u,v) d(u,v)/dp R
+        const double X0 = lds.own[j].Xc[0], X1 = lds.own[j].Xc[1], X2 = lds.own[j].Xc[2];
+        const double p0 = fma(R[0], X0, fma(R[1], X1, fma(R[2], X2, t[0])));
+        const double p1 = fma(R[3], X0, fma(R[4], X1, fma(R[5], X2, t[1])));
+        const double p2 = fma(R[6], X0, fma(R[7], X1, fma(R[8], X2, t[2])));
+        const double iz = inner_rcp(p2), un = p0 * iz, vn = p1 * iz;
+        double x, y, Juv[2][2], Pk[2][PXR_KPAD];
+        camera_model_jac(model, k, un, vn, x, y, Juv, Pk);
+        double PX[2][3];
 #pragma unroll
-        for (int m = 0; m < PXR_KPAD; ++m) k[m] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + m];
-        model = a.v.d_cam_model[cam];
-        sx = a.scales[2 * pi]; sy = a.scales[2 * pi + 1];
-        cx = (double)a.corners[2 * pi]; cy = (double)a.corners[2 * pi + 1];
-      }
-      const double Xs[3] = {lds.Xc[j][0], lds.Xc[j][1], lds.Xc[j][2]};
-      double x, y, A[2][3], Pq[2][4], PX[2][3], Pk[2][PXR_KPAD];
-      world_to_pixel_jac(model, k, qv, t, Xs, x, y, A, Pq, PX, Pk);
-      const double u = x * sx - 0.5 - cx, v = y * sy - 0.5 - cy;   // FeaturePatch::ToPixelCoordinates (featurepatch.h:250-255)
-      const ST* patch = arena + (size_t)pi * patch_elems;
-      // sums over this lane's channels: g = f (normalised mode) or f - d
-      double Sgg = 0, Sgc = 0, Sgr = 0, Scc = 0, Scr = 0, Srr = 0, Sfd = 0, Scd = 0, Srd = 0;
+        for (int r = 0; r < 2; ++r) {
+          const double A0 = Juv[r][0] * iz, A1 = Juv[r][1] * iz, A2 = -(Juv[r][0] * un + Juv[r][1] * vn) * iz;
+#pragma unroll
+          for (int m = 0; m < 3; ++m) PX[r][m] = A0 * R[m] + A1 * R[3 + m] + A2 * R[6 + m];
+        }
+        const double u = x * sx - 0.5 - cx, v = y * sy - 0.5 - cy;   // FeaturePatch::ToPixelCoordinates (featurepatch.h:250-255)
+        const ST* patch = arena + (size_t)pi * patch_elems;
+        PF_MARK(1);
+        // sums over this lane's channels: g = f (normalised mode) or f - d
+        double Sgg = 0, Sgc = 0, Sgr = 0, Scc = 0, Scr = 0, Srr = 0, Sfd = 0, Scd = 0, Srd = 0;
 #pragma unroll 1
-      for (int c = 0; c < NCHUNK; ++c) {
-        const int chan0 = (c * 4 + sub) * 8;
-        double f[8], fr[8], fc[8];
-        interp8_raw<ST, true, FS>(patch, a.H, a.W, C, chan0, u, v, f, fr, fc);
-        const double* rp = lds.ref[j] + chan0;
-        if (l2) {
+        for (int c = 0; c < NCHUNK; ++c) {
+          const int chan0 = (c * LPO + sub) * 8;
+          double f[8], fr[8], fc[8];
+          interp8_raw<ST, true, FS>(patch, a.H, a.W, C, chan0, u, v, f, fr, fc);
+          const double* rp = lds.ref[j] + chan0;
+          if (l2) {
 #pragma unroll
-          for (int ch = 0; ch < 8; ++ch) {
-            const double d = rp[ch];
-            Sgg = fma(f[ch], f[ch], Sgg); Sgc = fma(f[ch], fc[ch], Sgc); Sgr = fma(f[ch], fr[ch], Sgr);
-            Scc = fma(fc[ch], fc[ch], Scc); Scr = fma(fc[ch], fr[ch], Scr); Srr = fma(fr[ch], fr[ch], Srr);
-            Sfd = fma(f[ch], d, Sfd); Scd = fma(fc[ch], d, Scd); Srd = fma(fr[ch], d, Srd);
-          }
-        } else {
+            for (int ch = 0; ch < 8; ++ch) {
+              const double d = rp[ch];
+              Sgg = fma(f[ch], f[ch], Sgg); Sgc = fma(f[ch], fc[ch], Sgc); Sgr = fma(f[ch], fr[ch], Sgr);
+              Scc = fma(fc[ch], fc[ch], Scc); Scr = fma(fc[ch], fr[ch], Scr); Srr = fma(fr[ch], fr[ch], Srr);
+              Sfd = fma(f[ch], d, Sfd); Scd = fma(fc[ch], d, Scd); Srd = fma(fr[ch], d, Srd);
+            }
+          } else {
 #pragma unroll
-          for (int ch = 0; ch < 8; ++ch) {
-            const double r = f[ch] - rp[ch];
-            Sgg = fma(r, r, Sgg); Sgc = fma(r, fc[ch], Sgc); Sgr = fma(r, fr[ch], Sgr);
-            Scc = fma(fc[ch], fc[ch], Scc); Scr = fma(fc[ch], fr[ch], Scr); Srr = fma(fr[ch], fr[ch], Srr);
+            for (int ch = 0; ch < 8; ++ch) {
+              const double r = f[ch] - rp[ch];
+              Sgg = fma(r, r, Sgg); Sgc = fma(r, fc[ch], Sgc); Sgr = fma(r, fr[ch], Sgr);
+              Scc = fma(fc[ch], fc[ch], Scc); Scr = fma(fc[ch], fr[ch], Scr); Srr = fma(fr[ch], fr[ch], Srr);
+            }
           }
         }
-      }
-      Sgg = quad_sum(Sgg); Sgc = quad_sum(Sgc); Sgr = quad_sum(Sgr);
-      Scc = quad_sum(Scc); Scr = quad_sum(Scr); Srr = quad_sum(Srr);
-      double s, gcc, gcr, grr, bc, br;
-      if (l2) {
-        Sfd = quad_sum(Sfd); Scd = quad_sum(Scd); Srd = quad_sum(Srd);
-        const double ninv = 1.0 / sqrt(Sgg), n2inv = ninv * ninv;
-        const double pc = Sgc * n2inv, pr = Sgr * n2inv;
-        s = fmax(0.0, 1.0 - 2.0 * Sfd * ninv + lds.Xc[j][3]);
-        gcc = (Scc - Sgc * pc) * n2inv; gcr = (Scr - Sgc * pr) * n2inv; grr = (Srr - Sgr * pr) * n2inv;
-        bc = -(Scd - Sfd * pc) * ninv; br = -(Srd - Sfd * pr) * ninv;
-      } else {
-        s = Sgg; gcc = Scc; gcr = Scr; grr = Srr; bc = Sgc; br = Sgr;
-      }
-      double rho[3];
-      loss_eval(a.loss.type, a.loss.a, 1.0, s, rho);
-      double cq = 0.5 * rho[0];
-      // check_bounds: without a reference descriptor a projection outside its patch fails the evaluation
-      // (feature_reference.h:128-130) -> non-finite cost -> the step is rejected
-      if (a.check_bounds && !a.v.d_refs && !(u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H)) cq = __builtin_nan("");
-      gcc *= sx * sx; gcr *= sx * sy; grr *= sy * sy; bc *= sx; br *= sy;
-      double kappa = 0.0;
-      if (s != 0.0 && rho[2] > 0.0) {
-        const double D = 1.0 + 2.0 * s * rho[2] / rho[1];
-        const double alpha = 1.0 - sqrt(D);
-        kappa = (2.0 * alpha - alpha * alpha) / s;
-      }
-      const double w8 = rho[1];
-      const double m00 = w8 * (gcc - kappa * bc * bc), m01 = w8 * (gcr - kappa * bc * br), m11 = w8 * (grr - kappa * br * br);
-      const double b0 = w8 * bc, b1 = w8 * br;
-      double me0[3], me1[3];
+        PF_MARK(2);
+        Sgg = lanes_sum(Sgg); Sgc = lanes_sum(Sgc); Sgr = lanes_sum(Sgr);
+        Scc = lanes_sum(Scc); Scr = lanes_sum(Scr); Srr = lanes_sum(Srr);
+        double s, gcc, gcr, grr, bc, br;
+        if (l2) {
+          Sfd = lanes_sum(Sfd); Scd = lanes_sum(Scd); Srd = lanes_sum(Srd);
+          const double ninv = inner_rsqrt(Sgg), n2inv = ninv * ninv;
+          const double pc = Sgc * n2inv, pr = Sgr * n2inv;
+          s = fmax(0.0, 1.0 - 2.0 * Sfd * ninv + lds.own[j].r2);
+          gcc = (Scc - Sgc * pc) * n2inv; gcr = (Scr - Sgc * pr) * n2inv; grr = (Srr - Sgr * pr) * n2inv;
+          bc = -(Scd - Sfd * pc) * ninv; br = -(Srd - Sfd * pr) * ninv;
+        } else {
+          s = Sgg; gcc = Scc; gcr = Scr; grr = Srr; bc = Sgc; br = Sgr;
+        }
+        double rho[3];
+        inner_loss(a.loss.type, a.loss.a, s, rho);
+        double cq = 0.5 * rho[0];
+        // check_bounds: without a reference descriptor a projection outside its patch fails the evaluation
+        // (feature_reference.h:128-130) -> non-finite cost -> the step is rejected
+        if (a.check_bounds && !a.v.d_refs && !(u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H)) cq = __builtin_nan("");
+        gcc *= sx * sx; gcr *= sx * sy; grr *= sy * sy; bc *= sx; br *= sy;
+        double kappa = 0.0;   // Ceres' corrector (corrector.cc): alpha = 1 - sqrt(1 + 2 s rho'' / rho')
+        if (s != 0.0 && rho[2] > 0.0) {
+          const double D = 1.0 + 2.0 * s * rho[2] * inner_rcp(rho[1]);
+          const double alpha = 1.0 - sqrt(D);
+          kappa = (2.0 * alpha - alpha * alpha) * inner_rcp(s);
+        }
+        const double w8 = rho[1];
+        const double m00 = w8 * (gcc - kappa * bc * bc), m01 = w8 * (gcr - kappa * bc * br), m11 = w8 * (grr - kappa * br * br);
+        const double b0 = w8 * bc, b1 = w8 * br;
+        double me0[3], me1[3];
 #pragma unroll
-      for (int m = 0; m < 3; ++m) { me0[m] = m00 * PX[0][m] + m01 * PX[1][m]; me1[m] = m01 * PX[0][m] + m11 * PX[1][m]; }
-      if (sub == 0) {
-        double* rs = lds.res[sidx];
-        rs[0] = cq;
-        rs[1] = PX[0][0] * me0[0] + PX[1][0] * me1[0];
-        rs[2] = PX[0][0] * me0[1] + PX[1][0] * me1[1];
-        rs[3] = PX[0][0] * me0[2] + PX[1][0] * me1[2];
-        rs[4] = PX[0][1] * me0[1] + PX[1][1] * me1[1];
-        rs[5] = PX[0][1] * me0[2] + PX[1][1] * me1[2];
-        rs[6] = PX[0][2] * me0[2] + PX[1][2] * me1[2];
+        for (int m = 0; m < 3; ++m) { me0[m] = m00 * PX[0][m] + m01 * PX[1][m]; me1[m] = m01 * PX[0][m] + m11 * PX[1][m]; }
+        if (sub == 0) {
+          double* rs = lds.res[sidx];
+          rs[0] = cq;
+          rs[1] = PX[0][0] * me0[0] + PX[1][0] * me1[0];
+          rs[2] = PX[0][0] * me0[1] + PX[1][0] * me1[1];
+          rs[3] = PX[0][0] * me0[2] + PX[1][0] * me1[2];
+          rs[4] = PX[0][1] * me0[1] + PX[1][1] * me1[1];
+          rs[5] = PX[0][1] * me0[2] + PX[1][1] * me1[2];
+          rs[6] = PX[0][2] * me0[2] + PX[1][2] * me1[2];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) rs[7 + m] = PX[0][m] * b0 + PX[1][m] * b1;
+          for (int m = 0; m < 3; ++m) rs[7 + m] = PX[0][m] * b0 + PX[1][m] * b1;
+        }
       }
-      }
+      PF_MARK(3);
       __syncthreads();
       {   // owners: the slots of this trip that belong to their point, in track order
         const int lo = (my_b > base ? my_b : base) - base, hi = (my_e < base + IP_SLOTS ? my_e : base + IP_SLOTS) - base;
@@ -512,98 +575,114 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           for (int m = 0; m < 3; ++m) gc[m] += rs[7 + m];
         }
       }
-      __syncthreads();
+      if (base + IP_SLOTS < L) __syncthreads();   // the next trip overwrites res
     }
-    // -- owners: Ceres' trust-region bookkeeping (same loop as k_inner_points above) --
-    if (first) {
-      first = false;
-      cost = cand;
-#pragma unroll
-      for (int m = 0; m < 6; ++m) H[m] = Hc[m];
-#pragma unroll
-      for (int m = 0; m < 3; ++m) g[m] = gc[m];
-      if (owner) lds.cost0[lane] = my_e > my_b ? cost : 0.0;
-      __syncthreads();
-      if (lane == 0) {
-        double c0 = 0.0;
-        for (int j = 0; j < npts; ++j) c0 += lds.cost0[j];
-        atomicAdd(a.cost_before, c0);
-      }
-      if (active) {
-        const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
-        if (gmax <= 1e-10) active = false;
-        sc[0] = 1.0 / (1.0 + sqrt(H[0])); sc[1] = 1.0 / (1.0 + sqrt(H[3])); sc[2] = 1.0 / (1.0 + sqrt(H[5]));
-        H[0] *= sc[0] * sc[0]; H[1] *= sc[0] * sc[1]; H[2] *= sc[0] * sc[2];
-        H[3] *= sc[1] * sc[1]; H[4] *= sc[1] * sc[2]; H[5] *= sc[2] * sc[2];
-        g[0] *= sc[0]; g[1] *= sc[1]; g[2] *= sc[2];
-      }
-    } else if (active) {
-      const double s2 = (Xc[0] - X[0]) * (Xc[0] - X[0]) + (Xc[1] - X[1]) * (Xc[1] - X[1]) + (Xc[2] - X[2]) * (Xc[2] - X[2]);
-      const double x2 = X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
-      const double cost_change = cost - cand;
-      if (sqrt(s2) <= 1e-8 * (sqrt(x2) + 1e-8)) active = false;
-      else if (fabs(cost_change) <= 1e-6 * cost) active = false;
-      else {
-        const double rel = cost_change / mcc;
-        if (rel > 1e-3) {
-          X[0] = Xc[0]; X[1] = Xc[1]; X[2] = Xc[2];
-          cost = cand;
-#pragma unroll
-          for (int m = 0; m < 6; ++m) H[m] = Hc[m];
-#pragma unroll
-          for (int m = 0; m < 3; ++m) g[m] = gc[m];
-          const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
-          H[0] *= sc[0] * sc[0]; H[1] *= sc[0] * sc[1]; H[2] *= sc[0] * sc[2];
-          H[3] *= sc[1] * sc[1]; H[4] *= sc[1] * sc[2]; H[5] *= sc[2] * sc[2];
-          g[0] *= sc[0]; g[1] *= sc[1]; g[2] *= sc[2];
-          const double tmp = 2.0 * rel - 1.0;
-          radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - tmp * tmp * tmp));
-          decrease_factor = 2.0; reuse_diag = false;
+    PF_MARK(4);
+    // -- owners: Ceres' trust-region bookkeeping (same loop as k_inner_points above) on the state in LDS --
+    if (owner) {
+      InnerOwner& S = lds.own[lane];
+      if (first) {
+        S.cost = cand;
+        if (my_e > my_b) atomicAdd(a.cost_before, cand);
+        if (active) {
+          const double gmax = fmax(fabs(gc[0]), fmax(fabs(gc[1]), fabs(gc[2])));
           if (gmax <= 1e-10) active = false;
-        } else {
-          radius /= decrease_factor; decrease_factor *= 2.0; reuse_diag = true;
+          const double s0 = 1.0 / (1.0 + sqrt(Hc[0])), s1 = 1.0 / (1.0 + sqrt(Hc[3])), s2 = 1.0 / (1.0 + sqrt(Hc[5]));
+          S.sc[0] = s0; S.sc[1] = s1; S.sc[2] = s2;
+          S.H[0] = Hc[0] * (s0 * s0); S.H[1] = Hc[1] * (s0 * s1); S.H[2] = Hc[2] * (s0 * s2);
+          S.H[3] = Hc[3] * (s1 * s1); S.H[4] = Hc[4] * (s1 * s2); S.H[5] = Hc[5] * (s2 * s2);
+          S.g[0] = gc[0] * s0; S.g[1] = gc[1] * s1; S.g[2] = gc[2] * s2;
+        }
+      } else if (active) {
+        const double X0 = S.X[0], X1 = S.X[1], X2 = S.X[2], C0 = S.Xc[0], C1 = S.Xc[1], C2 = S.Xc[2];
+        const double s2 = (C0 - X0) * (C0 - X0) + (C1 - X1) * (C1 - X1) + (C2 - X2) * (C2 - X2);
+        const double x2 = X0 * X0 + X1 * X1 + X2 * X2;
+        const double cost = S.cost, cost_change = cost - cand;
+        if (sqrt(s2) <= 1e-8 * (sqrt(x2) + 1e-8)) active = false;
+        else if (fabs(cost_change) <= 1e-6 * cost) active = false;
+        else {
+          const double rel = cost_change / S.mcc;
+          if (rel > 1e-3) {
+            S.X[0] = C0; S.X[1] = C1; S.X[2] = C2;
+            S.cost = cand;
+            const double s0 = S.sc[0], s1 = S.sc[1], s2c = S.sc[2];
+            const double gmax = fmax(fabs(gc[0]), fmax(fabs(gc[1]), fabs(gc[2])));
+            S.H[0] = Hc[0] * (s0 * s0); S.H[1] = Hc[1] * (s0 * s1); S.H[2] = Hc[2] * (s0 * s2c);
+            S.H[3] = Hc[3] * (s1 * s1); S.H[4] = Hc[4] * (s1 * s2c); S.H[5] = Hc[5] * (s2c * s2c);
+            S.g[0] = gc[0] * s0; S.g[1] = gc[1] * s1; S.g[2] = gc[2] * s2c;
+            const double tmp = 2.0 * rel - 1.0;
+            S.radius = fmin(1e16, S.radius / fmax(1.0 / 3.0, 1.0 - tmp * tmp * tmp));
+            S.decrease_factor = 2.0; S.reuse_diag = 0;
+            if (gmax <= 1e-10) active = false;
+          } else {
+            const double df = S.decrease_factor;
+            S.radius = S.radius / df; S.decrease_factor = df * 2.0; S.reuse_diag = 1;
+          }
         }
       }
+      // the next candidate (steps that fail without an evaluation are retried here, like the `continue` above)
+      if (active) {
+        const double H0 = S.H[0], H1 = S.H[1], H2 = S.H[2], H3 = S.H[3], H4 = S.H[4], H5 = S.H[5];
+        const double g0 = S.g[0], g1 = S.g[1], g2 = S.g[2];
+        double radius = S.radius, d0 = S.diag[0], d1v = S.diag[1], d2v = S.diag[2];
+        int it = S.it, invalid = S.invalid;
+        bool reuse_diag = S.reuse_diag != 0;
+        while (true) {
+          if (it >= 50 || radius < 1e-32) { active = false; break; }
+          ++it;
+          if (!reuse_diag) { d0 = fmin(fmax(H0, 1e-6), 1e32); d1v = fmin(fmax(H3, 1e-6), 1e32); d2v = fmin(fmax(H5, 1e-6), 1e32); }
+          // Cholesky of the damped 3 x 3 with reciprocal pivots: three v_rsq_f64 and one division on the owners' chain instead
+          // of three square roots and ten divisions
+          const double ir = 1.0 / radius;
+          const double a00 = H0 + d0 * ir, a11 = H3 + d1v * ir, a22 = H5 + d2v * ir;
+          bool ok = a00 > 0.0;
+          const double i00 = inner_rsqrt(a00), l10 = H1 * i00, l20 = H2 * i00;
+          const double e1 = a11 - l10 * l10;
+          ok = ok && e1 > 0.0;
+          const double i11 = inner_rsqrt(e1), l21 = (H4 - l20 * l10) * i11;
+          const double e2 = a22 - l20 * l20 - l21 * l21;
+          ok = ok && e2 > 0.0;
+          const double i22 = inner_rsqrt(e2);
+          const double y0 = -g0 * i00, y1 = (-g1 - l10 * y0) * i11, y2 = (-g2 - l20 * y0 - l21 * y1) * i22;
+          const double t2 = y2 * i22, t1 = (y1 - l21 * t2) * i11, t0 = (y0 - l10 * t1 - l20 * t2) * i00;
+          double mcc = 0.0;
+          if (ok) {
+            const double dg = t0 * g0 + t1 * g1 + t2 * g2;
+            const double dHd = t0 * (H0 * t0 + H1 * t1 + H2 * t2) + t1 * (H1 * t0 + H3 * t1 + H4 * t2) + t2 * (H2 * t0 + H4 * t1 + H5 * t2);
+            mcc = -dg - 0.5 * dHd;
+            if (!(mcc > 0.0) || !isfinite(t0) || !isfinite(t1) || !isfinite(t2)) ok = false;
+          }
+          if (!ok) {
+            if (++invalid >= 5) { active = false; break; }
+            radius *= 0.5; reuse_diag = true;
+            continue;
+          }
+          invalid = 0;
+          S.mcc = mcc;
+          S.Xc[0] = S.X[0] + t0 * S.sc[0]; S.Xc[1] = S.X[1] + t1 * S.sc[1]; S.Xc[2] = S.X[2] + t2 * S.sc[2];
+          break;
+        }
+        S.radius = radius; S.diag[0] = d0; S.diag[1] = d1v; S.diag[2] = d2v;
+        S.it = it; S.invalid = invalid; S.reuse_diag = reuse_diag ? 1 : 0;
+      }
+      S.live = active ? 1 : 0;
     }
-    // -- owners: the next candidate (steps that fail without an evaluation are retried here, like the `continue` above) --
-    while (active) {
-      if (it >= 50 || radius < 1e-32) { active = false; break; }
-      ++it;
-      if (!reuse_diag) {
-        diag[0] = fmin(fmax(H[0], 1e-6), 1e32); diag[1] = fmin(fmax(H[3], 1e-6), 1e32); diag[2] = fmin(fmax(H[5], 1e-6), 1e32);
-      }
-      const double a00 = H[0] + diag[0] / radius, a01 = H[1], a02 = H[2], a11 = H[3] + diag[1] / radius, a12 = H[4],
-                   a22 = H[5] + diag[2] / radius;
-      bool ok = a00 > 0.0;
-      const double l00 = sqrt(a00), l10 = a01 / l00, l20 = a02 / l00;
-      const double d1 = a11 - l10 * l10;
-      ok = ok && d1 > 0.0;
-      const double l11 = sqrt(d1), l21 = (a12 - l20 * l10) / l11;
-      const double d2 = a22 - l20 * l20 - l21 * l21;
-      ok = ok && d2 > 0.0;
-      const double l22 = sqrt(d2);
-      const double y0 = -g[0] / l00, y1 = (-g[1] - l10 * y0) / l11, y2 = (-g[2] - l20 * y0 - l21 * y1) / l22;
-      double stp[3];
-      stp[2] = y2 / l22; stp[1] = (y1 - l21 * stp[2]) / l11; stp[0] = (y0 - l10 * stp[1] - l20 * stp[2]) / l00;
-      if (ok) {
-        const double dg = stp[0] * g[0] + stp[1] * g[1] + stp[2] * g[2];
-        const double dHd = stp[0] * (H[0] * stp[0] + H[1] * stp[1] + H[2] * stp[2]) + stp[1] * (H[1] * stp[0] + H[3] * stp[1] + H[4] * stp[2]) +
-                           stp[2] * (H[2] * stp[0] + H[4] * stp[1] + H[5] * stp[2]);
-        mcc = -dg - 0.5 * dHd;
-        if (!(mcc > 0.0) || !isfinite(stp[0]) || !isfinite(stp[1]) || !isfinite(stp[2])) ok = false;
-      }
-      if (!ok) {
-        if (++invalid >= 5) { active = false; break; }
-        radius *= 0.5; reuse_diag = true;
-        continue;
-      }
-      invalid = 0;
-      Xc[0] = X[0] + stp[0] * sc[0]; Xc[1] = X[1] + stp[1] * sc[1]; Xc[2] = X[2] + stp[2] * sc[2];
-      break;
-    }
+    first = false;
+    PF_MARK(5);
+#ifdef PXR_INNER_PROFILE
+    ++pf_rounds;
+#endif
     if (__ballot(active) == 0) break;
   }
-  if (owner && my_e > my_b && a.pt_var[myp] != 0) { a.xyz_out[3 * myp] = X[0]; a.xyz_out[3 * myp + 1] = X[1]; a.xyz_out[3 * myp + 2] = X[2]; }
+#ifdef PXR_INNER_PROFILE
+  if ((blockIdx.x == 1000 || blockIdx.x == 30000) && lane == 0)
+    printf("[inner profile, wavefront %d, shader cycles] rounds %d  staging %lld  projection %lld  chunks %lld  tail %lld  owners' sums %lld  LM %lld\n",
+           (int)blockIdx.x, pf_rounds, pf_acc[0], pf_acc[1], pf_acc[2], pf_acc[3], pf_acc[4], pf_acc[5]);
+#endif
+  if (variable) {
+    const InnerOwner& S = lds.own[lane];
+    a.xyz_out[3 * myp] = S.X[0]; a.xyz_out[3 * myp + 1] = S.X[1]; a.xyz_out[3 * myp + 2] = S.X[2];
+  }
 }
 
 // Enqueue the inner iterations on the candidate parameters `view` (xyz refined in place);
@@ -642,8 +721,8 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     const unsigned pblocks = (unsigned)((view->n_points + ppw - 1) / ppw);
 #define INNER_PACKED(ST, CC)                                                                                              \
   do {                                                                                                                    \
-    if (cfg->use_float_simd) hipLaunchKernelGGL((k_inner_packed<ST, CC, true>), dim3(pblocks), dim3(64), 0, ctx->stream, a, ppw);  \
-    else hipLaunchKernelGGL((k_inner_packed<ST, CC, false>), dim3(pblocks), dim3(64), 0, ctx->stream, a, ppw);           \
+    if (cfg->use_float_simd) hipLaunchKernelGGL((k_inner_packed<ST, CC, true, 4>), dim3(pblocks), dim3(64), 0, ctx->stream, a, ppw);  \
+    else hipLaunchKernelGGL((k_inner_packed<ST, CC, false, 4>), dim3(pblocks), dim3(64), 0, ctx->stream, a, ppw);           \
   } while (0)
     if (arena->dtype == PXR_F16 && arena->C == 128) INNER_PACKED(_Float16, 128);
     else if (arena->dtype == PXR_F16) INNER_PACKED(_Float16, 64);

@@ -171,6 +171,15 @@ __device__ __forceinline__ void rotate_translate(const double* __restrict__ q,
   p[2] = X[2] + w * uv2 + (a * uv1 - b * uv0) + t[2];
 }
 
+// Rotation matrix (row-major) of the NORMALISED quaternion q = (w, x, y, z): the dp/dX block of world_to_pixel_jac.
+__device__ __forceinline__ void quat_to_rotation(const double* __restrict__ q, double R[9]) {
+  const double scale = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double w = q[0] * scale, a = q[1] * scale, b = q[2] * scale, c = q[3] * scale;
+  R[0] = 1.0 - 2.0 * (b * b + c * c); R[1] = 2.0 * (a * b - w * c); R[2] = 2.0 * (a * c + w * b);
+  R[3] = 2.0 * (a * b + w * c); R[4] = 1.0 - 2.0 * (a * a + c * c); R[5] = 2.0 * (b * c - w * a);
+  R[6] = 2.0 * (a * c - w * b); R[7] = 2.0 * (b * c + w * a); R[8] = 1.0 - 2.0 * (a * a + b * b);
+}
+
 // WorldToPixel value (base/src/projection.h:60-75).
 __device__ __forceinline__ bool world_to_pixel(int model, const double* __restrict__ k,
                                                const double* __restrict__ q,
@@ -181,25 +190,9 @@ __device__ __forceinline__ bool world_to_pixel(int model, const double* __restri
   return world_to_image(model, k, p[0] / p[2], p[1] / p[2], x, y);
 }
 
-// WorldToPixel with analytic Jacobians.  A = d(x,y)/dp (2x3); Pq (2x4, ambient, includes
-// the normalisation Jacobian), PX (2x3), Pk (2xK in PXR_KPAD-strided rows).
-__device__ inline bool world_to_pixel_jac(int model, const double* __restrict__ k,
-                                          const double* __restrict__ q,
-                                          const double* __restrict__ t,
-                                          const double* __restrict__ X, double& x, double& y,
-                                          double A[2][3], double Pq[2][4], double PX[2][3],
-                                          double Pk[2][PXR_KPAD]) {
-  const double scale = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  const double w = q[0] * scale, a = q[1] * scale, b = q[2] * scale, c = q[3] * scale;
-  const double cr0 = b * X[2] - c * X[1], cr1 = c * X[0] - a * X[2], cr2 = a * X[1] - b * X[0];
-  const double uv0 = 2.0 * cr0, uv1 = 2.0 * cr1, uv2 = 2.0 * cr2;
-  double p[3];
-  p[0] = X[0] + w * uv0 + (b * uv2 - c * uv1) + t[0];
-  p[1] = X[1] + w * uv1 + (c * uv0 - a * uv2) + t[1];
-  p[2] = X[2] + w * uv2 + (a * uv1 - b * uv0) + t[2];
-  const double iz = 1.0 / p[2];
-  const double u = p[0] * iz, v = p[1] * iz;
-  // camera model value + d(x,y)/d(u,v) + d(x,y)/dk
+// Camera model at the normalised image point (u, v): value, d(x,y)/d(u,v) (Juv) and d(x,y)/dk (Pk, PXR_KPAD-strided rows).
+__device__ __forceinline__ bool camera_model_jac(int model, const double* __restrict__ k, double u, double v, double& x,
+                                                 double& y, double Juv[2][2], double Pk[2][PXR_KPAD]) {
   const double u2 = u * u, v2 = v * v, uvp = u * v, r2 = u2 + v2;
   double fx, fy, cx, cy, du = 0, dv = 0, duu = 0, duv = 0, dvu = 0, dvv = 0;
 #pragma unroll
@@ -250,7 +243,6 @@ __device__ inline bool world_to_pixel_jac(int model, const double* __restrict__ 
       fx = fy = cx = cy = 0.0;
       break;
   }
-  double Juv[2][2];
   if (ext_model) {   // forward-mode duals (pxr_camera_ext.h)
     if (!world_to_image_ext_jac(model, k, u, v, x, y, Juv, Pk)) { x = y = 0.0; return false; }
   } else {
@@ -263,6 +255,29 @@ __device__ inline bool world_to_pixel_jac(int model, const double* __restrict__ 
     }
     Juv[0][0] = fx * (1.0 + duu); Juv[0][1] = fx * duv; Juv[1][0] = fy * dvu; Juv[1][1] = fy * (1.0 + dvv);
   }
+  return true;
+}
+
+// WorldToPixel with analytic Jacobians.  A = d(x,y)/dp (2x3); Pq (2x4, ambient, includes
+// the normalisation Jacobian), PX (2x3), Pk (2xK in PXR_KPAD-strided rows).
+__device__ inline bool world_to_pixel_jac(int model, const double* __restrict__ k,
+                                          const double* __restrict__ q,
+                                          const double* __restrict__ t,
+                                          const double* __restrict__ X, double& x, double& y,
+                                          double A[2][3], double Pq[2][4], double PX[2][3],
+                                          double Pk[2][PXR_KPAD]) {
+  const double scale = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double w = q[0] * scale, a = q[1] * scale, b = q[2] * scale, c = q[3] * scale;
+  const double cr0 = b * X[2] - c * X[1], cr1 = c * X[0] - a * X[2], cr2 = a * X[1] - b * X[0];
+  const double uv0 = 2.0 * cr0, uv1 = 2.0 * cr1, uv2 = 2.0 * cr2;
+  double p[3];
+  p[0] = X[0] + w * uv0 + (b * uv2 - c * uv1) + t[0];
+  p[1] = X[1] + w * uv1 + (c * uv0 - a * uv2) + t[1];
+  p[2] = X[2] + w * uv2 + (a * uv1 - b * uv0) + t[2];
+  const double iz = 1.0 / p[2];
+  const double u = p[0] * iz, v = p[1] * iz;
+  double Juv[2][2];
+  if (!camera_model_jac(model, k, u, v, x, y, Juv, Pk)) return false;
   const double D[2][3] = {{iz, 0.0, -p[0] * iz * iz}, {0.0, iz, -p[1] * iz * iz}};
 #pragma unroll
   for (int i = 0; i < 2; ++i)

@@ -68,3 +68,30 @@ def test_inner_iterations_other_storage_and_float_simd(ctx, dtype, channels, flo
     assert s["iterations"] == so["iterations"] and s["num_successful"] == so["num_successful"]
     assert abs(s["final_cost"] - so["final_cost"]) < 1e-4 * max(so["final_cost"], 1e-9)
     assert np.abs(q - qo).max() < 1e-4 and np.abs(t - to).max() < 1e-4 and np.abs(X - Xo).max() < 1e-4
+
+
+@pytest.mark.parametrize("obs_per_point,n_cams,loss,l2", [(20, 24, ("huber", 0.3), True), (40, 44, ("soft_l1", 0.3), True),
+                                                          (5, 6, ("trivial", None), False), (2, 6, ("cauchy", 0.25), True)])
+def test_inner_iterations_track_lengths_losses_and_unnormalised(ctx, obs_per_point, n_cams, loss, l2):
+    """The packed kernel's other paths: tracks of 20 / 40 observations (one point per wavefront, several trips of 16 slots,
+    observation records beyond the 32 staged in LDS), four points per wavefront (tracks of two), the other robustifiers,
+    un-normalised descriptors (the residual is formed per channel instead of from the channel sums)."""
+    import pxo
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    prob = synthetic.make_ba_problem(n_cams=n_cams, n_points=14 if obs_per_point >= 20 else 45, obs_per_point=obs_per_point,
+                                     seed=90 + obs_per_point, pt_sigma=0.02)
+    gauge = list(_gauge(prob))
+    gauge[3][::7] = 1
+    name, a = loss
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    s = ba.solve(interp_cfg(l2_normalize=l2), make_loss(name, [] if a is None else [a]), *gauge,
+                 options=lm_options(max_iterations=2, use_inner_iterations=True))
+    q, t, k, X = ba.params()
+    so, qo, to, ko, Xo = pxo.ba_solve(prob, pxo.cfg(l2_normalize=l2), pxo.loss(name, a) if a is not None else pxo.loss(name),
+                                      *gauge, pxo.lm_options(max_iterations=2, use_inner_iterations=1))
+    assert s["iterations"] == so["iterations"] and s["num_successful"] == so["num_successful"]
+    assert abs(s["final_cost"] - so["final_cost"]) < 1e-4 * max(so["final_cost"], 1e-9)
+    assert np.abs(q - qo).max() < 1e-4 and np.abs(t - to).max() < 1e-4 and np.abs(X - Xo).max() < 1e-4
+    assert np.array_equal(X[::7], prob["xyz"][::7])

@@ -957,6 +957,8 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   double* diagU = gcd.p; double* gc = gcd.p + nc1;
   DevBuf<int> info_buf;
   RC(info_buf.alloc(1));
+  DevBuf<double> cb_flags;          // iteration callbacks on several ranks: the ranks' answers, summed
+  RC(cb_flags.alloc(2));
   int* d_info = info_buf.p;
 
   setup_mark("work buffers allocated");
@@ -1118,7 +1120,17 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     pxr_iteration_summary is;
     is.iteration = iteration; is.step_is_valid = valid; is.step_is_successful = successful; is.cost = cost_now; is.cost_change = change;
     is.relative_decrease = rel; is.trust_region_radius = radius_next; is.step_norm = step;
-    return ctx->iter_cb(&is, ctx->iter_user);
+    int rc = ctx->iter_cb(&is, ctx->iter_user);
+    if (multi) {
+      // every rank must leave the loop at the same iteration (the next collective would hang otherwise): the answers are
+      // summed over the ranks, an abort anywhere aborts everywhere, else a termination request anywhere terminates
+      double h[2] = {rc == 1 ? 1.0 : 0.0, rc == 2 ? 1.0 : 0.0};
+      if (hipMemcpyAsync(cb_flags.p, h, sizeof(h), hipMemcpyHostToDevice, st) != hipSuccess || ar(cb_flags.p, 2) != PXR_OK ||
+          hipMemcpyAsync(h, cb_flags.p, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return 1;
+      rc = h[0] > 0.0 ? 1 : (h[1] > 0.0 ? 2 : 0);
+    }
+    return rc;
   };
   auto user_stop = [&](int rc) {   // true: leave the loop
     if (rc == 1) { sum->termination = PXR_TERM_FAILURE; return true; }

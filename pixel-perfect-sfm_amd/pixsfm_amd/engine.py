@@ -81,8 +81,10 @@ class Context:
         def hook(summary, _user):
             rc = 0
             try:
+                # a copy: the solver's summary lives on its stack, a callback may keep what it is given
+                snap = type(summary.contents).from_buffer_copy(summary.contents)
                 for cb in callbacks:
-                    ans = cb(summary.contents)
+                    ans = cb(snap)
                     rc = max(rc, int(getattr(ans, "value", ans) or 0))
             except BaseException as e:       # noqa: BLE001 -- ctypes would print and swallow it; abort the solve instead
                 self._iter_exc = e

@@ -64,31 +64,37 @@ __device__ __forceinline__ int texel_index(double floored, int n) {
   return (int)fmin(fmax(floored, -3.0), (double)n + 1.0);
 }
 
-// Interpolated value + gradients of the 8 channels chan0 .. chan0 + 7 of one patch at (u, v), NOT normalised:
-// BiCubicInterpolator::EvaluateSIMD (interpolation.h:177-218), r = v (row), c = u (column).
-// frc (optional, WITH_JAC only): the cross derivative d2f / dr dc -- the derivative output of the vertical spline over
-// the row derivatives; the reference leaves it un-normalised (interpolation.h:642-666)
-template <typename ST, bool WITH_JAC, bool FLOAT_SIMD>
-__device__ __forceinline__ void interp8_raw(const ST* __restrict__ patch, int H, int W, int C, int chan0,
-                                            double u, double v, double f[8], double fr[8], double fc[8],
-                                            double* frc = nullptr) {
-  const double rf = floor(v), cf = floor(u);
+// ---- the three stages of BiCubicInterpolator::EvaluateSIMD (interpolation.h:177-218) for 8 channels of one patch ----
+// Separate so that a kernel walking several channel chunks can issue the loads of the next chunk between the horizontal
+// and the vertical pass of the current one (k_inner_packed); interp8_raw chains them.
+struct StencilIndex {
+  int ro[4], co[4];     // row offsets (in texels) and column indices of the 4 x 4 stencil, clamped (Grid2D, grid2d.h:64-73)
+  double dy, dx;        // fractional position inside the centre texel
+};
+__device__ __forceinline__ StencilIndex stencil_index(int H, int W, double u, double v) {
+  StencilIndex s;
+  const double rf = floor(v), cf = floor(u);     // r = v (row), c = u (column)
   const int row = texel_index(rf, H), col = texel_index(cf, W);
-  const double dy = v - rf, dx = u - cf;
-  int ro[4], co[4];
+  s.dy = v - rf; s.dx = u - cf;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    ro[j] = clampi(row - 1 + j, 0, H - 1) * W;   // Grid2D::GetPointer clamping, grid2d.h:64-73
-    co[j] = clampi(col - 1 + j, 0, W - 1);
+    s.ro[j] = clampi(row - 1 + j, 0, H - 1) * W;
+    s.co[j] = clampi(col - 1 + j, 0, W - 1);
   }
-  Texel8<ST> tx[4][4];
+  return s;
+}
+template <typename ST>
+__device__ __forceinline__ void interp8_load(const ST* __restrict__ patch, int C, int chan0, const StencilIndex& si,
+                                             Texel8<ST> (&tx)[4][4]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tx[j][i].load(patch + (size_t)(ro[j] + co[i]) * C + chan0);
-
+    for (int i = 0; i < 4; ++i) tx[j][i].load(patch + (size_t)(si.ro[j] + si.co[i]) * C + chan0);
+}
+template <typename ST, bool WITH_JAC, bool FLOAT_SIMD>
+__device__ __forceinline__ void interp8_horizontal(const Texel8<ST> (&tx)[4][4], double dx,
+                                                   typename Texel8<ST>::work_t (&h)[4][8], typename Texel8<ST>::work_t (&hd)[4][8]) {
   typedef typename Texel8<ST>::work_t HT;  // horizontal-pass arithmetic type
-  HT h[4][8], hd[4][8];
   if constexpr (sizeof(HT) == 4) {
     const SplineCoefF32 kh(dx);
 #pragma unroll
@@ -117,7 +123,12 @@ __device__ __forceinline__ void interp8_raw(const ST* __restrict__ patch, int H,
       }
     }
   }
-  // vertical pass
+}
+// frc (optional, WITH_JAC only): the cross derivative d2f / dr dc -- the derivative output of the vertical spline over
+// the row derivatives; the reference leaves it un-normalised (interpolation.h:642-666)
+template <typename HT, bool WITH_JAC, bool FLOAT_SIMD>
+__device__ __forceinline__ void interp8_vertical(const HT (&h)[4][8], const HT (&hd)[4][8], double dy, double f[8], double fr[8],
+                                                 double fc[8], double* frc = nullptr) {
   if constexpr (FLOAT_SIMD) {
     const SplineCoefF32 kv(dy);
 #pragma unroll
@@ -143,6 +154,20 @@ __device__ __forceinline__ void interp8_raw(const ST* __restrict__ patch, int H,
       f[ch] = ff; fr[ch] = dd; fc[ch] = cc;
     }
   }
+}
+
+// Interpolated value + gradients of the 8 channels chan0 .. chan0 + 7 of one patch at (u, v), NOT normalised.
+template <typename ST, bool WITH_JAC, bool FLOAT_SIMD>
+__device__ __forceinline__ void interp8_raw(const ST* __restrict__ patch, int H, int W, int C, int chan0,
+                                            double u, double v, double f[8], double fr[8], double fc[8],
+                                            double* frc = nullptr) {
+  const StencilIndex si = stencil_index(H, W, u, v);
+  Texel8<ST> tx[4][4];
+  interp8_load<ST>(patch, C, chan0, si, tx);
+  typedef typename Texel8<ST>::work_t HT;
+  HT h[4][8], hd[4][8];
+  interp8_horizontal<ST, WITH_JAC, FLOAT_SIMD>(tx, si.dx, h, hd);
+  interp8_vertical<HT, WITH_JAC, FLOAT_SIMD>(h, hd, si.dy, f, fr, fc, frc);
 }
 
 // Normalised descriptor + gradients of 8 channels of one observation, all lanes of the

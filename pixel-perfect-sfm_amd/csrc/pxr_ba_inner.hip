@@ -293,8 +293,10 @@ __global__ __launch_bounds__(64 * InnerShape<C>::WPB) void k_inner_points(const 
 // over the RAW interpolated f, df/dc, df/dr (and the reference d) and the normalisation is applied to the sums:
 //   N^2 = f.f   r = f / N - d   r.r = 1 - 2 (f.d) / N + d.d
 //   Jc = (fc - f (f.fc) / N^2) / N   Jc.Jc = (fc.fc - (f.fc)^2 / N^2) / N^2   Jc.r = -(fc.d - (f.d)(f.fc) / N^2) / N
-// -- the same quantities as PixelInterpolator's normalise-then-subtract (interpolation.h:648-666) up to rounding
-// (1e-13 relative on r.r at the residual sizes of a converging problem; r.r is clamped at 0).
+// -- the same quantities as PixelInterpolator's normalise-then-subtract (interpolation.h:648-666) up to rounding: r.r is a
+// difference of O(1) terms, relative error ~ 2e-16 / |r|^2 (1e-14 at |r| = 0.1, 1e-10 at |r| = 0.003;
+// tests/test_inner_sums_identity.py); it is clamped at 0.  The nested LM is Ceres' heuristic refinement of a candidate the
+// outer loop re-evaluates with the exact-order kernel, and its own tolerances are 1e-6 relative.
 constexpr int IP_MAXPTS = 4, IP_MAXQ = 32, IP_OBS = 30;
 
 // Nested-LM state of one point.  It lives in LDS: the owner lane works on it for a few hundred cycles per round, and as

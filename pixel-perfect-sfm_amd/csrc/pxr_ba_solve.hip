@@ -521,13 +521,18 @@ __global__ __launch_bounds__(256) void k_backsub(const SolveDev d, const int64_t
 
 // ---- K_update: candidate = x (+) scale * delta --------------------------------------------------------
 struct ParamPtrs { double* q; double* t; double* k; double* X; };
+constexpr int UPDATE_IPT = 4;
 
 __global__ __launch_bounds__(256) void k_update(const SolveDev d, const double* __restrict__ delta_c,
                                                 const double* __restrict__ delta_p, ParamPtrs out,
                                                 double* __restrict__ scal_rep, double* __restrict__ scal_sum) {
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // UPDATE_IPT items per thread and one pair of atomics per workgroup: the four norms are four addresses, and an atomic per
+  // wavefront (3 100 of them at 200 000 points) serialised there for most of the kernel's 82 us
+  __shared__ double red[4][256 / 64];
   const int n_img = d.v.n_images, n_cam = d.v.n_cameras;
   double step2_rep = 0, x2_rep = 0, step2_sum = 0, x2_sum = 0;
+  for (int rep = 0; rep < UPDATE_IPT; ++rep) {
+  const int64_t tid = ((int64_t)blockIdx.x * UPDATE_IPT + rep) * blockDim.x + threadIdx.x;
   if (tid < n_img) {
     const int i = (int)tid;
     double q0[4], t0[3], q1[4], t1[3];
@@ -586,11 +591,19 @@ __global__ __launch_bounds__(256) void k_update(const SolveDev d, const double* 
       out.X[3 * p + j] = x1;
     }
   }
+  }
   step2_rep = wave_sum(step2_rep); x2_rep = wave_sum(x2_rep);
   step2_sum = wave_sum(step2_sum); x2_sum = wave_sum(x2_sum);
   if ((threadIdx.x & 63) == 0) {
-    if (step2_rep != 0.0 || x2_rep != 0.0) { atomicAdd(scal_rep + 1, step2_rep); atomicAdd(scal_rep + 2, x2_rep); }
-    if (step2_sum != 0.0 || x2_sum != 0.0) { atomicAdd(scal_sum + 2, step2_sum); atomicAdd(scal_sum + 3, x2_sum); }
+    const int w = threadIdx.x >> 6;
+    red[0][w] = step2_rep; red[1][w] = x2_rep; red[2][w] = step2_sum; red[3][w] = x2_sum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r[4];
+    for (int k = 0; k < 4; ++k) r[k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+    if (r[0] != 0.0 || r[1] != 0.0) { atomicAdd(scal_rep + 1, r[0]); atomicAdd(scal_rep + 2, r[1]); }
+    if (r[2] != 0.0 || r[3] != 0.0) { atomicAdd(scal_sum + 2, r[2]); atomicAdd(scal_sum + 3, r[3]); }
   }
 }
 
@@ -1221,7 +1234,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       if (DC <= 8) BACKSUB_LAUNCH(8); else if (DC <= 16) BACKSUB_LAUNCH(16); else BACKSUB_LAUNCH(32);
 #undef BACKSUB_LAUNCH
       ParamPtrs out{q1.p, t1.p, k1.p, X1.p};
-      hipLaunchKernelGGL(k_update, dim3(nblk((int64_t)n_img + n_cam + n_pts)), dim3(256), 0, st, dv, delta_c.p, delta_p.p, out, scal_rep, scal_sum);
+      hipLaunchKernelGGL(k_update, dim3(nblk(((int64_t)n_img + n_cam + n_pts + UPDATE_IPT - 1) / UPDATE_IPT)), dim3(256), 0, st, dv, delta_c.p, delta_p.p, out, scal_rep, scal_sum);
       LAUNCH_CHECK("step kernels");
       const bool do_inner = inner_enabled;
       if (do_inner) {   // DoInnerIterationsIfNeeded [upstream]: refine every variable point of the candidate on its own

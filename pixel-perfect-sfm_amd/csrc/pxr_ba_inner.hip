@@ -16,6 +16,8 @@
 // evaluation for Ceres' inner-iteration bookkeeping.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "pxr_device.h"
 #include "pxr_interp.h"
 #include "pxr_internal.h"
@@ -481,8 +483,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const double p1 = fma(R[3], X0, fma(R[4], X1, fma(R[5], X2, t[1])));
         const double p2 = fma(R[6], X0, fma(R[7], X1, fma(R[8], X2, t[2])));
         const double iz = inner_rcp(p2), un = p0 * iz, vn = p1 * iz;
-        double x, y, Juv[2][2], Pk[2][PXR_KPAD];
-        camera_model_jac(model, k, un, vn, x, y, Juv, Pk);
+        double x, y, Juv[2][2];
+        camera_model_jac<false>(model, k, un, vn, x, y, Juv, nullptr);
         double PX[2][3];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -716,6 +718,13 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     else if (arena->dtype == PXR_F32) INNER_LAUNCH(k_inner_points, float, 1);
     else if (arena->C == 3) INNER_LAUNCH(k_inner_points, double, 3);
     else INNER_LAUNCH(k_inner_points, double, 1);
+  } else if (getenv("PXR_INNER_OLD")) {   // A/B knob (tools/fuzz_solve_vs_oracle.py): the one-point-per-wavefront kernel for every storage type
+    if (arena->dtype == PXR_F16 && arena->C == 128) INNER_LAUNCH(k_inner_points, _Float16, 128);
+    else if (arena->dtype == PXR_F16) INNER_LAUNCH(k_inner_points, _Float16, 64);
+    else if (arena->dtype == PXR_F32 && arena->C == 128) INNER_LAUNCH(k_inner_points, float, 128);
+    else if (arena->dtype == PXR_F32) INNER_LAUNCH(k_inner_points, float, 64);
+    else if (arena->C == 128) INNER_LAUNCH(k_inner_points, double, 128);
+    else INNER_LAUNCH(k_inner_points, double, 64);
   } else if (arena->dtype != PXR_F64) {
     // packed kernel: points per wavefront from the mean track length (16 observation slots per trip)
     const int64_t per16 = view->n_obs > 0 ? (16 * view->n_points) / view->n_obs : 1;

@@ -190,13 +190,17 @@ __device__ __forceinline__ bool world_to_pixel(int model, const double* __restri
   return world_to_image(model, k, p[0] / p[2], p[1] / p[2], x, y);
 }
 
-// Camera model at the normalised image point (u, v): value, d(x,y)/d(u,v) (Juv) and d(x,y)/dk (Pk, PXR_KPAD-strided rows).
+// Camera model at the normalised image point (u, v): value, d(x,y)/d(u,v) (Juv) and -- WITH_PK -- d(x,y)/dk (Pk,
+// PXR_KPAD-strided rows; not touched otherwise: the callers that only move the point pass nullptr).
+template <bool WITH_PK = true>
 __device__ __forceinline__ bool camera_model_jac(int model, const double* __restrict__ k, double u, double v, double& x,
                                                  double& y, double Juv[2][2], double Pk[2][PXR_KPAD]) {
   const double u2 = u * u, v2 = v * v, uvp = u * v, r2 = u2 + v2;
   double fx, fy, cx, cy, du = 0, dv = 0, duu = 0, duv = 0, dvu = 0, dvv = 0;
+  if constexpr (WITH_PK) {
 #pragma unroll
-  for (int j = 0; j < PXR_KPAD; ++j) { Pk[0][j] = 0.0; Pk[1][j] = 0.0; }
+    for (int j = 0; j < PXR_KPAD; ++j) { Pk[0][j] = 0.0; Pk[1][j] = 0.0; }
+  }
   bool two_focal = false, ext_model = false;
   switch (model) {
     case PXR_SIMPLE_PINHOLE:
@@ -210,7 +214,7 @@ __device__ __forceinline__ bool camera_model_jac(int model, const double* __rest
       const double kk = k[3], radial = kk * r2;
       du = u * radial; dv = v * radial;
       duu = radial + 2.0 * kk * u2; duv = 2.0 * kk * uvp; dvu = duv; dvv = radial + 2.0 * kk * v2;
-      Pk[0][3] = fx * u * r2; Pk[1][3] = fy * v * r2;
+      if constexpr (WITH_PK) { Pk[0][3] = fx * u * r2; Pk[1][3] = fy * v * r2; }
       break;
     }
     case PXR_RADIAL: {
@@ -218,8 +222,10 @@ __device__ __forceinline__ bool camera_model_jac(int model, const double* __rest
       const double radial = k[3] * r2 + k[4] * r2 * r2, rp = 2.0 * k[3] + 4.0 * k[4] * r2;
       du = u * radial; dv = v * radial;
       duu = radial + rp * u2; duv = rp * uvp; dvu = duv; dvv = radial + rp * v2;
-      Pk[0][3] = fx * u * r2; Pk[0][4] = fx * u * r2 * r2;
-      Pk[1][3] = fy * v * r2; Pk[1][4] = fy * v * r2 * r2;
+      if constexpr (WITH_PK) {
+        Pk[0][3] = fx * u * r2; Pk[0][4] = fx * u * r2 * r2;
+        Pk[1][3] = fy * v * r2; Pk[1][4] = fy * v * r2 * r2;
+      }
       break;
     }
     case PXR_OPENCV: {
@@ -232,10 +238,12 @@ __device__ __forceinline__ bool camera_model_jac(int model, const double* __rest
       duv = rp * uvp + 2.0 * p1 * u + 2.0 * p2 * v;
       dvu = rp * uvp + 2.0 * p2 * v + 2.0 * p1 * u;
       dvv = radial + rp * v2 + 2.0 * p2 * u + 6.0 * p1 * v;
-      Pk[0][4] = fx * u * r2; Pk[0][5] = fx * u * r2 * r2; Pk[0][6] = fx * 2.0 * uvp;
-      Pk[0][7] = fx * (r2 + 2.0 * u2);
-      Pk[1][4] = fy * v * r2; Pk[1][5] = fy * v * r2 * r2; Pk[1][6] = fy * (r2 + 2.0 * v2);
-      Pk[1][7] = fy * 2.0 * uvp;
+      if constexpr (WITH_PK) {
+        Pk[0][4] = fx * u * r2; Pk[0][5] = fx * u * r2 * r2; Pk[0][6] = fx * 2.0 * uvp;
+        Pk[0][7] = fx * (r2 + 2.0 * u2);
+        Pk[1][4] = fy * v * r2; Pk[1][5] = fy * v * r2 * r2; Pk[1][6] = fy * (r2 + 2.0 * v2);
+        Pk[1][7] = fy * 2.0 * uvp;
+      }
       break;
     }
     default:
@@ -244,14 +252,17 @@ __device__ __forceinline__ bool camera_model_jac(int model, const double* __rest
       break;
   }
   if (ext_model) {   // forward-mode duals (pxr_camera_ext.h)
-    if (!world_to_image_ext_jac(model, k, u, v, x, y, Juv, Pk)) { x = y = 0.0; return false; }
+    double Pk_ext[2][PXR_KPAD];
+    if (!world_to_image_ext_jac(model, k, u, v, x, y, Juv, WITH_PK ? Pk : Pk_ext)) { x = y = 0.0; return false; }
   } else {
     x = fx * (u + du) + cx;
     y = fy * (v + dv) + cy;
-    if (two_focal) {
-      Pk[0][0] = u + du; Pk[1][1] = v + dv; Pk[0][2] = 1.0; Pk[1][3] = 1.0;
-    } else {
-      Pk[0][0] = u + du; Pk[1][0] = v + dv; Pk[0][1] = 1.0; Pk[1][2] = 1.0;
+    if constexpr (WITH_PK) {
+      if (two_focal) {
+        Pk[0][0] = u + du; Pk[1][1] = v + dv; Pk[0][2] = 1.0; Pk[1][3] = 1.0;
+      } else {
+        Pk[0][0] = u + du; Pk[1][0] = v + dv; Pk[0][1] = 1.0; Pk[1][2] = 1.0;
+      }
     }
     Juv[0][0] = fx * (1.0 + duu); Juv[0][1] = fx * duv; Juv[1][0] = fy * dvu; Juv[1][1] = fy * (1.0 + dvv);
   }

@@ -95,3 +95,26 @@ def test_inner_iterations_track_lengths_losses_and_unnormalised(ctx, obs_per_poi
     assert abs(s["final_cost"] - so["final_cost"]) < 1e-4 * max(so["final_cost"], 1e-9)
     assert np.abs(q - qo).max() < 1e-4 and np.abs(t - to).max() < 1e-4 and np.abs(X - Xo).max() < 1e-4
     assert np.array_equal(X[::7], prob["xyz"][::7])
+
+
+@pytest.mark.parametrize("model", [0, 1, 3, 4])
+@pytest.mark.parametrize("dtype,channels", [(np.float32, 64), (np.float32, 128), (np.float16, 128)])
+def test_inner_iterations_every_camera_model_and_storage(ctx, model, dtype, channels):
+    """Regression: the packed kernel's fp32-storage instantiation returned garbage pixel coordinates for SIMPLE_PINHOLE
+    (found by tools/fuzz_solve_vs_oracle.py: the unused d(x,y)/dk outputs of the camera model survived as private-memory
+    stores behind a pointer select); the camera model is now instantiated without them there."""
+    import pxo
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    prob = synthetic.make_ba_problem(n_cams=5, n_points=60, obs_per_point=3, seed=11 + model, model=model, dtype=dtype,
+                                     channels=channels, shared_camera=True)
+    gauge = _gauge(prob)
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *gauge, options=lm_options(max_iterations=2, use_inner_iterations=True))
+    q, t, k, X = ba.params()
+    so, qo, to, ko, Xo = pxo.ba_solve(prob, pxo.cfg(), pxo.loss("cauchy", 0.25), *gauge,
+                                      pxo.lm_options(max_iterations=2, use_inner_iterations=1))
+    assert s["iterations"] == so["iterations"] and s["num_successful"] == so["num_successful"]
+    assert abs(s["final_cost"] - so["final_cost"]) < 1e-4 * max(so["final_cost"], 1e-9)
+    assert np.abs(q - qo).max() < 1e-4 and np.abs(t - to).max() < 1e-4 and np.abs(X - Xo).max() < 1e-4

@@ -97,8 +97,9 @@ def test_gpu_residuals_and_jacobians_match_oracle(ctx, model):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("inner", [False, True])
 @pytest.mark.parametrize("model", [5, 7, 10])
-def test_gpu_lm_with_extended_models_matches_oracle(ctx, model):
+def test_gpu_lm_with_extended_models_matches_oracle(ctx, model, inner):
     from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
     prob = _problem(model, seed=60 + model)
     n_img = len(prob["image_camera"])
@@ -111,14 +112,17 @@ def test_gpu_lm_with_extended_models_matches_oracle(ctx, model):
     gauge = (pose_const, tmask, cmask, np.zeros(48, np.uint8))
     arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
     ba = BAProblem(ctx, arena, prob)
-    s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *gauge, options=lm_options(max_iterations=5))
+    # inner: the nested per-point LM (csrc/pxr_ba_inner.hip) takes the models' d(x,y)/d(u,v) without d(x,y)/dk
+    s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *gauge, options=lm_options(max_iterations=5, use_inner_iterations=inner))
     q, t, k, X = ba.params()
-    so, qo, to, ko, Xo = pxo.ba_solve(prob, pxo.cfg(), pxo.loss("cauchy", 0.25), *gauge, pxo.lm_options(max_iterations=5))
+    so, qo, to, ko, Xo = pxo.ba_solve(prob, pxo.cfg(), pxo.loss("cauchy", 0.25), *gauge,
+                                      pxo.lm_options(max_iterations=5, use_inner_iterations=int(inner)))
     assert s["iterations"] == so["iterations"] and s["num_successful"] == so["num_successful"]
     if model == 7:
         # FOV couples focal length and depth almost degenerately on this scene: the LM trajectories are
         # ill-conditioned, so only the (matching) Jacobians above and the cost level are compared
         assert abs(s["final_cost"] - so["final_cost"]) < 1e-2 * so["final_cost"]
         return
-    assert abs(s["final_cost"] - so["final_cost"]) < 1e-6 * max(so["final_cost"], 1e-9)
-    assert np.abs(q - qo).max() < 1e-6 and np.abs(X - Xo).max() < 1e-6 and np.abs(k - ko).max() < 1e-5 * 1200
+    tol = 1e-4 if inner else 1e-6           # the nested LMs stop on 1e-6 relative tolerances: test_ba_inner_gpu.py
+    assert abs(s["final_cost"] - so["final_cost"]) < tol * max(so["final_cost"], 1e-9)
+    assert np.abs(q - qo).max() < tol and np.abs(X - Xo).max() < tol and np.abs(k - ko).max() < 10 * tol * 1200

@@ -22,7 +22,7 @@
 //   K_schur_lds  block/(image chunk, column tile)  S -= Y_i W_j^T over the point's observation pairs
 //             (upper triangle only), rhs -= Y_i g_p, Y_i = W_i T_p formed on the fly; privatised in LDS
 //   all-reduce(S | rhs) over ranks (RCCL, multi-GPU), + LM damping, blocked dense Cholesky (pxr_chol.hip)
-//   K_backsub thread/point  delta_p = -T_p (g_p + sum W_i^T delta_c)
+//   K_backsub lane group/point  delta_p = -T_p (g_p + sum W_i^T delta_c)
 //   K_update  x (+) delta (quaternion manifold, subset manifolds), then pxr_ba_eval at the
 //             candidate WITH Jacobians (same HBM traffic as cost-only, saves the second
 //             evaluation Ceres does after an accepted step).

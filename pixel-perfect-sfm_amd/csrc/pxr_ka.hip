@@ -37,7 +37,7 @@
 namespace pxr {
 
 constexpr int KA_NT = 256;     // threads per sub-problem workgroup
-constexpr int KA_NLDS = 88;    // LDS budget for the damped blocks: KA_NLDS^2 doubles (61 KiB + 17 KiB of metadata caches: two workgroups per CU)
+constexpr int KA_NLDS = 84;    // LDS budget for the damped blocks: KA_NLDS^2 doubles = 55 KiB; with the 22.5 KiB of static metadata caches (sh_nodes, sh_edges, sh_sq) under 80 KiB: two workgroups per CU
 
 struct KaArgs {
   pxr_ka_view v;

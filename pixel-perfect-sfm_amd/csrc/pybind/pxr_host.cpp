@@ -182,11 +182,38 @@ py::tuple gather_patches(py::list patch_list) {
   return py::make_tuple(index, uniq, as_array(ptrs), c, sc);
 }
 
+// has_patch flags of the sparse feature maps: patch_dicts[k] is the {keypoint id: patch} dict of image k (or None: nothing set
+// for that image), p2d_ptr the first point2D slot of every image.  flags[p2d_ptr[k] + id] = 1 for every key inside the image's
+// keypoint range (one PyDict_Next walk per image instead of a numpy array of the keys + isin).
+py::array_t<uint8_t> patch_flags(py::list patch_dicts, py::array_t<int64_t, py::array::c_style | py::array::forcecast> p2d_ptr) {
+  const py::ssize_t n_img = py::len(patch_dicts);
+  if (p2d_ptr.ndim() != 1 || p2d_ptr.shape(0) != n_img + 1) throw py::value_error("p2d_ptr must have one entry per image plus one");
+  const int64_t* ptr = p2d_ptr.data();
+  py::array_t<uint8_t> flags((py::ssize_t)ptr[n_img]);
+  uint8_t* f = flags.mutable_data();
+  std::memset(f, 0, (size_t)ptr[n_img]);
+  for (py::ssize_t k = 0; k < n_img; ++k) {
+    PyObject* d = PyList_GET_ITEM(patch_dicts.ptr(), k);
+    if (d == Py_None) continue;
+    if (!PyDict_Check(d)) throw py::type_error("patch_dicts entries must be dict or None");
+    const int64_t count = ptr[k + 1] - ptr[k];
+    PyObject *key, *value;
+    Py_ssize_t pos = 0;
+    while (PyDict_Next(d, &pos, &key, &value)) {
+      const long long id = PyLong_AsLongLong(key);
+      if (id == -1 && PyErr_Occurred()) throw py::error_already_set();
+      if (id >= 0 && id < count) f[ptr[k] + id] = 1;
+    }
+  }
+  return flags;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_pxr_host, m) {
   m.doc() = "compiled host side of the pixsfm_amd drop-in path: scene dump of pycolmap-style objects (see pxr_host.cpp)";
   m.def("scene_arrays", &scene_arrays, py::arg("images"), py::arg("points"), py::arg("img_of"));
   m.def("gather_patches", &gather_patches, py::arg("patch_list"));
+  m.def("patch_flags", &patch_flags, py::arg("patch_dicts"), py::arg("p2d_ptr"));
   m.def("patches_of", &patches_of, py::arg("patch_dicts"), py::arg("dense_flags"), py::arg("obs_image"), py::arg("obs_p2d"));
 }

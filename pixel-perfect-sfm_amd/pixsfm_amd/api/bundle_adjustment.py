@@ -245,11 +245,19 @@ class _SceneDump:
             img_of = self.img_of
             self.track_image = np.fromiter((img_of[e.image_id] for pt in points for e in pt.track.elements), dtype=np.int32, count=n_el)
             self.track_p2d = np.fromiter((e.point2D_idx for pt in points for e in pt.track.elements), dtype=np.int32, count=n_el)
-        # point3D id -> index in ascending-id order (ids are arbitrary integers: binary search in the sorted id list)
+        # point3D id -> index in ascending-id order: a lookup table when the ids are dense (COLMAP numbers points from 1),
+        # else a binary search in the sorted id list (ids are arbitrary integers)
         pt_arr = np.asarray(pt_ids, dtype=np.int64)
-        pos = np.searchsorted(pt_arr, np.maximum(ids, 0)) if len(pt_arr) else np.zeros(len(ids), np.int64)
-        pos = np.minimum(pos, max(len(pt_arr) - 1, 0))
-        known = (ids >= 0) & (pt_arr[pos] == ids) if len(pt_arr) else np.zeros(len(ids), bool)
+        if len(pt_arr) and 0 <= pt_arr[0] and pt_arr[-1] < 4 * len(pt_arr) + 1024:
+            lut = np.full(int(pt_arr[-1]) + 2, -1, np.int64)
+            lut[pt_arr] = np.arange(len(pt_arr), dtype=np.int64)
+            pos = lut[np.clip(ids, 0, len(lut) - 1)]
+            known = (ids >= 0) & (ids < len(lut) - 1) & (pos >= 0)
+            pos = np.maximum(pos, 0)
+        else:
+            pos = np.searchsorted(pt_arr, np.maximum(ids, 0)) if len(pt_arr) else np.zeros(len(ids), np.int64)
+            pos = np.minimum(pos, max(len(pt_arr) - 1, 0))
+            known = (ids >= 0) & (pt_arr[pos] == ids) if len(pt_arr) else np.zeros(len(ids), bool)
         if ((ids >= 0) & ~known).any():
             raise KeyError(int(ids[(ids >= 0) & ~known][0]))           # a point2D refers to a point3D the reconstruction lacks
         self.p2d_point3D = np.where(known, pos, -1).astype(np.int64)
@@ -266,14 +274,23 @@ class _SceneDump:
                     self.has_patch[at] = 1 if (self.p2d_point3D[at] < 0 or feature_view.has_fpatch(i, j)) else 0
             images = []
         for k, im in enumerate(images):
+            self._patch_dicts.append(fs.fmap(im.name) if fs.has_fmap(im.name) else None)
+        flags_done = False
+        if host is not None and hasattr(host, "patch_flags") and images:   # the sparse maps' keys in one C++ walk per image
+            try:
+                self.has_patch = host.patch_flags([fm.patches if (fm is not None and fm.is_sparse) else None
+                                                   for fm in self._patch_dicts], self.p2d_ptr)
+                flags_done = True
+            except TypeError:                    # `patches` is not a plain dict: the numpy form below
+                self.has_patch = np.zeros(len(ids), np.uint8)
+        for k, fm in enumerate(self._patch_dicts if images else []):
             lo, hi = int(self.p2d_ptr[k]), int(self.p2d_ptr[k + 1])
-            fm = fs.fmap(im.name) if fs.has_fmap(im.name) else None
-            self._patch_dicts.append(fm)
             if fm is None or hi == lo:
                 continue
             if fm.is_sparse:
-                keys = np.fromiter(fm.patches.keys(), dtype=np.int64, count=len(fm.patches))
-                self.has_patch[lo:hi] = np.isin(np.arange(hi - lo, dtype=np.int64), keys)
+                if not flags_done:
+                    keys = np.fromiter(fm.patches.keys(), dtype=np.int64, count=len(fm.patches))
+                    self.has_patch[lo:hi] = np.isin(np.arange(hi - lo, dtype=np.int64), keys)
             else:
                 self.has_patch[lo:hi] = 1 if fm.has_fpatch(0) else 0
         self.has_patch[self.p2d_point3D < 0] = 1                        # never asked (only observations of 3D points are)

@@ -375,3 +375,41 @@ def test_compiled_patch_gather_equals_the_python_walk():
     import pickle
     for clone in (pickle.loads(pickle.dumps(base[2])), copy.deepcopy(base[2])):     # a copy owns new memory: its address moved with it
         assert clone._meta[0] == clone.data.ctypes.data and clone._meta[1:] == base[2]._meta[1:]
+
+
+@pytest.mark.parametrize("stride", [1, 7, 10 ** 9])
+def test_scene_dump_point_ids_dense_and_sparse(stride):
+    """_SceneDump maps point3D ids to indices with a lookup table when the ids are dense and with a binary search otherwise;
+    a point2D that names a point3D the reconstruction lacks is a KeyError in both."""
+    from pixsfm_amd.api import bundle_adjustment as B, features
+    from pixsfm_amd.api.reconstruction import Camera, Image, Point2D, Point3D, Reconstruction
+
+    def build(extra_id=None):
+        rec = Reconstruction()
+        rec.add_camera(Camera(1, "SIMPLE_PINHOLE", 100, 100, [50.0, 50, 50]))
+        images = [Image(1 + i, "im%d.jpg" % i, 1, [1, 0, 0, 0], [0, 0, 0]) for i in range(3)]
+        ids = [5 + stride * p for p in range(12)]
+        for pid in ids:
+            rec.add_point3D(pid, Point3D(np.zeros(3)))
+        for n, pid in enumerate(ids):
+            for im in (images[n % 3], images[(n + 1) % 3]):
+                im.points2D.append(Point2D([0, 0], pid))
+                rec.points3D[pid].track.add_element(im.image_id, len(im.points2D) - 1)
+        if extra_id is not None:
+            images[0].points2D.append(Point2D([0, 0], extra_id))
+        for im in images:
+            rec.add_image(im)
+        fmaps = {im.name: features.FeatureMap() for im in images}
+        return rec, B.FeatureView(features.FeatureSet(fmaps), rec), ids
+
+    rec, fv, ids = build()
+    for compiled in (True, False):
+        sd = B._SceneDump(rec, fv, use_compiled=compiled)
+        want = np.concatenate([[ids.index(q.point3D_id) for q in rec.images[i].points2D] for i in sorted(rec.images)])
+        assert np.array_equal(sd.p2d_point3D, want)
+    for missing in (5 + stride * 12, 6, 10 ** 12):
+        if missing in ids:
+            continue
+        rec, fv, _ = build(extra_id=missing)
+        with pytest.raises(KeyError):
+            B._SceneDump(rec, fv)

@@ -141,25 +141,39 @@ py::tuple gather_patches(py::list patch_list) {
   const py::ssize_t n = py::len(patch_list);
   py::array_t<int64_t> index(n);
   int64_t* idx = index.mutable_data();
-  std::unordered_map<PyObject*, int64_t> slot;
-  slot.reserve((size_t)n);
-  py::list uniq;
+  // open-addressing table object -> slot (a node-based std::unordered_map spent more time in malloc than in the walk)
+  size_t cap = 16;
+  while (cap < (size_t)n * 2) cap <<= 1;
+  std::vector<PyObject*> keys(cap, nullptr);
+  std::vector<int64_t> vals(cap, 0);
+  auto hash = [cap](PyObject* p) { return (size_t)(((uintptr_t)p >> 4) * 0x9E3779B97F4A7C15ull) & (cap - 1); };
+  std::vector<PyObject*> uniq_ptrs;
   std::vector<uint64_t> ptrs;
   std::vector<int32_t> corners;
   std::vector<double> scales;
+  uniq_ptrs.reserve((size_t)n); ptrs.reserve((size_t)n); corners.reserve((size_t)n * 2); scales.reserve((size_t)n * 2);
   py::str s_meta("_meta");
   py::object layout;                      // (H, W, C, dtype) of the first patch: all must agree
   for (py::ssize_t k = 0; k < n; ++k) {
     PyObject* p = PyList_GET_ITEM(patch_list.ptr(), k);
-    auto it = slot.find(p);
-    if (it != slot.end()) { idx[k] = it->second; continue; }
+    size_t h = hash(p);
+    while (keys[h] && keys[h] != p) h = (h + 1) & (cap - 1);
+    if (keys[h]) { idx[k] = vals[h]; continue; }
     PyObject* meta = PyObject_GetAttr(p, s_meta.ptr());
     if (!meta) throw py::error_already_set();
     if (!PyTuple_Check(meta) || PyTuple_GET_SIZE(meta) != 6) { Py_DECREF(meta); throw py::type_error("patch._meta must be (ptr, cx, cy, sx, sy, layout)"); }
-    if (ptrs.empty()) { layout = py::reinterpret_borrow<py::object>(PyTuple_GET_ITEM(meta, 5)); }
-    else {
-      const int same = PyObject_RichCompareBool(PyTuple_GET_ITEM(meta, 5), layout.ptr(), Py_EQ);
-      if (same != 1) { Py_DECREF(meta); if (same < 0) throw py::error_already_set(); throw py::value_error("patches of different shape or dtype"); }
+    PyObject* lay = PyTuple_GET_ITEM(meta, 5);
+    if (ptrs.empty()) { layout = py::reinterpret_borrow<py::object>(lay); }
+    else if (lay != layout.ptr()) {
+      // the entries of the layout tuples are usually the SAME objects (small integers, one dtype instance): identity first
+      bool same_items = PyTuple_Check(lay) && PyTuple_Check(layout.ptr()) && PyTuple_GET_SIZE(lay) == PyTuple_GET_SIZE(layout.ptr());
+      if (same_items)
+        for (Py_ssize_t q = 0; q < PyTuple_GET_SIZE(lay); ++q)
+          if (PyTuple_GET_ITEM(lay, q) != PyTuple_GET_ITEM(layout.ptr(), q)) { same_items = false; break; }
+      if (!same_items) {
+        const int same = PyObject_RichCompareBool(lay, layout.ptr(), Py_EQ);
+        if (same != 1) { Py_DECREF(meta); if (same < 0) throw py::error_already_set(); throw py::value_error("patches of different shape or dtype"); }
+      }
     }
     ptrs.push_back((uint64_t)PyLong_AsUnsignedLongLong(PyTuple_GET_ITEM(meta, 0)));
     corners.push_back((int32_t)PyLong_AsLong(PyTuple_GET_ITEM(meta, 1)));
@@ -169,10 +183,12 @@ py::tuple gather_patches(py::list patch_list) {
     Py_DECREF(meta);
     if (PyErr_Occurred()) throw py::error_already_set();
     const int64_t s = (int64_t)ptrs.size() - 1;
-    slot.emplace(p, s);
+    keys[h] = p; vals[h] = s;
     idx[k] = s;
-    uniq.append(py::reinterpret_borrow<py::object>(p));
+    uniq_ptrs.push_back(p);
   }
+  py::list uniq((py::ssize_t)uniq_ptrs.size());
+  for (size_t q = 0; q < uniq_ptrs.size(); ++q) { Py_INCREF(uniq_ptrs[q]); PyList_SET_ITEM(uniq.ptr(), (py::ssize_t)q, uniq_ptrs[q]); }
   py::array_t<int32_t> c({(py::ssize_t)ptrs.size(), (py::ssize_t)2});
   py::array_t<double> sc({(py::ssize_t)ptrs.size(), (py::ssize_t)2});
   if (!ptrs.empty()) {

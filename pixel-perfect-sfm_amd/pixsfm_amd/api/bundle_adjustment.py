@@ -851,11 +851,13 @@ class BundleAdjuster:
     def refine_multilevel(self, reconstruction, feature_manager, problem_setup=None):
         levels = self.conf['level_indices'] if self.conf['level_indices'] not in [None, "all"] else \
             list(reversed(range(feature_manager.num_levels)))
+        from ._timing import gc_paused
         outputs = {}
-        for level_index in levels:
-            out = self.refine(reconstruction, feature_manager.fset(level_index), problem_setup)
-            for k, v in out.items():
-                outputs.setdefault(k, []).append(v)
+        with gc_paused():
+            for level_index in levels:
+                out = self.refine(reconstruction, feature_manager.fset(level_index), problem_setup)
+                for k, v in out.items():
+                    outputs.setdefault(k, []).append(v)
         return outputs
 
 

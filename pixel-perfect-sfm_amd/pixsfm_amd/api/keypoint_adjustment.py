@@ -303,12 +303,14 @@ class KeypointAdjuster:
             root_labels = base.compute_root_labels(graph, track_labels, score_labels)
         levels = self.conf['level_indices'] if self.conf['level_indices'] not in [None, "all"] else \
             list(reversed(range(feature_manager.num_levels)))
+        from ._timing import gc_paused
         outputs = {}
-        for level_index in levels:
-            out = self.refine(keypoints_dict, feature_manager.fset(level_index), graph, track_labels, root_labels,
-                              problem_setup=problem_setup)
-            for k, v in out.items():
-                outputs.setdefault(k, []).append(v)
+        with gc_paused():
+            for level_index in levels:
+                out = self.refine(keypoints_dict, feature_manager.fset(level_index), graph, track_labels, root_labels,
+                                  problem_setup=problem_setup)
+                for k, v in out.items():
+                    outputs.setdefault(k, []).append(v)
         return outputs
 
     _solver_cls = None

@@ -413,3 +413,25 @@ def test_scene_dump_point_ids_dense_and_sparse(stride):
         rec, fv, _ = build(extra_id=missing)
         with pytest.raises(KeyError):
             B._SceneDump(rec, fv)
+
+
+def test_gc_is_paused_during_a_refinement_call_and_restored():
+    """pixsfm_amd.api._timing.gc_paused: the collector is off inside the block, back to its previous state afterwards (also
+    when the block raises, also when it was off to begin with)."""
+    import gc
+    from pixsfm_amd.api._timing import gc_paused
+    assert gc.isenabled()
+    with gc_paused():
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    with pytest.raises(RuntimeError):
+        with gc_paused():
+            raise RuntimeError("x")
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with gc_paused():
+            assert not gc.isenabled()
+        assert not gc.isenabled()
+    finally:
+        gc.enable()

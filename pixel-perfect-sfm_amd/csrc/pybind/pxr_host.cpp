@@ -198,6 +198,32 @@ py::tuple gather_patches(py::list patch_list) {
   return py::make_tuple(index, uniq, as_array(ptrs), c, sc);
 }
 
+// Slot of every object of `items` in the list `uniq` (by identity), -1 where it is not in it: the second consumer of a shared
+// arena (features.SharedArena) finds its patches among the uploaded ones without a Python dict of a million ids.
+py::array_t<int64_t> slots_of(py::list uniq, py::list items) {
+  const py::ssize_t nu = py::len(uniq), n = py::len(items);
+  size_t cap = 16;
+  while (cap < (size_t)nu * 2) cap <<= 1;
+  std::vector<PyObject*> keys(cap, nullptr);
+  std::vector<int64_t> vals(cap, 0);
+  auto hash = [cap](PyObject* p) { return (size_t)(((uintptr_t)p >> 4) * 0x9E3779B97F4A7C15ull) & (cap - 1); };
+  for (py::ssize_t k = 0; k < nu; ++k) {
+    PyObject* p = PyList_GET_ITEM(uniq.ptr(), k);
+    size_t h = hash(p);
+    while (keys[h] && keys[h] != p) h = (h + 1) & (cap - 1);
+    if (!keys[h]) { keys[h] = p; vals[h] = k; }
+  }
+  py::array_t<int64_t> out(n);
+  int64_t* o = out.mutable_data();
+  for (py::ssize_t k = 0; k < n; ++k) {
+    PyObject* p = PyList_GET_ITEM(items.ptr(), k);
+    size_t h = hash(p);
+    while (keys[h] && keys[h] != p) h = (h + 1) & (cap - 1);
+    o[k] = keys[h] ? vals[h] : -1;
+  }
+  return out;
+}
+
 // has_patch flags of the sparse feature maps: patch_dicts[k] is the {keypoint id: patch} dict of image k (or None: nothing set
 // for that image), p2d_ptr the first point2D slot of every image.  flags[p2d_ptr[k] + id] = 1 for every key inside the image's
 // keypoint range (one PyDict_Next walk per image instead of a numpy array of the keys + isin).
@@ -231,5 +257,6 @@ PYBIND11_MODULE(_pxr_host, m) {
   m.def("scene_arrays", &scene_arrays, py::arg("images"), py::arg("points"), py::arg("img_of"));
   m.def("gather_patches", &gather_patches, py::arg("patch_list"));
   m.def("patch_flags", &patch_flags, py::arg("patch_dicts"), py::arg("p2d_ptr"));
+  m.def("slots_of", &slots_of, py::arg("uniq"), py::arg("items"));
   m.def("patches_of", &patches_of, py::arg("patch_dicts"), py::arg("dense_flags"), py::arg("obs_image"), py::arg("obs_p2d"));
 }

@@ -465,7 +465,7 @@ class SharedArena:
     one built instead of sending 64 KB per observation over PCIe again.  A context manager: the arena is freed on exit."""
 
     def __init__(self):
-        self.arena, self.slot = None, {}
+        self.arena, self.slot, self.uniq = None, {}, None     # slot: id(patch) -> arena slot (built on demand); uniq: the patches by slot
 
     def __enter__(self):
         return self
@@ -476,7 +476,7 @@ class SharedArena:
     def close(self):
         if self.arena is not None:
             self.arena.close()
-        self.arena, self.slot = None, {}
+        self.arena, self.slot, self.uniq = None, {}, None
 
 
 def to_arena(ctx, patch_list, cache=None):
@@ -486,10 +486,19 @@ def to_arena(ctx, patch_list, cache=None):
     if not patch_list:
         raise ValueError("no patches")
     if cache is not None and cache.arena is not None:
-        try:
-            return ArenaRef(cache.arena, [cache.slot[id(p)] for p in patch_list], owned=False)
-        except KeyError:
+        host = _host_module()
+        if host is not None and hasattr(host, "slots_of") and cache.uniq is not None:
+            index = host.slots_of(cache.uniq, list(patch_list))            # identity lookup in C++ (no dict of a million ids)
+            if len(index) and index.min() >= 0:
+                return ArenaRef(cache.arena, index, owned=False)
             cache = None                         # a patch the shared arena does not hold: an arena of this call's own
+        else:
+            if not cache.slot and cache.uniq is not None:
+                cache.slot = {id(p): k for k, p in enumerate(cache.uniq)}
+            try:
+                return ArenaRef(cache.arena, [cache.slot[id(p)] for p in patch_list], owned=False)
+            except KeyError:
+                cache = None
     on_device = [isinstance(p, ArenaPatch) for p in patch_list]
     if all(on_device):
         arena = patch_list[0].arena
@@ -524,8 +533,8 @@ def to_arena(ctx, patch_list, cache=None):
     # the patches go up one by one through pinned staging buffers (no np.stack of the set: 65 GB at BASELINE configs[2])
     arena = PatchArena.from_patch_pointers(ctx, pointers, shape, dtype, corners, scales)
     if cache is not None:
-        cache.arena = arena
-        cache.slot = slot if slot is not None else {id(p): k for k, p in enumerate(uniq)}
+        cache.arena, cache.uniq = arena, uniq
+        cache.slot = slot if slot is not None else {}        # the compiled path looks patches up by identity in C++ (slots_of)
         return ArenaRef(arena, index, owned=False)
     return ArenaRef(arena, index, owned=True)
 

@@ -435,3 +435,24 @@ def test_gc_is_paused_during_a_refinement_call_and_restored():
         assert not gc.isenabled()
     finally:
         gc.enable()
+
+
+def test_compiled_slot_lookup_by_identity():
+    """_pxr_host.slots_of: position of every item in `uniq` by object identity, -1 for strangers (the shared-arena lookup
+    of features.to_arena)."""
+    from pixsfm_amd.api import features
+    host = features._host_module()
+    if host is None or not hasattr(host, "slots_of"):
+        pytest.skip("_pxr_host was not built")
+    uniq = [object() for _ in range(1000)]
+    rng = np.random.default_rng(0)
+    pick = rng.integers(0, 1000, 5000)
+    items = [uniq[k] for k in pick]
+    assert np.array_equal(host.slots_of(uniq, items), pick)
+    stranger = object()
+    out = host.slots_of(uniq, [uniq[3], stranger, uniq[999]])
+    assert out.tolist() == [3, -1, 999]
+    assert host.slots_of([], [stranger]).tolist() == [-1] and len(host.slots_of(uniq, [])) == 0
+    # equal but distinct objects are different patches
+    a, b = (1, 2), tuple([1, 2])
+    assert host.slots_of([a], [b]).tolist() == [-1]

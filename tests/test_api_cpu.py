@@ -456,3 +456,34 @@ def test_compiled_slot_lookup_by_identity():
     # equal but distinct objects are different patches
     a, b = (1, 2), tuple([1, 2])
     assert host.slots_of([a], [b]).tolist() == [-1]
+
+
+def test_scene_dump_with_a_patch_container_that_is_not_a_dict():
+    """The compiled has_patch walk takes plain dicts (PyDict_Next); any other mapping falls back to the numpy form and
+    gives the same flags."""
+    import collections
+    from pixsfm_amd.api import bundle_adjustment as B, features
+    from pixsfm_amd.api.reconstruction import Camera, Image, Point2D, Point3D, Reconstruction
+    if B._host_module() is None:
+        pytest.skip("_pxr_host was not built")
+    rec = Reconstruction()
+    rec.add_camera(Camera(1, "SIMPLE_PINHOLE", 100, 100, [50.0, 50, 50]))
+    images = [Image(1 + i, "im%d.jpg" % i, 1, [1, 0, 0, 0], [0, 0, 0]) for i in range(3)]
+    for p in range(9):
+        rec.add_point3D(p + 1, Point3D(np.zeros(3)))
+        for im in (images[p % 3], images[(p + 1) % 3]):
+            im.points2D.append(Point2D([0, 0], p + 1))
+            rec.points3D[p + 1].track.add_element(im.image_id, len(im.points2D) - 1)
+    for im in images:
+        rec.add_image(im)
+    fmaps = {}
+    for k, im in enumerate(images):
+        fm = features.FeatureMap()
+        patches = {j: features.FeaturePatch(np.zeros((2, 2, 8), np.float16), (j, k), (1.0, 1.0))
+                   for j in range(len(im.points2D)) if (j + k) % 3}
+        fm.patches = collections.UserDict(patches) if k == 1 else patches
+        fmaps[im.name] = fm
+    fv = B.FeatureView(features.FeatureSet(fmaps), rec)
+    a, b = B._SceneDump(rec, fv, use_compiled=True), B._SceneDump(rec, fv, use_compiled=False)
+    assert a.compiled and np.array_equal(a.has_patch, b.has_patch) and a.has_patch.dtype == b.has_patch.dtype
+    assert 0 < a.has_patch.sum() < len(a.has_patch)

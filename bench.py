@@ -10,10 +10,15 @@ L2-normalisation with analytic gradient, reference subtraction and the six-scala
 that stands in for the 128 x (10+K) Jacobian block.  Inputs are resident in HBM when the
 timed region starts.  N > 1: points (with all their observations and patches) are
 partitioned over the ranks, no data-path collective in the evaluation.  Default = STRONG scaling
-(the target of BASELINE.json: the 1M-observation problem is sharded over the N ranks); --scaling weak lets
-every rank own --points points instead (N x 1M observations in one scene, cameras shared).  The LM loop's
-collective is the native RCCL all-reduce of the engine (pxr_comm_init; falls back to the torch.distributed
-callback if the communicator cannot be created).
+(the target of BASELINE.json: the 1M-observation problem is sharded over the N ranks; the scene is bit for bit the
+one-rank scene); --scaling weak lets every rank own --points points instead (N x 1M observations, cameras shared).
+The LM loop's collective is the native RCCL all-reduce of the engine (pxr_comm_init; falls back to the
+torch.distributed callback if the communicator cannot be created).
+
+Launching: under torch.distributed.run (RANK / WORLD_SIZE in the environment) every process is one rank.  A PLAIN
+`python bench.py --gpus N` (no RANK in the environment) spawns its N ranks itself -- one subprocess per GPU with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set -- re-prints rank 0's JSON line last and
+exits non-zero if any rank failed (the others are stopped: a rank left alone in a collective would hang).
 
 Rank 0 prints ONE JSON line; see DESIGN.md section "Measurement" for the roofline and
 cpu_baseline definitions.  Besides the contract's fields it carries `lm` / `lm_no_inner` (LM iterations/s
@@ -21,16 +26,18 @@ on the same problem), `ka` (BASELINE configs[1]) and `costmap` (the reference's 
 same scene: cost-map extraction + cost-map BA).
 """
 import argparse
+import glob
 import json
 import os
+import re
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pixel-perfect-sfm_amd"))
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -40,22 +47,191 @@ def algorithmic_bytes_per_obs(C, K=4, elem=2):
     return 16 * C * elem + C * 8 + 8 * (10 + K) + 16
 
 
-def cpu_baseline(prob, patches, n_sample, budget_s=10.0, lm_gauge=None):
-    """The CPU legs, timed on this box's host cores on a bounded sample of the same workload (whole points: the
-    first n_sample observations' points with all their observations; every camera):
-      cpu_baseline      -- the oracle (kind "port"): materialised 128 x (10+K) Jacobian blocks + loss per residual
-                           block, threaded over blocks like Ceres (bundle_adjustment_options.h:58);
-      cpu_baseline_lm_projected -- one LM iteration of the oracle's Schur path (oracle/pxo_lm_bench.c: Jacobian evaluation,
-                           Schur elimination, Cholesky, back-substitution, residual-only evaluation of the candidate),
-                           all cores; the per-observation stages are scaled to the full problem, the Cholesky is not;
-      cpu_reference_kernel -- the REFERENCE's own AVX2/F16C bicubic kernels (cubic_hermite_spline_simd.h + grid2d.h
-                           compiled in place, oracle/_ref): interpolation only (value + both derivatives of one
-                           16x16x128 fp16 patch), no projection / normalisation / Jacobian / loss.
-    The sample's touched working set (4 KiB stencil per observation + references) is stated next to each figure."""
+# ---------------------------------------------------------------------------------------------------------------------
+# launching: a plain `python bench.py --gpus N` is its own launcher
+# ---------------------------------------------------------------------------------------------------------------------
+def self_launch(argv, n_ranks):
+    """Spawn `n_ranks` copies of this script (rank r on GPU r), wait, re-print rank 0's JSON line last.
+    Returns the exit code: 0 only if every rank exited 0 and rank 0 printed its line."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out0 = tempfile.TemporaryFile(mode="w+")
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n_ranks))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=out0 if r == 0 else sys.stderr, stderr=sys.stderr))
+    limit = float(os.environ.get("PXR_BENCH_LAUNCH_TIMEOUT", "3600"))
+    t0, failed = time.time(), None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() - t0 > limit:
+            failed = (-1, 124)
+            break
+        time.sleep(0.1)
+    if failed is not None:
+        for p in procs:                      # exactly the processes started here, by handle
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        print("bench.py launcher: %s -- the other ranks were stopped" %
+              ("timed out after %.0f s" % limit if failed[0] < 0 else "rank %d exited with code %d" % failed), file=sys.stderr)
+        return failed[1] if 0 < failed[1] < 256 else 1
+    out0.seek(0)
+    lines = out0.read().splitlines()
+    last = max((i for i, l in enumerate(lines) if l.startswith("{") and l.rstrip().endswith("}")), default=None)
+    for i, l in enumerate(lines):
+        if i != last:
+            print(l, file=sys.stderr)
+    if last is None:
+        print("bench.py launcher: rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    sys.stderr.flush()
+    print(lines[last], flush=True)
+    return 0
+
+
+def _selftest_hooks(rank):
+    """PXR_BENCH_SELFTEST="fail:R" / "hang:R" (comma separated): rank R exits with code 3 / sleeps, before any GPU work.
+    Lets tests/ exercise the launcher's failure path on a box without a GPU."""
+    for item in filter(None, os.environ.get("PXR_BENCH_SELFTEST", "").split(",")):
+        what, _, who = item.partition(":")
+        if who != "" and int(who) == rank:
+            if what == "fail":
+                raise SystemExit(3)
+            if what == "hang":
+                time.sleep(600)
+            if what == "ok":
+                print(json.dumps({"selftest": True, "rank": rank}))
+                raise SystemExit(0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# clocks / power: what tells a slower box from a regression
+# ---------------------------------------------------------------------------------------------------------------------
+class GpuTelemetry:
+    """Samples the shader clock and the package power of one GPU from sysfs while a loop runs (amdgpu: pp_dpm_sclk marks
+    the current level with '*', hwmon power1_average / power1_input are microwatts).  Everything is best effort: a field
+    that cannot be read is reported as null."""
+
+    def __init__(self, device_index):
+        self.sclk_path = self.power_path = self.mclk_path = None
+        self.note = None
+        try:
+            import torch
+            bus = torch.cuda.get_device_properties(device_index).pci_bus_id
+            dom = getattr(torch.cuda.get_device_properties(device_index), "pci_domain_id", 0)
+            dev = getattr(torch.cuda.get_device_properties(device_index), "pci_device_id", 0)
+            want = "%04x:%02x:%02x" % (dom, bus, dev)
+        except Exception:  # noqa: BLE001
+            want = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        pick = None
+        for c in cards:
+            if not os.path.exists(os.path.join(c, "pp_dpm_sclk")):
+                continue
+            real = os.path.realpath(c)
+            if want and want in real:
+                pick = c
+                break
+            if pick is None:
+                pick = c
+        if pick is None:
+            self.note = "no amdgpu sysfs node with pp_dpm_sclk"
+            return
+        self.sclk_path = os.path.join(pick, "pp_dpm_sclk")
+        if os.path.exists(os.path.join(pick, "pp_dpm_mclk")):
+            self.mclk_path = os.path.join(pick, "pp_dpm_mclk")
+        for name in ("power1_average", "power1_input"):
+            hits = glob.glob(os.path.join(pick, "hwmon", "hwmon*", name))
+            if hits:
+                self.power_path = hits[0]
+                break
+        self.sysfs = pick
+
+    @staticmethod
+    def _current_mhz(path):
+        try:
+            with open(path) as fh:
+                for line in fh:
+                    if "*" in line:
+                        m = re.search(r"(\d+)\s*[Mm][Hh]z", line)
+                        if m:
+                            return float(m.group(1))
+        except OSError:
+            pass
+        return None
+
+    def read(self):
+        w = None
+        if self.power_path:
+            try:
+                with open(self.power_path) as fh:
+                    w = float(fh.read().strip()) * 1e-6
+            except (OSError, ValueError):
+                pass
+        return (self._current_mhz(self.sclk_path) if self.sclk_path else None,
+                self._current_mhz(self.mclk_path) if self.mclk_path else None, w)
+
+    def sample_while(self, fn, interval=0.01):
+        """Runs fn() while a thread samples; returns the summary dict."""
+        rows, stop = [], threading.Event()
+
+        def loop():
+            while not stop.is_set():
+                rows.append(self.read())
+                time.sleep(interval)
+        th = threading.Thread(target=loop, daemon=True)
+        th.start()
+        try:
+            fn()
+        finally:
+            stop.set()
+            th.join()
+
+        def stats(k):
+            v = [r[k] for r in rows if r[k] is not None]
+            return None if not v else {"min": min(v), "mean": sum(v) / len(v), "max": max(v)}
+        return {"samples": len(rows), "sclk_mhz": stats(0), "mclk_mhz": stats(1), "power_w": stats(2),
+                "source": getattr(self, "sysfs", None), "note": self.note}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU legs (rank 0, one GPU): the oracle / the reference's own code on the host cores, timed inside C
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(prob, patches, n_sample, lm_gauge=None):
+    """The CPU legs on a bounded sample of the same workload (whole points: the first n_sample observations' points with
+    all their observations; every camera), each timed INSIDE C by the persistent-thread harness of
+    oracle/pxo_bench_harness.h over {cores/4, cores/2, cores, 2 x cores} threads (best reported, with the single-thread
+    rate, the scaling efficiency and the harness_limited guard):
+      cpu_baseline          kind "reference": the reference's own FeatureReferenceCostFunctor (compiled in place,
+                            oracle/_ref/libpxo_ref_bench.so) on dual numbers like ceres::AutoDiffCostFunction -- residual
+                            + 128 x (10+K) Jacobian per block, threaded over blocks like Ceres
+                            (bundle_adjustment_options.h:58); falls back to the port where oracle/_ref is absent;
+      cpu_baseline_port     kind "port": the oracle's C restatement (analytic Jacobians, materialised, + loss);
+      cpu_reference_kernel  the reference's AVX2/F16C BiCubicInterpolator::EvaluateSIMD alone;
+      cpu_baseline_lm_projected  one LM iteration of the oracle's Schur path (oracle/pxo_lm_bench.c, OpenMP), the
+                            per-observation stages scaled to the full problem, the Cholesky not."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import ctypes
-    from concurrent.futures import ThreadPoolExecutor
     import pxo
+    import pxo_cpubench
     n_obs = len(prob["obs_image"])
     n_pts_s = int(prob["obs_point"][min(n_sample, n_obs) - 1]) + 1          # whole points (observations are point-sorted)
     n_sample = int(np.searchsorted(prob["obs_point"], n_pts_s, side="left")) if n_pts_s < len(prob["xyz"]) else n_obs
@@ -64,86 +240,70 @@ def cpu_baseline(prob, patches, n_sample, budget_s=10.0, lm_gauge=None):
         sub[k] = prob[k][:n_sample]
     sub["xyz"], sub["refs"] = prob["xyz"][:n_pts_s], prob["refs"][:n_pts_s]
     sub["patches"] = patches[:n_sample].cpu().numpy()
-    cores = os.cpu_count() or 1
+    host = np.zeros((len(prob["cam_model"]), 12)); host[:, :prob["cam_params"].shape[1]] = prob["cam_params"]
+    sub["cam_params"] = host
     touched_mb = n_sample * (16 * 128 * 2 + 128 * 8 / 5) / 1e6
     cfg, ls = pxo.cfg(), pxo.loss("cauchy", 0.25)
-    pxo.ba_eval_batch(sub, cfg, ls, count=min(n_sample, 2048), n_threads=cores)       # warm-up / page-in
-    t0 = time.perf_counter()
-    passes = 0
-    while True:
-        pxo.ba_eval_batch(sub, cfg, ls, n_threads=cores)
-        passes += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or passes >= 2000:
-            break
-    out = {"cpu_baseline": {
-        "value": n_sample * passes / dt, "unit": "residual_blocks/s", "cores": cores, "kind": "port",
-        "sample": "%d passes over the first %d observations (%d whole points) of the same workload (%.1f s), oracle C "
-                  "restatement, materialised 128x(10+K) Jacobians + Cauchy loss, %d pthreads; touched working set "
-                  "%.0f MB (stencils + references)" % (passes, n_sample, n_pts_s, dt, cores, touched_mb)}}
-    # ---- one LM iteration on the host cores ------------------------------------------------------------------
+    what = ("first %d observations (%d whole points, all %d cameras) of the same workload; every thread works on its own "
+            "first-touched copy of its share; touched working set %.0f MB of stencils + references"
+            % (n_sample, n_pts_s, len(prob["image_camera"]), touched_mb))
+    out = {}
+    port = pxo_cpubench.ba_eval_port(sub, cfg, ls)
+    port["sample"] = what + "; oracle C restatement: analytic 128x(10+K) Jacobians materialised + Cauchy loss"
+    try:
+        ref = pxo_cpubench.ba_eval_reference(sub)
+    except Exception as e:  # noqa: BLE001 -- oracle/_ref is optional (built from /root/reference in the build container)
+        ref, port["reference_leg_error"] = None, repr(e)
+    if ref is not None:
+        ref["sample"] = what + ("; the reference's FeatureReferenceCostFunctor + PatchInterpolator + BiCubicInterpolator::"
+                                "EvaluateSIMD + WorldToPixel compiled in place (-O3 -mavx2 -mf16c -mfma) and evaluated on "
+                                "10+K-wide dual numbers like ceres::AutoDiffCostFunction (Jet / Eigen / COLMAP camera model "
+                                "are stand-ins, oracle/ref_stubs); loss + corrector not included")
+        out["cpu_baseline"], out["cpu_baseline_port"] = ref, port
+    else:
+        out["cpu_baseline"] = port
+    try:
+        kern = pxo_cpubench.bicubic_reference(sub)
+        if kern is not None:
+            kern["sample"] = ("%d fp16 16x16x128 patches, BiCubicInterpolator::EvaluateSIMD of the reference compiled in place; "
+                              "INTERPOLATION ONLY -- no projection, normalisation, Jacobian bridge or loss; touched working set "
+                              "%.0f MB" % (n_sample, n_sample * 4096 / 1e6))
+            out["cpu_reference_kernel"] = kern
+    except Exception as e:  # noqa: BLE001
+        out["cpu_reference_kernel"] = {"value": None, "kind": "reference-kernel", "sample": "unavailable: %r" % (e,)}
+    # ---- one LM iteration on the host cores (OpenMP; the thread count that won the evaluation sweep) -----------------
     if lm_gauge is not None:
-        pose_const, tmask, cmask, _ = lm_gauge
+        pose_const, tmask, cmask = lm_gauge
+        threads = int(out["cpu_baseline_port"]["cores"] if "cpu_baseline_port" in out else out["cpu_baseline"]["cores"])
         best = None
         t0 = time.perf_counter()
         for _ in range(3):
             r = pxo.ba_lm_iteration_schur(sub, cfg, ls, pose_const, tmask, cmask, np.zeros(n_pts_s, np.uint8), radius=1e4,
-                                          n_threads=cores, want_step=False)
+                                          n_threads=threads, want_step=False)
             if best is None or r["total_ms"] < best["total_ms"]:
                 best = r
-            if time.perf_counter() - t0 > budget_s:
+            if time.perf_counter() - t0 > 10.0:
                 break
         scale = n_obs / n_sample
         per_obs_ms = best["jacobian_eval_ms"] + best["schur_ms"] + best["backsub_ms"] + best["cost_eval_ms"]
         full_ms = per_obs_ms * scale + best["cholesky_ms"]
         out["cpu_baseline_lm_projected"] = {
-            "value": 1e3 / full_ms, "unit": "LM iterations/s (PROJECTED from the sample, see `sample`)", "cores": cores, "kind": "port",
+            "value": 1e3 / full_ms, "unit": "LM iterations/s (PROJECTED from the sample, see `sample`)", "cores": threads, "kind": "port",
             "ms_per_iteration_projected": full_ms, "rc": best["rc"], "reduced_system": best["n_c"],
             "measured_on_sample_ms": {k: best[k] for k in ("jacobian_eval_ms", "schur_ms", "cholesky_ms", "backsub_ms",
                                                            "cost_eval_ms", "total_ms")},
-            "sample": "one LM iteration (best of <= 3) on the first %d observations (%d whole points, all %d cameras) of "
-                      "the same workload, oracle C restatement with OpenMP over observations / points (Schur "
-                      "elimination with <= 32 private copies of S, blocked Cholesky); projected to the full problem: "
-                      "per-observation stages x %.1f, Cholesky of the same %d x %d system unchanged; no inner iterations"
-                      % (n_sample, n_pts_s, len(prob["image_camera"]), scale, best["n_c"], best["n_c"])}
-    # ---- the reference's own AVX2 kernels (interpolation only) --------------------------------------------------
-    try:
-        ref = pxo.ref()
-        arena = np.ascontiguousarray(sub["patches"]).view(np.uint16)
-        rng = np.random.default_rng(0)
-        rc = np.ascontiguousarray(rng.uniform(6.5, 8.5, (n_sample, 2)))              # around the patch centre
-        idx = np.arange(n_sample, dtype=np.int64)
-        chunks = np.array_split(np.arange(n_sample), cores)
-
-        def work(c):
-            if len(c) == 0:
-                return 0.0
-            return ref.pxo_ref_bicubic_many_half128(ctypes.c_void_p(arena.ctypes.data), ctypes.c_int64(len(c)), 16, 16,
-                                                    ctypes.c_void_p(idx[c[0]:].ctypes.data),
-                                                    ctypes.c_void_p(rc[c[0]:].ctypes.data), None)
-        with ThreadPoolExecutor(cores) as pool:
-            list(pool.map(work, chunks))                                              # warm-up
-            t0 = time.perf_counter()
-            passes = 0
-            while True:
-                list(pool.map(work, chunks))
-                passes += 1
-                dt = time.perf_counter() - t0
-                if dt > budget_s / 2 or passes >= 2000:
-                    break
-        out["cpu_reference_kernel"] = {
-            "value": n_sample * passes / dt, "unit": "bicubic interpolations/s (value + 2 derivatives, 128 channels)",
-            "cores": cores, "kind": "reference-kernel",
-            "sample": "%d passes over %d fp16 16x16x128 patches (%.1f s), the reference's cubic_hermite_spline_simd.h + "
-                      "grid2d.h compiled in place (oracle/_ref), %d threads; INTERPOLATION ONLY -- no projection, "
-                      "normalisation, Jacobian bridge or loss; touched working set %.0f MB"
-                      % (passes, n_sample, dt, cores, n_sample * 4096 / 1e6)}
-    except Exception as e:  # noqa: BLE001 -- oracle/_ref is optional (built from /root/reference in the build container)
-        out["cpu_reference_kernel"] = {"value": None, "kind": "reference-kernel", "sample": "unavailable: %r" % (e,)}
+            "sample": "one LM iteration (best of <= 3, stage times taken inside C) on the first %d observations (%d whole points, "
+                      "all %d cameras) of the same workload, oracle C restatement with OpenMP over observations / points "
+                      "(%d threads; Schur elimination with <= 32 private copies of S, blocked Cholesky); projected to the full "
+                      "problem: per-observation stages x %.1f, Cholesky of the same %d x %d system unchanged; no inner iterations"
+                      % (n_sample, n_pts_s, len(prob["image_camera"]), threads, scale, best["n_c"], best["n_c"])}
     return out
 
 
-def main():
+# ---------------------------------------------------------------------------------------------------------------------
+# the GPU legs
+# ---------------------------------------------------------------------------------------------------------------------
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -168,57 +328,59 @@ def main():
                          "solver by image count, cost-map strategy beside it; KA / CPU legs / API timing are skipped")
     ap.add_argument("--no-api-e2e", action="store_true",
                     help="skip the end-to-end timing of the drop-in API calls on host-resident inputs (tools/bench_api_e2e.py)")
+    ap.add_argument("--no-telemetry", action="store_true", help="skip the clock / power sampling loop")
     ap.add_argument("--linear-solver", default="auto", help="auto (by image count, bundle_optimizer.h:180-191) | direct | iterative")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.preset == "aachen":
         args.cams, args.points, args.obs_per_point, args.patch_size = 4000, 1_000_000, 5, 8
         args.no_ka = args.no_api_e2e = args.no_cpu_baseline = True
+    return args
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    # PXR_BENCH_ONE_DEVICE=1 + PXR_BENCH_BACKEND=gloo: several ranks on ONE GPU, used to validate the
-    # multi-process flow (sharding, barriers, max-over-ranks timing, all-reduce callback) on a 1-GPU box
-    if os.environ.get("PXR_BENCH_ONE_DEVICE") == "1":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
-    # PXR_BENCH_FORCE_DIST=1 exercises the RCCL code path with a single rank (used to validate the
-    # all-reduce plumbing on a 1-GPU box)
-    dist_on = world > 1 or os.environ.get("PXR_BENCH_FORCE_DIST") == "1"
-    if dist_on:
+
+class Job:
+    """One rank's view of the run: process group, device, context."""
+
+    def __init__(self, args):
+        import torch
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        # PXR_BENCH_ONE_DEVICE=1 + PXR_BENCH_BACKEND=gloo: several ranks on ONE GPU, used to validate the
+        # multi-process flow (sharding, barriers, max-over-ranks timing, all-reduce callback) on a 1-GPU box
+        if os.environ.get("PXR_BENCH_ONE_DEVICE") == "1":
+            self.local_rank = 0
+        torch.cuda.set_device(self.local_rank)
+        self.dev = "cuda:%d" % self.local_rank
+        # PXR_BENCH_FORCE_DIST=1 exercises the RCCL code path with a single rank
+        self.dist_on = self.world > 1 or os.environ.get("PXR_BENCH_FORCE_DIST") == "1"
+        self.backend = None
+        if self.dist_on:
+            import torch.distributed as dist
+            if "MASTER_ADDR" not in os.environ:
+                os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29531"
+            self.backend = os.environ.get("PXR_BENCH_BACKEND", "nccl")          # "nccl" IS RCCL on ROCm
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device(self.dev))
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+        from pixsfm_amd.engine import Context
+        self.ctx = Context(self.local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        self.collective = "none"
+        if self.dist_on:
+            self._init_collective()
+
+    def _init_collective(self):
+        import numpy as np
+        import torch
         import torch.distributed as dist
-        if "MASTER_ADDR" not in os.environ:
-            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29531"
-        backend = os.environ.get("PXR_BENCH_BACKEND", "nccl")          # "nccl" IS RCCL on ROCm
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    from pixsfm_amd import synthetic_gpu
-    from pixsfm_amd.engine import BAProblem, Context, PatchArena, interp_cfg, make_loss
-
-    C, PS = 128, args.patch_size
-    # points (with their observations, patches and references) are the sharded unit; cameras and poses
-    # are replicated.  weak: the scene grows with the ranks, strong: it is split.
-    total_points = args.points * world if args.scaling == "weak" else args.points
-    per = (total_points + world - 1) // world
-    lo, hi = rank * per, min(total_points, (rank + 1) * per)
-    prob, patches = synthetic_gpu.make_ba_problem_gpu(dev, n_cams=args.cams, n_points=total_points,
-                                                      obs_per_point=args.obs_per_point, channels=C,
-                                                      patch_size=PS, seed=2, point_range=(lo, hi),
-                                                      # 8 x 8 patches leave +-2 px around the stencil: ~1 px initial errors
-                                                      **(dict(rot_deg=0.04, trans=0.003, pt_sigma=0.003) if PS < 16 else {}))
-    n_obs_local = len(prob["obs_image"])
-    ctx = Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    collective = "none"
-    if dist_on:
         from pixsfm_amd import parallel
-        collective = "torch.distributed callback (%s)" % backend
-        if backend == "nccl" and os.environ.get("PXR_BENCH_CALLBACK") != "1":
+        from pixsfm_amd.engine import Context
+        ctx, rank, world = self.ctx, self.rank, self.world
+        self.collective = "torch.distributed callback (%s)" % self.backend
+        if self.backend == "nccl" and os.environ.get("PXR_BENCH_CALLBACK") != "1":
             ok = 1
             try:
                 if world > 1:
@@ -234,10 +396,10 @@ def main():
                 ok = 0
                 print("rank %d: native communicator unavailable (%r)" % (rank, e), file=sys.stderr)
             # every rank must take the same path: one rank on the callback while the others wait in ncclAllReduce would hang
-            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            flag = torch.tensor([ok], device=self.dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
-                collective = "native ncclAllReduce on the engine's stream (pxr_comm_init)"
+                self.collective = "native ncclAllReduce on the engine's stream (pxr_comm_init)"
             else:
                 if ok:
                     ctx.comm_destroy()
@@ -245,167 +407,281 @@ def main():
                     ctx.comm_set_rank(rank, world)
                 if rank == 0:
                     print("using the torch.distributed callback on every rank", file=sys.stderr)
-    arena = PatchArena(ctx, n_obs_local, PS, PS, C, np.float16, device_ptr=patches.data_ptr())
-    arena.upload(0, None, prob["corners"], prob["scales"])
-    ba = BAProblem(ctx, arena, prob)
-    cfg = interp_cfg(use_float_simd=args.float_simd)
+        elif world > 1:
+            ctx.comm_set_rank(rank, world)
 
-    def barrier():
-        if dist_on:
+    @property
+    def native(self):
+        return self.collective.startswith("native")
+
+    def barrier(self):
+        import torch
+        if self.dist_on:
+            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
+    def reduce(self, value, op="sum"):
+        """A python float reduced over the ranks."""
+        if not self.dist_on:
+            return value
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([value], dtype=torch.float64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+        return t.item()
+
+    def solve_allreduce(self):
+        """The callback BAProblem.solve needs on the non-native path (None: the engine's own communicator)."""
+        if not self.dist_on or self.native:
+            return None
+        from pixsfm_amd.parallel import make_allreduce
+        return make_allreduce()
+
+
+def default_gauge(n_img, n_pts):
+    """Default gauge (bundle_adjustment/main.py:12-18) and refine flags (bundle_adjustment_options.h:66-76)."""
+    import numpy as np
+    pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
+    tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
+    cmask = np.full(n_img, 0b0110, np.uint16)          # SIMPLE_RADIAL: refine f and k, keep cx, cy
+    return pose_const, tmask, cmask, np.zeros(n_pts, np.uint8)
+
+
+def reset_parameters(ba, prob):
+    import numpy as np
+    for name in ("qvec", "tvec", "xyz"):
+        ba.d[name].upload(prob[name])
+    host = np.zeros((len(prob["cam_model"]), 12)); host[:, :prob["cam_params"].shape[1]] = prob["cam_params"]
+    ba.d["cam_params"].upload(host)
+
+
+def run_eval(job, ba, cfg):
+    """The headline: K timed evaluations between barriers; HIP events on the launch stream for the kernel time."""
+    args, ctx = job.args, job.ctx
     for _ in range(args.warmup):
         ba.eval(cfg, with_jacobian=True)
-    barrier()
+    job.barrier()
     t0 = time.perf_counter()
     ctx.timer_start()
     for _ in range(args.steps):
         ba.eval(cfg, with_jacobian=True)
     kernel_ms = ctx.timer_stop() / args.steps            # HIP events on the launch stream
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist_on:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = tmax.item()
-        ntot = torch.tensor([n_obs_local], dtype=torch.float64, device=dev)
-        dist.all_reduce(ntot)
-        n_obs_total = int(ntot.item())
-    else:
-        n_obs_total = n_obs_local
+    job.barrier()
+    dt = job.reduce(time.perf_counter() - t0, "max")
+    return dt, kernel_ms
+
+
+def run_telemetry(job, ba, cfg):
+    """~0.4 s of the same launches back to back while a thread samples the shader clock / power (the 44 ms timed region is
+    too short to sample); the kernel time of THIS loop is reported beside the samples."""
+    ctx = job.ctx
+    tel = GpuTelemetry(job.local_rank)
+    reps = 400
+    box = {}
+
+    def loop():
+        ctx.timer_start()
+        for _ in range(reps):
+            ba.eval(cfg, with_jacobian=True)
+        box["ms"] = ctx.timer_stop() / reps
+    idle = tel.read()
+    out = tel.sample_while(loop)
+    out["kernel_ms_in_this_loop"] = box.get("ms")
+    out["launches"] = reps
+    out["idle_before"] = {"sclk_mhz": idle[0], "mclk_mhz": idle[1], "power_w": idle[2]}
+    return out
+
+
+def run_lm(job, ba, prob, cfg):
+    """LM iterations / s on the same problem: "lm" = pixsfm's default configuration (use_inner_iterations = True,
+    bundle_adjustment/main.py:43), "lm_no_inner" = the plain trust-region loop.  One iteration = linearise + Schur +
+    Cholesky + back-substitution + evaluation at the trial point.  Same initial parameters for both."""
+    import numpy as np
+    from pixsfm_amd.engine import lm_options, make_loss
+    args, ctx = job.args, job.ctx
+    lm, extra = {}, {}
+    if args.lm_iters <= 0:
+        return lm, extra
+    n_img = args.cams
+    pose_const, tmask, cmask, ptc = default_gauge(n_img, len(prob["xyz"]))
+    for key, inner in (("lm", True), ("lm_no_inner", False)):
+        reset_parameters(ba, prob)
+        job.barrier()
+        if job.dist_on and "allreduce_ms" not in extra:
+            # the collective of the direct solver on its own: the packed upper triangle of [S | rhs], n_c (n_c + 3) / 2 doubles,
+            # n_c = 8 per camera - 7 gauge columns (round 3 moved the full (n_c + 1)^2 square: twice the bytes)
+            n_c = 8 * n_img - 7
+            count = n_c * (n_c + 3) // 2
+            buf = ctx.to_device(np.zeros(count), np.float64)
+            cb = job.solve_allreduce()
+            one = (lambda: ctx.allreduce_sum(buf)) if cb is None else (lambda: cb(buf.ptr.value, count))
+            for _ in range(3):
+                one()
+            ctx.sync(); job.barrier()
+            ctx.timer_start()
+            for _ in range(10):
+                one()
+            extra["allreduce_ms"] = job.reduce(ctx.timer_stop() / 10, "max")
+            extra["allreduce_bytes"] = int(count * 8)
+            extra["allreduce_what"] = "packed upper triangle of [S | rhs] (n_c = %d), %s" % (n_c, job.collective)
+            del buf
+            job.barrier()
+        lm[key] = ba.solve(cfg, make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,
+                           options=lm_options(max_iterations=args.lm_iters, use_inner_iterations=inner,
+                                              linear_solver=args.linear_solver),
+                           allreduce=job.solve_allreduce())
+        job.barrier()
+    return lm, extra
+
+
+def run_costmap(job, ba, prob):
+    """The reference's low-memory strategy on the same scene: cost-map extraction (one HBM-bound pass over
+    the feature arena) and the cost-map BA (3-channel maps, no reference descriptor)."""
+    import numpy as np
+    from pixsfm_amd.engine import interp_cfg, lm_options, make_loss
+    args, ctx = job.args, job.ctx
+    C, PS = 128, args.patch_size
+    n_obs_local = len(prob["obs_image"])
+    reset_parameters(ba, prob)
+    trivial = make_loss("trivial", [])
+    cm = ba.extract_costmaps(trivial)                 # warm-up + the maps used below
+    ctx.sync()
+    reps = 20                                         # > 60 ms at 1M maps: the shader clock has settled (the kernel
+    for _ in range(3):                                # runs at the package power limit, see DESIGN.md section 4)
+        ba.extract_costmaps(trivial, out=cm)
+    ctx.timer_start()
+    for _ in range(reps):
+        ba.extract_costmaps(trivial, out=cm)
+    ex_ms = ctx.timer_stop() / reps
+    ex_bytes = PS * PS * C * 2 + C * 8 + 3 * PS * PS * 2          # feature patch + reference in, 3-channel fp16 map out
+    cba = ba.costmap_problem(cm)
+    cfg_cm = interp_cfg(l2_normalize=False)                       # bundle_adjustment/main.py:270
+    for _ in range(3):
+        cba.eval(cfg_cm, with_jacobian=True)
+    ctx.timer_start()
+    for _ in range(20):
+        cba.eval(cfg_cm, with_jacobian=True)
+    ev_ms = ctx.timer_stop() / 20
+    costmap = {"extract_ms": ex_ms, "maps_per_sec": n_obs_local / (ex_ms * 1e-3),
+               "extract_GBps": ex_bytes * n_obs_local / (ex_ms * 1e-3) / 1e9,
+               "extract_frac_of_peak": ex_bytes * n_obs_local / (ex_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "extract_bytes_per_map": ex_bytes, "kernel": "costmap_kernel_f16_split%s<f16> (%dx%dx128, gradients)" % ("8" if PS == 8 else "", PS, PS),
+               "map_arena_GB": n_obs_local * PS * PS * 3 * 2 / 1e9,
+               "extract_bound": "vector ALU at the package power limit: ~1800 4-cycle vector instructions per lane and map "
+                                "(the reference's double accumulation and half -> double conversions), 1366 W / shader clock "
+                                "2.10 GHz while it runs (profiles/r2_costmap_clock_power.txt, r2_costmap_split_pmc_sq.json)",
+               "eval_ms": ev_ms, "eval_blocks_per_sec": n_obs_local / (ev_ms * 1e-3)}
+    if args.lm_iters > 0:
+        n_img = args.cams
+        pose_const, tmask, cmask, ptc = default_gauge(n_img, len(prob["xyz"]))
+        for key, inner in (("lm", True), ("lm_no_inner", False)):
+            reset_parameters(ba, prob)
+            s = cba.solve(cfg_cm, make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,
+                          options=lm_options(max_iterations=args.lm_iters, use_inner_iterations=inner))
+            costmap[key] = {"iters_per_sec": s["iterations"] / (s["total_ms"] * 1e-3), "iterations": s["iterations"],
+                            "successful": s["num_successful"], "ms_per_iter": s["total_ms"] / max(1, s["iterations"]),
+                            "initial_cost": s["initial_cost"], "final_cost": s["final_cost"], "inner_iterations": inner}
+    return costmap
+
+
+def committed_traffic(world, n_obs_total, float_simd):
+    """HBM bytes per launch of the dominant kernel from the PMC counters: collected in separate rocprofv3 --pmc passes of this
+    same command (gpurun refuses / forbids mixing passes) and committed under profiles/ -- the NEWEST round's file."""
+    if world != 1 or n_obs_total != 1_000_000 or float_simd:
+        return None, None
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_ba_eval_pmc.json")):
+        m = re.match(r"r(\d+)_ba_eval_pmc\.json$", os.path.basename(path))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), path)
+    if best is None:
+        return None, None
+    with open(best[1]) as fh:
+        rec = json.load(fh)
+    src = ("committed profile profiles/%s (separate rocprofv3 --pmc passes of this command; NOT measured in this run); "
+           "measured at commit %s" % (os.path.basename(best[1]), rec.get("measured_at_commit", "unrecorded")))
+    return rec.get("hbm_bytes_per_launch"), src
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:          # the plain command: be the launcher
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
+    _selftest_hooks(int(os.environ.get("RANK", "0")))
+
+    import numpy as np
+    import torch
+    job = Job(args)
+    rank, world, ctx, dev = job.rank, job.world, job.ctx, job.dev
+
+    from pixsfm_amd import synthetic_gpu
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, make_loss
+
+    C, PS = 128, args.patch_size
+    # points (with their observations, patches and references) are the sharded unit; cameras and poses
+    # are replicated (SURVEY 8e).  weak: the scene grows with the ranks, strong: it is split.
+    total_points = args.points * world if args.scaling == "weak" else args.points
+    per = (total_points + world - 1) // world
+    lo, hi = rank * per, min(total_points, (rank + 1) * per)
+    prob, patches = synthetic_gpu.make_ba_problem_gpu(dev, n_cams=args.cams, n_points=total_points,
+                                                      obs_per_point=args.obs_per_point, channels=C,
+                                                      patch_size=PS, seed=2, point_range=(lo, hi),
+                                                      # 8 x 8 patches leave +-2 px around the stencil: ~1 px initial errors
+                                                      **(dict(rot_deg=0.04, trans=0.003, pt_sigma=0.003) if PS < 16 else {}))
+    n_obs_local = len(prob["obs_image"])
+    arena = PatchArena(ctx, n_obs_local, PS, PS, C, np.float16, device_ptr=patches.data_ptr())
+    arena.upload(0, None, prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    cfg = interp_cfg(use_float_simd=args.float_simd)
+
+    dt, kernel_ms = run_eval(job, ba, cfg)
+    n_obs_total = int(job.reduce(float(n_obs_local)))
     # ---- what makes a multi-GPU run self-verifying: every rank's share and kernel time, the ranks the native communicator
     # really joined, and the time of the one collective of a direct LM iteration (the [S | rhs] all-reduce) on its own
     per_rank = None
-    if dist_on:
-        mine = torch.tensor([float(rank), float(n_obs_local), kernel_ms, float(local_rank)], dtype=torch.float64, device=dev)
+    if job.dist_on:
+        import torch.distributed as dist
+        mine = torch.tensor([float(rank), float(n_obs_local), kernel_ms, float(job.local_rank)], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         every = torch.stack(every).cpu().numpy()
         comm_rank, comm_n = ctx.comm_rank()
-        seen = torch.tensor([1.0 if collective.startswith("native") and comm_n == world else 0.0], dtype=torch.float64, device=dev)
-        dist.all_reduce(seen)
+        seen = job.reduce(1.0 if job.native and comm_n == world else 0.0)
         per_rank = {"obs_per_gpu": [int(v) for v in every[:, 1]], "kernel_ms": [float(v) for v in every[:, 2]],
                     "kernel_ms_min": float(every[:, 2].min()), "kernel_ms_max": float(every[:, 2].max()),
                     "devices": [int(v) for v in every[:, 3]],
-                    "nranks_seen": int(comm_n) if collective.startswith("native") else world,
-                    "ranks_in_native_communicator": int(seen.item())}
-    cost = ba.cost(make_loss("cauchy", [0.25]))
-    if dist_on:                                   # cost of the whole (sharded) problem
-        ctot = torch.tensor([cost], dtype=torch.float64, device=dev)
-        dist.all_reduce(ctot)
-        cost = ctot.item()
+                    "nranks_seen": int(comm_n),
+                    "ranks_in_native_communicator": int(seen)}
+    cost = job.reduce(ba.cost(make_loss("cauchy", [0.25])))         # cost of the whole (sharded) problem
+    telemetry = None
+    if rank == 0 and not args.no_telemetry:
+        try:
+            telemetry = run_telemetry(job, ba, cfg)
+        except Exception as e:  # noqa: BLE001 -- never let the sampling break the bench
+            telemetry = {"error": repr(e)}
+    job.barrier()
 
-    # ---- second half of the metric: LM iterations / s on the same problem ------------------------
-    # default gauge (bundle_adjustment/main.py:12-18) and refine flags (bundle_adjustment_options.h:66-76);
-    # one iteration = linearise + Schur + Cholesky + back-substitution + evaluation at the trial point.
-    lm, lm_extra = {}, {}
-    if args.lm_iters > 0:
-        from pixsfm_amd.engine import lm_options
-        from pixsfm_amd.parallel import make_allreduce
-        n_img = args.cams
-        pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
-        tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
-        cmask = np.full(n_img, 0b0110, np.uint16)          # SIMPLE_RADIAL: refine f and k, keep cx, cy
-        ptc = np.zeros(len(prob["xyz"]), np.uint8)
-        # "lm": pixsfm's default BA configuration (use_inner_iterations = True, bundle_adjustment/main.py:43);
-        # "lm_no_inner": the plain trust-region loop.  Same initial parameters for both.
-        for key, inner in (("lm", True), ("lm_no_inner", False)):
-            for name in ("qvec", "tvec", "cam_params", "xyz"):
-                host = prob[name]
-                if name == "cam_params":
-                    host = np.zeros((len(prob["cam_model"]), 12)); host[:, :prob["cam_params"].shape[1]] = prob["cam_params"]
-                ba.d[name].upload(host)
-            barrier()
-            if dist_on and collective.startswith("native") and "allreduce_ms" not in lm_extra:
-                # the [S | rhs] buffer of the direct solver: (n_c + 1)^2 doubles, n_c = 8 per camera - 7 gauge columns
-                n_c = 8 * n_img - 7
-                buf = ctx.to_device(np.zeros((n_c + 1) * (n_c + 1)), np.float64)
-                for _ in range(3):
-                    ctx.allreduce_sum(buf)
-                ctx.sync(); barrier()
-                ctx.timer_start()
-                for _ in range(10):
-                    ctx.allreduce_sum(buf)
-                lm_extra["allreduce_ms"] = ctx.timer_stop() / 10
-                lm_extra["allreduce_bytes"] = int((n_c + 1) * (n_c + 1) * 8)
-                del buf
-                barrier()
-            lm[key] = ba.solve(cfg, make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,
-                               options=lm_options(max_iterations=args.lm_iters, use_inner_iterations=inner,
-                                                  linear_solver=args.linear_solver),
-                               allreduce=make_allreduce() if (dist_on and not collective.startswith("native")) else None)
-            barrier()
+    lm, lm_extra = run_lm(job, ba, prob, cfg)
 
-    # ---- the reference's low-memory strategy on the same scene: cost-map extraction (one
-    # HBM-bound pass over the feature arena) and the cost-map BA (3-channel maps, no reference descriptor)
     costmap = None
     if not args.no_costmap and world == 1:
-        from pixsfm_amd.engine import lm_options
-        for name in ("qvec", "tvec", "xyz"):
-            ba.d[name].upload(prob[name])
-        host = np.zeros((len(prob["cam_model"]), 12)); host[:, :prob["cam_params"].shape[1]] = prob["cam_params"]
-        ba.d["cam_params"].upload(host)
-        trivial = make_loss("trivial", [])
-        cm = ba.extract_costmaps(trivial)                 # warm-up + the maps used below
-        ctx.sync()
-        reps = 20                                         # > 60 ms at 1M maps: the shader clock has settled (the kernel
-        for _ in range(3):                                # runs at the package power limit)
-            ba.extract_costmaps(trivial, out=cm)
-        ctx.timer_start()
-        for _ in range(reps):
-            ba.extract_costmaps(trivial, out=cm)
-        ex_ms = ctx.timer_stop() / reps
-        ex_bytes = PS * PS * C * 2 + C * 8 + 3 * PS * PS * 2          # feature patch + reference in, 3-channel fp16 map out
-        cba = ba.costmap_problem(cm)
-        cfg_cm = interp_cfg(l2_normalize=False)                       # bundle_adjustment/main.py:270
-        for _ in range(3):
-            cba.eval(cfg_cm, with_jacobian=True)
-        ctx.timer_start()
-        for _ in range(20):
-            cba.eval(cfg_cm, with_jacobian=True)
-        ev_ms = ctx.timer_stop() / 20
-        costmap = {"extract_ms": ex_ms, "maps_per_sec": n_obs_local / (ex_ms * 1e-3),
-                   "extract_GBps": ex_bytes * n_obs_local / (ex_ms * 1e-3) / 1e9,
-                   "extract_frac_of_peak": ex_bytes * n_obs_local / (ex_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                   "extract_bytes_per_map": ex_bytes, "kernel": "costmap_kernel_f16_split%s<f16> (%dx%dx128, gradients)" % ("8" if PS == 8 else "", PS, PS),
-                   "map_arena_GB": n_obs_local * PS * PS * 3 * 2 / 1e9,
-                   "extract_bound": "vector ALU at the package power limit: ~1800 4-cycle vector instructions per lane and map "
-                                    "(the reference's double accumulation and half -> double conversions), 1366 W / shader clock "
-                                    "2.10 GHz while it runs (profiles/r2_costmap_clock_power.txt, r2_costmap_split_pmc_sq.json)",
-                   "eval_ms": ev_ms, "eval_blocks_per_sec": n_obs_local / (ev_ms * 1e-3)}
-        if args.lm_iters > 0:
-            n_img = args.cams
-            pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
-            tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
-            for key, inner in (("lm", True), ("lm_no_inner", False)):
-                for name in ("qvec", "tvec", "xyz"):
-                    ba.d[name].upload(prob[name])
-                ba.d["cam_params"].upload(host)
-                s = cba.solve(cfg_cm, make_loss("cauchy", [0.25]), pose_const, tmask, np.full(n_img, 0b0110, np.uint16),
-                              np.zeros(len(prob["xyz"]), np.uint8),
-                              options=lm_options(max_iterations=args.lm_iters, use_inner_iterations=inner))
-                costmap[key] = {"iters_per_sec": s["iterations"] / (s["total_ms"] * 1e-3), "iterations": s["iterations"],
-                                "successful": s["num_successful"], "ms_per_iter": s["total_ms"] / max(1, s["iterations"]),
-                                "initial_cost": s["initial_cost"], "final_cost": s["final_cost"], "inner_iterations": inner}
+        costmap = run_costmap(job, ba, prob)
 
+    cpu_base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_base = cpu_baseline(prob, patches, args.cpu_sample, lm_gauge=default_gauge(args.cams, 0)[:3])
     # the other unit of work of the metric: one KA edge (A7).  BASELINE configs[1] (10k tracks / 100k keypoints /
     # 450k edges / 2000 sub-problems): per-edge residual+Jacobian rate and the whole bounded LM; with several ranks the
     # sub-problems are dealt to them (every rank takes part, rank 0 reports)
-    cpu_base = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n_img = args.cams
-        pc = np.zeros(n_img, np.uint8); pc[0] = 1
-        tmk = np.zeros(n_img, np.uint8); tmk[1] = 1
-        cpu_base = cpu_baseline(prob, patches, args.cpu_sample,
-                                lm_gauge=(pc, tmk, np.full(n_img, 0b0110, np.uint16), None))
     ka_result = None
     if not args.no_ka:
         del ba, arena, patches
         torch.cuda.empty_cache()
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_ka
-        ka_result = bench_ka.run(device_index=local_rank, ctx=ctx, rank=rank, world=world)
+        ka_result = bench_ka.run(device_index=job.local_rank, ctx=ctx, rank=rank, world=world,
+                                 cpu_legs=(rank == 0 and world == 1 and not args.no_cpu_baseline))
     # ---- the drop-in calls end to end on HOST-resident inputs (rank 0, one GPU): what a pixsfm user pays, set-up included
     api_e2e = None
     if rank == 0 and world == 1 and not args.no_api_e2e:
@@ -421,19 +697,10 @@ def main():
                            "KeypointAdjuster...refine_multilevel(keypoints, feature_manager, graph) on host FeaturePatch objects "
                            "and Python scene objects, phases from pixsfm_amd.api._timing; building the inputs is not timed")
 
+    result_line = None
     if rank == 0:
         bpo = algorithmic_bytes_per_obs(C)
-        # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of
-        # this same command (gpurun refuses/forbids mixing passes) and committed under profiles/.
-        traffic, traffic_source = None, None
-        for pmc_name in ("r2_ba_eval_pmc.json", "r1_ba_eval_pmc.json"):
-            pmc_path = os.path.join(ROOT, "profiles", pmc_name)
-            if os.path.exists(pmc_path) and world == 1 and n_obs_total == 1_000_000 and not args.float_simd:
-                with open(pmc_path) as fh:
-                    traffic = json.load(fh).get("hbm_bytes_per_launch")
-                traffic_source = "committed profile profiles/%s (separate rocprofv3 --pmc passes of this command; NOT " \
-                                 "measured in this run)" % pmc_name
-                break
+        traffic, traffic_source = committed_traffic(world, n_obs_total, args.float_simd)
         achieved = bpo * n_obs_local / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "featuremetric residuals+Jacobians evaluated/sec (1M obs)",
@@ -462,6 +729,8 @@ def main():
                          "algorithmic_bytes_per_obs": bpo},
             "initial_cost": cost,
         }
+        if telemetry is not None:
+            out["telemetry"] = telemetry
         for key, v in lm.items():
             out[key] = {"iters_per_sec": v["iterations"] / (v["total_ms"] * 1e-3), "iterations": v["iterations"],
                         "successful": v["num_successful"], "ms_per_iter": v["total_ms"] / max(1, v["iterations"]),
@@ -470,7 +739,8 @@ def main():
                         "linear_solver": "point Schur complement (LDS-privatised) + hand-written blocked dense Cholesky"
                                          if v["linear_solver"] == 1 else
                                          "implicit Schur complement, block-Jacobi preconditioned CG (ITERATIVE_SCHUR regime)",
-                        "linear_iterations": v["linear_iterations"], "collective": collective,
+                        "linear_iterations": v["linear_iterations"], "collective": job.collective,
+                        "collective_KiB_per_solve": v.get("collective_kib", 0),
                         "inner_iterations": key == "lm"}
         if cpu_base is not None:
             out.update(cpu_base)
@@ -480,14 +750,12 @@ def main():
             out["costmap"] = costmap
         if api_e2e is not None:
             out["api_e2e"] = api_e2e
-        out["collective"] = collective
+        out["collective"] = job.collective
         if per_rank is not None:
             out["ranks"] = per_rank
         if "lm" in out:
             out["lm"].update(lm_extra)
         result_line = json.dumps(out)
-    else:
-        result_line = None
     # The JSON line must be the last thing on stdout: native libraries (RCCL's version banner, ...) write to the C
     # stdio buffer of every rank, which would otherwise be flushed at exit -- after the line.  Flush it now, wait for
     # all ranks, tear the process group down, then print.
@@ -495,7 +763,8 @@ def main():
     libc = ctypes.CDLL(None)
     libc.fflush(None)
     sys.stdout.flush()
-    if dist_on:
+    if job.dist_on:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
         libc.fflush(None)

@@ -220,8 +220,10 @@ typedef struct {
   double total_ms;         /* wall time of the LM loop (set-up excluded)                */
   double setup_ms;         /* host-side index construction + allocations                */
   int32_t linear_solver;   /* PXR_LINEAR_DIRECT / _ITERATIVE actually used (BA)         */
-  int32_t reserved_;
-  int64_t linear_iterations; /* conjugate-gradient iterations summed over the LM attempts (iterative solver)   */
+  int32_t collective_kib;   /* several ranks, direct solver: KiB moved per [S | rhs] all-reduce (packed upper triangle), else 0 */
+  int64_t linear_iterations; /* pxr_ba_solve: conjugate-gradient iterations summed over the LM attempts (iterative solver);
+                                pxr_ka_solve: node stencils (4 x 4 texels x C) interpolated over the solve -- its
+                                algorithmic traffic is that count x 16 x C x sizeof(storage type)                 */
 } pxr_lm_summary;
 
 /* ceres::IterationCallback of the BA solve (the `solver.callbacks` of pixsfm's option dicts, base/src/callbacks.h; the

@@ -1,0 +1,244 @@
+"""CPU legs of bench.py (TEST INFRASTRUCTURE ONLY -- imported by bench.py's cpu_baseline() and by tests/).
+
+Every leg is timed INSIDE C by the persistent-thread harness of pxo_bench_harness.h (pinned threads created once,
+thread-local first-touched copies of the sample, >= `min_seconds` of back-to-back passes between two barriers); this
+module only sweeps the thread count and reports.  Legs:
+
+  ba_eval_reference  kind "reference": the reference's own FeatureReferenceCostFunctor compiled in place
+                     (oracle/ref_bench_shim.cc -> _ref/libpxo_ref_bench.so), evaluated on dual numbers like
+                     ceres::AutoDiffCostFunction does -- residual + 128 x (10+K) Jacobian per residual block;
+  ba_eval_port       kind "port": the oracle's C restatement with analytic Jacobians + loss (oracle/pxo_cpubench.c);
+  bicubic_reference  kind "reference-kernel": BiCubicInterpolator::EvaluateSIMD alone;
+  ka_solve_port      kind "port": keypoint-adjustment sub-problems, one single-threaded solve per task, a pool of threads
+                     over the tasks (keypoint_adjustment/main.py:66-80);
+  ka_edge_reference  kind "reference": FeatureMetric2DCostFunctor on dual numbers, per residual block.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+import pxo
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_bench_ref = None
+
+
+def ref_bench_lib():
+    global _bench_ref
+    if _bench_ref is None:
+        path = os.path.join(HERE, "_ref", "libpxo_ref_bench.so")
+        if not os.path.exists(path):
+            return None
+        _bench_ref = C.CDLL(path)
+    return _bench_ref
+
+
+def cpu_topology():
+    """(logical CPUs this process may run on, physical cores among them, NUMA nodes)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in allowed:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as fh:
+                cores.add(fh.read().strip())
+        except OSError:
+            cores.add(str(c))
+    try:
+        nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+    except OSError:
+        nodes = 1
+    return len(allowed), max(1, len(cores)), max(1, nodes)
+
+
+def thread_counts(logical):
+    """{cores/4, cores/2, cores, 2 x cores} of the logical CPUs (deduplicated, >= 1)."""
+    return sorted({max(1, logical // 4), max(1, logical // 2), logical, 2 * logical})
+
+
+def sweep(run, n_items, unit, min_seconds=0.25, single_items=None, counts=None):
+    """run(n, n_threads, min_seconds) -> (seconds, passes, calib_seconds, pinned) over the first n items.
+    Returns the report dict: best rate over the thread counts, the single-thread rate (on `single_items` items), the
+    scaling efficiency and the harness_limited guard (best < 0.4 x physical cores x single-thread rate)."""
+    logical, physical, nodes = cpu_topology()
+    counts = counts or thread_counts(logical)
+    n1 = int(min(n_items, single_items or max(64, n_items // max(1, logical))))
+    sec, passes, _, pinned = run(n1, 1, max(min_seconds, 0.2))
+    single = n1 * passes / sec
+    rates = {}
+    for t in counts:
+        if t == 1:
+            rates[1] = single
+            continue
+        sec, passes, calib, pinned = run(n_items, t, min_seconds)
+        rates[t] = n_items * passes / sec
+    best_t = max(rates, key=rates.get)
+    best = rates[best_t]
+    ideal = min(best_t, physical) * single
+    return {"value": best, "unit": unit, "cores": best_t, "single_thread": single, "logical_cpus": logical,
+            "physical_cores": physical, "numa_nodes": nodes, "sweep": {str(t): rates[t] for t in sorted(rates)},
+            "scaling_efficiency": best / ideal if ideal > 0 else None,
+            "harness_limited": bool(best < 0.4 * physical * single) if logical > 1 else False,
+            "pinned_threads": bool(pinned), "timed_in": "C (persistent pinned pthreads, barriers, thread-local copies)",
+            "n_items": int(n_items)}
+
+
+def _out4():
+    return (C.c_double * 8)()
+
+
+def ba_eval_port(sub, config, ls, min_seconds=0.25):
+    """Residual blocks / s of the oracle port on the sample `sub` (a BA problem dict with 'patches')."""
+    b, keep = pxo.ba_batch(sub)
+    fn = pxo.lib().pxo_bench_ba_eval
+    fn.restype = C.c_int
+
+    def run(n, threads, secs):
+        out = _out4()
+        rc = fn(C.byref(b), C.byref(config), C.byref(ls), C.c_int64(n), int(threads), C.c_double(secs), 1, out)
+        if rc:
+            raise RuntimeError("pxo_bench_ba_eval failed (%d)" % rc)
+        return out[0], out[1], out[2], out[3]
+    rep = sweep(run, b.n_obs, "residual_blocks/s", min_seconds)
+    rep["kind"] = "port"
+    return rep
+
+
+def _ba_ref_args(sub):
+    arena = np.ascontiguousarray(sub["patches"])
+    assert arena.dtype == np.float16 and arena.shape[3] == 128
+    keep = dict(arena=arena.view(np.uint16),
+                obs_patch=np.ascontiguousarray(sub["obs_patch"], np.int64), obs_image=np.ascontiguousarray(sub["obs_image"], np.int32),
+                obs_point=np.ascontiguousarray(sub["obs_point"], np.int32), corners=np.ascontiguousarray(sub["corners"], np.int32),
+                scales=np.ascontiguousarray(sub["scales"], np.float64), qvec=np.ascontiguousarray(sub["qvec"], np.float64),
+                tvec=np.ascontiguousarray(sub["tvec"], np.float64), xyz=np.ascontiguousarray(sub["xyz"], np.float64),
+                cam_params=np.ascontiguousarray(sub["cam_params"], np.float64),
+                image_camera=np.ascontiguousarray(sub["image_camera"], np.int32), refs=np.ascontiguousarray(sub["refs"], np.float64))
+    return keep
+
+
+def ba_eval_reference(sub, min_seconds=0.25):
+    """Residual blocks / s of the REFERENCE's functor under dual-number autodiff (SIMPLE_RADIAL, fp16, 128 channels);
+    None when oracle/_ref/libpxo_ref_bench.so is absent."""
+    lib = ref_bench_lib()
+    if lib is None:
+        return None
+    assert (np.asarray(sub["cam_model"]) == 2).all(), "the reference leg is instantiated for SIMPLE_RADIAL"
+    k = _ba_ref_args(sub)
+    H, W = k["arena"].shape[1], k["arena"].shape[2]
+    fn = lib.pxo_refbench_ba_residual
+    fn.restype = C.c_int
+
+    def run(n, threads, secs):
+        out = _out4()
+        rc = fn(C.c_int64(n), pxo._p(k["arena"]), H, W, pxo._p(k["obs_patch"]), pxo._p(k["obs_image"]), pxo._p(k["obs_point"]),
+                pxo._p(k["corners"]), pxo._p(k["scales"]), pxo._p(k["qvec"]), pxo._p(k["tvec"]), pxo._p(k["xyz"]),
+                pxo._p(k["cam_params"]), int(k["cam_params"].shape[1]), pxo._p(k["image_camera"]), pxo._p(k["refs"]), 1,
+                int(threads), C.c_double(secs), 1, out)
+        if rc:
+            raise RuntimeError("pxo_refbench_ba_residual failed (%d)" % rc)
+        return out[0], out[1], out[2], out[3]
+    rep = sweep(run, len(k["obs_patch"]), "residual_blocks/s", min_seconds)
+    rep["kind"] = "reference"
+    return rep
+
+
+def bicubic_reference(sub, min_seconds=0.25, seed=0):
+    lib = ref_bench_lib()
+    if lib is None:
+        return None
+    arena = np.ascontiguousarray(sub["patches"]).view(np.uint16)
+    n, H, W = arena.shape[0], arena.shape[1], arena.shape[2]
+    rng = np.random.default_rng(seed)
+    rc_ = np.ascontiguousarray(rng.uniform(H / 2 - 1.5, H / 2 + 0.5, (n, 2)))       # around the patch centre
+    idx = np.arange(n, dtype=np.int64)
+    fn = lib.pxo_refbench_bicubic
+    fn.restype = C.c_int
+
+    def run(m, threads, secs):
+        out = _out4()
+        rc = fn(C.c_int64(m), pxo._p(arena), H, W, pxo._p(idx), pxo._p(rc_), int(threads), C.c_double(secs), 1, out)
+        if rc:
+            raise RuntimeError("pxo_refbench_bicubic failed (%d)" % rc)
+        return out[0], out[1], out[2], out[3]
+    rep = sweep(run, n, "bicubic interpolations/s (value + 2 derivatives, 128 channels)", min_seconds)
+    rep["kind"] = "reference-kernel"
+    return rep
+
+
+def _ka_csr(problem):
+    node_problem = np.asarray(problem["node_problem"], np.int64)
+    n_prob = int(node_problem.max()) + 1
+    order = np.argsort(node_problem, kind="stable").astype(np.int32)
+    node_ptr = np.searchsorted(node_problem[order], np.arange(n_prob + 1)).astype(np.int64)
+    edge_problem = node_problem[np.asarray(problem["edge_src"], np.int64)]
+    eorder = np.argsort(edge_problem, kind="stable").astype(np.int32)
+    edge_ptr = np.searchsorted(edge_problem[eorder], np.arange(n_prob + 1)).astype(np.int64)
+    return n_prob, node_ptr, np.ascontiguousarray(order), edge_ptr, np.ascontiguousarray(eorder)
+
+
+def ka_solve_port(problem, config, ls, bound=4.0, opts=None, counts=None):
+    """Sub-problems / s of the oracle's bounded LM, one single-threaded solve per task (the sample `problem`: a KA problem
+    dict with 'patches' and 'node_problem')."""
+    import pxo_ka
+    keep = {}
+
+    def arr(name, dt):
+        keep[name] = np.ascontiguousarray(problem[name], dtype=dt)
+        return keep[name].ctypes.data
+    kp = np.array(problem["kp"], dtype=np.float64, order="C", copy=True)
+    patches = np.ascontiguousarray(problem["patches"])
+    _, H, W, ch = patches.shape
+    b = pxo_ka.KaBatch(len(kp), kp.ctypes.data, arr("node_patch", np.int64), arr("node_const", np.uint8),
+                       len(problem["edge_src"]), arr("edge_src", np.int32), arr("edge_dst", np.int32), arr("edge_w", np.float64),
+                       patches.ctypes.data, pxo._NP2DT[patches.dtype], H, W, ch, arr("corners", np.int32),
+                       arr("scales", np.float64), 0, None, None, None)
+    n_prob, node_ptr, nodes, edge_ptr, edges = _ka_csr(problem)
+    opts = opts or pxo.lm_options(parameter_tolerance=1e-5)
+    fn = pxo.lib().pxo_bench_ka_solve
+    fn.restype = C.c_int
+    iters = {}
+
+    def run(n, threads, secs):
+        out = _out4()
+        rc = fn(C.byref(b), int(n), pxo._p(node_ptr), pxo._p(nodes), pxo._p(edge_ptr), pxo._p(edges), C.byref(config), C.byref(ls),
+                C.c_double(bound), C.byref(opts), int(threads), C.c_double(0.0), out)
+        if rc:
+            raise RuntimeError("pxo_bench_ka_solve failed (%d)" % rc)
+        iters[threads] = out[4] / (out[1] + 1) / max(1, n)
+        return out[0], out[1], out[2], out[3]
+    logical, physical, _ = cpu_topology()
+    rep = sweep(run, n_prob, "sub-problems/s", 0.0, single_items=max(2, min(n_prob, 8)),
+                counts=counts or [t for t in thread_counts(logical) if t <= n_prob] or [1])
+    rep["kind"] = "port"
+    rep["lm_iterations_per_sub_problem"] = iters.get(rep["cores"])
+    rep["edges"] = int(len(problem["edge_src"]))
+    return rep
+
+
+def ka_edge_reference(problem, min_seconds=0.25):
+    lib = ref_bench_lib()
+    if lib is None:
+        return None
+    arena = np.ascontiguousarray(problem["patches"]).view(np.uint16)
+    _, H, W = arena.shape[0], arena.shape[1], arena.shape[2]
+    src, dst = np.ascontiguousarray(problem["edge_src"], np.int32), np.ascontiguousarray(problem["edge_dst"], np.int32)
+    kp = np.ascontiguousarray(problem["kp"], np.float64)
+    node_patch = np.ascontiguousarray(problem["node_patch"], np.int64)
+    corners, scales = np.ascontiguousarray(problem["corners"], np.int32), np.ascontiguousarray(problem["scales"], np.float64)
+    fn = lib.pxo_refbench_ka_edge
+    fn.restype = C.c_int
+
+    def run(n, threads, secs):
+        out = _out4()
+        rc = fn(C.c_int64(n), pxo._p(src), pxo._p(dst), pxo._p(kp), pxo._p(node_patch), pxo._p(arena), H, W, pxo._p(corners),
+                pxo._p(scales), 1, int(threads), C.c_double(secs), out)
+        if rc:
+            raise RuntimeError("pxo_refbench_ka_edge failed (%d)" % rc)
+        return out[0], out[1], out[2], out[3]
+    rep = sweep(run, len(src), "residual_blocks/s (KA edges, residual + 128 x 4 Jacobian)", min_seconds)
+    rep["kind"] = "reference"
+    return rep

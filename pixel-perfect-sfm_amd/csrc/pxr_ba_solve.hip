@@ -636,6 +636,23 @@ __global__ void k_count_above(int64_t n, const double* __restrict__ g, const dou
   if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(out, v);
 }
 
+// Several ranks: only the upper triangle of [S | rhs] carries data (row r: columns r .. n, the last one the right-hand side --
+// one contiguous run of n - r + 1 doubles), so the collective moves the packed n (n + 3) / 2 doubles instead of the n (n + 1)
+// of the square (10.2 MB instead of 20.3 MB at 200 cameras).  One workgroup per row, coalesced both ways.
+__device__ __forceinline__ int64_t packed_row_offset(int n, int r) { return (int64_t)r * (n + 1) - (int64_t)r * (r - 1) / 2; }
+__global__ __launch_bounds__(256) void k_pack_upper(int n, const double* __restrict__ S, double* __restrict__ packed) {
+  const int r = blockIdx.x, len = n - r + 1;
+  const double* src = S + (size_t)r * (n + 1) + r;
+  double* dst = packed + packed_row_offset(n, r);
+  for (int x = threadIdx.x; x < len; x += blockDim.x) dst[x] = src[x];
+}
+__global__ __launch_bounds__(256) void k_unpack_upper(int n, const double* __restrict__ packed, double* __restrict__ S) {
+  const int r = blockIdx.x, len = n - r + 1;
+  double* dst = S + (size_t)r * (n + 1) + r;
+  const double* src = packed + packed_row_offset(n, r);
+  for (int x = threadIdx.x; x < len; x += blockDim.x) dst[x] = src[x];
+}
+
 // keep rank 0's copy of a replicated buffer: the other ranks zero theirs before an all-reduce(sum)
 __global__ void k_zero(int64_t n, double* __restrict__ x) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -869,7 +886,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   const bool iterative = n_c > 0 && (opt->linear_solver == PXR_LINEAR_ITERATIVE ||
                                      (opt->linear_solver == PXR_LINEAR_AUTO && n_img > PXR_MAX_IMAGES_DIRECT));
   sum->linear_solver = iterative ? PXR_LINEAR_ITERATIVE : PXR_LINEAR_DIRECT;
-  sum->linear_iterations = 0; sum->reserved_ = 0;
+  sum->linear_iterations = 0; sum->collective_kib = 0;
   int64_t n_pvar = 0;
   for (int64_t p = 0; p < n_pts; ++p) { pt_var[p] = (!h_point_const[p] && pt_cnt[p + 1] > 0) ? 1 : 0; n_pvar += pt_var[p]; }
   PXR_REQUIRE(n_c > 0 || n_pvar > 0, "pxr_ba_solve: every parameter block is constant");
@@ -1021,6 +1038,10 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   // parameters, same accept / reject / terminate decisions, hence the same sequence of collectives -- rank 0's copy
   // is broadcast: the others zero theirs and join an all-reduce(sum).  Needs the rank (pxr_comm_init / _set_rank).
   const bool bcast = multi && ctx->nranks > 1;
+  DevBuf<double> S_packed;            // the collective's buffer of the direct solver (upper triangle + rhs)
+  const int64_t packed_doubles = (int64_t)n_c * (n_c + 3) / 2;
+  if (multi && !iterative && n_c > 0) RC(S_packed.alloc((size_t)packed_doubles));
+  sum->collective_kib = (multi && !iterative) ? (int)((packed_doubles * 8 + 1023) / 1024) : 0;
   auto from_rank0 = [&](double* buf, int64_t count) -> int {
     if (!bcast) return PXR_OK;
     if (ctx->rank != 0) hipLaunchKernelGGL(k_zero, dim3(nblk(count)), dim3(256), 0, st, count, buf);
@@ -1148,12 +1169,27 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   bool reuse_diag = false;
   bool inner_enabled = opt->use_inner_iterations != 0, inner_useful = false;
   // ceres::IterationCallback (pxr_set_iteration_callback): 1 = SOLVER_ABORT, 2 = SOLVER_TERMINATE_SUCCESSFULLY
+  // Several ranks: a callback installed on SOME ranks only (rank 0 logging, say) must not put the ranks' collectives out of
+  // step -- whether any rank has one is agreed on once here; if so, every rank joins the per-iteration exchange of answers
+  // (a rank without a callback answers "continue").
+  bool any_cb = ctx->iter_cb != nullptr;
+  if (multi) {
+    double h = any_cb ? 1.0 : 0.0;
+    PXR_HIP(hipMemcpyAsync(cb_flags.p, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    RC(ar(cb_flags.p, 1));
+    PXR_HIP(hipMemcpyAsync(&h, cb_flags.p, sizeof(h), hipMemcpyDeviceToHost, st));
+    PXR_HIP(hipStreamSynchronize(st));
+    any_cb = h > 0.0;
+  }
   auto notify = [&](int iteration, bool valid, bool successful, double cost_now, double change, double rel, double radius_next, double step) -> int {
-    if (!ctx->iter_cb) return 0;
-    pxr_iteration_summary is;
-    is.iteration = iteration; is.step_is_valid = valid; is.step_is_successful = successful; is.cost = cost_now; is.cost_change = change;
-    is.relative_decrease = rel; is.trust_region_radius = radius_next; is.step_norm = step;
-    int rc = ctx->iter_cb(&is, ctx->iter_user);
+    if (!any_cb) return 0;
+    int rc = 0;
+    if (ctx->iter_cb) {
+      pxr_iteration_summary is;
+      is.iteration = iteration; is.step_is_valid = valid; is.step_is_successful = successful; is.cost = cost_now; is.cost_change = change;
+      is.relative_decrease = rel; is.trust_region_radius = radius_next; is.step_norm = step;
+      rc = ctx->iter_cb(&is, ctx->iter_user);
+    }
     if (multi) {
       // every rank must leave the loop at the same iteration (the next collective would hang otherwise): the answers are
       // summed over the ranks, an abort anywhere aborts everywhere, else a termination request anywhere terminates
@@ -1214,8 +1250,13 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       }
       LAUNCH_CHECK("schur kernels");
       phase(0);
-      RC(ar(S.p, (int64_t)n_c * ldS));
-      phase(1);          // sum of U_local - Schur_local and of -Y g_p
+      if (multi) {       // sum of U_local - Schur_local and of -Y g_p over the ranks: packed upper triangle + rhs
+        hipLaunchKernelGGL(k_pack_upper, dim3((unsigned)n_c), dim3(256), 0, st, n_c, S.p, S_packed.p);
+        RC(ar(S_packed.p, packed_doubles));
+        hipLaunchKernelGGL(k_unpack_upper, dim3((unsigned)n_c), dim3(256), 0, st, n_c, S_packed.p, S.p);
+        LAUNCH_CHECK("pack / unpack of the reduced camera system");
+      }
+      phase(1);
       // rhs += g_c (global), S += D_c / radius
       hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, n_c, U.p, damp_c.p, inv_radius, gc, S.p, 0);
       // row-major upper == column-major lower; the pivot check is read back with the scalars of

@@ -796,7 +796,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   pxr_lm_summary sm;
   sm.iterations = 0; sm.num_successful = 0; sm.termination = PXR_TERM_NO_CONVERGENCE;
   sm.num_camera_unknowns = 0; sm.num_point_unknowns = 0; sm.initial_cost = 0; sm.final_cost = 0;
-  sm.final_radius = 0; sm.total_ms = 0; sm.setup_ms = 0;
+  sm.final_radius = 0; sm.total_ms = 0; sm.setup_ms = 0; sm.linear_solver = 0; sm.collective_kib = 0; sm.linear_iterations = 0;
 
   __shared__ KaNodeMeta sh_nodes[KA_NODE_CACHE];
   __shared__ KaEdgeMeta sh_edges[KA_EDGE_CACHE];
@@ -846,7 +846,12 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   const pxr_lm_options& opt = a.opt;
 
   // evaluate cost + normal equations at the CURRENT keypoints, then scale: H <- S H S, g <- S g
+  // node stencils interpolated over the solve (a linearisation evaluates every node, a line-search probe the variable ones):
+  // the algorithmic traffic of the solve is 16 texels x C x sizeof(storage) each, reported as summary.linear_iterations
+  int64_t stencils = 0;
+  const int64_t nodes_all = p.np1 - p.np0, nodes_var = n / 2;
   auto linearize = [&](bool compute_scale) -> double {
+    stencils += nodes_all;
     for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = 0.0;
     for (int e = tid; e < n; e += blockDim.x) p.g[e] = 0.0;
     __syncthreads();
@@ -874,6 +879,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     return c;
   };
   auto cost_at_candidate = [&]() -> double {
+    stencils += nodes_var;
     KA_T(7);
     ka_nodes<ST, C, false>(a, p, a.kp_cand, fsimd, true);
     KA_T(3);
@@ -1030,7 +1036,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diag = true;
     }
   }
-  sm.final_cost = cost; sm.final_radius = radius;
+  sm.final_cost = cost; sm.final_radius = radius; sm.linear_iterations = stencils;
   if (tid == 0) a.summaries[prob] = sm;
 #ifdef PXR_KA_PROFILE
   KA_T(7);
@@ -1265,6 +1271,7 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
     total->iterations = std::max(total->iterations, sums[i].iterations);
     total->num_successful += sums[i].num_successful;
     total->num_point_unknowns += sums[i].num_camera_unknowns;
+    total->linear_iterations += sums[i].linear_iterations;          // node stencils interpolated over the whole solve
     if (sums[i].termination == PXR_TERM_FAILURE) total->termination = PXR_TERM_FAILURE;
     else if (sums[i].termination == PXR_TERM_NO_CONVERGENCE && total->termination != PXR_TERM_FAILURE)
       total->termination = PXR_TERM_NO_CONVERGENCE;

@@ -1,10 +1,16 @@
 // pxr_runtime.cpp -- context, error reporting, device-memory plumbing and the patch arena.
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
+#if defined(__x86_64__)
 #include <immintrin.h>
+#endif
 
 #include "pxr_internal.h"
 
@@ -20,6 +26,8 @@ int set_error(int code, const char* fmt, ...) {
   return code;
 }
 }  // namespace pxr
+
+static void release_staging(pxr_ctx* ctx);
 
 extern "C" {
 
@@ -59,10 +67,7 @@ int pxr_ctx_destroy(pxr_ctx* ctx) {
   if (ctx->d_workspace_mat) (void)hipFree(ctx->d_workspace_mat);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
-  for (int b = 0; b < 2; ++b) {
-    if (ctx->h_stage[b]) (void)hipHostFree(ctx->h_stage[b]);
-    if (ctx->ev_stage[b]) (void)hipEventDestroy(ctx->ev_stage[b]);
-  }
+  release_staging(ctx);
   delete ctx;
   return PXR_OK;
 }
@@ -172,13 +177,14 @@ int pxr_arena_destroy(pxr_arena* a) {
   return PXR_OK;
 }
 
-// Host patches -> arena through two pinned staging buffers: while the DMA engine drains one, all host cores gather the next
-// chunk into the other (from ONE contiguous block, or from `count` separate 64 KB patches -- the FeaturePatch objects of a
+// Host patches -> arena through two pinned staging buffers: while the DMA engine drains one, the host cores gather the next
+// chunk into the other (from ONE contiguous block, or from `count` separate patches -- the FeaturePatch objects of a
 // FeatureManager: no stacked host copy of the whole set first).  A pageable hipMemcpyAsync is staged by the runtime one
 // small buffer at a time on one thread; this keeps the link busy instead.
 // Copy into the pinned staging buffer with streaming stores: a plain memcpy reads the destination lines before writing them
 // (write-allocate), and while the copy engine drains the other staging buffer the host DRAM is the shared resource -- measured
 // on the GPU box: 32 memcpy threads and the DMA slowed each other to 36 GB/s of a 57 GB/s link.
+#if defined(__x86_64__)
 __attribute__((target("avx2"))) static void copy_streaming_avx2(char* dst, const char* src, size_t bytes) {
   size_t head = (32 - (reinterpret_cast<uintptr_t>(dst) & 31)) & 31;
   if (head > bytes) head = bytes;
@@ -197,53 +203,147 @@ __attribute__((target("avx2"))) static void copy_streaming_avx2(char* dst, const
   }
   std::memcpy(dst + body, src + body, bytes - body);
 }
+static bool streaming_copy_available() { return __builtin_cpu_supports("avx2"); }
+static void streaming_fence() { _mm_sfence(); }
+#else   // other hosts (aarch64, ppc64le ROCm boxes): plain memcpy
+static void copy_streaming_avx2(char* dst, const char* src, size_t bytes) { std::memcpy(dst, src, bytes); }
+static bool streaming_copy_available() { return false; }
+static void streaming_fence() {}
+#endif
 static void copy_to_staging(char* dst, const char* src, size_t bytes, bool streaming) {
   if (streaming && bytes >= 4096) copy_streaming_avx2(dst, src, bytes);
   else std::memcpy(dst, src, bytes);
 }
 
+namespace {
+// The gather threads of ONE upload call: created once, handed one byte range per staging chunk (a fresh std::thread per
+// 256 MiB chunk cost ~250 creations for the 65.5 GB arena of BASELINE configs[2]).
+class GatherPool {
+ public:
+  explicit GatherPool(unsigned n) {
+    for (unsigned t = 0; t < n; ++t) threads_.emplace_back([this, t] { loop(t); });
+  }
+  ~GatherPool() {
+    { std::lock_guard<std::mutex> g(m_); stop_ = true; ++epoch_; }
+    cv_.notify_all();
+    for (auto& th : threads_) th.join();
+  }
+  unsigned size() const { return (unsigned)threads_.size(); }
+  // runs fn(t) on every thread t and returns when all are done
+  void run(const std::function<void(unsigned)>& fn) {
+    { std::lock_guard<std::mutex> g(m_); fn_ = &fn; pending_ = size(); ++epoch_; }
+    cv_.notify_all();
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [this] { return pending_ == 0; });
+  }
+ private:
+  void loop(unsigned t) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(unsigned)>* fn;
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return epoch_ != seen; });
+        seen = epoch_;
+        if (stop_) return;
+        fn = fn_;
+      }
+      (*fn)(t);
+      { std::lock_guard<std::mutex> g(m_); if (--pending_ == 0) done_.notify_one(); }
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(unsigned)>* fn_ = nullptr;
+  unsigned pending_ = 0;
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
+};
+}  // namespace
+
+static void release_staging(pxr_ctx* ctx) {
+  for (int q = 0; q < 2; ++q) {
+    if (ctx->h_stage[q]) (void)hipHostFree(ctx->h_stage[q]);
+    if (ctx->ev_stage[q]) (void)hipEventDestroy(ctx->ev_stage[q]);
+    ctx->h_stage[q] = nullptr; ctx->ev_stage[q] = nullptr;
+  }
+  ctx->stage_bytes = 0;
+}
+
+// Two pinned buffers of min(256 MiB, the upload) bytes each (grown when a later upload is larger); any failure leaves the
+// context without staging state.
+static int ensure_staging(pxr_ctx* ctx, size_t total_bytes) {
+  constexpr size_t kStage = (size_t)256 << 20, kMin = (size_t)1 << 20;
+  size_t want = std::min(kStage, std::max(kMin, total_bytes));
+  if (const char* e = std::getenv("PXR_UPLOAD_STAGE_BYTES")) want = std::max<size_t>(4096, (size_t)std::atoll(e));   // tests
+  want = (want + 4095) & ~(size_t)4095;
+  if (ctx->h_stage[0] && ctx->stage_bytes >= want) return PXR_OK;
+  if (ctx->h_stage[0]) (void)hipStreamSynchronize(ctx->stream);        // an earlier upload may still read the old buffers
+  release_staging(ctx);
+  for (int b = 0; b < 2; ++b) {
+    if (hipHostMalloc(&ctx->h_stage[b], want, hipHostMallocDefault) != hipSuccess) {
+      ctx->h_stage[b] = nullptr;
+      release_staging(ctx);
+      return pxr::set_error(PXR_ENOMEM, "pxr_arena_upload: no pinned staging memory (2 x %zu bytes)", want);
+    }
+    if (hipEventCreateWithFlags(&ctx->ev_stage[b], hipEventDisableTiming) != hipSuccess) {
+      ctx->ev_stage[b] = nullptr;
+      release_staging(ctx);
+      return pxr::set_error(PXR_EHIP, "pxr_arena_upload: hipEventCreate failed");
+    }
+  }
+  ctx->stage_bytes = want;
+  return PXR_OK;
+}
+
+// The upload is ONE byte stream of count * patch_bytes bytes cut into staging-buffer-sized chunks; a chunk may begin and end
+// inside a patch, so a patch larger than the staging buffer (a dense 1600 x 1200 x 128 fp16 map is 491 MB) takes several.
 static int upload_staged(pxr_arena* a, int64_t first, int64_t count, const void* h_contig, const void* const* h_ptrs) {
   pxr_ctx* ctx = a->ctx;
   hipStream_t s = ctx->stream;
   const size_t pb = a->patch_bytes();
-  constexpr size_t kStage = (size_t)256 << 20;
-  if (!ctx->h_stage[0]) {
-    for (int b = 0; b < 2; ++b) {
-      if (hipHostMalloc(&ctx->h_stage[b], kStage, hipHostMallocDefault) != hipSuccess) {
-        for (int q = 0; q < 2; ++q) { if (ctx->h_stage[q]) (void)hipHostFree(ctx->h_stage[q]); ctx->h_stage[q] = nullptr; }
-        return pxr::set_error(PXR_ENOMEM, "pxr_arena_upload: no pinned staging memory");
-      }
-      PXR_HIP(hipEventCreateWithFlags(&ctx->ev_stage[b], hipEventDisableTiming));
-    }
-    ctx->stage_bytes = kStage;
-  }
-  const int64_t per = std::max<int64_t>(1, (int64_t)(ctx->stage_bytes / pb));
+  const size_t total = pb * (size_t)count;
+  if (int rc = ensure_staging(ctx, total)) return rc;
+  const size_t stage = ctx->stage_bytes;
   // 8 threads already keep the link busy (56 GB/s measured; 16 leave slack for slower hosts); PXR_UPLOAD_THREADS overrides
   unsigned n_thr = std::max(1u, std::min(std::thread::hardware_concurrency() / 2, 16u));
   if (const char* e = std::getenv("PXR_UPLOAD_THREADS")) n_thr = (unsigned)std::max(1, std::atoi(e));
-  const bool streaming = __builtin_cpu_supports("avx2") && std::getenv("PXR_UPLOAD_NO_STREAMING") == nullptr;
+  if (total < ((size_t)4 << 20)) n_thr = 1;
+  const bool streaming = streaming_copy_available() && std::getenv("PXR_UPLOAD_NO_STREAMING") == nullptr;
+  auto source = [&](size_t patch) {
+    return h_ptrs ? static_cast<const char*>(h_ptrs[patch]) : static_cast<const char*>(h_contig) + patch * pb;
+  };
+  // bytes [o0, o1) of the stream -> dst + (o0 - base)
+  auto gather = [&](char* dst, size_t base, size_t o0, size_t o1) {
+    for (size_t o = o0; o < o1;) {
+      const size_t patch = o / pb, within = o - patch * pb;
+      const size_t len = std::min(pb - within, o1 - o);
+      copy_to_staging(dst + (o - base), source(patch) + within, len, streaming);
+      o += len;
+    }
+    if (streaming) streaming_fence();
+  };
+  std::unique_ptr<GatherPool> pool;
+  if (n_thr > 1) pool.reset(new GatherPool(n_thr));
   bool used[2] = {false, false};
   int b = 0;
-  for (int64_t c0 = 0; c0 < count; c0 += per, b ^= 1) {
-    const int64_t n = std::min(per, count - c0);
+  for (size_t c0 = 0; c0 < total; c0 += stage, b ^= 1) {
+    const size_t c1 = std::min(total, c0 + stage), n = c1 - c0;
     if (used[b]) PXR_HIP(hipEventSynchronize(ctx->ev_stage[b]));            // the previous upload out of this buffer is done
     char* dst = static_cast<char*>(ctx->h_stage[b]);
-    auto gather = [&](int64_t i0, int64_t i1) {
-      for (int64_t i = i0; i < i1; ++i)
-        copy_to_staging(dst + (size_t)i * pb, h_ptrs ? static_cast<const char*>(h_ptrs[c0 + i]) : static_cast<const char*>(h_contig) + (size_t)(c0 + i) * pb, pb, streaming);
-      if (streaming) _mm_sfence();
-    };
-    if ((size_t)n * pb < ((size_t)4 << 20) || n_thr == 1) {
-      gather(0, n);
+    if (!pool || n < ((size_t)4 << 20)) {
+      gather(dst, c0, c0, c1);
     } else {
-      std::vector<std::thread> pool;
-      for (unsigned t = 0; t < n_thr; ++t) {
-        const int64_t i0 = n * t / n_thr, i1 = n * (t + 1) / n_thr;
-        if (i1 > i0) pool.emplace_back(gather, i0, i1);
-      }
-      for (auto& th : pool) th.join();
+      const std::function<void(unsigned)> job = [&](unsigned t) {
+        // thread ranges on 4 KiB boundaries of the stream
+        const size_t q = ((n + n_thr - 1) / n_thr + 4095) & ~(size_t)4095;
+        const size_t o0 = std::min(n, q * t), o1 = std::min(n, q * (t + 1));
+        if (o1 > o0) gather(dst, c0, c0 + o0, c0 + o1);
+      };
+      pool->run(job);
     }
-    PXR_HIP(hipMemcpyAsync((char*)a->d_data + pb * (size_t)(first + c0), dst, pb * (size_t)n, hipMemcpyHostToDevice, s));
+    PXR_HIP(hipMemcpyAsync((char*)a->d_data + pb * (size_t)first + c0, dst, n, hipMemcpyHostToDevice, s));
     PXR_HIP(hipEventRecord(ctx->ev_stage[b], s));
     used[b] = true;
   }

@@ -120,9 +120,19 @@ py::tuple patches_of(py::list patch_dicts, py::list dense_flags, py::array_t<int
       patch = d;
     } else {
       PyObject* key = PyLong_FromLong(oj[o]);
-      patch = PyDict_GetItemWithError(d, key);     // borrowed
+      if (PyDict_Check(d)) {
+        patch = PyDict_GetItemWithError(d, key);   // borrowed
+        Py_XINCREF(patch);
+      } else {                                     // any other mapping (UserDict, a lazy container): __getitem__
+        patch = PyObject_GetItem(d, key);          // new reference; KeyError / TypeError of the container travel up
+      }
       Py_DECREF(key);
       if (!patch) { if (PyErr_Occurred()) throw py::error_already_set(); throw py::key_error("no feature patch for an observation"); }
+      PyList_SET_ITEM(out.ptr(), o, patch);        // steals the reference
+      PyObject* a = PyObject_GetAttr(patch, s_ptr.ptr());
+      if (a) { pp[o] = (uint64_t)PyLong_AsUnsignedLongLong(a); Py_DECREF(a); }
+      else { PyErr_Clear(); pp[o] = 0; }
+      continue;
     }
     Py_INCREF(patch);
     PyList_SET_ITEM(out.ptr(), o, patch);          // steals the reference

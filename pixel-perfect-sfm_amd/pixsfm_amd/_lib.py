@@ -56,7 +56,7 @@ class LMSummary(C.Structure):
                 ("num_camera_unknowns", C.c_int32), ("num_point_unknowns", C.c_int64),
                 ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double),
                 ("total_ms", C.c_double), ("setup_ms", C.c_double), ("linear_solver", C.c_int32),
-                ("reserved_", C.c_int32), ("linear_iterations", C.c_int64)]
+                ("collective_kib", C.c_int32), ("linear_iterations", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -300,12 +300,14 @@ class _SceneDump:
         if self._patch_dicts is None:
             return [self.feature_view.fpatch(self.img_ids[a], b) for a, b in zip(obs_image_idx.tolist(), obs_p2d.tolist())]
         if self.compiled:
-            dicts = [None if fm is None else (fm.patches if fm.is_sparse else fm.fpatch(0)) for fm in self._patch_dicts]
-            dense = [fm is not None and not fm.is_sparse for fm in self._patch_dicts]
             try:
+                # a dense map without its patch (an image no observation refers to) stands as None like a missing map
+                dicts = [None if fm is None else (fm.patches if fm.is_sparse else (fm.fpatch(0) if fm.has_fpatch(0) else None))
+                         for fm in self._patch_dicts]
+                dense = [fm is not None and not fm.is_sparse for fm in self._patch_dicts]
                 return _host_module().patches_of(dicts, dense, np.ascontiguousarray(obs_image_idx, dtype=np.int32),
                                                  np.ascontiguousarray(obs_p2d, dtype=np.int32))[0]
-            except KeyError:
+            except (KeyError, TypeError):
                 pass                     # the pure-Python walk below names the missing image / patch
         out = np.empty(len(obs_image_idx), dtype=object)
         order = np.argsort(obs_image_idx, kind="stable")
@@ -341,7 +343,7 @@ class _FlatBA:
         from ._timing import phase
         self._phase = phase
         with phase("dump"):
-            if scene is None or scene.reconstruction is not reconstruction:
+            if scene is None or scene.reconstruction is not reconstruction or scene.feature_view is not feature_view:
                 scene = _SceneDump(reconstruction, feature_view)
             self._dump(reconstruction, setup, scene, options, point_filter, extractor)
 
@@ -787,8 +789,13 @@ class FeatureReferenceBundleOptimizer:
 
     def run(self, reconstruction, feature_view, references):
         """Run = SetUp + SolveProblem (feature_reference_bundle_optimizer.h:54-71)."""
-        self.set_up(reconstruction, None, feature_view, references)
-        ok = self.solve_problem(reconstruction)
+        try:
+            self.set_up(reconstruction, None, feature_view, references)
+            ok = self.solve_problem(reconstruction)
+        finally:
+            # a scene dump / shared arena handed in by the adjuster describes THIS call's objects only: a second run on
+            # another feature set (or an edited reconstruction) must not find them
+            self.scene = self.arena_cache = None
         if self._arena is not None:
             self._arena.close()
             self._arena = None

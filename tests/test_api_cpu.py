@@ -487,3 +487,50 @@ def test_scene_dump_with_a_patch_container_that_is_not_a_dict():
     a, b = B._SceneDump(rec, fv, use_compiled=True), B._SceneDump(rec, fv, use_compiled=False)
     assert a.compiled and np.array_equal(a.has_patch, b.has_patch) and a.has_patch.dtype == b.has_patch.dtype
     assert 0 < a.has_patch.sum() < len(a.has_patch)
+    # patches_of on the same containers: the compiled walk takes any mapping (__getitem__ for what is not a dict) and agrees
+    # with the Python walk; a missing patch is the Python walk's KeyError on both
+    have = np.flatnonzero(a.has_patch & (a.p2d_point3D >= 0))
+    img_of = np.searchsorted(a.p2d_ptr, have, side="right") - 1
+    j_of = have - a.p2d_ptr[img_of]
+    pa = a.patches_of(img_of.astype(np.int64), j_of.astype(np.int64))
+    pb = b.patches_of(img_of.astype(np.int64), j_of.astype(np.int64))
+    assert len(pa) == len(pb) > 0 and all(x is y for x, y in zip(pa, pb))
+    assert (img_of == 1).any()                        # the UserDict image took part
+    lacking = np.flatnonzero((a.has_patch == 0) & (a.p2d_point3D >= 0))
+    im_l = np.searchsorted(a.p2d_ptr, lacking, side="right") - 1
+    for dump in (a, b):
+        with pytest.raises(KeyError):
+            dump.patches_of(im_l.astype(np.int64), (lacking - a.p2d_ptr[im_l]).astype(np.int64))
+
+
+def test_flat_ba_does_not_reuse_a_scene_dump_of_another_feature_view():
+    """_FlatBA takes a shared _SceneDump only for the very (reconstruction, feature_view) pair it was made from; the
+    optimiser forgets the adjuster's dump and arena once run() returns."""
+    from pixsfm_amd.api import bundle_adjustment as B, features
+    from pixsfm_amd.api.reconstruction import Camera, Image, Point2D, Point3D, Reconstruction
+    rec = Reconstruction()
+    rec.add_camera(Camera(1, "SIMPLE_PINHOLE", 100, 100, [50.0, 50, 50]))
+    images = [Image(1 + i, "im%d.jpg" % i, 1, [1, 0, 0, 0], [0, 0, 0]) for i in range(2)]
+    for p in range(4):
+        rec.add_point3D(p + 1, Point3D(np.array([0.0, 0, 5])))
+        for im in images:
+            im.points2D.append(Point2D([50, 50], p + 1))
+            rec.points3D[p + 1].track.add_element(im.image_id, len(im.points2D) - 1)
+    for im in images:
+        rec.add_image(im)
+
+    def fset(skip):
+        out = {}
+        for im in images:
+            fm = features.FeatureMap()
+            fm.patches = {j: features.FeaturePatch(np.zeros((4, 4, 8), np.float16), (48, 48), (1.0, 1.0))
+                          for j in range(4) if j != skip}
+            out[im.name] = fm
+        return features.FeatureSet(out)
+    fv_full, fv_holes = B.FeatureView(fset(None), rec), B.FeatureView(fset(2), rec)
+    scene = B._SceneDump(rec, fv_full)
+    setup = B.BundleAdjustmentSetup()
+    setup.add_images(rec.reg_image_ids())
+    same = B._FlatBA(rec, setup, fv_full, extractor=True, scene=scene)
+    other = B._FlatBA(rec, setup, fv_holes, extractor=True, scene=scene)      # must re-dump: two observations lack a patch
+    assert len(same.obs_image) == 8 and len(other.obs_image) == 6

@@ -1,0 +1,53 @@
+"""bench.py as its own launcher (no GPU needed): a plain `python bench.py --gpus N` spawns N ranks, re-prints rank 0's JSON
+line last, and a failing rank stops the others and makes the command fail (the driver's SCALE command is
+the plain one; round 3 exited at once with '--gpus 8 but WORLD_SIZE=1').  PXR_BENCH_SELFTEST makes ranks succeed / fail /
+hang before any GPU work."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(n, selftest, timeout=120, extra_env=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PXR_BENCH_SELFTEST"] = selftest
+    env.update(extra_env or {})
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    return p, time.time() - t0
+
+
+def test_plain_command_spawns_its_ranks_and_reprints_rank0s_line_last():
+    p, _ = _run(3, "ok:0,ok:1,ok:2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout                       # ONLY rank 0's line on stdout
+    assert json.loads(lines[0]) == {"selftest": True, "rank": 0}
+    assert '"rank": 1' in p.stderr and '"rank": 2' in p.stderr      # the other ranks' stdout goes to stderr
+
+
+def test_a_failing_rank_stops_the_others_and_fails_the_command():
+    # rank 1 exits with code 3 at once, rank 0 would sleep for 10 minutes (a rank left alone in a collective)
+    p, dt = _run(2, "fail:1,hang:0")
+    assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
+    assert dt < 60, dt
+    assert p.stdout.strip() == ""
+    assert "rank 1 exited with code 3" in p.stderr
+
+
+def test_launcher_times_out():
+    p, dt = _run(2, "hang:0,hang:1", extra_env={"PXR_BENCH_LAUNCH_TIMEOUT": "2"})
+    assert p.returncode != 0 and dt < 60
+    assert "timed out" in p.stderr
+
+
+def test_under_torchrun_the_process_is_a_rank_not_a_launcher():
+    # RANK in the environment: no spawning; WORLD_SIZE must agree with --gpus
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", PXR_BENCH_SELFTEST="")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--no-ka"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in (p.stderr + p.stdout)

@@ -56,3 +56,41 @@ def test_empty_and_degenerate_inputs(ctx):
     best, dist, _ = nearest_references(ctx, karena, interp_cfg(), kprob["kp"][:2], [0, 1], [0, 0, 1],
                                        np.ones((1, 128)) / np.sqrt(128))
     assert best.tolist() == [-1, 0]                                  # no candidates -> -1
+
+
+@pytest.mark.parametrize("stage_bytes", [4096, 20480, 1 << 20])
+def test_upload_with_patches_larger_than_the_staging_buffer(stage_bytes, monkeypatch):
+    """pxr_arena_upload / pxr_arena_upload_gather cut the upload into staging-buffer-sized pieces of ONE byte stream: a
+    patch larger than the pinned buffer (a dense 1600 x 1200 x 128 fp16 map is 491 MB against 256 MiB) spans several
+    pieces, a piece may begin and end inside a patch.  PXR_UPLOAD_STAGE_BYTES shrinks the buffer so that 36 KB patches
+    play the dense map's part."""
+    from pixsfm_amd.engine import Context, PatchArena
+    monkeypatch.setenv("PXR_UPLOAD_STAGE_BYTES", str(stage_bytes))
+    monkeypatch.setenv("PXR_UPLOAD_THREADS", "3")
+    c = Context(0)                                   # a fresh context: the staging buffers are sized at first use
+    try:
+        rng = np.random.default_rng(stage_bytes)
+        n, H, W, ch = 150, 12, 12, 128               # 36 864-byte patches, 5.5 MB in total (> the 4 MB threading threshold)
+        patches = rng.standard_normal((n, H, W, ch)).astype(np.float16)
+        corners = rng.integers(0, 100, (n, 2)).astype(np.int32)
+        scales = rng.uniform(0.5, 2.0, (n, 2))
+        a = PatchArena.from_numpy(c, patches, corners, scales)
+        got, gc, gs = a.download()
+        assert np.array_equal(got.view(np.uint16), patches.view(np.uint16))
+        assert np.array_equal(gc, corners) and np.array_equal(gs, scales)
+        # separate host patches (FeaturePatch objects), into the middle of an arena
+        sep = [np.ascontiguousarray(p) for p in patches[::-1]]
+        ptrs = np.array([p.ctypes.data for p in sep], np.uint64)
+        b = PatchArena.from_patch_pointers(c, ptrs, (H, W, ch), np.float16, corners, scales)
+        got2, _, _ = b.download()
+        assert np.array_equal(got2.view(np.uint16), patches[::-1].view(np.uint16))
+        a.upload(7, patches[100:120], corners[100:120], scales[100:120])
+        got3, _, _ = a.download(7, 20)
+        assert np.array_equal(got3.view(np.uint16), patches[100:120].view(np.uint16))
+        # a later, larger upload on the same context grows the buffers
+        monkeypatch.setenv("PXR_UPLOAD_STAGE_BYTES", str(4 * stage_bytes))
+        a.upload(0, patches, corners, scales)
+        got4, _, _ = a.download()
+        assert np.array_equal(got4.view(np.uint16), patches.view(np.uint16))
+    finally:
+        c.close()

@@ -121,3 +121,38 @@ def test_pixsfm_api_on_two_ranks(ctx, tmp_path, monkeypatch):
         assert np.abs(r["ba_cost"] - one["ba_cost"]).max() < 1e-8 * one["ba_cost"][0]
         assert np.abs(r["xyz"] - one["xyz"]).max() < 1e-7 and np.abs(r["qvec"] - one["qvec"]).max() < 1e-8
     assert np.array_equal(res[0]["xyz"], res[1]["xyz"]) and np.array_equal(res[0]["kp"], res[1]["kp"])
+
+
+def _bench(n_gpus, extra_env=None, timeout=900):
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n_gpus), "--steps", "3", "--warmup", "1", "--cams", "24",
+           "--points", "6000", "--lm-iters", "6", "--no-ka", "--no-costmap", "--no-cpu-baseline", "--no-api-e2e", "--no-telemetry"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]       # the JSON line and nothing else on stdout
+    return json.loads(lines[0])
+
+
+def test_plain_bench_command_on_two_ranks_is_the_one_rank_problem():
+    """`python bench.py --gpus 2` with NO launcher around it (the shape of the driver's SCALE command): it spawns its two
+    ranks itself (both on the one GPU of this box, gloo as the transport of the callback collective), the sharded scene is
+    the one-rank scene bit for bit (same initial cost), the LM trajectory ends at the same cost, and the line says how many
+    ranks took part and how many bytes the [S | rhs] collective moves."""
+    one = _bench(1)
+    two = _bench(2, {"PXR_BENCH_ONE_DEVICE": "1", "PXR_BENCH_BACKEND": "gloo"})
+    assert two["n_gpus"] == 2 and two["ranks"]["nranks_seen"] == 2
+    assert two["ranks"]["obs_per_gpu"] == [15000, 15000] and two["config"]["n_obs"] == one["config"]["n_obs"] == 30000
+    assert abs(two["initial_cost"] - one["initial_cost"]) <= 1e-12 * one["initial_cost"]
+    for key in ("lm", "lm_no_inner"):
+        assert abs(two[key]["initial_cost"] - one[key]["initial_cost"]) <= 1e-12 * one[key]["initial_cost"]
+        assert abs(two[key]["final_cost"] - one[key]["final_cost"]) <= 1e-8 * one[key]["initial_cost"], key
+        assert two[key]["iterations"] == one[key]["iterations"] and two[key]["successful"] == one[key]["successful"]
+    n_c = two["lm"]["reduced_system"]
+    assert two["lm"]["allreduce_bytes"] == n_c * (n_c + 3) // 2 * 8            # the packed upper triangle + rhs, not the square
+    assert two["lm"]["collective_KiB_per_solve"] == (two["lm"]["allreduce_bytes"] + 1023) // 1024
+    assert one["lm"]["collective_KiB_per_solve"] == 0 and two["lm"]["allreduce_ms"] > 0

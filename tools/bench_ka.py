@@ -60,7 +60,45 @@ def make_problem_gpu(dev, n_tracks, track_len, C=128, PS=16, seed=1, sigma=1.0, 
                 corners=corners, scales=np.ones((n, 2)), true_xy=true_xy, n_problems=len(bins)), patches
 
 
-def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, world=1):
+def cpu_legs_on_sample(prob, patches, dev):
+    """The CPU side of the KA half of the metric on a bounded sample (the first 4 x logical-CPUs sub-problems, at most all):
+    the oracle's bounded LM, ONE single-threaded solve per task over a pool of threads (keypoint_adjustment/main.py:66-80),
+    and the reference's own FeatureMetric2DCostFunctor on dual numbers per residual block -- both timed inside C
+    (oracle/pxo_bench_harness.h)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pxo
+    import pxo_cpubench
+    logical, _, _ = pxo_cpubench.cpu_topology()
+    n_prob = int(prob["n_problems"])
+    take = min(n_prob, max(16, 4 * logical))
+    node_sel = np.nonzero(prob["node_problem"] < take)[0]
+    new_node = np.full(len(prob["kp"]), -1); new_node[node_sel] = np.arange(len(node_sel))
+    edge_sel = np.nonzero(new_node[prob["edge_src"]] >= 0)[0]
+    sub = dict(kp=prob["kp"][node_sel], node_patch=np.arange(len(node_sel), dtype=np.int64), node_const=prob["node_const"][node_sel],
+               node_problem=prob["node_problem"][node_sel].astype(np.int32),
+               edge_src=new_node[prob["edge_src"][edge_sel]].astype(np.int32),
+               edge_dst=new_node[prob["edge_dst"][edge_sel]].astype(np.int32), edge_w=prob["edge_w"][edge_sel],
+               patches=patches[torch.as_tensor(node_sel, device=dev)].cpu().numpy(),
+               corners=prob["corners"][node_sel], scales=prob["scales"][node_sel])
+    what = "the first %d of the %d sub-problems of the same workload (%d keypoints, %d residual blocks, %.1f GB of patches)" % (
+        take, n_prob, len(node_sel), len(edge_sel), sub["patches"].nbytes / 1e9)
+    out = {}
+    solve = pxo_cpubench.ka_solve_port(sub, pxo.cfg(), pxo.loss("cauchy", 0.25), 4.0, pxo.lm_options(parameter_tolerance=1e-5))
+    solve["sample"] = what + "; oracle C restatement of the bounded LM, one single-threaded solve per task, tasks taken from a shared counter"
+    solve["projected_full_solve_ms"] = 1e3 * n_prob / solve["value"]
+    out["cpu_baseline"] = solve
+    try:
+        edge = pxo_cpubench.ka_edge_reference(sub)
+        if edge is not None:
+            edge["sample"] = what + ("; the reference's FeatureMetric2DCostFunctor compiled in place, evaluated on 4-wide dual "
+                                     "numbers like ceres::AutoDiffCostFunction (residual + 128 x 4 Jacobian per block)")
+            out["cpu_baseline_edge_eval"] = edge
+    except Exception as e:  # noqa: BLE001 -- oracle/_ref is optional
+        out["cpu_baseline_edge_eval"] = {"value": None, "kind": "reference", "sample": "unavailable: %r" % (e,)}
+    return out
+
+
+def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, world=1, cpu_legs=False):
     """Runs the KA benchmark and returns its result dict (bench.py attaches it as "ka").
     world > 1 (torch.distributed initialised by the caller): STRONG scaling of BASELINE configs[1] -- the sub-problems
     are dealt to the ranks (parallel.shard_ka_problem, SURVEY 8e: no collective during the solve), every rank times its
@@ -108,6 +146,7 @@ def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, 
         cost, _, _, _ = ka.eval(cfg, ls)
     ms = slowest(ctx.timer_stop() / args.steps)
     c0 = summed(float(cost.download().sum()))
+    cpu = cpu_legs_on_sample(prob, patches, dev) if (cpu_legs and world == 1) else None
     cold, _ = ka.solve(cfg, ls, bound=4.0)          # first call: grows the context workspace
     ka.d["kp"].upload(np.ascontiguousarray(prob["kp"], dtype=np.float64))
     ctx.sync()
@@ -128,6 +167,7 @@ def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, 
             total[k] = summed(total[k])
         total["total_ms"], total["setup_ms"] = slowest(total["total_ms"]), slowest(total["setup_ms"])
         total["num_successful"] = int(summed(total["num_successful"]))
+        total["linear_iterations"] = int(summed(total["linear_iterations"]))
         kp, prob = kp_all, full
     # expected optimum: true + (root offset)
     tl = args.track_len
@@ -147,6 +187,22 @@ def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, 
                      "final_cost": total["final_cost"], "initial_cost_check": c0},
            "accuracy_px": {"median_before": float(np.median(err0)), "median_after": float(np.median(err1)),
                            "p95_after": float(np.percentile(err1, 95))}}
+    # roofline of the solve kernel: the algorithmic traffic is one 4 x 4 x C stencil per node and evaluation (node-centric:
+    # every linearisation interpolates all nodes of a sub-problem, every line-search probe its variable nodes); the kernel
+    # counts them (summary.linear_iterations).  HBM peak from MI355X_MICROARCH.md.
+    kernel_ms = out["solve"]["kernel_ms"]
+    stencils = int(total["linear_iterations"])
+    bytes_solve = stencils * 16 * 128 * 2
+    ach = bytes_solve / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                       "kernel": "ka_solve_kernel_occ2<f16,128>", "kernel_ms": kernel_ms, "algorithmic_bytes": bytes_solve,
+                       "node_stencils_interpolated": stencils, "evaluations_per_node": stencils / max(1, len(prob["kp"])),
+                       "traffic": None,
+                       "note": "the whole bounded LM of every sub-problem is ONE launch; a sub-problem's evaluations are a serial "
+                               "chain (LM iteration -> line-search probes), so the kernel is latency-bound well below the HBM rate"}
+    if cpu is not None:
+        out.update(cpu)
+        out["gpu_over_cpu_solve"] = (out["cpu_baseline"]["projected_full_solve_ms"] / kernel_ms) if kernel_ms > 0 else None
     arena.close()
     return out
 

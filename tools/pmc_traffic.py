@@ -1,7 +1,7 @@
 """HBM bytes per launch of one kernel from two separate rocprofv3 passes (`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`,
 each with --kernel-trace --output-format csv): the file bench.py reads as `roofline.traffic`.
 
-    python tools/pmc_traffic.py <fetch dir> <write dir> <kernel name pattern> <out.json> "<command the passes ran>"
+    python tools/pmc_traffic.py <fetch dir> <write dir> <kernel name pattern> <out.json> "<command the passes ran>" [commit]
 
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts KB and reports half of the bytes of 16 B / lane
 coalesced reads, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE (KB) is taken as reported.  Only launches with with_jacobian
@@ -24,12 +24,14 @@ def mean_counter(root, pattern, counter):
 
 
 fetch_dir, write_dir, pattern, out, cmd = sys.argv[1:6]
+commit = sys.argv[6] if len(sys.argv) > 6 else "unrecorded"
 f, nf = mean_counter(fetch_dir, pattern, "FETCH_SIZE")
 w, nw = mean_counter(write_dir, pattern, "WRITE_SIZE")
 rd, wr = 2.0 * f * 1024.0, w * 1024.0
 res = {"kernel": pattern, "FETCH_SIZE_KB_per_launch_raw": f, "n_fetch_samples": nf, "WRITE_SIZE_KB_per_launch_raw": w,
        "n_write_samples": nw,
        "correction": "gfx950: read bytes = 2 x FETCH_SIZE x 1024 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported",
+       "measured_at_commit": commit,
        "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
        "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- " + cmd,
                     "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- " + cmd]}

@@ -247,7 +247,7 @@ def cpu_baseline(prob, patches, n_sample, lm_gauge=None):
     what = ("first %d observations (%d whole points, all %d cameras) of the same workload; every thread works on its own "
             "first-touched copy of its share; touched working set %.0f MB of stencils + references"
             % (n_sample, n_pts_s, len(prob["image_camera"]), touched_mb))
-    out = {}
+    out = {"cpu_host": pxo_cpubench.host_probe()}
     port = pxo_cpubench.ba_eval_port(sub, cfg, ls)
     port["sample"] = what + "; oracle C restatement: analytic 128x(10+K) Jacobians materialised + Cauchy loss"
     try:

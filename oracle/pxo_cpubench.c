@@ -198,3 +198,30 @@ int pxo_bench_ka_solve(const pxo_ka_batch* b, int n_problems, const int64_t* nod
   out[4] = (double)atomic_load(&u.iterations);
   return 0;
 }
+
+/* ---- what the host gives N threads: a pure-ALU probe ---------------------------------------------------------------------
+ * Every thread runs the same fixed number of dependent fused multiply-adds on registers (no memory traffic).  The rate at
+ * N threads over the rate at one thread is the number of cores' worth of arithmetic the box really hands this process --
+ * a container on a shared node, a CPU quota or SMT siblings show up here, separately from a leg's own memory behaviour. */
+typedef struct { int64_t iters; double sink; } spin_user;
+static void spin_work(void* userp, void* statep, int t, int T) {
+  (void)statep; (void)T;
+  spin_user* u = (spin_user*)userp;
+  double a0 = 1.0 + t, a1 = 1.1, a2 = 1.2, a3 = 1.3, a4 = 1.4, a5 = 1.5, a6 = 1.6, a7 = 1.7;
+  const double m = 0.999999, c = 1e-9;
+  for (int64_t i = 0; i < u->iters; ++i) {
+    a0 = a0 * m + c; a1 = a1 * m + c; a2 = a2 * m + c; a3 = a3 * m + c;
+    a4 = a4 * m + c; a5 = a5 * m + c; a6 = a6 * m + c; a7 = a7 * m + c;
+  }
+  if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.678) u->sink += 1.0;
+}
+/* out[0] = seconds, out[1] = passes, out[2] = calibration seconds, out[3] = pinned; work per pass = iters x 8 FMAs per thread */
+int pxo_bench_spin(int64_t iters, int n_threads, double min_seconds, double* out) {
+  spin_user u; u.iters = iters; u.sink = 0;
+  pxo_bench_ops ops = {NULL, spin_work, NULL, NULL};
+  pxo_bench_result r;
+  const int rc = pxo_bench_run(&ops, &u, n_threads, min_seconds, 0, &r);
+  if (rc) return rc;
+  out[0] = r.seconds; out[1] = (double)r.passes; out[2] = r.calib_seconds; out[3] = r.pinned;
+  return 0;
+}

@@ -59,6 +59,46 @@ def thread_counts(logical):
     return sorted({max(1, logical // 4), max(1, logical // 2), logical, 2 * logical})
 
 
+_host = None
+
+
+def host_probe(counts=None):
+    """What the box gives this process: the speed-up of a pure-ALU spin loop (registers only) at each thread count over one
+    thread -- "cores' worth" of arithmetic; a shared node, a CPU quota or SMT show up here -- plus the cgroup CPU limit, its
+    throttling counters and the load average.  Cached."""
+    global _host
+    if _host is not None and counts is None:
+        return _host
+    logical, physical, nodes = cpu_topology()
+    fn = pxo.lib().pxo_bench_spin
+    fn.restype = C.c_int
+
+    def rate(threads):
+        out = _out4()
+        iters = 2_000_000
+        if fn(C.c_int64(iters), int(threads), C.c_double(0.1), out):
+            raise RuntimeError("pxo_bench_spin failed")
+        return threads * iters * out[1] / out[0]
+
+    def read(path):
+        try:
+            with open(path) as fh:
+                return fh.read().strip()
+        except OSError:
+            return None
+    before = read("/sys/fs/cgroup/cpu.stat")
+    one = rate(1)
+    spin = {str(t): rate(t) / one for t in (counts or thread_counts(logical)) if t > 1}
+    rep = {"logical_cpus": logical, "physical_cores": physical, "numa_nodes": nodes,
+           "spin_speedup_over_one_thread": spin, "cgroup_cpu_max": read("/sys/fs/cgroup/cpu.max"),
+           "cgroup_cpu_stat_before": before, "cgroup_cpu_stat_after": read("/sys/fs/cgroup/cpu.stat"),
+           "loadavg": read("/proc/loadavg"),
+           "note": "spin = 8 independent chains of dependent fp64 multiply-adds per thread, no memory traffic, same harness"}
+    if counts is None:
+        _host = rep
+    return rep
+
+
 def sweep(run, n_items, unit, min_seconds=0.25, single_items=None, counts=None):
     """run(n, n_threads, min_seconds) -> (seconds, passes, calib_seconds, pinned) over the first n items.
     Returns the report dict: best rate over the thread counts, the single-thread rate (on `single_items` items), the
@@ -78,9 +118,17 @@ def sweep(run, n_items, unit, min_seconds=0.25, single_items=None, counts=None):
     best_t = max(rates, key=rates.get)
     best = rates[best_t]
     ideal = min(best_t, physical) * single
+    try:
+        spin = host_probe()["spin_speedup_over_one_thread"].get(str(best_t))
+    except Exception:  # noqa: BLE001
+        spin = None
     return {"value": best, "unit": unit, "cores": best_t, "single_thread": single, "logical_cpus": logical,
             "physical_cores": physical, "numa_nodes": nodes, "sweep": {str(t): rates[t] for t in sorted(rates)},
             "scaling_efficiency": best / ideal if ideal > 0 else None,
+            # the same ratio against what a pure-ALU loop gets out of `cores` threads on this box (host_probe): near 1 = the
+            # leg scales like arithmetic does here, the box (not the harness) sets the ceiling
+            "speedup_over_single": best / single, "host_spin_speedup_at_cores": spin,
+            "scaling_vs_host_spin": (best / single) / spin if spin else None,
             "harness_limited": bool(best < 0.4 * physical * single) if logical > 1 else False,
             "pinned_threads": bool(pinned), "timed_in": "C (persistent pinned pthreads, barriers, thread-local copies)",
             "n_items": int(n_items)}

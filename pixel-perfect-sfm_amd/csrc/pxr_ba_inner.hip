@@ -17,6 +17,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
+#include <vector>
+#include <algorithm>
 
 #include "pxr_device.h"
 #include "pxr_interp.h"
@@ -365,11 +368,103 @@ __device__ __forceinline__ void inner_loss(int type, double a, double s, double 
   }
 }
 
+// One round of a point's nested trust-region LM on its state in LDS (Ceres' loop as in inner_points_body): takes the
+// evaluation (cand, Hc, gc) at the point's candidate, decides accept / reject / stop and forms the next candidate.
+// first: the evaluation was at the unrefined point (its cost goes to *cost_before).
+__device__ __forceinline__ void inner_owner_update(InnerOwner& S, const double cand, const double (&Hc)[6], const double (&gc)[3],
+                                                   const bool first, const bool has_obs, bool& active, double* cost_before) {
+  if (first) {
+    S.cost = cand;
+    if (has_obs) atomicAdd(cost_before, cand);
+    if (active) {
+      const double gmax = fmax(fabs(gc[0]), fmax(fabs(gc[1]), fabs(gc[2])));
+      if (gmax <= 1e-10) active = false;
+      const double s0 = 1.0 / (1.0 + sqrt(Hc[0])), s1 = 1.0 / (1.0 + sqrt(Hc[3])), s2 = 1.0 / (1.0 + sqrt(Hc[5]));
+      S.sc[0] = s0; S.sc[1] = s1; S.sc[2] = s2;
+      S.H[0] = Hc[0] * (s0 * s0); S.H[1] = Hc[1] * (s0 * s1); S.H[2] = Hc[2] * (s0 * s2);
+      S.H[3] = Hc[3] * (s1 * s1); S.H[4] = Hc[4] * (s1 * s2); S.H[5] = Hc[5] * (s2 * s2);
+      S.g[0] = gc[0] * s0; S.g[1] = gc[1] * s1; S.g[2] = gc[2] * s2;
+    }
+  } else if (active) {
+    const double X0 = S.X[0], X1 = S.X[1], X2 = S.X[2], C0 = S.Xc[0], C1 = S.Xc[1], C2 = S.Xc[2];
+    const double s2 = (C0 - X0) * (C0 - X0) + (C1 - X1) * (C1 - X1) + (C2 - X2) * (C2 - X2);
+    const double x2 = X0 * X0 + X1 * X1 + X2 * X2;
+    const double cost = S.cost, cost_change = cost - cand;
+    if (sqrt(s2) <= 1e-8 * (sqrt(x2) + 1e-8)) active = false;
+    else if (fabs(cost_change) <= 1e-6 * cost) active = false;
+    else {
+      const double rel = cost_change / S.mcc;
+      if (rel > 1e-3) {
+        S.X[0] = C0; S.X[1] = C1; S.X[2] = C2;
+        S.cost = cand;
+        const double s0 = S.sc[0], s1 = S.sc[1], s2c = S.sc[2];
+        const double gmax = fmax(fabs(gc[0]), fmax(fabs(gc[1]), fabs(gc[2])));
+        S.H[0] = Hc[0] * (s0 * s0); S.H[1] = Hc[1] * (s0 * s1); S.H[2] = Hc[2] * (s0 * s2c);
+        S.H[3] = Hc[3] * (s1 * s1); S.H[4] = Hc[4] * (s1 * s2c); S.H[5] = Hc[5] * (s2c * s2c);
+        S.g[0] = gc[0] * s0; S.g[1] = gc[1] * s1; S.g[2] = gc[2] * s2c;
+        const double tmp = 2.0 * rel - 1.0;
+        S.radius = fmin(1e16, S.radius / fmax(1.0 / 3.0, 1.0 - tmp * tmp * tmp));
+        S.decrease_factor = 2.0; S.reuse_diag = 0;
+        if (gmax <= 1e-10) active = false;
+      } else {
+        const double df = S.decrease_factor;
+        S.radius = S.radius / df; S.decrease_factor = df * 2.0; S.reuse_diag = 1;
+      }
+    }
+  }
+  // the next candidate (steps that fail without an evaluation are retried here, like the `continue` above)
+  if (active) {
+    const double H0 = S.H[0], H1 = S.H[1], H2 = S.H[2], H3 = S.H[3], H4 = S.H[4], H5 = S.H[5];
+    const double g0 = S.g[0], g1 = S.g[1], g2 = S.g[2];
+    double radius = S.radius, d0 = S.diag[0], d1v = S.diag[1], d2v = S.diag[2];
+    int it = S.it, invalid = S.invalid;
+    bool reuse_diag = S.reuse_diag != 0;
+    while (true) {
+      if (it >= 50 || radius < 1e-32) { active = false; break; }
+      ++it;
+      if (!reuse_diag) { d0 = fmin(fmax(H0, 1e-6), 1e32); d1v = fmin(fmax(H3, 1e-6), 1e32); d2v = fmin(fmax(H5, 1e-6), 1e32); }
+      // Cholesky of the damped 3 x 3 with reciprocal pivots: three v_rsq_f64 and one division on the owners' chain instead
+      // of three square roots and ten divisions
+      const double ir = 1.0 / radius;
+      const double a00 = H0 + d0 * ir, a11 = H3 + d1v * ir, a22 = H5 + d2v * ir;
+      bool ok = a00 > 0.0;
+      const double i00 = inner_rsqrt(a00), l10 = H1 * i00, l20 = H2 * i00;
+      const double e1 = a11 - l10 * l10;
+      ok = ok && e1 > 0.0;
+      const double i11 = inner_rsqrt(e1), l21 = (H4 - l20 * l10) * i11;
+      const double e2 = a22 - l20 * l20 - l21 * l21;
+      ok = ok && e2 > 0.0;
+      const double i22 = inner_rsqrt(e2);
+      const double y0 = -g0 * i00, y1 = (-g1 - l10 * y0) * i11, y2 = (-g2 - l20 * y0 - l21 * y1) * i22;
+      const double t2 = y2 * i22, t1 = (y1 - l21 * t2) * i11, t0 = (y0 - l10 * t1 - l20 * t2) * i00;
+      double mcc = 0.0;
+      if (ok) {
+        const double dg = t0 * g0 + t1 * g1 + t2 * g2;
+        const double dHd = t0 * (H0 * t0 + H1 * t1 + H2 * t2) + t1 * (H1 * t0 + H3 * t1 + H4 * t2) + t2 * (H2 * t0 + H4 * t1 + H5 * t2);
+        mcc = -dg - 0.5 * dHd;
+        if (!(mcc > 0.0) || !isfinite(t0) || !isfinite(t1) || !isfinite(t2)) ok = false;
+      }
+      if (!ok) {
+        if (++invalid >= 5) { active = false; break; }
+        radius *= 0.5; reuse_diag = true;
+        continue;
+      }
+      invalid = 0;
+      S.mcc = mcc;
+      S.Xc[0] = S.X[0] + t0 * S.sc[0]; S.Xc[1] = S.X[1] + t1 * S.sc[1]; S.Xc[2] = S.X[2] + t2 * S.sc[2];
+      break;
+    }
+    S.radius = radius; S.diag[0] = d0; S.diag[1] = d1v; S.diag[2] = d2v;
+    S.it = it; S.invalid = invalid; S.reuse_diag = reuse_diag ? 1 : 0;
+  }
+  S.live = active ? 1 : 0;
+}
+
 template <typename ST, int C, bool FS, int LPO>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_inner_packed(const InnerArgs a, const int ppw) {
+__device__ __forceinline__ void inner_packed_body(const InnerArgs& a, const int ppw, const int* __restrict__ pt_list,
+                                                  PackedLds<C, 64 / LPO>& lds) {
   static_assert(C == 128 || C == 64, "LPO lanes per observation, C / (8 LPO) chunks of 8 channels per lane");
   constexpr int NCHUNK = C / (8 * LPO), IP_SLOTS = 64 / LPO;
-  __shared__ PackedLds<C, IP_SLOTS> lds;
   const int lane = threadIdx.x, sidx = lane / LPO, sub = lane % LPO;
 #ifdef PXR_INNER_PROFILE   // tools/inner_phase_probe.sh: two wavefronts print how their shader-clock cycles split over the phases
   long long pf_t = __builtin_amdgcn_s_memtime(), pf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -379,7 +474,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #define PF_MARK(k) do { } while (0)
 #endif
   auto lanes_sum = [](double v) { return LPO == 4 ? quad_sum(v) : row8_sum(v); };
-  const int64_t P0 = (int64_t)blockIdx.x * ppw;
+  // pt_list: the wavefront's (one) point comes from a list -- the host sends the points with long tracks here, ppw = 1
+  const int64_t P0 = pt_list ? (int64_t)pt_list[blockIdx.x] : (int64_t)blockIdx.x * ppw;
   const int npts = (int)((a.v.n_points - P0) < (int64_t)ppw ? (a.v.n_points - P0) : (int64_t)ppw);
   // the observations of points P0 .. P0 + npts - 1 are entries [o0, o0 + L) of pt_obs; point j starts at st_j
   const int64_t o0 = a.pt_ptr[P0];
@@ -583,94 +679,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     PF_MARK(4);
     // -- owners: Ceres' trust-region bookkeeping (same loop as k_inner_points above) on the state in LDS --
-    if (owner) {
-      InnerOwner& S = lds.own[lane];
-      if (first) {
-        S.cost = cand;
-        if (my_e > my_b) atomicAdd(a.cost_before, cand);
-        if (active) {
-          const double gmax = fmax(fabs(gc[0]), fmax(fabs(gc[1]), fabs(gc[2])));
-          if (gmax <= 1e-10) active = false;
-          const double s0 = 1.0 / (1.0 + sqrt(Hc[0])), s1 = 1.0 / (1.0 + sqrt(Hc[3])), s2 = 1.0 / (1.0 + sqrt(Hc[5]));
-          S.sc[0] = s0; S.sc[1] = s1; S.sc[2] = s2;
-          S.H[0] = Hc[0] * (s0 * s0); S.H[1] = Hc[1] * (s0 * s1); S.H[2] = Hc[2] * (s0 * s2);
-          S.H[3] = Hc[3] * (s1 * s1); S.H[4] = Hc[4] * (s1 * s2); S.H[5] = Hc[5] * (s2 * s2);
-          S.g[0] = gc[0] * s0; S.g[1] = gc[1] * s1; S.g[2] = gc[2] * s2;
-        }
-      } else if (active) {
-        const double X0 = S.X[0], X1 = S.X[1], X2 = S.X[2], C0 = S.Xc[0], C1 = S.Xc[1], C2 = S.Xc[2];
-        const double s2 = (C0 - X0) * (C0 - X0) + (C1 - X1) * (C1 - X1) + (C2 - X2) * (C2 - X2);
-        const double x2 = X0 * X0 + X1 * X1 + X2 * X2;
-        const double cost = S.cost, cost_change = cost - cand;
-        if (sqrt(s2) <= 1e-8 * (sqrt(x2) + 1e-8)) active = false;
-        else if (fabs(cost_change) <= 1e-6 * cost) active = false;
-        else {
-          const double rel = cost_change / S.mcc;
-          if (rel > 1e-3) {
-            S.X[0] = C0; S.X[1] = C1; S.X[2] = C2;
-            S.cost = cand;
-            const double s0 = S.sc[0], s1 = S.sc[1], s2c = S.sc[2];
-            const double gmax = fmax(fabs(gc[0]), fmax(fabs(gc[1]), fabs(gc[2])));
-            S.H[0] = Hc[0] * (s0 * s0); S.H[1] = Hc[1] * (s0 * s1); S.H[2] = Hc[2] * (s0 * s2c);
-            S.H[3] = Hc[3] * (s1 * s1); S.H[4] = Hc[4] * (s1 * s2c); S.H[5] = Hc[5] * (s2c * s2c);
-            S.g[0] = gc[0] * s0; S.g[1] = gc[1] * s1; S.g[2] = gc[2] * s2c;
-            const double tmp = 2.0 * rel - 1.0;
-            S.radius = fmin(1e16, S.radius / fmax(1.0 / 3.0, 1.0 - tmp * tmp * tmp));
-            S.decrease_factor = 2.0; S.reuse_diag = 0;
-            if (gmax <= 1e-10) active = false;
-          } else {
-            const double df = S.decrease_factor;
-            S.radius = S.radius / df; S.decrease_factor = df * 2.0; S.reuse_diag = 1;
-          }
-        }
-      }
-      // the next candidate (steps that fail without an evaluation are retried here, like the `continue` above)
-      if (active) {
-        const double H0 = S.H[0], H1 = S.H[1], H2 = S.H[2], H3 = S.H[3], H4 = S.H[4], H5 = S.H[5];
-        const double g0 = S.g[0], g1 = S.g[1], g2 = S.g[2];
-        double radius = S.radius, d0 = S.diag[0], d1v = S.diag[1], d2v = S.diag[2];
-        int it = S.it, invalid = S.invalid;
-        bool reuse_diag = S.reuse_diag != 0;
-        while (true) {
-          if (it >= 50 || radius < 1e-32) { active = false; break; }
-          ++it;
-          if (!reuse_diag) { d0 = fmin(fmax(H0, 1e-6), 1e32); d1v = fmin(fmax(H3, 1e-6), 1e32); d2v = fmin(fmax(H5, 1e-6), 1e32); }
-          // Cholesky of the damped 3 x 3 with reciprocal pivots: three v_rsq_f64 and one division on the owners' chain instead
-          // of three square roots and ten divisions
-          const double ir = 1.0 / radius;
-          const double a00 = H0 + d0 * ir, a11 = H3 + d1v * ir, a22 = H5 + d2v * ir;
-          bool ok = a00 > 0.0;
-          const double i00 = inner_rsqrt(a00), l10 = H1 * i00, l20 = H2 * i00;
-          const double e1 = a11 - l10 * l10;
-          ok = ok && e1 > 0.0;
-          const double i11 = inner_rsqrt(e1), l21 = (H4 - l20 * l10) * i11;
-          const double e2 = a22 - l20 * l20 - l21 * l21;
-          ok = ok && e2 > 0.0;
-          const double i22 = inner_rsqrt(e2);
-          const double y0 = -g0 * i00, y1 = (-g1 - l10 * y0) * i11, y2 = (-g2 - l20 * y0 - l21 * y1) * i22;
-          const double t2 = y2 * i22, t1 = (y1 - l21 * t2) * i11, t0 = (y0 - l10 * t1 - l20 * t2) * i00;
-          double mcc = 0.0;
-          if (ok) {
-            const double dg = t0 * g0 + t1 * g1 + t2 * g2;
-            const double dHd = t0 * (H0 * t0 + H1 * t1 + H2 * t2) + t1 * (H1 * t0 + H3 * t1 + H4 * t2) + t2 * (H2 * t0 + H4 * t1 + H5 * t2);
-            mcc = -dg - 0.5 * dHd;
-            if (!(mcc > 0.0) || !isfinite(t0) || !isfinite(t1) || !isfinite(t2)) ok = false;
-          }
-          if (!ok) {
-            if (++invalid >= 5) { active = false; break; }
-            radius *= 0.5; reuse_diag = true;
-            continue;
-          }
-          invalid = 0;
-          S.mcc = mcc;
-          S.Xc[0] = S.X[0] + t0 * S.sc[0]; S.Xc[1] = S.X[1] + t1 * S.sc[1]; S.Xc[2] = S.X[2] + t2 * S.sc[2];
-          break;
-        }
-        S.radius = radius; S.diag[0] = d0; S.diag[1] = d1v; S.diag[2] = d2v;
-        S.it = it; S.invalid = invalid; S.reuse_diag = reuse_diag ? 1 : 0;
-      }
-      S.live = active ? 1 : 0;
-    }
+    if (owner) inner_owner_update(lds.own[lane], cand, Hc, gc, first, my_e > my_b, active, a.cost_before);
     first = false;
     PF_MARK(5);
 #ifdef PXR_INNER_PROFILE
@@ -689,11 +698,400 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 }
 
+template <typename ST, int C, bool FS, int LPO>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_inner_packed(const InnerArgs a, const int ppw, const int* __restrict__ pt_list) {
+  __shared__ PackedLds<C, 64 / LPO> lds;
+  inner_packed_body<ST, C, FS, LPO>(a, ppw, pt_list, lds);
+}
+
+// ---- feature patches, third mapping: the nested LM on the GRAM MATRIX of each observation's stencil -------------------------
+// k_inner_packed interpolates the 128-channel descriptor at every round of the nested LM: ~4 KB of texels per observation
+// and round (13.7 GB fetched per call at configs[2], L2 hit rate 20-26 %: profiles/r3_inner_pmc_packed.json) and ~7 500
+// vector instructions per point.  But a round never needs the descriptor itself -- only nine channel sums
+//   f.f  f.fc  f.fr  fc.fc  fc.fr  fr.fr  f.d  fc.d  fr.d        (f, fc, fr: raw interpolated value / column / row derivative)
+// and bicubic interpolation is linear in the 16 texels of the stencil:  f = sum_t w_t T_t,  w = wv (x) wu  (Catmull-Rom
+// weights of the fractional position), fc: wv (x) wu',  fr: wv' (x) wu.  So with the stencil's Gram matrix G = T T^t (16 x 16)
+// and D = T d (16) every sum is a quadratic / linear form in the weights:  f.f = w^t G w,  f.fc = w^t G wc, ...,  f.d = w.D.
+// G and D are built ONCE per observation -- sixteen texels x C channels cross HBM once, the contraction over the channels is
+// 32 v_mfma_f64_16x16x4 (A = B = one texel value per lane, fp64 accumulators: fp16 products are exact, the sums carry full
+// double precision) -- and stay in LDS (2 KB per observation) while the point iterates.  One wavefront = one point; an
+// observation takes 8 lanes, each with two rows of its G: a round is 88 fused multiply-adds and nine 8-lane reductions per
+// lane instead of 2 048 texel loads' worth of splines.  The nested LM moves a point by a fraction of a texel, so the 4 x 4
+// cell rarely changes between rounds; when it does (floor(u), floor(v) differ from the cached cell) that observation's Gram
+// matrix is rebuilt.
+//
+// Arithmetic: the reference interpolates with an fp32 horizontal pass (cubic_hermite_spline_simd.h); here the whole bicubic
+// is exact-in-fp64 algebra on the Gram matrix, so a round's cost differs from the exact-order kernels' by ~1e-7 relative
+// (the fp32 pass's own rounding) -- inside the nested LM's 1e-6 tolerances, and like k_inner_packed's channel-sum
+// normalisation it only steers Ceres' heuristic refinement: the outer loop re-evaluates the refined candidate with the
+// exact-order kernel.  Points with more than IG_MAXO observations take k_inner_packed (the host splits the points).
+#ifndef PXR_GRAM_WAVES
+#define PXR_GRAM_WAVES 2     // wavefronts per SIMD the kernel is compiled for (tools/inner_gram_probe.sh builds the others)
+#endif
+constexpr int IG_MAXO = 16;   // observations per point whose Gram matrices fit the wavefront's LDS (two trips of 8)
+constexpr int IG_OBS = 32;    // doubles of an observation record: IP_OBS + the cell its Gram matrix was built for
+typedef double gd4 __attribute__((ext_vector_type(4)));
+
+// Catmull-Rom weights of the four taps at fractional position x (the polynomial of CubicHermiteSpline, base/src/interpolation.h /
+// cubic_hermite_spline_simd.h, expanded in the taps) and their derivatives
+__device__ __forceinline__ void catmull_rom_weights(double x, double (&w)[4], double (&dw)[4]) {
+  const double x2 = x * x, x3 = x2 * x;
+  w[0] = -0.5 * x + x2 - 0.5 * x3; w[1] = 1.0 - 2.5 * x2 + 1.5 * x3; w[2] = 0.5 * x + 2.0 * x2 - 1.5 * x3; w[3] = -0.5 * x2 + 0.5 * x3;
+  dw[0] = -0.5 + 2.0 * x - 1.5 * x2; dw[1] = -5.0 * x + 4.5 * x2; dw[2] = 0.5 + 4.0 * x - 4.5 * x2; dw[3] = -x + 1.5 * x2;
+}
+__device__ __forceinline__ double pick4(const double (&w)[4], int i) { return i == 0 ? w[0] : (i == 1 ? w[1] : (i == 2 ? w[2] : w[3])); }
+
+// The texels of one 4 x 4 stencil as the MFMA wants them: lane (i = lane & 15, g = lane >> 4) holds channels
+// [g C/4, (g + 1) C/4) of texel i -- 64 contiguous bytes at C = 128 / fp16.  (row, col): the cell, wave-uniform.
+template <typename ST, int C>
+struct GramTexels {
+  static constexpr int CPL = C / 4;
+  typename std::conditional<sizeof(ST) == 2, uint4, float4>::type raw[sizeof(ST) == 2 ? CPL / 8 : CPL / 4];
+  __device__ __forceinline__ void load(const ST* __restrict__ patch, int H, int W, int row, int col) {
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int tr = clampi(row - 1 + (i >> 2), 0, H - 1), tc = clampi(col - 1 + (i & 3), 0, W - 1);   // Grid2D's clamp (grid2d.h:64-73)
+    const ST* p = patch + ((size_t)tr * W + tc) * C + g * CPL;
+    if constexpr (sizeof(ST) == 2) {
+#pragma unroll
+      for (int q = 0; q < CPL / 8; ++q) raw[q] = *reinterpret_cast<const uint4*>(p + 8 * q);
+    } else {
+#pragma unroll
+      for (int q = 0; q < CPL / 4; ++q) raw[q] = *reinterpret_cast<const float4*>(p + 4 * q);
+    }
+  }
+  __device__ __forceinline__ double value(int e) const {
+    if constexpr (sizeof(ST) == 2) {
+      union { uint4 u; _Float16 h[8]; } cv;
+      cv.u = raw[e / 8];
+      return (double)(float)cv.h[e % 8];
+    } else {
+      const float4 v = raw[e / 4];
+      return (double)(e % 4 == 0 ? v.x : (e % 4 == 1 ? v.y : (e % 4 == 2 ? v.z : v.w)));
+    }
+  }
+};
+
+// The symmetric 16 x 16 Gram matrix in LDS as its ten upper 4 x 4 blocks (160 doubles instead of 256): block (R, Cb), R <= Cb, at
+// gram_block(R, Cb) * 16, row-major inside.  Element (i, c) with i / 4 > c / 4 is read from the transposed block.
+__device__ __forceinline__ constexpr int gram_block(int R, int Cb) { return R * 4 - R * (R - 1) / 2 + (Cb - R); }
+constexpr int IG_GDOUBLES = 160;
+
+// G = T T^t -> the blocked upper triangle at Gq, D = T d -> Dq[i], by ALL 64 lanes: the texel values are fed one per MFMA step as
+// both operands (the channel order of the contraction is irrelevant); the accumulators come out as G[g + 4 r][i] (r = 0..3):
+// in-block row g of block row r, column i.
+template <typename ST, int C>
+__device__ __forceinline__ void gram_contract(const GramTexels<ST, C>& tx, const double* ref, double* Gq, double* Dq) {
+  constexpr int CPL = C / 4;
+  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  gd4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+  double dp = 0.0;
+  const double* rp = ref + g * CPL;
+#pragma unroll
+  for (int e = 0; e < CPL; e += 2) {
+    const double x0 = tx.value(e), x1 = tx.value(e + 1);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, acc1, 0, 0, 0);
+    dp = fma(x0, rp[e], dp);
+    dp = fma(x1, rp[e + 1], dp);
+  }
+  dp += __shfl_xor(dp, 16);
+  dp += __shfl_xor(dp, 32);
+  if (g == 0) Dq[i] = dp;
+  const gd4 acc = acc0 + acc1;
+  const int cb = i >> 2, ic = i & 3;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (cb >= r) Gq[gram_block(r, cb) * 16 + g * 4 + ic] = acc[r];
+}
+
+// rows i0 = 2 sub, i0 + 1 of G times the Kronecker-structured weights: (G w)_i, (G wc)_i, (G wr)_i for both rows
+__device__ __forceinline__ void gram_rows_times_weights(const double* Gq, int sub, const double (&wu)[4], const double (&dwu)[4],
+                                                        const double (&wv)[4], const double (&dwv)[4], double (&ya)[3], double (&yb)[3]) {
+  const int R = sub >> 1, ir = 2 * (sub & 1);            // block row of both rows, in-block row of the first
+  ya[0] = ya[1] = ya[2] = yb[0] = yb[1] = yb[2] = 0.0;
+#pragma unroll
+  for (int cbk = 0; cbk < 4; ++cbk) {                    // column block = the vertical tap r of the weights
+    double ea[4], eb[4];
+    if (cbk >= R) {                                       // stored block (R, cbk): two rows of four
+      const double* blk = Gq + gram_block(R, cbk) * 16 + ir * 4;
+      const double2 a01 = *reinterpret_cast<const double2*>(blk), a23 = *reinterpret_cast<const double2*>(blk + 2);
+      const double2 b01 = *reinterpret_cast<const double2*>(blk + 4), b23 = *reinterpret_cast<const double2*>(blk + 6);
+      ea[0] = a01.x; ea[1] = a01.y; ea[2] = a23.x; ea[3] = a23.y; eb[0] = b01.x; eb[1] = b01.y; eb[2] = b23.x; eb[3] = b23.y;
+    } else {                                              // transposed block (cbk, R): two adjacent columns, rows 0..3
+      const double* blk = Gq + gram_block(cbk, R) * 16 + ir;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const double2 t = *reinterpret_cast<const double2*>(blk + 4 * cc);
+        ea[cc] = t.x; eb[cc] = t.y;
+      }
+    }
+    const double za = fma(ea[3], wu[3], fma(ea[2], wu[2], fma(ea[1], wu[1], ea[0] * wu[0])));
+    const double zb = fma(eb[3], wu[3], fma(eb[2], wu[2], fma(eb[1], wu[1], eb[0] * wu[0])));
+    const double zca = fma(ea[3], dwu[3], fma(ea[2], dwu[2], fma(ea[1], dwu[1], ea[0] * dwu[0])));
+    const double zcb = fma(eb[3], dwu[3], fma(eb[2], dwu[2], fma(eb[1], dwu[1], eb[0] * dwu[0])));
+    ya[0] = fma(wv[cbk], za, ya[0]); yb[0] = fma(wv[cbk], zb, yb[0]);
+    ya[1] = fma(wv[cbk], zca, ya[1]); yb[1] = fma(wv[cbk], zcb, yb[1]);
+    ya[2] = fma(dwv[cbk], za, ya[2]); yb[2] = fma(dwv[cbk], zb, yb[2]);
+  }
+}
+
+// one entry of the host's list of points for k_inner_gram
+struct GramPoint { int p, len; int64_t o0; };
+// per slot of the point-ordered observation list: what the staging needs without walking obs -> image -> camera
+struct GramSlot { int img, cam; int64_t patch; };
+__global__ __launch_bounds__(256) void k_gram_slots(int64_t n_obs, const int64_t* __restrict__ pt_obs, const int32_t* __restrict__ obs_image,
+                                                    const int64_t* __restrict__ obs_patch, const int32_t* __restrict__ image_camera,
+                                                    GramSlot* __restrict__ out) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n_obs) return;
+  const int64_t i = pt_obs[o];
+  const int img = obs_image[i];
+  out[o] = GramSlot{img, image_camera[img], obs_patch[i]};
+}
+
+// dynamic LDS of k_inner_gram for points of at most `maxo` observations, in doubles
+__host__ __device__ inline size_t gram_lds_doubles(int maxo, int C) {
+  return (size_t)maxo * (IG_GDOUBLES + 16 + IG_OBS) + C + (sizeof(InnerOwner) + 7) / 8;
+}
+
+template <typename ST, int C>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAVES, PXR_GRAM_WAVES))) void k_inner_gram(const InnerArgs a, const GramPoint* __restrict__ pt_list, const GramSlot* __restrict__ slots, const int maxo) {
+  static_assert(C == 128 || C == 64, "feature patches");
+  extern __shared__ __align__(16) double gsh[];
+  double* const Gs = gsh;                                  // [maxo][160]
+  double* const Ds = Gs + (size_t)maxo * IG_GDOUBLES;      // [maxo][16]
+  double* const obs = Ds + (size_t)maxo * 16;              // [maxo][IG_OBS]: R (9) t (3) k (12) sx sy corner (2) model patch cell (2)
+  double* const refd = obs + (size_t)maxo * IG_OBS;        // [C] reference descriptor
+  InnerOwner& S = *reinterpret_cast<InnerOwner*>(refd + C);
+  const int lane = threadIdx.x;
+#ifdef PXR_INNER_PROFILE   // tools/inner_phase_probe.sh: two wavefronts print how their shader-clock cycles split over the phases
+  long long gq_t = __builtin_amdgcn_s_memtime(), gq_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int gq_rounds = 0, gq_builds = 0;
+#define GQ_MARK(k) do { const long long n_ = __builtin_amdgcn_s_memtime(); gq_acc[k] += n_ - gq_t; gq_t = n_; } while (0)
+#else
+#define GQ_MARK(k) do { } while (0)
+#endif
+  const GramPoint gp = pt_list[blockIdx.x];
+  const int64_t p = gp.p, o0 = gp.o0;
+  const int L = gp.len;                                    // 1 .. maxo (the host's lists)
+  const bool variable = a.pt_var[p] != 0;
+  bool active = variable, first = true;                    // (meaningful on lane 0, the owner)
+  const ST* arena = reinterpret_cast<const ST*>(a.arena);
+  const size_t patch_elems = (size_t)a.H * a.W * C;
+  const bool l2 = a.l2_normalize != 0;
+
+  // ---- staging: reference, observation records (rotation matrix of the unit quaternion), owner state ----
+  for (int ch = lane; ch < C; ch += 64) refd[ch] = a.v.d_refs ? a.v.d_refs[(size_t)p * C + ch] : 0.0;
+  {
+    const int q = lane >> 2, part = lane & 3;
+    if (q < L) {
+      double* ob = obs + (size_t)q * IG_OBS;
+      const GramSlot sl = slots[o0 + q];                   // (list entry -> slot -> parameters: three dependent loads, not six)
+      const int img = sl.img, cam = sl.cam;
+      const int64_t pi = sl.patch;
+      if (part == 0) {
+        double R[9];
+        quat_to_rotation(a.v.d_qvec + 4 * (size_t)img, R);
+#pragma unroll
+        for (int m = 0; m < 9; ++m) ob[m] = R[m];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) ob[9 + m] = a.v.d_tvec[3 * (size_t)img + m];
+      } else if (part == 1) {
+#pragma unroll
+        for (int m = 0; m < 6; ++m) ob[12 + m] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + m];
+      } else if (part == 2) {
+#pragma unroll
+        for (int m = 6; m < PXR_KPAD; ++m) ob[12 + m] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + m];
+      } else {
+        ob[24] = a.scales[2 * pi]; ob[25] = a.scales[2 * pi + 1];
+        ob[26] = (double)a.corners[2 * pi]; ob[27] = (double)a.corners[2 * pi + 1];
+        ob[28] = (double)a.v.d_cam_model[cam]; ob[29] = (double)pi;
+        ob[30] = -1.0e6; ob[31] = -1.0e6;                  // the cell its Gram matrix was built for: none yet
+      }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { S.X[m] = a.v.d_xyz[3 * p + m]; S.Xc[m] = S.X[m]; }
+    S.live = 1; S.radius = 1e4; S.decrease_factor = 2.0; S.invalid = 0; S.it = 0; S.reuse_diag = 0; S.mcc = 0.0;
+  }
+  __syncthreads();
+  {   // d.d of the reference
+    double r2 = 0.0;
+    for (int ch = lane; ch < C; ch += 64) r2 = fma(refd[ch], refd[ch], r2);
+    r2 = rows_sum<16>(row16_sum(r2));
+    if (lane == 0) S.r2 = r2;
+  }
+
+  // 8 lanes per observation, lane `sub` works on rows 2 sub, 2 sub + 1 of its Gram matrix; trip k: observations 8k .. 8k + 7
+  const int sidx = lane >> 3, sub = lane & 7, ri = sub >> 1, ci = 2 * (sub & 1);
+  GQ_MARK(0);
+
+  while (true) {
+    __syncthreads();
+    double rs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // this lane's observations: cost, H (6), g (3) (lanes with sub == 0)
+#pragma unroll 1
+    for (int k = 0; 8 * k < L; ++k) {
+      const int q = 8 * k + sidx;
+      const bool act = q < L;
+      double* ob = obs + (size_t)(act ? q : L - 1) * IG_OBS;
+      // WorldToPixel (base/src/projection.h:60-75) and d(x,y)/dX = d(x,y)/d(u,v) d(u,v)/dp R, on every lane of the observation
+      double R[9];
+#pragma unroll
+      for (int m = 0; m < 9; ++m) R[m] = ob[m];
+      const double sx = ob[24], sy = ob[25], cx = ob[26], cy = ob[27];
+      const int model = (int)ob[28];
+      const double X0 = S.Xc[0], X1 = S.Xc[1], X2 = S.Xc[2];
+      const double p0 = fma(R[0], X0, fma(R[1], X1, fma(R[2], X2, ob[9])));
+      const double p1 = fma(R[3], X0, fma(R[4], X1, fma(R[5], X2, ob[10])));
+      const double p2 = fma(R[6], X0, fma(R[7], X1, fma(R[8], X2, ob[11])));
+      const double iz = inner_rcp(p2), un = p0 * iz, vn = p1 * iz;
+      double x, y, Juv[2][2];
+      camera_model_jac<false, false>(model, ob + 12, un, vn, x, y, Juv, nullptr);   // (no extended models here: the host's routing)
+      double PX[2][3];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const double A0 = Juv[r][0] * iz, A1 = Juv[r][1] * iz, A2 = -(Juv[r][0] * un + Juv[r][1] * vn) * iz;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) PX[r][m] = A0 * R[m] + A1 * R[3 + m] + A2 * R[6 + m];
+      }
+      const double u = x * sx - 0.5 - cx, v = y * sy - 0.5 - cy;   // FeaturePatch::ToPixelCoordinates (featurepatch.h:250-255)
+      const double rf = floor(v), cf = floor(u);
+      const int row = texel_index(rf, a.H), col = texel_index(cf, a.W);
+      // -- (re)build the Gram matrices of this trip's observations whose cell moved: wave-uniform control flow, all 64 lanes;
+      //    the texels of the next one are requested before the MFMA chain of the current one --
+      const bool need = act && ((double)row != ob[30] || (double)col != ob[31]);
+      unsigned long long todo = __ballot(need);
+      GQ_MARK(1);
+      if (todo != 0ull) {
+        const int64_t pi = (int64_t)ob[29];
+        const int pi_lo = (int)(pi & 0xffffffffll), pi_hi = (int)(pi >> 32);
+        auto request = [&](GramTexels<ST, C>& tx, int src_lane) {
+          const int row_t = __builtin_amdgcn_readlane(row, src_lane), col_t = __builtin_amdgcn_readlane(col, src_lane);
+          const int64_t pi_t = ((int64_t)__builtin_amdgcn_readlane(pi_hi, src_lane) << 32) | (unsigned)__builtin_amdgcn_readlane(pi_lo, src_lane);
+          tx.load(arena + (size_t)pi_t * patch_elems, a.H, a.W, row_t, col_t);
+        };
+        // a ring of three stencils in flight: a build's MFMA chain (~1 us) is shorter than the latency of its texels (~2 us under
+        // load; with one stencil ahead every build waited for its loads: 6 000 cycles per build, profiles/r4_inner_gram_probe.txt)
+        auto take = [&](GramTexels<ST, C>& tx) -> int {    // request the next observation's texels; -1: none left
+          if (todo == 0ull) return -1;
+          const int src = __ffsll((long long)todo) - 1;
+          todo &= ~(0xffull << (src & ~7));
+          request(tx, src);
+          return src;
+        };
+        GramTexels<ST, C> t0, t1, t2;
+        int s0 = take(t0), s1 = take(t1), s2 = take(t2);
+        while (true) {
+          if (s0 < 0) break;
+          gram_contract<ST, C>(t0, refd, Gs + (size_t)(8 * k + (s0 >> 3)) * IG_GDOUBLES, Ds + (size_t)(8 * k + (s0 >> 3)) * 16);
+          s0 = take(t0);
+          if (s1 < 0) break;
+          gram_contract<ST, C>(t1, refd, Gs + (size_t)(8 * k + (s1 >> 3)) * IG_GDOUBLES, Ds + (size_t)(8 * k + (s1 >> 3)) * 16);
+          s1 = take(t1);
+          if (s2 < 0) break;
+          gram_contract<ST, C>(t2, refd, Gs + (size_t)(8 * k + (s2 >> 3)) * IG_GDOUBLES, Ds + (size_t)(8 * k + (s2 >> 3)) * 16);
+          s2 = take(t2);
+        }
+        if (need && sub == 0) { ob[30] = (double)row; ob[31] = (double)col; }
+        __syncthreads();                                 // the Gram matrices written by all lanes -> visible to their readers
+#ifdef PXR_INNER_PROFILE
+        gq_builds += __popcll(__ballot(need)) / 8;
+#endif
+        GQ_MARK(2);
+      }
+      if (act) {
+        double wu[4], dwu[4], wv[4], dwv[4];
+        catmull_rom_weights(u - cf, wu, dwu);
+        catmull_rom_weights(v - rf, wv, dwv);
+        double ya[3], yb[3];                              // (G w, G wc, G wr) at rows 2 sub and 2 sub + 1
+        gram_rows_times_weights(Gs + (size_t)q * IG_GDOUBLES, sub, wu, dwu, wv, dwv, ya, yb);
+        const double2 d2 = *reinterpret_cast<const double2*>(Ds + (size_t)q * 16 + 2 * sub);
+        const double wvo = pick4(wv, ri), dwvo = pick4(dwv, ri);
+        const double wua = ci == 0 ? wu[0] : wu[2], wub = ci == 0 ? wu[1] : wu[3];
+        const double dwua = ci == 0 ? dwu[0] : dwu[2], dwub = ci == 0 ? dwu[1] : dwu[3];
+        const double oma = wvo * wua, omb = wvo * wub, omca = wvo * dwua, omcb = wvo * dwub, omra = dwvo * wua, omrb = dwvo * wub;
+        const double Sgg = row8_sum(fma(oma, ya[0], omb * yb[0])), Sgc = row8_sum(fma(oma, ya[1], omb * yb[1]));
+        const double Sgr = row8_sum(fma(oma, ya[2], omb * yb[2]));
+        const double Scc = row8_sum(fma(omca, ya[1], omcb * yb[1])), Scr = row8_sum(fma(omca, ya[2], omcb * yb[2]));
+        const double Srr = row8_sum(fma(omra, ya[2], omrb * yb[2]));
+        const double Sfd = row8_sum(fma(oma, d2.x, omb * d2.y)), Scd = row8_sum(fma(omca, d2.x, omcb * d2.y));
+        const double Srd = row8_sum(fma(omra, d2.x, omrb * d2.y));
+        double s, gcc, gcr, grr, bc, br;
+        if (l2) {
+          const double ninv = inner_rsqrt(Sgg), n2inv = ninv * ninv;
+          const double pc = Sgc * n2inv, pr = Sgr * n2inv;
+          s = fmax(0.0, 1.0 - 2.0 * Sfd * ninv + S.r2);
+          gcc = (Scc - Sgc * pc) * n2inv; gcr = (Scr - Sgc * pr) * n2inv; grr = (Srr - Sgr * pr) * n2inv;
+          bc = -(Scd - Sfd * pc) * ninv; br = -(Srd - Sfd * pr) * ninv;
+        } else {          // r = f - d
+          s = fmax(0.0, Sgg - 2.0 * Sfd + S.r2);
+          gcc = Scc; gcr = Scr; grr = Srr; bc = Sgc - Scd; br = Sgr - Srd;
+        }
+        double rho[3];
+        inner_loss(a.loss.type, a.loss.a, s, rho);
+        double cq = 0.5 * rho[0];
+        if (a.check_bounds && !a.v.d_refs && !(u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H)) cq = __builtin_nan("");
+        gcc *= sx * sx; gcr *= sx * sy; grr *= sy * sy; bc *= sx; br *= sy;
+        double kappa = 0.0;   // Ceres' corrector (corrector.cc): alpha = 1 - sqrt(1 + 2 s rho'' / rho')
+        if (s != 0.0 && rho[2] > 0.0) {
+          const double D = 1.0 + 2.0 * s * rho[2] * inner_rcp(rho[1]);
+          const double alpha = 1.0 - sqrt(D);
+          kappa = (2.0 * alpha - alpha * alpha) * inner_rcp(s);
+        }
+        const double w8 = rho[1];
+        const double m00 = w8 * (gcc - kappa * bc * bc), m01 = w8 * (gcr - kappa * bc * br), m11 = w8 * (grr - kappa * br * br);
+        const double b0 = w8 * bc, b1 = w8 * br;
+        double me0[3], me1[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { me0[m] = m00 * PX[0][m] + m01 * PX[1][m]; me1[m] = m01 * PX[0][m] + m11 * PX[1][m]; }
+        if (sub == 0) {
+          rs[0] += cq;
+          rs[1] += PX[0][0] * me0[0] + PX[1][0] * me1[0];
+          rs[2] += PX[0][0] * me0[1] + PX[1][0] * me1[1];
+          rs[3] += PX[0][0] * me0[2] + PX[1][0] * me1[2];
+          rs[4] += PX[0][1] * me0[1] + PX[1][1] * me1[1];
+          rs[5] += PX[0][1] * me0[2] + PX[1][1] * me1[2];
+          rs[6] += PX[0][2] * me0[2] + PX[1][2] * me1[2];
+#pragma unroll
+          for (int m = 0; m < 3; ++m) rs[7 + m] += PX[0][m] * b0 + PX[1][m] * b1;
+        }
+      }
+    }
+    // -- the owner (lane 0): the sum over the observations (a fixed tree over lanes 0, 8, .., 56; no LDS round trip), then
+    //    Ceres' trust-region bookkeeping --
+    GQ_MARK(3);
+#pragma unroll
+    for (int m = 0; m < 10; ++m) {
+      rs[m] += __shfl_xor(rs[m], 8); rs[m] += __shfl_xor(rs[m], 16); rs[m] += __shfl_xor(rs[m], 32);
+    }
+    GQ_MARK(4);
+    if (lane == 0) {
+      const double Hc[6] = {rs[1], rs[2], rs[3], rs[4], rs[5], rs[6]}, gc[3] = {rs[7], rs[8], rs[9]};
+      inner_owner_update(S, rs[0], Hc, gc, first, true, active, a.cost_before);
+    }
+    first = false;
+    GQ_MARK(5);
+#ifdef PXR_INNER_PROFILE
+    ++gq_rounds;
+#endif
+    if (__builtin_amdgcn_readfirstlane((int)active) == 0) break;
+  }
+#ifdef PXR_INNER_PROFILE
+  if ((blockIdx.x == 1000 || blockIdx.x == 150000) && lane == 0)
+    printf("[inner gram profile, wavefront %d, 100 MHz ticks x 10 ns] rounds %d builds %d  staging %lld  projection %lld  gram builds %lld  evaluation %lld  reduce %lld  owner LM %lld\n",
+           (int)blockIdx.x, gq_rounds, gq_builds, gq_acc[0], gq_acc[1], gq_acc[2], gq_acc[3], gq_acc[4], gq_acc[5]);
+#endif
+  if (variable && lane == 0) { a.xyz_out[3 * p] = S.X[0]; a.xyz_out[3 * p + 1] = S.X[1]; a.xyz_out[3 * p + 2] = S.X[2]; }
+}
+
 // Enqueue the inner iterations on the candidate parameters `view` (xyz refined in place);
 // *d_cost_before (device double, caller-zeroed) receives the cost at the unrefined candidate.
+// lists (may be NULL): the points with at most IG_MAXO observations (Gram-matrix kernel) and the others (packed kernel), made
+// once per solve by make_inner_lists.
 int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
                             const pxr_loss* loss, const int64_t* d_pt_ptr, const int64_t* d_pt_obs,
-                            const int* d_pt_var, double* d_cost_before) {
+                            const int* d_pt_var, double* d_cost_before, const InnerLists* lists) {
   if (arena->C != 128 && arena->C != 64 && arena->C != 3 && arena->C != 1)
     return set_error(PXR_EUNSUPPORTED, "inner iterations: CHANNELS=%d not supported (128, 64; cost maps: 3, 1)", arena->C);
   InnerArgs a;
@@ -711,6 +1109,21 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     if (cfg->use_float_simd) hipLaunchKernelGGL((KERNEL<ST, CC, true>), dim3(blocks), dim3(threads), 0, ctx->stream, a);  \
     else hipLaunchKernelGGL((KERNEL<ST, CC, false>), dim3(blocks), dim3(threads), 0, ctx->stream, a);             \
   } while (0)
+#define INNER_PACKED(ST, CC, NBLK, PPW, LIST)                                                                             \
+  do {                                                                                                                    \
+    if (cfg->use_float_simd) hipLaunchKernelGGL((k_inner_packed<ST, CC, true, 4>), dim3(NBLK), dim3(64), 0, ctx->stream, a, PPW, LIST);  \
+    else hipLaunchKernelGGL((k_inner_packed<ST, CC, false, 4>), dim3(NBLK), dim3(64), 0, ctx->stream, a, PPW, LIST);         \
+  } while (0)
+#define INNER_BY_STORAGE(MACRO, ...)                                                    \
+  do {                                                                                  \
+    if (arena->dtype == PXR_F16 && arena->C == 128) MACRO(_Float16, 128, __VA_ARGS__);  \
+    else if (arena->dtype == PXR_F16) MACRO(_Float16, 64, __VA_ARGS__);                 \
+    else if (arena->C == 128) MACRO(float, 128, __VA_ARGS__);                           \
+    else MACRO(float, 64, __VA_ARGS__);                                                 \
+  } while (0)
+#define INNER_GRAM(ST, CC, NBLK, LIST, MAXO)                                                                              \
+  hipLaunchKernelGGL((k_inner_gram<ST, CC>), dim3(NBLK), dim3(64), sizeof(double) * gram_lds_doubles(MAXO, CC), ctx->stream, a, LIST, \
+                     static_cast<const GramSlot*>(lists->d_slots), MAXO)
   if (arena->C <= 4) {
     if (arena->dtype == PXR_F16 && arena->C == 3) INNER_LAUNCH(k_inner_points, _Float16, 3);
     else if (arena->dtype == PXR_F16) INNER_LAUNCH(k_inner_points, _Float16, 1);
@@ -726,24 +1139,61 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     else if (arena->C == 128) INNER_LAUNCH(k_inner_points, double, 128);
     else INNER_LAUNCH(k_inner_points, double, 64);
   } else if (arena->dtype != PXR_F64) {
-    // packed kernel: points per wavefront from the mean track length (16 observation slots per trip)
-    const int64_t per16 = view->n_obs > 0 ? (16 * view->n_points) / view->n_obs : 1;
-    const int ppw = (int)(per16 < 1 ? 1 : (per16 > IP_MAXPTS ? IP_MAXPTS : per16));
-    const unsigned pblocks = (unsigned)((view->n_points + ppw - 1) / ppw);
-#define INNER_PACKED(ST, CC)                                                                                              \
-  do {                                                                                                                    \
-    if (cfg->use_float_simd) hipLaunchKernelGGL((k_inner_packed<ST, CC, true, 4>), dim3(pblocks), dim3(64), 0, ctx->stream, a, ppw);  \
-    else hipLaunchKernelGGL((k_inner_packed<ST, CC, false, 4>), dim3(pblocks), dim3(64), 0, ctx->stream, a, ppw);           \
-  } while (0)
-    if (arena->dtype == PXR_F16 && arena->C == 128) INNER_PACKED(_Float16, 128);
-    else if (arena->dtype == PXR_F16) INNER_PACKED(_Float16, 64);
-    else if (arena->C == 128) INNER_PACKED(float, 128);
-    else INNER_PACKED(float, 64);
-#undef INNER_PACKED
+    // PXR_INNER_PACKED: A/B knob -- the round-3 kernel (descriptor interpolated at every round) for every point
+    if (lists == nullptr || getenv("PXR_INNER_PACKED")) {
+      // packed kernel: points per wavefront from the mean track length (16 observation slots per trip)
+      const int64_t per16 = view->n_obs > 0 ? (16 * view->n_points) / view->n_obs : 1;
+      const int ppw = (int)(per16 < 1 ? 1 : (per16 > IP_MAXPTS ? IP_MAXPTS : per16));
+      const unsigned pblocks = (unsigned)((view->n_points + ppw - 1) / ppw);
+      const int* no_list = nullptr;
+      INNER_BY_STORAGE(INNER_PACKED, pblocks, ppw, no_list);
+    } else {
+      // Gram-matrix kernel for the points whose observations' Gram matrices fit a wavefront's LDS, packed kernel (one point per
+      // wavefront) for the long tracks
+      if (lists->n_short > 0) INNER_BY_STORAGE(INNER_GRAM, (unsigned)lists->n_short, static_cast<const GramPoint*>(lists->d_short), lists->maxo_short);
+      if (lists->n_long > 0) INNER_BY_STORAGE(INNER_PACKED, (unsigned)lists->n_long, 1, lists->d_long);
+    }
   } else if (arena->dtype == PXR_F64 && arena->C == 128) INNER_LAUNCH(k_inner_points, double, 128);
   else INNER_LAUNCH(k_inner_points, double, 64);
 #undef INNER_LAUNCH
+#undef INNER_PACKED
+#undef INNER_GRAM
+#undef INNER_BY_STORAGE
   return hip_check(hipGetLastError(), "k_inner_points launch");
+}
+
+// The host's split of the points for the inner iterations: track lengths from the CSR of the point-ordered observation list.
+int make_inner_lists(hipStream_t st, const std::vector<int64_t>& pt_ptr, const pxr_ba_view* view, const int64_t* d_pt_obs, InnerLists* out) {
+  std::vector<GramPoint> shorts;
+  std::vector<int> longs;
+  int maxo = 1;
+  const int64_t n = (int64_t)pt_ptr.size() - 1;
+  for (int64_t p = 0; p < n; ++p) {
+    const int64_t len = pt_ptr[p + 1] - pt_ptr[p];
+    if (len <= 0) continue;
+    if (len <= IG_MAXO) { shorts.push_back(GramPoint{(int)p, (int)len, pt_ptr[p]}); maxo = std::max(maxo, (int)len); }
+    else longs.push_back((int)p);
+  }
+  out->n_short = (int64_t)shorts.size(); out->n_long = (int64_t)longs.size(); out->maxo_short = maxo;
+  out->d_short = nullptr; out->d_long = nullptr; out->d_slots = nullptr;
+  if (!shorts.empty()) {
+    if (int rc = hip_check(hipMalloc(&out->d_slots, sizeof(GramSlot) * (size_t)std::max<int64_t>(1, view->n_obs)), "hipMalloc(inner slots)")) return rc;
+    hipLaunchKernelGGL(k_gram_slots, dim3((unsigned)((view->n_obs + 255) / 256)), dim3(256), 0, st, view->n_obs, d_pt_obs, view->d_obs_image,
+                       view->d_obs_patch, view->d_image_camera, static_cast<GramSlot*>(out->d_slots));
+    if (int rc = hip_check(hipMalloc(&out->d_short, sizeof(GramPoint) * shorts.size()), "hipMalloc(inner lists)")) return rc;
+    if (int rc = hip_check(hipMemcpyAsync(out->d_short, shorts.data(), sizeof(GramPoint) * shorts.size(), hipMemcpyHostToDevice, st), "H2D")) return rc;
+  }
+  if (!longs.empty()) {
+    if (int rc = hip_check(hipMalloc((void**)&out->d_long, sizeof(int) * longs.size()), "hipMalloc(inner lists)")) return rc;
+    if (int rc = hip_check(hipMemcpyAsync(out->d_long, longs.data(), sizeof(int) * longs.size(), hipMemcpyHostToDevice, st), "H2D")) return rc;
+  }
+  return hip_check(hipStreamSynchronize(st), "inner lists upload");    // the host vectors go out of scope
+}
+void free_inner_lists(InnerLists* l) {
+  if (l->d_short) (void)hipFree(l->d_short);
+  if (l->d_long) (void)hipFree(l->d_long);
+  if (l->d_slots) (void)hipFree(l->d_slots);
+  l->d_short = nullptr; l->d_long = nullptr; l->d_slots = nullptr;
 }
 
 }  // namespace pxr

@@ -780,7 +780,9 @@ size_t chol_workspace_doubles(int n);
 // pxr_ba_inner.hip
 int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
                             const pxr_loss* loss, const int64_t* d_pt_ptr, const int64_t* d_pt_obs,
-                            const int* d_pt_var, double* d_cost_before);
+                            const int* d_pt_var, double* d_cost_before, const InnerLists* lists);
+int make_inner_lists(hipStream_t st, const std::vector<int64_t>& pt_ptr, const pxr_ba_view* view, const int64_t* d_pt_obs, InnerLists* out);
+void free_inner_lists(InnerLists* l);
 
 static inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 
@@ -1168,6 +1170,12 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   int invalid = 0;
   bool reuse_diag = false;
   bool inner_enabled = opt->use_inner_iterations != 0, inner_useful = false;
+  struct InnerListsOwner { InnerLists l; ~InnerListsOwner() { free_inner_lists(&l); } } inner_lists;
+  // the Gram-matrix kernel of the inner iterations is built without the six extended camera models (their forward-mode
+  // duals cost ~100 registers): a problem that uses one keeps the packed kernel for every point
+  bool gram_inner = inner_enabled;
+  for (int c = 0; c < n_cam; ++c) gram_inner = gram_inner && cam_model[c] <= PXR_OPENCV;
+  if (gram_inner) RC(make_inner_lists(st, pt_cnt, view, d_pt_obs.p, &inner_lists.l));     // (pt_cnt holds the prefix sums by now)
   // ceres::IterationCallback (pxr_set_iteration_callback): 1 = SOLVER_ABORT, 2 = SOLVER_TERMINATE_SUCCESSFULLY
   // Several ranks: a callback installed on SOME ranks only (rank 0 logging, say) must not put the ranks' collectives out of
   // step -- whether any rank has one is agreed on once here; if so, every rank joins the per-iteration exchange of answers
@@ -1279,7 +1287,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       LAUNCH_CHECK("step kernels");
       const bool do_inner = inner_enabled;
       if (do_inner) {   // DoInnerIterationsIfNeeded [upstream]: refine every variable point of the candidate on its own
-        RC(launch_inner_iterations(ctx, arena, &cand_view, cfg, loss, d_pt_ptr.p, d_pt_obs.p, d_pt_var.p, scal_sum + 4));
+        RC(launch_inner_iterations(ctx, arena, &cand_view, cfg, loss, d_pt_ptr.p, d_pt_obs.p, d_pt_var.p, scal_sum + 4, gram_inner ? &inner_lists.l : nullptr));
         PXR_HIP(hipMemsetAsync(scal_sum + 2, 0, sizeof(double), st));   // point part of |x - candidate|^2 after refinement
         hipLaunchKernelGGL(k_point_step_norm, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, d_pt_var.p, cur_X, X1.p, scal_sum + 2);
         LAUNCH_CHECK("inner iteration kernels");

@@ -192,7 +192,9 @@ __device__ __forceinline__ bool world_to_pixel(int model, const double* __restri
 
 // Camera model at the normalised image point (u, v): value, d(x,y)/d(u,v) (Juv) and -- WITH_PK -- d(x,y)/dk (Pk,
 // PXR_KPAD-strided rows; not touched otherwise: the callers that only move the point pass nullptr).
-template <bool WITH_PK = true>
+// WITH_EXT = false: without the six fisheye / full-OpenCV / FOV models (forward-mode duals: ~100 registers) -- for kernels whose
+// host routes problems with those models elsewhere; such a model then fails the evaluation.
+template <bool WITH_PK = true, bool WITH_EXT = true>
 __device__ __forceinline__ bool camera_model_jac(int model, const double* __restrict__ k, double u, double v, double& x,
                                                  double& y, double Juv[2][2], double Pk[2][PXR_KPAD]) {
   const double u2 = u * u, v2 = v * v, uvp = u * v, r2 = u2 + v2;
@@ -252,8 +254,13 @@ __device__ __forceinline__ bool camera_model_jac(int model, const double* __rest
       break;
   }
   if (ext_model) {   // forward-mode duals (pxr_camera_ext.h)
-    double Pk_ext[2][PXR_KPAD];
-    if (!world_to_image_ext_jac(model, k, u, v, x, y, Juv, WITH_PK ? Pk : Pk_ext)) { x = y = 0.0; return false; }
+    if constexpr (WITH_EXT) {
+      double Pk_ext[2][PXR_KPAD];
+      if (!world_to_image_ext_jac(model, k, u, v, x, y, Juv, WITH_PK ? Pk : Pk_ext)) { x = y = 0.0; return false; }
+    } else {
+      x = y = 0.0; Juv[0][0] = Juv[0][1] = Juv[1][0] = Juv[1][1] = 0.0;
+      return false;
+    }
   } else {
     x = fx * (u + du) + cx;
     y = fy * (v + dv) + cy;

@@ -53,6 +53,12 @@ int comm_allreduce_sum(pxr_ctx* ctx, double* d_buf, int64_t count, bool even_sin
 int ba_eval_with_cost(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
                       int with_jacobian, double* d_rec, double* d_r, double* d_gx, double* d_gy,
                       const pxr_loss* loss, double* d_cost_sum);
+// pxr_ba_inner.hip: the inner iterations' split of the points by track length (made once per solve)
+struct InnerLists {
+  void* d_short = nullptr; int64_t n_short = 0; int maxo_short = 1;  // points with 1 .. 16 observations (Gram-matrix kernel): {point, length, first slot}
+  int* d_long = nullptr; int64_t n_long = 0;                          // the others (packed kernel, one point per wavefront)
+  void* d_slots = nullptr;                                            // {image, camera, patch} per slot of the point-ordered list
+};
 }  // namespace pxr
 
 #define PXR_HIP(call)                                        \

@@ -116,5 +116,58 @@ def test_inner_iterations_every_camera_model_and_storage(ctx, model, dtype, chan
     so, qo, to, ko, Xo = pxo.ba_solve(prob, pxo.cfg(), pxo.loss("cauchy", 0.25), *gauge,
                                       pxo.lm_options(max_iterations=2, use_inner_iterations=1))
     assert s["iterations"] == so["iterations"] and s["num_successful"] == so["num_successful"]
-    assert abs(s["final_cost"] - so["final_cost"]) < 1e-4 * max(so["final_cost"], 1e-9)
+    # These noise-free scenes converge to residuals of |r| ~ 6e-4 (|r|^2 ~ 4e-7 per block, final cost 1e-9 of the initial one),
+    # where the fp32 rounding of the reference's horizontal spline pass (6e-8 per channel: 2 r . df ~ 7e-11 per block) is
+    # itself ~2e-4 of the cost: the Gram-matrix kernel's nested LM (exact fp64 bicubic) and the oracle's (fp32 pass) then
+    # minimise costs that differ by that much.  The cost is compared at 5e-4 here, the parameters at north_star's 1e-4 as before.
+    assert abs(s["final_cost"] - so["final_cost"]) < 5e-4 * max(so["final_cost"], 1e-9)
     assert np.abs(q - qo).max() < 1e-4 and np.abs(t - to).max() < 1e-4 and np.abs(X - Xo).max() < 1e-4
+
+
+def _ragged_scene(seed, channels, dtype, n_cams=24):
+    """Tracks of 2 .. 22 observations (beyond 16 the Gram matrices of a point no longer fit a wavefront's LDS: those points take
+    the packed kernel), initial errors of about a texel (cells change inside the nested LM: Gram matrices are rebuilt)."""
+    from pixsfm_amd import synthetic
+    rng = np.random.default_rng(seed)
+    prob = synthetic.make_ba_problem(n_cams=n_cams, n_points=60, obs_per_point=22, seed=seed, channels=channels, dtype=dtype,
+                                     pt_sigma=0.02, rot_deg=0.3)
+    keep = np.zeros(len(prob["obs_point"]), bool)
+    lengths = rng.integers(2, 23, 60)
+    lengths[:3] = (16, 17, 22)
+    for p in range(60):
+        idx = np.nonzero(prob["obs_point"] == p)[0]
+        keep[idx[:lengths[p]]] = True
+    for k in ("obs_image", "obs_point", "obs_patch"):
+        prob[k] = prob[k][keep]
+    return prob, lengths
+
+
+@pytest.mark.parametrize("dtype,channels,l2,loss", [(np.float16, 128, True, "cauchy"), (np.float32, 64, True, "huber"),
+                                                    (np.float16, 64, False, "trivial"), (np.float32, 128, False, "cauchy")])
+def test_gram_matrix_kernel_equals_the_interpolating_kernel(ctx, monkeypatch, dtype, channels, l2, loss):
+    """The inner iterations on the stencils' Gram matrices (k_inner_gram: nine channel sums as quadratic forms in the
+    Catmull-Rom weights, fp64 MFMA) against the kernel that interpolates the descriptor at every round (k_inner_packed,
+    PXR_INNER_PACKED=1): same outer trajectory, refined parameters equal far inside the nested LM's own 1e-6 tolerances, on
+    tracks of 2 .. 22 observations with texel-sized initial errors."""
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    prob, lengths = _ragged_scene(7, channels, dtype)
+    assert lengths.max() > 16 and lengths.min() <= 3
+    gauge = _gauge(prob)
+    out = {}
+    for mode in ("gram", "packed"):
+        if mode == "packed":
+            monkeypatch.setenv("PXR_INNER_PACKED", "1")
+        arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+        ba = BAProblem(ctx, arena, prob)
+        s = ba.solve(interp_cfg(l2_normalize=l2), make_loss(loss, [0.25] if loss != "trivial" else []), *gauge,
+                     options=lm_options(max_iterations=3, use_inner_iterations=True))
+        out[mode] = (s, ba.params())
+        arena.close()
+    (sg, pg), (sp, pp) = out["gram"], out["packed"]
+    assert sg["iterations"] == sp["iterations"] and sg["num_successful"] == sp["num_successful"]
+    assert abs(sg["initial_cost"] - sp["initial_cost"]) <= 1e-13 * sp["initial_cost"]
+    assert abs(sg["final_cost"] - sp["final_cost"]) < 2e-6 * sp["final_cost"]
+    for a, b in zip(pg, pp):
+        assert (np.abs(a - b) <= 2e-6 * np.maximum(1.0, np.abs(b))).all()
+    # the first iteration's refinement really moved the points (the kernels did run)
+    assert np.abs(pg[3] - prob["xyz"]).max() > 1e-4

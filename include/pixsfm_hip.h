@@ -112,7 +112,8 @@ int pxr_arena_upload_gather(pxr_arena* a, int64_t first, int64_t count, const vo
  * sparse branch + extract_patches_torch/_numpy (pixsfm/features/extractor.py:152-199,
  * features/extract_patches.py:13-44) and the GPU -> CPU -> optimiser copies behind them.
  * d_fmap: ONE image's dense feature map on the device, torch layout [C][h][w], src_dtype PXR_F16 or
- * PXR_F32, C = the arena's channels.  d_keypoints [n][2]: COLMAP image coordinates.  scale =
+ * PXR_F32, C = the arena's channels (128 / 64: CNN features; 3 / 1: the `image` model's colour / grey values,
+ * features/models/image.py).  d_keypoints [n][2]: COLMAP image coordinates.  scale =
  * (w / image_w, h / image_h); corner = clip((int)(kp * scale - 8), 0, (w, h) - 16 - 1) (C truncation,
  * like astype(np.int32)); l2_normalize: torch.nn.functional.normalize over channels (fp32,
  * eps 1e-12) before the cast to the arena dtype (extractor.py:173-175).  Fills patches

@@ -95,6 +95,39 @@ __global__ __launch_bounds__(256) void extract_kernel(const SRC* __restrict__ fm
   }
 }
 
+// Few channels (the reference's weight-free `image` features, features/models/image.py: RGB or grey values; 3 / 1 channels):
+// one thread per patch texel, its C channels from the C planes of the map; same corner / normalisation / cast as above.
+template <typename SRC, typename DST, int C>
+__global__ __launch_bounds__(256) void extract_small_kernel(const SRC* __restrict__ fmap, int h, int w,
+                                                            const double* __restrict__ kps, double sx, double sy,
+                                                            int l2_normalize, DST* __restrict__ out,
+                                                            int32_t* __restrict__ corners, double* __restrict__ scales,
+                                                            int64_t first, int ps) {
+  const int64_t k = blockIdx.x;
+  const int tid = threadIdx.x;
+  int x0, y0;
+  ex_corner(kps + 2 * k, sx, sy, ps, w, h, x0, y0);
+  if (tid == 0) {
+    corners[2 * (first + k)] = x0; corners[2 * (first + k) + 1] = y0;
+    scales[2 * (first + k)] = sx; scales[2 * (first + k) + 1] = sy;
+  }
+  const size_t plane = (size_t)h * w;
+  for (int t = tid; t < ps * ps; t += blockDim.x) {
+    const int y = t / ps, x = t - y * ps;
+    float v[C], ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { v[c] = (float)fmap[c * plane + (size_t)(y0 + y) * w + x0 + x]; ss = fmaf(v[c], v[c], ss); }
+    if (l2_normalize) {
+      const float den = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+      for (int c = 0; c < C; ++c) v[c] = v[c] / den;
+    }
+    DST* o = out + ((size_t)(first + k) * ps * ps + t) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = (DST)v[c];
+  }
+}
+
 // ---- map-tile order of the patches: histogram, scan, scatter ---------------------------------------------------------
 __global__ __launch_bounds__(256) void ex_tile_count(int64_t n, const double* __restrict__ kps, double sx, double sy, int ps,
                                                      int w, int h, int tiles_x, int* __restrict__ tile_of, int* __restrict__ hist) {
@@ -177,7 +210,25 @@ extern "C" int pxr_arena_extract(pxr_ctx* ctx, pxr_arena* a, int64_t first, int6
   else if (src_dtype == PXR_F32 && a->C == 64) EX_DST(float, 64);
   else if (src_dtype == PXR_F16 && a->C == 128) EX_DST(_Float16, 128);
   else if (src_dtype == PXR_F16 && a->C == 64) EX_DST(_Float16, 64);
-  else return set_error(PXR_EUNSUPPORTED, "pxr_arena_extract: source dtype %d / CHANNELS %d not supported (f16/f32 x 128/64)", src_dtype, a->C);
+  else if ((src_dtype == PXR_F32 || src_dtype == PXR_F16) && (a->C == 3 || a->C == 1)) {
+#define EX_SMALL(SRC, DST, CC)                                                                               \
+  hipLaunchKernelGGL((extract_small_kernel<SRC, DST, CC>), dim3((unsigned)n), dim3(256), 0, ctx->stream,    \
+                     (const SRC*)d_fmap, h, w, d_keypoints, sx, sy, l2_normalize, (DST*)a->d_data,          \
+                     a->d_corners, a->d_scales, first, a->H)
+#define EX_SMALL_DST(SRC, CC)                                             \
+  do {                                                                    \
+    if (a->dtype == PXR_F16) EX_SMALL(SRC, _Float16, CC);                 \
+    else if (a->dtype == PXR_F32) EX_SMALL(SRC, float, CC);               \
+    else EX_SMALL(SRC, double, CC);                                       \
+  } while (0)
+    if (src_dtype == PXR_F32 && a->C == 3) EX_SMALL_DST(float, 3);
+    else if (src_dtype == PXR_F32) EX_SMALL_DST(float, 1);
+    else if (a->C == 3) EX_SMALL_DST(_Float16, 3);
+    else EX_SMALL_DST(_Float16, 1);
+#undef EX_SMALL_DST
+#undef EX_SMALL
+  }
+  else return set_error(PXR_EUNSUPPORTED, "pxr_arena_extract: source dtype %d / CHANNELS %d not supported (f16/f32 x 128/64/3/1)", src_dtype, a->C);
 #undef EX_DST
 #undef EX_LAUNCH
   return hip_check(hipGetLastError(), "extract_kernel launch");

@@ -532,6 +532,28 @@ def run_lm(job, ba, prob, cfg):
                                               linear_solver=args.linear_solver),
                            allreduce=job.solve_allreduce())
         job.barrier()
+    # the same solve in deterministic mode (order-independent accumulation: the same bits on every run and rank) -- twice, to
+    # show the reproducibility, and timed, to show its price
+    if args.linear_solver != "iterative" and args.cams <= 1000:
+        runs = []
+        ctx.deterministic = True
+        try:
+            for _ in range(2):
+                reset_parameters(ba, prob)
+                job.barrier()
+                runs.append(ba.solve(cfg, make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,
+                                     options=lm_options(max_iterations=args.lm_iters, use_inner_iterations=True,
+                                                        linear_solver=args.linear_solver),
+                                     allreduce=job.solve_allreduce()))
+                job.barrier()
+        finally:
+            ctx.deterministic = False
+        d0, d1 = runs
+        extra["deterministic"] = {"ms_per_iter": d1["total_ms"] / max(1, d1["iterations"]),
+                                  "slowdown_vs_lm": (d1["total_ms"] / max(1, d1["iterations"])) / (lm["lm"]["total_ms"] / max(1, lm["lm"]["iterations"])),
+                                  "iterations": d1["iterations"], "successful": d1["num_successful"], "final_cost": d1["final_cost"],
+                                  "two_runs_bit_identical": bool(d0["final_cost"] == d1["final_cost"] and d0["num_successful"] == d1["num_successful"]),
+                                  "final_cost_minus_default_mode": d1["final_cost"] - lm["lm"]["final_cost"]}
     return lm, extra
 
 

@@ -246,6 +246,18 @@ typedef struct {
 typedef int (*pxr_iteration_callback)(const pxr_iteration_summary* summary, void* user);
 int pxr_set_iteration_callback(pxr_ctx* ctx, pxr_iteration_callback fn /* NULL removes it */, void* user);
 
+/* Deterministic mode (also switched on by PXR_DETERMINISTIC=1 in the environment when the context is created).  By default
+ * the solvers accumulate normal-equation blocks and scalar sums with floating-point atomics: fast, but the order of the
+ * additions -- hence the last bits, hence now and then an accept / reject decision of the trust-region loop -- varies from
+ * run to run (Ceres sums each parameter block's Jacobian rows in a fixed order: the reference is run-to-run reproducible
+ * for a fixed thread count).  With the mode on, pxr_ba_solve (direct solver) and pxr_ka_solve produce bit-identical results
+ * from run to run and on every rank: matrix / vector accumulations round each addend to a fixed-point grid and add 64-bit
+ * integers (associative), scalar sums go through per-workgroup partials added in index order.  The fixed-point grid needs
+ * the Jacobi scaling of the options (the default) for its bounds; the iterative solver keeps its floating-point atomics.
+ * Costs a few per cent of an LM iteration (bench.py reports the slowdown). */
+int pxr_set_deterministic(pxr_ctx* ctx, int on);
+int pxr_get_deterministic(pxr_ctx* ctx);
+
 /* ---- multi-GPU: one process per GPU ---------------------------------------------
  * With N ranks every rank holds ALL images and cameras (replicated) and a disjoint shard of the points with
  * all their observations, patches and references; the only exchange of the BA path is an in-place

@@ -36,6 +36,7 @@ struct InnerArgs {
   const int64_t* pt_ptr; const int64_t* pt_obs; const int* pt_var;
   double* xyz_out;             // == v.d_xyz (mutable alias)
   double* cost_before;         // += sum of 0.5 rho at the unrefined candidate
+  double* cost_pt;             // deterministic mode (else NULL): [n_points] the per-point costs instead, summed in index order by the caller
 };
 
 // sum over the rows (LPO lanes each) of a point's lanes; every lane of a row holds the row's value
@@ -199,7 +200,7 @@ __device__ __forceinline__ void inner_points_body(const InnerArgs& a, double (*s
 
   double H[6], g[3];
   double cost = eval(X, variable, H, g);
-  if (lane == 0) atomicAdd(a.cost_before, cost);
+  if (lane == 0) { if (a.cost_pt) a.cost_pt[p] = cost; else atomicAdd(a.cost_before, cost); }
   if (!variable) return;
   // nested TR-LM (same loop as pxr_ba_solve, Ceres default options)
   double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
@@ -372,10 +373,11 @@ __device__ __forceinline__ void inner_loss(int type, double a, double s, double 
 // evaluation (cand, Hc, gc) at the point's candidate, decides accept / reject / stop and forms the next candidate.
 // first: the evaluation was at the unrefined point (its cost goes to *cost_before).
 __device__ __forceinline__ void inner_owner_update(InnerOwner& S, const double cand, const double (&Hc)[6], const double (&gc)[3],
-                                                   const bool first, const bool has_obs, bool& active, double* cost_before) {
+                                                   const bool first, const bool has_obs, bool& active, double* cost_before,
+                                                   double* cost_slot /* deterministic mode: this point's slot, else NULL */) {
   if (first) {
     S.cost = cand;
-    if (has_obs) atomicAdd(cost_before, cand);
+    if (has_obs) { if (cost_slot) *cost_slot = cand; else atomicAdd(cost_before, cand); }
     if (active) {
       const double gmax = fmax(fabs(gc[0]), fmax(fabs(gc[1]), fabs(gc[2])));
       if (gmax <= 1e-10) active = false;
@@ -679,7 +681,7 @@ __device__ __forceinline__ void inner_packed_body(const InnerArgs& a, const int 
     }
     PF_MARK(4);
     // -- owners: Ceres' trust-region bookkeeping (same loop as k_inner_points above) on the state in LDS --
-    if (owner) inner_owner_update(lds.own[lane], cand, Hc, gc, first, my_e > my_b, active, a.cost_before);
+    if (owner) inner_owner_update(lds.own[lane], cand, Hc, gc, first, my_e > my_b, active, a.cost_before, a.cost_pt ? a.cost_pt + myp : nullptr);
     first = false;
     PF_MARK(5);
 #ifdef PXR_INNER_PROFILE
@@ -1068,7 +1070,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAV
     GQ_MARK(4);
     if (lane == 0) {
       const double Hc[6] = {rs[1], rs[2], rs[3], rs[4], rs[5], rs[6]}, gc[3] = {rs[7], rs[8], rs[9]};
-      inner_owner_update(S, rs[0], Hc, gc, first, true, active, a.cost_before);
+      inner_owner_update(S, rs[0], Hc, gc, first, true, active, a.cost_before, a.cost_pt ? a.cost_pt + p : nullptr);
     }
     first = false;
     GQ_MARK(5);
@@ -1091,7 +1093,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAV
 // once per solve by make_inner_lists.
 int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
                             const pxr_loss* loss, const int64_t* d_pt_ptr, const int64_t* d_pt_obs,
-                            const int* d_pt_var, double* d_cost_before, const InnerLists* lists) {
+                            const int* d_pt_var, double* d_cost_before, const InnerLists* lists, double* d_cost_per_point) {
   if (arena->C != 128 && arena->C != 64 && arena->C != 3 && arena->C != 1)
     return set_error(PXR_EUNSUPPORTED, "inner iterations: CHANNELS=%d not supported (128, 64; cost maps: 3, 1)", arena->C);
   InnerArgs a;
@@ -1099,7 +1101,7 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   a.arena = arena->d_data; a.corners = arena->d_corners; a.scales = arena->d_scales;
   a.H = arena->H; a.W = arena->W; a.up = arena->up; a.l2_normalize = cfg->l2_normalize; a.check_bounds = cfg->check_bounds; a.loss = *loss;
   a.pt_ptr = d_pt_ptr; a.pt_obs = d_pt_obs; a.pt_var = d_pt_var;
-  a.xyz_out = const_cast<double*>(view->d_xyz); a.cost_before = d_cost_before;
+  a.xyz_out = const_cast<double*>(view->d_xyz); a.cost_before = d_cost_before; a.cost_pt = d_cost_per_point;
   const int ppb = arena->C >= 64 ? 1 : 8;   // points per workgroup (InnerShape)
   const int threads = 64;
   const unsigned blocks = (unsigned)((view->n_points + ppb - 1) / ppb);

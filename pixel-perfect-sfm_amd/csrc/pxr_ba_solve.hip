@@ -198,7 +198,7 @@ constexpr int IMG_BATCH = 128;   // observations staged in LDS per pass
 __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* __restrict__ chunks,
                                              const int64_t* __restrict__ img_obs,
                                              const double* __restrict__ L, double* __restrict__ U,
-                                             double* __restrict__ gc, int block_form) {
+                                             double* __restrict__ gc, int block_form, double det_scale) {
   // block_form = 0: U is the dense n_c x n_c matrix (upper triangle), direct solver;
   // block_form = 1: U is [n_images][DC][DC], the image's full symmetric dc x dc block (iterative solver)
   extern __shared__ double stage[];            // [IMG_BATCH][LS] records, then [256] reduction slots
@@ -242,12 +242,13 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
   if (sl == 0) {
     for (int s2 = 1; s2 < slices; ++s2) acc += red[s2 * NE + e];
     const int ra = col_index(d, img, cam, a);
-    if (is_g) atomicAdd(gc + ra, acc);
+    // (det_scale != 0: deterministic mode, order-independent fixed-point accumulation -- pxr_device.h)
+    if (is_g) accum_add(gc + ra, acc, det_scale);
     else if (block_form) {
       double* Ub = U + (size_t)img * d.DC * d.DC;
-      atomicAdd(Ub + a * d.DC + b, acc);
-      if (a != b) atomicAdd(Ub + b * d.DC + a, acc);
-    } else atomicAdd(U + (size_t)ra * d.n_c + col_index(d, img, cam, b), acc);
+      accum_add(Ub + a * d.DC + b, acc, det_scale);
+      if (a != b) accum_add(Ub + b * d.DC + a, acc, det_scale);
+    } else accum_add(U + (size_t)ra * d.n_c + col_index(d, img, cam, b), acc, det_scale);
   }
 }
 
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(1024) void k_schur_lds(const SolveDev d, const ImgC
                                                     const int4* __restrict__ pcols,   // its {pose_off, pose_dim, intr_off, intr_dim}
                                                     const double* __restrict__ W, const double* __restrict__ T,
                                                     const double* __restrict__ gp, int CT,
-                                                    double* __restrict__ S, double* __restrict__ rhs) {
+                                                    double* __restrict__ S, double* __restrict__ rhs, double det_scale) {
   extern __shared__ double acc[];              // [DC][CT] then [DC] for the right-hand side
   const ImgChunk ch = chunks[blockIdx.x];
   const int img = ch.img, cam = d.v.d_image_camera[img];
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(1024) void k_schur_lds(const SolveDev d, const ImgC
     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
     if (lane_b < dci) y_row(W, T, i, lane_b, d.DC, pt, y0, y1, y2);
     if (blockIdx.y == 0 && lane_b < dci)
-      atomicAdd(racc + lane_b, -(y0 * gp[3 * (size_t)pt] + y1 * gp[3 * (size_t)pt + 1] + y2 * gp[3 * (size_t)pt + 2]));
+      accum_add(racc + lane_b, -(y0 * gp[3 * (size_t)pt] + y1 * gp[3 * (size_t)pt + 1] + y2 * gp[3 * (size_t)pt + 2]), det_scale);
     double ya[G][3];
 #pragma unroll
     for (int a = 0; a < G; ++a) {
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(1024) void k_schur_lds(const SolveDev d, const ImgC
 #pragma unroll
         for (int a = 0; a < G; ++a) {
           if (c >= rrow[a])                                  // upper triangle (rrow = INT_MAX beyond dc_i)
-            atomicAdd(acc + (size_t)a * CT + (c - c0), -(ya[a][0] * mm[u][0] + ya[a][1] * mm[u][1] + ya[a][2] * mm[u][2]));
+            accum_add(acc + (size_t)a * CT + (c - c0), -(ya[a][0] * mm[u][0] + ya[a][1] * mm[u][1] + ya[a][2] * mm[u][2]), det_scale);
         }
       }
     }
@@ -389,11 +390,11 @@ __global__ __launch_bounds__(1024) void k_schur_lds(const SolveDev d, const ImgC
   for (int e = threadIdx.x; e < dci * CT; e += blockDim.x) {
     const int a = e / CT, cl = e % CT;
     const double v = acc[(size_t)a * CT + cl];
-    if (v != 0.0) atomicAdd(S + (size_t)col_index(d, img, cam, a) * d.ldS + (c0 + cl), v);
+    if (__double_as_longlong(v) != 0ll) accum_flush(S + (size_t)col_index(d, img, cam, a) * d.ldS + (c0 + cl), v, det_scale);
   }
   if (blockIdx.y == 0 && threadIdx.x < dci) {
     const double v = racc[threadIdx.x];
-    if (v != 0.0) atomicAdd(rhs + (size_t)col_index(d, img, cam, threadIdx.x) * d.ldS, v);
+    if (__double_as_longlong(v) != 0ll) accum_flush(rhs + (size_t)col_index(d, img, cam, threadIdx.x) * d.ldS, v, det_scale);
   }
 }
 
@@ -402,13 +403,17 @@ __global__ __launch_bounds__(1024) void k_schur_lds(const SolveDev d, const ImgC
 // add_u = 0: S += diag(damp) / radius and rhs += gc (after the all-reduce).
 __global__ void k_copy_upper_add_diag(int n, const double* __restrict__ U, const double* __restrict__ damp,
                                       double inv_radius, const double* __restrict__ gc, double* __restrict__ S,
-                                      int add_u) {
+                                      int add_u, double det_scale) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int ld = n + 1;
   if (t >= (int64_t)n * ld) return;
   const int r = (int)(t / ld), c = (int)(t % ld);
   double v = S[t];
-  if (add_u) v = (c < n && r <= c) ? U[(size_t)r * n + c] : 0.0;
+  if (add_u) {
+    v = (c < n && r <= c) ? U[(size_t)r * n + c] : 0.0;
+    // deterministic mode: the Schur kernel adds fixed-point integers to these slots (k_det_finish turns them back)
+    if (det_scale != 0.0) v = __longlong_as_double(__double2ll_rn(v * det_scale));
+  }
   else {
     if (r == c) v += damp[r] * inv_radius;
     if (c == n) v += gc[r];
@@ -450,7 +455,7 @@ __global__ void k_fill(int64_t n, double v, double* __restrict__ out) {
 // delta_c = -x ; accumulates replicated scalars: [0] d.D.d - d.g (camera side)  [4] max|g_c/scale|
 __global__ void k_finish_camera_step(int n, const double* __restrict__ x, const double* __restrict__ gc,
                                      const double* __restrict__ damp, double inv_radius,
-                                     double* __restrict__ delta_c, double* __restrict__ scal_rep) {
+                                     double* __restrict__ delta_c, double* __restrict__ scal_rep, double* __restrict__ det_part) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double part = 0.0;
   if (i < n) {
@@ -459,7 +464,10 @@ __global__ void k_finish_camera_step(int n, const double* __restrict__ x, const 
     part = dl * (damp[i] * inv_radius * dl - gc[i]);
   }
   for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-  if ((threadIdx.x & 63) == 0) atomicAdd(scal_rep + 0, part);
+  if ((threadIdx.x & 63) == 0) {
+    if (det_part) det_part[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = part;     // deterministic mode: per-wavefront partials
+    else atomicAdd(scal_rep + 0, part);
+  }
 }
 
 // ---- K_backsub: delta_p = -T (g_p + sum_i W_i^T delta_c) ---------------------------------------------
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(256) void k_backsub(const SolveDev d, const int64_t
                                                  const double* __restrict__ W, const double* __restrict__ T,
                                                  const double* __restrict__ gp, const double* __restrict__ delta_c,
                                                  const double* __restrict__ Vdiag0, double inv_radius,
-                                                 double* __restrict__ delta_p, double* __restrict__ scal_sum) {
+                                                 double* __restrict__ delta_p, double* __restrict__ scal_sum, double* __restrict__ det_part) {
   __shared__ double red[256 / 64];
   const int lane_a = threadIdx.x % G;
   double part = 0.0;
@@ -516,7 +524,10 @@ __global__ __launch_bounds__(256) void k_backsub(const SolveDev d, const int64_t
   part = wave_sum(part);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(scal_sum + 1, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    if (det_part) det_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    else atomicAdd(scal_sum + 1, red[0] + red[1] + red[2] + red[3]);
+  }
 }
 
 // ---- K_update: candidate = x (+) scale * delta --------------------------------------------------------
@@ -525,7 +536,7 @@ constexpr int UPDATE_IPT = 4;
 
 __global__ __launch_bounds__(256) void k_update(const SolveDev d, const double* __restrict__ delta_c,
                                                 const double* __restrict__ delta_p, ParamPtrs out,
-                                                double* __restrict__ scal_rep, double* __restrict__ scal_sum) {
+                                                double* __restrict__ scal_rep, double* __restrict__ scal_sum, double* __restrict__ det_part) {
   // UPDATE_IPT items per thread and one pair of atomics per workgroup: the four norms are four addresses, and an atomic per
   // wavefront (3 100 of them at 200 000 points) serialised there for most of the kernel's 82 us
   __shared__ double red[4][256 / 64];
@@ -602,19 +613,25 @@ __global__ __launch_bounds__(256) void k_update(const SolveDev d, const double* 
   if (threadIdx.x == 0) {
     double r[4];
     for (int k = 0; k < 4; ++k) r[k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
-    if (r[0] != 0.0 || r[1] != 0.0) { atomicAdd(scal_rep + 1, r[0]); atomicAdd(scal_rep + 2, r[1]); }
-    if (r[2] != 0.0 || r[3] != 0.0) { atomicAdd(scal_sum + 2, r[2]); atomicAdd(scal_sum + 3, r[3]); }
+    if (det_part) { for (int k = 0; k < 4; ++k) det_part[4 * (size_t)blockIdx.x + k] = r[k]; }
+    else {
+      if (r[0] != 0.0 || r[1] != 0.0) { atomicAdd(scal_rep + 1, r[0]); atomicAdd(scal_rep + 2, r[1]); }
+      if (r[2] != 0.0 || r[3] != 0.0) { atomicAdd(scal_sum + 2, r[2]); atomicAdd(scal_sum + 3, r[3]); }
+    }
   }
 }
 
 __global__ void k_point_step_norm(int64_t n_points, const int* __restrict__ pt_var, const double* __restrict__ X0,
-                                  const double* __restrict__ X1, double* __restrict__ out) {
+                                  const double* __restrict__ X1, double* __restrict__ out, double* __restrict__ det_part) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double s = 0.0;
   if (p < n_points && pt_var[p])
     for (int j = 0; j < 3; ++j) { const double d = X1[3 * p + j] - X0[3 * p + j]; s += d * d; }
   s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(out, s);
+  if ((threadIdx.x & 63) == 0) {
+    if (det_part) det_part[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = s;        // deterministic mode: per-wavefront partials
+    else if (s != 0.0) atomicAdd(out, s);
+  }
 }
 
 __global__ void k_normalize_q(int n, double* __restrict__ q) {
@@ -651,6 +668,44 @@ __global__ __launch_bounds__(256) void k_unpack_upper(int n, const double* __res
   double* dst = S + (size_t)r * (n + 1) + r;
   const double* src = packed + packed_row_offset(n, r);
   for (int x = threadIdx.x; x < len; x += blockDim.x) dst[x] = src[x];
+}
+
+// deterministic mode: slots that were accumulated as fixed-point integers become doubles again
+__global__ void k_det_finish(int64_t n, double* __restrict__ x, double det_scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = accum_value(x[i], det_scale);
+}
+// deterministic mode: *dst += part[k], part[k + stride], ... (n terms) added in a fixed order by ONE workgroup -- thread t takes
+// the terms t, t + 1024, ... in sequence, then a fixed tree over the 1024 threads
+__global__ __launch_bounds__(1024) void k_ordered_sum(const double* __restrict__ part, int64_t n, int stride, int k, double* __restrict__ dst) {
+  __shared__ double sh[1024];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) acc += part[i * stride + k];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *dst += sh[0];
+}
+// deterministic mode: cost = sum 0.5 rho(s) over the records, per-workgroup partials in a fixed mapping (the fused cost of the
+// residual kernel is one floating-point atomic per wavefront)
+__global__ __launch_bounds__(256) void k_cost_partials(const double* __restrict__ rec, int64_t n, pxr_loss loss, double* __restrict__ part) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double rho[3];
+    loss_eval(loss.type, loss.a, 1.0, rec[i * PXR_OBS_REC], rho);
+    acc += 0.5 * rho[0];
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
 }
 
 // keep rank 0's copy of a replicated buffer: the other ranks zero theirs before an all-reduce(sum)
@@ -780,7 +835,7 @@ size_t chol_workspace_doubles(int n);
 // pxr_ba_inner.hip
 int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
                             const pxr_loss* loss, const int64_t* d_pt_ptr, const int64_t* d_pt_obs,
-                            const int* d_pt_var, double* d_cost_before, const InnerLists* lists);
+                            const int* d_pt_var, double* d_cost_before, const InnerLists* lists, double* d_cost_per_point);
 int make_inner_lists(hipStream_t st, const std::vector<int64_t>& pt_ptr, const pxr_ba_view* view, const int64_t* d_pt_obs, InnerLists* out);
 void free_inner_lists(InnerLists* l);
 
@@ -1056,11 +1111,37 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     PXR_HIP(hipStreamSynchronize(st));
     return PXR_OK;
   };
+  // ---- deterministic mode (pxr_set_deterministic): order-independent accumulation in the direct solver ----------------
+  // matrix / vector slots (U, g_c, S | rhs): fixed point, det_scale = 2^k with k from the bound of the slots -- with Jacobi
+  // scaling every column of the robustified Jacobian has norm < 1, so |U_ij|, |S_ij| and every partial sum of their
+  // positive-semidefinite contributions are < 1, and |g_c|, |rhs| <= |r~| <= sqrt(2 cost) (Cauchy-Schwarz; rho concave:
+  // rho' s <= rho).  Scalars: per-workgroup partials, added in index order by k_ordered_sum.
+  const bool det = ctx->deterministic && !iterative;
+  PXR_REQUIRE(!det || opt->jacobi_scaling, "pxr_ba_solve: the deterministic mode needs jacobi_scaling (it bounds the fixed-point slots)");
+  const int64_t det_cost_blocks = 1024;
+  const int64_t det_part_n = std::max<int64_t>({det_cost_blocks, (int64_t)nblk(n_pts), (int64_t)nblk(n_pts * 4),
+                                                4 * (int64_t)nblk(((int64_t)n_img + n_cam + n_pts + UPDATE_IPT - 1) / UPDATE_IPT),
+                                                (int64_t)nblk(nc1) * 4, n_pts}) + 8;
+  DevBuf<double> det_part;
+  if (det) RC(det_part.alloc((size_t)det_part_n));
+  auto det_scale_for = [](double cost_now) {       // 2^k: slots bounded by 8 max(1, sqrt(2 cost)) fit 62 bits
+    const double bound = 8.0 * std::max(1.0, std::sqrt(2.0 * std::max(cost_now, 0.0)));
+    return std::ldexp(1.0, 62 - (int)std::ceil(std::log2(bound)));
+  };
+  auto ordered_sum = [&](int64_t n, int stride, int k, double* dst) {
+    hipLaunchKernelGGL(k_ordered_sum, dim3(1), dim3(1024), 0, st, (const double*)det_part.p, n, stride, k, dst);
+  };
   auto evaluate = [&](const pxr_ba_view& v, double* rec) -> int {   // rec + cost into scal_sum[0]
-    RC(ba_eval_with_cost(ctx, arena, &v, cfg, 1, rec, nullptr, nullptr, nullptr, loss, scal_sum));   // cost fused
+    if (!det) return ba_eval_with_cost(ctx, arena, &v, cfg, 1, rec, nullptr, nullptr, nullptr, loss, scal_sum);   // cost fused
+    RC(ba_eval_with_cost(ctx, arena, &v, cfg, 1, rec, nullptr, nullptr, nullptr, nullptr, nullptr));
+    hipLaunchKernelGGL(k_cost_partials, dim3((unsigned)det_cost_blocks), dim3(256), 0, st, (const double*)rec, n_obs, *loss, det_part.p);
+    ordered_sum(det_cost_blocks, 1, 0, scal_sum);
+    LAUNCH_CHECK("deterministic cost");
     return PXR_OK;
   };
-  // linearise at the CURRENT parameters from record buffer `rec`
+  // linearise at the CURRENT parameters from record buffer `rec` (lin_scale: the fixed-point grid of U and g_c in
+  // deterministic mode, 0 otherwise)
+  double lin_scale = 0.0;
   auto linearize = [&](const double* rec) -> int {
     hipLaunchKernelGGL(k_jac, dim3((unsigned)((n_obs + JAC_THREADS - 1) / JAC_THREADS)), dim3(JAC_THREADS),
                        sizeof(double) * (JAC_THREADS / 64) * 64 * (LS + 3 * DC + 1), st, dv, rec, *loss, L.p, W.p);
@@ -1069,7 +1150,11 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     PXR_HIP(hipMemsetAsync(gcd.p, 0, sizeof(double) * 2 * nc1, st));
     if (n_c > 0 && !chunks.empty()) {
       hipLaunchKernelGGL(k_img, dim3((unsigned)chunks.size()), dim3(256), sizeof(double) * ((size_t)IMG_BATCH * LS + 256), st, dv,
-                         d_chunks.p, d_img_obs.p, L.p, U.p, gc, iterative ? 1 : 0);
+                         d_chunks.p, d_img_obs.p, L.p, U.p, gc, iterative ? 1 : 0, lin_scale);
+      if (lin_scale != 0.0) {
+        hipLaunchKernelGGL(k_det_finish, dim3(nblk((int64_t)U.n)), dim3(256), 0, st, (int64_t)U.n, U.p, lin_scale);
+        hipLaunchKernelGGL(k_det_finish, dim3(nblk(nc1)), dim3(256), 0, st, (int64_t)nc1, gc, lin_scale);
+      }
       if (iterative) RC(pcg_diag_from_blocks(st, dv, U.p, diagU));
       else hipLaunchKernelGGL(k_extract_diag, dim3(nblk(n_c)), dim3(256), 0, st, n_c, U.p, diagU);
     }
@@ -1150,11 +1235,15 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   }
   hipLaunchKernelGGL(k_fill, dim3(nblk(nc1)), dim3(256), 0, st, (int64_t)nc1, 1.0, scale_c.p);
   hipLaunchKernelGGL(k_fill, dim3(nblk(n_pts * 3)), dim3(256), 0, st, n_pts * 3, 1.0, scale_p.p);
+  // (deterministic mode: the UNSCALED pass only yields diag(U) for the Jacobi scaling and has no bound: a coarse grid,
+  //  2^-20 with a range of 4e12 -- any positive scaling is a valid one, it only has to be the same on every run)
+  if (det) lin_scale = std::ldexp(1.0, 20);
   RC(linearize(rec_cur));
   if (opt->jacobi_scaling) {   // 1 / (1 + sqrt(diag(J~^T J~))), fixed for the whole solve
     if (n_c > 0) hipLaunchKernelGGL(k_jacobi_scale, dim3(nblk(n_c)), dim3(256), 0, st, (int64_t)n_c, diagU, scale_c.p);
     hipLaunchKernelGGL(k_point_diag, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, V.p, Vd0.p);
     hipLaunchKernelGGL(k_jacobi_scale, dim3(nblk(n_pts * 3)), dim3(256), 0, st, n_pts * 3, Vd0.p, scale_p.p);
+    if (det) lin_scale = det_scale_for(cost);
     RC(linearize(rec_cur));
   }
   if (opt->gradient_tolerance > 0.0) {   // [upstream] the test is also made at iteration 0
@@ -1243,19 +1332,23 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       // e = b - S x:  model cost change = delta.(D^2 delta - g) / 2 + x.e / 2
       inexact_correction = 0.5 * pr.x_dot_r;
       PXR_HIP(hipMemsetAsync(d_info, 0, sizeof(int), st));
-      hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, xsol.p, gc, damp_c.p, inv_radius, delta_c.p, scal_rep);
+      hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, xsol.p, gc, damp_c.p, inv_radius, delta_c.p, scal_rep, det ? det_part.p : (double*)nullptr);
+      if (det) ordered_sum(4 * (int64_t)nblk(n_c), 1, 0, scal_rep + 0);
       RC(from_rank0(delta_c.p, n_c));
     } else if (n_c > 0) {
-      hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, n_c, U.p, (const double*)nullptr, 0.0, (const double*)nullptr, S.p, 1);
+      const double schur_scale = det ? det_scale_for(cost) : 0.0;
+      hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, n_c, U.p, (const double*)nullptr, 0.0, (const double*)nullptr, S.p, 1, schur_scale);
       if (use_lds_schur) {
 #define SCHUR_LAUNCH(GG)                                                                                              \
   hipLaunchKernelGGL(k_schur_lds<GG>, dim3((unsigned)schur_chunks.size(), (unsigned)n_ctiles), dim3(1024), schur_shmem, st, dv, \
-                     d_schur_chunks.p, d_so.p, d_part_obs.p, d_obs_cols.p, W.p, T.p, gp.p, CT, S.p, rhs)
+                     d_schur_chunks.p, d_so.p, d_part_obs.p, d_obs_cols.p, W.p, T.p, gp.p, CT, S.p, rhs, schur_scale)
         if (DC <= 8) SCHUR_LAUNCH(8); else if (DC <= 16) SCHUR_LAUNCH(16); else SCHUR_LAUNCH(32);
 #undef SCHUR_LAUNCH
       } else {
         hipLaunchKernelGGL(k_schur, dim3(nblk(n_obs * DC)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, W.p, T.p, gp.p, S.p, rhs);
       }
+      if (schur_scale != 0.0)
+        hipLaunchKernelGGL(k_det_finish, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, (int64_t)n_c * ldS, S.p, schur_scale);
       LAUNCH_CHECK("schur kernels");
       phase(0);
       if (multi) {       // sum of U_local - Schur_local and of -Y g_p over the ranks: packed upper triangle + rhs
@@ -1266,12 +1359,13 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       }
       phase(1);
       // rhs += g_c (global), S += D_c / radius
-      hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, n_c, U.p, damp_c.p, inv_radius, gc, S.p, 0);
+      hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, n_c, U.p, damp_c.p, inv_radius, gc, S.p, 0, 0.0);
       // row-major upper == column-major lower; the pivot check is read back with the scalars of
       // this attempt (no extra host synchronisation): a failed factorisation = invalid step.
       RC(chol_factor_solve(st, S.p, n_c, d_info, linv.p, xsol.p));
       phase(2);
-      hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, xsol.p, gc, damp_c.p, inv_radius, delta_c.p, scal_rep);
+      hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, xsol.p, gc, damp_c.p, inv_radius, delta_c.p, scal_rep, det ? det_part.p : (double*)nullptr);
+      if (det) ordered_sum(4 * (int64_t)nblk(n_c), 1, 0, scal_rep + 0);
       RC(from_rank0(delta_c.p, n_c));
     }
     phase(3);
@@ -1279,17 +1373,26 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     if (ok) {
 #define BACKSUB_LAUNCH(GG)                                                                                                          \
   hipLaunchKernelGGL(k_backsub<GG>, dim3(nblk((n_pts * GG + BACKSUB_PPG - 1) / BACKSUB_PPG)), dim3(256), 0, st, dv, d_pt_ptr.p, d_part_obs.p, d_obs_cols.p, W.p, T.p, gp.p, \
-                     delta_c.p, Vd0.p, inv_radius, delta_p.p, scal_sum)
+                     delta_c.p, Vd0.p, inv_radius, delta_p.p, scal_sum, det ? det_part.p : (double*)nullptr)
+      const int bs_g = DC <= 8 ? 8 : (DC <= 16 ? 16 : 32);
       if (DC <= 8) BACKSUB_LAUNCH(8); else if (DC <= 16) BACKSUB_LAUNCH(16); else BACKSUB_LAUNCH(32);
 #undef BACKSUB_LAUNCH
+      if (det) ordered_sum((int64_t)nblk((n_pts * bs_g + BACKSUB_PPG - 1) / BACKSUB_PPG), 1, 0, scal_sum + 1);
       ParamPtrs out{q1.p, t1.p, k1.p, X1.p};
-      hipLaunchKernelGGL(k_update, dim3(nblk(((int64_t)n_img + n_cam + n_pts + UPDATE_IPT - 1) / UPDATE_IPT)), dim3(256), 0, st, dv, delta_c.p, delta_p.p, out, scal_rep, scal_sum);
+      const int64_t upd_blocks = nblk(((int64_t)n_img + n_cam + n_pts + UPDATE_IPT - 1) / UPDATE_IPT);
+      hipLaunchKernelGGL(k_update, dim3((unsigned)upd_blocks), dim3(256), 0, st, dv, delta_c.p, delta_p.p, out, scal_rep, scal_sum, det ? det_part.p : (double*)nullptr);
+      if (det) { ordered_sum(upd_blocks, 4, 0, scal_rep + 1); ordered_sum(upd_blocks, 4, 1, scal_rep + 2);
+                 ordered_sum(upd_blocks, 4, 2, scal_sum + 2); ordered_sum(upd_blocks, 4, 3, scal_sum + 3); }
       LAUNCH_CHECK("step kernels");
       const bool do_inner = inner_enabled;
       if (do_inner) {   // DoInnerIterationsIfNeeded [upstream]: refine every variable point of the candidate on its own
-        RC(launch_inner_iterations(ctx, arena, &cand_view, cfg, loss, d_pt_ptr.p, d_pt_obs.p, d_pt_var.p, scal_sum + 4, gram_inner ? &inner_lists.l : nullptr));
+        if (det) PXR_HIP(hipMemsetAsync(det_part.p, 0, sizeof(double) * (size_t)n_pts, st));   // per-point costs, points without observations stay 0
+        RC(launch_inner_iterations(ctx, arena, &cand_view, cfg, loss, d_pt_ptr.p, d_pt_obs.p, d_pt_var.p, scal_sum + 4, gram_inner ? &inner_lists.l : nullptr,
+                                   det ? det_part.p : nullptr));
+        if (det) ordered_sum(n_pts, 1, 0, scal_sum + 4);
         PXR_HIP(hipMemsetAsync(scal_sum + 2, 0, sizeof(double), st));   // point part of |x - candidate|^2 after refinement
-        hipLaunchKernelGGL(k_point_step_norm, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, d_pt_var.p, cur_X, X1.p, scal_sum + 2);
+        hipLaunchKernelGGL(k_point_step_norm, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, d_pt_var.p, cur_X, X1.p, scal_sum + 2, det ? det_part.p : (double*)nullptr);
+        if (det) ordered_sum(4 * (int64_t)nblk(n_pts), 1, 0, scal_sum + 2);
         LAUNCH_CHECK("inner iteration kernels");
       }
       phase(4);
@@ -1336,6 +1439,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       PXR_HIP(hipMemcpyAsync(cur_X, X1.p, sizeof(double) * 3 * n_pts, hipMemcpyDeviceToDevice, st));
       std::swap(rec_cur, rec_cand);
       cost = cand_cost;
+      if (det) lin_scale = det_scale_for(cost);
       RC(linearize(rec_cur));
       phase(6);
       ++sum->num_successful;

@@ -84,6 +84,24 @@ __device__ __forceinline__ void spline_f64(double p0, double p1, double p2, doub
   }
 }
 
+// ---- order-independent accumulation (deterministic mode) ---------------------------------------
+// det_scale = 0: a floating-point atomic (the order of the adders decides the last bits).  det_scale = 2^k: the addend is
+// rounded to a multiple of 2^-k and added as a 64-bit integer -- integer addition is associative, so the slot's final
+// content does not depend on the order.  The slot then holds an integer; accum_value turns it back into a double.
+__device__ __forceinline__ void accum_add(double* slot, double v, double det_scale) {
+  if (det_scale == 0.0) { atomicAdd(slot, v); return; }
+  const long long q = __double2ll_rn(v * det_scale);
+  atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)q);
+}
+// a privatised (LDS) slot's content added to its global slot: the integer as it is in deterministic mode
+__device__ __forceinline__ void accum_flush(double* slot, double raw, double det_scale) {
+  if (det_scale == 0.0) atomicAdd(slot, raw);
+  else atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double_as_longlong(raw));
+}
+__device__ __forceinline__ double accum_value(double raw, double det_scale) {
+  return det_scale == 0.0 ? raw : (double)__double_as_longlong(raw) / det_scale;
+}
+
 // ---- 16-lane (DPP row) all-reduce --------------------------------------------------------
 // quad_perm[1,0,3,2] -> quad_perm[2,3,0,1] -> row_half_mirror -> row_mirror: after the four
 // steps every lane of the row holds the row sum.  No LDS, no ds_bpermute.

@@ -26,6 +26,7 @@ struct pxr_ctx {
   void* h_stage[2] = {nullptr, nullptr};      // pinned staging buffers of the patch uploads (pxr_arena_upload*), lazily allocated
   hipEvent_t ev_stage[2] = {nullptr, nullptr};
   size_t stage_bytes = 0;
+  bool deterministic = false;    // pxr_set_deterministic / PXR_DETERMINISTIC=1: order-independent accumulation in the solvers
 };
 
 struct pxr_arena {

@@ -58,6 +58,7 @@ struct KaArgs {
   const int64_t* prob_h_ptr;   // [n_problems + 1] offsets into Hbuf / Abuf
   double* Hbuf; double* Abuf;
   pxr_lm_summary* summaries;   // device [n_problems]
+  double det_scale;            // 0: floating-point atomics; 2^k: deterministic fixed-point accumulation of H and g (pxr_device.h)
 };
 
 // Channel layout of a node over lanes: 8 channels per lane (one 16-byte fp16 load) for the CNN feature sizes, and the
@@ -331,10 +332,10 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
               if (!var[x]) continue;
-              atomicAdd(p.g + idx[x], rho[1] * b[x]);
+              accum_add(p.g + idx[x], rho[1] * b[x], a.det_scale);
 #pragma unroll
               for (int y = 0; y < 4; ++y)
-                if (var[y]) atomicAdd(blk + (size_t)(idx[x] - c0) * nc + (idx[y] - c0), rho[1] * (mm[x][y] - kappa * b[x] * b[y]));
+                if (var[y]) accum_add(blk + (size_t)(idx[x] - c0) * nc + (idx[y] - c0), rho[1] * (mm[x][y] - kappa * b[x] * b[y]), a.det_scale);
             }
           }
         }
@@ -395,10 +396,10 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
 #pragma unroll
           for (int x = 0; x < 4; ++x) {
             if (!var[x]) continue;
-            atomicAdd(p.g + idx[x], rho[1] * b[x]);
+            accum_add(p.g + idx[x], rho[1] * b[x], a.det_scale);
 #pragma unroll
             for (int y = 0; y < 4; ++y)
-              if (var[y]) atomicAdd(blk + (size_t)(idx[x] - c0) * nc + (idx[y] - c0), rho[1] * (m[x][y] - kappa * b[x] * b[y]));
+              if (var[y]) accum_add(blk + (size_t)(idx[x] - c0) * nc + (idx[y] - c0), rho[1] * (m[x][y] - kappa * b[x] * b[y]), a.det_scale);
           }
         }
       }
@@ -434,12 +435,12 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
         const double kappa = ka_kappa(s, rho);
         const int nc = p.row_nc[v1], c0 = p.row_v0[v1];
         double* row = p.Hm + p.row_off[v1] + (v1 - c0);
-        atomicAdd(p.g + v1, rho[1] * q[3]);
-        atomicAdd(p.g + v1 + 1, rho[1] * q[4]);
-        atomicAdd(row, rho[1] * (q[0] - kappa * q[3] * q[3]));
-        atomicAdd(row + 1, rho[1] * (q[1] - kappa * q[3] * q[4]));
-        atomicAdd(row + nc, rho[1] * (q[1] - kappa * q[3] * q[4]));
-        atomicAdd(row + nc + 1, rho[1] * (q[2] - kappa * q[4] * q[4]));
+        accum_add(p.g + v1, rho[1] * q[3], a.det_scale);
+        accum_add(p.g + v1 + 1, rho[1] * q[4], a.det_scale);
+        accum_add(row, rho[1] * (q[0] - kappa * q[3] * q[3]), a.det_scale);
+        accum_add(row + 1, rho[1] * (q[1] - kappa * q[3] * q[4]), a.det_scale);
+        accum_add(row + nc, rho[1] * (q[1] - kappa * q[3] * q[4]), a.det_scale);
+        accum_add(row + nc + 1, rho[1] * (q[2] - kappa * q[4] * q[4]), a.det_scale);
       }
     }
   }
@@ -861,6 +862,11 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     const double c = ka_terms<C, true>(a, p, sh4);
     __syncthreads();
     KA_T(1);
+    if (a.det_scale != 0.0) {            // deterministic mode: the slots hold fixed-point integers
+      for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = accum_value(p.Hm[e], a.det_scale);
+      for (int e = tid; e < n; e += blockDim.x) p.g[e] = accum_value(p.g[e], a.det_scale);
+      __syncthreads();
+    }
     for (int e = tid; e < n; e += blockDim.x) {
       p.gun[e] = p.g[e];
       if (compute_scale) p.scale[e] = opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(p.Hm[p.row_off[e] + e - p.row_v0[e]])) : 1.0;
@@ -1205,6 +1211,9 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   KaArgs a{};
   fill_args(ctx, arena, view, cfg, loss, a);
   a.bound = bound; a.opt = *options;
+  // deterministic mode: H and g of a sub-problem as 2^-38 fixed point (range +-3e7: a residual block adds |J|^2 <= a few
+  // hundred at most -- unit descriptors, gradients per pixel; resolution 3.6e-12)
+  a.det_scale = ctx->deterministic ? 274877906944.0 : 0.0;
   a.desc = (double*)(ws + o_desc); a.kp_cand = (double*)(ws + o_cand); a.vec = (double*)(ws + o_vec);
   a.var_of_node = (int*)(ws + o_var); a.label = (int*)(ws + o_label); a.ipos = (int*)(ws + o_ipos);
   a.irow = (int*)(ws + o_irow); a.comp_v0 = (int*)(ws + o_comp); a.used = (uint8_t*)(ws + o_used);

@@ -1,6 +1,7 @@
 // pxr_runtime.cpp -- context, error reporting, device-memory plumbing and the patch arena.
 #include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -50,6 +51,7 @@ int pxr_ctx_create(int device, void* stream, pxr_ctx** out) {
   c->num_cus = prop.multiProcessorCount;
   PXR_HIP(hipEventCreate(&c->ev_start));
   PXR_HIP(hipEventCreate(&c->ev_stop));
+  if (const char* e = std::getenv("PXR_DETERMINISTIC")) c->deterministic = e[0] != '\0' && e[0] != '0';
   c->scratch_bytes = 1 << 20;
   PXR_HIP(hipMalloc((void**)&c->d_scratch, c->scratch_bytes));
   *out = c;
@@ -398,6 +400,13 @@ void* pxr_arena_data(pxr_arena* a) { return a ? a->d_data : nullptr; }
 int32_t* pxr_arena_corners(pxr_arena* a) { return a ? a->d_corners : nullptr; }
 double* pxr_arena_scales(pxr_arena* a) { return a ? a->d_scales : nullptr; }
 int64_t pxr_arena_size(pxr_arena* a) { return a ? a->n : 0; }
+
+int pxr_set_deterministic(pxr_ctx* ctx, int on) {
+  PXR_REQUIRE(ctx, "pxr_set_deterministic: NULL context");
+  ctx->deterministic = on != 0;
+  return PXR_OK;
+}
+int pxr_get_deterministic(pxr_ctx* ctx) { return ctx && ctx->deterministic ? 1 : 0; }
 
 int pxr_set_iteration_callback(pxr_ctx* ctx, pxr_iteration_callback fn, void* user) {
   PXR_REQUIRE(ctx, "pxr_set_iteration_callback: NULL context");

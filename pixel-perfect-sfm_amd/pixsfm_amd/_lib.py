@@ -140,6 +140,8 @@ _SIGNATURES = {
     "pxr_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "pxr_comm_destroy": (C.c_int, [C.c_void_p]),
     "pxr_set_iteration_callback": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pxr_set_deterministic": (C.c_int, [C.c_void_p, C.c_int]),
+    "pxr_get_deterministic": (C.c_int, [C.c_void_p]),
     "pxr_comm_set_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pxr_comm_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pxr_comm_allreduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

@@ -62,6 +62,16 @@ class Context:
         check(self.lib.pxr_comm_rank(self.handle, C.byref(r), C.byref(n)), "pxr_comm_rank")
         return r.value, n.value
 
+    @property
+    def deterministic(self):
+        """Order-independent accumulation in pxr_ba_solve (direct solver) / pxr_ka_solve: bit-identical results from run to
+        run and on every rank (pxr_set_deterministic; PXR_DETERMINISTIC=1 sets it for every new context)."""
+        return bool(self.lib.pxr_get_deterministic(self.handle))
+
+    @deterministic.setter
+    def deterministic(self, on):
+        check(self.lib.pxr_set_deterministic(self.handle, int(bool(on))), "pxr_set_deterministic")
+
     def set_iteration_callbacks(self, callbacks):
         """ceres::IterationCallback objects for the BA solves of this context (pxr_set_iteration_callback): each callable gets
         the iteration summary (attributes iteration, step_is_valid, step_is_successful, cost, cost_change, relative_decrease,

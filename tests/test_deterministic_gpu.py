@@ -1,0 +1,111 @@
+"""GPU: the deterministic mode (pxr_set_deterministic / PXR_DETERMINISTIC=1).
+
+By default the normal-equation blocks and the scalar sums of the solvers are accumulated with floating-point atomics, so the
+last bits -- and now and then an accept / reject decision -- change from run to run; tests can then only compare at 1e-7 /
+1e-8.  In deterministic mode the accumulations are order-independent (fixed-point integer adds for matrices and vectors,
+index-ordered partial sums for scalars): the SAME bits on every run, which is what Ceres gives for a fixed thread count
+(per-residual-block Jacobian rows summed in a fixed order, feature_reference.h:91-93)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _gauge(prob):
+    n_img, n_cam, n_pt = len(prob["image_camera"]), len(prob["cam_model"]), len(prob["xyz"])
+    pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
+    tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
+    return pose_const, tmask, np.full(n_cam, 0b0110, np.uint16), np.zeros(n_pt, np.uint8)
+
+
+def _solve_ba(ctx, prob, gauge, inner, loss="cauchy", iters=8):
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ba = BAProblem(ctx, arena, prob)
+    s = ba.solve(interp_cfg(), make_loss(loss, [0.25] if loss != "trivial" else []), *gauge,
+                 options=lm_options(max_iterations=iters, use_inner_iterations=inner))
+    out = (s, ba.params())
+    arena.close()
+    return out
+
+
+@pytest.fixture()
+def det_ctx():
+    from pixsfm_amd.engine import Context
+    c = Context(0)
+    c.deterministic = True
+    assert c.deterministic
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("inner,loss", [(False, "cauchy"), (True, "cauchy"), (True, "huber"), (False, "trivial")])
+def test_ba_direct_solver_is_bit_reproducible(ctx, det_ctx, inner, loss):
+    from pixsfm_amd import synthetic
+    prob = synthetic.make_ba_problem(n_cams=12, n_points=900, obs_per_point=5, seed=21, rot_deg=0.3, pt_sigma=0.02)
+    gauge = _gauge(prob)
+    runs = [_solve_ba(det_ctx, prob, gauge, inner, loss) for _ in range(3)]
+    s0, p0 = runs[0]
+    for s, p in runs[1:]:
+        assert s["iterations"] == s0["iterations"] and s["num_successful"] == s0["num_successful"]
+        assert s["initial_cost"] == s0["initial_cost"] and s["final_cost"] == s0["final_cost"]          # the same BITS
+        for a, b in zip(p, p0):
+            assert np.array_equal(a, b)
+    # and it is the same solve as the default mode's, to the tolerance the default mode's tests use
+    sd, pd = _solve_ba(ctx, prob, gauge, inner, loss)
+    assert not ctx.deterministic
+    assert sd["iterations"] == s0["iterations"] and sd["num_successful"] == s0["num_successful"]
+    assert abs(sd["initial_cost"] - s0["initial_cost"]) < 1e-12 * s0["initial_cost"]
+    assert abs(sd["final_cost"] - s0["final_cost"]) < 1e-7 * s0["initial_cost"]
+    for a, b in zip(pd, p0):
+        assert np.abs(a - b).max() < 1e-6 * max(1.0, np.abs(b).max())
+
+
+def test_ka_solver_is_bit_reproducible(ctx, det_ctx):
+    from pixsfm_amd import synthetic_ka
+    from pixsfm_amd.engine import PatchArena, interp_cfg, lm_options, make_loss
+    from pixsfm_amd.ka_engine import KAProblem
+    prob = synthetic_ka.make_ka_problem(n_tracks=120, track_len=8, seed=4, directed_both=False, sigma=1.2)
+
+    def solve(c):
+        arena = PatchArena.from_numpy(c, prob["patches"], prob["corners"], prob["scales"])
+        ka = KAProblem(c, arena, prob)
+        total, per = ka.solve(interp_cfg(), make_loss("cauchy", [0.25]), bound=4.0, options=lm_options(parameter_tolerance=1e-5),
+                              per_problem=True)
+        kp = ka.keypoints()
+        arena.close()
+        return total, per, kp
+    t0, per0, kp0 = solve(det_ctx)
+    for _ in range(2):
+        t, per, kp = solve(det_ctx)
+        assert np.array_equal(kp, kp0) and t["final_cost"] == t0["final_cost"]
+        assert [q["iterations"] for q in per] == [q["iterations"] for q in per0]
+    td, perd, kpd = solve(ctx)
+    assert abs(td["final_cost"] - t0["final_cost"]) < 1e-7 * t0["initial_cost"]
+    same = np.array([a["iterations"] == b["iterations"] for a, b in zip(perd, per0)])
+    assert same.mean() >= 0.9          # (a borderline accept / reject may flip between the two accumulation orders)
+    assert np.abs(kpd - kp0)[np.repeat(same[prob["node_problem"]], 1)].max() < 1e-5
+
+
+def test_fov_with_inner_iterations_is_reproducible(det_ctx):
+    """The case round 3 had to drop from test_camera_models_ext.py (ea9d2f6): on this ill-conditioned FOV scene, WHICH of the
+    five steps are accepted depended on the summation order of the atomics and changed from run to run.  In deterministic
+    mode it is one trajectory; the cost level is compared with the oracle's like for the other FOV cases (the extended
+    camera models take the packed inner-iteration kernel)."""
+    import pxo
+    import test_camera_models_ext as ext
+    prob = ext._problem(7, seed=67)
+    n_img = len(prob["image_camera"])
+    pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
+    tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
+    gauge = (pose_const, tmask, np.full(n_img, 0b11100, np.uint16), np.zeros(48, np.uint8))   # as in the extended-model LM test
+    runs = [_solve_ba(det_ctx, prob, gauge, True, iters=5) for _ in range(3)]
+    for s, p in runs[1:]:
+        assert s["num_successful"] == runs[0][0]["num_successful"] and s["final_cost"] == runs[0][0]["final_cost"]
+        for a, b in zip(p, runs[0][1]):
+            assert np.array_equal(a, b)
+    so = pxo.ba_solve(prob, pxo.cfg(), pxo.loss("cauchy", 0.25), *gauge, pxo.lm_options(max_iterations=5, use_inner_iterations=1))[0]
+    s = runs[0][0]
+    assert s["iterations"] == so["iterations"] and abs(s["initial_cost"] - so["initial_cost"]) < 1e-10 * so["initial_cost"]
+    # (ill-conditioned: the accepted steps differ from the oracle's -- the reason the case is only comparable by cost level)
+    assert s["final_cost"] < 0.5 * so["initial_cost"] and s["final_cost"] < 1.25 * so["final_cost"]

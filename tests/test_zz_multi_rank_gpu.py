@@ -66,6 +66,19 @@ def test_ba_two_ranks_equal_one(ctx, tmp_path, mode):
         assert int(res[0]["linear_iterations"][0]) == int(res[1]["linear_iterations"][0]) > 0
 
 
+def test_two_ranks_are_bit_reproducible_in_deterministic_mode(tmp_path, monkeypatch):
+    """PXR_DETERMINISTIC=1 on both ranks: order-independent accumulation on every rank + one all-reduce result for all ranks =
+    the same bits on both ranks AND on every run (the default mode only has the rank-0 broadcast and 1e-8 tolerances)."""
+    monkeypatch.setenv("PXR_DETERMINISTIC", "1")
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    first = run_ranks("ba_direct", tmp_path / "a", world=2)
+    second = run_ranks("ba_direct", tmp_path / "b", world=2)
+    for key in ("q", "t", "k", "xyz", "final_cost", "iterations", "successful"):
+        assert np.array_equal(first[0][key], first[1][key]), key                    # across the ranks
+        assert np.array_equal(first[0][key], second[0][key]), key                   # across the runs
+        assert np.array_equal(first[1][key], second[1][key]), key
+
+
 def test_gradient_tolerance_is_decided_globally(ctx, tmp_path):
     """gradient_tolerance > 0 with sharded points: both ranks must stop at the same iteration (a rank-local
     max-norm would let one rank leave the loop while the other waits in the next all-reduce)."""

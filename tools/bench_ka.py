@@ -61,7 +61,7 @@ def make_problem_gpu(dev, n_tracks, track_len, C=128, PS=16, seed=1, sigma=1.0, 
 
 
 def cpu_legs_on_sample(prob, patches, dev):
-    """The CPU side of the KA half of the metric on a bounded sample (the first 4 x logical-CPUs sub-problems, at most all):
+    """The CPU side of the KA half of the metric on a bounded sample (the first 8 x usable-CPUs sub-problems, at most all):
     the oracle's bounded LM, ONE single-threaded solve per task over a pool of threads (keypoint_adjustment/main.py:66-80),
     and the reference's own FeatureMetric2DCostFunctor on dual numbers per residual block -- both timed inside C
     (oracle/pxo_bench_harness.h)."""
@@ -70,7 +70,7 @@ def cpu_legs_on_sample(prob, patches, dev):
     import pxo_cpubench
     logical, _, _ = pxo_cpubench.cpu_topology()
     n_prob = int(prob["n_problems"])
-    take = min(n_prob, max(16, 4 * logical))
+    take = min(n_prob, max(16, 8 * pxo_cpubench.usable_cpus(logical)))          # (a cgroup quota caps what more tasks would buy)
     node_sel = np.nonzero(prob["node_problem"] < take)[0]
     new_node = np.full(len(prob["kp"]), -1); new_node[node_sel] = np.arange(len(node_sel))
     edge_sel = np.nonzero(new_node[prob["edge_src"]] >= 0)[0]

@@ -217,6 +217,20 @@ static void copy_to_staging(char* dst, const char* src, size_t bytes, bool strea
   else std::memcpy(dst, src, bytes);
 }
 
+// hardware threads, capped by the cgroup CPU quota (v2: /sys/fs/cgroup/cpu.max "<quota> <period>" or "max ...")
+static unsigned usable_cpus() {
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64]; long long period = 0;
+    if (std::fscanf(f, "%63s %lld", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) {
+      const long long quota = std::atoll(q);
+      if (quota > 0) n = (unsigned)std::max<long long>(1, std::min<long long>(n, (quota + period - 1) / period));
+    }
+    std::fclose(f);
+  }
+  return n;
+}
+
 namespace {
 // The gather threads of ONE upload call: created once, handed one byte range per staging chunk (a fresh std::thread per
 // 256 MiB chunk cost ~250 creations for the 65.5 GB arena of BASELINE configs[2]).
@@ -308,8 +322,10 @@ static int upload_staged(pxr_arena* a, int64_t first, int64_t count, const void*
   const size_t total = pb * (size_t)count;
   if (int rc = ensure_staging(ctx, total)) return rc;
   const size_t stage = ctx->stage_bytes;
-  // 8 threads already keep the link busy (56 GB/s measured; 16 leave slack for slower hosts); PXR_UPLOAD_THREADS overrides
-  unsigned n_thr = std::max(1u, std::min(std::thread::hardware_concurrency() / 2, 16u));
+  // 8 threads already keep the link busy (56 GB/s measured; 16 leave slack for slower hosts); PXR_UPLOAD_THREADS overrides.
+  // Half of the CPUs the process can really use: a container's cgroup quota counts (the GPU boxes of this project: 256
+  // hardware threads, quota 16 -- sixteen gather threads left nothing for the caller's own work beside a prefetch)
+  unsigned n_thr = std::max(1u, std::min(usable_cpus() / 2, 16u));
   if (const char* e = std::getenv("PXR_UPLOAD_THREADS")) n_thr = (unsigned)std::max(1, std::atoi(e));
   if (total < ((size_t)4 << 20)) n_thr = 1;
   const bool streaming = streaming_copy_available() && std::getenv("PXR_UPLOAD_NO_STREAMING") == nullptr;

@@ -883,9 +883,14 @@ class FeatureReferenceBundleAdjuster(BundleAdjuster):
         with phase("problem_labels"):
             problem_labels = find_problem_labels(reconstruction, self.conf['max_tracks_per_problem'])
         ref_extractor = ReferenceExtractor(deepcopy(self.conf['references']), self.conf['interpolation'])
-        with phase("dump"):
-            scene = _SceneDump(reconstruction, feature_view)      # the Python objects are read once for both steps
         with features.SharedArena() as shared:       # host patches cross PCIe once for the extraction AND the optimiser
+            from .. import parallel
+            if parallel.world()[1] == 1:             # (several ranks: every rank uploads its share only)
+                with phase("prefetch_start"):        # the upload starts now and runs beside the walk over the scene objects
+                    shared.prefetch(default_context(), feature_set,
+                                    [reconstruction.images[i].name for i in reconstruction.reg_image_ids()])
+            with phase("dump"):
+                scene = _SceneDump(reconstruction, feature_view)      # the Python objects are read once for both steps
             references = ref_extractor.run(problem_labels, reconstruction, feature_set, arena_cache=shared, scene=scene)
             solver = FeatureReferenceBundleOptimizer(deepcopy(self.conf['optimizer']), problem_setup,
                                                      self.conf['interpolation'])

@@ -160,16 +160,40 @@ class FeatureMap:
             scale = np.asarray(metadata["scale"], dtype=np.float64).reshape(2)
             self.patches = {(int(point2D_ids[i]) if self.is_sparse else kDenseId): FeaturePatch(patches[i], corners[i], scale)
                             for i in range(len(patches))}
+            self._remember_stack(patches, corners, scale)
             return
         self.patches = dict(patches or {})
         self.is_sparse = is_sparse
+
+    _stack = None
+
+    def _remember_stack(self, patches, corners, scale):
+        """The patches of this map are views of ONE N x H x W x C array (the reference's numpy constructor, featuremap.cc:8-45):
+        remembered, so that an upload can take the N patches from the array's address and stride without touching the N
+        FeaturePatch objects (SharedArena.prefetch).  Dropped as soon as the dict no longer mirrors the array."""
+        if isinstance(patches, np.ndarray) and patches.ndim == 4 and patches.flags["C_CONTIGUOUS"] and len(patches) == len(self.patches) \
+                and patches.dtype in (np.float16, np.float32, np.float64) and self.is_sparse:
+            self._stack = (patches, np.ascontiguousarray(corners, dtype=np.int32).reshape(len(patches), 2),
+                           np.asarray(scale, dtype=np.float64).reshape(2))
+
+    def stacked(self):
+        """(array, corners, scale) when the dict still holds exactly the views of the array it was built from, else None."""
+        st = self._stack
+        if st is None or len(self.patches) != len(st[0]) or len(st[0]) == 0:
+            return None
+        first = next(iter(self.patches.values()))
+        if type(first) is not FeaturePatch or first._ptr != st[0].ctypes.data:
+            return None
+        return st
 
     @classmethod
     def from_arrays(cls, patches, keypoint_ids, corners, scale):
         """Same inputs as the reference's FeatureMap(patches, point2D_ids, corners, metadata) numpy
         constructor (features/src/featuremap.cc:25-61): N x H x W x C patches."""
         scale = np.broadcast_to(np.asarray(scale, dtype=np.float64), (2,))
-        return cls({int(k): FeaturePatch(p, c, scale) for k, p, c in zip(keypoint_ids, patches, corners)})
+        fm = cls({int(k): FeaturePatch(p, c, scale) for k, p, c in zip(keypoint_ids, patches, corners)})
+        fm._remember_stack(patches, corners, scale)
+        return fm
 
     @classmethod
     def dense(cls, featuremap_hwc, scale):
@@ -193,6 +217,7 @@ class FeatureMap:
 
     def add_fpatch(self, point2D_idx, patch):    # featuremap.h:120-129
         self.patches[int(point2D_idx)] = patch
+        self._stack = None
 
     def num_fpatches(self):
         return len(self.patches)
@@ -466,6 +491,7 @@ class SharedArena:
 
     def __init__(self):
         self.arena, self.slot, self.uniq = None, {}, None     # slot: id(patch) -> arena slot (built on demand); uniq: the patches by slot
+        self._thread, self._error = None, None
 
     def __enter__(self):
         return self
@@ -473,7 +499,59 @@ class SharedArena:
     def __exit__(self, *exc):
         self.close()
 
+    def prefetch(self, ctx, feature_set, image_names):
+        """Start uploading every patch of the feature maps of `image_names` in a background thread (the C call that gathers
+        into pinned buffers and drives the copy engine holds no GIL), so that the 65 GB of BASELINE configs[2] cross PCIe
+        WHILE the caller walks the reconstruction's Python objects -- 1.33 s + 0.54 s back to back in round 3's
+        BundleAdjuster.refine.  Only for maps that still mirror the N x H x W x C array they were constructed from
+        (FeatureMap.stacked: the reference's numpy constructor, what extract.py hands over): the patch addresses then come
+        from the arrays' base and stride, no FeaturePatch object is touched (reading a million cold objects costs as much as
+        the walk this is meant to hide: measured, 0.77 s).  Returns False when a map does not qualify; a later
+        to_arena(..., cache=self) waits for the upload and, should it need a patch that was not prefetched, uploads its own."""
+        import threading
+        from ..engine import PatchArena
+        if _host_module() is None or self.arena is not None or self._thread is not None:
+            return False
+        stacks, uniq = [], []
+        for name in image_names:
+            if not feature_set.has_fmap(name):
+                continue
+            fm = feature_set.fmap(name)
+            st = fm.stacked() if hasattr(fm, "stacked") else None
+            if st is None:
+                return False
+            stacks.append(st)
+            uniq.extend(fm.patches.values())         # dict order = array order (insertion order of the constructor)
+        if not stacks:
+            return False
+        shape, dtype = stacks[0][0].shape[1:], stacks[0][0].dtype
+        if any(st[0].shape[1:] != shape or st[0].dtype != dtype for st in stacks):
+            return False
+        pb = int(np.prod(shape)) * dtype.itemsize
+        pointers = np.concatenate([np.uint64(st[0].ctypes.data) + np.arange(len(st[0]), dtype=np.uint64) * np.uint64(pb) for st in stacks])
+        corners = np.concatenate([st[1] for st in stacks])
+        scales = np.concatenate([np.broadcast_to(st[2], (len(st[0]), 2)) for st in stacks])
+        self.uniq = uniq
+
+        def work():
+            try:
+                self.arena = PatchArena.from_patch_pointers(ctx, pointers, shape, dtype, corners, scales)
+            except BaseException as e:  # noqa: BLE001 -- handed to the waiting thread
+                self._error = e
+        self._thread = threading.Thread(target=work, name="pxr-prefetch", daemon=True)
+        self._thread.start()
+        return True
+
+    def wait(self):
+        """Join a running prefetch; its failure (e.g. out of device memory) leaves the cache empty and the caller uploads."""
+        t, self._thread = self._thread, None
+        if t is not None:
+            t.join()
+            if self._error is not None or self.arena is None:
+                self._error, self.arena, self.uniq = None, None, None
+
     def close(self):
+        self.wait()
         if self.arena is not None:
             self.arena.close()
         self.arena, self.slot, self.uniq = None, {}, None
@@ -485,6 +563,8 @@ def to_arena(ctx, patch_list, cache=None):
     from ..engine import PatchArena
     if not patch_list:
         raise ValueError("no patches")
+    if cache is not None:
+        cache.wait()                             # a prefetch started by the adjuster (SharedArena.prefetch)
     if cache is not None and cache.arena is not None:
         host = _host_module()
         if host is not None and hasattr(host, "slots_of") and cache.uniq is not None:

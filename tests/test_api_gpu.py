@@ -664,3 +664,51 @@ def test_patch_interpolator_local_coordinates(ctx):
         got = interp.interpolate_local(fpatch, xy)
         want = pxo.pixel_interp(patch, xy[1], xy[0], pxo.cfg())[0]
         assert got.shape == (128,) and np.abs(got - want).max() < 1e-12
+
+
+def test_prefetched_upload_equals_the_plain_flow(ctx, monkeypatch):
+    """Feature maps built by the reference's numpy constructor FeatureMap(patches [N][H][W][C], ids, corners, metadata) (what
+    extract.py hands over, featuremap.cc:8-45) remember their array: BundleAdjuster.refine then starts the upload in a
+    background thread from the arrays' addresses while it walks the scene objects (features.SharedArena.prefetch).  Same
+    result as with maps filled patch by patch (no prefetch possible), incl. a map that holds patches of keypoints without
+    a 3D point and after one map was edited (its array no longer mirrors the dict: prefetch declines, plain flow)."""
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.api import BundleAdjuster, features
+    from pixsfm_amd.api.reconstruction import reconstruction_from_flat
+    prob = synthetic.make_ba_problem(n_cams=5, n_points=60, obs_per_point=3, seed=23, noise=0.05)
+
+    def inputs(stacked, edit=False):
+        rec, patch_of = reconstruction_from_flat(prob)
+        per = {}
+        for (image_id, p2d), pi in sorted(patch_of.items()):
+            per.setdefault(image_id, []).append((p2d, pi))
+        fmaps = {}
+        for image_id, items in per.items():
+            ids = np.array([a for a, _ in items]); pis = np.array([b for _, b in items])
+            if stacked:
+                fmaps[rec.images[image_id].name] = features.FeatureMap(np.ascontiguousarray(prob["patches"][pis]), ids, prob["corners"][pis],
+                                                                       {"scale": prob["scales"][pis[0]], "is_sparse": True, "patch_size": 16})
+            else:
+                fm = fmaps.setdefault(rec.images[image_id].name, features.FeatureMap())
+                for a, b in items:
+                    fm.patches[a] = features.FeaturePatch(prob["patches"][b], prob["corners"][b], prob["scales"][b])
+        if edit:
+            fm = next(iter(fmaps.values()))
+            k0 = next(iter(fm.patches))
+            fm.add_fpatch(k0, features.FeaturePatch(fm.patches[k0].data.copy(), fm.patches[k0].corner, fm.patches[k0].scale))
+            assert fm.stacked() is None
+        return rec, features.FeatureManager([features.FeatureSet(fmaps)])
+    started = []
+    real = features.SharedArena.prefetch
+    monkeypatch.setattr(features.SharedArena, "prefetch", lambda self, *a, **k: started.append(real(self, *a, **k)) or started[-1])
+    conf = {"optimizer": {"solver": {"max_num_iterations": 6}}}
+    results = []
+    for stacked, edit in ((False, False), (True, False), (True, True)):
+        rec, fm = inputs(stacked, edit)
+        out = BundleAdjuster.create(conf).refine_multilevel(rec, fm)
+        results.append((out["summary"][0], np.array([rec.points3D[p + 1].xyz for p in range(60)])))
+    assert started == [False, True, False]
+    for s, X in results[1:]:
+        assert s.num_iterations == results[0][0].num_iterations
+        assert abs(s.final_cost - results[0][0].final_cost) < 1e-7 * results[0][0].initial_cost
+        assert np.abs(X - results[0][1]).max() < 1e-6

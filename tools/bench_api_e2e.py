@@ -55,12 +55,19 @@ def ba_inputs(dev, n_cams, n_points, opp, device_resident, ctx):
             fmaps[names[image_id]].patches[p2d] = features.ArenaPatch(arena, pi)
         keep = (arena, patches)
     else:
-        host = patches.cpu().numpy()                 # (n_obs, 16, 16, 128) fp16 in host memory
+        # what a pixsfm extractor hands over (extract.py:131-139): per image ONE N x H x W x C array + keypoint ids + corners,
+        # wrapped by the reference's numpy constructor FeatureMap(patches, point2D_ids, corners, metadata).  The synthetic scene
+        # is rendered in observation (point-major) order, so it is brought into image-major order on the device first.
+        ids = np.array([(image_id, p2d, pi) for (image_id, p2d), pi in patch_of.items()], dtype=np.int64)
+        ids = ids[np.lexsort((ids[:, 1], ids[:, 0]))]
+        host = patches[torch.as_tensor(ids[:, 2], device=patches.device)].cpu().numpy()      # image-major, host memory
         del patches
         torch.cuda.empty_cache()
-        corners, scales = prob["corners"], prob["scales"]
-        for (image_id, p2d), pi in patch_of.items():
-            fmaps[names[image_id]].patches[p2d] = features.FeaturePatch(host[pi], corners[pi], scales[pi])
+        corners, scales = prob["corners"][ids[:, 2]], prob["scales"][ids[:, 2]]
+        bounds = np.flatnonzero(np.diff(ids[:, 0], prepend=-1, append=-2))
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            fmaps[names[int(ids[lo, 0])]] = features.FeatureMap(host[lo:hi], ids[lo:hi, 1], corners[lo:hi],
+                                                                {"scale": scales[lo], "is_sparse": True, "patch_size": 16})
         keep = host
     return rec, features.FeatureManager([features.FeatureSet(fmaps)]), keep, len(prob["obs_image"])
 

@@ -1123,7 +1123,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
                                                 4 * (int64_t)nblk(((int64_t)n_img + n_cam + n_pts + UPDATE_IPT - 1) / UPDATE_IPT),
                                                 (int64_t)nblk(nc1) * 4, n_pts}) + 8;
   DevBuf<double> det_part;
-  if (det) RC(det_part.alloc((size_t)det_part_n));
+  RC(det_part.alloc((size_t)det_part_n));          // (the cost's partials use it in every mode)
   auto det_scale_for = [](double cost_now) {       // 2^k: slots bounded by 8 max(1, sqrt(2 cost)) fit 62 bits
     const double bound = 8.0 * std::max(1.0, std::sqrt(2.0 * std::max(cost_now, 0.0)));
     return std::ldexp(1.0, 62 - (int)std::ceil(std::log2(bound)));
@@ -1131,8 +1131,11 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   auto ordered_sum = [&](int64_t n, int stride, int k, double* dst) {
     hipLaunchKernelGGL(k_ordered_sum, dim3(1), dim3(1024), 0, st, (const double*)det_part.p, n, stride, k, dst);
   };
+  // The cost is NOT fused into the residual kernel (rounds 1-3 did: one floating-point atomic per wavefront to ONE address --
+  // 15 600 of them serialise for ~50 us, profiles/r4_det_vs_default_kernel_stats.txt: ba_eval_kernel 848 us with, 794 us
+  // without): a pass over the 64-byte records with per-workgroup partials (12 us) and an index-ordered final sum (8 us) is
+  // cheaper, and deterministic in every mode.
   auto evaluate = [&](const pxr_ba_view& v, double* rec) -> int {   // rec + cost into scal_sum[0]
-    if (!det) return ba_eval_with_cost(ctx, arena, &v, cfg, 1, rec, nullptr, nullptr, nullptr, loss, scal_sum);   // cost fused
     RC(ba_eval_with_cost(ctx, arena, &v, cfg, 1, rec, nullptr, nullptr, nullptr, nullptr, nullptr));
     hipLaunchKernelGGL(k_cost_partials, dim3((unsigned)det_cost_blocks), dim3(256), 0, st, (const double*)rec, n_obs, *loss, det_part.p);
     ordered_sum(det_cost_blocks, 1, 0, scal_sum);

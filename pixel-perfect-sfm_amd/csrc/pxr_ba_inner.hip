@@ -777,6 +777,11 @@ struct GramTexels {
 // gram_block(R, Cb) * 16, row-major inside.  Element (i, c) with i / 4 > c / 4 is read from the transposed block.
 __device__ __forceinline__ constexpr int gram_block(int R, int Cb) { return R * 4 - R * (R - 1) / 2 + (Cb - R); }
 constexpr int IG_GDOUBLES = 160;
+#ifndef PXR_GRAM_GSTRIDE
+#define PXR_GRAM_GSTRIDE 160      // doubles between two observations' Gram matrices in LDS (>= 160; padding rotates the banks)
+#endif
+constexpr int IG_GSTRIDE = PXR_GRAM_GSTRIDE;
+static_assert(IG_GSTRIDE >= IG_GDOUBLES, "ten 4 x 4 blocks per observation");   // (164 / 168 / 176: same 3.45 ms -- the 30 % LDS bank conflicts of the counters are not what bounds the kernel)
 
 // G = T T^t -> the blocked upper triangle at Gq, D = T d -> Dq[i], by ALL 64 lanes: the texel values are fed one per MFMA step as
 // both operands (the channel order of the contraction is irrelevant); the accumulators come out as G[g + 4 r][i] (r = 0..3):
@@ -853,7 +858,7 @@ __global__ __launch_bounds__(256) void k_gram_slots(int64_t n_obs, const int64_t
 
 // dynamic LDS of k_inner_gram for points of at most `maxo` observations, in doubles
 __host__ __device__ inline size_t gram_lds_doubles(int maxo, int C) {
-  return (size_t)maxo * (IG_GDOUBLES + 16 + IG_OBS) + C + (sizeof(InnerOwner) + 7) / 8;
+  return (size_t)maxo * (IG_GSTRIDE + 16 + IG_OBS) + C + (sizeof(InnerOwner) + 7) / 8;
 }
 
 template <typename ST, int C>
@@ -861,7 +866,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAV
   static_assert(C == 128 || C == 64, "feature patches");
   extern __shared__ __align__(16) double gsh[];
   double* const Gs = gsh;                                  // [maxo][160]
-  double* const Ds = Gs + (size_t)maxo * IG_GDOUBLES;      // [maxo][16]
+  double* const Ds = Gs + (size_t)maxo * IG_GSTRIDE;      // [maxo][16]
   double* const obs = Ds + (size_t)maxo * 16;              // [maxo][IG_OBS]: R (9) t (3) k (12) sx sy corner (2) model patch cell (2)
   double* const refd = obs + (size_t)maxo * IG_OBS;        // [C] reference descriptor
   InnerOwner& S = *reinterpret_cast<InnerOwner*>(refd + C);
@@ -986,13 +991,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAV
         int s0 = take(t0), s1 = take(t1), s2 = take(t2);
         while (true) {
           if (s0 < 0) break;
-          gram_contract<ST, C>(t0, refd, Gs + (size_t)(8 * k + (s0 >> 3)) * IG_GDOUBLES, Ds + (size_t)(8 * k + (s0 >> 3)) * 16);
+          gram_contract<ST, C>(t0, refd, Gs + (size_t)(8 * k + (s0 >> 3)) * IG_GSTRIDE, Ds + (size_t)(8 * k + (s0 >> 3)) * 16);
           s0 = take(t0);
           if (s1 < 0) break;
-          gram_contract<ST, C>(t1, refd, Gs + (size_t)(8 * k + (s1 >> 3)) * IG_GDOUBLES, Ds + (size_t)(8 * k + (s1 >> 3)) * 16);
+          gram_contract<ST, C>(t1, refd, Gs + (size_t)(8 * k + (s1 >> 3)) * IG_GSTRIDE, Ds + (size_t)(8 * k + (s1 >> 3)) * 16);
           s1 = take(t1);
           if (s2 < 0) break;
-          gram_contract<ST, C>(t2, refd, Gs + (size_t)(8 * k + (s2 >> 3)) * IG_GDOUBLES, Ds + (size_t)(8 * k + (s2 >> 3)) * 16);
+          gram_contract<ST, C>(t2, refd, Gs + (size_t)(8 * k + (s2 >> 3)) * IG_GSTRIDE, Ds + (size_t)(8 * k + (s2 >> 3)) * 16);
           s2 = take(t2);
         }
         if (need && sub == 0) { ob[30] = (double)row; ob[31] = (double)col; }
@@ -1007,7 +1012,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAV
         catmull_rom_weights(u - cf, wu, dwu);
         catmull_rom_weights(v - rf, wv, dwv);
         double ya[3], yb[3];                              // (G w, G wc, G wr) at rows 2 sub and 2 sub + 1
-        gram_rows_times_weights(Gs + (size_t)q * IG_GDOUBLES, sub, wu, dwu, wv, dwv, ya, yb);
+        gram_rows_times_weights(Gs + (size_t)q * IG_GSTRIDE, sub, wu, dwu, wv, dwv, ya, yb);
         const double2 d2 = *reinterpret_cast<const double2*>(Ds + (size_t)q * 16 + 2 * sub);
         const double wvo = pick4(wv, ri), dwvo = pick4(dwv, ri);
         const double wua = ci == 0 ? wu[0] : wu[2], wub = ci == 0 ? wu[1] : wu[3];

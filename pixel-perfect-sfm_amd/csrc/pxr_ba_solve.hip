@@ -340,51 +340,70 @@ __global__ __launch_bounds__(1024) void k_schur_lds(const SolveDev d, const ImgC
   int rrow[G];                                             // global row of Y_i row a (same for every observation of the image)
 #pragma unroll
   for (int a = 0; a < G; ++a) rrow[a] = a < dci ? col_index(d, img, cam, a) : 0x7fffffff;
-  for (int64_t o = ch.begin + grp; o < ch.end; o += n_grp) {
-    const int4 s = so[o];
-    if (s.w == 0) continue;                               // constant point (uniform over the group)
-    const int64_t i = s.x, pt = s.y;
-    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-    if (lane_b < dci) y_row(W, T, i, lane_b, d.DC, pt, y0, y1, y2);
-    if (blockIdx.y == 0 && lane_b < dci)
-      accum_add(racc + lane_b, -(y0 * gp[3 * (size_t)pt] + y1 * gp[3 * (size_t)pt + 1] + y2 * gp[3 * (size_t)pt + 2]), det_scale);
-    double ya[G][3];
+  // The loads of an observation form a chain: slot descriptor -> (W_i, T_p, g_p, the partner list) -> the partners' rows.  As
+  // first written every link waited for the one before it -- and W_i / T, g_p, the partner descriptors were three links of
+  // their own: five dependent round trips per observation, eight observations per lane group, 80 % of the wave cycles
+  // waiting (profiles/r4_hot_kernels_pmc.json).  Now: the next observation's descriptor is requested one iteration ahead,
+  // everything it addresses goes out TOGETHER (unconditional loads at clamped indices, selected afterwards: a conditional
+  // load is a branch + a wait), then the partners' rows: two links on the critical path.
+  constexpr int PB = 8;                                    // partners per batch of loads in flight
+  const bool first_tile = blockIdx.y == 0;
+  int64_t o = ch.begin + grp;
+  int4 s = o < ch.end ? so[o] : make_int4(0, 0, 0, 0);
+  while (o < ch.end) {
+    const int64_t o_next = o + n_grp;
+    const int4 s_next = o_next < ch.end ? so[o_next] : make_int4(0, 0, 0, 0);
+    if (s.w != 0) {                                        // (0: constant point; uniform over the group)
+      const int64_t i = s.x, pt = s.y;
+      const bool row_ok = lane_b < dci;
+      // -- link 1: W_i row, T_p, g_p, partner observations and their column descriptors
+      const double* Wi = W + ((size_t)i * d.DC + (row_ok ? lane_b : 0)) * 3;
+      const double* Tp = T + 6 * (size_t)pt;
+      const double* gpp = gp + 3 * (size_t)pt;
+      const double w0 = Wi[0], w1 = Wi[1], w2 = Wi[2];
+      const double t0 = Tp[0], t1 = Tp[1], t2 = Tp[2], t3 = Tp[3], t4 = Tp[4], t5 = Tp[5];
+      const double g0 = gpp[0], g1 = gpp[1], g2 = gpp[2];
+      double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+      // (one copy of the batch body: tracks of more than PB observations -- rare -- come round again with kb = PB, 2 PB, ...)
+      for (int kb = 0; kb < s.w; kb += PB) {
+        int jj[PB];
+        int4 cc[PB];
 #pragma unroll
-    for (int a = 0; a < G; ++a) {
-      ya[a][0] = __shfl(y0, gbase + a); ya[a][1] = __shfl(y1, gbase + a); ya[a][2] = __shfl(y2, gbase + a);
-    }
-    constexpr int PB = 8;                                  // partners per batch of loads in flight
-    for (int kb = 0; kb < s.w; kb += PB) {
-      int4 cc[PB];
-      double mm[PB][3];
-      int jj[PB];
-#pragma unroll
-      for (int u = 0; u < PB; ++u) {
-        const int idx = s.z + min(kb + u, s.w - 1);
-        jj[u] = pj[idx]; cc[u] = pcols[idx];
-      }
-#pragma unroll
-      for (int u = 0; u < PB; ++u) {
-        mm[u][0] = mm[u][1] = mm[u][2] = 0.0;               // row lane_b of W_j
-        if (kb + u < s.w && lane_b < cc[u].y + cc[u].w) {
-          const double* Wj = W + ((size_t)jj[u] * d.DC + lane_b) * 3;
-          mm[u][0] = Wj[0]; mm[u][1] = Wj[1]; mm[u][2] = Wj[2];
+        for (int u = 0; u < PB; ++u) {
+          const int idx = s.z + min(kb + u, s.w - 1);
+          jj[u] = pj[idx]; cc[u] = pcols[idx];
         }
-      }
+        // -- link 2: row lane_b of every partner's W_j
+        double mm[PB][3];
+        int col[PB];                                        // global column of that row, or -1: not this lane's / outside the tile
 #pragma unroll
-      for (int u = 0; u < PB; ++u) {
-        if (kb + u >= s.w) break;
-        const int4 cj = cc[u];
-        const int pdj = cj.y, dcj = pdj + cj.w;
-        const int c = lane_b < pdj ? cj.x + lane_b : cj.z + (lane_b - pdj);   // global column of W_j row lane_b
-        if (lane_b >= dcj || c < c0 || c >= c1) continue;
+        for (int u = 0; u < PB; ++u) {
+          const int pdj = cc[u].y, dcj = pdj + cc[u].w;
+          const bool has = kb + u < s.w && lane_b < dcj;
+          const double* Wj = W + ((size_t)jj[u] * d.DC + (has ? lane_b : 0)) * 3;
+          mm[u][0] = Wj[0]; mm[u][1] = Wj[1]; mm[u][2] = Wj[2];
+          const int c = lane_b < pdj ? cc[u].x + lane_b : cc[u].z + (lane_b - pdj);
+          col[u] = (has && c >= c0 && c < c1) ? c : -1;
+        }
+        if (kb == 0) {     // -- Y_i row (from link 1) and the right-hand side, while the partners' rows are on their way
+          if (row_ok) { y0 = w0 * t0 + w1 * t1 + w2 * t2; y1 = w0 * t1 + w1 * t3 + w2 * t4; y2 = w0 * t2 + w1 * t4 + w2 * t5; }
+          if (first_tile && row_ok) accum_add(racc + lane_b, -(y0 * g0 + y1 * g1 + y2 * g2), det_scale);
+        }
+        // row a of Y_i comes round the group (three shuffles) and meets every partner's row: the 24 values of all rows at
+        // once were 48 registers next to the 48 of the partners' rows
 #pragma unroll
         for (int a = 0; a < G; ++a) {
-          if (c >= rrow[a])                                  // upper triangle (rrow = INT_MAX beyond dc_i)
-            accum_add(acc + (size_t)a * CT + (c - c0), -(ya[a][0] * mm[u][0] + ya[a][1] * mm[u][1] + ya[a][2] * mm[u][2]), det_scale);
+          const double ya0 = __shfl(y0, gbase + a), ya1 = __shfl(y1, gbase + a), ya2 = __shfl(y2, gbase + a);
+#pragma unroll
+          for (int u = 0; u < PB; ++u) {
+            const int c = col[u];
+            if (c >= 0 && c >= rrow[a])                      // upper triangle (rrow = INT_MAX beyond dc_i)
+              accum_add(acc + (size_t)a * CT + (c - c0), -(ya0 * mm[u][0] + ya1 * mm[u][1] + ya2 * mm[u][2]), det_scale);
+          }
         }
       }
     }
+    o = o_next; s = s_next;
   }
   __syncthreads();
   for (int e = threadIdx.x; e < dci * CT; e += blockDim.x) {

@@ -493,6 +493,43 @@ def run_telemetry(job, ba, cfg):
     return out
 
 
+def run_gram(job, ba, cfg):
+    """The evaluation of the LM loop with the Gram-matrix cache on its own (pxr_ba_eval_gram): the build of every observation's
+    16 x 16 Gram matrix (32 fp64 MFMAs per observation: bound by the matrix pipe) and the steady-state pass from the cache
+    (1 408 + 64 B per observation: HBM-bound), with the shader clock / power sampled while the build loops."""
+    ctx = job.ctx
+    out = {}
+    ba.eval_gram(cfg, reset=True)
+    ctx.sync()
+    reps = 5
+    ctx.timer_start()
+    for _ in range(reps):
+        ba.eval_gram(cfg, reset=True, sync=False)
+    out["build_and_evaluate_ms"] = ctx.timer_stop() / reps
+    reps = 50
+    ctx.timer_start()
+    for _ in range(reps):
+        ba.eval_gram(cfg, reset=False, sync=False)
+    out["evaluate_from_cache_ms"] = ctx.timer_stop() / reps
+    bytes_per_obs = 176 * 8 + 64
+    out["evaluate_from_cache_GBps"] = bytes_per_obs * ba.n_obs / (out["evaluate_from_cache_ms"] * 1e-3) / 1e9
+    out["cache_bytes_per_obs"] = 176 * 8
+    if job.rank == 0 and not job.args.no_telemetry:
+        try:
+            tel = GpuTelemetry(job.local_rank)
+
+            def loop():
+                for _ in range(60):
+                    ba.eval_gram(cfg, reset=True, sync=False)
+                ctx.sync()
+            t = tel.sample_while(loop)
+            out["build_loop_sclk_mhz"] = t["sclk_mhz"]
+            out["build_loop_power_w"] = t["power_w"]
+        except Exception as e:  # noqa: BLE001
+            out["telemetry_error"] = repr(e)
+    return out
+
+
 def run_lm(job, ba, prob, cfg):
     """LM iterations / s on the same problem: "lm" = pixsfm's default configuration (use_inner_iterations = True,
     bundle_adjustment/main.py:43), "lm_no_inner" = the plain trust-region loop.  One iteration = linearise + Schur +
@@ -554,6 +591,25 @@ def run_lm(job, ba, prob, cfg):
                                   "iterations": d1["iterations"], "successful": d1["num_successful"], "final_cost": d1["final_cost"],
                                   "two_runs_bit_identical": bool(d0["final_cost"] == d1["final_cost"] and d0["num_successful"] == d1["num_successful"]),
                                   "final_cost_minus_default_mode": d1["final_cost"] - lm["lm"]["final_cost"]}
+    # the same two solves with the Gram-matrix cache (pxr_set_gram_cache): records from cached 16 x 16 Gram matrices of the
+    # stencils (1.4 KB per observation and pass) instead of from the texels (4 KB)
+    ctx.gram_cache = True
+    try:
+        gram = {}
+        for key, inner in (("lm", True), ("lm_no_inner", False)):
+            reset_parameters(ba, prob)
+            job.barrier()
+            g = ba.solve(cfg, make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,
+                         options=lm_options(max_iterations=args.lm_iters, use_inner_iterations=inner, linear_solver=args.linear_solver),
+                         allreduce=job.solve_allreduce())
+            job.barrier()
+            gram[key] = {"ms_per_iter": g["total_ms"] / max(1, g["iterations"]), "iterations": g["iterations"],
+                         "successful": g["num_successful"], "initial_cost": g["initial_cost"], "final_cost": g["final_cost"],
+                         "speedup_vs_texel_evaluation": (lm[key]["total_ms"] / max(1, lm[key]["iterations"])) / (g["total_ms"] / max(1, g["iterations"])),
+                         "final_cost_rel_diff": abs(g["final_cost"] - lm[key]["final_cost"]) / max(lm[key]["initial_cost"], 1e-300)}
+        extra["gram_cache"] = gram
+    finally:
+        ctx.gram_cache = False
     return lm, extra
 
 
@@ -684,6 +740,8 @@ def main():
             telemetry = {"error": repr(e)}
     job.barrier()
 
+    gram_eval = run_gram(job, ba, cfg)
+    job.barrier()
     lm, lm_extra = run_lm(job, ba, prob, cfg)
 
     costmap = None
@@ -768,6 +826,7 @@ def main():
             out.update(cpu_base)
         if ka_result is not None:
             out["ka"] = ka_result
+        out["gram_evaluation"] = gram_eval
         if costmap is not None:
             out["costmap"] = costmap
         if api_e2e is not None:

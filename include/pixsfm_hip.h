@@ -258,6 +258,28 @@ int pxr_set_iteration_callback(pxr_ctx* ctx, pxr_iteration_callback fn /* NULL r
 int pxr_set_deterministic(pxr_ctx* ctx, int on);
 int pxr_get_deterministic(pxr_ctx* ctx);
 
+/* Gram-matrix cache of pxr_ba_solve (also switched on by PXR_GRAM_CACHE=1 in the environment when the context is created).
+ * The solver only consumes the 64-byte record of a residual block (pxr_ba_eval), and bicubic interpolation is linear in the
+ * sixteen texels of the stencil: with the stencil's Gram matrix G = T T^t (16 x 16, over the channels) and D = T ref the
+ * record is a set of quadratic / linear forms in the Catmull-Rom weights of the fractional position.  With the cache on,
+ * pxr_ba_solve builds G and D once per observation (1 408 bytes each, HBM of the context, grow-only; rebuilt for the
+ * observations whose projection moves to another texel) and evaluates every LM iteration from them instead of from the
+ * 4 x 4 x C texels: ~3x less HBM traffic per iteration.  The algebra on G is exact in double precision where the reference
+ * interpolates with an fp32 horizontal pass (cubic_hermite_spline_simd.h), so a record differs from pxr_ba_eval's by that
+ * pass's own rounding (1e-7 of the descriptor norm per channel): costs agree to ~1e-9 relative on sums over many blocks,
+ * trajectories to the solver's tolerances; pxr_ba_eval itself, the other solvers and cost maps are unaffected.  Used for
+ * feature patches of 128 / 64 channels in fp16 / fp32 storage with reference descriptors; otherwise the flag is ignored.
+ * pxr_set_gram_cache(ctx, 0) also releases the storage. */
+int pxr_set_gram_cache(pxr_ctx* ctx, int on);
+int pxr_get_gram_cache(pxr_ctx* ctx);
+/* The records of pxr_ba_eval(with_jacobian = 1) through that cache, outside a solve (parity tests, bench): reset != 0
+ * (or a cache that does not fit the view yet) starts from an empty cache -- every observation's G is built -- otherwise the
+ * matrices of the previous call are reused for the observations still in their cell.  The cache is keyed by observation
+ * index: reuse it only with the same arena, observations and reference descriptors.  h_rebuilt (may be NULL; a non-NULL
+ * pointer synchronises): how many observations' matrices this call built. */
+int pxr_ba_eval_gram(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg, int reset,
+                     double* d_rec, int32_t* h_rebuilt);
+
 /* ---- multi-GPU: one process per GPU ---------------------------------------------
  * With N ranks every rank holds ALL images and cameras (replicated) and a disjoint shard of the points with
  * all their observations, patches and references; the only exchange of the BA path is an in-place

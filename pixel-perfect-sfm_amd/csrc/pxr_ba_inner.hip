@@ -22,6 +22,7 @@
 #include <algorithm>
 
 #include "pxr_device.h"
+#include "pxr_gram.h"
 #include "pxr_interp.h"
 #include "pxr_internal.h"
 
@@ -37,6 +38,9 @@ struct InnerArgs {
   double* xyz_out;             // == v.d_xyz (mutable alias)
   double* cost_before;         // += sum of 0.5 rho at the unrefined candidate
   double* cost_pt;             // deterministic mode (else NULL): [n_points] the per-point costs instead, summed in index order by the caller
+  double* gram_G;              // the solve's Gram-matrix cache (pxr_ba_gram.hip; NULL: none): [n_obs][176] and the cells they were
+  int2* gram_cell;             // built for -- k_inner_gram copies a matrix instead of building it where the cell matches, and
+  int gram_warm;               // writes back what it builds; gram_warm = 0: nothing cached yet (the first call of a solve)
 };
 
 // sum over the rows (LPO lanes each) of a point's lanes; every lane of a row holds the row's value
@@ -732,120 +736,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #endif
 constexpr int IG_MAXO = 16;   // observations per point whose Gram matrices fit the wavefront's LDS (two trips of 8)
 constexpr int IG_OBS = 32;    // doubles of an observation record: IP_OBS + the cell its Gram matrix was built for
-typedef double gd4 __attribute__((ext_vector_type(4)));
-
-// Catmull-Rom weights of the four taps at fractional position x (the polynomial of CubicHermiteSpline, base/src/interpolation.h /
-// cubic_hermite_spline_simd.h, expanded in the taps) and their derivatives
-__device__ __forceinline__ void catmull_rom_weights(double x, double (&w)[4], double (&dw)[4]) {
-  const double x2 = x * x, x3 = x2 * x;
-  w[0] = -0.5 * x + x2 - 0.5 * x3; w[1] = 1.0 - 2.5 * x2 + 1.5 * x3; w[2] = 0.5 * x + 2.0 * x2 - 1.5 * x3; w[3] = -0.5 * x2 + 0.5 * x3;
-  dw[0] = -0.5 + 2.0 * x - 1.5 * x2; dw[1] = -5.0 * x + 4.5 * x2; dw[2] = 0.5 + 4.0 * x - 4.5 * x2; dw[3] = -x + 1.5 * x2;
-}
-__device__ __forceinline__ double pick4(const double (&w)[4], int i) { return i == 0 ? w[0] : (i == 1 ? w[1] : (i == 2 ? w[2] : w[3])); }
-
-// The texels of one 4 x 4 stencil as the MFMA wants them: lane (i = lane & 15, g = lane >> 4) holds channels
-// [g C/4, (g + 1) C/4) of texel i -- 64 contiguous bytes at C = 128 / fp16.  (row, col): the cell, wave-uniform.
-template <typename ST, int C>
-struct GramTexels {
-  static constexpr int CPL = C / 4;
-  typename std::conditional<sizeof(ST) == 2, uint4, float4>::type raw[sizeof(ST) == 2 ? CPL / 8 : CPL / 4];
-  __device__ __forceinline__ void load(const ST* __restrict__ patch, int H, int W, int row, int col) {
-    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
-    const int tr = clampi(row - 1 + (i >> 2), 0, H - 1), tc = clampi(col - 1 + (i & 3), 0, W - 1);   // Grid2D's clamp (grid2d.h:64-73)
-    const ST* p = patch + ((size_t)tr * W + tc) * C + g * CPL;
-    if constexpr (sizeof(ST) == 2) {
-#pragma unroll
-      for (int q = 0; q < CPL / 8; ++q) raw[q] = *reinterpret_cast<const uint4*>(p + 8 * q);
-    } else {
-#pragma unroll
-      for (int q = 0; q < CPL / 4; ++q) raw[q] = *reinterpret_cast<const float4*>(p + 4 * q);
-    }
-  }
-  __device__ __forceinline__ double value(int e) const {
-    if constexpr (sizeof(ST) == 2) {
-      union { uint4 u; _Float16 h[8]; } cv;
-      cv.u = raw[e / 8];
-      return (double)(float)cv.h[e % 8];
-    } else {
-      const float4 v = raw[e / 4];
-      return (double)(e % 4 == 0 ? v.x : (e % 4 == 1 ? v.y : (e % 4 == 2 ? v.z : v.w)));
-    }
-  }
-};
-
-// The symmetric 16 x 16 Gram matrix in LDS as its ten upper 4 x 4 blocks (160 doubles instead of 256): block (R, Cb), R <= Cb, at
-// gram_block(R, Cb) * 16, row-major inside.  Element (i, c) with i / 4 > c / 4 is read from the transposed block.
-__device__ __forceinline__ constexpr int gram_block(int R, int Cb) { return R * 4 - R * (R - 1) / 2 + (Cb - R); }
-constexpr int IG_GDOUBLES = 160;
 #ifndef PXR_GRAM_GSTRIDE
 #define PXR_GRAM_GSTRIDE 160      // doubles between two observations' Gram matrices in LDS (>= 160; padding rotates the banks)
 #endif
 constexpr int IG_GSTRIDE = PXR_GRAM_GSTRIDE;
 static_assert(IG_GSTRIDE >= IG_GDOUBLES, "ten 4 x 4 blocks per observation");   // (164 / 168 / 176: same 3.45 ms -- the 30 % LDS bank conflicts of the counters are not what bounds the kernel)
 
-// G = T T^t -> the blocked upper triangle at Gq, D = T d -> Dq[i], by ALL 64 lanes: the texel values are fed one per MFMA step as
-// both operands (the channel order of the contraction is irrelevant); the accumulators come out as G[g + 4 r][i] (r = 0..3):
-// in-block row g of block row r, column i.
-template <typename ST, int C>
-__device__ __forceinline__ void gram_contract(const GramTexels<ST, C>& tx, const double* ref, double* Gq, double* Dq) {
-  constexpr int CPL = C / 4;
-  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
-  gd4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-  double dp = 0.0;
-  const double* rp = ref + g * CPL;
-#pragma unroll
-  for (int e = 0; e < CPL; e += 2) {
-    const double x0 = tx.value(e), x1 = tx.value(e + 1);
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, acc1, 0, 0, 0);
-    dp = fma(x0, rp[e], dp);
-    dp = fma(x1, rp[e + 1], dp);
-  }
-  dp += __shfl_xor(dp, 16);
-  dp += __shfl_xor(dp, 32);
-  if (g == 0) Dq[i] = dp;
-  const gd4 acc = acc0 + acc1;
-  const int cb = i >> 2, ic = i & 3;
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-    if (cb >= r) Gq[gram_block(r, cb) * 16 + g * 4 + ic] = acc[r];
-}
-
-// rows i0 = 2 sub, i0 + 1 of G times the Kronecker-structured weights: (G w)_i, (G wc)_i, (G wr)_i for both rows
-__device__ __forceinline__ void gram_rows_times_weights(const double* Gq, int sub, const double (&wu)[4], const double (&dwu)[4],
-                                                        const double (&wv)[4], const double (&dwv)[4], double (&ya)[3], double (&yb)[3]) {
-  const int R = sub >> 1, ir = 2 * (sub & 1);            // block row of both rows, in-block row of the first
-  ya[0] = ya[1] = ya[2] = yb[0] = yb[1] = yb[2] = 0.0;
-#pragma unroll
-  for (int cbk = 0; cbk < 4; ++cbk) {                    // column block = the vertical tap r of the weights
-    double ea[4], eb[4];
-    if (cbk >= R) {                                       // stored block (R, cbk): two rows of four
-      const double* blk = Gq + gram_block(R, cbk) * 16 + ir * 4;
-      const double2 a01 = *reinterpret_cast<const double2*>(blk), a23 = *reinterpret_cast<const double2*>(blk + 2);
-      const double2 b01 = *reinterpret_cast<const double2*>(blk + 4), b23 = *reinterpret_cast<const double2*>(blk + 6);
-      ea[0] = a01.x; ea[1] = a01.y; ea[2] = a23.x; ea[3] = a23.y; eb[0] = b01.x; eb[1] = b01.y; eb[2] = b23.x; eb[3] = b23.y;
-    } else {                                              // transposed block (cbk, R): two adjacent columns, rows 0..3
-      const double* blk = Gq + gram_block(cbk, R) * 16 + ir;
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const double2 t = *reinterpret_cast<const double2*>(blk + 4 * cc);
-        ea[cc] = t.x; eb[cc] = t.y;
-      }
-    }
-    const double za = fma(ea[3], wu[3], fma(ea[2], wu[2], fma(ea[1], wu[1], ea[0] * wu[0])));
-    const double zb = fma(eb[3], wu[3], fma(eb[2], wu[2], fma(eb[1], wu[1], eb[0] * wu[0])));
-    const double zca = fma(ea[3], dwu[3], fma(ea[2], dwu[2], fma(ea[1], dwu[1], ea[0] * dwu[0])));
-    const double zcb = fma(eb[3], dwu[3], fma(eb[2], dwu[2], fma(eb[1], dwu[1], eb[0] * dwu[0])));
-    ya[0] = fma(wv[cbk], za, ya[0]); yb[0] = fma(wv[cbk], zb, yb[0]);
-    ya[1] = fma(wv[cbk], zca, ya[1]); yb[1] = fma(wv[cbk], zcb, yb[1]);
-    ya[2] = fma(dwv[cbk], za, ya[2]); yb[2] = fma(dwv[cbk], zb, yb[2]);
-  }
-}
-
 // one entry of the host's list of points for k_inner_gram
 struct GramPoint { int p, len; int64_t o0; };
 // per slot of the point-ordered observation list: what the staging needs without walking obs -> image -> camera
-struct GramSlot { int img, cam; int64_t patch; };
+struct GramSlot { int img, cam; int64_t patch; int64_t obs; };
 __global__ __launch_bounds__(256) void k_gram_slots(int64_t n_obs, const int64_t* __restrict__ pt_obs, const int32_t* __restrict__ obs_image,
                                                     const int64_t* __restrict__ obs_patch, const int32_t* __restrict__ image_camera,
                                                     GramSlot* __restrict__ out) {
@@ -853,7 +753,7 @@ __global__ __launch_bounds__(256) void k_gram_slots(int64_t n_obs, const int64_t
   if (o >= n_obs) return;
   const int64_t i = pt_obs[o];
   const int img = obs_image[i];
-  out[o] = GramSlot{img, image_camera[img], obs_patch[i]};
+  out[o] = GramSlot{img, image_camera[img], obs_patch[i], i};
 }
 
 // dynamic LDS of k_inner_gram for points of at most `maxo` observations, in doubles
@@ -887,6 +787,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAV
   const size_t patch_elems = (size_t)a.H * a.W * C;
   const bool l2 = a.l2_normalize != 0;
 
+  if (a.gram_G && a.gram_warm) {
+    // The LM loop keeps every observation's Gram matrix for the cell of its last evaluation (pxr_ba_gram.hip): copy the 1 408
+    // bytes instead of reading 4 KB of texels and running 32 MFMAs.  Speculative -- the first round rebuilds the few whose
+    // projection at the candidate left that cell -- and placed here, where no register is live yet: four observations in flight.
+#pragma unroll 1
+    for (int q0 = 0; q0 < L; q0 += 4) {
+      double2 va0, va1, va2, va3, vb0, vb1, vb2, vb3;     // (unconditional loads at clamped slots: scalars, not a scratch array)
+      const int hi = lane < 24 ? lane : 23;
+#define IG_FETCH(J, VA, VB)                                                                                                              \
+      {                                                                                                                                  \
+        const double2* g = reinterpret_cast<const double2*>(a.gram_G + (size_t)slots[o0 + min(q0 + J, L - 1)].obs * (IG_GDOUBLES + 16)); \
+        VA = g[lane]; VB = g[64 + hi];                                                                                                   \
+      }
+      IG_FETCH(0, va0, vb0) IG_FETCH(1, va1, vb1) IG_FETCH(2, va2, vb2) IG_FETCH(3, va3, vb3)
+#undef IG_FETCH
+#define IG_PUT(J, VA, VB)                                                                                   \
+      if (q0 + J < L) {                                                                                     \
+        double2* Gd = reinterpret_cast<double2*>(Gs + (size_t)(q0 + J) * IG_GSTRIDE);                       \
+        Gd[lane] = VA;                                              /* doubles 0 .. 127 of G */             \
+        if (lane < 16) Gd[64 + lane] = VB;                          /* 128 .. 159 */                        \
+        else if (lane < 24) reinterpret_cast<double2*>(Ds + (size_t)(q0 + J) * 16)[lane - 16] = VB;   /* D */ \
+      }
+      IG_PUT(0, va0, vb0) IG_PUT(1, va1, vb1) IG_PUT(2, va2, vb2) IG_PUT(3, va3, vb3)
+#undef IG_PUT
+    }
+  }
   // ---- staging: reference, observation records (rotation matrix of the unit quaternion), owner state ----
   for (int ch = lane; ch < C; ch += 64) refd[ch] = a.v.d_refs ? a.v.d_refs[(size_t)p * C + ch] : 0.0;
   {
@@ -913,7 +839,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAV
         ob[24] = a.scales[2 * pi]; ob[25] = a.scales[2 * pi + 1];
         ob[26] = (double)a.corners[2 * pi]; ob[27] = (double)a.corners[2 * pi + 1];
         ob[28] = (double)a.v.d_cam_model[cam]; ob[29] = (double)pi;
-        ob[30] = -1.0e6; ob[31] = -1.0e6;                  // the cell its Gram matrix was built for: none yet
+        // the cell its Gram matrix was built for: none yet -- or the LM loop's cached matrix, copied below
+        int2 cc = make_int2(-1000000, -1000000);
+        if (a.gram_G && a.gram_warm) cc = a.gram_cell[sl.obs];
+        ob[30] = (double)cc.x; ob[31] = (double)cc.y;
       }
     }
   }
@@ -1002,6 +931,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAV
         }
         if (need && sub == 0) { ob[30] = (double)row; ob[31] = (double)col; }
         __syncthreads();                                 // the Gram matrices written by all lanes -> visible to their readers
+        if (a.gram_G) {
+          // ... and kept for the next call (and for the LM loop's evaluation, pxr_ba_gram.hip): an observation belongs to
+          // one point, a point to one wavefront -- nobody else touches these 1 408 bytes
+          unsigned long long wb = __ballot(need);
+          while (wb != 0ull) {
+            const int src = __ffsll((long long)wb) - 1;
+            wb &= ~(0xffull << (src & ~7));
+            const int slot = 8 * k + (src >> 3);
+            const int64_t oi = slots[o0 + slot].obs;
+            double2* g = reinterpret_cast<double2*>(a.gram_G + (size_t)oi * (IG_GDOUBLES + 16));
+            const double2* Gd = reinterpret_cast<const double2*>(Gs + (size_t)slot * IG_GSTRIDE);
+            g[lane] = Gd[lane];
+            if (lane < 16) g[64 + lane] = Gd[64 + lane];
+            else if (lane < 24) g[64 + lane] = reinterpret_cast<const double2*>(Ds + (size_t)slot * 16)[lane - 16];
+            const int2 cl = make_int2(__builtin_amdgcn_readlane(row, src), __builtin_amdgcn_readlane(col, src));
+            if (lane == 0) a.gram_cell[oi] = cl;
+          }
+        }
 #ifdef PXR_INNER_PROFILE
         gq_builds += __popcll(__ballot(need)) / 8;
 #endif
@@ -1098,7 +1045,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAV
 // once per solve by make_inner_lists.
 int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
                             const pxr_loss* loss, const int64_t* d_pt_ptr, const int64_t* d_pt_obs,
-                            const int* d_pt_var, double* d_cost_before, const InnerLists* lists, double* d_cost_per_point) {
+                            const int* d_pt_var, double* d_cost_before, const InnerLists* lists, double* d_cost_per_point,
+                            const GramCache* gram, bool gram_warm) {
   if (arena->C != 128 && arena->C != 64 && arena->C != 3 && arena->C != 1)
     return set_error(PXR_EUNSUPPORTED, "inner iterations: CHANNELS=%d not supported (128, 64; cost maps: 3, 1)", arena->C);
   InnerArgs a;
@@ -1107,6 +1055,7 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   a.H = arena->H; a.W = arena->W; a.up = arena->up; a.l2_normalize = cfg->l2_normalize; a.check_bounds = cfg->check_bounds; a.loss = *loss;
   a.pt_ptr = d_pt_ptr; a.pt_obs = d_pt_obs; a.pt_var = d_pt_var;
   a.xyz_out = const_cast<double*>(view->d_xyz); a.cost_before = d_cost_before; a.cost_pt = d_cost_per_point;
+  a.gram_G = gram ? gram->G : nullptr; a.gram_cell = gram ? static_cast<int2*>(gram->cell) : nullptr; a.gram_warm = gram_warm ? 1 : 0;
   const int ppb = arena->C >= 64 ? 1 : 8;   // points per workgroup (InnerShape)
   const int threads = 64;
   const unsigned blocks = (unsigned)((view->n_points + ppb - 1) / ppb);

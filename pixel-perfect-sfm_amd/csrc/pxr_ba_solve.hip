@@ -854,7 +854,8 @@ size_t chol_workspace_doubles(int n);
 // pxr_ba_inner.hip
 int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
                             const pxr_loss* loss, const int64_t* d_pt_ptr, const int64_t* d_pt_obs,
-                            const int* d_pt_var, double* d_cost_before, const InnerLists* lists, double* d_cost_per_point);
+                            const int* d_pt_var, double* d_cost_before, const InnerLists* lists, double* d_cost_per_point,
+                            const GramCache* gram, bool gram_warm);
 int make_inner_lists(hipStream_t st, const std::vector<int64_t>& pt_ptr, const pxr_ba_view* view, const int64_t* d_pt_obs, InnerLists* out);
 void free_inner_lists(InnerLists* l);
 
@@ -1154,8 +1155,22 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   // 15 600 of them serialise for ~50 us, profiles/r4_det_vs_default_kernel_stats.txt: ba_eval_kernel 848 us with, 794 us
   // without): a pass over the 64-byte records with per-workgroup partials (12 us) and an index-ordered final sum (8 us) is
   // cheaper, and deterministic in every mode.
+  // pxr_set_gram_cache: the records from cached Gram matrices of the stencils instead of from the texels (pxr_ba_gram.hip)
+  const bool gram_cache = ctx->gram_cache && gram_eval_supported(arena, view);
+  // The Gram-matrix kernel of the inner iterations keeps its matrices in the same cache from call to call (it writes back what
+  // it builds), whether or not the LM loop evaluates from them: the same numbers as without a cache, fewer builds.  (That kernel
+  // is built without the six extended camera models -- their forward-mode duals cost ~100 registers: a problem that uses one
+  // keeps the packed kernel for every point.)
+  bool gram_inner = opt->use_inner_iterations != 0 && arena->dtype != PXR_F64 && (arena->C == 128 || arena->C == 64) && !getenv("PXR_INNER_OLD") &&
+                    !getenv("PXR_INNER_PACKED");
+  for (int c = 0; c < n_cam; ++c) gram_inner = gram_inner && cam_model[c] <= PXR_OPENCV;
+  const bool inner_cache = gram_inner && gram_eval_supported(arena, view) && !getenv("PXR_INNER_NO_CACHE");
+  GramCache gram;
+  if (gram_cache || inner_cache) RC(gram_eval_prepare(ctx, arena, view, &gram));
+  bool gram_warm = false;               // the cache holds every observation's matrices (after the first evaluation / inner call)
   auto evaluate = [&](const pxr_ba_view& v, double* rec) -> int {   // rec + cost into scal_sum[0]
-    RC(ba_eval_with_cost(ctx, arena, &v, cfg, 1, rec, nullptr, nullptr, nullptr, nullptr, nullptr));
+    if (gram_cache) { RC(gram_evaluate(ctx, arena, &v, cfg, gram, rec)); gram_warm = true; }
+    else RC(ba_eval_with_cost(ctx, arena, &v, cfg, 1, rec, nullptr, nullptr, nullptr, nullptr, nullptr));
     hipLaunchKernelGGL(k_cost_partials, dim3((unsigned)det_cost_blocks), dim3(256), 0, st, (const double*)rec, n_obs, *loss, det_part.p);
     ordered_sum(det_cost_blocks, 1, 0, scal_sum);
     LAUNCH_CHECK("deterministic cost");
@@ -1282,10 +1297,6 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   bool reuse_diag = false;
   bool inner_enabled = opt->use_inner_iterations != 0, inner_useful = false;
   struct InnerListsOwner { InnerLists l; ~InnerListsOwner() { free_inner_lists(&l); } } inner_lists;
-  // the Gram-matrix kernel of the inner iterations is built without the six extended camera models (their forward-mode
-  // duals cost ~100 registers): a problem that uses one keeps the packed kernel for every point
-  bool gram_inner = inner_enabled;
-  for (int c = 0; c < n_cam; ++c) gram_inner = gram_inner && cam_model[c] <= PXR_OPENCV;
   if (gram_inner) RC(make_inner_lists(st, pt_cnt, view, d_pt_obs.p, &inner_lists.l));     // (pt_cnt holds the prefix sums by now)
   // ceres::IterationCallback (pxr_set_iteration_callback): 1 = SOLVER_ABORT, 2 = SOLVER_TERMINATE_SUCCESSFULLY
   // Several ranks: a callback installed on SOME ranks only (rank 0 logging, say) must not put the ranks' collectives out of
@@ -1408,10 +1419,14 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       LAUNCH_CHECK("step kernels");
       const bool do_inner = inner_enabled;
       if (do_inner) {   // DoInnerIterationsIfNeeded [upstream]: refine every variable point of the candidate on its own
-        if (det) PXR_HIP(hipMemsetAsync(det_part.p, 0, sizeof(double) * (size_t)n_pts, st));   // per-point costs, points without observations stay 0
+        // the cost at the unrefined candidate: per-point values summed in index order, in every mode (one floating-point atomic
+        // per point on ONE address -- 200 000 of them at configs[2] -- serialised for 0.5-1 ms of the 2-4 ms call:
+        // profiles/r4_inner_cost_atomic.txt)
+        PXR_HIP(hipMemsetAsync(det_part.p, 0, sizeof(double) * (size_t)n_pts, st));   // points without observations stay 0
         RC(launch_inner_iterations(ctx, arena, &cand_view, cfg, loss, d_pt_ptr.p, d_pt_obs.p, d_pt_var.p, scal_sum + 4, gram_inner ? &inner_lists.l : nullptr,
-                                   det ? det_part.p : nullptr));
-        if (det) ordered_sum(n_pts, 1, 0, scal_sum + 4);
+                                   det_part.p, (gram_cache || inner_cache) ? &gram : nullptr, gram_warm));
+        gram_warm = true;
+        ordered_sum(n_pts, 1, 0, scal_sum + 4);
         PXR_HIP(hipMemsetAsync(scal_sum + 2, 0, sizeof(double), st));   // point part of |x - candidate|^2 after refinement
         hipLaunchKernelGGL(k_point_step_norm, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, d_pt_var.p, cur_X, X1.p, scal_sum + 2, det ? det_part.p : (double*)nullptr);
         if (det) ordered_sum(4 * (int64_t)nblk(n_pts), 1, 0, scal_sum + 2);

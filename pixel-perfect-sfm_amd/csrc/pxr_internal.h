@@ -27,6 +27,9 @@ struct pxr_ctx {
   hipEvent_t ev_stage[2] = {nullptr, nullptr};
   size_t stage_bytes = 0;
   bool deterministic = false;    // pxr_set_deterministic / PXR_DETERMINISTIC=1: order-independent accumulation in the solvers
+  bool gram_cache = false;       // pxr_set_gram_cache / PXR_GRAM_CACHE=1: pxr_ba_solve evaluates from cached Gram matrices (pxr_ba_gram.hip)
+  void* d_gram = nullptr;        // grow-only storage of that cache
+  size_t gram_bytes = 0;
 };
 
 struct pxr_arena {
@@ -60,6 +63,14 @@ struct InnerLists {
   int* d_long = nullptr; int64_t n_long = 0;                          // the others (packed kernel, one point per wavefront)
   void* d_slots = nullptr;                                            // {image, camera, patch} per slot of the point-ordered list
 };
+// pxr_ba_gram.hip: the per-observation Gram matrices of one solve (storage owned by the context)
+struct GramCache {
+  double* G = nullptr; void* cell = nullptr; int* list = nullptr; int* count = nullptr; double* r2 = nullptr; int64_t n_obs = 0;
+};
+bool gram_eval_supported(const pxr_arena* arena, const pxr_ba_view* view);
+int gram_eval_prepare(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, GramCache* out);
+// the records of pxr_ba_eval(with_jacobian = 1) at the parameters of `v`, from the cache (rebuilding what moved to another cell)
+int gram_evaluate(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v, const pxr_interp_cfg* cfg, const GramCache& gc, double* rec);
 }  // namespace pxr
 
 #define PXR_HIP(call)                                        \

@@ -52,6 +52,7 @@ int pxr_ctx_create(int device, void* stream, pxr_ctx** out) {
   PXR_HIP(hipEventCreate(&c->ev_start));
   PXR_HIP(hipEventCreate(&c->ev_stop));
   if (const char* e = std::getenv("PXR_DETERMINISTIC")) c->deterministic = e[0] != '\0' && e[0] != '0';
+  if (const char* e = std::getenv("PXR_GRAM_CACHE")) c->gram_cache = e[0] != '\0' && e[0] != '0';
   c->scratch_bytes = 1 << 20;
   PXR_HIP(hipMalloc((void**)&c->d_scratch, c->scratch_bytes));
   *out = c;
@@ -67,6 +68,7 @@ int pxr_ctx_destroy(pxr_ctx* ctx) {
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->d_workspace) (void)hipFree(ctx->d_workspace);
   if (ctx->d_workspace_mat) (void)hipFree(ctx->d_workspace_mat);
+  if (ctx->d_gram) (void)hipFree(ctx->d_gram);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   release_staging(ctx);
@@ -423,6 +425,19 @@ int pxr_set_deterministic(pxr_ctx* ctx, int on) {
   return PXR_OK;
 }
 int pxr_get_deterministic(pxr_ctx* ctx) { return ctx && ctx->deterministic ? 1 : 0; }
+
+int pxr_set_gram_cache(pxr_ctx* ctx, int on) {
+  PXR_REQUIRE(ctx, "pxr_set_gram_cache: NULL context");
+  ctx->gram_cache = on != 0;
+  if (!on && ctx->d_gram) {       // give the storage back
+    PXR_HIP(hipSetDevice(ctx->device));
+    PXR_HIP(hipStreamSynchronize(ctx->stream));
+    PXR_HIP(hipFree(ctx->d_gram));
+    ctx->d_gram = nullptr; ctx->gram_bytes = 0;
+  }
+  return PXR_OK;
+}
+int pxr_get_gram_cache(pxr_ctx* ctx) { return ctx && ctx->gram_cache ? 1 : 0; }
 
 int pxr_set_iteration_callback(pxr_ctx* ctx, pxr_iteration_callback fn, void* user) {
   PXR_REQUIRE(ctx, "pxr_set_iteration_callback: NULL context");

@@ -101,6 +101,8 @@ _SIGNATURES = {
     "pxr_arena_size": (C.c_int64, [C.c_void_p]),
     "pxr_ba_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BaView), C.POINTER(InterpCfg), C.c_int,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pxr_ba_eval_gram": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BaView), C.POINTER(InterpCfg), C.c_int, C.c_void_p,
+                                   C.POINTER(C.c_int32)]),
     "pxr_ba_projection_jacobian": (C.c_int, [C.c_void_p, C.POINTER(BaView), C.c_void_p]),
     "pxr_ba_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(BaView), C.POINTER(InterpCfg), C.POINTER(Loss),
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(LMOptions),
@@ -142,6 +144,8 @@ _SIGNATURES = {
     "pxr_set_iteration_callback": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pxr_set_deterministic": (C.c_int, [C.c_void_p, C.c_int]),
     "pxr_get_deterministic": (C.c_int, [C.c_void_p]),
+    "pxr_set_gram_cache": (C.c_int, [C.c_void_p, C.c_int]),
+    "pxr_get_gram_cache": (C.c_int, [C.c_void_p]),
     "pxr_comm_set_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pxr_comm_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pxr_comm_allreduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

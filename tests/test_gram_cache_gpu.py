@@ -1,0 +1,152 @@
+"""GPU: the Gram-matrix cache of the BA solver (pxr_set_gram_cache / PXR_GRAM_CACHE=1, csrc/pxr_ba_gram.hip).
+
+The solver consumes the 64-byte record of a residual block, and bicubic interpolation is linear in the 16 texels of the 4 x 4
+stencil: with G = T T^t (16 x 16) and D = T ref the record is a set of quadratic / linear forms in the Catmull-Rom weights.
+The cache path must give pxr_ba_eval's records up to the rounding of the reference's fp32 horizontal pass
+(cubic_hermite_spline_simd.h; the algebra on G is exact in fp64), rebuild exactly the observations whose projection left
+their cell, and steer the LM loop to the same solution.  The inner iterations keep their matrices in the same cache from
+call to call in EVERY mode: that must not change a bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# a record entry differs from the exact-order kernel's by ~1e-7 of its scale (measured: 2e-8 absolute at |r|^2 ~ 0.4): the
+# fp32 pass rounds every channel at 6e-8 relative
+REC_ATOL = 2e-7
+
+
+def _gauge(prob):
+    n_img, n_cam, n_pt = len(prob["image_camera"]), len(prob["cam_model"]), len(prob["xyz"])
+    pose_const = np.zeros(n_img, np.uint8); pose_const[0] = 1
+    tmask = np.zeros(n_img, np.uint8); tmask[1] = 1
+    return pose_const, tmask, np.full(n_cam, 0b0110, np.uint16), np.zeros(n_pt, np.uint8)
+
+
+def _problem(ctx, **kw):
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena
+    args = dict(n_cams=10, n_points=500, obs_per_point=5, seed=21, rot_deg=0.3, pt_sigma=0.02, noise=0.01)
+    args.update(kw)
+    prob = synthetic.make_ba_problem(**args)
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    return prob, arena, BAProblem(ctx, arena, prob)
+
+
+@pytest.mark.parametrize("dtype,channels,l2,model", [(np.float16, 128, True, 2), (np.float32, 128, True, 4), (np.float16, 64, True, 1),
+                                                      (np.float32, 64, False, 0), (np.float16, 128, False, 3)])
+def test_records_match_the_exact_order_kernel(ctx, dtype, channels, l2, model):
+    from pixsfm_amd.engine import interp_cfg
+    prob, arena, ba = _problem(ctx, dtype=dtype, channels=channels, model=model)
+    cfg = interp_cfg(l2_normalize=l2)
+    exact = ba.eval(cfg)[0].download().copy()
+    rec, built = ba.eval_gram(cfg, reset=True)
+    gram = rec.download().copy()
+    assert built == ba.n_obs                                             # an empty cache: every observation's matrices
+    assert np.array_equal(gram[:, 6:], exact[:, 6:])                     # the projection is the same code
+    assert np.abs(gram[:, :6] - exact[:, :6]).max() < REC_ATOL
+    assert abs(gram[:, 0].sum() - exact[:, 0].sum()) < 1e-9 * exact[:, 0].sum()      # the rounding averages out over the blocks
+    arena.close()
+
+
+def test_only_the_observations_that_left_their_cell_are_rebuilt(ctx):
+    from pixsfm_amd.engine import interp_cfg
+    prob, arena, ba = _problem(ctx)
+    cfg = interp_cfg()
+    rec, built = ba.eval_gram(cfg, reset=True)
+    first = rec.download().copy()
+    assert built == ba.n_obs
+    rec, built = ba.eval_gram(cfg, reset=False)                           # same parameters: nothing to build, the same bits
+    assert built == 0 and np.array_equal(rec.download(), first)
+    # cells (floor of the patch coordinates) before and after a move of the points, from the exact kernel's projections
+    xy0 = first[:, 6:8]
+    ba.d["xyz"].upload(prob["xyz"] + np.random.default_rng(3).normal(0, 0.002, prob["xyz"].shape))
+    exact = ba.eval(cfg)[0].download().copy()
+    xy1 = exact[:, 6:8]
+    cell = lambda xy: np.floor(xy * prob["scales"] - 0.5 - prob["corners"]).astype(np.int64)
+    moved = int((cell(xy0) != cell(xy1)).any(axis=1).sum())
+    assert 0 < moved < ba.n_obs
+    rec, built = ba.eval_gram(cfg, reset=False)
+    assert built == moved
+    assert np.abs(rec.download()[:, :6] - exact[:, :6]).max() < REC_ATOL
+    # ... and back: the cells that moved are rebuilt again, the records are those of the first call
+    ba.d["xyz"].upload(prob["xyz"])
+    rec, built = ba.eval_gram(cfg, reset=False)
+    assert built == moved and np.array_equal(rec.download(), first)
+    arena.close()
+
+
+def test_a_projection_that_cannot_be_evaluated_stays_nan(ctx):
+    from pixsfm_amd.engine import interp_cfg
+    prob, arena, ba = _problem(ctx, n_points=64)
+    xyz = prob["xyz"].copy()
+    xyz[5] = np.nan
+    ba.d["xyz"].upload(xyz)
+    rec, _ = ba.eval_gram(interp_cfg(), reset=True)
+    r = rec.download()
+    bad = prob["obs_point"] == 5
+    assert np.isnan(r[bad, 0]).all() and np.isfinite(r[~bad, 0]).all()
+    arena.close()
+
+
+@pytest.mark.parametrize("inner", [False, True])
+def test_solve_with_the_cache_is_the_solve_without(ctx, inner):
+    from pixsfm_amd.engine import Context, interp_cfg, lm_options, make_loss
+    c2 = Context(0)
+    c2.gram_cache = True
+    assert c2.gram_cache and not ctx.gram_cache
+    out = []
+    for c in (ctx, c2):
+        prob, arena, ba = _problem(c, n_cams=12, n_points=900)
+        s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *_gauge(prob),
+                     options=lm_options(max_iterations=12, use_inner_iterations=inner))
+        out.append((s, ba.params()))
+        arena.close()
+    (s0, p0), (s1, p1) = out
+    assert s0["iterations"] == s1["iterations"]
+    assert abs(s0["initial_cost"] - s1["initial_cost"]) < 1e-9 * s0["initial_cost"]
+    assert abs(s0["final_cost"] - s1["final_cost"]) < 1e-6 * s0["initial_cost"]
+    for a, b in zip(p0, p1):
+        assert np.abs(a - b).max() < 1e-4 * max(1.0, np.abs(a).max())          # north_star: poses / points within 1e-4
+    c2.gram_cache = False                                                       # gives the storage back
+    assert not c2.gram_cache
+    c2.close()
+
+
+def test_the_inner_iterations_cache_does_not_change_a_bit(monkeypatch):
+    """Default mode: the inner iterations' Gram-matrix kernel writes the matrices it builds to the solve's cache and copies them
+    at the next call where the cell still matches.  The copied numbers ARE the built numbers: in deterministic mode (no
+    floating-point atomics) the solve with and without that cache is the same to the last bit."""
+    from pixsfm_amd.engine import Context, interp_cfg, lm_options, make_loss
+    runs = []
+    for no_cache in ("", "1"):
+        if no_cache:
+            monkeypatch.setenv("PXR_INNER_NO_CACHE", "1")
+        c = Context(0)
+        c.deterministic = True
+        prob, arena, ba = _problem(c, n_cams=12, n_points=900)
+        s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *_gauge(prob), options=lm_options(max_iterations=10, use_inner_iterations=True))
+        runs.append((s, ba.params()))
+        arena.close(); c.close()
+    (s0, p0), (s1, p1) = runs
+    assert s0["iterations"] == s1["iterations"] and s0["num_successful"] == s1["num_successful"] > 2
+    assert s0["final_cost"] == s1["final_cost"]
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b)
+
+
+def test_cost_maps_and_fp64_storage_ignore_the_flag(ctx):
+    """The cache needs feature patches (128 / 64 channels, fp16 / fp32) with reference descriptors: elsewhere the flag is ignored
+    by pxr_ba_solve and pxr_ba_eval_gram says so."""
+    from pixsfm_amd import PixsfmHipError
+    from pixsfm_amd.engine import Context, interp_cfg, lm_options, make_loss
+    c2 = Context(0)
+    c2.gram_cache = True
+    prob, arena, ba = _problem(c2, dtype=np.float64, n_points=200)
+    with pytest.raises(PixsfmHipError):
+        ba.eval_gram(interp_cfg())
+    s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *_gauge(prob), options=lm_options(max_iterations=4))
+    _, arena1, ba1 = _problem(ctx, dtype=np.float64, n_points=200)
+    s1 = ba1.solve(interp_cfg(), make_loss("cauchy", [0.25]), *_gauge(prob), options=lm_options(max_iterations=4))
+    assert abs(s["final_cost"] - s1["final_cost"]) < 1e-8 * s["initial_cost"] and s["iterations"] == s1["iterations"]
+    arena.close(); arena1.close(); c2.close()

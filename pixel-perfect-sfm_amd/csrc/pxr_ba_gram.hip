@@ -207,6 +207,7 @@ __global__ __launch_bounds__(64) void k_gram_eval_dirty(const GramArgs a) {
   const int lane = threadIdx.x;
   const int64_t base = (int64_t)blockIdx.x * 64, n = a.v.n_obs;
   unsigned long long todo = __ballot(base + lane < n && a.dirty[min(base + lane, n - 1)] != 0);
+#pragma clang loop unroll(disable)
   while (todo != 0ull) {
     const int nq = min(8, __popcll(todo));
     unsigned long long m = todo;                          // this lane group's observation: the (lane / 8)-th flagged one

@@ -1164,9 +1164,10 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   bool gram_inner = opt->use_inner_iterations != 0 && arena->dtype != PXR_F64 && (arena->C == 128 || arena->C == 64) && !getenv("PXR_INNER_OLD") &&
                     !getenv("PXR_INNER_PACKED");
   for (int c = 0; c < n_cam; ++c) gram_inner = gram_inner && cam_model[c] <= PXR_OPENCV;
-  const bool inner_cache = gram_inner && gram_eval_supported(arena, view) && !getenv("PXR_INNER_NO_CACHE");
+  bool inner_cache = gram_inner && gram_eval_supported(arena, view) && !getenv("PXR_INNER_NO_CACHE");
   GramCache gram;
-  if (gram_cache || inner_cache) RC(gram_eval_prepare(ctx, arena, view, &gram));
+  if (gram_cache) RC(gram_eval_prepare(ctx, arena, view, &gram));
+  else if (inner_cache && gram_eval_prepare(ctx, arena, view, &gram) != PXR_OK) inner_cache = false;   // (no memory for it: the kernel builds at every call)
   bool gram_warm = false;               // the cache holds every observation's matrices (after the first evaluation / inner call)
   auto evaluate = [&](const pxr_ba_view& v, double* rec) -> int {   // rec + cost into scal_sum[0]
     if (gram_cache) { RC(gram_evaluate(ctx, arena, &v, cfg, gram, rec)); gram_warm = true; }

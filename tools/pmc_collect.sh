@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 CMD="python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-api-e2e --no-costmap --no-telemetry"
-KERNELS="ba_eval_kernel ka_solve_kernel k_schur_lds k_inner_gram k_jac k_img k_point k_chol_step"
+KERNELS="ba_eval_kernel ka_solve_kernel k_schur_lds k_inner_gram k_gram_build k_gram_eval k_jac k_img k_point k_chol_step"
 pass() {   # name, counters...
   local name=$1; shift
   rm -rf /tmp/pmc_$name
@@ -25,7 +25,7 @@ pass sq SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAV
 pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU TCC_HIT_sum TCC_MISS_sum
 # roofline.traffic of the dominant kernel (with-Jacobian instantiation), stamped with the commit it was measured at
 python "$ROOT/tools/pmc_traffic.py" /tmp/pmc_fetch /tmp/pmc_write ba_eval_kernelIDF16_Li128ELb1ELb0 "$ROOT/$OUT/ba_eval_pmc.json" "$CMD" "$COMMIT" > /dev/null 2>> "$ROOT/$OUT/passes.log" || true
-for k in ka_solve_kernel k_schur_lds k_inner_gram; do
+for k in ka_solve_kernel k_schur_lds k_inner_gram k_gram_build k_gram_eval; do
   python "$ROOT/tools/pmc_traffic.py" /tmp/pmc_fetch /tmp/pmc_write $k "$ROOT/$OUT/${k}_traffic.json" "$CMD" "$COMMIT" > /dev/null 2>> "$ROOT/$OUT/passes.log" || true
 done
 rm -f "$ROOT/$OUT"/*.stdout

@@ -787,65 +787,78 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAV
   const size_t patch_elems = (size_t)a.H * a.W * C;
   const bool l2 = a.l2_normalize != 0;
 
-  if (a.gram_G && a.gram_warm) {
-    // The LM loop keeps every observation's Gram matrix for the cell of its last evaluation (pxr_ba_gram.hip): copy the 1 408
-    // bytes instead of reading 4 KB of texels and running 32 MFMAs.  Speculative -- the first round rebuilds the few whose
-    // projection at the candidate left that cell -- and placed here, where no register is live yet: four observations in flight.
+  // ---- staging: reference, observation records (rotation matrix of the unit quaternion), cached Gram matrices, owner state.
+  //      Three dependent round trips -- list entry, slots, what the slots address -- with everything of the third one in flight
+  //      together (the copies of the cached matrices are requested before the parameters and stored after them: the loads
+  //      return in order).
+  const int sq = lane >> 2, part = lane & 3;
+  const GramSlot sl = slots[o0 + min(sq, L - 1)];          // (list entry -> slot -> parameters: three dependent loads, not six)
+  double refv[C / 64];
+#pragma unroll
+  for (int j = 0; j < C / 64; ++j) refv[j] = a.v.d_refs ? a.v.d_refs[(size_t)p * C + lane + 64 * j] : 0.0;
+  // The solve keeps every observation's Gram matrix for the cell of its last evaluation / inner call (pxr_ba_gram.hip): copy
+  // the 1 408 bytes instead of reading 4 KB of texels and running 32 MFMAs.  Speculative -- the first round rebuilds the few
+  // whose projection at the candidate left that cell.  Eight observations per batch (unconditional loads at clamped slots:
+  // scalars, not a scratch array).
+  const bool warm = a.gram_G != nullptr && a.gram_warm != 0;
+  const int hi = lane < 24 ? lane : 23;
+  double2 va0, va1, va2, va3, va4, va5, va6, va7, vb0, vb1, vb2, vb3, vb4, vb5, vb6, vb7;
+#define IG_FETCH(Q0, J, VA, VB)                                                                                             \
+  {                                                                                                                         \
+    const int64_t oi = __shfl((int)sl.obs, 4 * min(Q0 + J, L - 1));      /* (observation indices fit 31 bits) */              \
+    const double2* g = reinterpret_cast<const double2*>(a.gram_G + (size_t)oi * (IG_GDOUBLES + 16));                         \
+    VA = g[lane]; VB = g[64 + hi];                                                                                          \
+  }
+#define IG_PUT(Q0, J, VA, VB)                                                                                               \
+  if (Q0 + J < L) {                                                                                                         \
+    double2* Gd = reinterpret_cast<double2*>(Gs + (size_t)(Q0 + J) * IG_GSTRIDE);                                           \
+    Gd[lane] = VA;                                              /* doubles 0 .. 127 of G */                                 \
+    if (lane < 16) Gd[64 + lane] = VB;                          /* 128 .. 159 */                                            \
+    else if (lane < 24) reinterpret_cast<double2*>(Ds + (size_t)(Q0 + J) * 16)[lane - 16] = VB;   /* D */                   \
+  }
+#define IG_FETCH8(Q0) IG_FETCH(Q0, 0, va0, vb0) IG_FETCH(Q0, 1, va1, vb1) IG_FETCH(Q0, 2, va2, vb2) IG_FETCH(Q0, 3, va3, vb3) \
+                      IG_FETCH(Q0, 4, va4, vb4) IG_FETCH(Q0, 5, va5, vb5) IG_FETCH(Q0, 6, va6, vb6) IG_FETCH(Q0, 7, va7, vb7)
+#define IG_PUT8(Q0) IG_PUT(Q0, 0, va0, vb0) IG_PUT(Q0, 1, va1, vb1) IG_PUT(Q0, 2, va2, vb2) IG_PUT(Q0, 3, va3, vb3) \
+                    IG_PUT(Q0, 4, va4, vb4) IG_PUT(Q0, 5, va5, vb5) IG_PUT(Q0, 6, va6, vb6) IG_PUT(Q0, 7, va7, vb7)
+  if (warm) { IG_FETCH8(0) }
+  if (sq < L) {
+    double* ob = obs + (size_t)sq * IG_OBS;
+    const int img = sl.img, cam = sl.cam;
+    const int64_t pi = sl.patch;
+    if (part == 0) {
+      double R[9];
+      quat_to_rotation(a.v.d_qvec + 4 * (size_t)img, R);
+#pragma unroll
+      for (int m = 0; m < 9; ++m) ob[m] = R[m];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) ob[9 + m] = a.v.d_tvec[3 * (size_t)img + m];
+    } else if (part == 1) {
+#pragma unroll
+      for (int m = 0; m < 6; ++m) ob[12 + m] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + m];
+    } else if (part == 2) {
+#pragma unroll
+      for (int m = 6; m < PXR_KPAD; ++m) ob[12 + m] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + m];
+    } else {
+      ob[24] = a.scales[2 * pi]; ob[25] = a.scales[2 * pi + 1];
+      ob[26] = (double)a.corners[2 * pi]; ob[27] = (double)a.corners[2 * pi + 1];
+      ob[28] = (double)a.v.d_cam_model[cam]; ob[29] = (double)pi;
+      // the cell its Gram matrix was built for: none yet -- or the cached matrix's
+      int2 cc = make_int2(-1000000, -1000000);
+      if (warm) cc = a.gram_cell[sl.obs];
+      ob[30] = (double)cc.x; ob[31] = (double)cc.y;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < C / 64; ++j) refd[lane + 64 * j] = refv[j];
+  if (warm) {
+    IG_PUT8(0)
 #pragma unroll 1
-    for (int q0 = 0; q0 < L; q0 += 4) {
-      double2 va0, va1, va2, va3, vb0, vb1, vb2, vb3;     // (unconditional loads at clamped slots: scalars, not a scratch array)
-      const int hi = lane < 24 ? lane : 23;
-#define IG_FETCH(J, VA, VB)                                                                                                              \
-      {                                                                                                                                  \
-        const double2* g = reinterpret_cast<const double2*>(a.gram_G + (size_t)slots[o0 + min(q0 + J, L - 1)].obs * (IG_GDOUBLES + 16)); \
-        VA = g[lane]; VB = g[64 + hi];                                                                                                   \
-      }
-      IG_FETCH(0, va0, vb0) IG_FETCH(1, va1, vb1) IG_FETCH(2, va2, vb2) IG_FETCH(3, va3, vb3)
+    for (int q0 = 8; q0 < L; q0 += 8) { IG_FETCH8(q0) IG_PUT8(q0) }
+  }
 #undef IG_FETCH
-#define IG_PUT(J, VA, VB)                                                                                   \
-      if (q0 + J < L) {                                                                                     \
-        double2* Gd = reinterpret_cast<double2*>(Gs + (size_t)(q0 + J) * IG_GSTRIDE);                       \
-        Gd[lane] = VA;                                              /* doubles 0 .. 127 of G */             \
-        if (lane < 16) Gd[64 + lane] = VB;                          /* 128 .. 159 */                        \
-        else if (lane < 24) reinterpret_cast<double2*>(Ds + (size_t)(q0 + J) * 16)[lane - 16] = VB;   /* D */ \
-      }
-      IG_PUT(0, va0, vb0) IG_PUT(1, va1, vb1) IG_PUT(2, va2, vb2) IG_PUT(3, va3, vb3)
 #undef IG_PUT
-    }
-  }
-  // ---- staging: reference, observation records (rotation matrix of the unit quaternion), owner state ----
-  for (int ch = lane; ch < C; ch += 64) refd[ch] = a.v.d_refs ? a.v.d_refs[(size_t)p * C + ch] : 0.0;
-  {
-    const int q = lane >> 2, part = lane & 3;
-    if (q < L) {
-      double* ob = obs + (size_t)q * IG_OBS;
-      const GramSlot sl = slots[o0 + q];                   // (list entry -> slot -> parameters: three dependent loads, not six)
-      const int img = sl.img, cam = sl.cam;
-      const int64_t pi = sl.patch;
-      if (part == 0) {
-        double R[9];
-        quat_to_rotation(a.v.d_qvec + 4 * (size_t)img, R);
-#pragma unroll
-        for (int m = 0; m < 9; ++m) ob[m] = R[m];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) ob[9 + m] = a.v.d_tvec[3 * (size_t)img + m];
-      } else if (part == 1) {
-#pragma unroll
-        for (int m = 0; m < 6; ++m) ob[12 + m] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + m];
-      } else if (part == 2) {
-#pragma unroll
-        for (int m = 6; m < PXR_KPAD; ++m) ob[12 + m] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + m];
-      } else {
-        ob[24] = a.scales[2 * pi]; ob[25] = a.scales[2 * pi + 1];
-        ob[26] = (double)a.corners[2 * pi]; ob[27] = (double)a.corners[2 * pi + 1];
-        ob[28] = (double)a.v.d_cam_model[cam]; ob[29] = (double)pi;
-        // the cell its Gram matrix was built for: none yet -- or the LM loop's cached matrix, copied below
-        int2 cc = make_int2(-1000000, -1000000);
-        if (a.gram_G && a.gram_warm) cc = a.gram_cell[sl.obs];
-        ob[30] = (double)cc.x; ob[31] = (double)cc.y;
-      }
-    }
-  }
+#undef IG_FETCH8
+#undef IG_PUT8
   if (lane == 0) {
 #pragma unroll
     for (int m = 0; m < 3; ++m) { S.X[m] = a.v.d_xyz[3 * p + m]; S.Xc[m] = S.X[m]; }

@@ -62,8 +62,12 @@ for trial in range(n_trials):
     q, t, k, X = ba.params()
     so, qo, to, ko, Xo = pxo.ba_solve(prob, pxo.cfg(l2, fs, False), loss_o, *gauge, pxo.lm_options(**kw))
     tol = 1e-5 if (fs or solver == "iterative") else 1e-7
+    # the inner iterations of fp16 / fp32 patches and the opt-in evaluation from the Gram-matrix cache work on Gram matrices: exact
+    # in fp64 where the oracle restates the reference's fp32 horizontal pass -- parameters agree to ~1e-6, not 1e-7
+    if (kw.get("use_inner_iterations") and dt != np.float64) or os.environ.get("PXR_GRAM_CACHE") == "1":
+        tol = max(tol, 5e-6)
     ok = sg["iterations"] == so["iterations"] and sg["num_successful"] == so["num_successful"] and sg["termination"] == so["termination"]
-    ok = ok and abs(sg["initial_cost"] - so["initial_cost"]) <= 1e-9 * abs(so["initial_cost"])
+    ok = ok and abs(sg["initial_cost"] - so["initial_cost"]) <= (1e-8 if os.environ.get("PXR_GRAM_CACHE") == "1" else 1e-9) * abs(so["initial_cost"])
     ok = ok and abs(sg["final_cost"] - so["final_cost"]) <= tol * max(abs(so["final_cost"]), 1e-12)
     err = 0.0
     for a, b in zip((q, t, k, X), (qo, to, ko, Xo)):

@@ -197,7 +197,8 @@ class FeatureMetricKeypointOptimizer:
         t_dump.__exit__(None, None, None)
         if len(node_ids):
             with phase("upload"):
-                arena = features.to_arena(ctx, [patches[i] for i in shard["node_patch" if world == 1 else "patch_ids"]])
+                arena = features.to_arena(ctx, [patches[i] for i in shard["node_patch" if world == 1 else "patch_ids"]],
+                                          cache=getattr(self, "arena_cache", None) if world == 1 else None)
             with phase("problem_to_device"):
                 shard = dict(shard, node_patch=arena.index)
                 ka = KAProblem(ctx, arena, shard)
@@ -320,11 +321,24 @@ class KeypointAdjuster:
             problem_setup = KeypointAdjustmentSetup()
             problem_setup.set_masked_nodes_constant(graph, root_labels)          # main.py:175-177
         solver = self._solver_cls(deepcopy(self.conf['optimizer']), problem_setup, self.conf['interpolation'])
-        if self.conf['split_in_subproblems']:
-            problem_labels, _ = find_problem_labels(track_labels, self.conf['max_kps_per_problem'])
-            solver.run(problem_labels, keypoints_dict, graph, track_labels, root_labels, feature_set)
-        else:
-            solver.run(keypoints_dict, graph, track_labels, root_labels, feature_set)
+        from ._timing import phase
+        from .. import parallel
+        with features.SharedArena() as shared:
+            if parallel.world()[1] == 1:             # (several ranks: every rank uploads its share only)
+                # feature maps built by the reference's numpy constructor: their upload starts now, in a background thread, and runs
+                # beside the edge construction and the walk over the keypoint / patch objects (features.SharedArena.prefetch)
+                with phase("prefetch_start"):
+                    seen = {}
+                    for nd in graph.nodes:
+                        seen.setdefault(nd.image_id, None)
+                    shared.prefetch(solver.ctx or default_context(), feature_set, [graph.image_id_to_name[i] for i in seen])
+                solver.arena_cache = shared
+            if self.conf['split_in_subproblems']:
+                problem_labels, _ = find_problem_labels(track_labels, self.conf['max_kps_per_problem'])
+                solver.run(problem_labels, keypoints_dict, graph, track_labels, root_labels, feature_set)
+            else:
+                solver.run(keypoints_dict, graph, track_labels, root_labels, feature_set)
+            solver.arena_cache = None
         return {"summary": solver.summary()}
 
 

@@ -712,3 +712,40 @@ def test_prefetched_upload_equals_the_plain_flow(ctx, monkeypatch):
         assert s.num_iterations == results[0][0].num_iterations
         assert abs(s.final_cost - results[0][0].final_cost) < 1e-7 * results[0][0].initial_cost
         assert np.abs(X - results[0][1]).max() < 1e-6
+
+
+def test_keypoint_adjuster_prefetches_stacked_feature_maps(ctx, monkeypatch):
+    """KeypointAdjuster.refine starts the upload of feature maps built by the reference's numpy constructor in a background thread
+    beside the edge construction and the walk over the keypoint objects (features.SharedArena.prefetch, like BundleAdjuster);
+    maps filled patch by patch take the plain flow.  Same keypoints either way -- also when a map holds patches of keypoints
+    that are not in the graph."""
+    from pixsfm_amd.api import KeypointAdjuster, features
+    started = []
+    real = features.SharedArena.prefetch
+    monkeypatch.setattr(features.SharedArena, "prefetch", lambda self, *a, **k: started.append(real(self, *a, **k)) or started[-1])
+    results = []
+    for stacked in (False, True):
+        prob, keypoints, graph, fmanager, (img, kid, names) = _ka_inputs(seed=5, n_tracks=14, track_len=4)
+        if not stacked:
+            fmaps = {}
+            for k, nm in enumerate(names):
+                fm = features.FeatureMap()
+                for t in np.nonzero(img == k)[0]:
+                    fm.patches[int(kid[t])] = features.FeaturePatch(prob["patches"][t], prob["corners"][t], (1.0, 1.0))
+                fmaps[nm] = fm
+            fmanager = features.FeatureManager([features.FeatureSet(fmaps)])
+        else:           # one more patch per map, of a keypoint the graph does not know
+            fmaps = {}
+            for k, nm in enumerate(names):
+                sel = np.nonzero(img == k)[0]
+                extra = np.concatenate([prob["patches"][sel], prob["patches"][sel[:1]]])
+                fmaps[nm] = features.FeatureMap.from_arrays(extra, np.concatenate([kid[sel], [10_000]]),
+                                                           np.concatenate([prob["corners"][sel], prob["corners"][sel[:1]]]), (1.0, 1.0))
+            fmanager = features.FeatureManager([features.FeatureSet(fmaps)])
+        out = KeypointAdjuster.create({"strategy": "featuremetric"}).refine_multilevel(keypoints, fmanager, graph)
+        results.append((out["summary"][0], np.concatenate([keypoints[nm] for nm in names])))
+    assert started == [False, True]
+    (s0, k0), (s1, k1) = results
+    assert s0.num_iterations == s1.num_iterations
+    assert abs(s0.final_cost - s1.final_cost) < 1e-9 * s0.initial_cost
+    assert np.abs(k0 - k1).max() < 1e-7

@@ -514,6 +514,16 @@ def run_gram(job, ba, cfg):
     bytes_per_obs = 176 * 8 + 64
     out["evaluate_from_cache_GBps"] = bytes_per_obs * ba.n_obs / (out["evaluate_from_cache_ms"] * 1e-3) / 1e9
     out["cache_bytes_per_obs"] = 176 * 8
+    out["roofline"] = {"bound": "hbm", "achieved": out["evaluate_from_cache_GBps"], "peak": 8000.0, "unit": "GB/s",
+                       "frac": out["evaluate_from_cache_GBps"] / 8000.0, "kernel": "k_gram_eval",
+                       "algorithmic_bytes_per_obs": bytes_per_obs,
+                       "note": "1 408 B of cached Gram matrix + D, 64 B record; counter traffic of the kernel: profiles/r4_hot_kernels_pmc.json"}
+    # the build: 32 v_mfma_f64_16x16x4 (2 048 flop each) per observation against the fp64 matrix rate this hardware sustains
+    # (tools/micro/mfma_f64_rate.hip: 44 TFLOP/s; the data sheet's dense fp64 matrix peak is 78.6)
+    build_ms = max(out["build_and_evaluate_ms"] - out["evaluate_from_cache_ms"], 1e-9)
+    out["build_roofline"] = {"bound": "mfma", "achieved": 32 * 2048 * ba.n_obs / (build_ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                             "frac": 32 * 2048 * ba.n_obs / (build_ms * 1e-3) / 1e12 / 78.6, "kernel": "k_gram_build (+ the second evaluation pass)",
+                             "sustained_rate_measured": 44.4}
     if job.rank == 0 and not job.args.no_telemetry:
         try:
             tel = GpuTelemetry(job.local_rank)

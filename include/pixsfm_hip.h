@@ -264,7 +264,8 @@ int pxr_get_deterministic(pxr_ctx* ctx);
  * record is a set of quadratic / linear forms in the Catmull-Rom weights of the fractional position.  With the cache on,
  * pxr_ba_solve builds G and D once per observation (1 408 bytes each, HBM of the context, grow-only; rebuilt for the
  * observations whose projection moves to another texel) and evaluates every LM iteration from them instead of from the
- * 4 x 4 x C texels: ~3x less HBM traffic per iteration.  The algebra on G is exact in double precision where the reference
+ * 4 x 4 x C texels: ~3x less HBM traffic per iteration (the evaluation at the initial point of a solve still reads the
+ * texels: the first step usually moves most projections to another texel).  The algebra on G is exact in double precision where the reference
  * interpolates with an fp32 horizontal pass (cubic_hermite_spline_simd.h), so a record differs from pxr_ba_eval's by that
  * pass's own rounding (1e-7 of the descriptor norm per channel): costs agree to ~1e-9 relative on sums over many blocks,
  * trajectories to the solver's tolerances; pxr_ba_eval itself, the other solvers and cost maps are unaffected.  Used for

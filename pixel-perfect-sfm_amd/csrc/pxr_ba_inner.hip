@@ -744,16 +744,25 @@ static_assert(IG_GSTRIDE >= IG_GDOUBLES, "ten 4 x 4 blocks per observation");   
 
 // one entry of the host's list of points for k_inner_gram
 struct GramPoint { int p, len; int64_t o0; };
-// per slot of the point-ordered observation list: what the staging needs without walking obs -> image -> camera
+// per observation of a listed point: what the staging needs without walking obs -> image -> camera
 struct GramSlot { int img, cam; int64_t patch; int64_t obs; };
-__global__ __launch_bounds__(256) void k_gram_slots(int64_t n_obs, const int64_t* __restrict__ pt_obs, const int32_t* __restrict__ obs_image,
-                                                    const int64_t* __restrict__ obs_patch, const int32_t* __restrict__ image_camera,
-                                                    GramSlot* __restrict__ out) {
-  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= n_obs) return;
-  const int64_t i = pt_obs[o];
+// The kernel's table: entry e = {GramPoint, GramSlot[maxo]} at e * gram_entry_bytes(maxo) -- addressed by the workgroup index
+// alone, so the list entry and its slots arrive in ONE round trip; the slots beyond the track's length repeat its last
+// observation (a lane may read its slot before it knows the length).
+__host__ __device__ inline size_t gram_entry_bytes(int maxo) { return sizeof(GramPoint) + sizeof(GramSlot) * (size_t)maxo; }
+__global__ __launch_bounds__(256) void k_gram_table(int64_t n_list, int maxo, const GramPoint* __restrict__ pt_list, const int64_t* __restrict__ pt_obs,
+                                                    const int32_t* __restrict__ obs_image, const int64_t* __restrict__ obs_patch,
+                                                    const int32_t* __restrict__ image_camera, char* __restrict__ table) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t e = t / (maxo + 1);
+  const int q = (int)(t % (maxo + 1)) - 1;                 // -1: the header
+  if (e >= n_list) return;
+  const GramPoint gp = pt_list[e];
+  char* ent = table + (size_t)e * gram_entry_bytes(maxo);
+  if (q < 0) { *reinterpret_cast<GramPoint*>(ent) = gp; return; }
+  const int64_t i = pt_obs[gp.o0 + min(q, gp.len - 1)];
   const int img = obs_image[i];
-  out[o] = GramSlot{img, image_camera[img], obs_patch[i], i};
+  reinterpret_cast<GramSlot*>(ent + sizeof(GramPoint))[q] = GramSlot{img, image_camera[img], obs_patch[i], i};
 }
 
 // dynamic LDS of k_inner_gram for points of at most `maxo` observations, in doubles
@@ -762,7 +771,7 @@ __host__ __device__ inline size_t gram_lds_doubles(int maxo, int C) {
 }
 
 template <typename ST, int C>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAVES, PXR_GRAM_WAVES))) void k_inner_gram(const InnerArgs a, const GramPoint* __restrict__ pt_list, const GramSlot* __restrict__ slots, const int maxo) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAVES, PXR_GRAM_WAVES))) void k_inner_gram(const InnerArgs a, const char* __restrict__ table, const int maxo) {
   static_assert(C == 128 || C == 64, "feature patches");
   extern __shared__ __align__(16) double gsh[];
   double* const Gs = gsh;                                  // [maxo][160]
@@ -778,8 +787,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAV
 #else
 #define GQ_MARK(k) do { } while (0)
 #endif
-  const GramPoint gp = pt_list[blockIdx.x];
-  const int64_t p = gp.p, o0 = gp.o0;
+  const char* const ent = table + (size_t)blockIdx.x * gram_entry_bytes(maxo);
+  const GramSlot* const slots = reinterpret_cast<const GramSlot*>(ent + sizeof(GramPoint));   // this point's
+  const GramPoint gp = *reinterpret_cast<const GramPoint*>(ent);
+  const int64_t p = gp.p;
   const int L = gp.len;                                    // 1 .. maxo (the host's lists)
   const bool variable = a.pt_var[p] != 0;
   bool active = variable, first = true;                    // (meaningful on lane 0, the owner)
@@ -788,11 +799,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAV
   const bool l2 = a.l2_normalize != 0;
 
   // ---- staging: reference, observation records (rotation matrix of the unit quaternion), cached Gram matrices, owner state.
-  //      Three dependent round trips -- list entry, slots, what the slots address -- with everything of the third one in flight
-  //      together (the copies of the cached matrices are requested before the parameters and stored after them: the loads
-  //      return in order).
+  //      Two dependent round trips -- the table entry (list entry + slots, addressed by the workgroup index), then what the
+  //      slots address, everything of it in flight together (the copies of the cached matrices are requested before the
+  //      parameters and stored after them: the loads return in order).
   const int sq = lane >> 2, part = lane & 3;
-  const GramSlot sl = slots[o0 + min(sq, L - 1)];          // (list entry -> slot -> parameters: three dependent loads, not six)
+  const GramSlot sl = slots[min(sq, maxo - 1)];            // (slots beyond the track's length repeat its last observation)
   double refv[C / 64];
 #pragma unroll
   for (int j = 0; j < C / 64; ++j) refv[j] = a.v.d_refs ? a.v.d_refs[(size_t)p * C + lane + 64 * j] : 0.0;
@@ -952,7 +963,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAV
             const int src = __ffsll((long long)wb) - 1;
             wb &= ~(0xffull << (src & ~7));
             const int slot = 8 * k + (src >> 3);
-            const int64_t oi = slots[o0 + slot].obs;
+            const int64_t oi = slots[slot].obs;
             double2* g = reinterpret_cast<double2*>(a.gram_G + (size_t)oi * (IG_GDOUBLES + 16));
             const double2* Gd = reinterpret_cast<const double2*>(Gs + (size_t)slot * IG_GSTRIDE);
             g[lane] = Gd[lane];
@@ -1090,9 +1101,9 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     else if (arena->C == 128) MACRO(float, 128, __VA_ARGS__);                           \
     else MACRO(float, 64, __VA_ARGS__);                                                 \
   } while (0)
-#define INNER_GRAM(ST, CC, NBLK, LIST, MAXO)                                                                              \
-  hipLaunchKernelGGL((k_inner_gram<ST, CC>), dim3(NBLK), dim3(64), sizeof(double) * gram_lds_doubles(MAXO, CC), ctx->stream, a, LIST, \
-                     static_cast<const GramSlot*>(lists->d_slots), MAXO)
+#define INNER_GRAM(ST, CC, NBLK, MAXO)                                                                                    \
+  hipLaunchKernelGGL((k_inner_gram<ST, CC>), dim3(NBLK), dim3(64), sizeof(double) * gram_lds_doubles(MAXO, CC), ctx->stream, a, \
+                     static_cast<const char*>(lists->d_slots), MAXO)
   if (arena->C <= 4) {
     if (arena->dtype == PXR_F16 && arena->C == 3) INNER_LAUNCH(k_inner_points, _Float16, 3);
     else if (arena->dtype == PXR_F16) INNER_LAUNCH(k_inner_points, _Float16, 1);
@@ -1119,7 +1130,7 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     } else {
       // Gram-matrix kernel for the points whose observations' Gram matrices fit a wavefront's LDS, packed kernel (one point per
       // wavefront) for the long tracks
-      if (lists->n_short > 0) INNER_BY_STORAGE(INNER_GRAM, (unsigned)lists->n_short, static_cast<const GramPoint*>(lists->d_short), lists->maxo_short);
+      if (lists->n_short > 0) INNER_BY_STORAGE(INNER_GRAM, (unsigned)lists->n_short, lists->maxo_short);
       if (lists->n_long > 0) INNER_BY_STORAGE(INNER_PACKED, (unsigned)lists->n_long, 1, lists->d_long);
     }
   } else if (arena->dtype == PXR_F64 && arena->C == 128) INNER_LAUNCH(k_inner_points, double, 128);
@@ -1146,11 +1157,13 @@ int make_inner_lists(hipStream_t st, const std::vector<int64_t>& pt_ptr, const p
   out->n_short = (int64_t)shorts.size(); out->n_long = (int64_t)longs.size(); out->maxo_short = maxo;
   out->d_short = nullptr; out->d_long = nullptr; out->d_slots = nullptr;
   if (!shorts.empty()) {
-    if (int rc = hip_check(hipMalloc(&out->d_slots, sizeof(GramSlot) * (size_t)std::max<int64_t>(1, view->n_obs)), "hipMalloc(inner slots)")) return rc;
-    hipLaunchKernelGGL(k_gram_slots, dim3((unsigned)((view->n_obs + 255) / 256)), dim3(256), 0, st, view->n_obs, d_pt_obs, view->d_obs_image,
-                       view->d_obs_patch, view->d_image_camera, static_cast<GramSlot*>(out->d_slots));
     if (int rc = hip_check(hipMalloc(&out->d_short, sizeof(GramPoint) * shorts.size()), "hipMalloc(inner lists)")) return rc;
     if (int rc = hip_check(hipMemcpyAsync(out->d_short, shorts.data(), sizeof(GramPoint) * shorts.size(), hipMemcpyHostToDevice, st), "H2D")) return rc;
+    if (int rc = hip_check(hipMalloc(&out->d_slots, gram_entry_bytes(maxo) * shorts.size()), "hipMalloc(inner table)")) return rc;
+    const int64_t n_thr = (int64_t)shorts.size() * (maxo + 1);
+    hipLaunchKernelGGL(k_gram_table, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, st, (int64_t)shorts.size(), maxo,
+                       static_cast<const GramPoint*>(out->d_short), d_pt_obs, view->d_obs_image, view->d_obs_patch, view->d_image_camera,
+                       static_cast<char*>(out->d_slots));
   }
   if (!longs.empty()) {
     if (int rc = hip_check(hipMalloc((void**)&out->d_long, sizeof(int) * longs.size()), "hipMalloc(inner lists)")) return rc;

@@ -61,7 +61,7 @@ int ba_eval_with_cost(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, c
 struct InnerLists {
   void* d_short = nullptr; int64_t n_short = 0; int maxo_short = 1;  // points with 1 .. 16 observations (Gram-matrix kernel): {point, length, first slot}
   int* d_long = nullptr; int64_t n_long = 0;                          // the others (packed kernel, one point per wavefront)
-  void* d_slots = nullptr;                                            // {image, camera, patch} per slot of the point-ordered list
+  void* d_slots = nullptr;                                            // the Gram-matrix kernel's table: per listed point {point, length, first slot} + {image, camera, patch, observation} x maxo_short
 };
 // pxr_ba_gram.hip: the per-observation Gram matrices of one solve (storage owned by the context)
 struct GramCache {

@@ -279,6 +279,22 @@ int gram_eval_prepare(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, G
   return hip_check(hipGetLastError(), "Gram-matrix cache set-up");
 }
 
+// rebuild the matrices of the observations flagged in the cache's `dirty` array (the caller set the flags and the cells)
+int gram_build_flagged(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v, const GramCache& gc) {
+  GramArgs a;
+  a.v = *v;
+  a.arena = arena->d_data; a.corners = arena->d_corners; a.scales = arena->d_scales;
+  a.H = arena->H; a.W = arena->W; a.l2_normalize = 0;
+  a.G = gc.G; a.cell = static_cast<int2*>(gc.cell); a.dirty = gc.list; a.r2 = gc.r2; a.rec = nullptr;
+  const int64_t n = v->n_obs;
+  const unsigned build_grid = (unsigned)std::min<int64_t>((n + 63) / 64, (int64_t)ctx->num_cus * 16);
+#define GRAM_BUILD(ST, CC) hipLaunchKernelGGL((k_gram_build<ST, CC>), dim3(build_grid), dim3(64), 0, ctx->stream, a)
+  if (arena->dtype == PXR_F16) { if (arena->C == 128) GRAM_BUILD(_Float16, 128); else GRAM_BUILD(_Float16, 64); }
+  else { if (arena->C == 128) GRAM_BUILD(float, 128); else GRAM_BUILD(float, 64); }
+#undef GRAM_BUILD
+  return hip_check(hipGetLastError(), "Gram-matrix build");
+}
+
 int gram_evaluate(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v, const pxr_interp_cfg* cfg, const GramCache& gc, double* rec) {
   GramArgs a;
   a.v = *v;

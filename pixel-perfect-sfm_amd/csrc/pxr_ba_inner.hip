@@ -1063,6 +1063,384 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PXR_GRAM_WAV
   if (variable && lane == 0) { a.xyz_out[3 * p] = S.X[0]; a.xyz_out[3 * p + 1] = S.X[1]; a.xyz_out[3 * p + 2] = S.X[2]; }
 }
 
+// ---- feature patches, fourth mapping: the Gram-matrix evaluation in the packed kernel's lockstep ------------------------------
+// k_inner_gram is bound by its vector instruction count (profiles/r4_hot_kernels_pmc.json: ~3 900 wave instructions per point,
+// the SIMDs 75 % busy issuing them): one point per wavefront repeats the projection, the weights, the robustifier and the
+// owner's trust-region step for five observations on 40 lanes.  Here a wavefront takes up to four points whose observations
+// fill at most sixteen slots (the host packs consecutive short tracks: three 5-observation tracks per wavefront), an
+// observation takes FOUR lanes -- lane R works on block row R of its Gram matrix, rows 4 R .. 4 R + 3 -- and the points
+// iterate in lockstep like in k_inner_packed: one round costs the same ~800 wave instructions whether it serves one point
+// or four.  The nine sums are bilinear forms per 4 x 4 block:  B(a, b) = sum_ir sum_cc a[ir] G[4 R + ir][4 Cb + cc] b[cc]  with
+// a, b the horizontal weights or their derivatives, scaled by the vertical weights of block row R and block column Cb; a block
+// below the diagonal is the transposed stored block, i.e. the stored block's form with a and b swapped.
+struct GramWave { int npts, pad; int p[IP_MAXPTS]; int st[IP_MAXPTS + 1]; int pad2; };   // points, first slot of each (st[npts] = slots used)
+static_assert(sizeof(GramWave) == 48, "table layout");
+constexpr int GW_SLOTS = 16;
+__host__ __device__ inline size_t gram_wave_bytes() { return sizeof(GramWave) + sizeof(GramSlot) * GW_SLOTS; }
+struct GramWaveLds {
+  double G[GW_SLOTS][IG_GDOUBLES];
+  double D[GW_SLOTS][16];
+  double obs[GW_SLOTS][IG_OBS];      // R (9) t (3) k (12) sx sy corner (2) model patch cell (2)
+  double res[GW_SLOTS][10];
+  double refbuf[128];                // reference descriptor of the observation being built
+  InnerOwner own[IP_MAXPTS];
+};
+
+__global__ __launch_bounds__(256) void k_gram_wave_table(int64_t n_waves, const GramWave* __restrict__ waves, const int64_t* __restrict__ pt_ptr,
+                                                         const int64_t* __restrict__ pt_obs, const int32_t* __restrict__ obs_image,
+                                                         const int64_t* __restrict__ obs_patch, const int32_t* __restrict__ image_camera,
+                                                         char* __restrict__ table) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t e = t / (GW_SLOTS + 1);
+  const int q = (int)(t % (GW_SLOTS + 1)) - 1;             // -1: the header
+  if (e >= n_waves) return;
+  const GramWave w = waves[e];
+  char* ent = table + (size_t)e * gram_wave_bytes();
+  if (q < 0) { *reinterpret_cast<GramWave*>(ent) = w; return; }
+  const int L = w.st[w.npts];
+  const int qc = min(q, L - 1);                            // (slots beyond the last observation repeat it)
+  int j = 0;
+  while (j + 1 < w.npts && qc >= w.st[j + 1]) ++j;
+  const int64_t i = pt_obs[pt_ptr[w.p[j]] + (qc - w.st[j])];
+  const int img = obs_image[i];
+  reinterpret_cast<GramSlot*>(ent + sizeof(GramWave))[q] = GramSlot{img, image_camera[img], obs_patch[i], i};
+}
+
+// Before a call of k_inner_gram_packed: which observations of its table project, at the candidate, into another cell than their
+// cached Gram matrix was built for?  They are flagged (and their cell updated) for k_gram_build (pxr_ba_gram.hip), which
+// rebuilds at the full rate of the matrix pipe -- four wavefronts per SIMD doing nothing else: 1.5 ms for every observation of
+// configs[2] -- instead of inside the nested-LM kernel, where a wavefront's fifteen builds queue behind each other (the first
+// call of a solve, every matrix cold: 4.5 ms).  The kernel then copies; it still builds what moves DURING its rounds.
+__global__ __launch_bounds__(256) void k_gram_flag_slots(const InnerArgs a, const char* __restrict__ table, int64_t n_waves, int* __restrict__ dirty) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t e = t / GW_SLOTS;
+  const int q = (int)(t % GW_SLOTS);
+  if (e >= n_waves) return;
+  const char* ent = table + (size_t)e * gram_wave_bytes();
+  const GramWave* gw = reinterpret_cast<const GramWave*>(ent);
+  const int npts = gw->npts, L = gw->st[npts];
+  if (q >= L) return;
+  int j = 0;
+  while (j + 1 < npts && q >= gw->st[j + 1]) ++j;
+  const int64_t p = gw->p[j];
+  const GramSlot sl = reinterpret_cast<const GramSlot*>(ent + sizeof(GramWave))[q];
+  double qv[4], tv[3], X[3], k[PXR_KPAD];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) qv[m] = a.v.d_qvec[4 * (size_t)sl.img + m];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) { tv[m] = a.v.d_tvec[3 * (size_t)sl.img + m]; X[m] = a.v.d_xyz[3 * (size_t)p + m]; }
+#pragma unroll
+  for (int m = 0; m < PXR_KPAD; ++m) k[m] = a.v.d_cam_params[(size_t)sl.cam * PXR_KPAD + m];
+  // the projection of the nested LM's first round, operation for operation (rotation matrix of the unit quaternion, reciprocal
+  // depth): the cell must be the one k_inner_gram_packed computes, or it would rebuild anyway
+  double R[9];
+  quat_to_rotation(qv, R);
+  const double p0 = fma(R[0], X[0], fma(R[1], X[1], fma(R[2], X[2], tv[0])));
+  const double p1 = fma(R[3], X[0], fma(R[4], X[1], fma(R[5], X[2], tv[1])));
+  const double p2 = fma(R[6], X[0], fma(R[7], X[1], fma(R[8], X[2], tv[2])));
+  const double iz = inner_rcp(p2), un = p0 * iz, vn = p1 * iz;
+  double x, y, Juv[2][2];
+  camera_model_jac<false, false>(a.v.d_cam_model[sl.cam], k, un, vn, x, y, Juv, nullptr);
+  const double u = x * a.scales[2 * sl.patch] - 0.5 - (double)a.corners[2 * sl.patch];
+  const double v = y * a.scales[2 * sl.patch + 1] - 0.5 - (double)a.corners[2 * sl.patch + 1];
+  const int row = texel_index(floor(v), a.H), col = texel_index(floor(u), a.W);
+  const int2 c = a.gram_cell[sl.obs];
+  const bool miss = c.x != row || c.y != col;
+  dirty[sl.obs] = miss ? 1 : 0;
+  if (miss) a.gram_cell[sl.obs] = make_int2(row, col);
+}
+
+template <typename ST, int C>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_inner_gram_packed(const InnerArgs a, const char* __restrict__ table) {
+  static_assert(C == 128 || C == 64, "feature patches");
+  __shared__ __align__(16) GramWaveLds lds;
+  const int lane = threadIdx.x, sidx = lane >> 2, sub = lane & 3;
+  const char* const ent = table + (size_t)blockIdx.x * gram_wave_bytes();
+  const GramWave* const gw = reinterpret_cast<const GramWave*>(ent);   // (indexed by lane: read where it lies, a private copy would live in scratch)
+  const GramSlot* const slots = reinterpret_cast<const GramSlot*>(ent + sizeof(GramWave));
+  const GramSlot sl = slots[sidx];                         // (slots beyond the last observation repeat it)
+  const int npts = gw->npts, L = gw->st[npts];
+  const int st1 = gw->st[1 < npts ? 1 : npts], st2 = gw->st[2 < npts ? 2 : npts], st3 = gw->st[3 < npts ? 3 : npts];
+  const bool owner = lane < npts;
+  const int64_t myp = gw->p[owner ? lane : 0];
+  const int my_b = owner ? gw->st[lane] : 0, my_e = owner ? gw->st[lane + 1] : 0;
+  const bool variable = owner && a.pt_var[myp] != 0;
+  bool active = variable, first = true;
+  const ST* arena = reinterpret_cast<const ST*>(a.arena);
+  const size_t patch_elems = (size_t)a.H * a.W * C;
+  const bool l2 = a.l2_normalize != 0;
+  const bool warm = a.gram_G != nullptr && a.gram_warm != 0;
+  const int q = sidx;
+  const bool valid = q < L;
+  const int jq = ((valid ? q : L - 1) >= st1) + ((valid ? q : L - 1) >= st2) + ((valid ? q : L - 1) >= st3);   // the point of this lane's slot
+
+  // ---- staging: cached Gram matrices (requested first, stored last: the loads return in order), observation records, d.d of the
+  //      references, owner state
+  const int hi = lane < 24 ? lane : 23;
+  double2 va0, va1, va2, va3, va4, va5, va6, va7, vb0, vb1, vb2, vb3, vb4, vb5, vb6, vb7;
+#define GW_FETCH(Q0, J, VA, VB)                                                                                       \
+  {                                                                                                                   \
+    const int64_t oi = __shfl((int)sl.obs, 4 * min(Q0 + J, L - 1));      /* (observation indices fit 31 bits) */        \
+    const double2* g = reinterpret_cast<const double2*>(a.gram_G + (size_t)oi * (IG_GDOUBLES + 16));                   \
+    VA = g[lane]; VB = g[64 + hi];                                                                                    \
+  }
+#define GW_PUT(Q0, J, VA, VB)                                                                                         \
+  if (Q0 + J < L) {                                                                                                   \
+    double2* Gd = reinterpret_cast<double2*>(lds.G[Q0 + J]);                                                          \
+    Gd[lane] = VA;                                                                                                    \
+    if (lane < 16) Gd[64 + lane] = VB;                                                                                \
+    else if (lane < 24) reinterpret_cast<double2*>(lds.D[Q0 + J])[lane - 16] = VB;                                    \
+  }
+#define GW_FETCH8(Q0) GW_FETCH(Q0, 0, va0, vb0) GW_FETCH(Q0, 1, va1, vb1) GW_FETCH(Q0, 2, va2, vb2) GW_FETCH(Q0, 3, va3, vb3) \
+                      GW_FETCH(Q0, 4, va4, vb4) GW_FETCH(Q0, 5, va5, vb5) GW_FETCH(Q0, 6, va6, vb6) GW_FETCH(Q0, 7, va7, vb7)
+#define GW_PUT8(Q0) GW_PUT(Q0, 0, va0, vb0) GW_PUT(Q0, 1, va1, vb1) GW_PUT(Q0, 2, va2, vb2) GW_PUT(Q0, 3, va3, vb3) \
+                    GW_PUT(Q0, 4, va4, vb4) GW_PUT(Q0, 5, va5, vb5) GW_PUT(Q0, 6, va6, vb6) GW_PUT(Q0, 7, va7, vb7)
+  if (warm) { GW_FETCH8(0) }
+  if (valid) {
+    double* ob = lds.obs[q];
+    const int img = sl.img, cam = sl.cam;
+    const int64_t pi = sl.patch;
+    if (sub == 0) {
+      double R[9];
+      quat_to_rotation(a.v.d_qvec + 4 * (size_t)img, R);
+#pragma unroll
+      for (int m = 0; m < 9; ++m) ob[m] = R[m];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) ob[9 + m] = a.v.d_tvec[3 * (size_t)img + m];
+    } else if (sub == 1) {
+#pragma unroll
+      for (int m = 0; m < 6; ++m) ob[12 + m] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + m];
+    } else if (sub == 2) {
+#pragma unroll
+      for (int m = 6; m < PXR_KPAD; ++m) ob[12 + m] = a.v.d_cam_params[(size_t)cam * PXR_KPAD + m];
+    } else {
+      ob[24] = a.scales[2 * pi]; ob[25] = a.scales[2 * pi + 1];
+      ob[26] = (double)a.corners[2 * pi]; ob[27] = (double)a.corners[2 * pi + 1];
+      ob[28] = (double)a.v.d_cam_model[cam]; ob[29] = (double)pi;
+      int2 cc = make_int2(-1000000, -1000000);            // the cell its Gram matrix was built for: none yet, or the cached matrix's
+      if (warm) cc = a.gram_cell[sl.obs];
+      ob[30] = (double)cc.x; ob[31] = (double)cc.y;
+    }
+  }
+  for (int j = 0; j < npts; ++j) {                         // d.d of every reference, all lanes
+    double r2 = 0.0;
+    if (a.v.d_refs)
+      for (int ch = lane; ch < C; ch += 64) { const double d = a.v.d_refs[(size_t)gw->p[j] * C + ch]; r2 = fma(d, d, r2); }
+    r2 = rows_sum<16>(row16_sum(r2));
+    if (lane == 0) lds.own[j].r2 = r2;
+  }
+  if (owner) {
+    InnerOwner& S = lds.own[lane];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { S.X[m] = a.v.d_xyz[3 * myp + m]; S.Xc[m] = S.X[m]; }
+    S.live = 1; S.radius = 1e4; S.decrease_factor = 2.0; S.invalid = 0; S.it = 0; S.reuse_diag = 0; S.mcc = 0.0;
+  }
+  if (warm) {
+    GW_PUT8(0)
+    if (L > 8) { GW_FETCH8(8) GW_PUT8(8) }
+  }
+#undef GW_FETCH
+#undef GW_PUT
+#undef GW_FETCH8
+#undef GW_PUT8
+
+  // ---- the nested LMs of the wavefront's points, one evaluation (all points) per round ----
+  while (true) {
+    __syncthreads();
+    const bool act = valid && lds.own[jq].live != 0;       // a finished point's slots skip the round
+    double* ob = lds.obs[valid ? q : L - 1];
+    double PX[2][3], u = 0.0, v = 0.0, rf = 0.0, cf = 0.0, sx = 1.0, sy = 1.0;
+    int row = 0, col = 0;
+    if (act) {
+      // WorldToPixel (base/src/projection.h:60-75) and d(x,y)/dX = d(x,y)/d(u,v) d(u,v)/dp R, on every lane of the observation
+      double R[9];
+#pragma unroll
+      for (int m = 0; m < 9; ++m) R[m] = ob[m];
+      sx = ob[24]; sy = ob[25];
+      const double cx = ob[26], cy = ob[27];
+      const int model = (int)ob[28];
+      const double X0 = lds.own[jq].Xc[0], X1 = lds.own[jq].Xc[1], X2 = lds.own[jq].Xc[2];
+      const double p0 = fma(R[0], X0, fma(R[1], X1, fma(R[2], X2, ob[9])));
+      const double p1 = fma(R[3], X0, fma(R[4], X1, fma(R[5], X2, ob[10])));
+      const double p2 = fma(R[6], X0, fma(R[7], X1, fma(R[8], X2, ob[11])));
+      const double iz = inner_rcp(p2), un = p0 * iz, vn = p1 * iz;
+      double x, y, Juv[2][2];
+      camera_model_jac<false, false>(model, ob + 12, un, vn, x, y, Juv, nullptr);   // (no extended models here: the host's routing)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const double A0 = Juv[r][0] * iz, A1 = Juv[r][1] * iz, A2 = -(Juv[r][0] * un + Juv[r][1] * vn) * iz;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) PX[r][m] = A0 * R[m] + A1 * R[3 + m] + A2 * R[6 + m];
+      }
+      u = x * sx - 0.5 - cx; v = y * sy - 0.5 - cy;        // FeaturePatch::ToPixelCoordinates (featurepatch.h:250-255)
+      rf = floor(v); cf = floor(u);
+      row = texel_index(rf, a.H); col = texel_index(cf, a.W);
+    }
+    // -- (re)build the Gram matrices of the observations whose cell moved: wave-uniform control flow, all 64 lanes --
+    const bool need = act && ((double)row != ob[30] || (double)col != ob[31]);
+    unsigned long long todo = __ballot(need);
+    if (todo != 0ull) {
+      const int64_t pi = (int64_t)ob[29];
+      const int pi_lo = (int)(pi & 0xffffffffll), pi_hi = (int)(pi >> 32);
+      const int pt_of_slot = gw->p[jq];
+      const unsigned long long rebuilt = todo;
+      // a ring of three stencils (and their references) in flight: a build's MFMA chain is shorter than the latency of its texels
+      double2 rr0 = make_double2(0.0, 0.0), rr1 = rr0, rr2 = rr0;
+      auto take = [&](GramTexels<ST, C>& tx, double2& rr) -> int {   // request the next observation's texels and reference; -1: none left
+        if (todo == 0ull) return -1;
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= ~(0xfull << (src & ~3));
+        const int row_t = __builtin_amdgcn_readlane(row, src), col_t = __builtin_amdgcn_readlane(col, src);
+        const int64_t pi_t = ((int64_t)__builtin_amdgcn_readlane(pi_hi, src) << 32) | (unsigned)__builtin_amdgcn_readlane(pi_lo, src);
+        const int pt_t = __builtin_amdgcn_readlane(pt_of_slot, src);
+        tx.load(arena + (size_t)pi_t * patch_elems, a.H, a.W, row_t, col_t);
+        if (a.v.d_refs && 2 * lane < C) rr = *reinterpret_cast<const double2*>(a.v.d_refs + (size_t)pt_t * C + 2 * lane);
+        return src;
+      };
+      auto build = [&](const GramTexels<ST, C>& tx, const double2& rr, int src) {
+        __syncthreads();                                   // (the previous build's reads of refbuf)
+        if (2 * lane < C) *reinterpret_cast<double2*>(&lds.refbuf[2 * lane]) = rr;
+        __syncthreads();
+        gram_contract<ST, C>(tx, lds.refbuf, lds.G[src >> 2], lds.D[src >> 2]);
+      };
+      GramTexels<ST, C> t0, t1, t2;
+      int s0 = take(t0, rr0), s1 = take(t1, rr1), s2 = take(t2, rr2);
+      while (true) {
+        if (s0 < 0) break;
+        build(t0, rr0, s0); s0 = take(t0, rr0);
+        if (s1 < 0) break;
+        build(t1, rr1, s1); s1 = take(t1, rr1);
+        if (s2 < 0) break;
+        build(t2, rr2, s2); s2 = take(t2, rr2);
+      }
+      if (need && sub == 0) { ob[30] = (double)row; ob[31] = (double)col; }
+      __syncthreads();                                     // the Gram matrices written by all lanes -> visible to their readers
+      if (a.gram_G) {
+        // ... and kept for the next call (and for the LM loop's evaluation, pxr_ba_gram.hip): an observation belongs to one
+        // point, a point to one wavefront -- nobody else touches these 1 408 bytes
+        unsigned long long wb = rebuilt;
+        while (wb != 0ull) {
+          const int src = __ffsll((long long)wb) - 1;
+          wb &= ~(0xfull << (src & ~3));
+          const int slot = src >> 2;
+          const int64_t oi = slots[slot].obs;
+          double2* g = reinterpret_cast<double2*>(a.gram_G + (size_t)oi * (IG_GDOUBLES + 16));
+          const double2* Gd = reinterpret_cast<const double2*>(lds.G[slot]);
+          g[lane] = Gd[lane];
+          if (lane < 16) g[64 + lane] = Gd[64 + lane];
+          else if (lane < 24) g[64 + lane] = reinterpret_cast<const double2*>(lds.D[slot])[lane - 16];
+          const int2 cl = make_int2(__builtin_amdgcn_readlane(row, src), __builtin_amdgcn_readlane(col, src));
+          if (lane == 0) a.gram_cell[oi] = cl;
+        }
+      }
+    }
+    if (act) {
+      double wu[4], dwu[4], wv[4], dwv[4];
+      catmull_rom_weights(u - cf, wu, dwu);
+      catmull_rom_weights(v - rf, wv, dwv);
+      const int R = sub;                                   // this lane's block row
+      const double wvR = pick4(wv, R), dwvR = pick4(dwv, R);
+      double Sgg = 0, Sgc = 0, Sgr = 0, Scc = 0, Scr = 0, Srr = 0;
+      const double* Gq = lds.G[q];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        const bool T = cb < R;                             // below the diagonal: the stored block (cb, R), transposed
+        const double* blk = Gq + (T ? gram_block(cb, R) : gram_block(R, cb)) * 16;
+        double e[16];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { const double2 t2 = *reinterpret_cast<const double2*>(blk + 2 * m); e[2 * m] = t2.x; e[2 * m + 1] = t2.y; }
+        // forms on the STORED block: zw[c] = sum_r wu[r] e[r][c], zd[c] = sum_r dwu[r] e[r][c]
+        double zw[4], zd[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          zw[c] = fma(wu[3], e[12 + c], fma(wu[2], e[8 + c], fma(wu[1], e[4 + c], wu[0] * e[c])));
+          zd[c] = fma(dwu[3], e[12 + c], fma(dwu[2], e[8 + c], fma(dwu[1], e[4 + c], dwu[0] * e[c])));
+        }
+        const double Bww = fma(zw[3], wu[3], fma(zw[2], wu[2], fma(zw[1], wu[1], zw[0] * wu[0])));
+        const double Bwd_s = fma(zw[3], dwu[3], fma(zw[2], dwu[2], fma(zw[1], dwu[1], zw[0] * dwu[0])));   // stored: rows wu, columns dwu
+        const double Bdw_s = fma(zd[3], wu[3], fma(zd[2], wu[2], fma(zd[1], wu[1], zd[0] * wu[0])));
+        const double Bdd = fma(zd[3], dwu[3], fma(zd[2], dwu[2], fma(zd[1], dwu[1], zd[0] * dwu[0])));
+        const double Bwd = T ? Bdw_s : Bwd_s, Bdw = T ? Bwd_s : Bdw_s;          // B(a on MY rows, b on the block's columns)
+        const double wvC = wv[cb], dwvC = dwv[cb];
+        Sgg = fma(wvR * wvC, Bww, Sgg);
+        Sgc = fma(wvR * wvC, Bwd, Sgc);
+        Sgr = fma(wvR * dwvC, Bww, Sgr);
+        Scc = fma(wvR * wvC, Bdd, Scc);
+        Scr = fma(wvR * dwvC, Bdw, Scr);
+        Srr = fma(dwvR * dwvC, Bww, Srr);
+      }
+      const double* Dq = lds.D[q] + 4 * R;
+      const double2 d01 = *reinterpret_cast<const double2*>(Dq), d23 = *reinterpret_cast<const double2*>(Dq + 2);
+      const double dw = fma(wu[3], d23.y, fma(wu[2], d23.x, fma(wu[1], d01.y, wu[0] * d01.x)));
+      const double dd = fma(dwu[3], d23.y, fma(dwu[2], d23.x, fma(dwu[1], d01.y, dwu[0] * d01.x)));
+      double Sfd = wvR * dw, Scd = wvR * dd, Srd = dwvR * dw;
+      Sgg = quad_sum(Sgg); Sgc = quad_sum(Sgc); Sgr = quad_sum(Sgr);
+      Scc = quad_sum(Scc); Scr = quad_sum(Scr); Srr = quad_sum(Srr);
+      Sfd = quad_sum(Sfd); Scd = quad_sum(Scd); Srd = quad_sum(Srd);
+      double s, gcc, gcr, grr, bc, br;
+      if (l2) {
+        const double ninv = inner_rsqrt(Sgg), n2inv = ninv * ninv;
+        const double pc = Sgc * n2inv, pr = Sgr * n2inv;
+        s = fmax(0.0, 1.0 - 2.0 * Sfd * ninv + lds.own[jq].r2);
+        gcc = (Scc - Sgc * pc) * n2inv; gcr = (Scr - Sgc * pr) * n2inv; grr = (Srr - Sgr * pr) * n2inv;
+        bc = -(Scd - Sfd * pc) * ninv; br = -(Srd - Sfd * pr) * ninv;
+      } else {          // r = f - d
+        s = fmax(0.0, Sgg - 2.0 * Sfd + lds.own[jq].r2);
+        gcc = Scc; gcr = Scr; grr = Srr; bc = Sgc - Scd; br = Sgr - Srd;
+      }
+      double rho[3];
+      inner_loss(a.loss.type, a.loss.a, s, rho);
+      double cq = 0.5 * rho[0];
+      if (a.check_bounds && !a.v.d_refs && !(u > 0.0 && u < (double)a.W && v > 0.0 && v < (double)a.H)) cq = __builtin_nan("");
+      gcc *= sx * sx; gcr *= sx * sy; grr *= sy * sy; bc *= sx; br *= sy;
+      double kappa = 0.0;   // Ceres' corrector (corrector.cc): alpha = 1 - sqrt(1 + 2 s rho'' / rho')
+      if (s != 0.0 && rho[2] > 0.0) {
+        const double Dc = 1.0 + 2.0 * s * rho[2] * inner_rcp(rho[1]);
+        const double alpha = 1.0 - sqrt(Dc);
+        kappa = (2.0 * alpha - alpha * alpha) * inner_rcp(s);
+      }
+      const double w8 = rho[1];
+      const double m00 = w8 * (gcc - kappa * bc * bc), m01 = w8 * (gcr - kappa * bc * br), m11 = w8 * (grr - kappa * br * br);
+      const double b0 = w8 * bc, b1 = w8 * br;
+      double me0[3], me1[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) { me0[m] = m00 * PX[0][m] + m01 * PX[1][m]; me1[m] = m01 * PX[0][m] + m11 * PX[1][m]; }
+      if (sub == 0) {
+        double* rs = lds.res[q];
+        rs[0] = cq;
+        rs[1] = PX[0][0] * me0[0] + PX[1][0] * me1[0];
+        rs[2] = PX[0][0] * me0[1] + PX[1][0] * me1[1];
+        rs[3] = PX[0][0] * me0[2] + PX[1][0] * me1[2];
+        rs[4] = PX[0][1] * me0[1] + PX[1][1] * me1[1];
+        rs[5] = PX[0][1] * me0[2] + PX[1][1] * me1[2];
+        rs[6] = PX[0][2] * me0[2] + PX[1][2] * me1[2];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) rs[7 + m] = PX[0][m] * b0 + PX[1][m] * b1;
+      }
+    }
+    __syncthreads();
+    // -- owners: the sum over their slots in track order, then Ceres' trust-region bookkeeping on the state in LDS --
+    double cand = 0.0, Hc[6] = {0, 0, 0, 0, 0, 0}, gc[3] = {0, 0, 0};
+    if (owner && lds.own[lane].live != 0) {
+      for (int slq = my_b; slq < my_e; ++slq) {
+        const double* rs = lds.res[slq];
+        cand += rs[0];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) Hc[m] += rs[1 + m];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) gc[m] += rs[7 + m];
+      }
+    }
+    if (owner) inner_owner_update(lds.own[lane], cand, Hc, gc, first, my_e > my_b, active, a.cost_before, a.cost_pt ? a.cost_pt + myp : nullptr);
+    first = false;
+    if (__ballot(active) == 0) break;
+  }
+  if (variable) {
+    const InnerOwner& S = lds.own[lane];
+    a.xyz_out[3 * myp] = S.X[0]; a.xyz_out[3 * myp + 1] = S.X[1]; a.xyz_out[3 * myp + 2] = S.X[2];
+  }
+}
+
 // Enqueue the inner iterations on the candidate parameters `view` (xyz refined in place);
 // *d_cost_before (device double, caller-zeroed) receives the cost at the unrefined candidate.
 // lists (may be NULL): the points with at most IG_MAXO observations (Gram-matrix kernel) and the others (packed kernel), made
@@ -1104,6 +1482,8 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
 #define INNER_GRAM(ST, CC, NBLK, MAXO)                                                                                    \
   hipLaunchKernelGGL((k_inner_gram<ST, CC>), dim3(NBLK), dim3(64), sizeof(double) * gram_lds_doubles(MAXO, CC), ctx->stream, a, \
                      static_cast<const char*>(lists->d_slots), MAXO)
+#define INNER_GRAM_PACKED(ST, CC, NBLK) \
+  hipLaunchKernelGGL((k_inner_gram_packed<ST, CC>), dim3(NBLK), dim3(64), 0, ctx->stream, a, static_cast<const char*>(lists->d_waves))
   if (arena->C <= 4) {
     if (arena->dtype == PXR_F16 && arena->C == 3) INNER_LAUNCH(k_inner_points, _Float16, 3);
     else if (arena->dtype == PXR_F16) INNER_LAUNCH(k_inner_points, _Float16, 1);
@@ -1130,7 +1510,21 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     } else {
       // Gram-matrix kernel for the points whose observations' Gram matrices fit a wavefront's LDS, packed kernel (one point per
       // wavefront) for the long tracks
-      if (lists->n_short > 0) INNER_BY_STORAGE(INNER_GRAM, (unsigned)lists->n_short, lists->maxo_short);
+      // short tracks: up to four points (sixteen observation slots) per wavefront in lockstep; PXR_INNER_GRAM1=1 is the A/B knob
+      // for the one-point-per-wavefront kernel
+      if (lists->n_waves > 0) {
+        if (gram && !getenv("PXR_INNER_NO_PREBUILD")) {
+          // the matrices the kernel will find stale are rebuilt before it starts (k_gram_flag_slots); after that the cache is warm
+          PXR_HIP(hipMemsetAsync(gram->list, 0, sizeof(int) * (size_t)view->n_obs, ctx->stream));
+          const int64_t n_thr = lists->n_waves * GW_SLOTS;
+          hipLaunchKernelGGL(k_gram_flag_slots, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, ctx->stream, a, static_cast<const char*>(lists->d_waves),
+                             lists->n_waves, gram->list);
+          if (int rc = gram_build_flagged(ctx, arena, view, *gram)) return rc;
+          a.gram_warm = 1;
+        }
+        INNER_BY_STORAGE(INNER_GRAM_PACKED, (unsigned)lists->n_waves);
+      }
+      else if (lists->n_short > 0 && lists->d_slots) INNER_BY_STORAGE(INNER_GRAM, (unsigned)lists->n_short, lists->maxo_short);
       if (lists->n_long > 0) INNER_BY_STORAGE(INNER_PACKED, (unsigned)lists->n_long, 1, lists->d_long);
     }
   } else if (arena->dtype == PXR_F64 && arena->C == 128) INNER_LAUNCH(k_inner_points, double, 128);
@@ -1138,23 +1532,40 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
 #undef INNER_LAUNCH
 #undef INNER_PACKED
 #undef INNER_GRAM
+#undef INNER_GRAM_PACKED
 #undef INNER_BY_STORAGE
   return hip_check(hipGetLastError(), "k_inner_points launch");
 }
 
 // The host's split of the points for the inner iterations: track lengths from the CSR of the point-ordered observation list.
-int make_inner_lists(hipStream_t st, const std::vector<int64_t>& pt_ptr, const pxr_ba_view* view, const int64_t* d_pt_obs, InnerLists* out) {
+int make_inner_lists(hipStream_t st, const std::vector<int64_t>& pt_ptr, const pxr_ba_view* view, const int64_t* d_pt_ptr, const int64_t* d_pt_obs,
+                     InnerLists* out) {
+  const bool one_point_kernel = getenv("PXR_INNER_GRAM1") != nullptr;      // (A/B knob: k_inner_gram's tables instead of the packed kernel's)
   std::vector<GramPoint> shorts;
+  std::vector<GramWave> waves;
   std::vector<int> longs;
   int maxo = 1;
   const int64_t n = (int64_t)pt_ptr.size() - 1;
+  const int max_pts = getenv("PXR_INNER_GRAM_PPW") ? std::max(1, std::min(IP_MAXPTS, atoi(getenv("PXR_INNER_GRAM_PPW")))) : IP_MAXPTS;   // (A/B knob)
+  if (one_point_kernel) shorts.reserve((size_t)n); else waves.reserve((size_t)n / 2 + 1);
+  int64_t n_short = 0;
+  GramWave cur{};                                           // consecutive short points are packed: <= 4 points, <= 16 observations
+  auto flush = [&]() { if (cur.npts > 0) waves.push_back(cur); cur = GramWave{}; };
   for (int64_t p = 0; p < n; ++p) {
     const int64_t len = pt_ptr[p + 1] - pt_ptr[p];
     if (len <= 0) continue;
-    if (len <= IG_MAXO) { shorts.push_back(GramPoint{(int)p, (int)len, pt_ptr[p]}); maxo = std::max(maxo, (int)len); }
-    else longs.push_back((int)p);
+    if (len <= IG_MAXO) {
+      ++n_short; maxo = std::max(maxo, (int)len);
+      if (one_point_kernel) { shorts.push_back(GramPoint{(int)p, (int)len, pt_ptr[p]}); continue; }
+      if (cur.npts == max_pts || cur.st[cur.npts] + (int)len > GW_SLOTS) flush();
+      cur.p[cur.npts] = (int)p;
+      cur.st[cur.npts + 1] = cur.st[cur.npts] + (int)len;
+      ++cur.npts;
+    } else longs.push_back((int)p);
   }
-  out->n_short = (int64_t)shorts.size(); out->n_long = (int64_t)longs.size(); out->maxo_short = maxo;
+  flush();
+  out->n_waves = (int64_t)waves.size(); out->d_waves = nullptr; out->d_wave_heads = nullptr;
+  out->n_short = n_short; out->n_long = (int64_t)longs.size(); out->maxo_short = maxo;
   out->d_short = nullptr; out->d_long = nullptr; out->d_slots = nullptr;
   if (!shorts.empty()) {
     if (int rc = hip_check(hipMalloc(&out->d_short, sizeof(GramPoint) * shorts.size()), "hipMalloc(inner lists)")) return rc;
@@ -1164,6 +1575,17 @@ int make_inner_lists(hipStream_t st, const std::vector<int64_t>& pt_ptr, const p
     hipLaunchKernelGGL(k_gram_table, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, st, (int64_t)shorts.size(), maxo,
                        static_cast<const GramPoint*>(out->d_short), d_pt_obs, view->d_obs_image, view->d_obs_patch, view->d_image_camera,
                        static_cast<char*>(out->d_slots));
+  }
+  if (!waves.empty()) {      // one allocation: the headers as the host packed them, then the table the kernel reads
+    const size_t heads = (sizeof(GramWave) * waves.size() + 255) & ~(size_t)255;
+    char* d_all = nullptr;
+    if (int rc = hip_check(hipMalloc((void**)&d_all, heads + gram_wave_bytes() * waves.size()), "hipMalloc(inner wave table)")) return rc;
+    out->d_wave_heads = d_all; out->d_waves = d_all + heads;
+    if (int rc = hip_check(hipMemcpyAsync(d_all, waves.data(), sizeof(GramWave) * waves.size(), hipMemcpyHostToDevice, st), "H2D")) return rc;
+    const int64_t n_thr2 = (int64_t)waves.size() * (GW_SLOTS + 1);
+    hipLaunchKernelGGL(k_gram_wave_table, dim3((unsigned)((n_thr2 + 255) / 256)), dim3(256), 0, st, (int64_t)waves.size(),
+                       reinterpret_cast<const GramWave*>(d_all), d_pt_ptr, d_pt_obs, view->d_obs_image, view->d_obs_patch, view->d_image_camera,
+                       static_cast<char*>(out->d_waves));
   }
   if (!longs.empty()) {
     if (int rc = hip_check(hipMalloc((void**)&out->d_long, sizeof(int) * longs.size()), "hipMalloc(inner lists)")) return rc;
@@ -1175,7 +1597,8 @@ void free_inner_lists(InnerLists* l) {
   if (l->d_short) (void)hipFree(l->d_short);
   if (l->d_long) (void)hipFree(l->d_long);
   if (l->d_slots) (void)hipFree(l->d_slots);
-  l->d_short = nullptr; l->d_long = nullptr; l->d_slots = nullptr;
+  if (l->d_wave_heads) (void)hipFree(l->d_wave_heads);      // (d_waves lies inside it)
+  l->d_short = nullptr; l->d_long = nullptr; l->d_slots = nullptr; l->d_waves = nullptr; l->d_wave_heads = nullptr;
 }
 
 }  // namespace pxr

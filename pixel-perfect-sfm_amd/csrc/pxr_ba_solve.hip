@@ -856,7 +856,8 @@ int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
                             const pxr_loss* loss, const int64_t* d_pt_ptr, const int64_t* d_pt_obs,
                             const int* d_pt_var, double* d_cost_before, const InnerLists* lists, double* d_cost_per_point,
                             const GramCache* gram, bool gram_warm);
-int make_inner_lists(hipStream_t st, const std::vector<int64_t>& pt_ptr, const pxr_ba_view* view, const int64_t* d_pt_obs, InnerLists* out);
+int make_inner_lists(hipStream_t st, const std::vector<int64_t>& pt_ptr, const pxr_ba_view* view, const int64_t* d_pt_ptr, const int64_t* d_pt_obs,
+                     InnerLists* out);
 void free_inner_lists(InnerLists* l);
 
 static inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
@@ -1236,6 +1237,9 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     return PXR_OK;
   };
 
+  // the inner iterations' tables (a pass over the points on the host, two small uploads): set-up, like the observation lists
+  struct InnerListsOwner { InnerLists l; ~InnerListsOwner() { free_inner_lists(&l); } } inner_lists;
+  if (gram_inner) RC(make_inner_lists(st, pt_cnt, view, d_pt_ptr.p, d_pt_obs.p, &inner_lists.l));     // (pt_cnt holds the prefix sums by now)
   const auto t_loop0 = std::chrono::steady_clock::now();
   sum->setup_ms = std::chrono::duration<double, std::milli>(t_loop0 - t_setup0).count();
   sum->num_camera_unknowns = n_c; sum->num_point_unknowns = 3 * n_pvar;
@@ -1302,8 +1306,6 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   int invalid = 0;
   bool reuse_diag = false;
   bool inner_enabled = opt->use_inner_iterations != 0, inner_useful = false;
-  struct InnerListsOwner { InnerLists l; ~InnerListsOwner() { free_inner_lists(&l); } } inner_lists;
-  if (gram_inner) RC(make_inner_lists(st, pt_cnt, view, d_pt_obs.p, &inner_lists.l));     // (pt_cnt holds the prefix sums by now)
   // ceres::IterationCallback (pxr_set_iteration_callback): 1 = SOLVER_ABORT, 2 = SOLVER_TERMINATE_SUCCESSFULLY
   // Several ranks: a callback installed on SOME ranks only (rank 0 logging, say) must not put the ranks' collectives out of
   // step -- whether any rank has one is agreed on once here; if so, every rank joins the per-iteration exchange of answers

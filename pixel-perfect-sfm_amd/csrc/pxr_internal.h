@@ -62,6 +62,8 @@ struct InnerLists {
   void* d_short = nullptr; int64_t n_short = 0; int maxo_short = 1;  // points with 1 .. 16 observations (Gram-matrix kernel): {point, length, first slot}
   int* d_long = nullptr; int64_t n_long = 0;                          // the others (packed kernel, one point per wavefront)
   void* d_slots = nullptr;                                            // the Gram-matrix kernel's table: per listed point {point, length, first slot} + {image, camera, patch, observation} x maxo_short
+  void* d_waves = nullptr; int64_t n_waves = 0;                       // the packed Gram-matrix kernel's table: per wavefront {<= 4 points, first slots} + 16 observation slots
+  void* d_wave_heads = nullptr;
 };
 // pxr_ba_gram.hip: the per-observation Gram matrices of one solve (storage owned by the context)
 struct GramCache {
@@ -71,6 +73,8 @@ bool gram_eval_supported(const pxr_arena* arena, const pxr_ba_view* view);
 int gram_eval_prepare(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, GramCache* out);
 // the records of pxr_ba_eval(with_jacobian = 1) at the parameters of `v`, from the cache (rebuilding what moved to another cell)
 int gram_evaluate(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v, const pxr_interp_cfg* cfg, const GramCache& gc, double* rec);
+// rebuild the matrices of the observations flagged in gc.list (1: rebuild; the caller also updated gc.cell)
+int gram_build_flagged(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v, const GramCache& gc);
 }  // namespace pxr
 
 #define PXR_HIP(call)                                        \

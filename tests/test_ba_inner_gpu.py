@@ -35,7 +35,15 @@ def test_inner_iterations_match_oracle(ctx, obs_per_point, pt_sigma):
         # the nested LMs stop on Ceres' default tolerances (1e-6 relative cost change): a borderline decision may
         # differ by one inner iteration between the two implementations -> compare at north_star's 1e-4
         assert abs(s["final_cost"] - so["final_cost"]) < 1e-4 * max(so["final_cost"], 1e-9)
-        assert np.abs(q - qo).max() < 1e-4 and np.abs(t - to).max() < 1e-4 and np.abs(X - Xo).max() < 1e-4
+        assert np.abs(q - qo).max() < 1e-4 and np.abs(t - to).max() < 1e-4
+        # Points: 1e-4 -- except a point that ran away (three observations, a robust loss: seed 53 sends point 17 from inside the
+        # unit cube to y = -15.8, where it projects 1 700 pixels outside its 16 x 16 patches).  There the interpolation is
+        # clamped at the patch border: the cost no longer depends on the position, every solver leaves such a point wherever
+        # its last step put it (run to run by 5e-3 with floating-point atomics in the outer loop).  Both solvers must lose the
+        # SAME points; the costs above already agree.
+        inside = np.abs(Xo).max(axis=1) < 3.0
+        assert np.array_equal(inside, np.abs(X).max(axis=1) < 3.0) and inside.sum() >= len(Xo) - 2
+        assert np.abs(X - Xo)[inside].max() < 1e-4
         assert np.array_equal(X[::9], prob["xyz"][::9])
     # with inner iterations the first step already lands lower than without
     arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
@@ -145,8 +153,8 @@ def _ragged_scene(seed, channels, dtype, n_cams=24):
 @pytest.mark.parametrize("dtype,channels,l2,loss", [(np.float16, 128, True, "cauchy"), (np.float32, 64, True, "huber"),
                                                     (np.float16, 64, False, "trivial"), (np.float32, 128, False, "cauchy")])
 def test_gram_matrix_kernel_equals_the_interpolating_kernel(ctx, monkeypatch, dtype, channels, l2, loss):
-    """The inner iterations on the stencils' Gram matrices (k_inner_gram: nine channel sums as quadratic forms in the
-    Catmull-Rom weights, fp64 MFMA) against the kernel that interpolates the descriptor at every round (k_inner_packed,
+    """The inner iterations on the stencils' Gram matrices (k_inner_gram_packed / k_inner_gram: nine channel sums as quadratic forms
+    in the Catmull-Rom weights, fp64 MFMA) against the kernel that interpolates the descriptor at every round (k_inner_packed,
     PXR_INNER_PACKED=1): same outer trajectory, refined parameters equal far inside the nested LM's own 1e-6 tolerances, on
     tracks of 2 .. 22 observations with texel-sized initial errors."""
     from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
@@ -154,8 +162,11 @@ def test_gram_matrix_kernel_equals_the_interpolating_kernel(ctx, monkeypatch, dt
     assert lengths.max() > 16 and lengths.min() <= 3
     gauge = _gauge(prob)
     out = {}
-    for mode in ("gram", "packed"):
+    for mode in ("gram", "gram1", "packed"):
+        if mode == "gram1":          # one point per wavefront, eight lanes per observation (k_inner_gram) instead of up to four points
+            monkeypatch.setenv("PXR_INNER_GRAM1", "1")               # in lockstep on four lanes per observation (k_inner_gram_packed)
         if mode == "packed":
+            monkeypatch.delenv("PXR_INNER_GRAM1")
             monkeypatch.setenv("PXR_INNER_PACKED", "1")
         arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
         ba = BAProblem(ctx, arena, prob)
@@ -169,5 +180,11 @@ def test_gram_matrix_kernel_equals_the_interpolating_kernel(ctx, monkeypatch, dt
     assert abs(sg["final_cost"] - sp["final_cost"]) < 2e-6 * sp["final_cost"]
     for a, b in zip(pg, pp):
         assert (np.abs(a - b) <= 2e-6 * np.maximum(1.0, np.abs(b))).all()
+    # the two Gram-matrix kernels do the same algebra in another order of additions
+    s1, p1 = out["gram1"]
+    assert s1["iterations"] == sg["iterations"] and s1["num_successful"] == sg["num_successful"]
+    assert abs(s1["final_cost"] - sg["final_cost"]) < 1e-8 * sg["final_cost"]
+    for a, b in zip(p1, pg):
+        assert (np.abs(a - b) <= 1e-7 * np.maximum(1.0, np.abs(b))).all()
     # the first iteration's refinement really moved the points (the kernels did run)
     assert np.abs(pg[3] - prob["xyz"]).max() > 1e-4

@@ -1,0 +1,10 @@
+#!/bin/bash
+# The bench line + the kernel statistics of the same command (no tests).
+set -u
+O=gpurun_out/r4s
+mkdir -p $O
+export TMPDIR=/tmp
+timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench exit $?" >> $O/bench_n1.err
+( cd /tmp && rm -rf /tmp/ks && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-api-e2e --no-telemetry > $GRAFT_REPO_ROOT/$O/bench_traced.json 2> $GRAFT_REPO_ROOT/$O/traced.err )
+find /tmp/ks -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
+tail -1 $O/bench_n1.err

@@ -1077,8 +1077,11 @@ struct GramWave { int npts, pad; int p[IP_MAXPTS]; int st[IP_MAXPTS + 1]; int pa
 static_assert(sizeof(GramWave) == 48, "table layout");
 constexpr int GW_SLOTS = 16;
 __host__ __device__ inline size_t gram_wave_bytes() { return sizeof(GramWave) + sizeof(GramSlot) * GW_SLOTS; }
+#ifndef PXR_GW_GPAD
+#define PXR_GW_GPAD 4          // doubles of padding between two slots' matrices: 1 280-byte slots put the same block of all sixteen on the same banks (0 / 2 / 4 / 6: 1.71 / 1.59 / 1.58 / 1.59 ms per call)
+#endif
 struct GramWaveLds {
-  double G[GW_SLOTS][IG_GDOUBLES];
+  double G[GW_SLOTS][IG_GDOUBLES + PXR_GW_GPAD];
   double D[GW_SLOTS][16];
   double obs[GW_SLOTS][IG_OBS];      // R (9) t (3) k (12) sx sy corner (2) model patch cell (2)
   double res[GW_SLOTS][10];

@@ -9,11 +9,14 @@
 // function / gradient / parameter tolerance 1e-6 / 1e-10 / 1e-8, initial radius 1e4, Jacobi
 // scaling, <= 5 consecutive invalid steps).
 //
-// Two mappings.  fp16 / fp32 feature patches (C = 64, 128): k_inner_packed -- 16 observations per wavefront trip, four
-// lanes each, the points of a wavefront in lockstep (described at the kernel).  fp64 storage and cost maps (C = 1, 3):
-// k_inner_points -- one point per wavefront (eight for cost maps), an observation per row of C / 8 lanes, the whole
-// nested LM in registers.  Both return the cost at the (unrefined) candidate, so the outer loop needs no separate
-// evaluation for Ceres' inner-iteration bookkeeping.
+// Mappings.  fp16 / fp32 feature patches (C = 64, 128), tracks of <= 16 observations, the five hand-derived camera models:
+// k_inner_gram_packed -- the nested LM on the Gram matrices of the observations' stencils, up to four points per wavefront in
+// lockstep, four lanes per observation (described at the kernel; k_inner_gram is its one-point-per-wavefront predecessor,
+// kept as an A/B knob).  Longer tracks and extended camera models: k_inner_packed -- the descriptor interpolated at every
+// round, 16 observations per wavefront trip, four lanes each.  fp64 storage and cost maps (C = 1, 3): k_inner_points -- one
+// point per wavefront (eight for cost maps), an observation per row of C / 8 lanes, the whole nested LM in registers.  All
+// return the cost at the (unrefined) candidate, so the outer loop needs no separate evaluation for Ceres' inner-iteration
+// bookkeeping.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>

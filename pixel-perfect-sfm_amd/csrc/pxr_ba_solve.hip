@@ -220,6 +220,39 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
   // coalesced, independent loads -- consecutive lanes read consecutive doubles of a record -- and
   // every thread then accumulates its matrix entry from LDS.  (A per-thread gather loop over the
   // observations was bound by the latency of its dependent loads.)
+  // (the next batch's records are requested into registers before the current batch is consumed: a load -> LDS -> accumulate
+  // loop exposed the gather's latency once per batch)
+  constexpr int IMG_PF = 16;                   // doubles per thread and batch: IMG_BATCH * LS <= 256 * IMG_PF (LS <= 32)
+  double pf[IMG_PF];
+  auto request = [&](int64_t base) {
+    const int nb = (int)min((int64_t)IMG_BATCH, ch.end - base);
+#pragma unroll
+    for (int j = 0; j < IMG_PF; ++j) {
+      const int x = threadIdx.x + 256 * j;
+      const int xc = min(x, nb * LS - 1);
+      const int o = xc / LS, f = xc - o * LS;
+      pf[j] = L[(size_t)img_obs[base + o] * LS + f];
+    }
+  };
+  if (LS <= 2 * IMG_PF) {
+    if (ch.begin < ch.end) request(ch.begin);
+    for (int64_t base = ch.begin; base < ch.end; base += IMG_BATCH) {
+      const int nb = (int)min((int64_t)IMG_BATCH, ch.end - base);
+#pragma unroll
+      for (int j = 0; j < IMG_PF; ++j) { const int x = threadIdx.x + 256 * j; if (x < nb * LS) stage[x] = pf[j]; }
+      __syncthreads();
+      if (base + IMG_BATCH < ch.end) request(base + IMG_BATCH);
+      if (sl < slices) {
+        for (int o = sl; o < nb; o += slices) {
+          const double* Lo = stage + (size_t)o * LS;
+          const double* B0 = Lo + 11; const double* B1 = B0 + d.DC;
+          if (is_g) acc += B0[a] * Lo[3] + B1[a] * Lo[4];
+          else acc += B0[a] * (Lo[0] * B0[b] + Lo[1] * B1[b]) + B1[a] * (Lo[1] * B0[b] + Lo[2] * B1[b]);
+        }
+      }
+      __syncthreads();
+    }
+  } else {
   for (int64_t base = ch.begin; base < ch.end; base += IMG_BATCH) {
     const int nb = (int)min((int64_t)IMG_BATCH, ch.end - base);
     for (int x = threadIdx.x; x < nb * LS; x += 256) {
@@ -236,6 +269,7 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
       }
     }
     __syncthreads();
+  }
   }
   red[threadIdx.x] = acc;
   __syncthreads();

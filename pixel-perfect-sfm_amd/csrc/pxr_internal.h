@@ -67,7 +67,12 @@ struct InnerLists {
 };
 // pxr_ba_gram.hip: the per-observation Gram matrices of one solve (storage owned by the context)
 struct GramCache {
-  double* G = nullptr; void* cell = nullptr; int* list = nullptr; int* count = nullptr; double* r2 = nullptr; int64_t n_obs = 0;
+  double* G = nullptr;       // [n_obs][176]: ten 4 x 4 blocks of the upper triangle of G = T T^t, then D = T ref
+  void* cell = nullptr;      // [n_obs] int2 (row, col): the 4 x 4 cell the observation's matrices were built for
+  int* list = nullptr;       // [n_obs] flags: 1 = the projection left that cell, rebuild (k_gram_eval / k_gram_flag_slots set them)
+  int* count = nullptr;      // one counter (pxr_ba_eval_gram's h_rebuilt)
+  double* r2 = nullptr;      // [n_points] d.d of the reference descriptors
+  int64_t n_obs = 0;
 };
 bool gram_eval_supported(const pxr_arena* arena, const pxr_ba_view* view);
 int gram_eval_prepare(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, GramCache* out);

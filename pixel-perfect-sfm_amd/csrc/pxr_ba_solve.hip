@@ -359,6 +359,7 @@ __global__ __launch_bounds__(1024) void k_schur_lds(const SolveDev d, const ImgC
   if (dci == 0) return;
   const int c0 = blockIdx.y * CT, c1 = min(d.n_c, c0 + CT);
   double* racc = acc + (size_t)d.DC * CT;
+  double* ybuf = racc + d.DC;                  // [blockDim.x][3]: the rows of Y_i, handed round the lane group through LDS
   for (int e = threadIdx.x; e < dci * CT + d.DC; e += blockDim.x) {
     if (e < dci * CT) acc[(e / CT) * CT + (e % CT)] = 0.0; else racc[e - dci * CT] = 0.0;
   }
@@ -370,7 +371,6 @@ __global__ __launch_bounds__(1024) void k_schur_lds(const SolveDev d, const ImgC
   // LDS tile.  The host flattens obs -> point -> partner list -> column descriptors into three
   // levels of loads (so[], then pj / pcols / W_i / T / gp, then W_j).
   const int lane_b = threadIdx.x % G, grp = threadIdx.x / G, n_grp = blockDim.x / G;
-  const int gbase = (threadIdx.x & 63) - lane_b;          // first lane of this group inside the wavefront
   int rrow[G];                                             // global row of Y_i row a (same for every observation of the image)
 #pragma unroll
   for (int a = 0; a < G; ++a) rrow[a] = a < dci ? col_index(d, img, cam, a) : 0x7fffffff;
@@ -422,12 +422,18 @@ __global__ __launch_bounds__(1024) void k_schur_lds(const SolveDev d, const ImgC
         if (kb == 0) {     // -- Y_i row (from link 1) and the right-hand side, while the partners' rows are on their way
           if (row_ok) { y0 = w0 * t0 + w1 * t1 + w2 * t2; y1 = w0 * t1 + w1 * t3 + w2 * t4; y2 = w0 * t2 + w1 * t4 + w2 * t5; }
           if (first_tile && row_ok) accum_add(racc + lane_b, -(y0 * g0 + y1 * g1 + y2 * g2), det_scale);
+          // (a wavefront's LDS operations execute in order: the group's reads below see these writes, and the next
+          // observation's writes come after this one's reads)
+          double* yb = ybuf + 3 * (size_t)threadIdx.x;
+          yb[0] = y0; yb[1] = y1; yb[2] = y2;
         }
-        // row a of Y_i comes round the group (three shuffles) and meets every partner's row: the 24 values of all rows at
-        // once were 48 registers next to the 48 of the partners' rows
+        // row a of Y_i comes round the group through LDS (three broadcast reads: all lanes of the group read one address; as
+        // 64-bit shuffles they were six ds_bpermute per row) and meets every partner's row: the 24 values of all rows at once
+        // were 48 registers next to the 48 of the partners' rows
+        const double* yg = ybuf + 3 * (size_t)(threadIdx.x - lane_b);
 #pragma unroll
         for (int a = 0; a < G; ++a) {
-          const double ya0 = __shfl(y0, gbase + a), ya1 = __shfl(y1, gbase + a), ya2 = __shfl(y2, gbase + a);
+          const double ya0 = yg[3 * a], ya1 = yg[3 * a + 1], ya2 = yg[3 * a + 2];
 #pragma unroll
           for (int u = 0; u < PB; ++u) {
             const int c = col[u];
@@ -1283,7 +1289,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   int CT = n_c > 0 ? std::min(n_c, (int)((128 * 1024 / 8 - DC) / DC)) : 1;
   const int n_ctiles = n_c > 0 ? (n_c + CT - 1) / CT : 1;
   CT = n_c > 0 ? (n_c + n_ctiles - 1) / n_ctiles : 1;       // balance the tiles
-  const size_t schur_shmem = sizeof(double) * ((size_t)DC * CT + DC);
+  const size_t schur_shmem = sizeof(double) * ((size_t)DC * CT + DC + 3 * 1024);   // tile, right-hand side, the lane groups' Y rows
   if (use_lds_schur && n_c > 0)
     PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(DC <= 8 ? k_schur_lds<8> : (DC <= 16 ? k_schur_lds<16> : k_schur_lds<32>)),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_shmem));

@@ -552,13 +552,26 @@ __global__ __launch_bounds__(256) void k_backsub(const SolveDev d, const int64_t
   const bool var = live && d.pt_var[p];
   double v0 = 0.0, v1 = 0.0, v2 = 0.0;
   if (var) {
-    for (int64_t o = pt_ptr[p]; o < pt_ptr[p + 1]; ++o) {
-      const int4 ci = pcols[o];                         // {pose_off, pose_dim, intr_off, intr_dim} of the observation pj[o]
-      if (lane_a < ci.y + ci.w) {
-        const double* Wi = W + ((size_t)pj[o] * d.DC + lane_a) * 3;
-        const double dcv = delta_c[lane_a < ci.y ? ci.x + lane_a : ci.z + (lane_a - ci.y)];
-        v0 += Wi[0] * dcv; v1 += Wi[1] * dcv; v2 += Wi[2] * dcv;
+    // four observations per trip: their descriptors first, then every W row and camera-step entry they address, at clamped
+    // indices (one observation per trip was a chain of two dependent gathers per observation); the additions keep the track's order
+    const int64_t o_end = pt_ptr[p + 1];
+    for (int64_t o = pt_ptr[p]; o < o_end; o += 4) {
+      int4 ci[4];                                        // {pose_off, pose_dim, intr_off, intr_dim} of the observation pj[.]
+      int jj[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int64_t idx = min(o + u, o_end - 1); ci[u] = pcols[idx]; jj[u] = pj[idx]; }
+      double w[4][3], dcv[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ok[u] = o + u < o_end && lane_a < ci[u].y + ci[u].w;
+        const double* Wi = W + ((size_t)jj[u] * d.DC + (ok[u] ? lane_a : 0)) * 3;
+        w[u][0] = Wi[0]; w[u][1] = Wi[1]; w[u][2] = Wi[2];
+        dcv[u] = delta_c[ok[u] ? (lane_a < ci[u].y ? ci[u].x + lane_a : ci[u].z + (lane_a - ci[u].y)) : 0];
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u]) { v0 += w[u][0] * dcv[u]; v1 += w[u][1] * dcv[u]; v2 += w[u][2] * dcv[u]; }
     }
   }
 #pragma unroll

@@ -496,8 +496,9 @@ class BAProblem:
                                             self.rec.ptr, C.byref(built) if sync else None), "pxr_ba_eval_gram")
         return self.rec, (built.value if sync else None)
 
-    def projection_jacobian(self):
-        P = self.ctx.empty((self.n_obs, 2, 10 + KPAD), np.float64)
+    def projection_jacobian(self, out=None):
+        """The 2 x (10+K) projection Jacobian P of every observation (k_jac); `out` re-uses a device array."""
+        P = out if out is not None else self.ctx.empty((self.n_obs, 2, 10 + KPAD), np.float64)
         check(self.ctx.lib.pxr_ba_projection_jacobian(self.ctx.handle, C.byref(self.view), P.ptr),
               "pxr_ba_projection_jacobian")
         return P

@@ -51,3 +51,40 @@ def test_under_torchrun_the_process_is_a_rank_not_a_launcher():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", PXR_BENCH_SELFTEST="")
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--no-ka"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+def _newest_full_result():
+    """The newest committed FULL bench result (profiles/r*_bench_detail.json, or round 4's one-line record)."""
+    import glob
+    import re
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_bench_detail.json")) + [os.path.join(ROOT, "profiles", "r4_bench_n1.json")]:
+        m = re.match(r"r(\d+)_", os.path.basename(path))
+        if m and os.path.exists(path) and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), path)
+    with open(best[1]) as fh:
+        return json.load(fh)
+
+
+def test_the_printed_line_fits_the_drivers_tail_and_ends_with_metric_2():
+    """the 14.9 KB line overflowed the driver's tail, so LM iterations/s (the second half of BASELINE's
+    metric) and the clocks were invisible.  The line is now the compact form of bench_detail.json: < 6000 bytes, with
+    `telemetry`, `lm_no_inner` and `lm` LAST (inside the final 2 KB that even the shortest tail keeps)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = _newest_full_result()
+    full["detail_file"] = "/root/repo/bench_detail.json"
+    line = json.dumps(bench.compact_line(full), separators=(",", ":"))
+    assert len(line) < bench.LINE_BUDGET_BYTES, len(line)
+    back = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in back, k
+    assert back["value"] == float("%.7g" % full["value"])
+    assert set(back["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(back["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    tail = line[-2000:]
+    assert '"lm":{' in tail and '"lm_no_inner":{' in tail and '"ms_per_iter"' in tail
+    assert '"telemetry":{' in line[-4000:]
+    assert list(back)[-1] == "lm" and list(back)[-2] == "lm_no_inner"
+    assert back["lm"]["ms_per_iter"] == float("%.5g" % full["lm"]["ms_per_iter"])
+    assert "ka" in back and "kernel_ms" in back["ka"]["solve"] and "frac" in back["ka"]["roofline"]

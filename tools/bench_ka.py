@@ -98,7 +98,7 @@ def cpu_legs_on_sample(prob, patches, dev):
     return out
 
 
-def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, world=1, cpu_legs=False):
+def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, world=1, cpu_legs=False, telemetry=None, solves=8):
     """Runs the KA benchmark and returns its result dict (bench.py attaches it as "ka").
     world > 1 (torch.distributed initialised by the caller): STRONG scaling of BASELINE configs[1] -- the sub-problems
     are dealt to the ranks (parallel.shard_ka_problem, SURVEY 8e: no collective during the solve), every rank times its
@@ -152,9 +152,26 @@ def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, 
     ctx.sync()
     if world > 1:
         dist.barrier()
-    t0 = time.perf_counter()
-    total, _ = ka.solve(cfg, ls, bound=4.0)
-    wall = slowest(time.perf_counter() - t0)
+    # `solves` whole solves from the same initial keypoints, back to back (a single 5 ms launch says more about the clock the
+    # GPU happened to idle at than about the kernel); the shader clock / power are sampled over the loop when asked for
+    kp_init = np.ascontiguousarray(prob["kp"], dtype=np.float64)
+    runs, walls = [], []
+
+    def loop():
+        for _ in range(max(1, solves)):
+            ka.d["kp"].upload(kp_init)
+            ctx.sync()
+            t0 = time.perf_counter()
+            s, _ = ka.solve(cfg, ls, bound=4.0)
+            walls.append(time.perf_counter() - t0)
+            runs.append(s)
+    tel = telemetry.sample_while(loop, interval=0.002) if (telemetry is not None and rank == 0) else (loop() or None)
+    total = dict(runs[-1])
+    kms = [r["total_ms"] - r["setup_ms"] for r in runs]
+    total_kernel_first, total_kernel_min = kms[0], min(kms)
+    total["total_ms"] = float(np.mean([r["total_ms"] for r in runs]))
+    total["setup_ms"] = float(np.mean([r["setup_ms"] for r in runs]))
+    wall = slowest(float(np.mean(walls)))
     kp = ka.keypoints()
     n_edges_total, n_problems_total = int(summed(ka.n_edges)), int(summed(ka.n_problems))
     gather_ms = 0.0
@@ -182,7 +199,9 @@ def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, 
            "edge_eval": {"edges_per_s": n_edges_total / (ms * 1e-3), "kernel_ms": ms,
                          "algorithmic_GBps": 8244 * n_edges_total / (ms * 1e-3) / 1e9},
            "solve": {"wall_ms": wall * 1e3, "first_call_ms": cold["total_ms"], "total_ms": total["total_ms"],
-                     "kernel_ms": total["total_ms"] - total["setup_ms"], "lm_iterations_max": total["iterations"],
+                     "kernel_ms": total["total_ms"] - total["setup_ms"], "kernel_ms_min": slowest(total_kernel_min),
+                     "kernel_ms_first": slowest(total_kernel_first), "solves_timed": len(runs),
+                     "lm_iterations_max": total["iterations"],
                      "successful_steps": total["num_successful"], "initial_cost": total["initial_cost"],
                      "final_cost": total["final_cost"], "initial_cost_check": c0},
            "accuracy_px": {"median_before": float(np.median(err0)), "median_after": float(np.median(err1)),
@@ -200,6 +219,8 @@ def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, 
                        "traffic": None,
                        "note": "the whole bounded LM of every sub-problem is ONE launch; a sub-problem's evaluations are a serial "
                                "chain (LM iteration -> line-search probes), so the kernel is latency-bound well below the HBM rate"}
+    if tel is not None:
+        out["telemetry"] = tel
     if cpu is not None:
         out.update(cpu)
         out["gpu_over_cpu_solve"] = (out["cpu_baseline"]["projected_full_solve_ms"] / kernel_ms) if kernel_ms > 0 else None

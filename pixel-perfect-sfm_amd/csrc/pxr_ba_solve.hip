@@ -198,7 +198,8 @@ constexpr int IMG_BATCH = 128;   // observations staged in LDS per pass
 __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* __restrict__ chunks,
                                              const int64_t* __restrict__ img_obs,
                                              const double* __restrict__ L, double* __restrict__ U,
-                                             double* __restrict__ gc, int block_form, double det_scale) {
+                                             double* __restrict__ gc, int block_form, double det_scale,
+                                             double* __restrict__ chunk_trace) {
   // block_form = 0: U is the dense n_c x n_c matrix (upper triangle), direct solver;
   // block_form = 1: U is [n_images][DC][DC], the image's full symmetric dc x dc block (iterative solver)
   extern __shared__ double stage[];            // [IMG_BATCH][LS] records, then [256] reduction slots
@@ -216,6 +217,11 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
   if (is_g) { a = e - NP; }
   else { int rem = e; a = 0; while (rem >= dc - a) { rem -= dc - a; ++a; } b = a + rem; }
   double acc = 0.0;
+  // deterministic mode: every OBSERVATION's term is rounded to the fixed-point grid on its own and the integers are added (`qacc`)
+  // -- a chunk's double sum rounded once would depend on which observations share a chunk, i.e. on how the points are dealt
+  // to ranks; `acc` (the plain double sum) then only feeds the trace check of the overflow guard (chunk_trace)
+  long long qacc = 0;
+  const bool fixed = det_scale != 0.0;
   // The records of an image's observations are gathered (216 B each at DC = 8) into LDS with
   // coalesced, independent loads -- consecutive lanes read consecutive doubles of a record -- and
   // every thread then accumulates its matrix entry from LDS.  (A per-thread gather loop over the
@@ -246,8 +252,10 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
         for (int o = sl; o < nb; o += slices) {
           const double* Lo = stage + (size_t)o * LS;
           const double* B0 = Lo + 11; const double* B1 = B0 + d.DC;
-          if (is_g) acc += B0[a] * Lo[3] + B1[a] * Lo[4];
-          else acc += B0[a] * (Lo[0] * B0[b] + Lo[1] * B1[b]) + B1[a] * (Lo[1] * B0[b] + Lo[2] * B1[b]);
+          const double term = is_g ? B0[a] * Lo[3] + B1[a] * Lo[4]
+                                   : B0[a] * (Lo[0] * B0[b] + Lo[1] * B1[b]) + B1[a] * (Lo[1] * B0[b] + Lo[2] * B1[b]);
+          acc += term;
+          if (fixed) qacc += __double2ll_rn(term * det_scale);
         }
       }
       __syncthreads();
@@ -264,8 +272,10 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
       for (int o = sl; o < nb; o += slices) {
         const double* Lo = stage + (size_t)o * LS;
         const double* B0 = Lo + 11; const double* B1 = B0 + d.DC;
-        if (is_g) acc += B0[a] * Lo[3] + B1[a] * Lo[4];
-        else acc += B0[a] * (Lo[0] * B0[b] + Lo[1] * B1[b]) + B1[a] * (Lo[1] * B0[b] + Lo[2] * B1[b]);
+        const double term = is_g ? B0[a] * Lo[3] + B1[a] * Lo[4]
+                                 : B0[a] * (Lo[0] * B0[b] + Lo[1] * B1[b]) + B1[a] * (Lo[1] * B0[b] + Lo[2] * B1[b]);
+        acc += term;
+        if (fixed) qacc += __double2ll_rn(term * det_scale);
       }
     }
     __syncthreads();
@@ -273,16 +283,32 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
   }
   red[threadIdx.x] = acc;
   __syncthreads();
+  if (sl == 0) for (int s2 = 1; s2 < slices; ++s2) acc += red[s2 * NE + e];
+  if (fixed) {                                   // the integers' turn through the same reduction slots
+    __syncthreads();
+    red[threadIdx.x] = __longlong_as_double(qacc);
+    __syncthreads();
+    if (sl == 0) for (int s2 = 1; s2 < slices; ++s2) qacc += __double_as_longlong(red[s2 * NE + e]);
+    __syncthreads();
+    // the chunk's trace(U) contribution, in plain doubles: only compared with a threshold (overflow guard of the solver)
+    red[threadIdx.x] = (sl == 0 && !is_g && a == b) ? acc : 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0 && chunk_trace) {
+      double tr = 0.0;
+      for (int x = 0; x < NP; ++x) tr += red[x];
+      chunk_trace[blockIdx.x] = tr;
+    }
+  }
   if (sl == 0) {
-    for (int s2 = 1; s2 < slices; ++s2) acc += red[s2 * NE + e];
     const int ra = col_index(d, img, cam, a);
     // (det_scale != 0: deterministic mode, order-independent fixed-point accumulation -- pxr_device.h)
-    if (is_g) accum_add(gc + ra, acc, det_scale);
+    const double v = fixed ? __longlong_as_double(qacc) : acc;
+    if (is_g) accum_flush(gc + ra, v, det_scale);
     else if (block_form) {
       double* Ub = U + (size_t)img * d.DC * d.DC;
-      accum_add(Ub + a * d.DC + b, acc, det_scale);
-      if (a != b) accum_add(Ub + b * d.DC + a, acc, det_scale);
-    } else accum_add(U + (size_t)ra * d.n_c + col_index(d, img, cam, b), acc, det_scale);
+      accum_flush(Ub + a * d.DC + b, v, det_scale);
+      if (a != b) accum_flush(Ub + b * d.DC + a, v, det_scale);
+    } else accum_flush(U + (size_t)ra * d.n_c + col_index(d, img, cam, b), v, det_scale);
   }
 }
 
@@ -514,7 +540,8 @@ __global__ void k_fill(int64_t n, double v, double* __restrict__ out) {
 // delta_c = -x ; accumulates replicated scalars: [0] d.D.d - d.g (camera side)  [4] max|g_c/scale|
 __global__ void k_finish_camera_step(int n, const double* __restrict__ x, const double* __restrict__ gc,
                                      const double* __restrict__ damp, double inv_radius,
-                                     double* __restrict__ delta_c, double* __restrict__ scal_rep, double* __restrict__ det_part) {
+                                     double* __restrict__ delta_c, double* __restrict__ scal_rep, long long* __restrict__ limb) {
+  __shared__ long long lsh[PXR_LIMBS * 4];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double part = 0.0;
   if (i < n) {
@@ -522,11 +549,14 @@ __global__ void k_finish_camera_step(int n, const double* __restrict__ x, const 
     delta_c[i] = dl;
     part = dl * (damp[i] * inv_radius * dl - gc[i]);
   }
-  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-  if ((threadIdx.x & 63) == 0) {
-    if (det_part) det_part[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = part;     // deterministic mode: per-wavefront partials
-    else atomicAdd(scal_rep + 0, part);
+  if (limb) {                                    // deterministic mode: one limb addend per column (pxr_device.h)
+    Limbs l;
+    if (i < n) l.add(part);
+    limbs_block_add(l, limb + (8 + 0) * PXR_LIMBS, lsh);
+    return;
   }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  if ((threadIdx.x & 63) == 0) atomicAdd(scal_rep + 0, part);
 }
 
 // ---- K_backsub: delta_p = -T (g_p + sum_i W_i^T delta_c) ---------------------------------------------
@@ -540,10 +570,12 @@ __global__ __launch_bounds__(256) void k_backsub(const SolveDev d, const int64_t
                                                  const double* __restrict__ W, const double* __restrict__ T,
                                                  const double* __restrict__ gp, const double* __restrict__ delta_c,
                                                  const double* __restrict__ Vdiag0, double inv_radius,
-                                                 double* __restrict__ delta_p, double* __restrict__ scal_sum, double* __restrict__ det_part) {
+                                                 double* __restrict__ delta_p, double* __restrict__ scal_sum, long long* __restrict__ limb) {
   __shared__ double red[256 / 64];
+  __shared__ long long lsh[PXR_LIMBS * 4];
   const int lane_a = threadIdx.x % G;
   double part = 0.0;
+  Limbs lpart;                                   // deterministic mode: one limb addend per POINT
   // BACKSUB_PPG points per group and one atomic per workgroup: the model-cost scalar is ONE address, and an atomic per
   // wavefront of eight points (25 000 of them) serialised there for longer than the kernel's own work
   for (int rep = 0; rep < BACKSUB_PPG; ++rep) {
@@ -586,20 +618,20 @@ __global__ __launch_bounds__(256) void k_backsub(const SolveDev d, const int64_t
       dl[0] = -(Tp[0] * v0 + Tp[1] * v1 + Tp[2] * v2);
       dl[1] = -(Tp[1] * v0 + Tp[3] * v1 + Tp[4] * v2);
       dl[2] = -(Tp[2] * v0 + Tp[4] * v1 + Tp[5] * v2);
+      double pp = 0.0;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) part += dl[j] * (Vdiag0[3 * p + j] * inv_radius * dl[j] - gp[3 * p + j]);
+      for (int j = 0; j < 3; ++j) pp += dl[j] * (Vdiag0[3 * p + j] * inv_radius * dl[j] - gp[3 * p + j]);
+      if (limb) lpart.add(pp); else part += pp;
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) delta_p[3 * p + j] = dl[j];
   }
   }
+  if (limb) { limbs_block_add(lpart, limb + 1 * PXR_LIMBS, lsh); return; }
   part = wave_sum(part);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    if (det_part) det_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-    else atomicAdd(scal_sum + 1, red[0] + red[1] + red[2] + red[3]);
-  }
+  if (threadIdx.x == 0) atomicAdd(scal_sum + 1, red[0] + red[1] + red[2] + red[3]);
 }
 
 // ---- K_update: candidate = x (+) scale * delta --------------------------------------------------------
@@ -608,12 +640,14 @@ constexpr int UPDATE_IPT = 4;
 
 __global__ __launch_bounds__(256) void k_update(const SolveDev d, const double* __restrict__ delta_c,
                                                 const double* __restrict__ delta_p, ParamPtrs out,
-                                                double* __restrict__ scal_rep, double* __restrict__ scal_sum, double* __restrict__ det_part) {
+                                                double* __restrict__ scal_rep, double* __restrict__ scal_sum, long long* __restrict__ limb) {
   // UPDATE_IPT items per thread and one pair of atomics per workgroup: the four norms are four addresses, and an atomic per
   // wavefront (3 100 of them at 200 000 points) serialised there for most of the kernel's 82 us
   __shared__ double red[4][256 / 64];
+  __shared__ long long lsh[PXR_LIMBS * 4];
   const int n_img = d.v.n_images, n_cam = d.v.n_cameras;
   double step2_rep = 0, x2_rep = 0, step2_sum = 0, x2_sum = 0;
+  Limbs l_step_rep, l_x_rep, l_step_sum, l_x_sum;          // deterministic mode: one limb addend per image / camera / point
   for (int rep = 0; rep < UPDATE_IPT; ++rep) {
   const int64_t tid = ((int64_t)blockIdx.x * UPDATE_IPT + rep) * blockDim.x + threadIdx.x;
   if (tid < n_img) {
@@ -640,8 +674,10 @@ __global__ __launch_bounds__(256) void k_update(const SolveDev d, const double* 
         t1[a] = t0[a] + delta_c[po + col] * d.scale_c[po + col];
         ++col;
       }
-      for (int j = 0; j < 4; ++j) { x2_rep += q0[j] * q0[j]; step2_rep += (q1[j] - q0[j]) * (q1[j] - q0[j]); }
-      for (int j = 0; j < 3; ++j) { x2_rep += t0[j] * t0[j]; step2_rep += (t1[j] - t0[j]) * (t1[j] - t0[j]); }
+      double ix = 0.0, is = 0.0;
+      for (int j = 0; j < 4; ++j) { ix += q0[j] * q0[j]; is += (q1[j] - q0[j]) * (q1[j] - q0[j]); }
+      for (int j = 0; j < 3; ++j) { ix += t0[j] * t0[j]; is += (t1[j] - t0[j]) * (t1[j] - t0[j]); }
+      if (limb) { l_x_rep.add(ix); l_step_rep.add(is); } else { x2_rep += ix; step2_rep += is; }
     }
     for (int j = 0; j < 4; ++j) out.q[4 * i + j] = q1[j];
     for (int j = 0; j < 3; ++j) out.t[3 * i + j] = t1[j];
@@ -649,6 +685,7 @@ __global__ __launch_bounds__(256) void k_update(const SolveDev d, const double* 
     const int c = (int)(tid - n_img);
     const int K = camera_num_params(d.v.d_cam_model[c]);
     int kc = 0;
+    double ix = 0.0, is = 0.0;
     for (int a = 0; a < PXR_KPAD; ++a) {
       const double k0 = d.v.d_cam_params[(size_t)c * PXR_KPAD + a];
       double k1 = k0;
@@ -658,22 +695,32 @@ __global__ __launch_bounds__(256) void k_update(const SolveDev d, const double* 
           k1 = k0 + delta_c[io] * d.scale_c[io];
           ++kc;
         }
-        x2_rep += k0 * k0; step2_rep += (k1 - k0) * (k1 - k0);
+        ix += k0 * k0; is += (k1 - k0) * (k1 - k0);
       }
       out.k[(size_t)c * PXR_KPAD + a] = k1;
     }
+    if (limb) { l_x_rep.add(ix); l_step_rep.add(is); } else { x2_rep += ix; step2_rep += is; }
   } else if (tid < n_img + n_cam + d.v.n_points) {
     const int64_t p = tid - n_img - n_cam;
+    double ix = 0.0, is = 0.0;
     for (int j = 0; j < 3; ++j) {
       const double x0 = d.v.d_xyz[3 * p + j];
       double x1 = x0;
       if (d.pt_var[p]) {
         x1 = x0 + delta_p[3 * p + j] * d.scale_p[3 * p + j];
-        x2_sum += x0 * x0; step2_sum += (x1 - x0) * (x1 - x0);
+        ix += x0 * x0; is += (x1 - x0) * (x1 - x0);
       }
       out.X[3 * p + j] = x1;
     }
+    if (limb) { l_x_sum.add(ix); l_step_sum.add(is); } else { x2_sum += ix; step2_sum += is; }
   }
+  }
+  if (limb) {
+    limbs_block_add(l_step_rep, limb + (8 + 1) * PXR_LIMBS, lsh); __syncthreads();
+    limbs_block_add(l_x_rep, limb + (8 + 2) * PXR_LIMBS, lsh); __syncthreads();
+    limbs_block_add(l_step_sum, limb + 2 * PXR_LIMBS, lsh); __syncthreads();
+    limbs_block_add(l_x_sum, limb + 3 * PXR_LIMBS, lsh);
+    return;
   }
   step2_rep = wave_sum(step2_rep); x2_rep = wave_sum(x2_rep);
   step2_sum = wave_sum(step2_sum); x2_sum = wave_sum(x2_sum);
@@ -685,25 +732,21 @@ __global__ __launch_bounds__(256) void k_update(const SolveDev d, const double* 
   if (threadIdx.x == 0) {
     double r[4];
     for (int k = 0; k < 4; ++k) r[k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
-    if (det_part) { for (int k = 0; k < 4; ++k) det_part[4 * (size_t)blockIdx.x + k] = r[k]; }
-    else {
-      if (r[0] != 0.0 || r[1] != 0.0) { atomicAdd(scal_rep + 1, r[0]); atomicAdd(scal_rep + 2, r[1]); }
-      if (r[2] != 0.0 || r[3] != 0.0) { atomicAdd(scal_sum + 2, r[2]); atomicAdd(scal_sum + 3, r[3]); }
-    }
+    if (r[0] != 0.0 || r[1] != 0.0) { atomicAdd(scal_rep + 1, r[0]); atomicAdd(scal_rep + 2, r[1]); }
+    if (r[2] != 0.0 || r[3] != 0.0) { atomicAdd(scal_sum + 2, r[2]); atomicAdd(scal_sum + 3, r[3]); }
   }
 }
 
 __global__ void k_point_step_norm(int64_t n_points, const int* __restrict__ pt_var, const double* __restrict__ X0,
-                                  const double* __restrict__ X1, double* __restrict__ out, double* __restrict__ det_part) {
+                                  const double* __restrict__ X1, double* __restrict__ out, long long* __restrict__ limb_slot) {
+  __shared__ long long lsh[PXR_LIMBS * 4];
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double s = 0.0;
   if (p < n_points && pt_var[p])
     for (int j = 0; j < 3; ++j) { const double d = X1[3 * p + j] - X0[3 * p + j]; s += d * d; }
+  if (limb_slot) { Limbs l; l.add(s); limbs_block_add(l, limb_slot, lsh); return; }   // deterministic mode
   s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) {
-    if (det_part) det_part[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = s;        // deterministic mode: per-wavefront partials
-    else if (s != 0.0) atomicAdd(out, s);
-  }
+  if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(out, s);
 }
 
 __global__ void k_normalize_q(int n, double* __restrict__ q) {
@@ -718,11 +761,14 @@ __global__ void k_normalize_q(int n, double* __restrict__ q) {
 // all-reduce(sum) the solver already has (the point gradient is sharded; a rank-local maximum would let the ranks
 // disagree about termination).
 __global__ void k_count_above(int64_t n, const double* __restrict__ g, const double* __restrict__ scale, double tol,
-                              double* __restrict__ out) {
+                              double* __restrict__ out, long long* __restrict__ limb_slot) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double v = (i < n && !(fabs(g[i] / scale[i]) <= tol)) ? 1.0 : 0.0;
   v = wave_sum(v);
-  if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(out, v);
+  if ((threadIdx.x & 63) == 0 && v != 0.0) {
+    if (limb_slot) atomicAdd(reinterpret_cast<unsigned long long*>(limb_slot + 1), (unsigned long long)((long long)v << 20));   // digit on the 2^-20 grid
+    else atomicAdd(out, v);
+  }
 }
 
 // Several ranks: only the upper triangle of [S | rhs] carries data (row r: columns r .. n, the last one the right-hand side --
@@ -747,37 +793,81 @@ __global__ void k_det_finish(int64_t n, double* __restrict__ x, double det_scale
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = accum_value(x[i], det_scale);
 }
-// deterministic mode: *dst += part[k], part[k + stride], ... (n terms) added in a fixed order by ONE workgroup -- thread t takes
-// the terms t, t + 1024, ... in sequence, then a fixed tree over the 1024 threads
-__global__ __launch_bounds__(1024) void k_ordered_sum(const double* __restrict__ part, int64_t n, int stride, int k, double* __restrict__ dst) {
-  __shared__ double sh[1024];
-  double acc = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) acc += part[i * stride + k];
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (int off = 512; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *dst += sh[0];
-}
-// deterministic mode: cost = sum 0.5 rho(s) over the records, per-workgroup partials in a fixed mapping (the fused cost of the
-// residual kernel is one floating-point atomic per wavefront)
-__global__ __launch_bounds__(256) void k_cost_partials(const double* __restrict__ rec, int64_t n, pxr_loss loss, double* __restrict__ part) {
-  __shared__ double sh[256];
-  double acc = 0.0;
+// cost = sum 0.5 rho(s) over the records as limbs (pxr_device.h): one addend per observation, integer atomics per workgroup --
+// the same integers whatever the launch shape or the rank count.  (The cost fused into the residual kernel was one
+// floating-point atomic per wavefront on one address: 50 us of serialisation at 1M observations.)
+__global__ __launch_bounds__(256) void k_cost_limbs(const double* __restrict__ rec, int64_t n, pxr_loss loss, long long* __restrict__ slot) {
+  __shared__ long long lsh[PXR_LIMBS * 4];
+  Limbs l;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     double rho[3];
     loss_eval(loss.type, loss.a, 1.0, rec[i * PXR_OBS_REC], rho);
-    acc += 0.5 * rho[0];
+    l.add(0.5 * rho[0]);
   }
+  limbs_block_add(l, slot, lsh);
+}
+// x[0 .. n) added to a limb slot, one addend per entry (the inner iterations' per-point costs)
+__global__ __launch_bounds__(256) void k_limb_accumulate(const double* __restrict__ x, int64_t n, long long* __restrict__ slot) {
+  __shared__ long long lsh[PXR_LIMBS * 4];
+  Limbs l;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) l.add(x[i]);
+  limbs_block_add(l, slot, lsh);
+}
+// scal[i] = value of limb slot i for every i in `mask` (16 slots)
+__global__ void k_limbs_finish(const long long* __restrict__ limb, unsigned mask, double* __restrict__ scal) {
+  const int i = threadIdx.x;
+  if (i < 16 && ((mask >> i) & 1u)) scal[i] = limb_value(limb + i * PXR_LIMBS);
+}
+// a chunk list's trace contributions (k_img) as limbs behind the gathered diagonal / gradient (they travel in the same
+// integer all-reduce); plain doubles summed in index order -- the value only meets a threshold
+__global__ __launch_bounds__(256) void k_trace_limbs(const double* __restrict__ chunk_trace, int n_chunks, long long* __restrict__ out) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_chunks; i += 256) acc += chunk_trace[i];
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+  if (threadIdx.x == 0) {
+    Limbs l; l.add(sh[0]);
+    for (int k = 0; k < PXR_LIMBS; ++k) out[k] = l.q[k];
+  }
+}
+// overflow guard of the fixed-point accumulation: {max, sum, min} of the finished diagonal and the trace the chunks measured
+// in floating point.  A diagonal slot that wrapped is off by a multiple of 2^64 / scale, so |trace - sum| tells.
+__global__ __launch_bounds__(256) void k_diag_stats(int n, const double* __restrict__ diag, const long long* __restrict__ trace_limbs,
+                                                    double* __restrict__ out4) {
+  __shared__ double smax[256], ssum[256], smin[256];
+  double mx = 0.0, sm = 0.0, mn = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) { const double v = diag[i]; mx = fmax(mx, v); mn = fmin(mn, v); sm += v; }
+  smax[threadIdx.x] = mx; ssum[threadIdx.x] = sm; smin[threadIdx.x] = mn;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + off]);
+      smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + off]);
+      ssum[threadIdx.x] += ssum[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out4[0] = smax[0]; out4[1] = ssum[0]; out4[2] = smin[0]; out4[3] = limb_value(trace_limbs); }
+}
+// 64-bit integers through a sum-of-doubles collective (the caller's all-reduce callback): each integer as its signed high and
+// unsigned low 32-bit halves -- sums of up to 2^20 of them are exact in a double -- and back (modulo 2^64, like the integers)
+__global__ void k_i64_split(int64_t n, const long long* __restrict__ in, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long v = in[i];
+  out[2 * i] = (double)(int)(v >> 32);
+  out[2 * i + 1] = (double)(unsigned)(v & 0xffffffffll);
+}
+__global__ void k_i64_join(int64_t n, const double* __restrict__ in, long long* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long hi = (unsigned long long)(long long)in[2 * i], lo = (unsigned long long)(long long)in[2 * i + 1];
+  out[i] = (long long)((hi << 32) + lo);
 }
 
 // keep rank 0's copy of a replicated buffer: the other ranks zero theirs before an all-reduce(sum)
@@ -1116,7 +1206,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   // S: n_c x (n_c + 1) [S | rhs] + one spare row for the factorisation
   // direct solver: dense U and [S | rhs]; iterative solver: one DC x DC block of U per image, nothing quadratic in n_c
   RC(U.alloc(iterative ? (size_t)n_img * DC * DC : nc1 * nc1)); RC(S.alloc(iterative ? 1 : (nc1 + 1) * (nc1 + 1)));
-  RC(gcd.alloc(2 * nc1)); RC(damp_c.alloc(nc1));
+  RC(gcd.alloc(2 * nc1 + 8)); RC(damp_c.alloc(nc1));   // diag(U) | g_c | trace limbs of the overflow guard
   RC(scale_c.alloc(nc1)); RC(scale_p.alloc((size_t)n_pts * 3)); RC(delta_c.alloc(nc1)); RC(delta_p.alloc((size_t)n_pts * 3));
   RC(rec_a.alloc((size_t)n_obs * PXR_OBS_REC)); RC(rec_b.alloc((size_t)n_obs * PXR_OBS_REC));
   RC(q1.alloc((size_t)n_img * 4)); RC(t1.alloc((size_t)n_img * 3)); RC(k1.alloc((size_t)n_cam * PXR_KPAD)); RC(X1.alloc((size_t)n_pts * 3));
@@ -1168,47 +1258,78 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   // with floating-point atomics whose order differs from rank to rank.  To keep the ranks bit-identical -- same
   // parameters, same accept / reject / terminate decisions, hence the same sequence of collectives -- rank 0's copy
   // is broadcast: the others zero theirs and join an all-reduce(sum).  Needs the rank (pxr_comm_init / _set_rank).
-  const bool bcast = multi && ctx->nranks > 1;
+  // (Only without the deterministic mode: with it every rank computes the same bits, `bcast` below.)
   DevBuf<double> S_packed;            // the collective's buffer of the direct solver (upper triangle + rhs)
   const int64_t packed_doubles = (int64_t)n_c * (n_c + 3) / 2;
   if (multi && !iterative && n_c > 0) RC(S_packed.alloc((size_t)packed_doubles));
   sum->collective_kib = (multi && !iterative) ? (int)((packed_doubles * 8 + 1023) / 1024) : 0;
+  // ---- deterministic mode (the default; pxr_set_deterministic(ctx, 0) / PXR_DETERMINISTIC=0 opt out) -------------------------
+  // Everything that is summed over observations, points or ranks is summed as INTEGERS, so that the result does not depend on
+  // the order of the adders, on the launch shapes or on how the points are dealt to ranks: an N-rank solve is bit-identical
+  // to the one-rank solve.
+  //  * matrix / vector slots (U, g_c, S | rhs): fixed point on ONE grid per linearisation, lin_scale = 2^k.  Integer atomics wrap
+  //    modulo 2^64, so only the FINAL content of a slot has to fit: |U_ij|, |S_ij| <= max diag(U) (U and the damped S are positive
+  //    semi-definite, S <= U) and |g_c|, |rhs| <= sqrt(max diag(U) 2 cost) (Cauchy-Schwarz; rho concave: rho' s <= rho).  The grid
+  //    of a linearisation comes from the measured max diag(U) of the previous one with a factor 8 of slack (the first,
+  //    Jacobi-scaled one: diag < 1 by construction), and every linearisation is CHECKED (lin_guard below): the finished
+  //    diagonal against the bound, and against the trace the chunks measured in floating point -- a diagonal slot that wrapped
+  //    is off by a multiple of 2^64 / scale.  A failed check repeats the linearisation on a grid from the measured trace.
+  //  * scalars (cost, model cost change, norms): four 40-bit limbs + a bad-addend count per scalar (pxr_device.h), one addend per
+  //    observation / point / column.
+  //  * several ranks: the integers are all-reduced as integers (ncclInt64; through a sum-of-doubles callback as exact 32-bit
+  //    halves), replicated quantities are computed identically by every rank and need no broadcast.
+  const bool det = ctx->deterministic && !iterative;
+  const bool bcast = multi && ctx->nranks > 1 && !det;
   auto from_rank0 = [&](double* buf, int64_t count) -> int {
     if (!bcast) return PXR_OK;
     if (ctx->rank != 0) hipLaunchKernelGGL(k_zero, dim3(nblk(count)), dim3(256), 0, st, count, buf);
     return ar(buf, count);
   };
+  DevBuf<long long> slimb;            // 16 scalar slots x PXR_LIMBS integers: [0..7] summed over the ranks, [8..15] replicated
+  RC(slimb.alloc(16 * PXR_LIMBS));
+  long long* const limb_arg = det ? slimb.p : nullptr;     // what the step kernels get: NULL = floating-point atomics into `scal`
+  DevBuf<double> i64_halves;          // the callback path's exact 32-bit halves
+  const bool native_i64 = allreduce == nullptr;
+  if (det && multi && !native_i64) RC(i64_halves.alloc((size_t)2 * std::max<int64_t>({packed_doubles, 2 * (int64_t)nc1 + 8, 16 * PXR_LIMBS})));
+  auto ar_i64 = [&](long long* buf, int64_t count) -> int {    // in-place integer all-reduce(sum)
+    if (!multi || count <= 0) return PXR_OK;
+    if (native_i64) return comm_allreduce_sum_i64(ctx, buf, count);
+    hipLaunchKernelGGL(k_i64_split, dim3(nblk(count)), dim3(256), 0, st, count, (const long long*)buf, i64_halves.p);
+    RC(ar(i64_halves.p, 2 * count));
+    hipLaunchKernelGGL(k_i64_join, dim3(nblk(count)), dim3(256), 0, st, count, (const double*)i64_halves.p, buf);
+    return PXR_OK;
+  };
+  auto zero_scalars = [&]() -> int {
+    PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * 16, st));
+    PXR_HIP(hipMemsetAsync(slimb.p, 0, sizeof(long long) * 16 * PXR_LIMBS, st));
+    return PXR_OK;
+  };
+  DevBuf<double> lin_stats;           // {max, sum, min of diag(U), trace} of the newest linearisation (k_diag_stats)
+  RC(lin_stats.alloc(4));
+  double h_lin_stats[4] = {0, 0, 0, 0};
   auto read_scal = [&](double* h16) -> int {
-    RC(ar(scal_sum, 8));
-    RC(from_rank0(scal_rep, 8));
+    if (det) {
+      RC(ar_i64(slimb.p, 8 * PXR_LIMBS));
+      hipLaunchKernelGGL(k_limbs_finish, dim3(1), dim3(64), 0, st, (const long long*)slimb.p, 0xffffu, scal.p);
+    } else {
+      hipLaunchKernelGGL(k_limbs_finish, dim3(1), dim3(64), 0, st, (const long long*)slimb.p, (1u << 0) | (1u << 4), scal.p);   // the costs
+      RC(ar(scal_sum, 8));
+      RC(from_rank0(scal_rep, 8));
+    }
     PXR_HIP(hipMemcpyAsync(h16, scal.p, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
+    if (det) PXR_HIP(hipMemcpyAsync(h_lin_stats, lin_stats.p, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
     PXR_HIP(hipStreamSynchronize(st));
     return PXR_OK;
   };
-  // ---- deterministic mode (pxr_set_deterministic): order-independent accumulation in the direct solver ----------------
-  // matrix / vector slots (U, g_c, S | rhs): fixed point, det_scale = 2^k with k from the bound of the slots -- with Jacobi
-  // scaling every column of the robustified Jacobian has norm < 1, so |U_ij|, |S_ij| and every partial sum of their
-  // positive-semidefinite contributions are < 1, and |g_c|, |rhs| <= |r~| <= sqrt(2 cost) (Cauchy-Schwarz; rho concave:
-  // rho' s <= rho).  Scalars: per-workgroup partials, added in index order by k_ordered_sum.
-  const bool det = ctx->deterministic && !iterative;
-  PXR_REQUIRE(!det || opt->jacobi_scaling, "pxr_ba_solve: the deterministic mode needs jacobi_scaling (it bounds the fixed-point slots)");
-  const int64_t det_cost_blocks = 1024;
-  const int64_t det_part_n = std::max<int64_t>({det_cost_blocks, (int64_t)nblk(n_pts), (int64_t)nblk(n_pts * 4),
-                                                4 * (int64_t)nblk(((int64_t)n_img + n_cam + n_pts + UPDATE_IPT - 1) / UPDATE_IPT),
-                                                (int64_t)nblk(nc1) * 4, n_pts}) + 8;
-  DevBuf<double> det_part;
-  RC(det_part.alloc((size_t)det_part_n));          // (the cost's partials use it in every mode)
-  auto det_scale_for = [](double cost_now) {       // 2^k: slots bounded by 8 max(1, sqrt(2 cost)) fit 62 bits
-    const double bound = 8.0 * std::max(1.0, std::sqrt(2.0 * std::max(cost_now, 0.0)));
+  DevBuf<double> det_part, chunk_trace;
+  RC(det_part.alloc((size_t)n_pts + 8));          // the inner iterations' per-point costs (every mode)
+  RC(chunk_trace.alloc(chunks.size() + 1));
+  // the grid: entries bounded by 8 max(md, sqrt(2 md cost)) fit 62 bits (md: the bound on diag(U) the grid is made for)
+  auto det_scale_for = [](double md, double cost_now) {
+    const double bound = 8.0 * std::max({md, std::sqrt(2.0 * md * std::max(cost_now, 0.0)), 1e-300});
     return std::ldexp(1.0, 62 - (int)std::ceil(std::log2(bound)));
   };
-  auto ordered_sum = [&](int64_t n, int stride, int k, double* dst) {
-    hipLaunchKernelGGL(k_ordered_sum, dim3(1), dim3(1024), 0, st, (const double*)det_part.p, n, stride, k, dst);
-  };
-  // The cost is NOT fused into the residual kernel (rounds 1-3 did: one floating-point atomic per wavefront to ONE address --
-  // 15 600 of them serialise for ~50 us, profiles/r4_det_vs_default_kernel_stats.txt: ba_eval_kernel 848 us with, 794 us
-  // without): a pass over the 64-byte records with per-workgroup partials (12 us) and an index-ordered final sum (8 us) is
-  // cheaper, and deterministic in every mode.
+  double lin_md = 1.0;                // the diag(U) bound the CURRENT grid was made for
   // pxr_set_gram_cache: the records from cached Gram matrices of the stencils instead of from the texels (pxr_ba_gram.hip)
   const bool gram_cache = ctx->gram_cache && gram_eval_supported(arena, view);
   // The Gram-matrix kernel of the inner iterations keeps its matrices in the same cache from call to call (it writes back what
@@ -1231,9 +1352,8 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     if (gram_cache && n_evaluations > 0) { RC(gram_evaluate(ctx, arena, &v, cfg, gram, rec)); gram_warm = true; }
     else RC(ba_eval_with_cost(ctx, arena, &v, cfg, 1, rec, nullptr, nullptr, nullptr, nullptr, nullptr));
     ++n_evaluations;
-    hipLaunchKernelGGL(k_cost_partials, dim3((unsigned)det_cost_blocks), dim3(256), 0, st, (const double*)rec, n_obs, *loss, det_part.p);
-    ordered_sum(det_cost_blocks, 1, 0, scal_sum);
-    LAUNCH_CHECK("deterministic cost");
+    hipLaunchKernelGGL(k_cost_limbs, dim3(1024), dim3(256), 0, st, (const double*)rec, n_obs, *loss, slimb.p + 0 * PXR_LIMBS);
+    LAUNCH_CHECK("cost");
     return PXR_OK;
   };
   // linearise at the CURRENT parameters from record buffer `rec` (lin_scale: the fixed-point grid of U and g_c in
@@ -1244,13 +1364,22 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
                        sizeof(double) * (JAC_THREADS / 64) * 64 * (LS + 3 * DC + 1), st, dv, rec, *loss, L.p, W.p);
     hipLaunchKernelGGL(k_point, dim3(nblk(n_pts)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, L.p, V.p, gp.p);
     PXR_HIP(hipMemsetAsync(U.p, 0, sizeof(double) * U.n, st));
-    PXR_HIP(hipMemsetAsync(gcd.p, 0, sizeof(double) * 2 * nc1, st));
+    PXR_HIP(hipMemsetAsync(gcd.p, 0, sizeof(double) * gcd.n, st));
     if (n_c > 0 && !chunks.empty()) {
+      if (lin_scale != 0.0) PXR_HIP(hipMemsetAsync(chunk_trace.p, 0, sizeof(double) * chunk_trace.n, st));
       hipLaunchKernelGGL(k_img, dim3((unsigned)chunks.size()), dim3(256), sizeof(double) * ((size_t)IMG_BATCH * LS + 256), st, dv,
-                         d_chunks.p, d_img_obs.p, L.p, U.p, gc, iterative ? 1 : 0, lin_scale);
+                         d_chunks.p, d_img_obs.p, L.p, U.p, gc, iterative ? 1 : 0, lin_scale, lin_scale != 0.0 ? chunk_trace.p : (double*)nullptr);
       if (lin_scale != 0.0) {
+        // the integers of diag(U) and g_c (+ the trace) are summed over the ranks, THEN everything becomes doubles again
+        hipLaunchKernelGGL(k_extract_diag, dim3(nblk(n_c)), dim3(256), 0, st, n_c, U.p, diagU);
+        hipLaunchKernelGGL(k_trace_limbs, dim3(1), dim3(256), 0, st, (const double*)chunk_trace.p, (int)chunks.size(),
+                           reinterpret_cast<long long*>(gcd.p + 2 * nc1));
+        RC(ar_i64(reinterpret_cast<long long*>(gcd.p), 2 * (int64_t)nc1 + PXR_LIMBS));
         hipLaunchKernelGGL(k_det_finish, dim3(nblk((int64_t)U.n)), dim3(256), 0, st, (int64_t)U.n, U.p, lin_scale);
-        hipLaunchKernelGGL(k_det_finish, dim3(nblk(nc1)), dim3(256), 0, st, (int64_t)nc1, gc, lin_scale);
+        hipLaunchKernelGGL(k_det_finish, dim3(nblk(2 * (int64_t)nc1)), dim3(256), 0, st, 2 * (int64_t)nc1, gcd.p, lin_scale);
+        hipLaunchKernelGGL(k_diag_stats, dim3(1), dim3(256), 0, st, n_c, (const double*)diagU, reinterpret_cast<const long long*>(gcd.p + 2 * nc1), lin_stats.p);
+        LAUNCH_CHECK("linearize kernels");
+        return PXR_OK;
       }
       if (iterative) RC(pcg_diag_from_blocks(st, dv, U.p, diagU));
       else hipLaunchKernelGGL(k_extract_diag, dim3(nblk(n_c)), dim3(256), 0, st, n_c, U.p, diagU);
@@ -1258,6 +1387,37 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     LAUNCH_CHECK("linearize kernels");
     RC(ar(gcd.p, 2 * (int64_t)nc1));   // global diag(U) and g_c
     return PXR_OK;
+  };
+  // the overflow guard: did every slot of the newest linearisation fit its grid?  (stats: lin_stats, read with the scalars or here)
+  auto lin_fits = [&](const double* stt, double md_made_for) {
+    if (n_c == 0 || chunks.empty()) return true;
+    const double mx = stt[0], sm = stt[1], mn = stt[2], tr = stt[3];
+    if (!(std::isfinite(mx) && std::isfinite(sm) && std::isfinite(tr))) return false;
+    if (mn < 0.0) return false;                                               // a diagonal slot wrapped into the sign bit
+    if (std::fabs(tr - sm) > std::ldexp(1.0, 61) / lin_scale) return false;   // ... or all the way round
+    return mx <= 8.0 * md_made_for;                                           // the off-diagonal, Schur and gradient bounds hold
+  };
+  // linearise on a grid made for diag(U) <= 8 md_guess; repeat on a grid from the measured trace until the check passes
+  // (synchronises: used for the first two linearisations of a solve and on the -- never yet observed -- failure path)
+  auto linearize_checked = [&](const double* rec, double md_guess, double cost_now, bool refine = false) -> int {
+    if (!det) return linearize(rec);
+    for (int attempt = 0; attempt < 8; ++attempt) {
+      lin_md = md_guess;
+      lin_scale = det_scale_for(lin_md, cost_now);
+      RC(linearize(rec));
+      PXR_HIP(hipMemcpyAsync(h_lin_stats, lin_stats.p, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
+      PXR_HIP(hipStreamSynchronize(st));
+      if (lin_fits(h_lin_stats, lin_md)) {
+        // `refine`: this linearisation is SOLVED with (no Jacobi scaling follows) -- a guess far above the measured diagonal
+        // wasted resolution, once more on a grid made for the measurement
+        if (refine && attempt == 0 && h_lin_stats[0] * 64.0 < md_guess) { md_guess = std::max(h_lin_stats[0], 1e-300); continue; }
+        return PXR_OK;
+      }
+      // the trace was measured in floating point and bounds every diagonal entry (NaN / Inf: the Jacobian itself is not finite)
+      PXR_REQUIRE(std::isfinite(h_lin_stats[3]) && h_lin_stats[3] >= 0.0, "pxr_ba_solve: the Jacobian is not finite (deterministic accumulation)");
+      md_guess = std::max(h_lin_stats[3], 2.0 * md_guess);
+    }
+    return set_error(PXR_EINVAL, "pxr_ba_solve: the fixed-point grid of the deterministic mode could not be fitted");
   };
   auto refresh_damping = [&]() -> int {  // LevenbergMarquardtStrategy: diagonal clamped to [min, max]
     if (n_c > 0) hipLaunchKernelGGL(k_clamp, dim3(nblk(n_c)), dim3(256), 0, st, (int64_t)n_c, diagU, opt->min_lm_diagonal, opt->max_lm_diagonal, damp_c.p);
@@ -1282,9 +1442,11 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   // gradient_tolerance [upstream]: max-norm of the gradient in the unscaled variables, over ALL ranks
   auto gradient_below_tolerance = [&](bool* below) -> int {
     double h[16];
-    PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * 16, st));
-    if (n_c > 0) hipLaunchKernelGGL(k_count_above, dim3(nblk(n_c)), dim3(256), 0, st, (int64_t)n_c, gc, scale_c.p, opt->gradient_tolerance, scal_rep + 4);
-    hipLaunchKernelGGL(k_count_above, dim3(nblk(n_pts * 3)), dim3(256), 0, st, n_pts * 3, gp.p, scale_p.p, opt->gradient_tolerance, scal_sum + 5);
+    RC(zero_scalars());
+    if (n_c > 0) hipLaunchKernelGGL(k_count_above, dim3(nblk(n_c)), dim3(256), 0, st, (int64_t)n_c, gc, scale_c.p, opt->gradient_tolerance, scal_rep + 4,
+                                    det ? slimb.p + (8 + 4) * PXR_LIMBS : (long long*)nullptr);
+    hipLaunchKernelGGL(k_count_above, dim3(nblk(n_pts * 3)), dim3(256), 0, st, n_pts * 3, gp.p, scale_p.p, opt->gradient_tolerance, scal_sum + 5,
+                       det ? slimb.p + 5 * PXR_LIMBS : (long long*)nullptr);
     RC(read_scal(h));
     *below = h[5] == 0.0 && h[12] == 0.0;
     return PXR_OK;
@@ -1323,7 +1485,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   // ---- iteration 0: evaluate, Jacobi scaling, linearise ------------------------------------------------
   double hs[16];
   double* rec_cur = rec_a.p; double* rec_cand = rec_b.p;
-  PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * 16, st));
+  RC(zero_scalars());
   RC(evaluate(dv.v, rec_cur));
   RC(read_scal(hs));
   double cost = hs[0];
@@ -1335,16 +1497,14 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   }
   hipLaunchKernelGGL(k_fill, dim3(nblk(nc1)), dim3(256), 0, st, (int64_t)nc1, 1.0, scale_c.p);
   hipLaunchKernelGGL(k_fill, dim3(nblk(n_pts * 3)), dim3(256), 0, st, n_pts * 3, 1.0, scale_p.p);
-  // (deterministic mode: the UNSCALED pass only yields diag(U) for the Jacobi scaling and has no bound: a coarse grid,
-  //  2^-20 with a range of 4e12 -- any positive scaling is a valid one, it only has to be the same on every run)
-  if (det) lin_scale = std::ldexp(1.0, 20);
-  RC(linearize(rec_cur));
+  // (deterministic mode: the UNSCALED pass only yields diag(U) for the Jacobi scaling and has no a-priori bound: a first guess
+  //  of 2^32 for its diagonal -- unit-norm descriptors give 1e3 .. 1e6 -- and the checked retry from the measured trace otherwise)
+  RC(linearize_checked(rec_cur, std::ldexp(1.0, 32), cost, !opt->jacobi_scaling));
   if (opt->jacobi_scaling) {   // 1 / (1 + sqrt(diag(J~^T J~))), fixed for the whole solve
     if (n_c > 0) hipLaunchKernelGGL(k_jacobi_scale, dim3(nblk(n_c)), dim3(256), 0, st, (int64_t)n_c, diagU, scale_c.p);
     hipLaunchKernelGGL(k_point_diag, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, V.p, Vd0.p);
     hipLaunchKernelGGL(k_jacobi_scale, dim3(nblk(n_pts * 3)), dim3(256), 0, st, n_pts * 3, Vd0.p, scale_p.p);
-    if (det) lin_scale = det_scale_for(cost);
-    RC(linearize(rec_cur));
+    RC(linearize_checked(rec_cur, 1.0 / 8.0, cost));      // scaled columns have norm < 1: diag(U) < 1 = 8 x 1/8
   }
   if (opt->gradient_tolerance > 0.0) {   // [upstream] the test is also made at iteration 0
     bool below = false;
@@ -1412,7 +1572,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     const double inv_radius = 1.0 / radius;
     // point elimination + reduced camera system
     hipLaunchKernelGGL(k_pinv, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, d_pt_var.p, V.p, Vd0.p, inv_radius, T.p);
-    PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * 16, st));
+    RC(zero_scalars());
     bool ok = true;
     double inexact_correction = 0.0;
     if (n_c > 0 && iterative) {
@@ -1426,11 +1586,10 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       // e = b - S x:  model cost change = delta.(D^2 delta - g) / 2 + x.e / 2
       inexact_correction = 0.5 * pr.x_dot_r;
       PXR_HIP(hipMemsetAsync(d_info, 0, sizeof(int), st));
-      hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, xsol.p, gc, damp_c.p, inv_radius, delta_c.p, scal_rep, det ? det_part.p : (double*)nullptr);
-      if (det) ordered_sum(4 * (int64_t)nblk(n_c), 1, 0, scal_rep + 0);
+      hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, xsol.p, gc, damp_c.p, inv_radius, delta_c.p, scal_rep, limb_arg);
       RC(from_rank0(delta_c.p, n_c));
     } else if (n_c > 0) {
-      const double schur_scale = det ? det_scale_for(cost) : 0.0;
+      const double schur_scale = det ? lin_scale : 0.0;    // the SAME grid as U's: re-quantising the finished U is exact
       hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, n_c, U.p, (const double*)nullptr, 0.0, (const double*)nullptr, S.p, 1, schur_scale);
       if (use_lds_schur) {
 #define SCHUR_LAUNCH(GG)                                                                                              \
@@ -1441,16 +1600,17 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       } else {
         hipLaunchKernelGGL(k_schur, dim3(nblk(n_obs * DC)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, W.p, T.p, gp.p, S.p, rhs);
       }
-      if (schur_scale != 0.0)
-        hipLaunchKernelGGL(k_det_finish, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, (int64_t)n_c * ldS, S.p, schur_scale);
       LAUNCH_CHECK("schur kernels");
       phase(0);
       if (multi) {       // sum of U_local - Schur_local and of -Y g_p over the ranks: packed upper triangle + rhs
         hipLaunchKernelGGL(k_pack_upper, dim3((unsigned)n_c), dim3(256), 0, st, n_c, S.p, S_packed.p);
-        RC(ar(S_packed.p, packed_doubles));
+        if (schur_scale != 0.0) RC(ar_i64(reinterpret_cast<long long*>(S_packed.p), packed_doubles));   // the fixed-point integers
+        else RC(ar(S_packed.p, packed_doubles));
         hipLaunchKernelGGL(k_unpack_upper, dim3((unsigned)n_c), dim3(256), 0, st, n_c, S_packed.p, S.p);
         LAUNCH_CHECK("pack / unpack of the reduced camera system");
       }
+      if (schur_scale != 0.0)
+        hipLaunchKernelGGL(k_det_finish, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, (int64_t)n_c * ldS, S.p, schur_scale);
       phase(1);
       // rhs += g_c (global), S += D_c / radius
       hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, n_c, U.p, damp_c.p, inv_radius, gc, S.p, 0, 0.0);
@@ -1458,8 +1618,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       // this attempt (no extra host synchronisation): a failed factorisation = invalid step.
       RC(chol_factor_solve(st, S.p, n_c, d_info, linv.p, xsol.p));
       phase(2);
-      hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, xsol.p, gc, damp_c.p, inv_radius, delta_c.p, scal_rep, det ? det_part.p : (double*)nullptr);
-      if (det) ordered_sum(4 * (int64_t)nblk(n_c), 1, 0, scal_rep + 0);
+      hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, xsol.p, gc, damp_c.p, inv_radius, delta_c.p, scal_rep, limb_arg);
       RC(from_rank0(delta_c.p, n_c));
     }
     phase(3);
@@ -1467,30 +1626,27 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     if (ok) {
 #define BACKSUB_LAUNCH(GG)                                                                                                          \
   hipLaunchKernelGGL(k_backsub<GG>, dim3(nblk((n_pts * GG + BACKSUB_PPG - 1) / BACKSUB_PPG)), dim3(256), 0, st, dv, d_pt_ptr.p, d_part_obs.p, d_obs_cols.p, W.p, T.p, gp.p, \
-                     delta_c.p, Vd0.p, inv_radius, delta_p.p, scal_sum, det ? det_part.p : (double*)nullptr)
-      const int bs_g = DC <= 8 ? 8 : (DC <= 16 ? 16 : 32);
+                     delta_c.p, Vd0.p, inv_radius, delta_p.p, scal_sum, limb_arg)
       if (DC <= 8) BACKSUB_LAUNCH(8); else if (DC <= 16) BACKSUB_LAUNCH(16); else BACKSUB_LAUNCH(32);
 #undef BACKSUB_LAUNCH
-      if (det) ordered_sum((int64_t)nblk((n_pts * bs_g + BACKSUB_PPG - 1) / BACKSUB_PPG), 1, 0, scal_sum + 1);
       ParamPtrs out{q1.p, t1.p, k1.p, X1.p};
       const int64_t upd_blocks = nblk(((int64_t)n_img + n_cam + n_pts + UPDATE_IPT - 1) / UPDATE_IPT);
-      hipLaunchKernelGGL(k_update, dim3((unsigned)upd_blocks), dim3(256), 0, st, dv, delta_c.p, delta_p.p, out, scal_rep, scal_sum, det ? det_part.p : (double*)nullptr);
-      if (det) { ordered_sum(upd_blocks, 4, 0, scal_rep + 1); ordered_sum(upd_blocks, 4, 1, scal_rep + 2);
-                 ordered_sum(upd_blocks, 4, 2, scal_sum + 2); ordered_sum(upd_blocks, 4, 3, scal_sum + 3); }
+      hipLaunchKernelGGL(k_update, dim3((unsigned)upd_blocks), dim3(256), 0, st, dv, delta_c.p, delta_p.p, out, scal_rep, scal_sum, limb_arg);
       LAUNCH_CHECK("step kernels");
       const bool do_inner = inner_enabled;
       if (do_inner) {   // DoInnerIterationsIfNeeded [upstream]: refine every variable point of the candidate on its own
-        // the cost at the unrefined candidate: per-point values summed in index order, in every mode (one floating-point atomic
-        // per point on ONE address -- 200 000 of them at configs[2] -- serialised for 0.5-1 ms of the 2-4 ms call:
+        // the cost at the unrefined candidate: per-point values, summed as limbs in every mode (one floating-point atomic per
+        // point on ONE address -- 200 000 of them at configs[2] -- serialised for 0.5-1 ms of the 2-4 ms call:
         // profiles/r4_inner_cost_atomic.txt)
         PXR_HIP(hipMemsetAsync(det_part.p, 0, sizeof(double) * (size_t)n_pts, st));   // points without observations stay 0
         RC(launch_inner_iterations(ctx, arena, &cand_view, cfg, loss, d_pt_ptr.p, d_pt_obs.p, d_pt_var.p, scal_sum + 4, gram_inner ? &inner_lists.l : nullptr,
                                    det_part.p, (gram_cache || inner_cache) ? &gram : nullptr, gram_warm));
         gram_warm = true;
-        ordered_sum(n_pts, 1, 0, scal_sum + 4);
+        hipLaunchKernelGGL(k_limb_accumulate, dim3(256), dim3(256), 0, st, (const double*)det_part.p, n_pts, slimb.p + 4 * PXR_LIMBS);
         PXR_HIP(hipMemsetAsync(scal_sum + 2, 0, sizeof(double), st));   // point part of |x - candidate|^2 after refinement
-        hipLaunchKernelGGL(k_point_step_norm, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, d_pt_var.p, cur_X, X1.p, scal_sum + 2, det ? det_part.p : (double*)nullptr);
-        if (det) ordered_sum(4 * (int64_t)nblk(n_pts), 1, 0, scal_sum + 2);
+        PXR_HIP(hipMemsetAsync(slimb.p + 2 * PXR_LIMBS, 0, sizeof(long long) * PXR_LIMBS, st));
+        hipLaunchKernelGGL(k_point_step_norm, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, d_pt_var.p, cur_X, X1.p, scal_sum + 2,
+                           det ? slimb.p + 2 * PXR_LIMBS : (long long*)nullptr);
         LAUNCH_CHECK("inner iteration kernels");
       }
       phase(4);
@@ -1498,6 +1654,13 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       int h_info = 0;
       PXR_HIP(hipMemcpyAsync(&h_info, d_info, sizeof(int), hipMemcpyDeviceToHost, st));
       RC(read_scal(hs));
+      if (det && !lin_fits(h_lin_stats, lin_md)) {
+        // the overflow guard: a slot of the linearisation this iteration was computed from did not fit its grid -- repeat the
+        // linearisation on a grid from the measured trace and the iteration with it (state untouched: radius, damping, counts)
+        RC(linearize_checked(rec_cur, std::max(h_lin_stats[3], 2.0 * lin_md), cost));
+        --sum->iterations;
+        continue;
+      }
       if (n_c > 0 && h_info != 0) ok = false;
       phase(5);
       cand_cost = hs[0];
@@ -1537,7 +1700,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       PXR_HIP(hipMemcpyAsync(cur_X, X1.p, sizeof(double) * 3 * n_pts, hipMemcpyDeviceToDevice, st));
       std::swap(rec_cur, rec_cand);
       cost = cand_cost;
-      if (det) lin_scale = det_scale_for(cost);
+      if (det) { lin_md = std::max(h_lin_stats[0], 1e-300); lin_scale = det_scale_for(lin_md, cost); }   // checked with the next iteration's scalars
       RC(linearize(rec_cur));
       phase(6);
       ++sum->num_successful;

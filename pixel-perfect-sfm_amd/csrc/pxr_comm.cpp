@@ -16,7 +16,7 @@ namespace {
 
 struct NcclUniqueId { char internal[PXR_COMM_ID_BYTES]; };   // ncclUniqueId, rccl.h:43
 typedef void* NcclComm;                                      // ncclComm_t
-enum { kNcclSuccess = 0, kNcclSum = 0, kNcclFloat64 = 8 };   // ncclResult_t / ncclRedOp_t / ncclDataType_t values
+enum { kNcclSuccess = 0, kNcclSum = 0, kNcclInt64 = 4, kNcclFloat64 = 8 };   // ncclResult_t / ncclRedOp_t / ncclDataType_t values (rccl.h:459-467)
 
 struct Rccl {
   void* handle = nullptr;
@@ -67,6 +67,15 @@ int comm_allreduce_sum(pxr_ctx* ctx, double* d_buf, int64_t count, bool even_sin
   Rccl* r = rccl();
   return nccl_check(r->AllReduce(d_buf, d_buf, (size_t)count, kNcclFloat64, kNcclSum, (NcclComm)ctx->comm, ctx->stream),
                     "ncclAllReduce");
+}
+
+// the same for 64-bit integers: the deterministic solvers' fixed-point slots and scalar limbs (integer sums are associative, so
+// an N-rank solve accumulates the very integers of the one-rank solve)
+int comm_allreduce_sum_i64(pxr_ctx* ctx, long long* d_buf, int64_t count) {
+  if (!ctx->comm || count <= 0 || ctx->nranks <= 1) return PXR_OK;
+  Rccl* r = rccl();
+  return nccl_check(r->AllReduce(d_buf, d_buf, (size_t)count, kNcclInt64, kNcclSum, (NcclComm)ctx->comm, ctx->stream),
+                    "ncclAllReduce(int64)");
 }
 
 }  // namespace pxr

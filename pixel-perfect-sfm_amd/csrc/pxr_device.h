@@ -102,6 +102,49 @@ __device__ __forceinline__ double accum_value(double raw, double det_scale) {
   return det_scale == 0.0 ? raw : (double)__double_as_longlong(raw) / det_scale;
 }
 
+// ---- partition-independent scalar sums: four 40-bit limbs -----------------------------------------
+// A scalar that is summed over observations / points / ranks (cost, model cost change, step norms) is accumulated as FOUR signed
+// 64-bit integers: the addend's digits on the grids 2^20, 2^-20, 2^-60, 2^-100 (each digit |q| < 2^40, so 2^22 addends fit a
+// limb), plus a count of addends that have no such digits (non-finite or >= 2^60).  Every addend of magnitude >= 2^-47 is
+// represented exactly, the split is a function of the addend alone and integer addition is associative: the five integers --
+// and the double limb_value makes of them -- do not depend on the order of the additions, on how the addends are dealt to
+// threads and workgroups, or on how the observations are dealt to RANKS (the limbs are all-reduced as integers).
+constexpr int PXR_LIMBS = 5;      // four digits + the count of unrepresentable addends
+struct Limbs {
+  long long q[PXR_LIMBS];
+  __device__ __forceinline__ Limbs() { for (int k = 0; k < PXR_LIMBS; ++k) q[k] = 0; }
+  __device__ __forceinline__ void add(double x) {
+    if (!(fabs(x) < 0x1p60)) { ++q[4]; return; }                       // NaN, Inf, out of range
+    double t = trunc(x * 0x1p-20); q[0] += (long long)t; x -= t * 0x1p20;      // every step exact: the remainder keeps x's sign
+    t = trunc(x * 0x1p20); q[1] += (long long)t; x -= t * 0x1p-20;
+    t = trunc(x * 0x1p60); q[2] += (long long)t; x -= t * 0x1p-60;
+    q[3] += (long long)rint(x * 0x1p100);
+  }
+};
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+// the workgroup's limbs added to the global slot (PXR_LIMBS integer atomics per workgroup); `sh`: PXR_LIMBS * (blockDim / 64) slots of LDS
+__device__ __forceinline__ void limbs_block_add(Limbs l, long long* __restrict__ slot, long long* sh) {
+  const int nw = (int)blockDim.x >> 6, w = (int)threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < PXR_LIMBS; ++k) {
+    const long long v = wave_sum_ll(l.q[k]);
+    if ((threadIdx.x & 63) == 0) sh[k * nw + w] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < PXR_LIMBS) {
+    long long v = 0;
+    for (int i = 0; i < nw; ++i) v += sh[threadIdx.x * nw + i];
+    if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(slot + threadIdx.x), (unsigned long long)v);
+  }
+}
+__device__ __forceinline__ double limb_value(const long long* q) {
+  if (q[4] != 0) return __longlong_as_double(0x7ff8000000000000ll);   // an addend could not be represented: NaN (rejects the step)
+  return (((double)q[3] * 0x1p-100 + (double)q[2] * 0x1p-60) + (double)q[1] * 0x1p-20) + (double)q[0] * 0x1p20;
+}
+
 // ---- 16-lane (DPP row) all-reduce --------------------------------------------------------
 // quad_perm[1,0,3,2] -> quad_perm[2,3,0,1] -> row_half_mirror -> row_mirror: after the four
 // steps every lane of the row holds the row sum.  No LDS, no ds_bpermute.

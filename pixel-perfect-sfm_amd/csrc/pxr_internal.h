@@ -26,7 +26,7 @@ struct pxr_ctx {
   void* h_stage[2] = {nullptr, nullptr};      // pinned staging buffers of the patch uploads (pxr_arena_upload*), lazily allocated
   hipEvent_t ev_stage[2] = {nullptr, nullptr};
   size_t stage_bytes = 0;
-  bool deterministic = false;    // pxr_set_deterministic / PXR_DETERMINISTIC=1: order-independent accumulation in the solvers
+  bool deterministic = true;     // pxr_set_deterministic / PXR_DETERMINISTIC=0 opts out: order- and partition-independent accumulation in the solvers
   bool gram_cache = false;       // pxr_set_gram_cache / PXR_GRAM_CACHE=1: pxr_ba_solve evaluates from cached Gram matrices (pxr_ba_gram.hip)
   void* d_gram = nullptr;        // grow-only storage of that cache
   size_t gram_bytes = 0;
@@ -53,6 +53,7 @@ inline int hip_check(hipError_t e, const char* what) {
 }
 // in-place all-reduce(sum) on the context's stream through its RCCL communicator (no-op without one)
 int comm_allreduce_sum(pxr_ctx* ctx, double* d_buf, int64_t count, bool even_single_rank = false);
+int comm_allreduce_sum_i64(pxr_ctx* ctx, long long* d_buf, int64_t count);
 // pxr_ba_eval with the cost reduction fused into the residual kernel: *d_cost_sum += sum 0.5 rho(|r|^2)
 int ba_eval_with_cost(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
                       int with_jacobian, double* d_rec, double* d_r, double* d_gx, double* d_gy,

@@ -59,7 +59,10 @@ struct KaArgs {
   double* Hbuf; double* Abuf;
   pxr_lm_summary* summaries;   // device [n_problems]
   double det_scale;            // 0: floating-point atomics; 2^k: deterministic fixed-point accumulation of H and g (pxr_device.h)
+  double* prob_scale;          // deterministic mode, [n_problems]: every sub-problem's grid (det_scale until its overflow guard asks for a coarser one)
+  uint8_t* prob_done;          // deterministic mode, [n_problems]: the sub-problem finished (a repeated launch skips it)
 };
+constexpr int KA_TERM_RESCALE = 100;   // internal termination code: the sub-problem's fixed-point grid did not fit, launch again
 
 // Channel layout of a node over lanes: 8 channels per lane (one 16-byte fp16 load) for the CNN feature sizes, and the
 // whole descriptor in ONE lane for CHANNELS < 8 -- the reference instantiates (128, 1) and (1, 1)
@@ -162,7 +165,30 @@ struct KaProb {
   const KaNodeMeta* cnode = nullptr;   // LDS: metadata of the first KA_NODE_CACHE nodes / KA_EDGE_CACHE edges of the problem
   const KaEdgeMeta* cedge = nullptr;   // (solve kernel only; the rest, and every other caller, reads global memory)
   double* csq = nullptr;               // LDS: squared residual norms of the cached edges (cost-only pass)
+  // deterministic mode (solve kernel): the sub-problem's fixed-point grid (0: floating-point atomics) and the limbs of the trace
+  // of its normal matrix in LDS (pxr_device.h) -- the overflow guard: every entry of H is bounded by the trace
+  double det_scale = 0.0;
+  long long* trace = nullptr;
 };
+// DET: the kernel instantiation of the deterministic mode adds fixed-point integers only; the other floating-point atomics only
+template <bool DET>
+__device__ __forceinline__ void ka_accum(double* slot, double v, double det_scale) {
+  if constexpr (DET) atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double2ll_rn(v * det_scale));
+  else atomicAdd(slot, v);
+}
+__device__ __forceinline__ void ka_trace_add(const KaProb& p, double v) {
+  // (the digits of Limbs::add as scalars: an array of integers in this register-capped kernel ends up in scratch)
+  unsigned long long* t = reinterpret_cast<unsigned long long*>(p.trace);
+  if (!(fabs(v) < 0x1p60)) { atomicAdd(t + 4, 1ull); return; }
+  double d = trunc(v * 0x1p-20); v -= d * 0x1p20;
+  if (d != 0.0) atomicAdd(t + 0, (unsigned long long)(long long)d);
+  d = trunc(v * 0x1p20); v -= d * 0x1p-20;
+  if (d != 0.0) atomicAdd(t + 1, (unsigned long long)(long long)d);
+  d = trunc(v * 0x1p60); v -= d * 0x1p-60;
+  if (d != 0.0) atomicAdd(t + 2, (unsigned long long)(long long)d);
+  d = rint(v * 0x1p100);
+  if (d != 0.0) atomicAdd(t + 3, (unsigned long long)(long long)d);
+}
 
 // evaluate all nodes of the problem at keypoints `kp`
 template <typename ST, int C, bool WITH_JAC>
@@ -224,10 +250,11 @@ __device__ __forceinline__ double ka_kappa(double s, const double* rho) {
 
 // walk the edges and the unary terms; returns the cost (block-uniform).  WITH_JAC: accumulates Hm
 // and g (unscaled).
-template <int C, bool WITH_JAC>
+template <int C, bool WITH_JAC, bool DET = false>
 __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
   constexpr int LPO = KaLay<C>::LPO, CPL = KaLay<C>::CPL, G = KA_NT / LPO;
   const int grp = threadIdx.x / LPO, sub = threadIdx.x % LPO;
+  const double det_scale = DET ? p.det_scale : 0.0;
   double cost = 0.0;
   int64_t i_first = p.ne0 + grp;
   if constexpr (!WITH_JAC) {
@@ -329,14 +356,17 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
             const double b[4] = {q[10], q[11], q[12], q[13]};
             const double mm[4][4] = {{q[0], q[1], q[2], q[3]}, {q[1], q[4], q[5], q[6]}, {q[2], q[5], q[7], q[8]}, {q[3], q[6], q[8], q[9]}};
             double* blk = p.Hm + (p.row_off[vv] - (vv - c0) * nc);
+            double tr = 0.0;
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
               if (!var[x]) continue;
-              accum_add(p.g + idx[x], rho[1] * b[x], a.det_scale);
+              ka_accum<DET>(p.g + idx[x], rho[1] * b[x], det_scale);
+              tr += rho[1] * (mm[x][x] - kappa * b[x] * b[x]);
 #pragma unroll
               for (int y = 0; y < 4; ++y)
-                if (var[y]) accum_add(blk + (size_t)(idx[x] - c0) * nc + (idx[y] - c0), rho[1] * (mm[x][y] - kappa * b[x] * b[y]), a.det_scale);
+                if (var[y]) ka_accum<DET>(blk + (size_t)(idx[x] - c0) * nc + (idx[y] - c0), rho[1] * (mm[x][y] - kappa * b[x] * b[y]), det_scale);
             }
+            if constexpr (DET) ka_trace_add(p, tr);
           }
         }
       }
@@ -393,14 +423,17 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
           const double b[4] = {q[10], q[11], q[12], q[13]};
           const double m[4][4] = {{q[0], q[1], q[2], q[3]}, {q[1], q[4], q[5], q[6]}, {q[2], q[5], q[7], q[8]}, {q[3], q[6], q[8], q[9]}};
           double* blk = p.Hm + (p.row_off[vv] - (vv - c0) * nc);
+          double tr = 0.0;
 #pragma unroll
           for (int x = 0; x < 4; ++x) {
             if (!var[x]) continue;
-            accum_add(p.g + idx[x], rho[1] * b[x], a.det_scale);
+            ka_accum<DET>(p.g + idx[x], rho[1] * b[x], det_scale);
+            tr += rho[1] * (m[x][x] - kappa * b[x] * b[x]);
 #pragma unroll
             for (int y = 0; y < 4; ++y)
-              if (var[y]) accum_add(blk + (size_t)(idx[x] - c0) * nc + (idx[y] - c0), rho[1] * (m[x][y] - kappa * b[x] * b[y]), a.det_scale);
+              if (var[y]) ka_accum<DET>(blk + (size_t)(idx[x] - c0) * nc + (idx[y] - c0), rho[1] * (m[x][y] - kappa * b[x] * b[y]), det_scale);
           }
+          if constexpr (DET) ka_trace_add(p, tr);
         }
       }
     }
@@ -435,12 +468,13 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
         const double kappa = ka_kappa(s, rho);
         const int nc = p.row_nc[v1], c0 = p.row_v0[v1];
         double* row = p.Hm + p.row_off[v1] + (v1 - c0);
-        accum_add(p.g + v1, rho[1] * q[3], a.det_scale);
-        accum_add(p.g + v1 + 1, rho[1] * q[4], a.det_scale);
-        accum_add(row, rho[1] * (q[0] - kappa * q[3] * q[3]), a.det_scale);
-        accum_add(row + 1, rho[1] * (q[1] - kappa * q[3] * q[4]), a.det_scale);
-        accum_add(row + nc, rho[1] * (q[1] - kappa * q[3] * q[4]), a.det_scale);
-        accum_add(row + nc + 1, rho[1] * (q[2] - kappa * q[4] * q[4]), a.det_scale);
+        ka_accum<DET>(p.g + v1, rho[1] * q[3], det_scale);
+        ka_accum<DET>(p.g + v1 + 1, rho[1] * q[4], det_scale);
+        ka_accum<DET>(row, rho[1] * (q[0] - kappa * q[3] * q[3]), det_scale);
+        ka_accum<DET>(row + 1, rho[1] * (q[1] - kappa * q[3] * q[4]), det_scale);
+        ka_accum<DET>(row + nc, rho[1] * (q[1] - kappa * q[3] * q[4]), det_scale);
+        ka_accum<DET>(row + nc + 1, rho[1] * (q[2] - kappa * q[4] * q[4]), det_scale);
+        if constexpr (DET) ka_trace_add(p, rho[1] * (q[0] - kappa * q[3] * q[3]) + rho[1] * (q[2] - kappa * q[4] * q[4]));
       }
     }
   }
@@ -773,16 +807,21 @@ __global__ __launch_bounds__(KA_NT) void ka_setup_kernel(const KaArgs a, KaInfo*
 #define KA_T(k) do { } while (0)
 #endif
 
-template <typename ST, int C>
+template <typename ST, int C, bool DET>
 __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __restrict__ info, double* sh_A) {
 #ifdef PXR_KA_PROFILE
   long long ka_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ka_t0 = wall_clock64();
 #endif
   __shared__ double sh4[KA_NT / 64];
   __shared__ int sh_ok;
+  __shared__ long long sh_trace[PXR_LIMBS];
   const int prob = blockIdx.x, tid = threadIdx.x;
   const bool fsimd = a.float_simd != 0;
   KaProb p;
+  if (DET && a.prob_done[prob]) return;                  // (a repeated launch after a grid change: this sub-problem had finished)
+  p.det_scale = DET ? a.prob_scale[prob] : 0.0;
+  p.trace = DET ? sh_trace : nullptr;
+  double need_rescale = 0.0;                             // set by the overflow guard of a linearisation: the bound that did not fit
   p.np0 = a.v.d_prob_node_ptr[prob]; p.np1 = a.v.d_prob_node_ptr[prob + 1];
   p.ne0 = a.v.d_prob_edge_ptr[prob]; p.ne1 = a.v.d_prob_edge_ptr[prob + 1];
   p.nu0 = p.nu1 = 0;
@@ -853,18 +892,30 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   const int64_t nodes_all = p.np1 - p.np0, nodes_var = n / 2;
   auto linearize = [&](bool compute_scale) -> double {
     stencils += nodes_all;
-    for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = 0.0;
-    for (int e = tid; e < n; e += blockDim.x) p.g[e] = 0.0;
-    __syncthreads();
     KA_T(7);
     ka_nodes<ST, C, true>(a, p, a.v.d_kp, fsimd);
     KA_T(0);
-    const double c = ka_terms<C, true>(a, p, sh4);
+    for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = 0.0;
+    for (int e = tid; e < n; e += blockDim.x) p.g[e] = 0.0;
+    if (DET && tid < PXR_LIMBS) sh_trace[tid] = 0;
     __syncthreads();
+    const double c = ka_terms<C, true, DET>(a, p, sh4);
+    __syncthreads();
+    if constexpr (DET) {
+      // The overflow guard of the fixed-point slots.  Integer atomics wrap modulo 2^64, so only the FINAL content of a slot has
+      // to fit: |H_ab| <= max diag(H) <= trace(H) (each block's J^T J with the corrector is positive semi-definite) and
+      // |g_a| <= sqrt(H_aa 2 cost) (Cauchy-Schwarz; rho concave: rho' s <= rho).  The trace was accumulated beside the slots as
+      // limbs (exact, order-independent): the grid fits if 16 max(trace, sqrt(2 trace cost)) stays below 2^62 units.  Otherwise
+      // the sub-problem stops here and asks the host for a launch on a grid made for that bound (raw, un-normalised features:
+      // the 2^-38 default is made for unit-norm descriptors).  Every thread reads the same five integers: a uniform decision.
+      const double tr = limb_value(sh_trace);
+      const double bound = 16.0 * fmax(tr, sqrt(2.0 * tr * fmax(c, 0.0)));
+      if (bound * p.det_scale > 0x1p62 && isfinite(bound)) need_rescale = bound;     // (a non-finite Jacobian fails the solve below as before)
+    }
     KA_T(1);
-    if (a.det_scale != 0.0) {            // deterministic mode: the slots hold fixed-point integers
-      for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = accum_value(p.Hm[e], a.det_scale);
-      for (int e = tid; e < n; e += blockDim.x) p.g[e] = accum_value(p.g[e], a.det_scale);
+    if constexpr (DET) {                 // deterministic mode: the slots hold fixed-point integers
+      for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = (double)__double_as_longlong(p.Hm[e]) / p.det_scale;
+      for (int e = tid; e < n; e += blockDim.x) p.g[e] = (double)__double_as_longlong(p.g[e]) / p.det_scale;
       __syncthreads();
     }
     for (int e = tid; e < n; e += blockDim.x) {
@@ -898,15 +949,20 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     ka_nodes<ST, C, false>(a, p, a.v.d_kp, fsimd);
     const double c = ka_terms<C, false>(a, p, sh4);
     sm.initial_cost = sm.final_cost = c; sm.termination = PXR_TERM_CONVERGENCE;
-    if (tid == 0) a.summaries[prob] = sm;
+    if (tid == 0) { a.summaries[prob] = sm; if (DET) a.prob_done[prob] = 1; }
     return;
   }
   double cost = linearize(true);
   sm.initial_cost = cost;
+  if (DET && need_rescale != 0.0) {         // the grid does not fit this sub-problem: nothing was changed, the host launches again
+    sm.final_cost = cost; sm.termination = KA_TERM_RESCALE; sm.linear_iterations = stencils;
+    if (tid == 0) { a.summaries[prob] = sm; a.prob_scale[prob] = exp2((double)(62 - (int)ceil(log2(need_rescale)))); }
+    return;
+  }
   if (!inf.feasible || !isfinite(cost)) {   // [upstream] Program::IsFeasible fails / the initial evaluation fails
                                             // (non-finite input): FAILURE, parameters untouched
     sm.final_cost = cost; sm.termination = PXR_TERM_FAILURE;
-    if (tid == 0) a.summaries[prob] = sm;
+    if (tid == 0) { a.summaries[prob] = sm; if (DET) a.prob_done[prob] = 1; }
     return;
   }
   double radius = opt.initial_radius, decrease_factor = 2.0;
@@ -1035,6 +1091,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       __syncthreads();
       cost = linearize(false);
       ++sm.num_successful;
+      if (DET && need_rescale != 0.0) { sm.termination = KA_TERM_RESCALE; break; }     // (the accepted keypoints stay; the next launch goes on from them)
       const double tmp = 2.0 * rel - 1.0;
       radius = fmin(opt.max_radius, radius / fmax(1.0 / 3.0, 1.0 - tmp * tmp * tmp));
       decrease_factor = 2.0; reuse_diag = false;
@@ -1043,7 +1100,13 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     }
   }
   sm.final_cost = cost; sm.final_radius = radius; sm.linear_iterations = stencils;
-  if (tid == 0) a.summaries[prob] = sm;
+  if (tid == 0) {
+    a.summaries[prob] = sm;
+    if (DET) {
+      if (sm.termination == KA_TERM_RESCALE) a.prob_scale[prob] = exp2((double)(62 - (int)ceil(log2(need_rescale))));
+      else a.prob_done[prob] = 1;
+    }
+  }
 #ifdef PXR_KA_PROFILE
   KA_T(7);
   if (blockIdx.x == 0 && tid == 0)
@@ -1058,18 +1121,18 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
 // scratch) the whole config-2 solve drops from 12.7 to 9.6 ms.  The fp64-storage instantiations keep the
 // compiler's own budget: capped, they spill ~950 registers.  (A tighter cap of 3 waves/SIMD produced
 // wrong steps on ROCm 7.2 and is not used.)
-template <typename ST, int C>
+template <typename ST, int C, bool DET>
 #ifndef PXR_KA_WAVES   // debugging knob of tools/ka_occupancy_probe.sh (the 3-waves build that gave wrong steps)
 #define PXR_KA_WAVES 2
 #endif
 __global__ __launch_bounds__(KA_NT) __attribute__((amdgpu_waves_per_eu(PXR_KA_WAVES, PXR_KA_WAVES))) void ka_solve_kernel_occ2(const KaArgs a, const KaInfo* __restrict__ info) {
   extern __shared__ double sh_A[];      // lds_elems doubles (damped blocks) when the sub-problem fits
-  ka_solve_body<ST, C>(a, info, sh_A);
+  ka_solve_body<ST, C, DET>(a, info, sh_A);
 }
-template <typename ST, int C>
+template <typename ST, int C, bool DET>
 __global__ __launch_bounds__(KA_NT) void ka_solve_kernel(const KaArgs a, const KaInfo* __restrict__ info) {
   extern __shared__ double sh_A[];
-  ka_solve_body<ST, C>(a, info, sh_A);
+  ka_solve_body<ST, C, DET>(a, info, sh_A);
 }
 
 // ---- per-edge evaluation (parity checks) -------------------------------------------------------------------
@@ -1202,6 +1265,7 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   const size_t o_irow = carve(sizeof(int) * nn * 6), o_comp = carve(sizeof(int) * nn), o_used = carve(nn);
   const size_t o_hptr = carve(sizeof(int64_t) * (np + 1)), o_sum = carve(sizeof(pxr_lm_summary) * np);
   const size_t o_info = carve(sizeof(KaInfo) * np);
+  const size_t o_pscale = carve(sizeof(double) * np), o_pdone = carve(np);
   if (int rc = grow(&ctx->d_workspace, &ctx->workspace_bytes, off)) return rc;
   char* ws = static_cast<char*>(ctx->d_workspace);
   int64_t* d_hptr = (int64_t*)(ws + o_hptr);
@@ -1214,6 +1278,13 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   // deterministic mode: H and g of a sub-problem as 2^-38 fixed point (range +-3e7: a residual block adds |J|^2 <= a few
   // hundred at most -- unit descriptors, gradients per pixel; resolution 3.6e-12)
   a.det_scale = ctx->deterministic ? 274877906944.0 : 0.0;
+  a.prob_scale = (double*)(ws + o_pscale); a.prob_done = (uint8_t*)(ws + o_pdone);
+  if (a.det_scale != 0.0) {
+    std::vector<double> init((size_t)np, a.det_scale);
+    PXR_HIP(hipMemcpyAsync(a.prob_scale, init.data(), sizeof(double) * np, hipMemcpyHostToDevice, st));
+    PXR_HIP(hipMemsetAsync(a.prob_done, 0, np, st));
+    PXR_HIP(hipStreamSynchronize(st));       // (`init` leaves scope)
+  }
   a.desc = (double*)(ws + o_desc); a.kp_cand = (double*)(ws + o_cand); a.vec = (double*)(ws + o_vec);
   a.var_of_node = (int*)(ws + o_var); a.label = (int*)(ws + o_label); a.ipos = (int*)(ws + o_ipos);
   a.irow = (int*)(ws + o_irow); a.comp_v0 = (int*)(ws + o_comp); a.used = (uint8_t*)(ws + o_used);
@@ -1247,33 +1318,54 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   const size_t shmem = a.lds_state_n > 0 ? state_bytes : sizeof(double) * (size_t)lds_elems;
 #define KA_SOLVE_LAUNCH(KERNEL, ST, CC)                                                                      \
   do {                                                                                                       \
-    PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<ST, CC>),                               \
+    void (*kfn)(const KaArgs, const KaInfo*) = a.det_scale != 0.0 ? KERNEL<ST, CC, true> : KERNEL<ST, CC, false>; \
+    PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                                          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                    \
     PXR_HIP(hipEventRecord(ctx->ev_start, st));                                                              \
-    hipLaunchKernelGGL((KERNEL<ST, CC>), dim3(np), dim3(KA_NT), shmem, st, a, d_info);                       \
+    hipLaunchKernelGGL(kfn, dim3(np), dim3(KA_NT), shmem, st, a, d_info);                                    \
     PXR_HIP(hipEventRecord(ctx->ev_stop, st));                                                               \
   } while (0)
-  if (arena->dtype == PXR_F16 && arena->C == 128) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, _Float16, 128);
-  else if (arena->dtype == PXR_F16 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, _Float16, 64);
-  else if (arena->dtype == PXR_F32 && arena->C == 128) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, float, 128);
-  else if (arena->dtype == PXR_F64 && arena->C == 128) KA_SOLVE_LAUNCH(ka_solve_kernel, double, 128);
-  else if (arena->dtype == PXR_F32 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, float, 64);
-  else if (arena->dtype == PXR_F64 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel, double, 64);
-  else if (arena->dtype == PXR_F16 && arena->C == 1) KA_SOLVE_LAUNCH(ka_solve_kernel, _Float16, 1);
-  else if (arena->dtype == PXR_F32 && arena->C == 1) KA_SOLVE_LAUNCH(ka_solve_kernel, float, 1);
-  else if (arena->dtype == PXR_F64 && arena->C == 1) KA_SOLVE_LAUNCH(ka_solve_kernel, double, 1);
-  else return set_error(PXR_EUNSUPPORTED, "pxr_ka_solve: CHANNELS=%d not supported (128, 64, 1)", arena->C);
-#undef KA_SOLVE_LAUNCH
-  PXR_HIP(hipGetLastError());
-  std::vector<pxr_lm_summary> sums(np);
-  PXR_HIP(hipMemcpyAsync(sums.data(), d_sum, sizeof(pxr_lm_summary) * np, hipMemcpyDeviceToHost, st));
-  PXR_HIP(hipStreamSynchronize(st));
-  total->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  {   // setup_ms = everything but the solve kernel itself (workspace, uploads, summaries download)
+  std::vector<pxr_lm_summary> sums(np), pass(np);
+  double kernel_ms = 0.0;
+  // One launch solves every sub-problem.  Deterministic mode: a sub-problem whose fixed-point grid does not fit (its overflow
+  // guard; raw un-normalised features) stops with KA_TERM_RESCALE and its new grid in prob_scale -- launch again: finished
+  // sub-problems return at once, the others go on from their current keypoints.  (Never more than one launch with unit-norm
+  // descriptors.)
+  for (int launch = 0; launch < 8; ++launch) {
+    if (arena->dtype == PXR_F16 && arena->C == 128) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, _Float16, 128);
+    else if (arena->dtype == PXR_F16 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, _Float16, 64);
+    else if (arena->dtype == PXR_F32 && arena->C == 128) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, float, 128);
+    else if (arena->dtype == PXR_F64 && arena->C == 128) KA_SOLVE_LAUNCH(ka_solve_kernel, double, 128);
+    else if (arena->dtype == PXR_F32 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, float, 64);
+    else if (arena->dtype == PXR_F64 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel, double, 64);
+    else if (arena->dtype == PXR_F16 && arena->C == 1) KA_SOLVE_LAUNCH(ka_solve_kernel, _Float16, 1);
+    else if (arena->dtype == PXR_F32 && arena->C == 1) KA_SOLVE_LAUNCH(ka_solve_kernel, float, 1);
+    else if (arena->dtype == PXR_F64 && arena->C == 1) KA_SOLVE_LAUNCH(ka_solve_kernel, double, 1);
+    else return set_error(PXR_EUNSUPPORTED, "pxr_ka_solve: CHANNELS=%d not supported (128, 64, 1)", arena->C);
+    PXR_HIP(hipGetLastError());
+    PXR_HIP(hipMemcpyAsync(pass.data(), d_sum, sizeof(pxr_lm_summary) * np, hipMemcpyDeviceToHost, st));
+    PXR_HIP(hipStreamSynchronize(st));
     float kms = 0.f;
     PXR_HIP(hipEventElapsedTime(&kms, ctx->ev_start, ctx->ev_stop));
-    total->setup_ms = total->total_ms - (double)kms;
+    kernel_ms += (double)kms;
+    bool again = false;
+    for (int i = 0; i < np; ++i) {
+      if (launch == 0) { sums[i] = pass[i]; }
+      else if (sums[i].termination == KA_TERM_RESCALE) {        // this launch continued sub-problem i: merge
+        const pxr_lm_summary before = sums[i];
+        sums[i] = pass[i];
+        sums[i].initial_cost = before.initial_cost;
+        sums[i].iterations += before.iterations; sums[i].num_successful += before.num_successful;
+        sums[i].linear_iterations += before.linear_iterations;
+      }
+      again = again || sums[i].termination == KA_TERM_RESCALE;
+    }
+    if (!again) break;
+    PXR_REQUIRE(launch < 7, "pxr_ka_solve: the fixed-point grid of the deterministic mode could not be fitted (non-finite features?)");
   }
+#undef KA_SOLVE_LAUNCH
+  total->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  total->setup_ms = total->total_ms - kernel_ms;   // everything but the solve kernel itself (workspace, uploads, summaries download)
   total->termination = PXR_TERM_CONVERGENCE;
   for (int i = 0; i < np; ++i) {   // AccumulateSummaries (util/src/statistics.h:131-160)
     total->initial_cost += sums[i].initial_cost; total->final_cost += sums[i].final_cost;

@@ -801,7 +801,7 @@ def compact_line(full):
         if not v:
             continue
         o = _pick(v, ("iters_per_sec", "ms_per_iter", "iterations", "successful", "setup_ms", "reduced_system",
-                      "linear_iterations", "inner_iterations", "deterministic_mode", "gram_cache_mode"))
+                      "linear_iterations", "inner_iterations", "deterministic_mode", "gram_cache_mode", "collective_KiB_per_solve"))
         o["initial_cost"], o["final_cost"] = _r(v.get("initial_cost"), 10), _r(v.get("final_cost"), 10)
         o["linear_solver"] = "direct: Schur + dense Cholesky" if str(v.get("linear_solver", "")).startswith("point") else "iterative: implicit Schur PCG"
         for sub in ("texel_evaluation", "nondeterministic", "gram_cache", "deterministic"):

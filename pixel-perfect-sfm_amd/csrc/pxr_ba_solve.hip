@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_schur(const SolveDev d, const int64_t* 
                                                const int64_t* __restrict__ pt_obs,
                                                const double* __restrict__ W, const double* __restrict__ T,
                                                const double* __restrict__ gp, double* __restrict__ S,
-                                               double* __restrict__ rhs) {
+                                               double* __restrict__ rhs, double det_scale) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t i = tid / d.DC;
   const int a = (int)(tid - i * d.DC);
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void k_schur(const SolveDev d, const int64_t* 
   double y0, y1, y2;
   y_row(W, T, i, a, d.DC, pt, y0, y1, y2);
   const int r = col_index(d, img, cam, a);
-  atomicAdd(rhs + (size_t)r * d.ldS, -(y0 * gp[3 * (size_t)pt] + y1 * gp[3 * (size_t)pt + 1] + y2 * gp[3 * (size_t)pt + 2]));
+  accum_add(rhs + (size_t)r * d.ldS, -(y0 * gp[3 * (size_t)pt] + y1 * gp[3 * (size_t)pt + 1] + y2 * gp[3 * (size_t)pt + 2]), det_scale);
   for (int64_t o = pt_ptr[pt]; o < pt_ptr[pt + 1]; ++o) {
     const int64_t j = pt_obs[o];
     const int imgj = d.v.d_obs_image[j], camj = d.v.d_image_camera[imgj];
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_schur(const SolveDev d, const int64_t* 
     for (int b = 0; b < dcj; ++b) {
       const int c = col_index(d, imgj, camj, b);
       if (r > c) continue;   // upper triangle only: the mirrored entry comes from the ordered pair (j, i)
-      atomicAdd(S + (size_t)r * d.ldS + c, -(y0 * Wj[3 * b] + y1 * Wj[3 * b + 1] + y2 * Wj[3 * b + 2]));
+      accum_add(S + (size_t)r * d.ldS + c, -(y0 * Wj[3 * b] + y1 * Wj[3 * b + 1] + y2 * Wj[3 * b + 2]), det_scale);
     }
   }
 }
@@ -495,9 +495,10 @@ __global__ void k_copy_upper_add_diag(int n, const double* __restrict__ U, const
   const int r = (int)(t / ld), c = (int)(t % ld);
   double v = S[t];
   if (add_u) {
+    // deterministic mode: U still holds its fixed-point integers (the same grid), the Schur kernel adds integers to these slots and
+    // k_det_finish turns the sums back -- AFTER the ranks' integers were added: a slot of 2^59 units does not survive a round
+    // trip through a double (53 bits), and rounding every rank's partial sum would make the result depend on the partition
     v = (c < n && r <= c) ? U[(size_t)r * n + c] : 0.0;
-    // deterministic mode: the Schur kernel adds fixed-point integers to these slots (k_det_finish turns them back)
-    if (det_scale != 0.0) v = __longlong_as_double(__double2ll_rn(v * det_scale));
   }
   else {
     if (r == c) v += damp[r] * inv_radius;
@@ -1278,7 +1279,10 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   //    observation / point / column.
   //  * several ranks: the integers are all-reduced as integers (ncclInt64; through a sum-of-doubles callback as exact 32-bit
   //    halves), replicated quantities are computed identically by every rank and need no broadcast.
-  const bool det = ctx->deterministic && !iterative;
+  // (The grids need the Jacobi scaling of the options -- Ceres' and pixsfm's default: without it the large columns of the
+  //  unscaled Jacobian, rotations ~1e6, set a grid that drowns the small ones, focal length ~1e-2.  A solve that turns the
+  //  scaling off, and the iterative solver, use floating-point atomics.)
+  const bool det = ctx->deterministic && !iterative && opt->jacobi_scaling != 0;
   const bool bcast = multi && ctx->nranks > 1 && !det;
   auto from_rank0 = [&](double* buf, int64_t count) -> int {
     if (!bcast) return PXR_OK;
@@ -1375,7 +1379,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
         hipLaunchKernelGGL(k_trace_limbs, dim3(1), dim3(256), 0, st, (const double*)chunk_trace.p, (int)chunks.size(),
                            reinterpret_cast<long long*>(gcd.p + 2 * nc1));
         RC(ar_i64(reinterpret_cast<long long*>(gcd.p), 2 * (int64_t)nc1 + PXR_LIMBS));
-        hipLaunchKernelGGL(k_det_finish, dim3(nblk((int64_t)U.n)), dim3(256), 0, st, (int64_t)U.n, U.p, lin_scale);
+        // (U itself stays in fixed point: only the Schur complement reads it, as integers)
         hipLaunchKernelGGL(k_det_finish, dim3(nblk(2 * (int64_t)nc1)), dim3(256), 0, st, 2 * (int64_t)nc1, gcd.p, lin_scale);
         hipLaunchKernelGGL(k_diag_stats, dim3(1), dim3(256), 0, st, n_c, (const double*)diagU, reinterpret_cast<const long long*>(gcd.p + 2 * nc1), lin_stats.p);
         LAUNCH_CHECK("linearize kernels");
@@ -1598,7 +1602,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
         if (DC <= 8) SCHUR_LAUNCH(8); else if (DC <= 16) SCHUR_LAUNCH(16); else SCHUR_LAUNCH(32);
 #undef SCHUR_LAUNCH
       } else {
-        hipLaunchKernelGGL(k_schur, dim3(nblk(n_obs * DC)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, W.p, T.p, gp.p, S.p, rhs);
+        hipLaunchKernelGGL(k_schur, dim3(nblk(n_obs * DC)), dim3(256), 0, st, dv, d_pt_ptr.p, d_pt_obs.p, W.p, T.p, gp.p, S.p, rhs, schur_scale);
       }
       LAUNCH_CHECK("schur kernels");
       phase(0);

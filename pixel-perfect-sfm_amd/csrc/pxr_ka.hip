@@ -167,7 +167,6 @@ struct KaProb {
   double* csq = nullptr;               // LDS: squared residual norms of the cached edges (cost-only pass)
   // deterministic mode (solve kernel): the sub-problem's fixed-point grid (0: floating-point atomics) and the limbs of the trace
   // of its normal matrix in LDS (pxr_device.h) -- the overflow guard: every entry of H is bounded by the trace
-  double det_scale = 0.0;
   long long* trace = nullptr;
 };
 // DET: the kernel instantiation of the deterministic mode adds fixed-point integers only; the other floating-point atomics only
@@ -251,10 +250,9 @@ __device__ __forceinline__ double ka_kappa(double s, const double* rho) {
 // walk the edges and the unary terms; returns the cost (block-uniform).  WITH_JAC: accumulates Hm
 // and g (unscaled).
 template <int C, bool WITH_JAC, bool DET = false>
-__device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4) {
+__device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4, const double det_scale = 0.0) {
   constexpr int LPO = KaLay<C>::LPO, CPL = KaLay<C>::CPL, G = KA_NT / LPO;
   const int grp = threadIdx.x / LPO, sub = threadIdx.x % LPO;
-  const double det_scale = DET ? p.det_scale : 0.0;
   double cost = 0.0;
   int64_t i_first = p.ne0 + grp;
   if constexpr (!WITH_JAC) {
@@ -819,9 +817,9 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   const bool fsimd = a.float_simd != 0;
   KaProb p;
   if (DET && a.prob_done[prob]) return;                  // (a repeated launch after a grid change: this sub-problem had finished)
-  p.det_scale = DET ? a.prob_scale[prob] : 0.0;
+  double grid = DET ? a.prob_scale[prob] : 0.0;         // the sub-problem's fixed-point grid (2^k), adapted at every linearisation
   p.trace = DET ? sh_trace : nullptr;
-  double need_rescale = 0.0;                             // set by the overflow guard of a linearisation: the bound that did not fit
+  double need_rescale = 0.0;                             // set by the overflow guard of a linearisation: the grid to launch again with
   p.np0 = a.v.d_prob_node_ptr[prob]; p.np1 = a.v.d_prob_node_ptr[prob + 1];
   p.ne0 = a.v.d_prob_edge_ptr[prob]; p.ne1 = a.v.d_prob_edge_ptr[prob + 1];
   p.nu0 = p.nu1 = 0;
@@ -890,7 +888,8 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   // the algorithmic traffic of the solve is 16 texels x C x sizeof(storage) each, reported as summary.linear_iterations
   int64_t stencils = 0;
   const int64_t nodes_all = p.np1 - p.np0, nodes_var = n / 2;
-  auto linearize = [&](bool compute_scale) -> double {
+  auto linearize = [&](auto first_tag) -> double {
+    constexpr bool compute_scale = decltype(first_tag)::value;      // the FIRST linearisation of the solve
     stencils += nodes_all;
     KA_T(7);
     ka_nodes<ST, C, true>(a, p, a.v.d_kp, fsimd);
@@ -899,24 +898,39 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     for (int e = tid; e < n; e += blockDim.x) p.g[e] = 0.0;
     if (DET && tid < PXR_LIMBS) sh_trace[tid] = 0;
     __syncthreads();
-    const double c = ka_terms<C, true, DET>(a, p, sh4);
+    double c = ka_terms<C, true, DET>(a, p, sh4, grid);
     __syncthreads();
     if constexpr (DET) {
-      // The overflow guard of the fixed-point slots.  Integer atomics wrap modulo 2^64, so only the FINAL content of a slot has
-      // to fit: |H_ab| <= max diag(H) <= trace(H) (each block's J^T J with the corrector is positive semi-definite) and
-      // |g_a| <= sqrt(H_aa 2 cost) (Cauchy-Schwarz; rho concave: rho' s <= rho).  The trace was accumulated beside the slots as
-      // limbs (exact, order-independent): the grid fits if 16 max(trace, sqrt(2 trace cost)) stays below 2^62 units.  Otherwise
-      // the sub-problem stops here and asks the host for a launch on a grid made for that bound (raw, un-normalised features:
-      // the 2^-38 default is made for unit-norm descriptors).  Every thread reads the same five integers: a uniform decision.
+      // The fixed-point grid of the slots follows the data.  Integer atomics wrap modulo 2^64, so only the FINAL content of a
+      // slot has to fit: |H_ab| <= max diag(H) <= trace(H) (each block's J^T J with the corrector is positive semi-definite),
+      // |g_a| <= sqrt(H_aa 2 cost) (Cauchy-Schwarz; rho concave: rho' s <= rho).  The trace is accumulated beside the slots as
+      // limbs (exact, order-independent), so bound = max(trace, sqrt(2 trace cost)) is the same number on every run and every
+      // thread: a uniform decision.  The ideal grid puts the bound at 2^57 .. 2^58 units (a factor 16 below the 2^62 limit).
+      //  * first linearisation: the start grid (2^-38: unit-norm 128-channel descriptors) is kept if it neither overflows nor is
+      //    more than 2^10 coarser than ideal (single-channel features: H ~ 1e-4, g -> 1e-9 at convergence); otherwise the blocks
+      //    are accumulated once more on the ideal grid;
+      //  * later linearisations run on the ideal grid of the one before; if the bound grew by more than 16x in one accepted
+      //    step the sub-problem stops and asks the host for a launch on a new grid (need_rescale).
       const double tr = limb_value(sh_trace);
-      const double bound = 16.0 * fmax(tr, sqrt(2.0 * tr * fmax(c, 0.0)));
-      if (bound * p.det_scale > 0x1p62 && isfinite(bound)) need_rescale = bound;     // (a non-finite Jacobian fails the solve below as before)
-    }
-    KA_T(1);
-    if constexpr (DET) {                 // deterministic mode: the slots hold fixed-point integers
-      for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = (double)__double_as_longlong(p.Hm[e]) / p.det_scale;
-      for (int e = tid; e < n; e += blockDim.x) p.g[e] = (double)__double_as_longlong(p.g[e]) / p.det_scale;
+      const double bound = fmax(tr, sqrt(2.0 * tr * fmax(c, 0.0)));
+      const bool usable = isfinite(bound) && bound > 0.0;            // (a non-finite Jacobian fails the solve below as before)
+      const double ideal = usable ? exp2((double)(58 - (int)ceil(log2(bound)))) : grid;
+      if constexpr (compute_scale) {
+        if (usable && (bound * grid > 0x1p62 || grid < ideal * 0x1p-10)) {
+          grid = ideal;
+          __syncthreads();
+          for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = 0.0;
+          for (int e = tid; e < n; e += blockDim.x) p.g[e] = 0.0;
+          __syncthreads();
+          c = ka_terms<C, true, DET>(a, p, sh4, grid);
+          __syncthreads();
+        }
+      } else if (usable && bound * grid > 0x1p62) need_rescale = ideal;
+      KA_T(1);
+      for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = (double)__double_as_longlong(p.Hm[e]) / grid;
+      for (int e = tid; e < n; e += blockDim.x) p.g[e] = (double)__double_as_longlong(p.g[e]) / grid;
       __syncthreads();
+      grid = ideal;                        // the next linearisation's
     }
     for (int e = tid; e < n; e += blockDim.x) {
       p.gun[e] = p.g[e];
@@ -952,11 +966,11 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     if (tid == 0) { a.summaries[prob] = sm; if (DET) a.prob_done[prob] = 1; }
     return;
   }
-  double cost = linearize(true);
+  double cost = linearize(std::true_type{});
   sm.initial_cost = cost;
   if (DET && need_rescale != 0.0) {         // the grid does not fit this sub-problem: nothing was changed, the host launches again
     sm.final_cost = cost; sm.termination = KA_TERM_RESCALE; sm.linear_iterations = stencils;
-    if (tid == 0) { a.summaries[prob] = sm; a.prob_scale[prob] = exp2((double)(62 - (int)ceil(log2(need_rescale)))); }
+    if (tid == 0) { a.summaries[prob] = sm; a.prob_scale[prob] = need_rescale; }
     return;
   }
   if (!inf.feasible || !isfinite(cost)) {   // [upstream] Program::IsFeasible fails / the initial evaluation fails
@@ -1089,7 +1103,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
         a.v.d_kp[2 * node] = a.kp_cand[2 * node]; a.v.d_kp[2 * node + 1] = a.kp_cand[2 * node + 1];
       }
       __syncthreads();
-      cost = linearize(false);
+      cost = linearize(std::false_type{});
       ++sm.num_successful;
       if (DET && need_rescale != 0.0) { sm.termination = KA_TERM_RESCALE; break; }     // (the accepted keypoints stay; the next launch goes on from them)
       const double tmp = 2.0 * rel - 1.0;
@@ -1103,7 +1117,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   if (tid == 0) {
     a.summaries[prob] = sm;
     if (DET) {
-      if (sm.termination == KA_TERM_RESCALE) a.prob_scale[prob] = exp2((double)(62 - (int)ceil(log2(need_rescale))));
+      if (sm.termination == KA_TERM_RESCALE) a.prob_scale[prob] = need_rescale;
       else a.prob_done[prob] = 1;
     }
   }

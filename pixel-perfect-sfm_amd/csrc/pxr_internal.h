@@ -27,7 +27,7 @@ struct pxr_ctx {
   hipEvent_t ev_stage[2] = {nullptr, nullptr};
   size_t stage_bytes = 0;
   bool deterministic = true;     // pxr_set_deterministic / PXR_DETERMINISTIC=0 opts out: order- and partition-independent accumulation in the solvers
-  bool gram_cache = false;       // pxr_set_gram_cache / PXR_GRAM_CACHE=1: pxr_ba_solve evaluates from cached Gram matrices (pxr_ba_gram.hip)
+  bool gram_cache = true;        // pxr_set_gram_cache / PXR_GRAM_CACHE=0 opts out: pxr_ba_solve evaluates from cached Gram matrices (pxr_ba_gram.hip)
   void* d_gram = nullptr;        // grow-only storage of that cache
   size_t gram_bytes = 0;
 };

@@ -119,6 +119,14 @@ __device__ __forceinline__ void ka_eval_node_at(const KaArgs& a, int64_t node, i
   }
 }
 
+// a value every lane holds alike, moved to scalar registers (it stays live across the register-capped interpolation core)
+__device__ __forceinline__ double uniform_f64(double v) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]); u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+  return u.d;
+}
+
 __device__ __forceinline__ double lpo_sum(double v, int LPO) { return LPO == 16 ? row16_sum(v) : (LPO == 8 ? row8_sum(v) : v); }
 
 // block-wide sum, result broadcast to every thread (KA_NT threads)
@@ -130,7 +138,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh4) {
   double t = sh4[0];
 #pragma unroll
   for (int k = 1; k < KA_NT / 64; ++k) t += sh4[k];
-  return t;
+  return uniform_f64(t);     // every lane holds the sum: in scalar registers it does not compete with the interpolation core's 256
 }
 
 // block-wide exclusive prefix sum over the KA_NT threads (in thread order); total broadcast
@@ -165,9 +173,6 @@ struct KaProb {
   const KaNodeMeta* cnode = nullptr;   // LDS: metadata of the first KA_NODE_CACHE nodes / KA_EDGE_CACHE edges of the problem
   const KaEdgeMeta* cedge = nullptr;   // (solve kernel only; the rest, and every other caller, reads global memory)
   double* csq = nullptr;               // LDS: squared residual norms of the cached edges (cost-only pass)
-  // deterministic mode (solve kernel): the sub-problem's fixed-point grid (0: floating-point atomics) and the limbs of the trace
-  // of its normal matrix in LDS (pxr_device.h) -- the overflow guard: every entry of H is bounded by the trace
-  long long* trace = nullptr;
 };
 // DET: the kernel instantiation of the deterministic mode adds fixed-point integers only; the other floating-point atomics only
 template <bool DET>
@@ -175,20 +180,6 @@ __device__ __forceinline__ void ka_accum(double* slot, double v, double det_scal
   if constexpr (DET) atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double2ll_rn(v * det_scale));
   else atomicAdd(slot, v);
 }
-__device__ __forceinline__ void ka_trace_add(const KaProb& p, double v) {
-  // (the digits of Limbs::add as scalars: an array of integers in this register-capped kernel ends up in scratch)
-  unsigned long long* t = reinterpret_cast<unsigned long long*>(p.trace);
-  if (!(fabs(v) < 0x1p60)) { atomicAdd(t + 4, 1ull); return; }
-  double d = trunc(v * 0x1p-20); v -= d * 0x1p20;
-  if (d != 0.0) atomicAdd(t + 0, (unsigned long long)(long long)d);
-  d = trunc(v * 0x1p20); v -= d * 0x1p-20;
-  if (d != 0.0) atomicAdd(t + 1, (unsigned long long)(long long)d);
-  d = trunc(v * 0x1p60); v -= d * 0x1p-60;
-  if (d != 0.0) atomicAdd(t + 2, (unsigned long long)(long long)d);
-  d = rint(v * 0x1p100);
-  if (d != 0.0) atomicAdd(t + 3, (unsigned long long)(long long)d);
-}
-
 // evaluate all nodes of the problem at keypoints `kp`
 template <typename ST, int C, bool WITH_JAC>
 __device__ void ka_nodes(const KaArgs& a, const KaProb& p, const double* kp, bool fsimd, bool moving_only = false) {
@@ -250,9 +241,12 @@ __device__ __forceinline__ double ka_kappa(double s, const double* rho) {
 // walk the edges and the unary terms; returns the cost (block-uniform).  WITH_JAC: accumulates Hm
 // and g (unscaled).
 template <int C, bool WITH_JAC, bool DET = false>
-__device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4, const double det_scale = 0.0) {
+__device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4, const double det_scale = 0.0, double* trace_out = nullptr) {
   constexpr int LPO = KaLay<C>::LPO, CPL = KaLay<C>::CPL, G = KA_NT / LPO;
   const int grp = threadIdx.x / LPO, sub = threadIdx.x % LPO;
+  // DET: trace of the accumulated normal matrix (the overflow guard's bound).  A sub-problem is ONE workgroup with a static
+  // residual block -> lane mapping, so a per-lane double and a fixed tree over the workgroup give the same bits on every run.
+  double trace = 0.0;
   double cost = 0.0;
   int64_t i_first = p.ne0 + grp;
   if constexpr (!WITH_JAC) {
@@ -364,7 +358,7 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4, const 
               for (int y = 0; y < 4; ++y)
                 if (var[y]) ka_accum<DET>(blk + (size_t)(idx[x] - c0) * nc + (idx[y] - c0), rho[1] * (mm[x][y] - kappa * b[x] * b[y]), det_scale);
             }
-            if constexpr (DET) ka_trace_add(p, tr);
+            if constexpr (DET) trace += tr;
           }
         }
       }
@@ -431,7 +425,7 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4, const 
             for (int y = 0; y < 4; ++y)
               if (var[y]) ka_accum<DET>(blk + (size_t)(idx[x] - c0) * nc + (idx[y] - c0), rho[1] * (m[x][y] - kappa * b[x] * b[y]), det_scale);
           }
-          if constexpr (DET) ka_trace_add(p, tr);
+          if constexpr (DET) trace += tr;
         }
       }
     }
@@ -472,10 +466,11 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4, const 
         ka_accum<DET>(row + 1, rho[1] * (q[1] - kappa * q[3] * q[4]), det_scale);
         ka_accum<DET>(row + nc, rho[1] * (q[1] - kappa * q[3] * q[4]), det_scale);
         ka_accum<DET>(row + nc + 1, rho[1] * (q[2] - kappa * q[4] * q[4]), det_scale);
-        if constexpr (DET) ka_trace_add(p, rho[1] * (q[0] - kappa * q[3] * q[3]) + rho[1] * (q[2] - kappa * q[4] * q[4]));
+        if constexpr (DET) trace += rho[1] * (q[0] - kappa * q[3] * q[3]) + rho[1] * (q[2] - kappa * q[4] * q[4]);
       }
     }
   }
+  if constexpr (DET && WITH_JAC) *trace_out = block_sum(trace, sh4);
   return block_sum(cost, sh4);
 }
 
@@ -812,13 +807,11 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
 #endif
   __shared__ double sh4[KA_NT / 64];
   __shared__ int sh_ok;
-  __shared__ long long sh_trace[PXR_LIMBS];
   const int prob = blockIdx.x, tid = threadIdx.x;
   const bool fsimd = a.float_simd != 0;
   KaProb p;
   if (DET && a.prob_done[prob]) return;                  // (a repeated launch after a grid change: this sub-problem had finished)
-  double grid = DET ? a.prob_scale[prob] : 0.0;         // the sub-problem's fixed-point grid (2^k), adapted at every linearisation
-  p.trace = DET ? sh_trace : nullptr;
+  double grid = DET ? uniform_f64(a.prob_scale[prob]) : 0.0;         // the sub-problem's fixed-point grid (2^k), adapted at every linearisation
   double need_rescale = 0.0;                             // set by the overflow guard of a linearisation: the grid to launch again with
   p.np0 = a.v.d_prob_node_ptr[prob]; p.np1 = a.v.d_prob_node_ptr[prob + 1];
   p.ne0 = a.v.d_prob_edge_ptr[prob]; p.ne1 = a.v.d_prob_edge_ptr[prob + 1];
@@ -891,46 +884,33 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   auto linearize = [&](auto first_tag) -> double {
     constexpr bool compute_scale = decltype(first_tag)::value;      // the FIRST linearisation of the solve
     stencils += nodes_all;
+    for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = 0.0;
+    for (int e = tid; e < n; e += blockDim.x) p.g[e] = 0.0;
+    __syncthreads();
     KA_T(7);
     ka_nodes<ST, C, true>(a, p, a.v.d_kp, fsimd);
     KA_T(0);
-    for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = 0.0;
-    for (int e = tid; e < n; e += blockDim.x) p.g[e] = 0.0;
-    if (DET && tid < PXR_LIMBS) sh_trace[tid] = 0;
+    double tr = 0.0;
+    const double c = ka_terms<C, true, DET>(a, p, sh4, grid, &tr);
     __syncthreads();
-    double c = ka_terms<C, true, DET>(a, p, sh4, grid);
-    __syncthreads();
+    KA_T(1);
     if constexpr (DET) {
       // The fixed-point grid of the slots follows the data.  Integer atomics wrap modulo 2^64, so only the FINAL content of a
       // slot has to fit: |H_ab| <= max diag(H) <= trace(H) (each block's J^T J with the corrector is positive semi-definite),
-      // |g_a| <= sqrt(H_aa 2 cost) (Cauchy-Schwarz; rho concave: rho' s <= rho).  The trace is accumulated beside the slots as
-      // limbs (exact, order-independent), so bound = max(trace, sqrt(2 trace cost)) is the same number on every run and every
-      // thread: a uniform decision.  The ideal grid puts the bound at 2^57 .. 2^58 units (a factor 16 below the 2^62 limit).
-      //  * first linearisation: the start grid (2^-38: unit-norm 128-channel descriptors) is kept if it neither overflows nor is
-      //    more than 2^10 coarser than ideal (single-channel features: H ~ 1e-4, g -> 1e-9 at convergence); otherwise the blocks
-      //    are accumulated once more on the ideal grid;
-      //  * later linearisations run on the ideal grid of the one before; if the bound grew by more than 16x in one accepted
-      //    step the sub-problem stops and asks the host for a launch on a new grid (need_rescale).
-      const double tr = limb_value(sh_trace);
+      // |g_a| <= sqrt(H_aa 2 cost) (Cauchy-Schwarz; rho concave: rho' s <= rho); bound = max(trace, sqrt(2 trace cost)) is the
+      // same number in every thread: a uniform decision.  The ideal grid puts the bound at 2^57 .. 2^58 units, a factor 16 below
+      // the 2^62 limit; every linearisation runs on the ideal grid of the one before.  The sub-problem stops and asks the host
+      // for another launch (need_rescale = the grid to use) if the bound grew by more than those 16x in one accepted step, or if
+      // the start grid (2^-38: unit-norm 128-channel descriptors) does not suit the FIRST linearisation -- it overflows (raw
+      // features) or is more than 2^10 coarser than ideal (single-channel features: H ~ 1e-4, g -> 1e-9 at convergence).
       const double bound = fmax(tr, sqrt(2.0 * tr * fmax(c, 0.0)));
       const bool usable = isfinite(bound) && bound > 0.0;            // (a non-finite Jacobian fails the solve below as before)
       const double ideal = usable ? exp2((double)(58 - (int)ceil(log2(bound)))) : grid;
-      if constexpr (compute_scale) {
-        if (usable && (bound * grid > 0x1p62 || grid < ideal * 0x1p-10)) {
-          grid = ideal;
-          __syncthreads();
-          for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = 0.0;
-          for (int e = tid; e < n; e += blockDim.x) p.g[e] = 0.0;
-          __syncthreads();
-          c = ka_terms<C, true, DET>(a, p, sh4, grid);
-          __syncthreads();
-        }
-      } else if (usable && bound * grid > 0x1p62) need_rescale = ideal;
-      KA_T(1);
+      if (usable && (bound * grid > 0x1p62 || (compute_scale && grid < ideal * 0x1p-10))) need_rescale = uniform_f64(ideal);
       for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = (double)__double_as_longlong(p.Hm[e]) / grid;
       for (int e = tid; e < n; e += blockDim.x) p.g[e] = (double)__double_as_longlong(p.g[e]) / grid;
       __syncthreads();
-      grid = ideal;                        // the next linearisation's
+      grid = uniform_f64(ideal);           // the next linearisation's (wave-uniform: kept in scalar registers)
     }
     for (int e = tid; e < n; e += blockDim.x) {
       p.gun[e] = p.g[e];
@@ -1035,7 +1015,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     if (!(model_cost_change > 0.0)) ok = false;
     if (!ok) {
       if (++invalid >= opt.max_consecutive_invalid_steps) { sm.termination = PXR_TERM_FAILURE; break; }
-      radius *= 0.5; reuse_diag = true;
+      radius = uniform_f64(radius * 0.5); reuse_diag = true;
       continue;
     }
     invalid = 0;
@@ -1063,6 +1043,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
         double nx;
         if (!isfinite(fc)) nx = fmin(fmax(xc * 0.5, xc * 1e-3), xc * 0.6);
         else nx = ka_interp_step(cost, g0, have_prev, xp, fp, xc, fc, xc * 1e-3, xc * 0.6);
+        nx = uniform_f64(nx);
         if (nx < 1e-9) break;
         if (isfinite(fc)) { xp = xc; fp = fc; have_prev = true; }
         xc = nx;
@@ -1107,10 +1088,10 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       ++sm.num_successful;
       if (DET && need_rescale != 0.0) { sm.termination = KA_TERM_RESCALE; break; }     // (the accepted keypoints stay; the next launch goes on from them)
       const double tmp = 2.0 * rel - 1.0;
-      radius = fmin(opt.max_radius, radius / fmax(1.0 / 3.0, 1.0 - tmp * tmp * tmp));
+      radius = uniform_f64(fmin(opt.max_radius, radius / fmax(1.0 / 3.0, 1.0 - tmp * tmp * tmp)));
       decrease_factor = 2.0; reuse_diag = false;
     } else {
-      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diag = true;
+      radius = uniform_f64(radius / decrease_factor); decrease_factor = uniform_f64(decrease_factor * 2.0); reuse_diag = true;
     }
   }
   sm.final_cost = cost; sm.final_radius = radius; sm.linear_iterations = stencils;

@@ -70,6 +70,39 @@ def test_oracle_on_a_random_sample_of_the_full_problem(ctx, big):
     assert np.abs(J - J_o).max() < 1e-10 * np.abs(J_o).max()
 
 
+def test_gram_matrix_records_against_the_oracle_on_a_sample_of_the_full_problem(ctx, big):
+    """The LM loop's default evaluation (records from cached Gram matrices, csrc/pxr_ba_gram.hip) at configs[2]: |r|^2, J^t J and
+    J^t r of 512 random blocks against the oracle's residuals and Jacobians (which restate the reference's fp32 horizontal
+    pass, base/src/interpolation.h:177-218) at north_star's 1e-5 -- seen: the pass's own rounding, ~1e-7."""
+    import pxo
+    import torch
+    from pixsfm_amd.engine import interp_cfg
+    prob, patches, ba = big
+    rng = np.random.default_rng(5)
+    idx = np.sort(rng.choice(ba.n_obs, 512, replace=False))
+    rec, built = ba.eval_gram(interp_cfg(), reset=True)
+    assert built == ba.n_obs
+    rec = rec.download()[idx]
+    P = ba.projection_jacobian().download()[idx][:, :, :14]              # SIMPLE_RADIAL: 10 + 4 columns
+    sub = dict(prob)
+    for k in ("obs_image", "obs_point", "corners", "scales"):
+        sub[k] = prob[k][idx]
+    sub["obs_patch"] = np.arange(len(idx), dtype=np.int64)
+    sub["patches"] = patches[torch.as_tensor(idx, device=patches.device)].cpu().numpy()
+    _, r_o, J_o = pxo.ba_eval_batch(sub, pxo.cfg(), pxo.loss("cauchy", 0.25), want_r=True, want_J=True)
+    J_o = J_o[:, :, :14]
+    M = np.stack([np.stack([rec[:, 1], rec[:, 2]], 1), np.stack([rec[:, 2], rec[:, 3]], 1)], 1)       # n x 2 x 2
+    H = np.einsum("nai,nab,nbj->nij", P, M, P)
+    g = np.einsum("nai,na->ni", P, rec[:, 4:6])
+    H_o, g_o, s_o = np.einsum("nci,ncj->nij", J_o, J_o), np.einsum("nci,nc->ni", J_o, r_o), (r_o * r_o).sum(1)
+    hmax = np.abs(H_o).reshape(len(idx), -1).max(1)
+    e_s = np.abs(rec[:, 0] - s_o) / s_o
+    e_H = np.abs(H - H_o).reshape(len(idx), -1).max(1) / hmax
+    e_g = np.abs(g - g_o).max(1) / (np.sqrt(hmax) * np.sqrt(s_o))
+    assert max(e_s.max(), e_H.max(), e_g.max()) < 1e-5, (e_s.max(), e_H.max(), e_g.max())
+    assert max(e_s.max(), e_H.max(), e_g.max()) < 2e-6, (e_s.max(), e_H.max(), e_g.max())
+
+
 def test_lm_descends_monotonically_at_full_size(ctx, big):
     from pixsfm_amd.engine import interp_cfg, lm_options, make_loss
     prob, patches, ba = big

@@ -1,4 +1,5 @@
-"""GPU: the Gram-matrix cache of the BA solver (pxr_set_gram_cache / PXR_GRAM_CACHE=1, csrc/pxr_ba_gram.hip).
+"""GPU: the Gram-matrix cache of the BA solver (csrc/pxr_ba_gram.hip; the DEFAULT evaluation of the LM loop since round 5,
+pxr_set_gram_cache(ctx, 0) / PXR_GRAM_CACHE=0 opt out).
 
 The solver consumes the 64-byte record of a residual block, and bicubic interpolation is linear in the 16 texels of the 4 x 4
 stencil: with G = T T^t (16 x 16) and D = T ref the record is a set of quadratic / linear forms in the Catmull-Rom weights.
@@ -93,10 +94,10 @@ def test_a_projection_that_cannot_be_evaluated_stays_nan(ctx):
 def test_solve_with_the_cache_is_the_solve_without(ctx, inner):
     from pixsfm_amd.engine import Context, interp_cfg, lm_options, make_loss
     c2 = Context(0)
-    c2.gram_cache = True
-    assert c2.gram_cache and not ctx.gram_cache
+    c2.gram_cache = False                       # the opt-out: every evaluation by the exact-order kernel (texels)
+    assert ctx.gram_cache and not c2.gram_cache
     out = []
-    for c in (ctx, c2):
+    for c in (c2, ctx):
         prob, arena, ba = _problem(c, n_cams=12, n_points=900)
         s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *_gauge(prob),
                      options=lm_options(max_iterations=12, use_inner_iterations=inner))
@@ -108,8 +109,6 @@ def test_solve_with_the_cache_is_the_solve_without(ctx, inner):
     assert abs(s0["final_cost"] - s1["final_cost"]) < 1e-6 * s0["initial_cost"]
     for a, b in zip(p0, p1):
         assert np.abs(a - b).max() < 1e-4 * max(1.0, np.abs(a).max())          # north_star: poses / points within 1e-4
-    c2.gram_cache = False                                                       # gives the storage back
-    assert not c2.gram_cache
     c2.close()
 
 
@@ -154,3 +153,73 @@ def test_cost_maps_and_fp64_storage_ignore_the_flag(ctx):
     s1 = ba1.solve(interp_cfg(), make_loss("cauchy", [0.25]), *_gauge(prob), options=lm_options(max_iterations=4))
     assert abs(s["final_cost"] - s1["final_cost"]) < 1e-8 * s["initial_cost"] and s["iterations"] == s1["iterations"]
     arena.close(); arena1.close(); c2.close()
+
+
+# ---- pinned against the REFERENCE (VERDICT r4 missing-2 / next-3) --------------------------------------------------------------
+# north_star: residuals / Jacobians within 1e-5 relative of the Ceres reference.  What the Gram-matrix path produces is the
+# solver's view of a block -- |r|^2, J^t J, J^t r -- so that is what is compared, against the same quantities formed from the
+# reference functor's own residual and Jacobian (tests/golden/residuals_ref.npz: FeatureReferenceCostFunctor of
+# residuals/src/feature_reference.h:123-134 over base/src/interpolation.h:177-218, compiled in place).
+GRAM_VS_REFERENCE_RTOL = 1e-5          # the contract
+GRAM_VS_REFERENCE_SEEN = 2e-6          # what the fp32 horizontal pass of the reference actually leaves (asserted too)
+
+
+def _golden():
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden_residuals", os.path.join(here, "golden", "make_golden_residuals.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m, np.load(os.path.join(here, "golden", "residuals_ref.npz"))
+
+
+@pytest.mark.parametrize("storage", [np.float16, np.float32])
+def test_gram_records_match_the_reference_functors_vectors(ctx, storage):
+    """All five camera models of the golden set, with / without L2 normalisation, fp16 and fp32 storage (the golden patches hold
+    fp16 values: as fp32 storage the reference computes the same numbers), incl. the cases whose stencil is clamped at the
+    patch border.  Per block: |r|^2, J^t J ((10+K)^2) and J^t r from the record + the projection Jacobian P (k_jac, pinned in
+    tests/test_residuals_golden.py) against the reference's r and J."""
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg
+    gen, gold = _golden()
+    groups = {}
+    for c in gen.ba_cases():
+        if not c["check_bounds"]:                      # (check_bounds is not a Gram-path feature: the solver keeps the exact-order kernel for it)
+            groups.setdefault(c["l2"], []).append(c)
+    n_checked, worst = 0, 0.0
+    models = set()
+    for l2, cs in groups.items():
+        m = len(cs)
+        cam_params = np.zeros((m, 12))
+        for i, c in enumerate(cs):
+            cam_params[i, :len(c["params"])] = c["params"]
+        ids = np.arange(m, dtype=np.int32)
+        prob = dict(obs_image=ids, obs_point=ids, obs_patch=np.arange(m, dtype=np.int64), image_camera=ids,
+                    qvec=np.stack([c["q"] for c in cs]), tvec=np.stack([c["t"] for c in cs]),
+                    cam_model=np.array([c["model"] for c in cs], np.int32), cam_params=cam_params,
+                    xyz=np.stack([c["X"] for c in cs]), refs=np.stack([c["ref"] for c in cs]),
+                    patches=np.stack([c["d"] for c in cs]).astype(storage), corners=np.stack([c["c"] for c in cs]).astype(np.int32),
+                    scales=np.stack([c["s"] for c in cs]))
+        arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+        ba = BAProblem(ctx, arena, prob)
+        rec, built = ba.eval_gram(interp_cfg(l2_normalize=l2), reset=True)
+        rec = rec.download()
+        assert built == m
+        P = ba.projection_jacobian().download()
+        for i, c in enumerate(cs):
+            n, K = c["name"], len(c["params"])
+            r_ref, J_ref = gold[n + "_r"], gold[n + "_J"]
+            Pi = P[i][:, :10 + K]
+            M = np.array([[rec[i, 1], rec[i, 2]], [rec[i, 2], rec[i, 3]]])
+            H, g, s = Pi.T @ M @ Pi, Pi.T @ rec[i, 4:6], rec[i, 0]
+            H_ref, g_ref, s_ref = J_ref.T @ J_ref, J_ref.T @ r_ref, float(r_ref @ r_ref)
+            # scales: |r|^2 against itself, J^t J against its largest entry, J^t r against |J| |r| (it vanishes at an optimum)
+            errs = (abs(s - s_ref) / s_ref, np.abs(H - H_ref).max() / np.abs(H_ref).max(),
+                    np.abs(g - g_ref).max() / (np.sqrt(np.abs(H_ref).max()) * np.sqrt(s_ref)))
+            worst = max(worst, *errs)
+            assert max(errs) < GRAM_VS_REFERENCE_RTOL, (n, errs)
+            models.add(c["model"])
+            n_checked += 1
+        arena.close()
+    assert n_checked >= 20 and models == {0, 1, 2, 3, 4}
+    assert worst < GRAM_VS_REFERENCE_SEEN, worst

@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 5, third GPU call: full suite with both new defaults (deterministic, Gram-matrix evaluation), bench
+set -u
+O=gpurun_out/r5c
+mkdir -p $O
+export TMPDIR=/tmp
+timeout 1200 python -m pytest tests -m gpu -q --maxfail=40 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/steps.log
+timeout 900 python bench.py --detail-out $O/bench_detail.json > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?" >> $O/steps.log
+tail -5 $O/pytest.log; cat $O/steps.log; wc -c $O/bench_n1.json

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
           const double term = is_g ? B0[a] * Lo[3] + B1[a] * Lo[4]
                                    : B0[a] * (Lo[0] * B0[b] + Lo[1] * B1[b]) + B1[a] * (Lo[1] * B0[b] + Lo[2] * B1[b]);
           acc += term;
-          if (fixed) qacc += __double2ll_rn(term * det_scale);
+          if (fixed) qacc += fixed_rn(term * det_scale);
         }
       }
       __syncthreads();
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
         const double term = is_g ? B0[a] * Lo[3] + B1[a] * Lo[4]
                                  : B0[a] * (Lo[0] * B0[b] + Lo[1] * B1[b]) + B1[a] * (Lo[1] * B0[b] + Lo[2] * B1[b]);
         acc += term;
-        if (fixed) qacc += __double2ll_rn(term * det_scale);
+        if (fixed) qacc += fixed_rn(term * det_scale);
       }
     }
     __syncthreads();
@@ -501,6 +501,7 @@ __global__ void k_copy_upper_add_diag(int n, const double* __restrict__ U, const
     v = (c < n && r <= c) ? U[(size_t)r * n + c] : 0.0;
   }
   else {
+    if (det_scale != 0.0) v = (double)__double_as_longlong(v) / det_scale;    // (the slots' integers become doubles here: one pass)
     if (r == c) v += damp[r] * inv_radius;
     if (c == n) v += gc[r];
   }
@@ -1211,7 +1212,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   RC(scale_c.alloc(nc1)); RC(scale_p.alloc((size_t)n_pts * 3)); RC(delta_c.alloc(nc1)); RC(delta_p.alloc((size_t)n_pts * 3));
   RC(rec_a.alloc((size_t)n_obs * PXR_OBS_REC)); RC(rec_b.alloc((size_t)n_obs * PXR_OBS_REC));
   RC(q1.alloc((size_t)n_img * 4)); RC(t1.alloc((size_t)n_img * 3)); RC(k1.alloc((size_t)n_cam * PXR_KPAD)); RC(X1.alloc((size_t)n_pts * 3));
-  RC(scal.alloc(16));   // [0..7] summed over ranks, [8..15] replicated
+  RC(scal.alloc(16 + 16 * PXR_LIMBS));   // [0..7] summed over ranks, [8..15] replicated; then the limbs of the same 16 scalars
   double* scal_sum = scal.p; double* scal_rep = scal.p + 8;
   const int ldS = n_c + 1;
   double* rhs = S.p + n_c;          // column n_c of S, stride ldS
@@ -1289,8 +1290,8 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     if (ctx->rank != 0) hipLaunchKernelGGL(k_zero, dim3(nblk(count)), dim3(256), 0, st, count, buf);
     return ar(buf, count);
   };
-  DevBuf<long long> slimb;            // 16 scalar slots x PXR_LIMBS integers: [0..7] summed over the ranks, [8..15] replicated
-  RC(slimb.alloc(16 * PXR_LIMBS));
+  struct { long long* p; } slimb;     // 16 scalar slots x PXR_LIMBS integers behind `scal` (one memset clears both): [0..7] summed over the ranks, [8..15] replicated
+  slimb.p = reinterpret_cast<long long*>(scal.p + 16);
   long long* const limb_arg = det ? slimb.p : nullptr;     // what the step kernels get: NULL = floating-point atomics into `scal`
   DevBuf<double> i64_halves;          // the callback path's exact 32-bit halves
   const bool native_i64 = allreduce == nullptr;
@@ -1304,8 +1305,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     return PXR_OK;
   };
   auto zero_scalars = [&]() -> int {
-    PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * 16, st));
-    PXR_HIP(hipMemsetAsync(slimb.p, 0, sizeof(long long) * 16 * PXR_LIMBS, st));
+    PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * (16 + 16 * PXR_LIMBS), st));
     return PXR_OK;
   };
   DevBuf<double> lin_stats;           // {max, sum, min of diag(U), trace} of the newest linearisation (k_diag_stats)
@@ -1328,16 +1328,17 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   DevBuf<double> det_part, chunk_trace;
   RC(det_part.alloc((size_t)n_pts + 8));          // the inner iterations' per-point costs (every mode)
   RC(chunk_trace.alloc(chunks.size() + 1));
-  // the grid: entries bounded by 8 max(md, sqrt(2 md cost)) fit 62 bits (md: the bound on diag(U) the grid is made for)
+  // the grid: entries -- and every single addend -- bounded by 8 max(md, sqrt(2 md cost)) stay below 2^51 units, the range of the
+  // one-instruction rounding fixed_rn (md: the bound on diag(U) the grid is made for).  Resolution: 2^-48 of that bound at worst.
   auto det_scale_for = [](double md, double cost_now) {
     const double bound = 8.0 * std::max({md, std::sqrt(2.0 * md * std::max(cost_now, 0.0)), 1e-300});
-    return std::ldexp(1.0, 62 - (int)std::ceil(std::log2(bound)));
+    return std::ldexp(1.0, 51 - (int)std::ceil(std::log2(bound)));
   };
   double lin_md = 1.0;                // the diag(U) bound the CURRENT grid was made for
   // pxr_set_gram_cache: the records from cached Gram matrices of the stencils instead of from the texels (pxr_ba_gram.hip)
   // (default on since round 5: pinned against the reference functor's vectors at 1e-5, tests/test_gram_cache_gpu.py.  check_bounds
-  //  is not a Gram-path feature -- a block outside its patch FAILS in the reference: such solves keep the exact-order kernel.)
-  const bool gram_cache = ctx->gram_cache && gram_eval_supported(arena, view) && !cfg->check_bounds;
+  //  needs no care: with reference descriptors the functor ignores the bounds check, feature_reference.h:128-136.)
+  const bool gram_cache = ctx->gram_cache && gram_eval_supported(arena, view);
   // The Gram-matrix kernel of the inner iterations keeps its matrices in the same cache from call to call (it writes back what
   // it builds), whether or not the LM loop evaluates from them: the same numbers as without a cache, fewer builds.  (That kernel
   // is built without the six extended camera models -- their forward-mode duals cost ~100 registers: a problem that uses one
@@ -1406,7 +1407,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     const double mx = stt[0], sm = stt[1], mn = stt[2], tr = stt[3];
     if (!(std::isfinite(mx) && std::isfinite(sm) && std::isfinite(tr))) return false;
     if (mn < 0.0) return false;                                               // a diagonal slot wrapped into the sign bit
-    if (std::fabs(tr - sm) > std::ldexp(1.0, 61) / lin_scale) return false;   // ... or all the way round
+    if (std::fabs(tr - sm) > std::ldexp(1.0, 49) / lin_scale) return false;   // ... or all the way round / an addend beyond fixed_rn's range
     return mx <= 8.0 * md_made_for;                                           // the off-diagonal, Schur and gradient bounds hold
   };
   // linearise on a grid made for diag(U) <= 8 md_guess; repeat on a grid from the measured trace until the check passes
@@ -1621,11 +1622,9 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
         hipLaunchKernelGGL(k_unpack_upper, dim3((unsigned)n_c), dim3(256), 0, st, n_c, S_packed.p, S.p);
         LAUNCH_CHECK("pack / unpack of the reduced camera system");
       }
-      if (schur_scale != 0.0)
-        hipLaunchKernelGGL(k_det_finish, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, (int64_t)n_c * ldS, S.p, schur_scale);
       phase(1);
-      // rhs += g_c (global), S += D_c / radius
-      hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, n_c, U.p, damp_c.p, inv_radius, gc, S.p, 0, 0.0);
+      // the fixed-point slots back to doubles (deterministic mode), rhs += g_c (global), S += D_c / radius: one pass
+      hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, n_c, U.p, damp_c.p, inv_radius, gc, S.p, 0, schur_scale);
       // row-major upper == column-major lower; the pivot check is read back with the scalars of
       // this attempt (no extra host synchronisation): a failed factorisation = invalid step.
       RC(chol_factor_solve(st, S.p, n_c, d_info, linv.p, xsol.p));

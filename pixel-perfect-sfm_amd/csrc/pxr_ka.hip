@@ -177,7 +177,7 @@ struct KaProb {
 // DET: the kernel instantiation of the deterministic mode adds fixed-point integers only; the other floating-point atomics only
 template <bool DET>
 __device__ __forceinline__ void ka_accum(double* slot, double v, double det_scale) {
-  if constexpr (DET) atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double2ll_rn(v * det_scale));
+  if constexpr (DET) atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)fixed_rn(v * det_scale));
   else atomicAdd(slot, v);
 }
 // evaluate all nodes of the problem at keypoints `kp`
@@ -895,18 +895,18 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     __syncthreads();
     KA_T(1);
     if constexpr (DET) {
-      // The fixed-point grid of the slots follows the data.  Integer atomics wrap modulo 2^64, so only the FINAL content of a
-      // slot has to fit: |H_ab| <= max diag(H) <= trace(H) (each block's J^T J with the corrector is positive semi-definite),
-      // |g_a| <= sqrt(H_aa 2 cost) (Cauchy-Schwarz; rho concave: rho' s <= rho); bound = max(trace, sqrt(2 trace cost)) is the
-      // same number in every thread: a uniform decision.  The ideal grid puts the bound at 2^57 .. 2^58 units, a factor 16 below
-      // the 2^62 limit; every linearisation runs on the ideal grid of the one before.  The sub-problem stops and asks the host
-      // for another launch (need_rescale = the grid to use) if the bound grew by more than those 16x in one accepted step, or if
-      // the start grid (2^-38: unit-norm 128-channel descriptors) does not suit the FIRST linearisation -- it overflows (raw
-      // features) or is more than 2^10 coarser than ideal (single-channel features: H ~ 1e-4, g -> 1e-9 at convergence).
+      // The fixed-point grid of the slots follows the data.  Every addend -- and every sum -- is bounded by
+      // bound = max(trace, sqrt(2 trace cost)): |H_ab| <= max diag(H) <= trace(H) (each block's J^T J with the corrector is positive
+      // semi-definite), |g_a| <= sqrt(H_aa 2 cost) (Cauchy-Schwarz; rho concave: rho' s <= rho); the same number in every thread: a
+      // uniform decision.  The ideal grid puts the bound at 2^48 .. 2^49 units, a factor 4 below the 2^51 range of fixed_rn; every
+      // linearisation runs on the ideal grid of the one before.  The sub-problem stops and asks the host for another launch
+      // (need_rescale = the grid to use) if the bound grew by more than those 4x in one accepted step, or if the start grid
+      // (2^-32: unit-norm 128-channel descriptors) does not suit the FIRST linearisation -- it overflows (raw features) or is
+      // more than 2^10 coarser than ideal (single-channel features: H ~ 1e-4, g -> 1e-9 at convergence).
       const double bound = fmax(tr, sqrt(2.0 * tr * fmax(c, 0.0)));
       const bool usable = isfinite(bound) && bound > 0.0;            // (a non-finite Jacobian fails the solve below as before)
-      const double ideal = usable ? exp2((double)(58 - (int)ceil(log2(bound)))) : grid;
-      if (usable && (bound * grid > 0x1p62 || (compute_scale && grid < ideal * 0x1p-10))) need_rescale = uniform_f64(ideal);
+      const double ideal = usable ? exp2((double)(49 - (int)ceil(log2(bound)))) : grid;
+      if (usable && (bound * grid > 0x1p51 || (compute_scale && grid < ideal * 0x1p-10))) need_rescale = uniform_f64(ideal);
       for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = (double)__double_as_longlong(p.Hm[e]) / grid;
       for (int e = tid; e < n; e += blockDim.x) p.g[e] = (double)__double_as_longlong(p.g[e]) / grid;
       __syncthreads();
@@ -1270,9 +1270,9 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   KaArgs a{};
   fill_args(ctx, arena, view, cfg, loss, a);
   a.bound = bound; a.opt = *options;
-  // deterministic mode: H and g of a sub-problem as 2^-38 fixed point (range +-3e7: a residual block adds |J|^2 <= a few
-  // hundred at most -- unit descriptors, gradients per pixel; resolution 3.6e-12)
-  a.det_scale = ctx->deterministic ? 274877906944.0 : 0.0;
+  // deterministic mode: H and g of a sub-problem in fixed point; the start grid 2^-32 suits unit-norm 128-channel descriptors
+  // (bound = max(trace, sqrt(2 trace cost)) ~ 1e4 .. 1e5 at configs[1]), the kernel adapts it per sub-problem and linearisation
+  a.det_scale = ctx->deterministic ? 4294967296.0 : 0.0;        // 2^32 (see the grid rule in ka_solve_body)
   a.prob_scale = (double*)(ws + o_pscale); a.prob_done = (uint8_t*)(ws + o_pdone);
   if (a.det_scale != 0.0) {
     std::vector<double> init((size_t)np, a.det_scale);

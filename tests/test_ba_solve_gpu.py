@@ -29,6 +29,24 @@ def _gauge(prob, refine_focal=True, refine_pp=False, refine_extra=True):
     return pose_const, tmask, cmask, np.zeros(n_pt, np.uint8)
 
 
+@pytest.fixture(params=["texels", "gram"])
+def ctx(request, exact_ctx):
+    """Every comparison with the oracle runs twice: on the exact-order evaluation (the reference's arithmetic: tight tolerances)
+    and on the default one (cached Gram matrices: the tolerances of conftest.FP32_PASS_*)."""
+    if request.param == "texels":
+        return exact_ctx
+    return request.getfixturevalue("default_ctx")
+
+
+@pytest.fixture(scope="module")
+def default_ctx():
+    from pixsfm_amd.engine import Context
+    c = Context(0)
+    assert c.gram_cache and c.deterministic
+    yield c
+    c.close()
+
+
 def _run_both(ctx, prob, gauge, max_it=25, **opt_kw):
     import pxo
     from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
@@ -38,6 +56,7 @@ def _run_both(ctx, prob, gauge, max_it=25, **opt_kw):
     q, t, k, X = ba.params()
     s_cpu, qo, to, ko, Xo = pxo.ba_solve(prob, pxo.cfg(), pxo.loss("cauchy", 0.25), *gauge,
                                          pxo.lm_options(max_iterations=max_it, **opt_kw))
+    s_gpu["_gram"] = bool(ctx.gram_cache)
     return s_gpu, (q, t, k, X), s_cpu, (qo, to, ko, Xo)
 
 
@@ -49,8 +68,12 @@ def _assert_same(s_gpu, pg, s_cpu, po, ptol=1e-6, trajectory=True):
         assert s_gpu["iterations"] == s_cpu["iterations"]
         assert s_gpu["num_successful"] == s_cpu["num_successful"]
         assert s_gpu["termination"] == s_cpu["termination"]
+    from conftest import FP32_PASS_FINAL_COST_RTOL, FP32_PASS_PARAM_RTOL
+    ctol = 1e-6
+    if s_gpu.get("_gram"):       # the default evaluation differs from the oracle's by the fp32 pass's rounding (conftest.py)
+        ctol, ptol = FP32_PASS_FINAL_COST_RTOL, max(ptol, FP32_PASS_PARAM_RTOL)
     assert abs(s_gpu["initial_cost"] - s_cpu["initial_cost"]) < 1e-10 * s_cpu["initial_cost"]
-    assert abs(s_gpu["final_cost"] - s_cpu["final_cost"]) < 1e-6 * max(s_cpu["final_cost"], 1e-9)
+    assert abs(s_gpu["final_cost"] - s_cpu["final_cost"]) < ctol * max(s_cpu["final_cost"], 1e-9)
     for a, b, name in zip(pg, po, ("qvec", "tvec", "cam", "xyz")):
         b = np.asarray(b)
         a = a[:, :b.shape[1]] if a.ndim == 2 else a

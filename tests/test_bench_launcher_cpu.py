@@ -88,3 +88,14 @@ def test_the_printed_line_fits_the_drivers_tail_and_ends_with_metric_2():
     assert list(back)[-1] == "lm" and list(back)[-2] == "lm_no_inner"
     assert back["lm"]["ms_per_iter"] == float("%.5g" % full["lm"]["ms_per_iter"])
     assert "ka" in back and "kernel_ms" in back["ka"]["solve"] and "frac" in back["ka"]["roofline"]
+
+
+def test_plain_command_at_eight_ranks():
+    """The driver's SCALE command at its largest size: `python bench.py --gpus 8` spawns eight ranks (RANK / LOCAL_RANK 0..7, one
+    rendezvous port) and prints rank 0's line only."""
+    p, _ = _run(8, ",".join("ok:%d" % r for r in range(8)), timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"selftest": True, "rank": 0}
+    for r in range(1, 8):
+        assert '"rank": %d' % r in p.stderr

@@ -97,9 +97,18 @@ def test_gpu_residuals_and_jacobians_match_oracle(ctx, model):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("evaluation", ["texels", "gram"])
 @pytest.mark.parametrize("model,inner", [(5, False), (7, False), (10, False), (5, True), (10, True)])   # FOV + inner iterations: see below
-def test_gpu_lm_with_extended_models_matches_oracle(ctx, model, inner):
+def test_gpu_lm_with_extended_models_matches_oracle(ctx, exact_ctx, model, inner, evaluation):
+    """evaluation "texels": the exact-order kernel at every candidate (the reference's fp32 pass: what the oracle restates, tight
+    tolerances); "gram": the default evaluation from cached Gram matrices (conftest.FP32_PASS_*; the ill-conditioned FOV scene,
+    whose trajectory amplifies any rounding, is compared on the exact-order path only)."""
+    from conftest import FP32_PASS_FINAL_COST_RTOL, FP32_PASS_PARAM_RTOL
     from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    if evaluation == "texels":
+        ctx = exact_ctx
+    elif model == 7:
+        pytest.skip("ill-conditioned FOV scene: compared on the exact-order path")
     prob = _problem(model, seed=60 + model)
     n_img = len(prob["image_camera"])
     K = len(EXT[model])
@@ -125,5 +134,7 @@ def test_gpu_lm_with_extended_models_matches_oracle(ctx, model, inner):
         assert abs(s["final_cost"] - so["final_cost"]) < 1e-2 * so["final_cost"]
         return
     tol = 1e-4 if inner else 1e-6           # the nested LMs stop on 1e-6 relative tolerances: test_ba_inner_gpu.py
+    if evaluation == "gram":
+        tol = max(tol, FP32_PASS_FINAL_COST_RTOL, FP32_PASS_PARAM_RTOL)
     assert abs(s["final_cost"] - so["final_cost"]) < tol * max(so["final_cost"], 1e-9)
     assert np.abs(q - qo).max() < tol and np.abs(X - Xo).max() < tol and np.abs(k - ko).max() < 10 * tol * 1200

@@ -75,12 +75,15 @@ def test_ba_direct_solver_is_bit_reproducible(fast_ctx, det_ctx, inner, loss):
         assert s["initial_cost"] == s0["initial_cost"] and s["final_cost"] == s0["final_cost"]          # the same BITS
         for a, b in zip(p, p0):
             assert np.array_equal(a, b)
-    # and it is the same solve as with floating-point atomics, to the tolerance that mode's tests use
-    sd, pd = _solve_ba(fast_ctx, prob, gauge, inner, loss)
-    assert sd["iterations"] == s0["iterations"] and sd["num_successful"] == s0["num_successful"]
-    assert abs(sd["initial_cost"] - s0["initial_cost"]) < 1e-12 * s0["initial_cost"]
-    assert abs(sd["final_cost"] - s0["final_cost"]) < 1e-7 * s0["initial_cost"]
-    for a, b in zip(pd, p0):
+    # and it is the same solve as with floating-point atomics, to the tolerance that mode's tests use -- compared while both are
+    # still descending (4 iterations): on the noise floor of this scene an accept / reject decision hinges on the last bits of a
+    # cost change, which is exactly what differs between two accumulation orders
+    s4, p4 = _solve_ba(det_ctx, prob, gauge, inner, loss, iters=4)
+    sd, pd = _solve_ba(fast_ctx, prob, gauge, inner, loss, iters=4)
+    assert sd["iterations"] == s4["iterations"] and sd["num_successful"] == s4["num_successful"]
+    assert abs(sd["initial_cost"] - s4["initial_cost"]) < 1e-12 * s4["initial_cost"]
+    assert abs(sd["final_cost"] - s4["final_cost"]) < 1e-7 * s4["initial_cost"]
+    for a, b in zip(pd, p4):
         assert np.abs(a - b).max() < 1e-6 * max(1.0, np.abs(b).max())
 
 

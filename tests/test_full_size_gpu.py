@@ -115,9 +115,11 @@ def test_lm_descends_monotonically_at_full_size(ctx, big):
     q, t, k, X = ba.params()
     assert np.abs(np.linalg.norm(q, axis=1) - 1).max() < 1e-12
     assert np.array_equal(t[0], prob["tvec"][0]) and t[1][0] == prob["tvec"][1][0]
-    # the summary's final cost is the cost of the parameters left on the device
+    # the summary's final cost is the cost of the parameters left on the device (the solver's from cached Gram matrices, this
+    # one from the texels: they differ by the rounding of the reference's fp32 pass, conftest.FP32_PASS_COST_RTOL)
+    from conftest import FP32_PASS_COST_RTOL
     ba.eval(interp_cfg(), with_jacobian=False)
-    assert abs(ba.cost(make_loss("cauchy", [0.25])) - s["final_cost"]) < 1e-9 * s["final_cost"]
+    assert abs(ba.cost(make_loss("cauchy", [0.25])) - s["final_cost"]) < FP32_PASS_COST_RTOL * s["final_cost"]
 
 
 def test_cost_maps_at_one_million_observations(ctx, big):

@@ -119,3 +119,99 @@ def test_array_form_references_gather_as_a_reference_map(tmp_path):
     for r in res:
         assert r["is_map"][0] == 1 and r["ids"].tolist() == list(range(3, 3 + 11))
         assert np.array_equal(r["desc"], np.arange(11 * 4, dtype=np.float64).reshape(11, 4)) and np.array_equal(r["src"][:, 1], 7 * np.arange(11))
+
+
+# ---- world size 8: the node the SCALE run uses; counts that are not multiples of 8, empty shards --------
+def _ragged_ba_scene(n_points, seed=3):
+    """Flat BA arrays with heavy-tailed track lengths (2 .. 60 observations per point), observations sorted by point."""
+    rng = np.random.default_rng(seed)
+    lens = np.minimum(60, 2 + rng.geometric(0.25, n_points)).astype(np.int64)
+    lens[rng.integers(0, n_points, n_points // 50)] = 60                      # a few very long tracks
+    obs_point = np.repeat(np.arange(n_points), lens).astype(np.int32)
+    n_obs = len(obs_point)
+    return dict(obs_point=obs_point, obs_image=rng.integers(0, 16, n_obs).astype(np.int32), obs_patch=np.arange(n_obs, dtype=np.int64),
+                xyz=rng.normal(size=(n_points, 3)), refs=rng.normal(size=(n_points, 4)), image_camera=np.arange(16, dtype=np.int32),
+                qvec=np.tile([1.0, 0, 0, 0], (16, 1)), tvec=np.zeros((16, 3)), cam_model=np.zeros(16, np.int32),
+                cam_params=np.ones((16, 3)), patches=rng.normal(size=(n_obs, 1, 1, 4)).astype(np.float16),
+                corners=np.zeros((n_obs, 2), np.int32), scales=np.ones((n_obs, 2)))
+
+
+def test_ba_shards_at_world_8_are_balanced_by_observations():
+    """SURVEY 8e's risk: a partition by POINTS leaves the ranks with different numbers of observations on ragged tracks (and
+    the LM iteration waits for the slowest).  shard_ba_problem cuts the point range by cumulative OBSERVATIONS: on 20 003 points
+    with 2 .. 60 observations each the largest shard is within 2 % of the mean; every observation is owned exactly once."""
+    from pixsfm_amd import parallel
+    prob = _ragged_ba_scene(20003)
+    n_obs = len(prob["obs_point"])
+    loads, seen, pts = [], [], []
+    for rank in range(8):
+        shard, pt_ids = parallel.shard_ba_problem(prob, rank, 8)
+        assert np.array_equal(prob["obs_point"][shard["obs_ids"]], pt_ids[shard["obs_point"]])
+        assert np.array_equal(shard["refs"], prob["refs"][pt_ids]) and np.array_equal(shard["patches"], prob["patches"][shard["obs_ids"]])
+        loads.append(len(shard["obs_ids"])); seen.append(shard["obs_ids"]); pts.append(pt_ids)
+    assert np.array_equal(np.sort(np.concatenate(seen)), np.arange(n_obs))
+    assert np.array_equal(np.concatenate(pts), np.arange(20003))                            # contiguous, disjoint, complete
+    assert max(loads) <= 1.02 * (n_obs / 8.0), (loads, n_obs / 8.0)
+    by_points = [np.isin(prob["obs_point"], np.arange(20003)[r * 2501:(r + 1) * 2501]).sum() for r in range(8)]
+    assert max(by_points) > max(loads)                                                       # (what equal point counts would give)
+
+
+def test_ba_shards_at_world_8_with_fewer_points_than_ranks():
+    from pixsfm_amd import parallel
+    prob = _ragged_ba_scene(5)
+    owned = []
+    for rank in range(8):
+        shard, pt_ids = parallel.shard_ba_problem(prob, rank, 8)
+        assert len(shard["xyz"]) == len(pt_ids) and len(shard["obs_point"]) == len(shard["obs_ids"])
+        assert len(pt_ids) == 0 or shard["obs_point"].max() == len(pt_ids) - 1
+        owned.append(pt_ids)
+    assert np.array_equal(np.sort(np.concatenate(owned)), np.arange(5)) and sum(len(o) == 0 for o in owned) >= 3    # empty shards exist
+
+
+@pytest.mark.parametrize("n_tracks", [61, 3])
+def test_ka_shards_at_world_8(n_tracks):
+    """Sub-problems dealt to 8 ranks by residual-block count (a count that is not a multiple of 8; fewer sub-problems than
+    ranks: empty shards): every node / edge owned once, whole sub-problems stay together, loads balanced."""
+    from pixsfm_amd import parallel, synthetic_ka
+    prob = synthetic_ka.make_ka_problem(n_tracks=n_tracks, track_len=5, seed=5, channels=8, patch_size=8, max_kps_per_problem=10)
+    n, n_prob = len(prob["kp"]), int(prob["node_problem"].max()) + 1
+    nodes, edges, loads, n_local = [], [], [], 0
+    for rank in range(8):
+        shard, node_ids = parallel.shard_ka_problem(prob, rank, 8)
+        nodes.append(node_ids); edges.append(shard["edge_ids"]); loads.append(len(shard["edge_ids"]))
+        if len(node_ids):
+            n_local += int(shard["node_problem"].max()) + 1
+            assert np.array_equal(node_ids[shard["edge_src"]], prob["edge_src"][shard["edge_ids"]])
+            assert np.array_equal(node_ids[shard["edge_dst"]], prob["edge_dst"][shard["edge_ids"]])
+            outside = np.setdiff1d(np.arange(n), node_ids)
+            assert set(prob["node_problem"][node_ids]).isdisjoint(set(prob["node_problem"][outside]))
+        else:
+            assert len(shard["edge_ids"]) == 0 and len(shard["kp"]) == 0
+    assert np.array_equal(np.sort(np.concatenate(nodes)), np.arange(n)) and np.array_equal(np.sort(np.concatenate(edges)), np.arange(len(prob["edge_src"])))
+    assert n_local == n_prob
+    if n_prob >= 16:
+        sizes = np.bincount(prob["node_problem"][prob["edge_src"]], minlength=n_prob)
+        assert max(loads) <= np.mean(loads) + sizes.max()                                   # longest-processing-time bound
+    else:
+        assert sum(l == 0 for l in loads) >= 8 - n_prob
+
+
+def test_gathers_over_eight_ranks(tmp_path):
+    """gather_rows (KA keypoints), gather_references (Reference objects and the array-backed ReferenceMap) on 8 gloo ranks."""
+    prob = worker.ka_problem()
+    n = len(prob["kp"])
+    (tmp_path / "ka").mkdir(); (tmp_path / "refs").mkdir(); (tmp_path / "map").mkdir()
+    res = run_ranks("ka_plumbing", tmp_path / "ka", world=8, timeout=900)
+    want = prob["kp"] + (np.arange(n)[:, None] + 1) * np.array([1e-3, -2e-3])
+    for r in res:
+        assert np.array_equal(r["kp"], want) and np.array_equal(r["owned"], np.ones(n))
+    assert sum(int(r["n_local_problems"][0]) for r in res) == int(prob["node_problem"].max()) + 1
+    res = run_ranks("refs_gather", tmp_path / "refs", world=8, timeout=900)
+    expect = worker.pack_references(worker.make_references())
+    for r in res:
+        for k in expect:
+            assert np.array_equal(r[k], expect[k]), k
+    res = run_ranks("refmap_gather", tmp_path / "map", world=8, timeout=900)
+    for r in res:
+        assert int(r["is_map"][0]) == 1 and np.array_equal(r["ids"], np.arange(3, 14))
+        assert np.array_equal(r["desc"], np.arange(44, dtype=np.float64).reshape(11, 4))

@@ -3,9 +3,20 @@ pxr_ka_solve on small random problems -- camera models, shared cameras, random c
 parameter subsets / constant points, losses, interpolation switches, inner iterations, direct and iterative Schur solver,
 tolerances; KA with random bounds, constant nodes, weights.  A short horizon (few iterations) so that the accept / reject
 decisions of the two LM loops must coincide.
-python tools/fuzz_solve_vs_oracle.py [n_trials] [seed]"""
+
+By default the sweep runs the REFERENCE's arithmetic -- the exact-order evaluation (PXR_GRAM_CACHE=0) and the packed
+inner-iteration kernel (PXR_INNER_PACKED=1): the fp32 horizontal pass everywhere, what the oracle restates -- and holds the
+solvers to the tolerances of rounds 1-3 (final cost / parameters 1e-7, initial cost 1e-9).  `--default-arithmetic` sweeps the
+shipped defaults instead (Gram-matrix algebra, exact fp64), at the one looser tolerance that difference is priced at (5e-6, the
+value of tests/conftest.py FP32_PASS_PARAM_RTOL rounded down).
+python tools/fuzz_solve_vs_oracle.py [n_trials] [seed] [--default-arithmetic]"""
 import os
 import sys
+DEFAULT_ARITHMETIC = "--default-arithmetic" in sys.argv
+sys.argv = [a for a in sys.argv if a != "--default-arithmetic"]
+if not DEFAULT_ARITHMETIC:
+    os.environ["PXR_GRAM_CACHE"] = "0"
+    os.environ["PXR_INNER_PACKED"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'pixel-perfect-sfm_amd'))
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -62,12 +73,12 @@ for trial in range(n_trials):
     q, t, k, X = ba.params()
     so, qo, to, ko, Xo = pxo.ba_solve(prob, pxo.cfg(l2, fs, False), loss_o, *gauge, pxo.lm_options(**kw))
     tol = 1e-5 if (fs or solver == "iterative") else 1e-7
-    # the inner iterations of fp16 / fp32 patches and the opt-in evaluation from the Gram-matrix cache work on Gram matrices: exact
-    # in fp64 where the oracle restates the reference's fp32 horizontal pass -- parameters agree to ~1e-6, not 1e-7
-    if (kw.get("use_inner_iterations") and dt != np.float64) or os.environ.get("PXR_GRAM_CACHE") == "1":
+    # the shipped defaults work on Gram matrices (exact in fp64 where the oracle restates the reference's fp32 horizontal pass):
+    # parameters agree to ~1e-6 there, not 1e-7; the initial cost is the exact-order kernel's in every mode
+    if DEFAULT_ARITHMETIC and dt != np.float64:
         tol = max(tol, 5e-6)
     ok = sg["iterations"] == so["iterations"] and sg["num_successful"] == so["num_successful"] and sg["termination"] == so["termination"]
-    ok = ok and abs(sg["initial_cost"] - so["initial_cost"]) <= (1e-8 if os.environ.get("PXR_GRAM_CACHE") == "1" else 1e-9) * abs(so["initial_cost"])
+    ok = ok and abs(sg["initial_cost"] - so["initial_cost"]) <= 1e-9 * abs(so["initial_cost"])
     ok = ok and abs(sg["final_cost"] - so["final_cost"]) <= tol * max(abs(so["final_cost"]), 1e-12)
     err = 0.0
     for a, b in zip((q, t, k, X), (qo, to, ko, Xo)):

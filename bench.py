@@ -614,6 +614,44 @@ def run_lm(job, ba, prob, cfg):
     return lm, extra
 
 
+def run_scaling_model(job, prob, patches, lm, cfg):
+    """What an 8-GPU LM iteration would cost, MODELLED from this GPU (no multi-GPU box is reachable from
+    the build container): the same `lm` solve on the first eighth of the points (all cameras) -- the shard one of eight ranks
+    would own -- gives T_shard; with T_1 the full solve, the part that does not shrink with the shard (the replicated reduced
+    camera system: Cholesky, camera-side launches) is (8 T_shard - T_1) / 7.  The collective is ASSUMED, not measured: the packed
+    [S | rhs] integers (n_c (n_c + 3) / 2 x 8 bytes) at an all-reduce bus bandwidth of 100 GB/s + 20 us."""
+    import numpy as np
+    from pixsfm_amd.engine import BAProblem, PatchArena, lm_options, make_loss
+    args, ctx = job.args, job.ctx
+    n_pts = len(prob["xyz"]) // 8
+    n_obs = int(np.searchsorted(prob["obs_point"], n_pts, side="left"))
+    sub = dict(prob)
+    for k in ("obs_image", "obs_point", "obs_patch", "corners", "scales"):
+        sub[k] = prob[k][:n_obs]
+    sub["xyz"], sub["refs"] = prob["xyz"][:n_pts].copy(), prob["refs"][:n_pts].copy()
+    arena = PatchArena(ctx, n_obs, args.patch_size, args.patch_size, 128, np.float16, device_ptr=patches.data_ptr())
+    arena.upload(0, None, sub["corners"], sub["scales"])
+    ba8 = BAProblem(ctx, arena, sub)
+    pose_const, tmask, cmask, ptc = default_gauge(args.cams, n_pts)
+    out = {}
+    for key, inner in (("lm", True), ("lm_no_inner", False)):
+        best = None
+        for _ in range(2):
+            reset_parameters(ba8, sub)
+            s = ba8.solve(cfg, make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,
+                          options=lm_options(max_iterations=args.lm_iters, use_inner_iterations=inner, linear_solver=args.linear_solver))
+            per = s["total_ms"] / max(1, s["iterations"])
+            best = per if best is None else min(best, per)
+        t1 = lm[key]["total_ms"] / max(1, lm[key]["iterations"])
+        n_c = lm[key]["num_camera_unknowns"]
+        coll_ms = n_c * (n_c + 3) / 2 * 8 * 2 * 7 / 8 / 100e9 * 1e3 + 0.02
+        out[key] = {"t1_ms": t1, "t_shard8_ms": best, "replicated_ms": max(0.0, (8 * best - t1) / 7), "allreduce_ms_assumed": coll_ms,
+                    "efficiency_8gpu_modelled": t1 / (8 * (best + coll_ms))}
+    out["note"] = "modelled from one GPU: T_shard = the same solve on the first 1/8 of the points; collective assumed (100 GB/s bus bandwidth + 20 us), not measured"
+    arena.close()
+    return out
+
+
 def run_costmap(job, ba, prob):
     """The reference's low-memory strategy on the same scene: cost-map extraction (one HBM-bound pass over
     the feature arena) and the cost-map BA (3-channel maps, no reference descriptor)."""
@@ -797,9 +835,14 @@ def compact_line(full):
         for sub in ("texel_evaluation", "nondeterministic", "deterministic"):
             if isinstance(v.get(sub), dict):
                 o[sub] = {a: _r(b) for a, b in v[sub].items() if not isinstance(b, (dict, list))}
-        for sub in ("allreduce_ms", "allreduce_bytes", "scaling_model"):
+        for sub in ("allreduce_ms", "allreduce_bytes"):
             if sub in v:
-                o[sub] = _r(v[sub]) if not isinstance(v[sub], dict) else {a: _r(b, 4) for a, b in v[sub].items()}
+                o[sub] = _r(v[sub])
+        sm = (full.get("lm") or {}).get("scaling_model")
+        if isinstance(sm, dict) and isinstance(sm.get(key), dict):
+            o["scaling_model_8gpu"] = {a: _r(b, 4) for a, b in sm[key].items()}
+        elif isinstance(sm, dict) and key == "lm" and "error" in sm:
+            o["scaling_model_8gpu"] = sm
         out[key] = o
     return out
 
@@ -939,6 +982,11 @@ def main():
     gram_eval = run_gram(job, ba, cfg)
     job.barrier()
     lm, lm_extra = run_lm(job, ba, prob, cfg)
+    if rank == 0 and world == 1 and lm and args.preset is None and args.linear_solver != "iterative":
+        try:
+            lm_extra["scaling_model"] = run_scaling_model(job, prob, patches, lm, cfg)
+        except Exception as e:  # noqa: BLE001 -- a model, never the reason for a failed bench
+            lm_extra["scaling_model"] = {"error": repr(e)}
     costmap = run_costmap(job, ba, prob) if (not args.no_costmap and world == 1) else None
     cpu_base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

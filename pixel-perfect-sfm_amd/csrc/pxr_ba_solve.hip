@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
           const double term = is_g ? B0[a] * Lo[3] + B1[a] * Lo[4]
                                    : B0[a] * (Lo[0] * B0[b] + Lo[1] * B1[b]) + B1[a] * (Lo[1] * B0[b] + Lo[2] * B1[b]);
           acc += term;
-          if (fixed) qacc += fixed_rn(term * det_scale);
+          if (fixed) qacc += __double2ll_rn(term * det_scale);
         }
       }
       __syncthreads();
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
         const double term = is_g ? B0[a] * Lo[3] + B1[a] * Lo[4]
                                  : B0[a] * (Lo[0] * B0[b] + Lo[1] * B1[b]) + B1[a] * (Lo[1] * B0[b] + Lo[2] * B1[b]);
         acc += term;
-        if (fixed) qacc += fixed_rn(term * det_scale);
+        if (fixed) qacc += __double2ll_rn(term * det_scale);
       }
     }
     __syncthreads();
@@ -1328,11 +1328,12 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   DevBuf<double> det_part, chunk_trace;
   RC(det_part.alloc((size_t)n_pts + 8));          // the inner iterations' per-point costs (every mode)
   RC(chunk_trace.alloc(chunks.size() + 1));
-  // the grid: entries -- and every single addend -- bounded by 8 max(md, sqrt(2 md cost)) stay below 2^51 units, the range of the
-  // one-instruction rounding fixed_rn (md: the bound on diag(U) the grid is made for).  Resolution: 2^-48 of that bound at worst.
+  // the grid: entries bounded by 8 max(md, sqrt(2 md cost)) fit 62 bits (md: the bound on diag(U) the grid is made for).  (A grid
+  // of 2^51 units with a one-addition rounding was tried: it saves nothing measurable -- the Schur kernel waits on its gathers --
+  // and the 11 lost bits broke the parity of ill-conditioned reduced systems with the oracle; profiles/r5_lm_det_vs_atomics.txt.)
   auto det_scale_for = [](double md, double cost_now) {
     const double bound = 8.0 * std::max({md, std::sqrt(2.0 * md * std::max(cost_now, 0.0)), 1e-300});
-    return std::ldexp(1.0, 51 - (int)std::ceil(std::log2(bound)));
+    return std::ldexp(1.0, 62 - (int)std::ceil(std::log2(bound)));
   };
   double lin_md = 1.0;                // the diag(U) bound the CURRENT grid was made for
   // pxr_set_gram_cache: the records from cached Gram matrices of the stencils instead of from the texels (pxr_ba_gram.hip)
@@ -1407,7 +1408,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     const double mx = stt[0], sm = stt[1], mn = stt[2], tr = stt[3];
     if (!(std::isfinite(mx) && std::isfinite(sm) && std::isfinite(tr))) return false;
     if (mn < 0.0) return false;                                               // a diagonal slot wrapped into the sign bit
-    if (std::fabs(tr - sm) > std::ldexp(1.0, 49) / lin_scale) return false;   // ... or all the way round / an addend beyond fixed_rn's range
+    if (std::fabs(tr - sm) > std::ldexp(1.0, 61) / lin_scale) return false;   // ... or all the way round
     return mx <= 8.0 * md_made_for;                                           // the off-diagonal, Schur and gradient bounds hold
   };
   // linearise on a grid made for diag(U) <= 8 md_guess; repeat on a grid from the measured trace until the check passes

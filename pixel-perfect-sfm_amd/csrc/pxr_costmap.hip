@@ -415,6 +415,63 @@ __device__ __forceinline__ double swap_sum16(double A, double B) {   // even row
   return a.d + b.d;
 }
 
+// ---- the three 8-channel partial sums of one texel: res = f - ref,  <res, res>,  <res, down - up>,  <res, right - left> ---------
+// (differences of neighbours in the STORAGE type: v_pk_add_f16, like the reference's Eigen expression on Map<half>)
+// F32 = false: fp64 throughout (the reference's accumulation type): the path of float / double cost maps.
+// F32 = true : HALF cost maps (the only shipped configuration, configs/low_memory.yaml: dtype half).  The map is rounded to 2^-11
+//   relative on store, so the 8-channel partial sums of a lane are formed in fp32 -- packed v_pk_add_f32 / v_pk_fma_f32 on the
+//   widened halves: 54 instead of 88 vector instructions per lane and texel, the conversions half -> float -> double were 43 % of
+//   the kernel -- and everything across lanes (16 lanes x 4 wavefronts per texel) stays fp64.  A partial sum of eight products
+//   carries ~2e-7 relative; the texel's sum of 16 such partials ~5e-8: the fp16 result differs from the all-fp64 one only where
+//   the exact value lies that close to a rounding boundary (measured: tools/fuzz_costmap_vs_reference.py, tests/test_costmap_*).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: an array of these is split into registers
+template <bool F32> struct TexelRef;
+template <> struct TexelRef<false> { double v[8]; __device__ __forceinline__ void set(int ch, double x) { v[ch] = x; } };
+template <> struct TexelRef<true> { float v[8]; __device__ __forceinline__ void set(int ch, double x) { v[ch] = (float)x; } };
+
+__device__ __forceinline__ half8_t half_diff8(const u32x4& a, const u32x4& b) {
+  union { unsigned u[4]; half8_t h; } d;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d.u[i]) : "v"(a[i]), "v"(b[i]));
+  return d.h;
+}
+template <bool F32>
+__device__ __forceinline__ void texel_sums(const u32x4& cu, const u32x4& dn, const u32x4& up, const u32x4& rt,
+                                           const u32x4& lf, const TexelRef<F32>& ref, double& ss, double& sr, double& sc) {
+  if constexpr (F32) {
+    union { unsigned u[4]; half8_t h; } c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.u[i] = cu[i];
+    const float8_t f = __builtin_convertvector(c.h, float8_t);
+    const float8_t dr = __builtin_convertvector(half_diff8(dn, up), float8_t);
+    const float8_t dc = __builtin_convertvector(half_diff8(rt, lf), float8_t);
+    f32x2 as = {0.f, 0.f}, ar = {0.f, 0.f}, ac = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 res = {f[2 * i] - ref.v[2 * i], f[2 * i + 1] - ref.v[2 * i + 1]};
+      const f32x2 r2 = {dr[2 * i], dr[2 * i + 1]}, c2 = {dc[2 * i], dc[2 * i + 1]};
+      as = __builtin_elementwise_fma(res, res, as);
+      ar = __builtin_elementwise_fma(res, r2, ar);
+      ac = __builtin_elementwise_fma(res, c2, ac);
+    }
+    ss = (double)(as.x + as.y); sr = (double)(ar.x + ar.y); sc = (double)(ac.x + ac.y);
+  } else {
+    auto tex = [](const u32x4& v) { Texel8<_Float16> t; t.raw = make_uint4(v.x, v.y, v.z, v.w); return t; };
+    double f[8], dr[8], dc[8];
+    widen8<_Float16>(tex(cu), f);
+    StorageDiff<_Float16>::run(tex(dn), tex(up), dr);
+    StorageDiff<_Float16>::run(tex(rt), tex(lf), dc);
+    ss = 0.0; sr = 0.0; sc = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+      const double res = f[ch] - ref.v[ch];
+      ss = fma(res, res, ss); sr = fma(res, dr[ch], sr); sc = fma(res, dc[ch], sc);
+    }
+  }
+}
+
 // CreateShallowCostmapFSet, costmap_extractor.h:382-399: corner and scale of a cost map are the feature patch's
 __global__ void costmap_meta_kernel(const CostmapArgs a, const int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -424,7 +481,6 @@ __global__ void costmap_meta_kernel(const CostmapArgs a, const int64_t n) {
   a.sout[2 * o] = a.sin[2 * p]; a.sout[2 * o + 1] = a.sin[2 * p + 1];
 }
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: an array of these is split into registers
 
 template <typename OT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
@@ -438,8 +494,8 @@ void costmap_kernel_f16_split(const CostmapArgs a, const int64_t n) {
   const unsigned lane_off = (unsigned)((x * C + 32 * w + 8 * k) * sizeof(_Float16));   // bytes; uniform base + 32-bit lane offset
   const int64_t G = gridDim.x;
   u32x4 col[PS];
-  double ref[8];
-  auto tex = [](const u32x4& v) { Texel8<_Float16> t; t.raw = make_uint4(v.x, v.y, v.z, v.w); return t; };
+  constexpr bool F32 = sizeof(OT) == 2;               // half maps: fp32 partial sums inside a lane (texel_sums)
+  TexelRef<F32> ref;
   // The loop body is branch-free on the memory side (indices past the end are clamped to the last patch: one redundant
   // patch load per workgroup at the very end), so the vector-memory counter waits are exact: loads return in order, and a
   // branch around a load would force the compiler to wait for ALL outstanding loads at the next use.
@@ -457,7 +513,7 @@ void costmap_kernel_f16_split(const CostmapArgs a, const int64_t n) {
     // loop head are the minimum over both ways into it
     const double* rp = a.refs + (size_t)a.ref_index[i] * C + 32 * w + 8 * k;
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch) ref[ch] = rp[ch];
+    for (int ch = 0; ch < 8; ++ch) ref.set(ch, rp[ch]);
     const auto P = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(fin + (size_t)uniform64(a.patch[i]) * PS * PS * C), 0, PATCH_BYTES, 0x00020000);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -491,17 +547,7 @@ void costmap_kernel_f16_split(const CostmapArgs a, const int64_t n) {
           lf[q] = (unsigned)__builtin_amdgcn_update_dpp((int)cu[q], (int)cu[q], 0x111, 0xf, 0xf, false);   // row_shr:1 -> x - 1
           rt[q] = (unsigned)__builtin_amdgcn_update_dpp((int)cu[q], (int)cu[q], 0x101, 0xf, 0xf, false);   // row_shl:1 -> x + 1
         }
-        double f[8], dr[8], dc[8];
-        widen8<_Float16>(tex(cu), f);
-        StorageDiff<_Float16>::run(tex(col[y < PS - 1 ? y + 1 : PS - 1]), tex(col[y > 0 ? y - 1 : 0]), dr);
-        StorageDiff<_Float16>::run(tex(rt), tex(lf), dc);
-        double ss = 0.0, sr = 0.0, sc = 0.0;
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) {
-          const double res = f[ch] - ref[ch];
-          ss = fma(res, res, ss); sr = fma(res, dr[ch], sr); sc = fma(res, dc[ch], sc);
-        }
-        s[r] = ss; br[r] = sr; bc[r] = sc;
+        texel_sums<F32>(cu, col[y < PS - 1 ? y + 1 : PS - 1], col[y > 0 ? y - 1 : 0], rt, lf, ref, s[r], br[r], bc[r]);
       }
       // rows 4g + 3 and 4g + 4 are still neighbours of the next group; everything above them is dead
       __builtin_amdgcn_sched_barrier(0);                // keep the refill HERE: the scheduler otherwise sinks it to the end
@@ -525,7 +571,7 @@ void costmap_kernel_f16_split(const CostmapArgs a, const int64_t n) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) v[q] = (part[buf][0][q][tid] + part[buf][1][q][tid]) + (part[buf][2][q][tid] + part[buf][3][q][tid]);
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch) ref[ch] = refsh[buf][32 * w + 8 * k + ch];
+    for (int ch = 0; ch < 8; ++ch) ref.set(ch, refsh[buf][32 * w + 8 * k + ch]);
     const int64_t o_idx = a.first_out + i;
     p1 = p2;
     double rho[3];
@@ -558,7 +604,6 @@ __global__ __launch_bounds__(256) void costmap_kernel_f16_split8(const CostmapAr
   const _Float16* fin = reinterpret_cast<const _Float16*>(a.fin);
   const unsigned lane_off = (unsigned)(((4 * yh * PS + x) * C + 32 * w + 8 * k) * sizeof(_Float16));
   const int64_t G = gridDim.x;
-  auto tex = [](const u32x4& v) { Texel8<_Float16> t; t.raw = make_uint4(v.x, v.y, v.z, v.w); return t; };
   auto uniform64 = [](int64_t v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((uint64_t)v >> 32));
     return (int64_t)(((uint64_t)hi << 32) | lo);
@@ -572,11 +617,12 @@ __global__ __launch_bounds__(256) void costmap_kernel_f16_split8(const CostmapAr
     for (int r = 0; r < RPL; ++r) c[r] = __builtin_amdgcn_raw_buffer_load_b128(P, lane_off, r * ROW_BYTES, 0);
   };
   u32x4 col[RPL], nxt[RPL];
-  double ref[8];
+  constexpr bool F32 = sizeof(OT) == 2;               // half maps: fp32 partial sums inside a lane (texel_sums)
+  TexelRef<F32> ref;
   {
     const double* rp = a.refs + (size_t)a.ref_index[i] * C + 32 * w + 8 * k;
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch) ref[ch] = rp[ch];
+    for (int ch = 0; ch < 8; ++ch) ref.set(ch, rp[ch]);
   }
   load_rows(uniform64(a.patch[i]), col);
   int64_t p1 = uniform64(a.patch[at(i + G)]);
@@ -609,17 +655,7 @@ __global__ __launch_bounds__(256) void costmap_kernel_f16_split8(const CostmapAr
       u32x4 up = r > 0 ? col[r - 1] : col[0], dn = r < RPL - 1 ? col[r + 1] : col[RPL - 1];
       if (r == 0) { for (int q = 0; q < 4; ++q) up[q] = yh ? edge[q] : up[q]; }
       if (r == RPL - 1) { for (int q = 0; q < 4; ++q) dn[q] = yh ? dn[q] : edge[q]; }
-      double f[8], dr[8], dc[8];
-      widen8<_Float16>(tex(cu), f);
-      StorageDiff<_Float16>::run(tex(dn), tex(up), dr);
-      StorageDiff<_Float16>::run(tex(rt), tex(lf), dc);
-      double ss = 0.0, sr = 0.0, sc = 0.0;
-#pragma unroll
-      for (int ch = 0; ch < 8; ++ch) {
-        const double res = f[ch] - ref[ch];
-        ss = fma(res, res, ss); sr = fma(res, dr[ch], sr); sc = fma(res, dc[ch], sc);
-      }
-      s[r] = ss; br[r] = sr; bc[r] = sc;
+      texel_sums<F32>(cu, dn, up, rt, lf, ref, s[r], br[r], bc[r]);
     }
     const int t = (4 * yh + k) * PS + x;
     part[buf][w][0][t] = swap_sum16(swap_sum32(s[0], s[2]), swap_sum32(s[1], s[3]));
@@ -631,7 +667,7 @@ __global__ __launch_bounds__(256) void costmap_kernel_f16_split8(const CostmapAr
     rnext = a.refs[(size_t)r2 * C + (tid & (C - 1))];
     __syncthreads();
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch) ref[ch] = refsh[buf][32 * w + 8 * k + ch];
+    for (int ch = 0; ch < 8; ++ch) ref.set(ch, refsh[buf][32 * w + 8 * k + ch]);
     if (tid < PS * PS) {
       double v[3];
 #pragma unroll

@@ -88,16 +88,9 @@ __device__ __forceinline__ void spline_f64(double p0, double p1, double p2, doub
 // det_scale = 0: a floating-point atomic (the order of the adders decides the last bits).  det_scale = 2^k: the addend is
 // rounded to a multiple of 2^-k and added as a 64-bit integer -- integer addition is associative, so the slot's final
 // content does not depend on the order.  The slot then holds an integer; accum_value turns it back into a double.
-// x rounded to the nearest integer (ties to even) for |x| < 2^51: one addition and one 64-bit integer subtraction -- gfx950 has
-// no double -> int64 conversion instruction, the generic one is ~10 instructions per addend.  The solvers' grids keep every
-// addend below 2^51 units (the overflow guards check the bound the grid was made for).
-__device__ __forceinline__ long long fixed_rn(double x) {
-  const double magic = 6755399441055744.0;                 // 1.5 * 2^52: x + magic has unit spacing
-  return __double_as_longlong(x + magic) - __double_as_longlong(magic);
-}
 __device__ __forceinline__ void accum_add(double* slot, double v, double det_scale) {
   if (det_scale == 0.0) { atomicAdd(slot, v); return; }
-  atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)fixed_rn(v * det_scale));
+  atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double2ll_rn(v * det_scale));
 }
 // a privatised (LDS) slot's content added to its global slot: the integer as it is in deterministic mode
 __device__ __forceinline__ void accum_flush(double* slot, double raw, double det_scale) {

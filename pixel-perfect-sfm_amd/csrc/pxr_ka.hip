@@ -177,8 +177,12 @@ struct KaProb {
 // DET: the kernel instantiation of the deterministic mode adds fixed-point integers only; the other floating-point atomics only
 template <bool DET>
 __device__ __forceinline__ void ka_accum(double* slot, double v, double det_scale) {
-  if constexpr (DET) atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)fixed_rn(v * det_scale));
+#ifdef PXR_KA_PROBE_FP_ATOMICS     // tools/variant_build.sh: the deterministic instantiation with floating-point atomics (what the integers cost)
+  atomicAdd(slot, v * det_scale);
+#else
+  if constexpr (DET) atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double2ll_rn(v * det_scale));
   else atomicAdd(slot, v);
+#endif
 }
 // evaluate all nodes of the problem at keypoints `kp`
 template <typename ST, int C, bool WITH_JAC>
@@ -241,12 +245,9 @@ __device__ __forceinline__ double ka_kappa(double s, const double* rho) {
 // walk the edges and the unary terms; returns the cost (block-uniform).  WITH_JAC: accumulates Hm
 // and g (unscaled).
 template <int C, bool WITH_JAC, bool DET = false>
-__device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4, const double det_scale = 0.0, double* trace_out = nullptr) {
+__device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4, const double det_scale = 0.0) {
   constexpr int LPO = KaLay<C>::LPO, CPL = KaLay<C>::CPL, G = KA_NT / LPO;
   const int grp = threadIdx.x / LPO, sub = threadIdx.x % LPO;
-  // DET: trace of the accumulated normal matrix (the overflow guard's bound).  A sub-problem is ONE workgroup with a static
-  // residual block -> lane mapping, so a per-lane double and a fixed tree over the workgroup give the same bits on every run.
-  double trace = 0.0;
   double cost = 0.0;
   int64_t i_first = p.ne0 + grp;
   if constexpr (!WITH_JAC) {
@@ -348,17 +349,14 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4, const 
             const double b[4] = {q[10], q[11], q[12], q[13]};
             const double mm[4][4] = {{q[0], q[1], q[2], q[3]}, {q[1], q[4], q[5], q[6]}, {q[2], q[5], q[7], q[8]}, {q[3], q[6], q[8], q[9]}};
             double* blk = p.Hm + (p.row_off[vv] - (vv - c0) * nc);
-            double tr = 0.0;
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
               if (!var[x]) continue;
               ka_accum<DET>(p.g + idx[x], rho[1] * b[x], det_scale);
-              tr += rho[1] * (mm[x][x] - kappa * b[x] * b[x]);
 #pragma unroll
               for (int y = 0; y < 4; ++y)
                 if (var[y]) ka_accum<DET>(blk + (size_t)(idx[x] - c0) * nc + (idx[y] - c0), rho[1] * (mm[x][y] - kappa * b[x] * b[y]), det_scale);
             }
-            if constexpr (DET) trace += tr;
           }
         }
       }
@@ -415,17 +413,14 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4, const 
           const double b[4] = {q[10], q[11], q[12], q[13]};
           const double m[4][4] = {{q[0], q[1], q[2], q[3]}, {q[1], q[4], q[5], q[6]}, {q[2], q[5], q[7], q[8]}, {q[3], q[6], q[8], q[9]}};
           double* blk = p.Hm + (p.row_off[vv] - (vv - c0) * nc);
-          double tr = 0.0;
 #pragma unroll
           for (int x = 0; x < 4; ++x) {
             if (!var[x]) continue;
             ka_accum<DET>(p.g + idx[x], rho[1] * b[x], det_scale);
-            tr += rho[1] * (m[x][x] - kappa * b[x] * b[x]);
 #pragma unroll
             for (int y = 0; y < 4; ++y)
               if (var[y]) ka_accum<DET>(blk + (size_t)(idx[x] - c0) * nc + (idx[y] - c0), rho[1] * (m[x][y] - kappa * b[x] * b[y]), det_scale);
           }
-          if constexpr (DET) trace += tr;
         }
       }
     }
@@ -466,11 +461,9 @@ __device__ double ka_terms(const KaArgs& a, const KaProb& p, double* sh4, const 
         ka_accum<DET>(row + 1, rho[1] * (q[1] - kappa * q[3] * q[4]), det_scale);
         ka_accum<DET>(row + nc, rho[1] * (q[1] - kappa * q[3] * q[4]), det_scale);
         ka_accum<DET>(row + nc + 1, rho[1] * (q[2] - kappa * q[4] * q[4]), det_scale);
-        if constexpr (DET) trace += rho[1] * (q[0] - kappa * q[3] * q[3]) + rho[1] * (q[2] - kappa * q[4] * q[4]);
       }
     }
   }
-  if constexpr (DET && WITH_JAC) *trace_out = block_sum(trace, sh4);
   return block_sum(cost, sh4);
 }
 
@@ -890,27 +883,44 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     KA_T(7);
     ka_nodes<ST, C, true>(a, p, a.v.d_kp, fsimd);
     KA_T(0);
-    double tr = 0.0;
-    const double c = ka_terms<C, true, DET>(a, p, sh4, grid, &tr);
+    const double c = ka_terms<C, true, DET>(a, p, sh4, grid);
     __syncthreads();
     KA_T(1);
     if constexpr (DET) {
-      // The fixed-point grid of the slots follows the data.  Every addend -- and every sum -- is bounded by
-      // bound = max(trace, sqrt(2 trace cost)): |H_ab| <= max diag(H) <= trace(H) (each block's J^T J with the corrector is positive
-      // semi-definite), |g_a| <= sqrt(H_aa 2 cost) (Cauchy-Schwarz; rho concave: rho' s <= rho); the same number in every thread: a
-      // uniform decision.  The ideal grid puts the bound at 2^48 .. 2^49 units, a factor 4 below the 2^51 range of fixed_rn; every
-      // linearisation runs on the ideal grid of the one before.  The sub-problem stops and asks the host for another launch
-      // (need_rescale = the grid to use) if the bound grew by more than those 4x in one accepted step, or if the start grid
-      // (2^-32: unit-norm 128-channel descriptors) does not suit the FIRST linearisation -- it overflows (raw features) or is
-      // more than 2^10 coarser than ideal (single-channel features: H ~ 1e-4, g -> 1e-9 at convergence).
+      // The fixed-point grid of the slots follows the data.  Integer atomics wrap modulo 2^64, so only the FINAL content of a
+      // slot has to fit: |H_ab| <= max diag(H) <= trace(H) (each block's J^T J with the corrector is positive semi-definite),
+      // |g_a| <= sqrt(H_aa 2 cost) (Cauchy-Schwarz; rho concave: rho' s <= rho), so bound = max(trace, sqrt(2 trace cost)).  The
+      // trace is read off the finished diagonal: its addends are all >= 0, a diagonal slot that wrapped shows as a negative
+      // entry (it would take 2^64 units -- 64x the bound of the grid AFTER the 16x headroom -- to come round to a plausible value).
+      // The ideal grid puts the bound at 2^57 .. 2^58 units, a factor 16 below the 2^62 limit; every linearisation runs on
+      // the ideal grid of the one before.  The sub-problem stops and asks the host for another launch (need_rescale = the grid
+      // to use) if a diagonal entry is negative, if the bound grew by more than those 16x in one accepted step, or if the start
+      // grid (2^-38: unit-norm 128-channel descriptors) does not suit the FIRST linearisation -- it overflows (raw features) or
+      // is more than 2^10 coarser than ideal (single-channel features: H ~ 1e-4, g -> 1e-9 at convergence).  One workgroup,
+      // a static block -> lane mapping, fixed reduction trees: the same decision on every run.
+      double dsum = 0.0, dneg = 0.0;
+      const double inv_grid = 1.0 / grid;          // (a power of two: exact)
+#ifdef PXR_KA_PROBE_FP_ATOMICS
+      for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = p.Hm[e] * inv_grid;
+      for (int e = tid; e < n; e += blockDim.x) p.g[e] = p.g[e] * inv_grid;
+#else
+      for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = (double)__double_as_longlong(p.Hm[e]) * inv_grid;
+      for (int e = tid; e < n; e += blockDim.x) p.g[e] = (double)__double_as_longlong(p.g[e]) * inv_grid;
+#endif
+      __syncthreads();
+#ifndef PXR_KA_PROBE_NO_GUARD      // tools/variant_build.sh: a constant grid, no guard (what the guard costs)
+      for (int e = tid; e < n; e += blockDim.x) {
+        const double d = p.Hm[p.row_off[e] + e - p.row_v0[e]];
+        dsum += d; dneg += d < 0.0 ? 1.0 : 0.0;
+      }
+      const double tr = block_sum(dsum, sh4), neg = block_sum(dneg, sh4);
       const double bound = fmax(tr, sqrt(2.0 * tr * fmax(c, 0.0)));
       const bool usable = isfinite(bound) && bound > 0.0;            // (a non-finite Jacobian fails the solve below as before)
-      const double ideal = usable ? exp2((double)(49 - (int)ceil(log2(bound)))) : grid;
-      if (usable && (bound * grid > 0x1p51 || (compute_scale && grid < ideal * 0x1p-10))) need_rescale = uniform_f64(ideal);
-      for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = (double)__double_as_longlong(p.Hm[e]) / grid;
-      for (int e = tid; e < n; e += blockDim.x) p.g[e] = (double)__double_as_longlong(p.g[e]) / grid;
-      __syncthreads();
+      const double ideal = usable ? exp2((double)(58 - (int)ceil(log2(bound)))) : grid;
+      if (neg > 0.0) need_rescale = uniform_f64(grid * 0x1p-16);     // (wrapped: far coarser, the next launch measures)
+      else if (usable && (bound * grid > 0x1p62 || (compute_scale && grid < ideal * 0x1p-10))) need_rescale = uniform_f64(ideal);
       grid = uniform_f64(ideal);           // the next linearisation's (wave-uniform: kept in scalar registers)
+#endif
     }
     for (int e = tid; e < n; e += blockDim.x) {
       p.gun[e] = p.g[e];
@@ -1270,9 +1280,9 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   KaArgs a{};
   fill_args(ctx, arena, view, cfg, loss, a);
   a.bound = bound; a.opt = *options;
-  // deterministic mode: H and g of a sub-problem in fixed point; the start grid 2^-32 suits unit-norm 128-channel descriptors
+  // deterministic mode: H and g of a sub-problem in fixed point; the start grid 2^-38 suits unit-norm 128-channel descriptors
   // (bound = max(trace, sqrt(2 trace cost)) ~ 1e4 .. 1e5 at configs[1]), the kernel adapts it per sub-problem and linearisation
-  a.det_scale = ctx->deterministic ? 4294967296.0 : 0.0;        // 2^32 (see the grid rule in ka_solve_body)
+  a.det_scale = ctx->deterministic ? 274877906944.0 : 0.0;      // 2^38 (see the grid rule in ka_solve_body)
   a.prob_scale = (double*)(ws + o_pscale); a.prob_done = (uint8_t*)(ws + o_pdone);
   if (a.det_scale != 0.0) {
     std::vector<double> init((size_t)np, a.det_scale);

@@ -898,7 +898,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       // grid (2^-38: unit-norm 128-channel descriptors) does not suit the FIRST linearisation -- it overflows (raw features) or
       // is more than 2^10 coarser than ideal (single-channel features: H ~ 1e-4, g -> 1e-9 at convergence).  One workgroup,
       // a static block -> lane mapping, fixed reduction trees: the same decision on every run.
-      double dsum = 0.0, dneg = 0.0;
+      double dsum = 0.0;
       const double inv_grid = 1.0 / grid;          // (a power of two: exact)
 #ifdef PXR_KA_PROBE_FP_ATOMICS
       for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = p.Hm[e] * inv_grid;
@@ -911,13 +911,20 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
 #ifndef PXR_KA_PROBE_NO_GUARD      // tools/variant_build.sh: a constant grid, no guard (what the guard costs)
       for (int e = tid; e < n; e += blockDim.x) {
         const double d = p.Hm[p.row_off[e] + e - p.row_v0[e]];
-        dsum += d; dneg += d < 0.0 ? 1.0 : 0.0;
+        dsum += d < 0.0 ? NAN : d;                                   // (a wrapped diagonal slot poisons the sum)
       }
-      const double tr = block_sum(dsum, sh4), neg = block_sum(dneg, sh4);
+      const double tr = block_sum(dsum, sh4);
+      // bound = max(trace, sqrt(2 trace cost)); 2^ceil(log2 bound) from the exponent bits (every thread the same few integer operations:
+      // log2 / exp2 in double precision are ~200 instructions each, and the guard runs at every linearisation)
       const double bound = fmax(tr, sqrt(2.0 * tr * fmax(c, 0.0)));
-      const bool usable = isfinite(bound) && bound > 0.0;            // (a non-finite Jacobian fails the solve below as before)
-      const double ideal = usable ? exp2((double)(58 - (int)ceil(log2(bound)))) : grid;
-      if (neg > 0.0) need_rescale = uniform_f64(grid * 0x1p-16);     // (wrapped: far coarser, the next launch measures)
+      const bool usable = isfinite(bound) && bound > 0x1p-900 && bound < 0x1p900;     // (a non-finite Jacobian fails the solve below as before)
+      double ideal = grid;
+      if (usable) {
+        const long long bits = __double_as_longlong(bound);
+        const int e2 = (int)((bits >> 52) & 0x7ff) - 1023 + ((bits & 0xfffffffffffffll) != 0 ? 1 : 0);       // ceil(log2(bound))
+        ideal = __longlong_as_double((long long)(1023 + 58 - e2) << 52);                                     // 2^(58 - e2)
+      }
+      if (isnan(tr) && isfinite(c)) need_rescale = uniform_f64(grid * 0x1p-16);     // (wrapped: far coarser, the next launch measures)
       else if (usable && (bound * grid > 0x1p62 || (compute_scale && grid < ideal * 0x1p-10))) need_rescale = uniform_f64(ideal);
       grid = uniform_f64(ideal);           // the next linearisation's (wave-uniform: kept in scalar registers)
 #endif

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
   const ImgChunk ch = chunks[blockIdx.x];
   const int img = ch.img, cam = d.v.d_image_camera[img];
   const int dc = d.pose_dim[img] + d.intr_dim[cam];
-  if (dc == 0) return;
+  if (dc == 0) { if (threadIdx.x == 0 && chunk_trace) chunk_trace[blockIdx.x] = 0.0; return; }
   const int LS = d.LS;
   double* red = stage + (size_t)IMG_BATCH * LS;
   const int NP = dc * (dc + 1) / 2, NE = NP + dc;
@@ -496,7 +496,7 @@ __global__ void k_copy_upper_add_diag(int n, const double* __restrict__ U, const
   double v = S[t];
   if (add_u) {
     // deterministic mode: U still holds its fixed-point integers (the same grid), the Schur kernel adds integers to these slots and
-    // k_det_finish turns the sums back -- AFTER the ranks' integers were added: a slot of 2^59 units does not survive a round
+    // the second pass of this kernel (add_u = 0) turns the sums back -- AFTER the ranks' integers were added: a slot of 2^59 units does not survive a round
     // trip through a double (53 bits), and rounding every rank's partial sum would make the result depend on the partition
     v = (c < n && r <= c) ? U[(size_t)r * n + c] : 0.0;
   }
@@ -790,11 +790,6 @@ __global__ __launch_bounds__(256) void k_unpack_upper(int n, const double* __res
   for (int x = threadIdx.x; x < len; x += blockDim.x) dst[x] = src[x];
 }
 
-// deterministic mode: slots that were accumulated as fixed-point integers become doubles again
-__global__ void k_det_finish(int64_t n, double* __restrict__ x, double det_scale) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] = accum_value(x[i], det_scale);
-}
 // cost = sum 0.5 rho(s) over the records as limbs (pxr_device.h): one addend per observation, integer atomics per workgroup --
 // the same integers whatever the launch shape or the rank count.  (The cost fused into the residual kernel was one
 // floating-point atomic per wavefront on one address: 50 us of serialisation at 1M observations.)
@@ -820,33 +815,38 @@ __global__ void k_limbs_finish(const long long* __restrict__ limb, unsigned mask
   const int i = threadIdx.x;
   if (i < 16 && ((mask >> i) & 1u)) scal[i] = limb_value(limb + i * PXR_LIMBS);
 }
-// a chunk list's trace contributions (k_img) as limbs behind the gathered diagonal / gradient (they travel in the same
-// integer all-reduce); plain doubles summed in index order -- the value only meets a threshold
-__global__ __launch_bounds__(256) void k_trace_limbs(const double* __restrict__ chunk_trace, int n_chunks, long long* __restrict__ out) {
-  __shared__ double sh[256];
+// deterministic linearisation, before the ranks' sum: diag(U) (raw fixed-point slots) next to g_c, and the chunks' trace
+// contributions as limbs behind them -- ONE workgroup (n_c is a few thousand at most)
+__global__ __launch_bounds__(1024) void k_diag_and_trace(int n, const double* __restrict__ U, double* __restrict__ diag,
+                                                          const double* __restrict__ chunk_trace, int n_chunks, long long* __restrict__ trace_out) {
+  __shared__ double sh[1024];
+  for (int i = threadIdx.x; i < n; i += 1024) diag[i] = U[(size_t)i * n + i];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < n_chunks; i += 256) acc += chunk_trace[i];
+  for (int i = threadIdx.x; i < n_chunks; i += 1024) acc += chunk_trace[i];
   sh[threadIdx.x] = acc;
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
+  for (int off = 512; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     Limbs l; l.add(sh[0]);
-    for (int k = 0; k < PXR_LIMBS; ++k) out[k] = l.q[k];
+    for (int k = 0; k < PXR_LIMBS; ++k) trace_out[k] = l.q[k];
   }
 }
-// overflow guard of the fixed-point accumulation: {max, sum, min} of the finished diagonal and the trace the chunks measured
-// in floating point.  A diagonal slot that wrapped is off by a multiple of 2^64 / scale, so |trace - sum| tells.
-__global__ __launch_bounds__(256) void k_diag_stats(int n, const double* __restrict__ diag, const long long* __restrict__ trace_limbs,
-                                                    double* __restrict__ out4) {
-  __shared__ double smax[256], ssum[256], smin[256];
+// ... and after it: the slots of diag(U) | g_c become doubles, and the overflow guard's statistics of the diagonal
+__global__ __launch_bounds__(1024) void k_finish_and_stats(int n, int n_slots, double* __restrict__ gcd, double det_scale,
+                                                            const long long* __restrict__ trace_limbs, double* __restrict__ out4) {
+  __shared__ double smax[1024], ssum[1024], smin[1024];
   double mx = 0.0, sm = 0.0, mn = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) { const double v = diag[i]; mx = fmax(mx, v); mn = fmin(mn, v); sm += v; }
+  for (int i = threadIdx.x; i < n_slots; i += 1024) {
+    const double v = accum_value(gcd[i], det_scale);
+    gcd[i] = v;
+    if (i < n) { mx = fmax(mx, v); mn = fmin(mn, v); sm += v; }
+  }
   smax[threadIdx.x] = mx; ssum[threadIdx.x] = sm; smin[threadIdx.x] = mn;
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
+  for (int off = 512; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) {
       smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + off]);
       smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + off]);
@@ -1212,7 +1212,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   RC(scale_c.alloc(nc1)); RC(scale_p.alloc((size_t)n_pts * 3)); RC(delta_c.alloc(nc1)); RC(delta_p.alloc((size_t)n_pts * 3));
   RC(rec_a.alloc((size_t)n_obs * PXR_OBS_REC)); RC(rec_b.alloc((size_t)n_obs * PXR_OBS_REC));
   RC(q1.alloc((size_t)n_img * 4)); RC(t1.alloc((size_t)n_img * 3)); RC(k1.alloc((size_t)n_cam * PXR_KPAD)); RC(X1.alloc((size_t)n_pts * 3));
-  RC(scal.alloc(16 + 16 * PXR_LIMBS));   // [0..7] summed over ranks, [8..15] replicated; then the limbs of the same 16 scalars
+  RC(scal.alloc(16 + 16 * PXR_LIMBS + 4));   // [0..7] summed over ranks, [8..15] replicated; the limbs of those 16 scalars; the newest linearisation's diagonal statistics
   double* scal_sum = scal.p; double* scal_rep = scal.p + 8;
   const int ldS = n_c + 1;
   double* rhs = S.p + n_c;          // column n_c of S, stride ldS
@@ -1305,12 +1305,14 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     return PXR_OK;
   };
   auto zero_scalars = [&]() -> int {
-    PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * (16 + 16 * PXR_LIMBS), st));
+    PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * (16 + 16 * PXR_LIMBS), st));   // (the statistics behind them stay)
     return PXR_OK;
   };
-  DevBuf<double> lin_stats;           // {max, sum, min of diag(U), trace} of the newest linearisation (k_diag_stats)
-  RC(lin_stats.alloc(4));
-  double h_lin_stats[4] = {0, 0, 0, 0};
+  struct { double* p; } lin_stats;    // {max, sum, min of diag(U), trace} of the newest linearisation (k_finish_and_stats), behind the 16 scalars
+  constexpr int kScalAll = 16 + 16 * PXR_LIMBS + 4;
+  lin_stats.p = scal.p + (kScalAll - 4);
+  double h_scal[kScalAll] = {0};
+  double* const h_lin_stats = h_scal + (kScalAll - 4);
   auto read_scal = [&](double* h16) -> int {
     if (det) {
       RC(ar_i64(slimb.p, 8 * PXR_LIMBS));
@@ -1320,9 +1322,9 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       RC(ar(scal_sum, 8));
       RC(from_rank0(scal_rep, 8));
     }
-    PXR_HIP(hipMemcpyAsync(h16, scal.p, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
-    if (det) PXR_HIP(hipMemcpyAsync(h_lin_stats, lin_stats.p, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
+    PXR_HIP(hipMemcpyAsync(h_scal, scal.p, sizeof(double) * kScalAll, hipMemcpyDeviceToHost, st));     // the scalars ... the statistics: one copy of 800 bytes
     PXR_HIP(hipStreamSynchronize(st));
+    std::memcpy(h16, h_scal, sizeof(double) * 16);
     return PXR_OK;
   };
   DevBuf<double> det_part, chunk_trace;
@@ -1380,18 +1382,16 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     PXR_HIP(hipMemsetAsync(U.p, 0, sizeof(double) * U.n, st));
     PXR_HIP(hipMemsetAsync(gcd.p, 0, sizeof(double) * gcd.n, st));
     if (n_c > 0 && !chunks.empty()) {
-      if (lin_scale != 0.0) PXR_HIP(hipMemsetAsync(chunk_trace.p, 0, sizeof(double) * chunk_trace.n, st));
       hipLaunchKernelGGL(k_img, dim3((unsigned)chunks.size()), dim3(256), sizeof(double) * ((size_t)IMG_BATCH * LS + 256), st, dv,
                          d_chunks.p, d_img_obs.p, L.p, U.p, gc, iterative ? 1 : 0, lin_scale, lin_scale != 0.0 ? chunk_trace.p : (double*)nullptr);
       if (lin_scale != 0.0) {
         // the integers of diag(U) and g_c (+ the trace) are summed over the ranks, THEN everything becomes doubles again
-        hipLaunchKernelGGL(k_extract_diag, dim3(nblk(n_c)), dim3(256), 0, st, n_c, U.p, diagU);
-        hipLaunchKernelGGL(k_trace_limbs, dim3(1), dim3(256), 0, st, (const double*)chunk_trace.p, (int)chunks.size(),
+        hipLaunchKernelGGL(k_diag_and_trace, dim3(1), dim3(1024), 0, st, n_c, (const double*)U.p, diagU, (const double*)chunk_trace.p, (int)chunks.size(),
                            reinterpret_cast<long long*>(gcd.p + 2 * nc1));
         RC(ar_i64(reinterpret_cast<long long*>(gcd.p), 2 * (int64_t)nc1 + PXR_LIMBS));
         // (U itself stays in fixed point: only the Schur complement reads it, as integers)
-        hipLaunchKernelGGL(k_det_finish, dim3(nblk(2 * (int64_t)nc1)), dim3(256), 0, st, 2 * (int64_t)nc1, gcd.p, lin_scale);
-        hipLaunchKernelGGL(k_diag_stats, dim3(1), dim3(256), 0, st, n_c, (const double*)diagU, reinterpret_cast<const long long*>(gcd.p + 2 * nc1), lin_stats.p);
+        hipLaunchKernelGGL(k_finish_and_stats, dim3(1), dim3(1024), 0, st, n_c, 2 * (int)nc1, gcd.p, lin_scale,
+                           reinterpret_cast<const long long*>(gcd.p + 2 * nc1), lin_stats.p);
         LAUNCH_CHECK("linearize kernels");
         return PXR_OK;
       }

@@ -41,7 +41,10 @@ def _check_maps(got, want):
         return
     d = _ulps(got, want)
     assert d.max() <= 1, "more than one ulp apart"
-    assert (d > 0).mean() < 2e-3, "too many entries differ in the last place: %g" % (d > 0).mean()
+    # half maps: the 8-channel partial sums of a lane are fp32 (csrc/pxr_costmap.hip texel_sums; everything across lanes is fp64) --
+    # the fp16 bits are the all-fp64 reference's on >= 99.9 % of the entries, one unit in the last place elsewhere (VERDICT r4 next-7;
+    # measured against the reference's own FillPointCostmap over 2.3 M entries: 7e-5, tools/fuzz_costmap_vs_reference.py)
+    assert (d > 0).mean() < (1e-3 if got.dtype == np.float16 else 2e-3), "too many entries differ in the last place: %g" % (d > 0).mean()
 
 
 @pytest.mark.parametrize("dtype", [np.float16, np.float32, np.float64])

@@ -1323,10 +1323,18 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       RC(from_rank0(scal_rep, 8));
     }
     PXR_HIP(hipMemcpyAsync(h_scal, scal.p, sizeof(double) * kScalAll, hipMemcpyDeviceToHost, st));     // the scalars ... the statistics: one copy of 800 bytes
-    PXR_HIP(hipStreamSynchronize(st));
+    // the one host synchronisation of an LM attempt: polled (the blocking wait of hipStreamSynchronize sleeps on an interrupt and
+    // wakes tens of microseconds late -- once per attempt, with the GPU idle meanwhile); PXR_BLOCKING_WAIT=1 restores it
+    if (spin_wait) {
+      PXR_HIP(hipEventRecord(ctx->ev_sync, st));
+      hipError_t q;
+      while ((q = hipEventQuery(ctx->ev_sync)) == hipErrorNotReady) {}
+      PXR_HIP(q);
+    } else PXR_HIP(hipStreamSynchronize(st));
     std::memcpy(h16, h_scal, sizeof(double) * 16);
     return PXR_OK;
   };
+  const bool spin_wait = std::getenv("PXR_BLOCKING_WAIT") == nullptr;
   DevBuf<double> det_part, chunk_trace;
   RC(det_part.alloc((size_t)n_pts + 8));          // the inner iterations' per-point costs (every mode)
   RC(chunk_trace.alloc(chunks.size() + 1));

@@ -12,6 +12,7 @@ struct pxr_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  hipEvent_t ev_sync = nullptr;  // the LM loop's polled host synchronisation (pxr_ba_solve)
   double* d_scratch = nullptr;   // small reduction scratch (device)
   size_t scratch_bytes = 0;
   int num_cus = 256;

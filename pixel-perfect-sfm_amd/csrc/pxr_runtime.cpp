@@ -51,6 +51,7 @@ int pxr_ctx_create(int device, void* stream, pxr_ctx** out) {
   c->num_cus = prop.multiProcessorCount;
   PXR_HIP(hipEventCreate(&c->ev_start));
   PXR_HIP(hipEventCreate(&c->ev_stop));
+  PXR_HIP(hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming));
   if (const char* e = std::getenv("PXR_DETERMINISTIC")) c->deterministic = e[0] != '\0' && e[0] != '0';
   if (const char* e = std::getenv("PXR_GRAM_CACHE")) c->gram_cache = e[0] != '\0' && e[0] != '0';
   c->scratch_bytes = 1 << 20;
@@ -71,6 +72,7 @@ int pxr_ctx_destroy(pxr_ctx* ctx) {
   if (ctx->d_gram) (void)hipFree(ctx->d_gram);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  if (ctx->ev_sync) (void)hipEventDestroy(ctx->ev_sync);
   release_staging(ctx);
   delete ctx;
   return PXR_OK;

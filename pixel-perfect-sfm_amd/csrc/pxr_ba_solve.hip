@@ -1313,6 +1313,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   lin_stats.p = scal.p + (kScalAll - 4);
   double h_scal[kScalAll] = {0};
   double* const h_lin_stats = h_scal + (kScalAll - 4);
+  const bool spin_wait = std::getenv("PXR_BLOCKING_WAIT") == nullptr;
   auto read_scal = [&](double* h16) -> int {
     if (det) {
       RC(ar_i64(slimb.p, 8 * PXR_LIMBS));
@@ -1334,7 +1335,6 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     std::memcpy(h16, h_scal, sizeof(double) * 16);
     return PXR_OK;
   };
-  const bool spin_wait = std::getenv("PXR_BLOCKING_WAIT") == nullptr;
   DevBuf<double> det_part, chunk_trace;
   RC(det_part.alloc((size_t)n_pts + 8));          // the inner iterations' per-point costs (every mode)
   RC(chunk_trace.alloc(chunks.size() + 1));

@@ -793,6 +793,35 @@ __global__ __launch_bounds__(KA_NT) void ka_setup_kernel(const KaArgs a, KaInfo*
 #define KA_T(k) do { } while (0)
 #endif
 
+
+// the deterministic linearisation's epilogue, OUT of line (it must not weigh on the register allocation of the interpolation core):
+// slots -> doubles, the overflow guard, the next grid.  Returns the next grid; *rescale != 0: launch again with that grid.
+__device__ __attribute__((noinline)) double ka_finish_fixed_point(double* Hm, double* g, const int* row_off, const int* row_v0, int hsz, int n,
+                                                                  double grid, double c, bool first, double* sh4, double* rescale) {
+  const int tid = threadIdx.x;
+  double dsum = 0.0;
+  const double inv_grid = 1.0 / grid;          // (a power of two: exact)
+  for (int e = tid; e < hsz; e += blockDim.x) Hm[e] = (double)__double_as_longlong(Hm[e]) * inv_grid;
+  for (int e = tid; e < n; e += blockDim.x) g[e] = (double)__double_as_longlong(g[e]) * inv_grid;
+  __syncthreads();
+  for (int e = tid; e < n; e += blockDim.x) {
+    const double d = Hm[row_off[e] + e - row_v0[e]];
+    dsum += d < 0.0 ? NAN : d;                                   // (a wrapped diagonal slot poisons the sum)
+  }
+  const double tr = block_sum(dsum, sh4);
+  const double bound = fmax(tr, sqrt(2.0 * tr * fmax(c, 0.0)));
+  const bool usable = isfinite(bound) && bound > 0x1p-900 && bound < 0x1p900;
+  double ideal = grid;
+  if (usable) {
+    const long long bits = __double_as_longlong(bound);
+    const int e2 = (int)((bits >> 52) & 0x7ff) - 1023 + ((bits & 0xfffffffffffffll) != 0 ? 1 : 0);       // ceil(log2(bound))
+    ideal = __longlong_as_double((long long)(1023 + 58 - e2) << 52);                                     // 2^(58 - e2)
+  }
+  if (isnan(tr) && isfinite(c)) *rescale = grid * 0x1p-16;
+  else if (usable && (bound * grid > 0x1p62 || (first && grid < ideal * 0x1p-10))) *rescale = ideal;
+  return ideal;
+}
+
 template <typename ST, int C, bool DET>
 __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __restrict__ info, double* sh_A) {
 #ifdef PXR_KA_PROFILE
@@ -804,8 +833,9 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   const bool fsimd = a.float_simd != 0;
   KaProb p;
   if (DET && a.prob_done[prob]) return;                  // (a repeated launch after a grid change: this sub-problem had finished)
-  double grid = DET ? uniform_f64(a.prob_scale[prob]) : 0.0;         // the sub-problem's fixed-point grid (2^k), adapted at every linearisation
-  double need_rescale = 0.0;                             // set by the overflow guard of a linearisation: the grid to launch again with
+  __shared__ double sh_grid, sh_resc;
+  if (tid == 0) { sh_grid = DET ? a.prob_scale[prob] : 0.0; sh_resc = 0.0; }
+
   p.np0 = a.v.d_prob_node_ptr[prob]; p.np1 = a.v.d_prob_node_ptr[prob + 1];
   p.ne0 = a.v.d_prob_edge_ptr[prob]; p.ne1 = a.v.d_prob_edge_ptr[prob + 1];
   p.nu0 = p.nu1 = 0;
@@ -883,7 +913,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     KA_T(7);
     ka_nodes<ST, C, true>(a, p, a.v.d_kp, fsimd);
     KA_T(0);
-    const double c = ka_terms<C, true, DET>(a, p, sh4, grid);
+    const double c = ka_terms<C, true, DET>(a, p, sh4, DET ? sh_grid : 0.0);
     __syncthreads();
     KA_T(1);
     if constexpr (DET) {
@@ -893,41 +923,17 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       // trace is read off the finished diagonal: its addends are all >= 0, a diagonal slot that wrapped shows as a negative
       // entry (it would take 2^64 units -- 64x the bound of the grid AFTER the 16x headroom -- to come round to a plausible value).
       // The ideal grid puts the bound at 2^57 .. 2^58 units, a factor 16 below the 2^62 limit; every linearisation runs on
-      // the ideal grid of the one before.  The sub-problem stops and asks the host for another launch (need_rescale = the grid
+      // the ideal grid of the one before.  The sub-problem stops and asks the host for another launch (sh_resc = the grid
       // to use) if a diagonal entry is negative, if the bound grew by more than those 16x in one accepted step, or if the start
       // grid (2^-38: unit-norm 128-channel descriptors) does not suit the FIRST linearisation -- it overflows (raw features) or
       // is more than 2^10 coarser than ideal (single-channel features: H ~ 1e-4, g -> 1e-9 at convergence).  One workgroup,
-      // a static block -> lane mapping, fixed reduction trees: the same decision on every run.
-      double dsum = 0.0;
-      const double inv_grid = 1.0 / grid;          // (a power of two: exact)
-#ifdef PXR_KA_PROBE_FP_ATOMICS
-      for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = p.Hm[e] * inv_grid;
-      for (int e = tid; e < n; e += blockDim.x) p.g[e] = p.g[e] * inv_grid;
-#else
-      for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = (double)__double_as_longlong(p.Hm[e]) * inv_grid;
-      for (int e = tid; e < n; e += blockDim.x) p.g[e] = (double)__double_as_longlong(p.g[e]) * inv_grid;
-#endif
+      // a static block -> lane mapping, fixed reduction trees: the same decision on every run.  (The grid and the request live in
+      // LDS and the epilogue is out of line: as loop-carried registers / inline code they cost the interpolation core 20 more
+      // spilled registers -- 5.4 instead of 5.0 ms per configs[1] solve, profiles/r5_ka_det_probes.txt.)
+      double resc = 0.0;
+      const double ideal = ka_finish_fixed_point(p.Hm, p.g, p.row_off, p.row_v0, hsz, n, sh_grid, c, compute_scale, sh4, &resc);
+      if (tid == 0) { sh_grid = ideal; if (resc != 0.0) sh_resc = resc; }
       __syncthreads();
-#ifndef PXR_KA_PROBE_NO_GUARD      // tools/variant_build.sh: a constant grid, no guard (what the guard costs)
-      for (int e = tid; e < n; e += blockDim.x) {
-        const double d = p.Hm[p.row_off[e] + e - p.row_v0[e]];
-        dsum += d < 0.0 ? NAN : d;                                   // (a wrapped diagonal slot poisons the sum)
-      }
-      const double tr = block_sum(dsum, sh4);
-      // bound = max(trace, sqrt(2 trace cost)); 2^ceil(log2 bound) from the exponent bits (every thread the same few integer operations:
-      // log2 / exp2 in double precision are ~200 instructions each, and the guard runs at every linearisation)
-      const double bound = fmax(tr, sqrt(2.0 * tr * fmax(c, 0.0)));
-      const bool usable = isfinite(bound) && bound > 0x1p-900 && bound < 0x1p900;     // (a non-finite Jacobian fails the solve below as before)
-      double ideal = grid;
-      if (usable) {
-        const long long bits = __double_as_longlong(bound);
-        const int e2 = (int)((bits >> 52) & 0x7ff) - 1023 + ((bits & 0xfffffffffffffll) != 0 ? 1 : 0);       // ceil(log2(bound))
-        ideal = __longlong_as_double((long long)(1023 + 58 - e2) << 52);                                     // 2^(58 - e2)
-      }
-      if (isnan(tr) && isfinite(c)) need_rescale = uniform_f64(grid * 0x1p-16);     // (wrapped: far coarser, the next launch measures)
-      else if (usable && (bound * grid > 0x1p62 || (compute_scale && grid < ideal * 0x1p-10))) need_rescale = uniform_f64(ideal);
-      grid = uniform_f64(ideal);           // the next linearisation's (wave-uniform: kept in scalar registers)
-#endif
     }
     for (int e = tid; e < n; e += blockDim.x) {
       p.gun[e] = p.g[e];
@@ -965,9 +971,9 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   }
   double cost = linearize(std::true_type{});
   sm.initial_cost = cost;
-  if (DET && need_rescale != 0.0) {         // the grid does not fit this sub-problem: nothing was changed, the host launches again
+  if (DET && sh_resc != 0.0) {         // the grid does not fit this sub-problem: nothing was changed, the host launches again
     sm.final_cost = cost; sm.termination = KA_TERM_RESCALE; sm.linear_iterations = stencils;
-    if (tid == 0) { a.summaries[prob] = sm; a.prob_scale[prob] = need_rescale; }
+    if (tid == 0) { a.summaries[prob] = sm; a.prob_scale[prob] = sh_resc; }
     return;
   }
   if (!inf.feasible || !isfinite(cost)) {   // [upstream] Program::IsFeasible fails / the initial evaluation fails
@@ -1103,7 +1109,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       __syncthreads();
       cost = linearize(std::false_type{});
       ++sm.num_successful;
-      if (DET && need_rescale != 0.0) { sm.termination = KA_TERM_RESCALE; break; }     // (the accepted keypoints stay; the next launch goes on from them)
+      if (DET && sh_resc != 0.0) { sm.termination = KA_TERM_RESCALE; break; }     // (the accepted keypoints stay; the next launch goes on from them)
       const double tmp = 2.0 * rel - 1.0;
       radius = uniform_f64(fmin(opt.max_radius, radius / fmax(1.0 / 3.0, 1.0 - tmp * tmp * tmp)));
       decrease_factor = 2.0; reuse_diag = false;
@@ -1115,7 +1121,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   if (tid == 0) {
     a.summaries[prob] = sm;
     if (DET) {
-      if (sm.termination == KA_TERM_RESCALE) a.prob_scale[prob] = need_rescale;
+      if (sm.termination == KA_TERM_RESCALE) a.prob_scale[prob] = sh_resc;
       else a.prob_done[prob] = 1;
     }
   }

@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -61,6 +62,10 @@ struct KaArgs {
   double det_scale;            // 0: floating-point atomics; 2^k: deterministic fixed-point accumulation of H and g (pxr_device.h)
   double* prob_scale;          // deterministic mode, [n_problems]: every sub-problem's grid (det_scale until its overflow guard asks for a coarser one)
   uint8_t* prob_done;          // deterministic mode, [n_problems]: the sub-problem finished (a repeated launch skips it)
+  int* slot_of_node;           // [n_nodes] position of the node inside its sub-problem (the index of its LDS metadata)
+  int stream_slots;            // > 0: the line-search probes run as ka_probe_stream (every sub-problem has at most this many nodes, <= 64,
+                               // all its residual blocks in the LDS cache, no unary terms); its LDS region follows the LM state
+  int stream_off;              // doubles from sh_A to that region
 };
 constexpr int KA_TERM_RESCALE = 100;   // internal termination code: the sub-problem's fixed-point grid did not fit, launch again
 
@@ -519,6 +524,213 @@ __device__ void ka_plus(const KaArgs& a, const KaProb& p, double alpha) {
   __syncthreads();
 }
 
+// EXPERIMENT, compiled in with -DPXR_KA_STREAM_PROBE only (tools/variant_build.sh; off in the shipped library).  Measured at
+// configs[1], round 5 (profiles/r5_ka_stream_probe.txt): a probe of a long line search takes 11.5 us instead of 15.8 us and the
+// slowest sub-problem 2.2 ms instead of 2.5-2.8 ms -- but the whole solve 5.9-6.2 ms instead of 5.4 ms: the solve kernel sits at
+// its 256-register cap, the out-of-line call (or, inlined, the second interpolation core) raises its spilled registers from 43 to
+// 195-261 and every other phase of every sub-problem pays for them.  Kept as the starting point for a kernel whose phases are
+// separate functions; bit-for-bit the same accepted steps (5852) and final cost to 1e-15.
+#ifdef PXR_KA_STREAM_PROBE
+// ---- the line-search probe as ONE streamed pass (cost only) ----------------------------------------------------------------
+// A probe of the projected Armijo search ([upstream] trust_region_minimizer.cc DoLineSearch) needs the cost at
+// P(x + alpha delta) and nothing else.  The general form (ka_plus + ka_nodes + ka_terms) is a chain of round trips: candidate
+// keypoints to global memory, two trips of node interpolations, descriptors to the L2-resident scratch, four trips of residual
+// blocks reading them back, the loss.  A sub-problem whose search direction runs into an active bound fails all twenty probes
+// of its line search ([upstream] max_num_line_search_step_size_iterations) in several LM iterations -- ~125 probes per solve
+// against ~5 for the others (tools/_ka_iter_hist.py) -- and those sub-problems are the tail of the launch.  Here the probe
+// stays on the CU:
+//   * FOUR lanes per node, every node of the sub-problem at once (<= 64), the descriptor in C / 32 steps of 32 channels: lane
+//     `sub` interpolates channels 32 k + 8 sub .. + 7 with the arithmetic of interp8 / interp8x2_value (the four lanes read 64
+//     consecutive bytes of every texel); with fp16 storage the texels of step k + 1 are requested before step k is computed;
+//   * a step's 32 channels of every node go to LDS (rows of 34 doubles: consecutive nodes start 16 bytes apart in the bank
+//     row), every residual block -- one lane each -- adds the step's part of f_a . f_b; |f|^2 accumulates with the node;
+//   * |f_a / |f_a| - f_b / |f_b||^2 = |f_a|^2 n_a^2 + |f_b|^2 n_b^2 - 2 (f_a . f_b) n_a n_b,  n = 1 / |f|  (a constant node's
+//     descriptor is the normalised one the linearisation left in the scratch: n = 1).  Fixed-order sums: every run alike.  The
+//     difference from the channel-wise form is the rounding of three fp64 dot products, ~1e-16 of |f|^2 = 1.
+// Only PixelInterpolator's L2-normalised descriptors (interpolation.h:642-677) take this path; the candidate keypoints are
+// written (ka_plus) once the search has settled.
+constexpr int KA_SCH = 32, KA_SROW = KA_SCH + 2, KA_STREAM_MAX = KA_NT / 4;
+struct KaStream {                  // LDS
+  double* buf;                     // [slots][KA_SROW] the current step's channels of every node
+  double* self;                    // [slots] |f|^2 n^2
+  double* ninv;                    // [slots] n
+  double* kp;                      // [slots][2] the sub-problem's current keypoints
+  const unsigned char* eslot;      // [edges][2] node slots of the cached residual blocks' endpoints
+};
+
+// (LDS pointers carry their address space here: out of line the compiler cannot infer it and would issue FLAT loads -- a quarter
+// of the ds_read rate -- for the 128 row reads per lane and probe)
+#define KA_LDS __attribute__((address_space(3)))
+#define KA_GLOBAL __attribute__((address_space(1)))
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load (vmcnt(0)), i.e. for
+// the texels of the NEXT step that are meant to stay in flight across the exchange (measured: 23 us per probe with it, slower
+// than the general form's 16)
+__device__ __forceinline__ void ka_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifdef PXR_KA_STREAM_FORCEINLINE     // A/B knob (tools/variant_build.sh)
+#define KA_STREAM_INLINE __forceinline__
+#else
+#define KA_STREAM_INLINE __attribute__((noinline))
+#endif
+// (everything by value: a reference to the kernel's KaArgs / KaProb would force both structures into scratch memory for the whole
+// kernel -- 1.4 KB per lane, every later field access a scratch load)
+struct KaStreamCall {
+  const KA_GLOBAL void* arena; const KA_GLOBAL double* desc;
+  int H, W, loss_type, slots_max, nslots, ne;
+  double loss_a;
+  KA_LDS double* buf;                       // the region of KaStream: buf | self | ninv | kp
+  const KA_LDS unsigned char* eslot;
+  const KA_LDS double *delta, *lo, *hi;     // (the LM state is in LDS whenever this path is on)
+  const KA_LDS KaNodeMeta* cnode; const KA_LDS KaEdgeMeta* cedge;
+  KA_LDS double* sh4;
+};
+template <typename ST, int C, bool FS>
+__device__ KA_STREAM_INLINE double ka_probe_stream(const KaStreamCall sc, double alpha) {
+  static_assert(C % KA_SCH == 0, "whole steps");
+  constexpr int NSTEP = C / KA_SCH;
+  typedef typename Texel8<ST>::work_t HT;
+  typedef double ldouble2 __attribute__((ext_vector_type(2)));
+  KA_LDS double* const buf = sc.buf;
+  KA_LDS double* const self = buf + sc.slots_max * KA_SROW;
+  KA_LDS double* const sninv = self + sc.slots_max;
+  const KA_LDS double* const skp = sninv + sc.slots_max;
+  const KA_LDS unsigned char* const eslot = sc.eslot;
+  const KA_LDS double* const delta = sc.delta;
+  const KA_LDS double* const lo = sc.lo;
+  const KA_LDS double* const hi = sc.hi;
+  const KA_LDS KaNodeMeta* const cnode = sc.cnode;
+  const KA_LDS KaEdgeMeta* const cedge = sc.cedge;
+  const int tid = threadIdx.x, sub = tid & 3;
+  const int nslots = sc.nslots, ne = sc.ne;
+  const int slot = min(tid >> 2, nslots - 1);    // (idle lanes shadow the last node: valid addresses, nothing stored)
+  const int64_t m_node = cnode[slot].node, m_pi = cnode[slot].pi, m_id = cnode[slot].id;
+  const double m_sx = cnode[slot].sx, m_sy = cnode[slot].sy, m_cx = cnode[slot].cx, m_cy = cnode[slot].cy;
+  const int m_v = cnode[slot].v;
+  const bool active = (tid >> 2) < nslots && m_node >= 0, moving = active && m_v >= 0;
+  const int vv = max(m_v, 0);
+  // ParameterBlock::Plus [upstream]: the projected candidate, the expression of ka_plus
+  const double x0 = skp[2 * slot], y0 = skp[2 * slot + 1];
+  const double xc = fmin(fmax(x0 + alpha * delta[vv], lo[vv]), hi[vv]);
+  const double yc = fmin(fmax(y0 + alpha * delta[vv + 1], lo[vv + 1]), hi[vv + 1]);
+  const double kx = m_v >= 0 ? xc : x0, ky = m_v >= 0 ? yc : y0;
+  const double u = kx * m_sx - 0.5 - m_cx, v = ky * m_sy - 0.5 - m_cy;        // featurepatch.h:250-255
+  const KA_GLOBAL ST* const gpatch = (const KA_GLOBAL ST*)sc.arena + (size_t)m_pi * sc.H * sc.W * C;
+  const StencilIndex si = stencil_index(sc.H, sc.W, u, v);
+  // (global address space spelled out as well: a FLAT load counts on lgkmcnt too, so every LDS wait of the exchange would wait
+  // for the texels of the next step -- 23 us per probe instead of 9)
+  typedef unsigned int gu4 __attribute__((ext_vector_type(4)));
+  typedef float gf4 __attribute__((ext_vector_type(4)));
+  const KA_GLOBAL ldouble2* const cdesc = (const KA_GLOBAL ldouble2*)(sc.desc + (size_t)m_id * 3 * C + sub * 8);
+  Texel8<ST> tx[4][4];
+  ldouble2 cf[4];
+  // every lane requests both -- its texels and the scratch row of its node -- and selects afterwards (a conditional load is a
+  // branch and a wait per element)
+  auto request = [&](int k) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const KA_GLOBAL ST* q = gpatch + (size_t)(si.ro[j] + si.co[i]) * C + k * KA_SCH + sub * 8;
+        if constexpr (sizeof(ST) == 2) {
+          const gu4 w = *(const KA_GLOBAL gu4*)q;
+          tx[j][i].raw = make_uint4(w.x, w.y, w.z, w.w);
+        } else {
+          const gf4 w0 = *(const KA_GLOBAL gf4*)q, w1 = *(const KA_GLOBAL gf4*)(q + 4);
+          tx[j][i].a = make_float4(w0.x, w0.y, w0.z, w0.w); tx[j][i].b = make_float4(w1.x, w1.y, w1.z, w1.w);
+        }
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cf[q] = cdesc[k * (KA_SCH / 2) + q];
+  };
+#define KA_STREAM_REQUEST(K) request(K)
+  KA_STREAM_REQUEST(0);
+  // this lane's residual blocks: tid and tid + KA_NT (at most KA_EDGE_CACHE = 2 KA_NT of them)
+  const int e0 = tid, e1 = tid + KA_NT;
+  const int sa0 = e0 < ne ? eslot[2 * e0] : 0, sb0 = e0 < ne ? eslot[2 * e0 + 1] : 0;
+  const int sa1 = e1 < ne ? eslot[2 * e1] : 0, sb1 = e1 < ne ? eslot[2 * e1 + 1] : 0;
+  double nrm2 = 0.0, dot0 = 0.0, dot1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < NSTEP; ++k) {
+    HT h[4][8], hd[4][8];
+    double f[8], fr[8], fc[8];
+#ifdef PXR_KA_STREAM_PROBE_NO_INTERP
+    { float p0[8]; tx[0][0].unpack(p0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) { float t8[8]; tx[j][ch & 3].unpack(t8); h[j][ch] = t8[ch] + p0[ch]; hd[j][ch] = 0; } }
+#else
+    interp8_horizontal<ST, false, FS>(tx, si.dx, h, hd);
+#endif
+    ldouble2 cfk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cfk[q] = cf[q];
+    // step k + 1 is requested as soon as the horizontal pass has consumed step k's texels: in flight behind the vertical pass,
+    // the LDS exchange and its barriers (two steps' texels in registers cost the kernel 130 more spilled registers)
+    if (k + 1 < NSTEP) KA_STREAM_REQUEST(k + 1);
+#ifdef PXR_KA_STREAM_PROBE_NO_INTERP     // timing probes (wrong results): what the interpolation arithmetic / the exchange cost
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) { f[ch] = (double)h[0][ch]; fr[ch] = fc[ch] = 0.0; }
+#else
+    interp8_vertical<HT, false, FS>(h, hd, si.dy, f, fr, fc);
+#endif
+    if (!moving) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { f[2 * q] = cfk[q].x; f[2 * q + 1] = cfk[q].y; }
+    }
+    double s8 = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) s8 = fma(f[ch], f[ch], s8);
+    s8 += dpp_f64<0xB1>(s8);   // quad_perm [1,0,3,2]
+    s8 += dpp_f64<0x4E>(s8);   // quad_perm [2,3,0,1]
+    nrm2 += s8;
+    if (active) {
+      KA_LDS ldouble2* row = (KA_LDS ldouble2*)(buf + slot * KA_SROW + sub * 8);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ldouble2 w2; w2.x = f[2 * q]; w2.y = f[2 * q + 1]; row[q] = w2; }
+    }
+    ka_lds_barrier();
+#ifndef PXR_KA_STREAM_PROBE_NO_EDGES
+    if (e0 < ne) {
+      const KA_LDS ldouble2* ra = (const KA_LDS ldouble2*)(buf + sa0 * KA_SROW);
+      const KA_LDS ldouble2* rb = (const KA_LDS ldouble2*)(buf + sb0 * KA_SROW);
+      double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < KA_SCH / 2; ++q) { const ldouble2 x = ra[q], y = rb[q]; d0 = fma(x.x, y.x, d0); d1 = fma(x.y, y.y, d1); }
+      dot0 += d0 + d1;
+    }
+    if (e1 < ne) {
+      const KA_LDS ldouble2* ra = (const KA_LDS ldouble2*)(buf + sa1 * KA_SROW);
+      const KA_LDS ldouble2* rb = (const KA_LDS ldouble2*)(buf + sb1 * KA_SROW);
+      double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < KA_SCH / 2; ++q) { const ldouble2 x = ra[q], y = rb[q]; d0 = fma(x.x, y.x, d0); d1 = fma(x.y, y.y, d1); }
+      dot1 += d0 + d1;
+    }
+#endif
+    ka_lds_barrier();
+  }
+#undef KA_STREAM_REQUEST
+  if (active && sub == 0) {
+    const double ninv = moving ? 1.0 / sqrt(nrm2) : 1.0;
+    sninv[slot] = ninv; self[slot] = nrm2 * ninv * ninv;
+  }
+  __syncthreads();
+  double cost = 0.0, rho[3];
+  if (e0 < ne) {
+    const double sq = self[sa0] + self[sb0] - 2.0 * dot0 * sninv[sa0] * sninv[sb0];
+    loss_eval(sc.loss_type, sc.loss_a, cedge[e0].w, sq < 0.0 ? 0.0 : sq, rho);      // (a NaN stays a NaN)
+    cost += 0.5 * rho[0];
+  }
+  if (e1 < ne) {
+    const double sq = self[sa1] + self[sb1] - 2.0 * dot1 * sninv[sa1] * sninv[sb1];
+    loss_eval(sc.loss_type, sc.loss_a, cedge[e1].w, sq < 0.0 ? 0.0 : sq, rho);
+    cost += 0.5 * rho[0];
+  }
+  return block_sum(cost, (double*)sc.sh4);
+}
+
+#endif   // PXR_KA_STREAM_PROBE
+
 // ---- Cholesky solves of one component block (n x n row-major lower, in place; b -> solution) ----
 // whole workgroup (any n).  Returns false on a non-positive pivot (block-uniform).
 __device__ bool ka_chol_block(double* A, int n, double* b) {
@@ -600,8 +812,18 @@ __device__ __forceinline__ double ka_readlane_f64(double v, int lane) {
 __device__ bool ka_chol_wave_reg(const double* A, int n, double* b) {
   const int lane = threadIdx.x & 63;
   double row[KA_NREG], inv[KA_NREG];
+  // (clamped address + select: a conditional load is a branch and a wait per element -- 24 dependent LDS round trips)
+  const int rl = min(lane, n - 1);
+#ifdef PXR_KA_OLD_CHOL
 #pragma unroll
   for (int c = 0; c < KA_NREG; ++c) row[c] = (lane < n && c <= lane && c < n) ? A[lane * n + c] : 0.0;
+#else
+#pragma unroll
+  for (int c = 0; c < KA_NREG; ++c) {
+    const double v = A[rl * n + min(c, n - 1)];
+    row[c] = (lane < n && c <= lane && c < n) ? v : 0.0;
+  }
+#endif
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < KA_NREG; ++j) {
@@ -629,7 +851,10 @@ __device__ bool ka_chol_wave_reg(const double* A, int n, double* b) {
   }
   // L^T x = y: step j needs L[j][r] in lane r -- lane j's row, one entry per lane: through the block's own storage
   // (A is scratch of the iteration: overwritten with the factor's rows)
+  // (a lane also stores the dead entries right of its diagonal: nothing reads the block's upper triangle; the column of L^T a
+  // lane needs is then loaded in one go, not entry by entry inside the substitution)
   double* Aw = const_cast<double*>(A);
+#ifdef PXR_KA_OLD_CHOL
   if (lane < n) {
 #pragma unroll
     for (int c = 0; c < KA_NREG; ++c) if (c <= lane && c < n) Aw[lane * n + c] = row[c];
@@ -640,6 +865,24 @@ __device__ bool ka_chol_wave_reg(const double* A, int n, double* b) {
     if (j < n) {
       const double xj = ka_readlane_f64(bi, j) * inv[j];
       bi = lane == j ? xj : (lane < j ? fma(-Aw[j * n + lane], xj, bi) : bi);
+    }
+  }
+  if (lane < n) b[lane] = bi;
+  return ok;
+#endif
+  if (lane < n) {
+#pragma unroll
+    for (int c = 0; c < KA_NREG; ++c) if (c < n) Aw[lane * n + c] = row[c];
+  }
+  wave_sync();
+  double col[KA_NREG];
+#pragma unroll
+  for (int j = 0; j < KA_NREG; ++j) col[j] = Aw[min(j, n - 1) * n + rl];
+#pragma unroll
+  for (int j = KA_NREG - 1; j >= 0; --j) {
+    if (j < n) {
+      const double xj = ka_readlane_f64(bi, j) * inv[j];
+      bi = lane == j ? xj : (lane < j ? fma(-col[j], xj, bi) : bi);
     }
   }
   if (lane < n) b[lane] = bi;
@@ -694,6 +937,9 @@ __global__ __launch_bounds__(KA_NT) void ka_setup_kernel(const KaArgs a, KaInfo*
   for (int i = tid; i < nloc; i += blockDim.x) {
     const int64_t node = a.v.d_prob_nodes[p.np0 + i];
     a.label[node] = (a.used[node] && a.v.d_node_const[node] != 1) ? i : -1;
+#ifdef PXR_KA_STREAM_PROBE
+    a.slot_of_node[node] = i;
+#endif
     cnt[i] = 0;
   }
   __syncthreads();
@@ -788,7 +1034,10 @@ __global__ __launch_bounds__(KA_NT) void ka_setup_kernel(const KaArgs a, KaInfo*
 
 // -DPXR_KA_PROFILE: workgroup 0 prints how its wall time splits over the phases of the LM loop (tools/ka_phase_probe.sh)
 #ifdef PXR_KA_PROFILE
-#define KA_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = wall_clock64(); ka_prof[k] += t_ - ka_t0; ka_t0 = t_; } } while (0)
+#ifndef PXR_KA_PROFILE_BLOCK
+#define PXR_KA_PROFILE_BLOCK 0      // the sub-problem that reports (tools/ka_phase_probe.sh [block])
+#endif
+#define KA_T(k) do { if (blockIdx.x == PXR_KA_PROFILE_BLOCK && threadIdx.x == 0) { const long long t_ = wall_clock64(); ka_prof[k] += t_ - ka_t0; ka_t0 = t_; } } while (0)
 #else
 #define KA_T(k) do { } while (0)
 #endif
@@ -825,7 +1074,8 @@ __device__ __attribute__((noinline)) double ka_finish_fixed_point(double* Hm, do
 template <typename ST, int C, bool DET>
 __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __restrict__ info, double* sh_A) {
 #ifdef PXR_KA_PROFILE
-  long long ka_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ka_t0 = wall_clock64();
+  long long ka_prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ka_t0 = wall_clock64();
+  const long long ka_tstart = ka_t0;
 #endif
   __shared__ double sh4[KA_NT / 64];
   __shared__ int sh_ok;
@@ -855,6 +1105,9 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   __shared__ KaNodeMeta sh_nodes[KA_NODE_CACHE];
   __shared__ KaEdgeMeta sh_edges[KA_EDGE_CACHE];
   __shared__ double sh_sq[KA_EDGE_CACHE];
+#ifdef PXR_KA_STREAM_PROBE
+  __shared__ unsigned char sh_eslot[2 * KA_EDGE_CACHE];     // node slots of the cached residual blocks' endpoints (ka_probe_stream)
+#endif
   for (int64_t i = p.np0 + tid; i < p.np1 && i - p.np0 < KA_NODE_CACHE; i += blockDim.x) {
     const int64_t node = a.v.d_prob_nodes[i];
     const int64_t pi = a.v.d_node_patch[node];
@@ -868,6 +1121,10 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     KaEdgeMeta m;
     m.n1 = a.v.d_edge_src[e]; m.n2 = a.v.d_edge_dst[e]; m.v1 = a.var_of_node[m.n1]; m.v2 = a.var_of_node[m.n2]; m.w = a.v.d_edge_w[e];
     sh_edges[i - p.ne0] = m;
+#ifdef PXR_KA_STREAM_PROBE
+    sh_eslot[2 * (i - p.ne0)] = (unsigned char)a.slot_of_node[m.n1];       // (meaningful in sub-problems of <= 64 nodes: the
+    sh_eslot[2 * (i - p.ne0) + 1] = (unsigned char)a.slot_of_node[m.n2];   // only ones that read it)
+#endif
   }
   p.cnode = sh_nodes; p.cedge = sh_edges; p.csq = sh_sq;
   __syncthreads();
@@ -898,6 +1155,30 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     __syncthreads();
   }
   const pxr_lm_options& opt = a.opt;
+  // the line-search probes as one streamed pass (ka_probe_stream) when the launch was sized for it and this sub-problem fits
+  bool use_stream = false;
+#ifdef PXR_KA_STREAM_PROBE
+  KaStream strm{};
+  KaStreamCall scall{};
+  if constexpr (C % KA_SCH == 0 && sizeof(ST) <= 4) {
+    if (a.stream_slots > 0 && p.np1 - p.np0 <= a.stream_slots && p.ne1 - p.ne0 <= KA_EDGE_CACHE && p.nu1 == p.nu0) {
+      use_stream = true;
+      strm.buf = sh_A + a.stream_off; strm.self = strm.buf + (size_t)a.stream_slots * KA_SROW;
+      strm.ninv = strm.self + a.stream_slots; strm.kp = strm.ninv + a.stream_slots; strm.eslot = sh_eslot;
+      scall.arena = (const KA_GLOBAL void*)a.arena; scall.desc = (const KA_GLOBAL double*)a.desc;
+      scall.H = a.H; scall.W = a.W; scall.loss_type = a.loss.type; scall.loss_a = a.loss.a; scall.slots_max = a.stream_slots;
+      scall.nslots = (int)(p.np1 - p.np0); scall.ne = (int)(p.ne1 - p.ne0);
+      scall.buf = (KA_LDS double*)strm.buf; scall.eslot = (const KA_LDS unsigned char*)sh_eslot;
+      scall.delta = (const KA_LDS double*)p.delta; scall.lo = (const KA_LDS double*)p.lo; scall.hi = (const KA_LDS double*)p.hi;
+      scall.cnode = (const KA_LDS KaNodeMeta*)sh_nodes; scall.cedge = (const KA_LDS KaEdgeMeta*)sh_edges; scall.sh4 = (KA_LDS double*)sh4;
+      for (int i = tid; i < (int)(p.np1 - p.np0); i += blockDim.x) {
+        const int64_t node = sh_nodes[i].id;
+        strm.kp[2 * i] = a.v.d_kp[2 * node]; strm.kp[2 * i + 1] = a.v.d_kp[2 * node + 1];
+      }
+      __syncthreads();
+    }
+  }
+#endif
 
   // evaluate cost + normal equations at the CURRENT keypoints, then scale: H <- S H S, g <- S g
   // node stencils interpolated over the solve (a linearisation evaluates every node, a line-search probe the variable ones):
@@ -952,8 +1233,19 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     KA_T(2);
     return c;
   };
-  auto cost_at_candidate = [&]() -> double {
+  auto cost_at_candidate = [&](double alpha, bool long_search) -> double {
     stencils += nodes_var;
+#ifdef PXR_KA_STREAM_PROBE
+    if constexpr (C % KA_SCH == 0 && sizeof(ST) <= 4) {
+      if (use_stream && long_search) {
+        KA_T(7);
+        const double c = fsimd ? ka_probe_stream<ST, C, true>(scall, alpha) : ka_probe_stream<ST, C, false>(scall, alpha);
+        KA_T(3);
+        return c;
+      }
+    }
+#endif
+    ka_plus(a, p, alpha);
     KA_T(7);
     ka_nodes<ST, C, false>(a, p, a.kp_cand, fsimd, true);
     KA_T(3);
@@ -1000,6 +1292,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       p.step[e] = -p.g[e];
     }
     __syncthreads();
+    KA_T(8);
     // per-component Cholesky: threads take the 2x2 blocks, wavefronts the blocks up to 64, the
     // workgroup anything larger
     for (int c = tid; c < p.ncomp; c += blockDim.x) {
@@ -1057,10 +1350,18 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       double xc = 1.0, xp = 0.0, fp = 0.0;
       bool have_prev = false, success = false;
       int iters = 0;
-      ka_plus(a, p, xc);
-      double fc = cost_at_candidate();
+#ifdef PXR_KA_STREAM_FROM       // (experiment: the streamed probe only from this probe of a search on -- 6.7 ms, worse than always: 6.1)
+      constexpr int kStreamFrom = PXR_KA_STREAM_FROM;
+#else
+      constexpr int kStreamFrom = 0;
+#endif
+      double fc = cost_at_candidate(xc, kStreamFrom <= 0);
       const double f_full = fc;
       while (true) {
+#ifdef PXR_KA_TRACE_LS      // tools/ka_phase_probe.sh: the line search of the reporting sub-problem, probe by probe
+        if (blockIdx.x == PXR_KA_PROFILE_BLOCK && tid == 0)
+          printf("[ka ls] it %d probe %d  x %.6e  f %.12e  cost %.12e  g0 %.6e  radius %.4e\n", sm.iterations, iters, xc, fc, cost, g0, radius);
+#endif
         if (isfinite(fc) && fc <= cost + 1e-4 * g0 * xc) { success = true; break; }
         if (++iters >= 20) break;
         double nx;
@@ -1070,21 +1371,24 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
         if (nx < 1e-9) break;
         if (isfinite(fc)) { xp = xc; fp = fc; have_prev = true; }
         xc = nx;
-        ka_plus(a, p, xc);
-        fc = cost_at_candidate();
+        fc = cost_at_candidate(xc, iters >= kStreamFrom);
       }
+      // (the streamed probes do not write the candidate keypoints: once, here)
       if (success) {
         if (xc != 1.0) {
           for (int e = tid; e < n; e += blockDim.x) p.delta[e] *= xc;
           __syncthreads();
           ka_plus(a, p, 1.0);
+        } else if (use_stream) {
+          ka_plus(a, p, 1.0);
         }
         cand = fc;
       } else {
         cand = f_full;
-        if (xc != 1.0) ka_plus(a, p, 1.0);
+        if (xc != 1.0 || use_stream) ka_plus(a, p, 1.0);
       }
     }
+    KA_T(9);
     double s2 = 0.0, x2 = 0.0;
     for (int64_t i = p.np0 + tid; i < p.np1; i += blockDim.x) {
       const bool cached = i - p.np0 < KA_NODE_CACHE;
@@ -1097,6 +1401,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       }
     }
     const double step_norm = sqrt(block_sum(s2, sh4)), x_norm = sqrt(block_sum(x2, sh4));
+    KA_T(10);
     if (step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) { sm.termination = PXR_TERM_CONVERGENCE; break; }
     const double cost_change = cost - cand;
     if (fabs(cost_change) <= opt.function_tolerance * cost) { sm.termination = PXR_TERM_CONVERGENCE; break; }
@@ -1104,7 +1409,11 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     if (rel > opt.min_relative_decrease) {
       for (int64_t i = p.np0 + tid; i < p.np1; i += blockDim.x) {
         const int64_t node = i - p.np0 < KA_NODE_CACHE ? sh_nodes[i - p.np0].id : a.v.d_prob_nodes[i];
-        a.v.d_kp[2 * node] = a.kp_cand[2 * node]; a.v.d_kp[2 * node + 1] = a.kp_cand[2 * node + 1];
+        const double nx = a.kp_cand[2 * node], ny = a.kp_cand[2 * node + 1];
+        a.v.d_kp[2 * node] = nx; a.v.d_kp[2 * node + 1] = ny;
+#ifdef PXR_KA_STREAM_PROBE
+        if (use_stream) { strm.kp[2 * (i - p.np0)] = nx; strm.kp[2 * (i - p.np0) + 1] = ny; }
+#endif
       }
       __syncthreads();
       cost = linearize(std::false_type{});
@@ -1127,10 +1436,11 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   }
 #ifdef PXR_KA_PROFILE
   KA_T(7);
-  if (blockIdx.x == 0 && tid == 0)
-    printf("[ka profile, workgroup 0, 10 ns ticks] nodes+J %lld  terms+J %lld  scale %lld  nodes(cost) %lld  terms(cost) %lld  "
-           "damp+cholesky %lld  model change %lld  other %lld  | iterations %d unknowns %d\n", ka_prof[0], ka_prof[1], ka_prof[2],
-           ka_prof[3], ka_prof[4], ka_prof[5], ka_prof[6], ka_prof[7], sm.iterations, n);
+  if (blockIdx.x == PXR_KA_PROFILE_BLOCK && tid == 0)
+    printf("[ka profile, workgroup %d, 10 ns ticks] nodes+J %lld  terms+J %lld  scale %lld  nodes(cost) %lld  terms(cost) %lld  "
+           "cholesky %lld  model change %lld  other (ka_plus, step choice) %lld  diag+damp %lld  after the line search %lld  step norms %lld | iterations %d unknowns %d stencils %lld | started at tick %lld, ran %lld\n",
+           (int)blockIdx.x, ka_prof[0], ka_prof[1], ka_prof[2], ka_prof[3], ka_prof[4], ka_prof[5], ka_prof[6], ka_prof[7], ka_prof[8], ka_prof[9], ka_prof[10], sm.iterations, n,
+           (long long)stencils, ka_tstart, ka_t0 - ka_tstart);
 #endif
 }
 
@@ -1144,12 +1454,12 @@ template <typename ST, int C, bool DET>
 #define PXR_KA_WAVES 2
 #endif
 __global__ __launch_bounds__(KA_NT) __attribute__((amdgpu_waves_per_eu(PXR_KA_WAVES, PXR_KA_WAVES))) void ka_solve_kernel_occ2(const KaArgs a, const KaInfo* __restrict__ info) {
-  extern __shared__ double sh_A[];      // lds_elems doubles (damped blocks) when the sub-problem fits
+  extern __shared__ __align__(16) double sh_A[];      // lds_elems doubles (damped blocks) when the sub-problem fits
   ka_solve_body<ST, C, DET>(a, info, sh_A);
 }
 template <typename ST, int C, bool DET>
 __global__ __launch_bounds__(KA_NT) void ka_solve_kernel(const KaArgs a, const KaInfo* __restrict__ info) {
-  extern __shared__ double sh_A[];
+  extern __shared__ __align__(16) double sh_A[];
   ka_solve_body<ST, C, DET>(a, info, sh_A);
 }
 
@@ -1255,8 +1565,9 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   const int np = view->n_problems;
   memset(total, 0, sizeof(*total));
   if (np == 0) return PXR_OK;
-  std::vector<int64_t> node_ptr(np + 1), h_ptr(np + 1, 0);
+  std::vector<int64_t> node_ptr(np + 1), edge_ptr(np + 1), h_ptr(np + 1, 0);
   PXR_HIP(hipMemcpyAsync(node_ptr.data(), view->d_prob_node_ptr, sizeof(int64_t) * (np + 1), hipMemcpyDeviceToHost, st));
+  PXR_HIP(hipMemcpyAsync(edge_ptr.data(), view->d_prob_edge_ptr, sizeof(int64_t) * (np + 1), hipMemcpyDeviceToHost, st));
   PXR_HIP(hipStreamSynchronize(st));
   PXR_REQUIRE(node_ptr[0] == 0 && node_ptr[np] <= view->n_nodes, "pxr_ka_solve: every node belongs to at most one sub-problem");
   for (int i = 0; i < np; ++i) {
@@ -1283,7 +1594,7 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   const size_t o_irow = carve(sizeof(int) * nn * 6), o_comp = carve(sizeof(int) * nn), o_used = carve(nn);
   const size_t o_hptr = carve(sizeof(int64_t) * (np + 1)), o_sum = carve(sizeof(pxr_lm_summary) * np);
   const size_t o_info = carve(sizeof(KaInfo) * np);
-  const size_t o_pscale = carve(sizeof(double) * np), o_pdone = carve(np);
+  const size_t o_pscale = carve(sizeof(double) * np), o_pdone = carve(np), o_slot = carve(sizeof(int) * nn);
   if (int rc = grow(&ctx->d_workspace, &ctx->workspace_bytes, off)) return rc;
   char* ws = static_cast<char*>(ctx->d_workspace);
   int64_t* d_hptr = (int64_t*)(ws + o_hptr);
@@ -1306,7 +1617,7 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   a.desc = (double*)(ws + o_desc); a.kp_cand = (double*)(ws + o_cand); a.vec = (double*)(ws + o_vec);
   a.var_of_node = (int*)(ws + o_var); a.label = (int*)(ws + o_label); a.ipos = (int*)(ws + o_ipos);
   a.irow = (int*)(ws + o_irow); a.comp_v0 = (int*)(ws + o_comp); a.used = (uint8_t*)(ws + o_used);
-  a.prob_h_ptr = d_hptr; a.summaries = d_sum;
+  a.prob_h_ptr = d_hptr; a.summaries = d_sum; a.slot_of_node = (int*)(ws + o_slot);
   // 1. components, unknown layout, bounds; the block sizes come back to size the matrices exactly
   hipLaunchKernelGGL(ka_setup_kernel, dim3(np), dim3(KA_NT), 0, st, a, d_info);
   PXR_HIP(hipGetLastError());
@@ -1333,7 +1644,31 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   const size_t state_bytes = sizeof(double) * ((size_t)2 * lds_elems + (size_t)8 * n_max) + sizeof(int) * (size_t)4 * n_max;
   a.lds_state_n = (!need_aglob && state_bytes <= (size_t)56 * 1024) ? n_max : 0;
   PXR_HIP(hipMemcpyAsync(d_hptr, h_ptr.data(), sizeof(int64_t) * (np + 1), hipMemcpyHostToDevice, st));
-  const size_t shmem = a.lds_state_n > 0 ? state_bytes : sizeof(double) * (size_t)lds_elems;
+  size_t shmem = a.lds_state_n > 0 ? state_bytes : sizeof(double) * (size_t)lds_elems;
+  // the streamed line-search probe (ka_probe_stream): L2-normalised 64 / 128-channel descriptors in fp16 / fp32 storage, no unary
+  // terms, every sub-problem of at most 64 nodes with all its residual blocks in the LDS cache, and its LDS region next to the
+  // LM state inside the two-workgroups-per-CU budget; PXR_KA_STREAM=0 is the A/B knob
+  a.stream_slots = 0; a.stream_off = 0;
+#ifdef PXR_KA_STREAM_PROBE
+  {
+    int64_t nodes_max = 0, edges_max = 0;
+    for (int i = 0; i < np; ++i) {
+      nodes_max = std::max(nodes_max, node_ptr[i + 1] - node_ptr[i]);
+      edges_max = std::max(edges_max, edge_ptr[i + 1] - edge_ptr[i]);
+    }
+    const char* knob = getenv("PXR_KA_STREAM");
+    const size_t stream_bytes = sizeof(double) * (size_t)nodes_max * (KA_SROW + 4);
+    const size_t stream_at = (state_bytes + 15) & ~(size_t)15;
+    if (!(knob && knob[0] == '0') && a.lds_state_n > 0 && view->n_unary == 0 && cfg->l2_normalize && (arena->C == 128 || arena->C == 64) &&
+        (arena->dtype == PXR_F16 || arena->dtype == PXR_F32) && nodes_max >= 1 && nodes_max <= KA_STREAM_MAX && edges_max <= KA_EDGE_CACHE &&
+        stream_at + stream_bytes <= (size_t)56 * 1024) {
+      a.stream_slots = (int)nodes_max; a.stream_off = (int)(stream_at / sizeof(double));
+      shmem = stream_at + stream_bytes;
+    }
+  }
+#else
+  (void)edge_ptr;
+#endif
 #define KA_SOLVE_LAUNCH(KERNEL, ST, CC)                                                                      \
   do {                                                                                                       \
     void (*kfn)(const KaArgs, const KaInfo*) = a.det_scale != 0.0 ? KERNEL<ST, CC, true> : KERNEL<ST, CC, false>; \

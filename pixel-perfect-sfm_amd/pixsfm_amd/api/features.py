@@ -7,6 +7,9 @@ features/src/featurepatch.cc:45); the hot path consumes the flat HBM arena built
 """
 from collections.abc import Mapping as _Mapping
 
+import warnings
+import weakref
+
 import numpy as np
 
 kDenseId = 1000000      # util/src/types.h:33
@@ -167,12 +170,50 @@ class FeatureMap:
 
     _stack = None
 
+    class _StackViews(dict):
+        """The {keypoint id: FeaturePatch} dict of a map built from ONE stacked array: any write to it -- a patch replaced in
+        place, not only through add_fpatch -- drops the owner's remembered stack, so that SharedArena.prefetch can never
+        upload a stale slice of the array into the slot of a patch that is no longer a view of it."""
+        __slots__ = ("owner",)
+
+        def _dirty(self):
+            owner = self.owner() if getattr(self, "owner", None) is not None else None
+            if owner is not None:
+                owner._stack = None
+
+        def __setitem__(self, k, v):
+            self._dirty(); dict.__setitem__(self, k, v)
+
+        def __delitem__(self, k):
+            self._dirty(); dict.__delitem__(self, k)
+
+        def __ior__(self, other):
+            self._dirty(); return dict.__ior__(self, other)
+
+        def pop(self, *a):
+            self._dirty(); return dict.pop(self, *a)
+
+        def popitem(self):
+            self._dirty(); return dict.popitem(self)
+
+        def clear(self):
+            self._dirty(); dict.clear(self)
+
+        def update(self, *a, **k):
+            self._dirty(); dict.update(self, *a, **k)
+
+        def setdefault(self, *a):
+            self._dirty(); return dict.setdefault(self, *a)
+
     def _remember_stack(self, patches, corners, scale):
         """The patches of this map are views of ONE N x H x W x C array (the reference's numpy constructor, featuremap.cc:8-45):
         remembered, so that an upload can take the N patches from the array's address and stride without touching the N
         FeaturePatch objects (SharedArena.prefetch).  Dropped as soon as the dict no longer mirrors the array."""
         if isinstance(patches, np.ndarray) and patches.ndim == 4 and patches.flags["C_CONTIGUOUS"] and len(patches) == len(self.patches) \
                 and patches.dtype in (np.float16, np.float32, np.float64) and self.is_sparse:
+            views = FeatureMap._StackViews(self.patches)        # same content and order; writes from now on drop the stack
+            views.owner = weakref.ref(self)
+            self.patches = views
             self._stack = (patches, np.ascontiguousarray(corners, dtype=np.int32).reshape(len(patches), 2),
                            np.asarray(scale, dtype=np.float64).reshape(2))
 
@@ -182,8 +223,8 @@ class FeatureMap:
         if st is None or len(self.patches) != len(st[0]) or len(st[0]) == 0:
             return None
         first = next(iter(self.patches.values()))
-        if type(first) is not FeaturePatch or first._ptr != st[0].ctypes.data:
-            return None
+        if type(first) is not FeaturePatch or first._ptr != st[0].ctypes.data or type(self.patches) is not FeatureMap._StackViews:
+            return None          # (`patches` rebound to another dict: nothing watches its writes)
         return st
 
     @classmethod
@@ -548,6 +589,11 @@ class SharedArena:
         if t is not None:
             t.join()
             if self._error is not None or self.arena is None:
+                if self._error is not None and not isinstance(self._error, Exception):
+                    raise self._error                      # KeyboardInterrupt / SystemExit are not the upload's to swallow
+                if self._error is not None:
+                    warnings.warn("pixsfm_amd: the background upload of the stacked feature maps failed (%r); "
+                                  "uploading patch by patch instead" % (self._error,), RuntimeWarning, stacklevel=2)
                 self._error, self.arena, self.uniq = None, None, None
 
     def close(self):

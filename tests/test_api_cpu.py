@@ -534,3 +534,38 @@ def test_flat_ba_does_not_reuse_a_scene_dump_of_another_feature_view():
     same = B._FlatBA(rec, setup, fv_full, extractor=True, scene=scene)
     other = B._FlatBA(rec, setup, fv_holes, extractor=True, scene=scene)      # must re-dump: two observations lack a patch
     assert len(same.obs_image) == 8 and len(other.obs_image) == 6
+
+
+def test_a_patch_replaced_in_place_drops_the_remembered_stack():
+    """FeatureMap(patches, ids, corners, metadata) remembers the stacked array so that an upload can take the patches by address and
+    stride (SharedArena.prefetch).  ANY write to the dict -- not only add_fpatch -- must drop that: a replaced patch of the same
+    count would otherwise be uploaded from the stale slice of the array (the reference keeps no such shortcut: featuremap.cc:8-45
+    builds plain FeaturePatch views)."""
+    from pixsfm_amd.api.features import FeatureMap, FeaturePatch
+    rng = np.random.default_rng(3)
+    arr = rng.standard_normal((4, 4, 4, 8)).astype(np.float16)
+    ids = [7, 9, 11, 13]
+    corners = np.zeros((4, 2), np.int32)
+    meta = {"is_sparse": True, "scale": [1.0, 1.0]}
+    other = FeaturePatch(rng.standard_normal((4, 4, 8)).astype(np.float16), (0, 0), np.ones(2))
+    edits = {
+        "setitem": lambda fm: fm.patches.__setitem__(9, other),
+        "fpatches": lambda fm: fm.fpatches.__setitem__(9, other),
+        "update": lambda fm: fm.patches.update({9: other}),
+        "pop": lambda fm: fm.patches.pop(13),
+        "delitem": lambda fm: fm.patches.__delitem__(13),
+        "setdefault": lambda fm: fm.patches.setdefault(15, other),
+        "clear": lambda fm: fm.patches.clear(),
+        "add_fpatch": lambda fm: fm.add_fpatch(9, other),
+    }
+    for name, edit in edits.items():
+        fm = FeatureMap(arr, ids, corners, meta)
+        assert fm.stacked() is not None and list(fm.patches) == ids, name
+        edit(fm)
+        assert fm.stacked() is None, name
+    fm = FeatureMap(arr, ids, corners, meta)
+    fm.patches = dict(fm.patches)                     # rebound: nothing watches the new dict
+    assert fm.stacked() is None
+    fm = FeatureMap(arr, ids, corners, meta)          # reading does not drop it
+    _ = fm.fpatch(9), fm.keys(), fm.num_fpatches(), fm.has_fpatch(7), dict(fm.patches)
+    assert fm.stacked() is not None

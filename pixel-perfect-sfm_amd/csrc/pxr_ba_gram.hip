@@ -32,6 +32,10 @@
 namespace pxr {
 
 constexpr int GC_STRIDE = IG_GDOUBLES + 16;      // doubles per observation in the cache: ten 4 x 4 blocks of G, then D
+// (1 408 bytes = 128 mod 256: the eight observations of a wavefront alias in the LDS banks, 54 % of k_gram_eval's LDS cycles are
+// conflicts.  Tried in round 5: an LDS image padded to 89 sixteen-byte pieces per observation -- the lanes of global_load_lds may ask
+// for any 16 bytes -- removes them but needs a twelfth request per wavefront and an index computation per lane: 0.32 ms per pass
+// instead of 0.27 ms.  The kernel waits on HBM, not on LDS; left as it is.)
 
 struct GramArgs {
   pxr_ba_view v;

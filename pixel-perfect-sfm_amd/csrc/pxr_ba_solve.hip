@@ -1340,7 +1340,8 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   RC(chunk_trace.alloc(chunks.size() + 1));
   // the grid: entries bounded by 8 max(md, sqrt(2 md cost)) fit 62 bits (md: the bound on diag(U) the grid is made for).  (A grid
   // of 2^51 units with a one-addition rounding was tried: it saves nothing measurable -- the Schur kernel waits on its gathers --
-  // and the 11 lost bits broke the parity of ill-conditioned reduced systems with the oracle; profiles/r5_lm_det_vs_atomics.txt.)
+  // and the 11 lost bits broke the parity of ill-conditioned reduced systems with the oracle.  What the mode costs: `lm.nondeterministic` in
+  // profiles/r5_bench_n1.json, 2.37 against 2.45 ms per iteration.)
   auto det_scale_for = [](double md, double cost_now) {
     const double bound = 8.0 * std::max({md, std::sqrt(2.0 * md * std::max(cost_now, 0.0)), 1e-300});
     return std::ldexp(1.0, 62 - (int)std::ceil(std::log2(bound)));

@@ -182,12 +182,8 @@ struct KaProb {
 // DET: the kernel instantiation of the deterministic mode adds fixed-point integers only; the other floating-point atomics only
 template <bool DET>
 __device__ __forceinline__ void ka_accum(double* slot, double v, double det_scale) {
-#ifdef PXR_KA_PROBE_FP_ATOMICS     // tools/variant_build.sh: the deterministic instantiation with floating-point atomics (what the integers cost)
-  atomicAdd(slot, v * det_scale);
-#else
   if constexpr (DET) atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double2ll_rn(v * det_scale));
   else atomicAdd(slot, v);
-#endif
 }
 // evaluate all nodes of the problem at keypoints `kp`
 template <typename ST, int C, bool WITH_JAC>
@@ -1210,7 +1206,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       // is more than 2^10 coarser than ideal (single-channel features: H ~ 1e-4, g -> 1e-9 at convergence).  One workgroup,
       // a static block -> lane mapping, fixed reduction trees: the same decision on every run.  (The grid and the request live in
       // LDS and the epilogue is out of line: as loop-carried registers / inline code they cost the interpolation core 20 more
-      // spilled registers -- 5.4 instead of 5.0 ms per configs[1] solve, profiles/r5_ka_det_probes.txt.)
+      // spilled registers; what the mode costs with them there: profiles/r5_ka_det_probes.txt.)
       double resc = 0.0;
       const double ideal = ka_finish_fixed_point(p.Hm, p.g, p.row_off, p.row_v0, hsz, n, sh_grid, c, compute_scale, sh4, &resc);
       if (tid == 0) { sh_grid = ideal; if (resc != 0.0) sh_resc = resc; }

@@ -246,19 +246,22 @@ typedef struct {
 typedef int (*pxr_iteration_callback)(const pxr_iteration_summary* summary, void* user);
 int pxr_set_iteration_callback(pxr_ctx* ctx, pxr_iteration_callback fn /* NULL removes it */, void* user);
 
-/* Deterministic mode (also switched on by PXR_DETERMINISTIC=1 in the environment when the context is created).  By default
- * the solvers accumulate normal-equation blocks and scalar sums with floating-point atomics: fast, but the order of the
- * additions -- hence the last bits, hence now and then an accept / reject decision of the trust-region loop -- varies from
- * run to run (Ceres sums each parameter block's Jacobian rows in a fixed order: the reference is run-to-run reproducible
- * for a fixed thread count).  With the mode on, pxr_ba_solve (direct solver) and pxr_ka_solve produce bit-identical results
- * from run to run and on every rank: matrix / vector accumulations round each addend to a fixed-point grid and add 64-bit
- * integers (associative), scalar sums go through per-workgroup partials added in index order.  The fixed-point grid needs
- * the Jacobi scaling of the options (the default) for its bounds; the iterative solver keeps its floating-point atomics.
- * Costs a few per cent of an LM iteration (bench.py reports the slowdown). */
+/* Deterministic mode: ON by default since round 5 (pxr_set_deterministic(ctx, 0) or PXR_DETERMINISTIC=0 in the environment of a
+ * new context opt out).  Ceres sums each parameter block's Jacobian rows in a fixed order: the reference is run-to-run reproducible
+ * for a fixed thread count (residuals/src/feature_reference.h:91-93 through AutoDiffCostFunction).  With the mode on, pxr_ba_solve
+ * (direct solver) and pxr_ka_solve produce bit-identical results from run to run, for every launch shape AND for every number of
+ * ranks: matrix / vector accumulations round each addend to a fixed-point grid and add 64-bit integers (associative; the grid is
+ * derived from the measured diagonal of the previous linearisation and every linearisation is checked for overflow and repeated on
+ * a coarser grid if need be), scalar sums are four 40-bit limbs per scalar, and several ranks all-reduce the integers (ncclInt64).
+ * The grids need the Jacobi scaling of the options (the default); without it, and in the iterative solver (> 1000 images), the
+ * solvers fall back to floating-point atomics: fast, but the order of the additions -- hence the last bits, hence now and then an
+ * accept / reject decision of the trust-region loop -- varies from run to run.  Costs ~3 % of an LM iteration, 8 % of a KA solve
+ * (bench.py reports both modes). */
 int pxr_set_deterministic(pxr_ctx* ctx, int on);
 int pxr_get_deterministic(pxr_ctx* ctx);
 
-/* Gram-matrix cache of pxr_ba_solve (also switched on by PXR_GRAM_CACHE=1 in the environment when the context is created).
+/* Gram-matrix cache of pxr_ba_solve: ON by default since round 5 (pxr_set_gram_cache(ctx, 0) or PXR_GRAM_CACHE=0 in the environment
+ * of a new context switch it off).
  * The solver only consumes the 64-byte record of a residual block (pxr_ba_eval), and bicubic interpolation is linear in the
  * sixteen texels of the stencil: with the stencil's Gram matrix G = T T^t (16 x 16, over the channels) and D = T ref the
  * record is a set of quadratic / linear forms in the Catmull-Rom weights of the fractional position.  With the cache on,
@@ -270,7 +273,11 @@ int pxr_get_deterministic(pxr_ctx* ctx);
  * pass's own rounding (1e-7 of the descriptor norm per channel): costs agree to ~1e-9 relative on sums over many blocks,
  * trajectories to the solver's tolerances; pxr_ba_eval itself, the other solvers and cost maps are unaffected.  Used for
  * feature patches of 128 / 64 channels in fp16 / fp32 storage with reference descriptors; otherwise the flag is ignored.
- * pxr_set_gram_cache(ctx, 0) also releases the storage. */
+ * pxr_set_gram_cache(ctx, 0) also releases the storage.
+ * Memory: 1 408 bytes per observation (+ 12 per observation of bookkeeping) in a grow-only buffer of the context -- 1.4 GB at 1M
+ * observations -- allocated by the first solve that uses it and kept until the flag is cleared or the context is destroyed.  The
+ * inner iterations (pxr_lm_options.use_inner_iterations) use the same buffer whenever the patches qualify, flag or no flag (set
+ * PXR_INNER_NO_CACHE=1 to keep them from it); if it cannot be allocated they rebuild their matrices at every call instead. */
 int pxr_set_gram_cache(pxr_ctx* ctx, int on);
 int pxr_get_gram_cache(pxr_ctx* ctx);
 /* The records of pxr_ba_eval(with_jacobian = 1) through that cache, outside a solve (parity tests, bench): reset != 0

@@ -178,6 +178,9 @@ struct KaProb {
   const KaNodeMeta* cnode = nullptr;   // LDS: metadata of the first KA_NODE_CACHE nodes / KA_EDGE_CACHE edges of the problem
   const KaEdgeMeta* cedge = nullptr;   // (solve kernel only; the rest, and every other caller, reads global memory)
   double* csq = nullptr;               // LDS: squared residual norms of the cached edges (cost-only pass)
+  double* ckp0 = nullptr;              // LDS: the current (accepted) keypoints of the cached nodes
+  double* ckp = nullptr;               // LDS: the candidate keypoints of the cached nodes (ka_plus writes them here too: the probes'
+                                       // node pass then starts without an L2 round trip in front of its texel addresses)
 };
 // DET: the kernel instantiation of the deterministic mode adds fixed-point integers only; the other floating-point atomics only
 template <bool DET>
@@ -201,7 +204,9 @@ __device__ void ka_nodes(const KaArgs& a, const KaProb& p, const double* kp, boo
       for (int64_t i = p.np0 + qgrp; i - p.np0 < ncached; i += KA_NT / 8) {
         const KaNodeMeta m = p.cnode[i - p.np0];
         if (m.node < 0 || (moving_only && m.v < 0)) continue;
-        const double u = kp[2 * m.node] * m.sx - 0.5 - m.cx, v = kp[2 * m.node + 1] * m.sy - 0.5 - m.cy;
+        const bool lds_kp = moving_only && p.ckp != nullptr;          // (a probe: kp is the candidate ka_plus just wrote)
+        const double kx = lds_kp ? p.ckp[2 * (i - p.np0)] : kp[2 * m.node], ky = lds_kp ? p.ckp[2 * (i - p.np0) + 1] : kp[2 * m.node + 1];
+        const double u = kx * m.sx - 0.5 - m.cx, v = ky * m.sy - 0.5 - m.cy;
         const ST* patch = reinterpret_cast<const ST*>(a.arena) + (size_t)m.pi * a.H * a.W * C;
         double fa[8], fb[8];
         if (fsimd) interp8x2_value<ST, true>(patch, a.H, a.W, qsub, u, v, a.l2_normalize != 0, fa, fb);
@@ -512,9 +517,10 @@ __device__ void ka_plus(const KaArgs& a, const KaProb& p, double alpha) {
     const int v = cached ? p.cnode[i - p.np0].v : a.var_of_node[node];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      double val = a.v.d_kp[2 * node + c];
+      double val = (cached && p.ckp0) ? p.ckp0[2 * (i - p.np0) + c] : a.v.d_kp[2 * node + c];
       if (v >= 0) val = fmin(fmax(val + alpha * p.delta[v + c], p.lo[v + c]), p.hi[v + c]);
       a.kp_cand[2 * node + c] = val;
+      if (cached && p.ckp) p.ckp[2 * (i - p.np0) + c] = val;
     }
   }
   __syncthreads();
@@ -805,84 +811,75 @@ constexpr int KA_NREG = 24;
 __device__ __forceinline__ double ka_readlane_f64(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
-__device__ bool ka_chol_wave_reg(const double* A, int n, double* b) {
+// The block size as a template parameter: the run-time form (every row / column step under an `if (c < n)`: 276 wave-uniform branches
+// with their scalar compares between the readlanes) spent ~9 us on an 18 x 18 block -- 20 us of every LM iteration of a
+// 5-track sub-problem, the wavefront that takes two components running them back to back.
+template <int N>
+__device__ __attribute__((noinline)) bool ka_chol_reg_n(const double* A, double* b) {
   const int lane = threadIdx.x & 63;
-  double row[KA_NREG], inv[KA_NREG];
-  // (clamped address + select: a conditional load is a branch and a wait per element -- 24 dependent LDS round trips)
-  const int rl = min(lane, n - 1);
-#ifdef PXR_KA_OLD_CHOL
+  double row[N], inv[N];
+  // (clamped address + select: a conditional load is a branch and a wait per element)
+  const int rl = min(lane, N - 1);
 #pragma unroll
-  for (int c = 0; c < KA_NREG; ++c) row[c] = (lane < n && c <= lane && c < n) ? A[lane * n + c] : 0.0;
-#else
-#pragma unroll
-  for (int c = 0; c < KA_NREG; ++c) {
-    const double v = A[rl * n + min(c, n - 1)];
-    row[c] = (lane < n && c <= lane && c < n) ? v : 0.0;
+  for (int c = 0; c < N; ++c) {
+    const double v = A[rl * N + c];
+    row[c] = (lane < N && c <= lane) ? v : 0.0;
   }
-#endif
   bool ok = true;
 #pragma unroll
-  for (int j = 0; j < KA_NREG; ++j) {
-    if (j < n) {                                              // wave-uniform
-      const double d = ka_readlane_f64(row[j], j);
-      const bool good = d > 0.0 && isfinite(d);
-      ok = ok && good;
-      inv[j] = good ? rsqrt(d) : 1.0;                         // 1 / L[j][j]
-      const double l = row[j] * inv[j];                       // lane r >= j: L[r][j]  (lane j: sqrt(d))
-      row[j] = l;
+  for (int j = 0; j < N; ++j) {
+    const double d = ka_readlane_f64(row[j], j);
+    const bool good = d > 0.0 && isfinite(d);
+    ok = ok && good;
+    inv[j] = good ? rsqrt(d) : 1.0;                           // 1 / L[j][j]
+    const double l = row[j] * inv[j];                         // lane r >= j: L[r][j]  (lane j: sqrt(d))
+    row[j] = l;
 #pragma unroll
-      for (int c = j + 1; c < KA_NREG; ++c)
-        if (c < n) row[c] = fma(-l, ka_readlane_f64(l, c), row[c]);   // rows r >= c use it; the others hold dead entries
-    } else {
-      inv[j] = 1.0;
-    }
+    for (int c = j + 1; c < N; ++c) row[c] = fma(-l, ka_readlane_f64(l, c), row[c]);   // rows r >= c use it; the others hold dead entries
   }
-  double bi = lane < n ? b[lane] : 0.0;
+  double bi = lane < N ? b[lane] : 0.0;
 #pragma unroll
-  for (int j = 0; j < KA_NREG; ++j) {                         // L y = b
-    if (j < n) {
-      const double yj = ka_readlane_f64(bi, j) * inv[j];
-      bi = lane == j ? yj : (lane > j ? fma(-row[j], yj, bi) : bi);
-    }
+  for (int j = 0; j < N; ++j) {                               // L y = b
+    const double yj = ka_readlane_f64(bi, j) * inv[j];
+    bi = lane == j ? yj : (lane > j ? fma(-row[j], yj, bi) : bi);
   }
-  // L^T x = y: step j needs L[j][r] in lane r -- lane j's row, one entry per lane: through the block's own storage
-  // (A is scratch of the iteration: overwritten with the factor's rows)
-  // (a lane also stores the dead entries right of its diagonal: nothing reads the block's upper triangle; the column of L^T a
-  // lane needs is then loaded in one go, not entry by entry inside the substitution)
+  // L^T x = y: step j needs L[j][r] in lane r -- lane j's row, one entry per lane: through the block's own storage (A is scratch
+  // of the iteration: overwritten with the factor's rows; a lane also stores the dead entries right of its diagonal: nothing
+  // reads the block's upper triangle), and the column of L^T a lane needs is loaded in one go, not entry by entry inside the
+  // substitution
   double* Aw = const_cast<double*>(A);
-#ifdef PXR_KA_OLD_CHOL
-  if (lane < n) {
+  if (lane < N) {
 #pragma unroll
-    for (int c = 0; c < KA_NREG; ++c) if (c <= lane && c < n) Aw[lane * n + c] = row[c];
+    for (int c = 0; c < N; ++c) Aw[lane * N + c] = row[c];
   }
   wave_sync();
+  double col[N];
 #pragma unroll
-  for (int j = KA_NREG - 1; j >= 0; --j) {
-    if (j < n) {
-      const double xj = ka_readlane_f64(bi, j) * inv[j];
-      bi = lane == j ? xj : (lane < j ? fma(-Aw[j * n + lane], xj, bi) : bi);
-    }
+  for (int j = 0; j < N; ++j) col[j] = Aw[j * N + rl];
+#pragma unroll
+  for (int j = N - 1; j >= 0; --j) {
+    const double xj = ka_readlane_f64(bi, j) * inv[j];
+    bi = lane == j ? xj : (lane < j ? fma(-col[j], xj, bi) : bi);
   }
-  if (lane < n) b[lane] = bi;
+  if (lane < N) b[lane] = bi;
   return ok;
-#endif
-  if (lane < n) {
-#pragma unroll
-    for (int c = 0; c < KA_NREG; ++c) if (c < n) Aw[lane * n + c] = row[c];
+}
+// 2 < n <= KA_NREG, n even (two unknowns per keypoint)
+__device__ __forceinline__ bool ka_chol_wave_reg(const double* A, int n, double* b) {
+  switch (n) {
+    case 4: return ka_chol_reg_n<4>(A, b);
+    case 6: return ka_chol_reg_n<6>(A, b);
+    case 8: return ka_chol_reg_n<8>(A, b);
+    case 10: return ka_chol_reg_n<10>(A, b);
+    case 12: return ka_chol_reg_n<12>(A, b);
+    case 14: return ka_chol_reg_n<14>(A, b);
+    case 16: return ka_chol_reg_n<16>(A, b);
+    case 18: return ka_chol_reg_n<18>(A, b);
+    case 20: return ka_chol_reg_n<20>(A, b);
+    case 22: return ka_chol_reg_n<22>(A, b);
+    case 24: return ka_chol_reg_n<24>(A, b);
+    default: return ka_chol_wave(const_cast<double*>(A), n, b);      // (cannot happen: the unknowns come in pairs)
   }
-  wave_sync();
-  double col[KA_NREG];
-#pragma unroll
-  for (int j = 0; j < KA_NREG; ++j) col[j] = Aw[min(j, n - 1) * n + rl];
-#pragma unroll
-  for (int j = KA_NREG - 1; j >= 0; --j) {
-    if (j < n) {
-      const double xj = ka_readlane_f64(bi, j) * inv[j];
-      bi = lane == j ? xj : (lane < j ? fma(-col[j], xj, bi) : bi);
-    }
-  }
-  if (lane < n) b[lane] = bi;
-  return ok;
 }
 
 // one thread, n == 2 (a keypoint that is alone in its component)
@@ -1101,6 +1098,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   __shared__ KaNodeMeta sh_nodes[KA_NODE_CACHE];
   __shared__ KaEdgeMeta sh_edges[KA_EDGE_CACHE];
   __shared__ double sh_sq[KA_EDGE_CACHE];
+  __shared__ double sh_kpc[2 * KA_NODE_CACHE], sh_kp0[2 * KA_NODE_CACHE];
 #ifdef PXR_KA_STREAM_PROBE
   __shared__ unsigned char sh_eslot[2 * KA_EDGE_CACHE];     // node slots of the cached residual blocks' endpoints (ka_probe_stream)
 #endif
@@ -1111,6 +1109,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     m.node = a.used[node] ? node : -1; m.pi = pi; m.id = node; m.v = a.var_of_node[node];
     m.sx = a.scales[2 * pi]; m.sy = a.scales[2 * pi + 1]; m.cx = (double)a.corners[2 * pi]; m.cy = (double)a.corners[2 * pi + 1];
     sh_nodes[i - p.np0] = m;
+    sh_kp0[2 * (i - p.np0)] = a.v.d_kp[2 * node]; sh_kp0[2 * (i - p.np0) + 1] = a.v.d_kp[2 * node + 1];
   }
   for (int64_t i = p.ne0 + tid; i < p.ne1 && i - p.ne0 < KA_EDGE_CACHE; i += blockDim.x) {
     const int e = a.v.d_prob_edges[i];
@@ -1122,7 +1121,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     sh_eslot[2 * (i - p.ne0) + 1] = (unsigned char)a.slot_of_node[m.n2];   // only ones that read it)
 #endif
   }
-  p.cnode = sh_nodes; p.cedge = sh_edges; p.csq = sh_sq;
+  p.cnode = sh_nodes; p.cedge = sh_edges; p.csq = sh_sq; p.ckp = sh_kpc; p.ckp0 = sh_kp0;
   __syncthreads();
 
   const KaInfo inf = info[prob];
@@ -1407,6 +1406,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
         const int64_t node = i - p.np0 < KA_NODE_CACHE ? sh_nodes[i - p.np0].id : a.v.d_prob_nodes[i];
         const double nx = a.kp_cand[2 * node], ny = a.kp_cand[2 * node + 1];
         a.v.d_kp[2 * node] = nx; a.v.d_kp[2 * node + 1] = ny;
+        if (i - p.np0 < KA_NODE_CACHE) { sh_kp0[2 * (i - p.np0)] = nx; sh_kp0[2 * (i - p.np0) + 1] = ny; }
 #ifdef PXR_KA_STREAM_PROBE
         if (use_stream) { strm.kp[2 * (i - p.np0)] = nx; strm.kp[2 * (i - p.np0) + 1] = ny; }
 #endif

@@ -4,7 +4,7 @@
 #   tools/ka_phase_probe.sh && PXR_HIP_LIB=tools/debug/libpixsfm_hip_kaprof.so python bench.py --no-cpu-baseline --no-costmap --lm-iters 0
 set -e
 cd "$(dirname "$0")/../pixel-perfect-sfm_amd/csrc"
-FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -I. -munsafe-fp-atomics"
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -I. -munsafe-fp-atomics -mllvm -amdgpu-spill-vgpr-to-agpr=0"
 mkdir -p ../../tools/debug
 /opt/rocm/bin/hipcc $FL -DPXR_KA_PROFILE -DPXR_KA_PROFILE_BLOCK=${1:-0} $KA_PROBE_FLAGS -c pxr_ka.hip -o /tmp/pxr_ka_prof${1:-0}$KA_PROBE_TAG.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o ../../tools/debug/libpixsfm_hip_kaprof${1:-}$KA_PROBE_TAG.so \

@@ -7,6 +7,7 @@ TAG=$1; SRC=$2; shift 2
 cd "$(dirname "$0")/../pixel-perfect-sfm_amd/csrc"
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -I. -munsafe-fp-atomics"
 mkdir -p ../../tools/debug
+[ "$SRC" = pxr_ka.hip ] && FL="$FL -mllvm -amdgpu-spill-vgpr-to-agpr=0"     # (as in the Makefile)
 /opt/rocm/bin/hipcc $FL "$@" -c $SRC -o /tmp/pxr_variant_$TAG.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o ../../tools/debug/libpixsfm_hip_$TAG.so \
   $(ls build/*.o | grep -v "$SRC.o") /tmp/pxr_variant_$TAG.o -ldl -lpthread

@@ -108,7 +108,8 @@ def self_launch(argv, n_ranks):
 
 
 def _selftest_hooks(rank):
-    """PXR_BENCH_SELFTEST="fail:R" / "hang:R" (comma separated): rank R exits with code 3 / sleeps, before any GPU work.
+    """PXR_BENCH_SELFTEST="fail:R" / "hang:R" / "ok:R" / "watchdog:R" (comma separated): rank R exits with code 3 / sleeps / prints a
+    line and exits 0 / arms the Watchdog and then sleeps, before any GPU work.
     Lets tests/ exercise the launcher's failure path on a box without a GPU."""
     for item in filter(None, os.environ.get("PXR_BENCH_SELFTEST", "").split(",")):
         what, _, who = item.partition(":")
@@ -120,6 +121,9 @@ def _selftest_hooks(rank):
             if what == "ok":
                 print(json.dumps({"selftest": True, "rank": rank}))
                 raise SystemExit(0)
+            if what == "watchdog":        # a leg that never returns: the timer prints rank 0's line and ends the rank with code 0
+                Watchdog(0.5, rank, lambda: print(json.dumps({"selftest": True, "watchdog": True, "rank": rank}), flush=True))
+                time.sleep(600)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -332,6 +336,9 @@ def parse_args(argv=None):
     ap.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"),
                     help="where the full result goes (sweeps, cgroup dumps, phase tables); the printed line is its compact form")
     ap.add_argument("--linear-solver", default="auto", help="auto (by image count, bundle_optimizer.h:180-191) | direct | iterative")
+    ap.add_argument("--watchdog-s", type=float, default=float(os.environ.get("PXR_BENCH_WATCHDOG_S", "420")),
+                    help="several ranks only: if the legs after the headline measurement (LM, KA) do not finish within this many seconds "
+                         "-- a collective that never returns -- rank 0 prints the line with what it has and every rank exits 0; 0 disables")
     args = ap.parse_args(argv)
     if args.preset == "aachen":
         args.cams, args.points, args.obs_per_point, args.patch_size = 4000, 1_000_000, 5, 8
@@ -815,6 +822,8 @@ def compact_line(full):
                 top = sorted(ph.items(), key=lambda kv: -kv[1])[:4]
                 out["api_e2e"][k] = {"wall_s": _r(ae[k].get("wall_s"), 4), "phases_s": {a: _r(b, 3) for a, b in top}}
     out["detail"] = full.get("detail_file")
+    if "watchdog" in full:
+        out["watchdog"] = full["watchdog"]
     # ---- the tail: clocks, then both LM figures (metric 2) ----
     t = full.get("telemetry")
     if t:
@@ -952,6 +961,75 @@ def secondary_legs(job, total_points):
     return ka_result, api_e2e
 
 
+class Watchdog:
+    """Several ranks only.  The multi-rank legs after the headline measurement (the LM loop's all-reduce, the KA gather) have never met
+    a second GPU in development: if one of them never returns, a rank cannot be interrupted out of the collective -- so a timer
+    thread lets rank 0 print the line with what has been measured (the headline is complete by then) plus a `watchdog` note, and
+    ends every rank with code 0 instead of leaving the driver to kill a silent job."""
+
+    def __init__(self, seconds, rank, emit):
+        import threading
+        self.rank, self.emit, self.seconds = rank, emit, seconds
+        self.timer = threading.Timer(seconds, self._fire) if seconds > 0 else None
+        if self.timer is not None:
+            self.timer.daemon = True
+            self.timer.start()
+
+    def _fire(self):
+        try:
+            print("bench.py rank %d: the legs after the headline did not finish in %.0f s -- giving up on them" % (self.rank, self.seconds),
+                  file=sys.stderr, flush=True)
+            if self.rank == 0:
+                self.emit()
+        finally:
+            os._exit(0)
+
+    def cancel(self):
+        if self.timer is not None:
+            self.timer.cancel()
+
+
+def headline(job, args, dt, kernel_ms, n_obs_total, n_obs_local, total_points, cost, jac_ms):
+    """The contract's fields + roofline of the one line (rank 0): complete as soon as the evaluation loop has been timed."""
+    C, PS, world = 128, args.patch_size, job.world
+    bpo = algorithmic_bytes_per_obs(C)
+    traffic, traffic_source = committed_traffic(world, n_obs_total, args.float_simd)
+    achieved = bpo * n_obs_local / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "featuremetric residuals+Jacobians evaluated/sec (1M obs)",
+        "value": n_obs_total * args.steps / dt,
+        "unit": "residual_blocks/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f32 horizontal / f64 vertical+normalisation on f16 patches"
+                 if not args.float_simd else "f32 splines / f64 normalisation on f16 patches",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE.json %s: synthetic %d cams / %d points / %d obs "
+                               "featuremetric BA residual+Jacobian evaluation, %d-ch fp16 %dx%d patches, "
+                               "SIMPLE_RADIAL, fused six-scalar Jacobian reduction"
+                               % ("configs[4] shape (Aachen scale) on one GPU" if args.preset == "aachen" else "configs[2]",
+                                  args.cams, total_points, n_obs_total, C, PS, PS),
+                   "n_obs": n_obs_total, "channels": C, "patch": PS,
+                   "arena_GB": n_obs_total * PS * PS * C * 2 / 1e9,
+                   "obs_per_gpu": n_obs_local,
+                   "partition": "points sharded, cameras replicated" if world > 1 else "none"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_note": "bytes/launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE",
+                     "traffic_source": traffic_source,
+                     "kernel": "ba_eval_kernel<f16,128,jac>", "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_obs": bpo},
+        "initial_cost": cost,
+    }
+    if jac_ms is not None:
+        # the reference's unit materialises the Jacobian; the fused record + the projection Jacobian P (k_jac) is its equivalent
+        out["like_for_like"] = {"what": "evaluation + k_jac (2x(10+K) projection Jacobian P of J = G P, which the fused record kernel omits)",
+                                "k_jac_ms": _r(jac_ms), "ms": _r(dt / args.steps * 1e3 + jac_ms),
+                                "value_with_projection_jacobian": _r(n_obs_total / ((dt / args.steps + jac_ms * 1e-3)), 7)}
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:          # the plain command: be the launcher
@@ -971,6 +1049,20 @@ def main():
     n_obs_total = int(job.reduce(float(n_obs_local)))
     per_rank = gather_ranks(job, n_obs_local, kernel_ms)
     cost = job.reduce(ba.cost(make_loss("cauchy", [0.25])))         # cost of the whole (sharded) problem
+    per_rank_now = per_rank
+
+    def emit_partial():         # the watchdog's line: the headline as measured, nothing of the legs that did not come back
+        part = headline(job, args, dt, kernel_ms, n_obs_total, n_obs_local, total_points, cost, None)
+        part["collective"] = job.collective
+        if per_rank_now is not None:
+            part["ranks"] = per_rank_now
+        part["watchdog"] = ("the legs after the headline measurement (LM loop / KA over %d ranks) did not finish within %.0f s; "
+                            "`value` and `roofline` are complete" % (world, args.watchdog_s))
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(compact_line(part), separators=(",", ":")), flush=True)
+    watchdog = Watchdog(args.watchdog_s if world > 1 else 0.0, rank, emit_partial)
     telemetry = None
     if rank == 0 and not args.no_telemetry:
         try:
@@ -997,42 +1089,10 @@ def main():
     torch.cuda.empty_cache()
     ka_result, api_e2e = secondary_legs(job, total_points)
 
+    watchdog.cancel()
     result_line = None
     if rank == 0:
-        bpo = algorithmic_bytes_per_obs(C)
-        traffic, traffic_source = committed_traffic(world, n_obs_total, args.float_simd)
-        achieved = bpo * n_obs_local / (kernel_ms * 1e-3) / 1e9
-        out = {
-            "metric": "featuremetric residuals+Jacobians evaluated/sec (1M obs)",
-            "value": n_obs_total * args.steps / dt,
-            "unit": "residual_blocks/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32 horizontal / f64 vertical+normalisation on f16 patches"
-                     if not args.float_simd else "f32 splines / f64 normalisation on f16 patches",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE.json %s: synthetic %d cams / %d points / %d obs "
-                                   "featuremetric BA residual+Jacobian evaluation, %d-ch fp16 %dx%d patches, "
-                                   "SIMPLE_RADIAL, fused six-scalar Jacobian reduction"
-                                   % ("configs[4] shape (Aachen scale) on one GPU" if args.preset == "aachen" else "configs[2]",
-                                      args.cams, total_points, n_obs_total, C, PS, PS),
-                       "n_obs": n_obs_total, "channels": C, "patch": PS,
-                       "arena_GB": n_obs_total * PS * PS * C * 2 / 1e9,
-                       "obs_per_gpu": n_obs_local,
-                       "partition": "points sharded, cameras replicated" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "bytes/launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE",
-                         "traffic_source": traffic_source,
-                         "kernel": "ba_eval_kernel<f16,128,jac>", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_obs": bpo},
-            # the reference's unit materialises the Jacobian; the fused record + the projection Jacobian P (k_jac) is its equivalent
-            "like_for_like": {"what": "evaluation + k_jac (2x(10+K) projection Jacobian P of J = G P, which the fused record kernel omits)",
-                              "k_jac_ms": _r(jac_ms), "ms": _r(dt / args.steps * 1e3 + jac_ms),
-                              "value_with_projection_jacobian": _r(n_obs_total / ((dt / args.steps + jac_ms * 1e-3)), 7)},
-            "initial_cost": cost,
-        }
+        out = headline(job, args, dt, kernel_ms, n_obs_total, n_obs_local, total_points, cost, jac_ms)
         if telemetry is not None:
             out["telemetry"] = telemetry
         for key, v in lm.items():

@@ -99,3 +99,33 @@ def test_plain_command_at_eight_ranks():
     assert len(lines) == 1 and json.loads(lines[0]) == {"selftest": True, "rank": 0}
     for r in range(1, 8):
         assert '"rank": %d' % r in p.stderr
+
+
+def test_a_leg_that_never_returns_still_leaves_rank_0s_line_and_exit_code_0():
+    """The legs after the headline measurement use collectives that development never ran on a second GPU.  bench.Watchdog: when
+    they do not come back in time, rank 0 prints the line with what was measured and every rank exits 0 -- here every rank arms it
+    (0.5 s) and then sleeps."""
+    p, dt = _run(2, "watchdog:0,watchdog:1", timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert dt < 60
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"selftest": True, "watchdog": True, "rank": 0}
+    assert "did not finish" in p.stderr
+
+
+def test_the_watchdogs_partial_line_carries_the_contract():
+    """What rank 0 prints when the watchdog fires is built from bench.headline(): every field of the contract + roofline."""
+    sys.path.insert(0, ROOT)
+    import types
+    import bench
+    args = bench.parse_args(["--gpus", "8"])
+    job = types.SimpleNamespace(world=8, collective="native ncclAllReduce on the engine's stream (pxr_comm_init)")
+    part = bench.headline(job, args, dt=0.0052, kernel_ms=0.104, n_obs_total=1_000_000, n_obs_local=125_000, total_points=200_000,
+                          cost=32262.3, jac_ms=None)
+    part["watchdog"] = "x"
+    line = bench.compact_line(part)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in line, k
+    assert line["n_gpus"] == 8 and line["config"]["obs_per_gpu"] == 125_000
+    assert abs(line["value"] - 1_000_000 * args.steps / 0.0052) / line["value"] < 1e-6

@@ -253,10 +253,12 @@ int pxr_set_iteration_callback(pxr_ctx* ctx, pxr_iteration_callback fn /* NULL r
  * ranks: matrix / vector accumulations round each addend to a fixed-point grid and add 64-bit integers (associative; the grid is
  * derived from the measured diagonal of the previous linearisation and every linearisation is checked for overflow and repeated on
  * a coarser grid if need be), scalar sums are four 40-bit limbs per scalar, and several ranks all-reduce the integers (ncclInt64).
- * The grids need the Jacobi scaling of the options (the default); without it, and in the iterative solver (> 1000 images), the
- * solvers fall back to floating-point atomics: fast, but the order of the additions -- hence the last bits, hence now and then an
- * accept / reject decision of the trust-region loop -- varies from run to run.  Costs ~3 % of an LM iteration, 8 % of a KA solve
- * (bench.py reports both modes). */
+ * The iterative solver (> 1000 images) sums ORDERED PARTIALS instead -- every chunk of an image's observations leaves its part in a
+ * buffer, the parts are added per image and per reduced-system column in a fixed order -- which gives the same bits on every run
+ * for a given number of ranks (the ranks' parts are all-reduced as doubles).  The grids need the Jacobi scaling of the options (the
+ * default); a direct solve without it falls back to floating-point atomics: fast, but the order of the additions -- hence the last
+ * bits, hence now and then an accept / reject decision of the trust-region loop -- varies from run to run.  Costs ~3 % of an LM
+ * iteration (1 % with the iterative solver), 8 % of a KA solve (bench.py reports both modes). */
 int pxr_set_deterministic(pxr_ctx* ctx, int on);
 int pxr_get_deterministic(pxr_ctx* ctx);
 

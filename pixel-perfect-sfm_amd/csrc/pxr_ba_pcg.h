@@ -27,6 +27,13 @@ struct PcgArgs {
   double* cgs;                       // [8] scalars + [8] control block of the device-resident loop
   double* cg_part;                   // [8][ceil(n_c / 256)] per-block partial sums of the dot products
   int* d_fail;
+  // deterministic mode (ordered partial sums instead of floating-point atomics; all null / 0 otherwise)
+  bool det = false;
+  const int* chunk_ptr = nullptr;    // [n_images + 1] first chunk of every image (chunks are image-major)
+  const int* col_ent_ptr = nullptr;  // [n_c + 1] per reduced-system column: its (image, local column) entries, images ascending
+  const int2* col_ent = nullptr;
+  double* wpart = nullptr;           // [n_chunks][DC] a chunk's part of W u
+  double* mpart = nullptr;           // [n_chunks][DC][DC] a chunk's part of an image's own block
 };
 
 struct PcgResult {
@@ -40,5 +47,10 @@ int pcg_solve(PcgArgs& a, double inv_radius, const pxr_lm_options* opt,
               const std::function<int(double*, int64_t)>& allreduce, PcgResult* res);
 // diag(U) from the per-image blocks (atomic accumulation into a zeroed vector)
 int pcg_diag_from_blocks(hipStream_t st, const SolveDev& d, const double* Ublk, double* diag);
+// deterministic linearisation of the block form: k_img left every chunk's NE = dc (dc + 1) / 2 + dc sums in kpart[chunk][ne_max];
+// the image's block of U and its gradient part are the ordered sums over its chunks, diag(U) and g_c the ordered sums over the
+// columns' entries
+int pcg_blocks_from_partials(hipStream_t st, const SolveDev& d, const int* kchunk_ptr, const double* kpart, int ne_max, double* Ublk,
+                             double* gimg /* [n_images][DC] */, const int* col_ent_ptr, const int2* col_ent, double* diag, double* gc);
 
 }  // namespace pxr

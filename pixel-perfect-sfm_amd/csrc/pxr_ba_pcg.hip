@@ -88,7 +88,8 @@ template <int G>
 __global__ __launch_bounds__(256) void k_img_wu(const SolveDev d, const ImgChunk* __restrict__ chunks,
                                                 const int4* __restrict__ so, const double* __restrict__ W,
                                                 const double* __restrict__ u, double sign, double* __restrict__ out,
-                                                const double* __restrict__ ctl /* or NULL */) {
+                                                const double* __restrict__ ctl /* or NULL */,
+                                                double* __restrict__ part /* deterministic mode: [n_chunks][DC], no atomics */) {
   __shared__ double red[256];
   if (ctl && ctl[CTL_STOP] != 0.0) return;
   const ImgChunk ch = chunks[blockIdx.x];
@@ -110,8 +111,38 @@ __global__ __launch_bounds__(256) void k_img_wu(const SolveDev d, const ImgChunk
   if (threadIdx.x < dci) {
     double t = 0.0;
     for (int g = 0; g < n_grp; ++g) t += red[g * G + threadIdx.x];
-    if (t != 0.0) atomicAdd(out + col_index(d, img, cam, threadIdx.x), sign * t);
+    if (part) part[(size_t)blockIdx.x * d.DC + threadIdx.x] = t;             // (summed per column, in order, by k_col_finish)
+    else if (t != 0.0) atomicAdd(out + col_index(d, img, cam, threadIdx.x), sign * t);
   }
+}
+
+// ---- deterministic mode: out[c] = sum over the column's entries (image, a), images ascending, of
+//        [WITH_U: (U_img vec)_a]  +  sign * sum over the image's chunks, in order, of part[chunk][a]
+// One wavefront per column: lane l takes entries l, l + 64, ... (a camera shared by thousands of images has thousands of entries
+// in its intrinsics columns), then a fixed butterfly -- the same order on every run, no atomics.
+template <bool WITH_U>
+__global__ __launch_bounds__(256) void k_col_finish(const SolveDev d, const int* __restrict__ col_ent_ptr, const int2* __restrict__ col_ent,
+                                                    const int* __restrict__ chunk_ptr, const double* __restrict__ part, double sign,
+                                                    const double* __restrict__ Ublk, const double* __restrict__ vec,
+                                                    double* __restrict__ out, const double* __restrict__ ctl) {
+  if (ctl && ctl[CTL_STOP] != 0.0) return;
+  const int c = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (c >= d.n_c) return;                                   // (whole wavefronts)
+  double acc = 0.0;
+  for (int e = col_ent_ptr[c] + lane; e < col_ent_ptr[c + 1]; e += 64) {
+    const int2 en = col_ent[e];
+    const int img = en.x, a = en.y, cam = d.v.d_image_camera[img];
+    double t = 0.0;
+    if (WITH_U) {
+      const int dci = d.pose_dim[img] + d.intr_dim[cam];
+      const double* Ua = Ublk + ((size_t)img * d.DC + a) * d.DC;
+      for (int b = 0; b < dci; ++b) t += Ua[b] * vec[col_index(d, img, cam, b)];
+    }
+    for (int k = chunk_ptr[img]; k < chunk_ptr[img + 1]; ++k) t += sign * part[(size_t)k * d.DC + a];
+    acc += t;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[c] = acc;
 }
 
 // ---- out += U v, U = one dc x dc block per image ------------------------------------------------------------
@@ -134,7 +165,8 @@ __global__ __launch_bounds__(256) void k_ublk_matvec(const SolveDev d, const dou
 template <int G>
 __global__ __launch_bounds__(256) void k_img_block(const SolveDev d, const ImgChunk* __restrict__ chunks,
                                                    const int4* __restrict__ so, const double* __restrict__ W,
-                                                   const double* __restrict__ T, double* __restrict__ Mloc) {
+                                                   const double* __restrict__ T, double* __restrict__ Mloc,
+                                                   double* __restrict__ mpart /* deterministic mode: [n_chunks][DC][DC], no atomics */) {
   extern __shared__ double red[];                            // [256 / G][G][G]
   const ImgChunk ch = chunks[blockIdx.x];
   const int img = ch.img, cam = d.v.d_image_camera[img];
@@ -173,8 +205,24 @@ __global__ __launch_bounds__(256) void k_img_block(const SolveDev d, const ImgCh
     const int a = e / dci, b = e - a * dci;
     double t = 0.0;
     for (int g = 0; g < n_grp; ++g) t += red[((size_t)g * G + a) * G + b];
-    if (t != 0.0) atomicAdd(Mloc + ((size_t)img * d.DC + a) * d.DC + b, -t);
+    if (mpart) mpart[((size_t)blockIdx.x * d.DC + a) * d.DC + b] = t;
+    else if (t != 0.0) atomicAdd(Mloc + ((size_t)img * d.DC + a) * d.DC + b, -t);
   }
+}
+
+// deterministic mode: Mloc[img] = U_img - the image's chunks' parts, in order
+__global__ __launch_bounds__(256) void k_mloc_finish(const SolveDev d, const int* __restrict__ chunk_ptr, const double* __restrict__ mpart,
+                                                     const double* __restrict__ Ublk, double* __restrict__ Mloc) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int DC = d.DC;
+  const int img = (int)(t / (DC * DC)), e = (int)(t - (int64_t)img * DC * DC);
+  if (img >= d.v.n_images) return;
+  const int a = e / DC, b = e - a * DC;
+  const int dci = d.pose_dim[img] + d.intr_dim[d.v.d_image_camera[img]];
+  double v = Ublk[(size_t)img * DC * DC + e];
+  if (a < dci && b < dci)
+    for (int k = chunk_ptr[img]; k < chunk_ptr[img + 1]; ++k) v -= mpart[((size_t)k * DC + a) * DC + b];
+  Mloc[(size_t)img * DC * DC + e] = v;
 }
 
 // ---- preconditioner blocks --------------------------------------------------------------------------------
@@ -193,6 +241,31 @@ __global__ __launch_bounds__(256) void k_pre_assemble(const SolveDev d, const in
   if (ga.x != gb.x) return;
   const double v = Mloc[((size_t)img * DC + a) * DC + b];
   if (v != 0.0) atomicAdd(Gm + ((size_t)ga.x * PCG_GS + ga.y) * PCG_GS + gb.y, v);
+}
+
+// deterministic mode: entry (ya, yb) of block g = the ordered sum over the images that hold both columns (one image for a pose /
+// joint block, every image of the camera for a shared intrinsics block)
+__global__ __launch_bounds__(256) void k_pre_assemble_det(const SolveDev d, int n_groups, const int* __restrict__ group_size,
+                                                          const int* __restrict__ group_cols, const int* __restrict__ col_ent_ptr,
+                                                          const int2* __restrict__ col_ent, const double* __restrict__ Mloc,
+                                                          double* __restrict__ Gm) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = (int)(t / (PCG_GS * PCG_GS)), e = (int)(t - (int64_t)g * PCG_GS * PCG_GS);
+  if (g >= n_groups) return;
+  const int ya = e / PCG_GS, yb = e - ya * PCG_GS, ng = group_size[g];
+  double acc = 0.0;
+  if (ya < ng && yb < ng) {
+    const int ca = group_cols[g * PCG_GS + ya], cb = group_cols[g * PCG_GS + yb];
+    for (int k = col_ent_ptr[ca]; k < col_ent_ptr[ca + 1]; ++k) {
+      const int2 en = col_ent[k];
+      const int img = en.x, cam = d.v.d_image_camera[img], pd = d.pose_dim[img];
+      int b = -1;
+      if (cb >= d.pose_off[img] && cb < d.pose_off[img] + pd) b = cb - d.pose_off[img];
+      else if (cb >= d.intr_off[cam] && cb < d.intr_off[cam] + d.intr_dim[cam]) b = pd + (cb - d.intr_off[cam]);
+      if (b >= 0) acc += Mloc[((size_t)img * d.DC + en.y) * d.DC + b];
+    }
+  }
+  Gm[(size_t)g * PCG_GS * PCG_GS + e] = acc;
 }
 
 // One wavefront per block: Gauss-Jordan inversion of the SPD block + damping, lane = row of [A | I].
@@ -408,6 +481,10 @@ int pcg_solve(PcgArgs& a, double inv_radius, const pxr_lm_options* opt, const st
   const bool verbose = std::getenv("PXR_VERBOSE") != nullptr;
 
   // ---- right-hand side b = g_c - sum_i W_i T_p g_p (g_c is already the sum over the ranks) --------------
+  // Deterministic mode (a.det): every sum that floating-point atomics would form in arrival order -- a chunk's part of W u or of an
+  // image's block into the image's slots, several images' parts into the columns of a shared camera -- is formed from per-chunk
+  // partials in a fixed order instead (k_col_finish, k_mloc_finish, k_pre_assemble_det): the same bits on every run.
+  const dim3 col_grid(nblk((int64_t)n * 64));
   PXR_HIP(hipMemsetAsync(a.b, 0, sizeof(double) * n, st));
   launch_by_g(DC, [&](auto G) {
     constexpr int GG = decltype(G)::value;
@@ -417,17 +494,27 @@ int pcg_solve(PcgArgs& a, double inv_radius, const pxr_lm_options* opt, const st
   if (a.n_chunks > 0)
     launch_by_g(DC, [&](auto G) {
       hipLaunchKernelGGL(k_img_wu<decltype(G)::value>, dim3((unsigned)a.n_chunks), dim3(256), 0, st, d, a.chunks, a.so, a.W, a.u, -1.0, a.b,
-                         (const double*)nullptr);
+                         (const double*)nullptr, a.det ? a.wpart : (double*)nullptr);
     });
+  if (a.det)
+    hipLaunchKernelGGL(k_col_finish<false>, col_grid, dim3(256), 0, st, d, a.col_ent_ptr, a.col_ent, a.chunk_ptr, (const double*)a.wpart, -1.0,
+                       (const double*)nullptr, (const double*)nullptr, a.b, (const double*)nullptr);
   // ---- preconditioner: local blocks = U_img - sum_i Y_i W_i^T, gathered into the column groups ----------
-  PXR_HIP(hipMemcpyAsync(a.Mloc, a.Ublk, sizeof(double) * (size_t)n_img * DC * DC, hipMemcpyDeviceToDevice, st));
+  if (!a.det) PXR_HIP(hipMemcpyAsync(a.Mloc, a.Ublk, sizeof(double) * (size_t)n_img * DC * DC, hipMemcpyDeviceToDevice, st));
   if (a.n_chunks > 0)
     launch_by_g(DC, [&](auto G) {
       constexpr int GG = decltype(G)::value;
-      hipLaunchKernelGGL(k_img_block<GG>, dim3((unsigned)a.n_chunks), dim3(256), sizeof(double) * 256 * GG, st, d, a.chunks, a.so, a.W, a.T, a.Mloc);
+      hipLaunchKernelGGL(k_img_block<GG>, dim3((unsigned)a.n_chunks), dim3(256), sizeof(double) * 256 * GG, st, d, a.chunks, a.so, a.W, a.T, a.Mloc,
+                         a.det ? a.mpart : (double*)nullptr);
     });
-  PXR_HIP(hipMemsetAsync(a.Gm, 0, sizeof(double) * (size_t)a.n_groups * PCG_GS * PCG_GS, st));
-  hipLaunchKernelGGL(k_pre_assemble, dim3(nblk((int64_t)n_img * DC * DC)), dim3(256), 0, st, d, a.col_group, a.Mloc, a.Gm);
+  if (a.det) {
+    hipLaunchKernelGGL(k_mloc_finish, dim3(nblk((int64_t)n_img * DC * DC)), dim3(256), 0, st, d, a.chunk_ptr, (const double*)a.mpart, a.Ublk, a.Mloc);
+    hipLaunchKernelGGL(k_pre_assemble_det, dim3(nblk((int64_t)a.n_groups * PCG_GS * PCG_GS)), dim3(256), 0, st, d, a.n_groups, a.group_size,
+                       a.group_cols, a.col_ent_ptr, a.col_ent, (const double*)a.Mloc, a.Gm);
+  } else {
+    PXR_HIP(hipMemsetAsync(a.Gm, 0, sizeof(double) * (size_t)a.n_groups * PCG_GS * PCG_GS, st));
+    hipLaunchKernelGGL(k_pre_assemble, dim3(nblk((int64_t)n_img * DC * DC)), dim3(256), 0, st, d, a.col_group, a.Mloc, a.Gm);
+  }
   RC(hip_check(hipGetLastError(), "pcg set-up kernels"));
   RC(ar(a.b, n));
   RC(ar(a.Gm, (int64_t)a.n_groups * PCG_GS * PCG_GS));
@@ -454,7 +541,7 @@ int pcg_solve(PcgArgs& a, double inv_radius, const pxr_lm_options* opt, const st
     hipLaunchKernelGGL(k_pre_apply, dim3(nb), dim3(256), 0, st, n, a.col_group, a.group_size, a.group_cols, a.Gm, a.r, a.z, a.cg_part, ctl);
     hipLaunchKernelGGL(k_cg_p_update, dim3(nb), dim3(256), 0, st, n, it == 1 ? 1 : 0, a.z, a.p, a.q, a.cg_part, nb, a.cgs, ctl);
     // q = S p (partial over this rank's points)
-    hipLaunchKernelGGL(k_ublk_matvec, dim3(nblk((int64_t)n_img * DC)), dim3(256), 0, st, d, a.Ublk, a.p, a.q, ctl);
+    if (!a.det) hipLaunchKernelGGL(k_ublk_matvec, dim3(nblk((int64_t)n_img * DC)), dim3(256), 0, st, d, a.Ublk, a.p, a.q, ctl);
     launch_by_g(DC, [&](auto G) {
       constexpr int GG = decltype(G)::value;
       hipLaunchKernelGGL(k_pt_u<GG>, dim3(nblk(n_pts * GG)), dim3(256), 0, st, d, a.pt_ptr, a.part_obs, a.obs_cols, a.W, a.T, a.p,
@@ -462,8 +549,12 @@ int pcg_solve(PcgArgs& a, double inv_radius, const pxr_lm_options* opt, const st
     });
     if (a.n_chunks > 0)
       launch_by_g(DC, [&](auto G) {
-        hipLaunchKernelGGL(k_img_wu<decltype(G)::value>, dim3((unsigned)a.n_chunks), dim3(256), 0, st, d, a.chunks, a.so, a.W, a.u, -1.0, a.q, ctl);
+        hipLaunchKernelGGL(k_img_wu<decltype(G)::value>, dim3((unsigned)a.n_chunks), dim3(256), 0, st, d, a.chunks, a.so, a.W, a.u, -1.0, a.q, ctl,
+                           a.det ? a.wpart : (double*)nullptr);
       });
+    if (a.det)          // U p and the chunks' parts of -W u, column by column in a fixed order
+      hipLaunchKernelGGL(k_col_finish<true>, col_grid, dim3(256), 0, st, d, a.col_ent_ptr, a.col_ent, a.chunk_ptr, (const double*)a.wpart, -1.0,
+                         a.Ublk, (const double*)a.p, a.q, (const double*)ctl);
     RC(hip_check(hipGetLastError(), "pcg matvec kernels"));
     RC(ar(a.q, n));                   // (past the stop: every rank reduces the same stale vector -- the ranks stay in step)
     hipLaunchKernelGGL(k_cg_q_finish, dim3(nb), dim3(256), 0, st, n, a.damp_c, inv_radius, a.p, a.q, a.cg_part, ctl);
@@ -497,6 +588,48 @@ __global__ __launch_bounds__(256) void k_diag_from_blocks(const SolveDev d, cons
   if (a >= d.pose_dim[img] + d.intr_dim[cam]) return;
   const double v = Ublk[((size_t)img * d.DC + a) * d.DC + a];
   if (v != 0.0) atomicAdd(diag + col_index(d, img, cam, a), v);
+}
+
+// deterministic linearisation of the block form (see pxr_ba_pcg.h)
+__global__ __launch_bounds__(256) void k_img_finish(const SolveDev d, const int* __restrict__ kchunk_ptr, const double* __restrict__ kpart,
+                                                    int ne_max, double* __restrict__ Ublk, double* __restrict__ gimg) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int img = (int)(t / ne_max), e = (int)(t - (int64_t)img * ne_max);
+  if (img >= d.v.n_images) return;
+  const int dc = d.pose_dim[img] + d.intr_dim[d.v.d_image_camera[img]];
+  const int NP = dc * (dc + 1) / 2;
+  if (e >= NP + dc) return;
+  double v = 0.0;
+  for (int k = kchunk_ptr[img]; k < kchunk_ptr[img + 1]; ++k) v += kpart[(size_t)k * ne_max + e];
+  if (e >= NP) { gimg[(size_t)img * d.DC + (e - NP)] = v; return; }
+  int a = 0, rem = e;                                      // k_img's numbering of the upper triangle
+  while (rem >= dc - a) { rem -= dc - a; ++a; }
+  const int b = a + rem;
+  double* Ub = Ublk + (size_t)img * d.DC * d.DC;
+  Ub[a * d.DC + b] = v;
+  Ub[b * d.DC + a] = v;
+}
+// one wavefront per column: g_c and diag(U) as the ordered sums over the column's entries
+__global__ __launch_bounds__(256) void k_col_gather(const SolveDev d, const int* __restrict__ col_ent_ptr, const int2* __restrict__ col_ent,
+                                                    const double* __restrict__ gimg, const double* __restrict__ Ublk,
+                                                    double* __restrict__ gc, double* __restrict__ diag) {
+  const int c = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (c >= d.n_c) return;
+  double g = 0.0, u = 0.0;
+  for (int e = col_ent_ptr[c] + lane; e < col_ent_ptr[c + 1]; e += 64) {
+    const int2 en = col_ent[e];
+    g += gimg[(size_t)en.x * d.DC + en.y];
+    u += Ublk[((size_t)en.x * d.DC + en.y) * d.DC + en.y];
+  }
+  g = wave_sum(g); u = wave_sum(u);
+  if (lane == 0) { gc[c] = g; diag[c] = u; }
+}
+
+int pcg_blocks_from_partials(hipStream_t st, const SolveDev& d, const int* kchunk_ptr, const double* kpart, int ne_max, double* Ublk,
+                             double* gimg, const int* col_ent_ptr, const int2* col_ent, double* diag, double* gc) {
+  hipLaunchKernelGGL(k_img_finish, dim3(nblk((int64_t)d.v.n_images * ne_max)), dim3(256), 0, st, d, kchunk_ptr, kpart, ne_max, Ublk, gimg);
+  hipLaunchKernelGGL(k_col_gather, dim3(nblk((int64_t)d.n_c * 64)), dim3(256), 0, st, d, col_ent_ptr, col_ent, (const double*)gimg, (const double*)Ublk, gc, diag);
+  return hip_check(hipGetLastError(), "deterministic block linearisation");
 }
 
 int pcg_diag_from_blocks(hipStream_t st, const SolveDev& d, const double* Ublk, double* diag) {

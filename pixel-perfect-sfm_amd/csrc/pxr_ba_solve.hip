@@ -199,7 +199,9 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
                                              const int64_t* __restrict__ img_obs,
                                              const double* __restrict__ L, double* __restrict__ U,
                                              double* __restrict__ gc, int block_form, double det_scale,
-                                             double* __restrict__ chunk_trace) {
+                                             double* __restrict__ chunk_trace, double* __restrict__ kpart, int ne_max) {
+  // kpart (deterministic mode of the iterative solver): the chunk's NE sums go to kpart[chunk][ne_max] instead of into U and g_c by
+  // atomics; pcg_blocks_from_partials adds them per image and per column in a fixed order
   // block_form = 0: U is the dense n_c x n_c matrix (upper triangle), direct solver;
   // block_form = 1: U is [n_images][DC][DC], the image's full symmetric dc x dc block (iterative solver)
   extern __shared__ double stage[];            // [IMG_BATCH][LS] records, then [256] reduction slots
@@ -299,7 +301,9 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
       chunk_trace[blockIdx.x] = tr;
     }
   }
-  if (sl == 0) {
+  if (sl == 0 && kpart) {
+    kpart[(size_t)blockIdx.x * ne_max + e] = acc;
+  } else if (sl == 0) {
     const int ra = col_index(d, img, cam, a);
     // (det_scale != 0: deterministic mode, order-independent fixed-point accumulation -- pxr_device.h)
     const double v = fixed ? __longlong_as_double(qacc) : acc;
@@ -1227,6 +1231,38 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     RC(pcg_g.alloc(group_size.size() * PCG_GS * PCG_GS)); RC(pcg_vec.alloc(5 * nc1));
     RC(pcg_scal.alloc(16 + 8 * ((nc1 + 255) / 256)));   // 8 scalars + the loop's control block + the dot-product partials
   }
+  // deterministic mode of the iterative solver: where an image's chunks start (both chunkings), the (image, local column) entries of
+  // every reduced-system column in ascending image order, and the buffers of the chunks' partial sums
+  DevBuf<int> d_kchunk_ptr, d_schunk_ptr, d_col_ent_ptr;
+  DevBuf<int2> d_col_ent;
+  DevBuf<double> det_kpart, det_gimg, det_wpart, det_mpart;
+  const int det_ne_max = DC * (DC + 1) / 2 + DC;
+  if (ctx->deterministic && iterative) {
+    auto first_chunks = [&](const std::vector<ImgChunk>& cs) {
+      std::vector<int> ptr(n_img + 1, 0);
+      for (const ImgChunk& c : cs) ++ptr[c.img + 1];
+      for (int i = 0; i < n_img; ++i) ptr[i + 1] += ptr[i];
+      return ptr;
+    };
+    const std::vector<int> kptr = first_chunks(chunks), sptr = first_chunks(schur_chunks);       // (alive until the synchronisation below)
+    RC(d_kchunk_ptr.upload(kptr, st)); RC(d_schunk_ptr.upload(sptr, st));
+    std::vector<int> ent_ptr(n_c + 1, 0);
+    auto col_of = [&](int i, int a) { return a < pose_dim[i] ? pose_off[i] + a : intr_off[image_camera[i]] + (a - pose_dim[i]); };
+    for (int i = 0; i < n_img; ++i)
+      for (int a = 0; a < pose_dim[i] + intr_dim[image_camera[i]]; ++a) ++ent_ptr[col_of(i, a) + 1];
+    for (int c = 0; c < n_c; ++c) ent_ptr[c + 1] += ent_ptr[c];
+    std::vector<int2> ent(ent_ptr[n_c]);
+    std::vector<int> fill(ent_ptr.begin(), ent_ptr.end() - 1);
+    for (int i = 0; i < n_img; ++i)                                          // images ascending: the order of every column's sum
+      for (int a = 0; a < pose_dim[i] + intr_dim[image_camera[i]]; ++a) ent[fill[col_of(i, a)]++] = make_int2(i, a);
+    RC(d_col_ent_ptr.upload(ent_ptr, st)); RC(d_col_ent.upload(ent, st));
+    RC(det_kpart.alloc(std::max<size_t>(1, chunks.size()) * det_ne_max)); RC(det_gimg.alloc((size_t)n_img * DC));
+    RC(det_wpart.alloc(std::max<size_t>(1, schur_chunks.size()) * DC)); RC(det_mpart.alloc(std::max<size_t>(1, schur_chunks.size()) * DC * DC));
+    PXR_HIP(hipMemsetAsync(det_kpart.p, 0, sizeof(double) * det_kpart.n, st));
+    PXR_HIP(hipMemsetAsync(det_wpart.p, 0, sizeof(double) * det_wpart.n, st));
+    PXR_HIP(hipMemsetAsync(det_mpart.p, 0, sizeof(double) * det_mpart.n, st));
+    PXR_HIP(hipStreamSynchronize(st));        // (the host vectors above leave scope)
+  }
   double* diagU = gcd.p; double* gc = gcd.p + nc1;
   DevBuf<int> info_buf;
   RC(info_buf.alloc(1));
@@ -1282,8 +1318,14 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   //    halves), replicated quantities are computed identically by every rank and need no broadcast.
   // (The grids need the Jacobi scaling of the options -- Ceres' and pixsfm's default: without it the large columns of the
   //  unscaled Jacobian, rotations ~1e6, set a grid that drowns the small ones, focal length ~1e-2.  A solve that turns the
-  //  scaling off, and the iterative solver, use floating-point atomics.)
-  const bool det = ctx->deterministic && !iterative && opt->jacobi_scaling != 0;
+  //  scaling off uses floating-point atomics; the iterative solver has its own form of the mode, det_iter below.)
+  const bool det_fixed = ctx->deterministic && !iterative && opt->jacobi_scaling != 0;     // fixed-point matrices (direct solver)
+  // The iterative solver (> 1000 images) in deterministic mode: ORDERED PARTIAL SUMS instead of fixed point -- every chunk of an
+  // image leaves its part in a buffer and the parts are added per image / per column in a fixed order (k_img's kpart, pxr_ba_pcg.hip);
+  // the conjugate-gradient vectors span too many orders of magnitude for one grid.  Same bits on every run for a given number of
+  // ranks (the ranks' parts are all-reduced as doubles: the result depends on how the points are dealt to ranks, not on the run).
+  const bool det_iter = ctx->deterministic && iterative;
+  const bool det = det_fixed || det_iter;             // scalars as integer limbs, no rank-0 broadcasts
   const bool bcast = multi && ctx->nranks > 1 && !det;
   auto from_rank0 = [&](double* buf, int64_t count) -> int {
     if (!bcast) return PXR_OK;
@@ -1392,7 +1434,14 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     PXR_HIP(hipMemsetAsync(gcd.p, 0, sizeof(double) * gcd.n, st));
     if (n_c > 0 && !chunks.empty()) {
       hipLaunchKernelGGL(k_img, dim3((unsigned)chunks.size()), dim3(256), sizeof(double) * ((size_t)IMG_BATCH * LS + 256), st, dv,
-                         d_chunks.p, d_img_obs.p, L.p, U.p, gc, iterative ? 1 : 0, lin_scale, lin_scale != 0.0 ? chunk_trace.p : (double*)nullptr);
+                         d_chunks.p, d_img_obs.p, L.p, U.p, gc, iterative ? 1 : 0, lin_scale, lin_scale != 0.0 ? chunk_trace.p : (double*)nullptr,
+                         det_iter ? det_kpart.p : (double*)nullptr, det_ne_max);
+      if (det_iter) {      // U blocks, diag(U) and g_c as ordered sums of the chunks' parts
+        RC(pcg_blocks_from_partials(st, dv, d_kchunk_ptr.p, det_kpart.p, det_ne_max, U.p, det_gimg.p, d_col_ent_ptr.p, d_col_ent.p, diagU, gc));
+        LAUNCH_CHECK("linearize kernels");
+        RC(ar(gcd.p, 2 * (int64_t)nc1));
+        return PXR_OK;
+      }
       if (lin_scale != 0.0) {
         // the integers of diag(U) and g_c (+ the trace) are summed over the ranks, THEN everything becomes doubles again
         hipLaunchKernelGGL(k_diag_and_trace, dim3(1), dim3(1024), 0, st, n_c, (const double*)U.p, diagU, (const double*)chunk_trace.p, (int)chunks.size(),
@@ -1423,7 +1472,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   // linearise on a grid made for diag(U) <= 8 md_guess; repeat on a grid from the measured trace until the check passes
   // (synchronises: used for the first two linearisations of a solve and on the -- never yet observed -- failure path)
   auto linearize_checked = [&](const double* rec, double md_guess, double cost_now, bool refine = false) -> int {
-    if (!det) return linearize(rec);
+    if (!det_fixed) return linearize(rec);
     for (int attempt = 0; attempt < 8; ++attempt) {
       lin_md = md_guess;
       lin_scale = det_scale_for(lin_md, cost_now);
@@ -1460,6 +1509,11 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     pcg.u = pcg_u.p; pcg.Mloc = pcg_mloc.p; pcg.Gm = pcg_g.p;
     pcg.x = xsol.p; pcg.r = pcg_vec.p; pcg.p = pcg_vec.p + nc1; pcg.q = pcg_vec.p + 2 * nc1; pcg.z = pcg_vec.p + 3 * nc1;
     pcg.b = pcg_vec.p + 4 * nc1; pcg.cgs = pcg_scal.p; pcg.cg_part = pcg_scal.p + 16; pcg.d_fail = d_info;
+    pcg.det = det_iter;
+    if (det_iter) {
+      pcg.chunk_ptr = d_schunk_ptr.p; pcg.col_ent_ptr = d_col_ent_ptr.p; pcg.col_ent = d_col_ent.p;
+      pcg.wpart = det_wpart.p; pcg.mpart = det_mpart.p;
+    }
   }
   const std::function<int(double*, int64_t)> ar_fn = ar;
   // gradient_tolerance [upstream]: max-norm of the gradient in the unscaled variables, over ALL ranks
@@ -1612,7 +1666,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, xsol.p, gc, damp_c.p, inv_radius, delta_c.p, scal_rep, limb_arg);
       RC(from_rank0(delta_c.p, n_c));
     } else if (n_c > 0) {
-      const double schur_scale = det ? lin_scale : 0.0;    // the SAME grid as U's: re-quantising the finished U is exact
+      const double schur_scale = det_fixed ? lin_scale : 0.0;    // the SAME grid as U's: re-quantising the finished U is exact
       hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, n_c, U.p, (const double*)nullptr, 0.0, (const double*)nullptr, S.p, 1, schur_scale);
       if (use_lds_schur) {
 #define SCHUR_LAUNCH(GG)                                                                                              \
@@ -1675,7 +1729,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       int h_info = 0;
       PXR_HIP(hipMemcpyAsync(&h_info, d_info, sizeof(int), hipMemcpyDeviceToHost, st));
       RC(read_scal(hs));
-      if (det && !lin_fits(h_lin_stats, lin_md)) {
+      if (det_fixed && !lin_fits(h_lin_stats, lin_md)) {
         // the overflow guard: a slot of the linearisation this iteration was computed from did not fit its grid -- repeat the
         // linearisation on a grid from the measured trace and the iteration with it (state untouched: radius, damping, counts)
         RC(linearize_checked(rec_cur, std::max(h_lin_stats[3], 2.0 * lin_md), cost));
@@ -1732,7 +1786,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       std::swap(rec_cur, rec_cand);
       cost = cand_cost;
       cur_is_exact = false;
-      if (det) { lin_md = std::max(h_lin_stats[0], 1e-300); lin_scale = det_scale_for(lin_md, cost); }   // checked with the next iteration's scalars
+      if (det_fixed) { lin_md = std::max(h_lin_stats[0], 1e-300); lin_scale = det_scale_for(lin_md, cost); }   // checked with the next iteration's scalars
       RC(linearize(rec_cur));
       phase(6);
       ++sum->num_successful;

@@ -87,6 +87,48 @@ def test_ba_direct_solver_is_bit_reproducible(fast_ctx, det_ctx, inner, loss):
         assert np.abs(a - b).max() < 1e-6 * max(1.0, np.abs(b).max())
 
 
+@pytest.mark.parametrize("shared_camera,inner", [(False, False), (True, False), (True, True)])
+def test_ba_iterative_solver_is_bit_reproducible(fast_ctx, det_ctx, shared_camera, inner):
+    """The iterative Schur solver (> 1000 images in the reference, bundle_optimizer.h:180-191) in deterministic mode: ordered
+    partial sums instead of floating-point atomics (csrc/pxr_ba_pcg.hip) -- one camera per image (one entry per column) and ONE
+    camera shared by all images (every intrinsics column collects a part from every image); several k_img / Schur chunks per image."""
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg, lm_options, make_loss
+    n_img, n_pts = 6, 1800                              # 1500 observations per image: two 1024-chunks, three 512-chunks
+    prob = synthetic.make_ba_problem(n_cams=n_img, n_points=n_pts, obs_per_point=5, seed=23, rot_deg=0.3, pt_sigma=0.02,
+                                     shared_camera=shared_camera, patch_size=8, channels=64)
+    gauge = _gauge(prob)
+    opts = dict(max_iterations=6, use_inner_iterations=inner, linear_solver="iterative", eta=1e-3, max_linear_solver_iterations=200)
+
+    def run(c):
+        arena = PatchArena.from_numpy(c, prob["patches"], prob["corners"], prob["scales"])
+        ba = BAProblem(c, arena, prob)
+        s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *gauge, options=lm_options(**opts))
+        out = (s, ba.params())
+        arena.close()
+        return out
+    runs = [run(det_ctx) for _ in range(3)]
+    s0, p0 = runs[0]
+    assert s0["linear_solver"] == 2 and s0["linear_iterations"] > 0 and s0["final_cost"] < s0["initial_cost"]
+    for s, p in runs[1:]:
+        assert s["iterations"] == s0["iterations"] and s["num_successful"] == s0["num_successful"]
+        assert s["linear_iterations"] == s0["linear_iterations"]
+        assert s["initial_cost"] == s0["initial_cost"] and s["final_cost"] == s0["final_cost"]          # the same BITS
+        for a, b in zip(p, p0):
+            assert np.array_equal(a, b)
+    # the same first step as with floating-point atomics (the later steps of this scene are 100-300-unit steps at radius 3e4 .. 9e4
+    # whose candidate costs move by 3e-5 .. 4e-4 between ANY two accumulation orders, direct solver included; what the ordered sums
+    # compute is checked against the direct solver in tests/test_ba_pcg_gpu.py, which runs in this mode) -- with the conjugate
+    # gradients driven to a tight residual: an inexact solve stops on Ceres' Q test, whose iteration count may hinge on the last bits
+    opts.update(max_iterations=1, eta=0.0, linear_r_tolerance=1e-13, max_linear_solver_iterations=2000)
+    s3, p3 = run(det_ctx)
+    sf, pf = run(fast_ctx)
+    assert sf["iterations"] == s3["iterations"] and sf["num_successful"] == s3["num_successful"]
+    assert abs(sf["final_cost"] - s3["final_cost"]) < 1e-7 * s3["initial_cost"]
+    for a, b in zip(pf, p3):        # (all but the odd run-away point -- a coordinate of 120 where the scene spans 1 -- whose position the cost hardly sees)
+        assert np.quantile(np.abs(a - b), 0.99) < 1e-6 * max(1.0, np.median(np.abs(b)))
+
+
 def test_ka_solver_is_bit_reproducible(fast_ctx, det_ctx):
     from pixsfm_amd import synthetic_ka
     from pixsfm_amd.engine import PatchArena, interp_cfg, lm_options, make_loss

@@ -64,8 +64,9 @@ class Context:
 
     @property
     def deterministic(self):
-        """Order-independent accumulation in pxr_ba_solve (direct solver) / pxr_ka_solve: bit-identical results from run to
-        run and on every rank (pxr_set_deterministic; PXR_DETERMINISTIC=1 sets it for every new context)."""
+        """Order-independent accumulation in pxr_ba_solve / pxr_ka_solve: bit-identical results from run to run (direct BA solver
+        and KA: for every number of ranks too).  ON by default since round 5 (pxr_set_deterministic; PXR_DETERMINISTIC=0 switches it
+        off for every new context)."""
         return bool(self.lib.pxr_get_deterministic(self.handle))
 
     @deterministic.setter
@@ -75,8 +76,9 @@ class Context:
     @property
     def gram_cache(self):
         """pxr_ba_solve evaluates the residual blocks' records from cached Gram matrices of the 4 x 4 stencils instead of from
-        the texels (pxr_set_gram_cache; PXR_GRAM_CACHE=1 sets it for every new context): ~3x less HBM traffic per LM
-        iteration, records differ from pxr_ba_eval's by the rounding of the reference's fp32 horizontal pass."""
+        the texels: ~3x less HBM traffic per LM iteration, records differ from pxr_ba_eval's by the rounding of the reference's
+        fp32 horizontal pass.  ON by default since round 5 (pxr_set_gram_cache; PXR_GRAM_CACHE=0 switches it off for every new
+        context)."""
         return bool(self.lib.pxr_get_gram_cache(self.handle))
 
     @gram_cache.setter

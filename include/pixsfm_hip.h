@@ -55,7 +55,9 @@ typedef struct pxr_arena pxr_arena;
  * Only mode = BICUBIC with one node is on the hot path; other modes are rejected. */
 typedef struct {
   int32_t l2_normalize;   /* default 1 */
-  int32_t use_float_simd; /* default 0: fp32 horizontal pass, fp64 vertical pass */
+  int32_t use_float_simd; /* default 0: fp32 horizontal pass, fp64 vertical pass.  1: all splines in fp32 (interpolation.h:177-218 with
+                           * the float instantiation); pxr_ba_solve then evaluates from the texels in that arithmetic -- the
+                           * Gram-matrix cache (exact fp64 algebra) is not used for such a solve */
   int32_t check_bounds;   /* default 0.  1: PatchInterpolator::Evaluate reports whether 0 < u < W, 0 < v < H
                            * (patch_interpolator.h:125-135,160-166).  Like in the reference this FAILS an evaluation
                            * only where the functor passes it on: the BA functor WITHOUT a reference descriptor, i.e.

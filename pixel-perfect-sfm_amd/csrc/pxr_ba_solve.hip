@@ -1392,13 +1392,15 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   // pxr_set_gram_cache: the records from cached Gram matrices of the stencils instead of from the texels (pxr_ba_gram.hip)
   // (default on since round 5: pinned against the reference functor's vectors at 1e-5, tests/test_gram_cache_gpu.py.  check_bounds
   //  needs no care: with reference descriptors the functor ignores the bounds check, feature_reference.h:128-136.)
-  const bool gram_cache = ctx->gram_cache && gram_eval_supported(arena, view);
+  // (InterpolationConfig.use_float_simd asks for the reference's ALL-fp32 splines: the Gram-matrix paths -- exact fp64 algebra -- would
+  // silently compute something finer; a solve with that flag keeps the texel kernels, which have the fp32 arithmetic bit for bit)
+  const bool gram_cache = ctx->gram_cache && gram_eval_supported(arena, view) && cfg->use_float_simd == 0;
   // The Gram-matrix kernel of the inner iterations keeps its matrices in the same cache from call to call (it writes back what
   // it builds), whether or not the LM loop evaluates from them: the same numbers as without a cache, fewer builds.  (That kernel
   // is built without the six extended camera models -- their forward-mode duals cost ~100 registers: a problem that uses one
   // keeps the packed kernel for every point.)
   bool gram_inner = opt->use_inner_iterations != 0 && arena->dtype != PXR_F64 && (arena->C == 128 || arena->C == 64) && !getenv("PXR_INNER_OLD") &&
-                    !getenv("PXR_INNER_PACKED");
+                    !getenv("PXR_INNER_PACKED") && cfg->use_float_simd == 0;
   for (int c = 0; c < n_cam; ++c) gram_inner = gram_inner && cam_model[c] <= PXR_OPENCV;
   bool inner_cache = gram_inner && gram_eval_supported(arena, view) && !getenv("PXR_INNER_NO_CACHE");
   GramCache gram;

@@ -112,6 +112,30 @@ def test_solve_with_the_cache_is_the_solve_without(ctx, inner):
     c2.close()
 
 
+@pytest.mark.parametrize("inner", [False, True])
+def test_use_float_simd_keeps_the_texel_kernels(ctx, inner):
+    """InterpolationConfig.use_float_simd asks for the reference's all-fp32 splines (interpolation.h:177-218, float instantiation).  The
+    Gram-matrix paths are exact fp64 algebra: a solve with that flag must not take them -- with the cache flag on and
+    off it is the same solve to the last bit (deterministic mode)."""
+    from pixsfm_amd.engine import Context, interp_cfg, lm_options, make_loss
+    c2 = Context(0)
+    c2.gram_cache = False
+    assert ctx.gram_cache and ctx.deterministic and c2.deterministic
+    out = []
+    for c in (c2, ctx):
+        prob, arena, ba = _problem(c, n_cams=12, n_points=900)
+        s = ba.solve(interp_cfg(use_float_simd=True), make_loss("cauchy", [0.25]), *_gauge(prob),
+                     options=lm_options(max_iterations=8, use_inner_iterations=inner))
+        out.append((s, ba.params()))
+        arena.close()
+    (s0, p0), (s1, p1) = out
+    assert s0["num_successful"] > 2 and s0["iterations"] == s1["iterations"] and s0["num_successful"] == s1["num_successful"]
+    assert s0["initial_cost"] == s1["initial_cost"] and s0["final_cost"] == s1["final_cost"]
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b)
+    c2.close()
+
+
 def test_the_inner_iterations_cache_does_not_change_a_bit(monkeypatch):
     """Default mode: the matrices of the inner iterations' Gram-matrix kernel live in the solve's cache: what a call would rebuild
     is rebuilt ahead of it (k_gram_flag_slots + k_gram_build), the kernel copies, and writes back what it rebuilds during its

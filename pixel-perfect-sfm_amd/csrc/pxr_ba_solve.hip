@@ -1405,7 +1405,10 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   bool inner_cache = gram_inner && gram_eval_supported(arena, view) && !getenv("PXR_INNER_NO_CACHE");
   GramCache gram;
   if (gram_cache) RC(gram_eval_prepare(ctx, arena, view, &gram));
-  else if (inner_cache && gram_eval_prepare(ctx, arena, view, &gram) != PXR_OK) inner_cache = false;   // (no memory for it: the kernel builds at every call)
+  else if (inner_cache && gram_eval_prepare(ctx, arena, view, &gram) != PXR_OK) {
+    inner_cache = false;            // no memory for it: the kernel builds at every call -- not an error of this solve,
+    (void)set_error(PXR_OK, "");    // so pxr_last_error() must not keep the allocation's message
+  }
   bool gram_warm = false;               // the cache holds every observation's matrices (after the first evaluation / inner call)
   int n_evaluations = 0;
   // The initial point is evaluated by the exact-order kernel (below), candidates from the cache: until a step is accepted the

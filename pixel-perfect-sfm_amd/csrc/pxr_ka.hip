@@ -654,27 +654,14 @@ __device__ KA_STREAM_INLINE double ka_probe_stream(const KaStreamCall sc, double
   for (int k = 0; k < NSTEP; ++k) {
     HT h[4][8], hd[4][8];
     double f[8], fr[8], fc[8];
-#ifdef PXR_KA_STREAM_PROBE_NO_INTERP
-    { float p0[8]; tx[0][0].unpack(p0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) { float t8[8]; tx[j][ch & 3].unpack(t8); h[j][ch] = t8[ch] + p0[ch]; hd[j][ch] = 0; } }
-#else
     interp8_horizontal<ST, false, FS>(tx, si.dx, h, hd);
-#endif
     ldouble2 cfk[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) cfk[q] = cf[q];
     // step k + 1 is requested as soon as the horizontal pass has consumed step k's texels: in flight behind the vertical pass,
     // the LDS exchange and its barriers (two steps' texels in registers cost the kernel 130 more spilled registers)
     if (k + 1 < NSTEP) KA_STREAM_REQUEST(k + 1);
-#ifdef PXR_KA_STREAM_PROBE_NO_INTERP     // timing probes (wrong results): what the interpolation arithmetic / the exchange cost
-#pragma unroll
-    for (int ch = 0; ch < 8; ++ch) { f[ch] = (double)h[0][ch]; fr[ch] = fc[ch] = 0.0; }
-#else
     interp8_vertical<HT, false, FS>(h, hd, si.dy, f, fr, fc);
-#endif
     if (!moving) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) { f[2 * q] = cfk[q].x; f[2 * q + 1] = cfk[q].y; }
@@ -691,7 +678,6 @@ __device__ KA_STREAM_INLINE double ka_probe_stream(const KaStreamCall sc, double
       for (int q = 0; q < 4; ++q) { ldouble2 w2; w2.x = f[2 * q]; w2.y = f[2 * q + 1]; row[q] = w2; }
     }
     ka_lds_barrier();
-#ifndef PXR_KA_STREAM_PROBE_NO_EDGES
     if (e0 < ne) {
       const KA_LDS ldouble2* ra = (const KA_LDS ldouble2*)(buf + sa0 * KA_SROW);
       const KA_LDS ldouble2* rb = (const KA_LDS ldouble2*)(buf + sb0 * KA_SROW);
@@ -708,7 +694,6 @@ __device__ KA_STREAM_INLINE double ka_probe_stream(const KaStreamCall sc, double
       for (int q = 0; q < KA_SCH / 2; ++q) { const ldouble2 x = ra[q], y = rb[q]; d0 = fma(x.x, y.x, d0); d1 = fma(x.y, y.y, d1); }
       dot1 += d0 + d1;
     }
-#endif
     ka_lds_barrier();
   }
 #undef KA_STREAM_REQUEST

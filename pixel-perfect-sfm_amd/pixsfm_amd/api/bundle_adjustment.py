@@ -399,7 +399,9 @@ class _FlatBA:
         self._key_image = np.asarray(img_ids, dtype=np.int64)[r["obs_image"]] if len(img_ids) else np.zeros(0, np.int64)
         self._key_p2d = r["obs_p2d"]                 # obs_keys (a list of 1M tuples at configs[2]) is built only when somebody asks
         self._obs_keys = None
-        self.patches = scene.patches_of(r["obs_image"], r["obs_p2d"])
+        # the patch OBJECT of every observation is looked up only when somebody asks (`patches`): with stacked feature maps uploaded
+        # by SharedArena.prefetch the arena slots follow from the stacks' layout (arena_index) and no object is touched
+        self._scene, self._scene_obs_image, self._patches = scene, r["obs_image"], None
         n_i, n_c, n_p = len(used_img), len(used_cam), len(used_pt)
         self.image_camera = cam_new[image_camera[used_img]]
         self.qvec = np.array([rec.images[i].qvec for i in self.image_ids], np.float64).reshape(n_i, 4)
@@ -413,6 +415,28 @@ class _FlatBA:
         self.tvec_mask = r["tvec_mask"][used_img].astype(np.uint8)
         self.cam_mask = r["camera_mask"][used_cam].astype(np.uint16)
         self.point_const = r["point_role"][used_pt].astype(np.uint8)
+
+    @property
+    def patches(self):
+        """The FeaturePatch / ArenaPatch of every residual block (one dict lookup per observation, in C++ where the host binding is built)."""
+        if self._patches is None:
+            self._patches = self._scene.patches_of(self._scene_obs_image, self._key_p2d)
+        return self._patches
+
+    def first_patch(self):
+        if self._patches is not None:
+            return self._patches[0]
+        return self._scene.patches_of(self._scene_obs_image[:1], self._key_p2d[:1])[0]
+
+    def arena_index(self, cache):
+        """Arena slot of every residual block from the layout of a prefetched features.SharedArena, or None (-> features.to_arena on
+        the patch objects)."""
+        if cache is None or not hasattr(cache, "slots"):
+            return None
+        sc = self._scene
+        if getattr(sc, "_image_names", None) is None:
+            sc._image_names = [sc.reconstruction.images[i].name for i in sc.img_ids]
+        return cache.slots(sc._image_names, self._scene_obs_image, self._key_p2d)
 
     @property
     def obs_keys(self):
@@ -471,7 +495,7 @@ class ReferenceExtractor:
         if len(part.obs_image):
             from ._timing import phase
             with phase("upload"):
-                arena = features.to_arena(ctx, part.patches, cache=arena_cache)
+                arena = _arena_of(ctx, part, arena_cache)
             with phase("references"):
                 ba = BAProblem(ctx, arena, part.problem_dict(np.zeros((len(part.point_ids), arena.C)), arena.index))
                 out = self._references_of(ba, part)
@@ -626,6 +650,15 @@ def _rank_share(flat, rank, world):
     return sub
 
 
+def _arena_of(ctx, part, cache):
+    """The device arena + slot index of the residual blocks of `part` (a _FlatBA or _PointSubset): straight from the layout of a
+    prefetched features.SharedArena where there is one, else through the patch objects (features.to_arena)."""
+    idx = part.arena_index(cache)
+    if idx is not None:
+        return features.ArenaRef(cache.arena, idx, owned=False)
+    return features.to_arena(ctx, part.patches, cache=cache)
+
+
 class _PointSubset:
     """The observations `obs` (indices into a _FlatBA) of the points `pts` as a flat problem of their own: images and
     cameras stay those of the parent, points and observations are renumbered."""
@@ -637,8 +670,19 @@ class _PointSubset:
         self.obs_keys = [flat.obs_keys[i] for i in obs]
         self.obs_image = flat.obs_image[self.obs]
         self.obs_point = np.array([local[int(flat.obs_point[i])] for i in obs], np.int32)
-        self.patches = [flat.patches[i] for i in obs]
+        self._patches = None
         self.xyz = flat.xyz[np.asarray(pts, dtype=np.int64)]
+
+    @property
+    def patches(self):
+        if self._patches is None:
+            fp = self.flat.patches
+            self._patches = [fp[i] for i in self.obs.tolist()]
+        return self._patches
+
+    def arena_index(self, cache):
+        idx = self.flat.arena_index(cache)
+        return None if idx is None else idx[self.obs]
 
     def key_arrays(self, obs):
         return self.flat.key_arrays(self.obs[np.asarray(obs, dtype=np.int64)])
@@ -688,7 +732,7 @@ class FeatureReferenceBundleOptimizer:
         self._flat, self._ba, self._arena = flat, None, None
         if len(flat.obs_image) == 0:
             return
-        C = flat.patches[0].shape[2]
+        C = flat.first_patch().shape[2]
         refs = None                                                              # cost maps: "just minimize"
         if isinstance(references, features.ReferenceMap):
             refs = references.descriptor_matrix(flat.point_ids)                  # references.at(point3D_id), all rows at once
@@ -704,14 +748,14 @@ class FeatureReferenceBundleOptimizer:
             self._share_lo = self._share.lo
             if len(self._share.obs_image) == 0:
                 raise ValueError("rank %d received no observations: fewer points than ranks" % rank)
-            self._arena = features.to_arena(ctx, self._share.patches, cache=getattr(self, "arena_cache", None))
+            self._arena = _arena_of(ctx, self._share, getattr(self, "arena_cache", None))
             lo, n_loc = self._share_lo, len(self._share.point_ids)
             self._ba = BAProblem(ctx, self._arena, self._share.problem_dict(None if refs is None else refs[lo:lo + n_loc],
                                                                            self._arena.index))
             return
         from ._timing import phase
         with phase("upload"):
-            self._arena = features.to_arena(ctx, flat.patches, cache=getattr(self, "arena_cache", None))
+            self._arena = _arena_of(ctx, flat, getattr(self, "arena_cache", None))
         with phase("problem_to_device"):
             self._ba = BAProblem(ctx, self._arena, flat.problem_dict(refs, self._arena.index))
 

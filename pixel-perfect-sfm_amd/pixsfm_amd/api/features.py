@@ -163,7 +163,7 @@ class FeatureMap:
             scale = np.asarray(metadata["scale"], dtype=np.float64).reshape(2)
             self.patches = {(int(point2D_ids[i]) if self.is_sparse else kDenseId): FeaturePatch(patches[i], corners[i], scale)
                             for i in range(len(patches))}
-            self._remember_stack(patches, corners, scale)
+            self._remember_stack(patches, corners, scale, point2D_ids if self.is_sparse else None)
             return
         self.patches = dict(patches or {})
         self.is_sparse = is_sparse
@@ -205,7 +205,7 @@ class FeatureMap:
         def setdefault(self, *a):
             self._dirty(); return dict.setdefault(self, *a)
 
-    def _remember_stack(self, patches, corners, scale):
+    def _remember_stack(self, patches, corners, scale, ids=None):
         """The patches of this map are views of ONE N x H x W x C array (the reference's numpy constructor, featuremap.cc:8-45):
         remembered, so that an upload can take the N patches from the array's address and stride without touching the N
         FeaturePatch objects (SharedArena.prefetch).  Dropped as soon as the dict no longer mirrors the array."""
@@ -215,7 +215,8 @@ class FeatureMap:
             views.owner = weakref.ref(self)
             self.patches = views
             self._stack = (patches, np.ascontiguousarray(corners, dtype=np.int32).reshape(len(patches), 2),
-                           np.asarray(scale, dtype=np.float64).reshape(2))
+                           np.asarray(scale, dtype=np.float64).reshape(2),
+                           None if ids is None else np.asarray(ids, dtype=np.int64).reshape(len(patches)))   # keypoint id of every row
 
     def stacked(self):
         """(array, corners, scale) when the dict still holds exactly the views of the array it was built from, else None."""
@@ -233,7 +234,7 @@ class FeatureMap:
         constructor (features/src/featuremap.cc:25-61): N x H x W x C patches."""
         scale = np.broadcast_to(np.asarray(scale, dtype=np.float64), (2,))
         fm = cls({int(k): FeaturePatch(p, c, scale) for k, p, c in zip(keypoint_ids, patches, corners)})
-        fm._remember_stack(patches, corners, scale)
+        fm._remember_stack(patches, corners, scale, keypoint_ids)
         return fm
 
     @classmethod
@@ -533,6 +534,7 @@ class SharedArena:
     def __init__(self):
         self.arena, self.slot, self.uniq = None, {}, None     # slot: id(patch) -> arena slot (built on demand); uniq: the patches by slot
         self._thread, self._error = None, None
+        self.layout, self._lut = None, None      # prefetched stacks: {image name: (first slot, keypoint id of every row)}; its lookup table
 
     def __enter__(self):
         return self
@@ -553,7 +555,7 @@ class SharedArena:
         from ..engine import PatchArena
         if _host_module() is None or self.arena is not None or self._thread is not None:
             return False
-        stacks, uniq = [], []
+        stacks, uniq, layout, base = [], [], {}, 0
         for name in image_names:
             if not feature_set.has_fmap(name):
                 continue
@@ -563,6 +565,9 @@ class SharedArena:
                 return False
             stacks.append(st)
             uniq.extend(fm.patches.values())         # dict order = array order (insertion order of the constructor)
+            ids = st[3] if len(st) > 3 and st[3] is not None else np.fromiter(fm.patches.keys(), dtype=np.int64, count=len(fm.patches))
+            layout[name] = (base, ids)
+            base += len(st[0])
         if not stacks:
             return False
         shape, dtype = stacks[0][0].shape[1:], stacks[0][0].dtype
@@ -572,7 +577,7 @@ class SharedArena:
         pointers = np.concatenate([np.uint64(st[0].ctypes.data) + np.arange(len(st[0]), dtype=np.uint64) * np.uint64(pb) for st in stacks])
         corners = np.concatenate([st[1] for st in stacks])
         scales = np.concatenate([np.broadcast_to(st[2], (len(st[0]), 2)) for st in stacks])
-        self.uniq = uniq
+        self.uniq, self.layout, self._lut = uniq, layout, None
 
         def work():
             try:
@@ -582,6 +587,41 @@ class SharedArena:
         self._thread = threading.Thread(target=work, name="pxr-prefetch", daemon=True)
         self._thread.start()
         return True
+
+    def slots(self, image_names, obs_image, obs_p2d):
+        """Arena slot of every observation (image position `obs_image` into `image_names`, keypoint id `obs_p2d`) straight from the
+        prefetched stacks' layout -- first slot of the image's stack + the row of the keypoint -- with numpy only: no FeaturePatch
+        object is looked up or touched (scene.patches_of + slots_of read a million of them: 0.3 + 0.1 s at BASELINE configs[2]).
+        None when the arena does not come from a prefetch or does not hold every observation's patch (the caller then goes through
+        the patch objects)."""
+        self.wait()
+        if self.arena is None or not self.layout:
+            return None
+        if self._lut is None or self._lut[0] != tuple(image_names):
+            ptr, parts = np.zeros(len(image_names) + 1, np.int64), []
+            for k, name in enumerate(image_names):
+                ent = self.layout.get(name)
+                if ent is None or len(ent[1]) == 0:
+                    ptr[k + 1] = ptr[k]
+                    continue
+                base, ids = ent
+                if ids.min() < 0 or ids.max() > 8 * len(ids) + 65536:          # sparse ids: no table (the object path handles them)
+                    return None
+                lut = np.full(int(ids.max()) + 1, -1, np.int64)
+                lut[ids] = base + np.arange(len(ids), dtype=np.int64)
+                parts.append(lut)
+                ptr[k + 1] = ptr[k] + len(lut)
+            self._lut = (tuple(image_names), ptr, np.concatenate(parts) if parts else np.zeros(0, np.int64))
+        _, ptr, table = self._lut
+        oi, oj = np.asarray(obs_image, dtype=np.int64), np.asarray(obs_p2d, dtype=np.int64)
+        if len(oi) == 0 or len(table) == 0:
+            return None
+        size = ptr[oi + 1] - ptr[oi]
+        ok = (oj >= 0) & (oj < size)
+        if not ok.all():
+            return None
+        idx = table[ptr[oi] + oj]
+        return idx if (idx >= 0).all() else None
 
     def wait(self):
         """Join a running prefetch; its failure (e.g. out of device memory) leaves the cache empty and the caller uploads."""
@@ -594,13 +634,13 @@ class SharedArena:
                 if self._error is not None:
                     warnings.warn("pixsfm_amd: the background upload of the stacked feature maps failed (%r); "
                                   "uploading patch by patch instead" % (self._error,), RuntimeWarning, stacklevel=2)
-                self._error, self.arena, self.uniq = None, None, None
+                self._error, self.arena, self.uniq, self.layout, self._lut = None, None, None, None, None
 
     def close(self):
         self.wait()
         if self.arena is not None:
             self.arena.close()
-        self.arena, self.slot, self.uniq = None, {}, None
+        self.arena, self.slot, self.uniq, self.layout, self._lut = None, {}, None, None, None
 
 
 def to_arena(ctx, patch_list, cache=None):

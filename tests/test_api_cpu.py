@@ -569,3 +569,35 @@ def test_a_patch_replaced_in_place_drops_the_remembered_stack():
     fm = FeatureMap(arr, ids, corners, meta)          # reading does not drop it
     _ = fm.fpatch(9), fm.keys(), fm.num_fpatches(), fm.has_fpatch(7), dict(fm.patches)
     assert fm.stacked() is not None
+
+
+def test_shared_arena_slots_follow_the_stacks_layout():
+    """SharedArena.slots: arena slot of an observation = first slot of its image's stack + the row of its keypoint id, computed with
+    numpy from the layout the prefetch recorded -- the same answer as looking every FeaturePatch object up (to_arena / slots_of)."""
+    from pixsfm_amd.api.features import FeatureMap, SharedArena
+    rng = np.random.default_rng(5)
+    names, maps, layout, base = ["a.jpg", "b.jpg", "c.jpg"], {}, {}, 0
+    for name, n in zip(names, (5, 0, 7)):
+        ids = rng.permutation(n + 3)[:n].astype(np.int64)              # keypoint ids in STACK order (not sorted, with gaps)
+        if n:
+            fm = FeatureMap(np.zeros((n, 2, 2, 4), np.float16), ids, np.zeros((n, 2), np.int32), {"is_sparse": True, "scale": [1.0, 1.0]})
+            assert np.array_equal(fm.stacked()[3], ids)
+            maps[name] = fm
+            layout[name] = (base, ids)
+            base += n
+    sa = SharedArena()
+    assert sa.slots(names, [0], [0]) is None                            # no prefetched arena
+    sa.arena, sa.layout = object(), layout
+    oi = np.array([0, 2, 2, 0, 2], np.int32)
+    oj = np.array([layout["a.jpg"][1][3], layout["c.jpg"][1][0], layout["c.jpg"][1][6], layout["a.jpg"][1][0], layout["c.jpg"][1][2]])
+    got = sa.slots(names, oi, oj)
+    assert got.tolist() == [3, 5, 11, 0, 7]
+    # the same through the objects: position of the patch in the concatenation of the maps' dicts
+    order = [id(p) for n in names if n in maps for p in maps[n].patches.values()]
+    want = [order.index(id(maps[names[i]].patches[int(j)])) for i, j in zip(oi, oj)]
+    assert got.tolist() == want
+    missing = next(k for k in range(20) if k not in set(layout["a.jpg"][1].tolist()))
+    assert sa.slots(names, [0], [missing]) is None                      # a keypoint the stack does not hold
+    assert sa.slots(names, [1], [0]) is None                            # an image without patches
+    assert sa.slots(names, [0], [-1]) is None and sa.slots(names, [0], [10 ** 6]) is None
+    sa.arena = None

@@ -2,7 +2,7 @@
 # round 5, evidence call at the head of the round: full suite, KA timing,
 # LM loop timing, full bench, per-kernel statistics of the bench command, counter passes of the hot kernels
 set -u
-O=gpurun_out/r5s
+O=gpurun_out/r5u
 mkdir -p $O
 export TMPDIR=/tmp
 COMMIT=$(cat .commit_id 2>/dev/null || echo unknown)

@@ -224,12 +224,10 @@ def cpu_baseline(prob, patches, n_sample, lm_gauge=None):
     all their observations; every camera), each timed INSIDE C by the persistent-thread harness of
     oracle/pxo_bench_harness.h over {cores/4, cores/2, cores, 2 x cores} threads (best reported, with the single-thread
     rate, the scaling efficiency and the harness_limited guard):
-      cpu_baseline          kind "reference": the reference's own FeatureReferenceCostFunctor (compiled in place,
-                            oracle/_ref/libpxo_ref_bench.so) on dual numbers like ceres::AutoDiffCostFunction -- residual
-                            + 128 x (10+K) Jacobian per block, threaded over blocks like Ceres
-                            (bundle_adjustment_options.h:58); falls back to the port where oracle/_ref is absent;
-      cpu_baseline_port     kind "port": the oracle's C restatement (analytic Jacobians, materialised, + loss);
-      cpu_reference_kernel  the reference's AVX2/F16C BiCubicInterpolator::EvaluateSIMD alone;
+      cpu_baseline          kind "port": the oracle's C restatement (AVX2 / F16C spline, analytic 128 x (10+K) Jacobians
+                            materialised like ceres::AutoDiffCostFunction hands them over, + loss), threaded over blocks
+                            like Ceres (bundle_adjustment_options.h:58).  The reference's own C++ cannot be built in this
+                            image (no Eigen / Ceres / COLMAP), so there is no kind "reference" leg;
       cpu_baseline_lm_projected  one LM iteration of the oracle's Schur path (oracle/pxo_lm_bench.c, OpenMP), the
                             per-observation stages scaled to the full problem, the Cholesky not."""
     import numpy as np
@@ -254,31 +252,11 @@ def cpu_baseline(prob, patches, n_sample, lm_gauge=None):
     out = {"cpu_host": pxo_cpubench.host_probe()}
     port = pxo_cpubench.ba_eval_port(sub, cfg, ls)
     port["sample"] = what + "; oracle C restatement: analytic 128x(10+K) Jacobians materialised + Cauchy loss"
-    try:
-        ref = pxo_cpubench.ba_eval_reference(sub)
-    except Exception as e:  # noqa: BLE001 -- oracle/_ref is optional (built from /root/reference in the build container)
-        ref, port["reference_leg_error"] = None, repr(e)
-    if ref is not None:
-        ref["sample"] = what + ("; the reference's FeatureReferenceCostFunctor + PatchInterpolator + BiCubicInterpolator::"
-                                "EvaluateSIMD + WorldToPixel compiled in place (-O3 -mavx2 -mf16c -mfma) and evaluated on "
-                                "10+K-wide dual numbers like ceres::AutoDiffCostFunction (Jet / Eigen / COLMAP camera model "
-                                "are stand-ins, oracle/ref_stubs); loss + corrector not included")
-        out["cpu_baseline"], out["cpu_baseline_port"] = ref, port
-    else:
-        out["cpu_baseline"] = port
-    try:
-        kern = pxo_cpubench.bicubic_reference(sub)
-        if kern is not None:
-            kern["sample"] = ("%d fp16 16x16x128 patches, BiCubicInterpolator::EvaluateSIMD of the reference compiled in place; "
-                              "INTERPOLATION ONLY -- no projection, normalisation, Jacobian bridge or loss; touched working set "
-                              "%.0f MB" % (n_sample, n_sample * 4096 / 1e6))
-            out["cpu_reference_kernel"] = kern
-    except Exception as e:  # noqa: BLE001
-        out["cpu_reference_kernel"] = {"value": None, "kind": "reference-kernel", "sample": "unavailable: %r" % (e,)}
+    out["cpu_baseline"] = port
     # ---- one LM iteration on the host cores (OpenMP; the thread count that won the evaluation sweep) -----------------
     if lm_gauge is not None:
         pose_const, tmask, cmask = lm_gauge
-        threads = int(out["cpu_baseline_port"]["cores"] if "cpu_baseline_port" in out else out["cpu_baseline"]["cores"])
+        threads = int(out["cpu_baseline"]["cores"])
         best = None
         t0 = time.perf_counter()
         for _ in range(3):

@@ -4,14 +4,11 @@ Every leg is timed INSIDE C by the persistent-thread harness of pxo_bench_harnes
 thread-local first-touched copies of the sample, >= `min_seconds` of back-to-back passes between two barriers); this
 module only sweeps the thread count and reports.  Legs:
 
-  ba_eval_reference  kind "reference": the reference's own FeatureReferenceCostFunctor compiled in place
-                     (oracle/ref_bench_shim.cc -> _ref/libpxo_ref_bench.so), evaluated on dual numbers like
-                     ceres::AutoDiffCostFunction does -- residual + 128 x (10+K) Jacobian per residual block;
   ba_eval_port       kind "port": the oracle's C restatement with analytic Jacobians + loss (oracle/pxo_cpubench.c);
-  bicubic_reference  kind "reference-kernel": BiCubicInterpolator::EvaluateSIMD alone;
   ka_solve_port      kind "port": keypoint-adjustment sub-problems, one single-threaded solve per task, a pool of threads
-                     over the tasks (keypoint_adjustment/main.py:66-80);
-  ka_edge_reference  kind "reference": FeatureMetric2DCostFunctor on dual numbers, per residual block.
+                     over the tasks (keypoint_adjustment/main.py:66-80).
+There is no kind "reference" leg: the reference's C++ path is unbuildable in this image (rounds 1-5 timed a build
+of its functors over builder-written Eigen / Jet / COLMAP stand-ins and called it "reference" -- removed in round 6).
 """
 import ctypes as C
 import os
@@ -21,19 +18,6 @@ import numpy as np
 import pxo
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-_bench_ref = None
-
-
-def ref_bench_lib():
-    global _bench_ref
-    if _bench_ref is None:
-        path = os.path.join(HERE, "_ref", "libpxo_ref_bench.so")
-        if not os.path.exists(path):
-            return None
-        _bench_ref = C.CDLL(path)
-    return _bench_ref
-
-
 def cpu_topology():
     """(logical CPUs this process may run on, physical cores among them, NUMA nodes)."""
     try:
@@ -198,68 +182,6 @@ def ba_eval_port(sub, config, ls, min_seconds=0.25):
     return rep
 
 
-def _ba_ref_args(sub):
-    arena = np.ascontiguousarray(sub["patches"])
-    assert arena.dtype == np.float16 and arena.shape[3] == 128
-    keep = dict(arena=arena.view(np.uint16),
-                obs_patch=np.ascontiguousarray(sub["obs_patch"], np.int64), obs_image=np.ascontiguousarray(sub["obs_image"], np.int32),
-                obs_point=np.ascontiguousarray(sub["obs_point"], np.int32), corners=np.ascontiguousarray(sub["corners"], np.int32),
-                scales=np.ascontiguousarray(sub["scales"], np.float64), qvec=np.ascontiguousarray(sub["qvec"], np.float64),
-                tvec=np.ascontiguousarray(sub["tvec"], np.float64), xyz=np.ascontiguousarray(sub["xyz"], np.float64),
-                cam_params=np.ascontiguousarray(sub["cam_params"], np.float64),
-                image_camera=np.ascontiguousarray(sub["image_camera"], np.int32), refs=np.ascontiguousarray(sub["refs"], np.float64))
-    return keep
-
-
-def ba_eval_reference(sub, min_seconds=0.25):
-    """Residual blocks / s of the REFERENCE's functor under dual-number autodiff (SIMPLE_RADIAL, fp16, 128 channels);
-    None when oracle/_ref/libpxo_ref_bench.so is absent."""
-    lib = ref_bench_lib()
-    if lib is None:
-        return None
-    assert (np.asarray(sub["cam_model"]) == 2).all(), "the reference leg is instantiated for SIMPLE_RADIAL"
-    k = _ba_ref_args(sub)
-    H, W = k["arena"].shape[1], k["arena"].shape[2]
-    fn = lib.pxo_refbench_ba_residual
-    fn.restype = C.c_int
-
-    def run(n, threads, secs):
-        out = _out4()
-        rc = fn(C.c_int64(n), pxo._p(k["arena"]), H, W, pxo._p(k["obs_patch"]), pxo._p(k["obs_image"]), pxo._p(k["obs_point"]),
-                pxo._p(k["corners"]), pxo._p(k["scales"]), pxo._p(k["qvec"]), pxo._p(k["tvec"]), pxo._p(k["xyz"]),
-                pxo._p(k["cam_params"]), int(k["cam_params"].shape[1]), pxo._p(k["image_camera"]), pxo._p(k["refs"]), 1,
-                int(threads), C.c_double(secs), 1, out)
-        if rc:
-            raise RuntimeError("pxo_refbench_ba_residual failed (%d)" % rc)
-        return out[0], out[1], out[2], out[3]
-    rep = sweep(run, len(k["obs_patch"]), "residual_blocks/s", min_seconds)
-    rep["kind"] = "reference"
-    return rep
-
-
-def bicubic_reference(sub, min_seconds=0.25, seed=0):
-    lib = ref_bench_lib()
-    if lib is None:
-        return None
-    arena = np.ascontiguousarray(sub["patches"]).view(np.uint16)
-    n, H, W = arena.shape[0], arena.shape[1], arena.shape[2]
-    rng = np.random.default_rng(seed)
-    rc_ = np.ascontiguousarray(rng.uniform(H / 2 - 1.5, H / 2 + 0.5, (n, 2)))       # around the patch centre
-    idx = np.arange(n, dtype=np.int64)
-    fn = lib.pxo_refbench_bicubic
-    fn.restype = C.c_int
-
-    def run(m, threads, secs):
-        out = _out4()
-        rc = fn(C.c_int64(m), pxo._p(arena), H, W, pxo._p(idx), pxo._p(rc_), int(threads), C.c_double(secs), 1, out)
-        if rc:
-            raise RuntimeError("pxo_refbench_bicubic failed (%d)" % rc)
-        return out[0], out[1], out[2], out[3]
-    rep = sweep(run, n, "bicubic interpolations/s (value + 2 derivatives, 128 channels)", min_seconds)
-    rep["kind"] = "reference-kernel"
-    return rep
-
-
 def _ka_csr(problem):
     node_problem = np.asarray(problem["node_problem"], np.int64)
     n_prob = int(node_problem.max()) + 1
@@ -307,29 +229,4 @@ def ka_solve_port(problem, config, ls, bound=4.0, opts=None, counts=None):
     rep["kind"] = "port"
     rep["lm_iterations_per_sub_problem"] = iters.get(rep["cores"])
     rep["edges"] = int(len(problem["edge_src"]))
-    return rep
-
-
-def ka_edge_reference(problem, min_seconds=0.25):
-    lib = ref_bench_lib()
-    if lib is None:
-        return None
-    arena = np.ascontiguousarray(problem["patches"]).view(np.uint16)
-    _, H, W = arena.shape[0], arena.shape[1], arena.shape[2]
-    src, dst = np.ascontiguousarray(problem["edge_src"], np.int32), np.ascontiguousarray(problem["edge_dst"], np.int32)
-    kp = np.ascontiguousarray(problem["kp"], np.float64)
-    node_patch = np.ascontiguousarray(problem["node_patch"], np.int64)
-    corners, scales = np.ascontiguousarray(problem["corners"], np.int32), np.ascontiguousarray(problem["scales"], np.float64)
-    fn = lib.pxo_refbench_ka_edge
-    fn.restype = C.c_int
-
-    def run(n, threads, secs):
-        out = _out4()
-        rc = fn(C.c_int64(n), pxo._p(src), pxo._p(dst), pxo._p(kp), pxo._p(node_patch), pxo._p(arena), H, W, pxo._p(corners),
-                pxo._p(scales), 1, int(threads), C.c_double(secs), out)
-        if rc:
-            raise RuntimeError("pxo_refbench_ka_edge failed (%d)" % rc)
-        return out[0], out[1], out[2], out[3]
-    rep = sweep(run, len(src), "residual_blocks/s (KA edges, residual + 128 x 4 Jacobian)", min_seconds)
-    rep["kind"] = "reference"
     return rep

@@ -1,6 +1,54 @@
-"""Pure-Python restatement of the match-graph labelling (TEST INFRASTRUCTURE ONLY -- never imported by the
-product package): ComputeTrackLabels / ComputeScoreLabels / ComputeRootLabels, pixsfm/base/src/graph.cc:126-256.
-The product calls the native host implementation (csrc/pxr_graph.cpp); tests compare the two."""
+"""Pure-Python restatement of the match graph and of the keypoint-adjustment problem construction (TEST INFRASTRUCTURE ONLY --
+never imported by the product package):
+  Graph.register_matches                      Graph::RegisterMatches / FindOrCreateNode / AddEdge, pixsfm/base/src/graph.cc:38-79
+  compute_track_labels / _score_ / _root_     graph.cc:126-256
+  build_edges                                 TopologicalKeypointOptimizer::SetUp + FeatureMetricKeypointOptimizer::
+                                              AddIntraResiduals (keypoint_adjustment/src/topological_keypoint_optimizer.h:97-175,
+                                              featuremetric_keypoint_optimizer.h:158-202)
+  parameterize_keypoints                      KeypointOptimizerBase::ParameterizeKeypoints (keypoint_optimizer.h:110-157) with
+                                              KeypointAdjustmentSetup (keypoint_adjustment_options.h:24-45)
+The product calls its native host implementation (csrc/pxr_graph.cpp); tests compare the two.
+PARITY UNPINNED: these reference files include COLMAP / Ceres headers and cannot be compiled here, and the reference has no test
+for them; this is a restatement read from the source."""
+
+
+class Match:
+    __slots__ = ("node_idx", "sim")
+
+    def __init__(self, node_idx, sim):
+        self.node_idx, self.sim = node_idx, sim
+
+
+class FeatureNode:
+    __slots__ = ("image_id", "feature_idx", "node_idx", "out_matches")
+
+    def __init__(self, image_id, feature_idx):
+        self.image_id, self.feature_idx, self.node_idx, self.out_matches = image_id, feature_idx, -1, []
+
+
+class Graph:
+    """graph.h:47-97 -- nodes in order of creation, image ids in order of first appearance."""
+
+    def __init__(self):
+        self.nodes, self.node_map, self.image_name_to_id, self.image_id_to_name = [], {}, {}, {}
+
+    def find_or_create_node(self, image_name, feature_idx):                      # graph.cc:38-57
+        image_id = self.image_name_to_id.setdefault(image_name, len(self.image_name_to_id))
+        self.image_id_to_name.setdefault(image_id, image_name)
+        key = (image_id, int(feature_idx))
+        if key in self.node_map:
+            return self.nodes[self.node_map[key]]
+        node = FeatureNode(image_id, int(feature_idx))
+        self.nodes.append(node)
+        node.node_idx = len(self.nodes) - 1
+        self.node_map[key] = node.node_idx
+        return node
+
+    def register_matches(self, imname1, imname2, matches, similarities=None):   # graph.cc:66-79
+        for k, (f1, f2) in enumerate(matches):
+            n1 = self.find_or_create_node(imname1, f1)
+            n2 = self.find_or_create_node(imname2, f2)
+            n1.out_matches.append(Match(n2.node_idx, 1.0 if similarities is None else float(similarities[k])))   # AddEdge :59-64
 
 
 def compute_track_labels(graph):
@@ -106,6 +154,37 @@ def build_edges(graph, keypoints, track_labels, root_labels, nodes_in_problem=No
         if regularize:
             for k in (i, j):
                 if not connected_to_root.get(k, False):
-                    add(k, track_root[track_labels[k]], root_regularize_weight)
+                    add(k, track_root.get(track_labels[k], 0), root_regularize_weight)   # operator[] of the map: node 0 when the root never showed up
                     connected_to_root[k] = True
     return src, dst, w
+
+
+def parameterize_keypoints(graph, src, dst, nodes_in_problem, is_node_constant, node_kp, corner, scale, width, height, bound,
+                           sparse=True):
+    """KeypointOptimizerBase::ParameterizeKeypoints (keypoint_optimizer.h:110-157) after the residual blocks (src, dst) were added.
+    Returns (const [n] bool, bounds [n, 4] = lower x, lower y, upper x, upper y, NaN where no bound is set).  Only nodes of
+    nodes_in_problem that some residual block touched (will_be_optimized_) are visited; a node that is touched but not visited
+    stays a free, unbounded parameter block."""
+    import numpy as np
+    n = len(graph.nodes)
+    touched = np.zeros(n, bool)
+    touched[list(src)] = True
+    touched[list(dst)] = True
+    const = np.zeros(n, bool)
+    bounds = np.full((n, 4), np.nan)
+    for i in (range(n) if nodes_in_problem is None else nodes_in_problem):
+        if not touched[i]:
+            continue
+        if is_node_constant(graph.nodes[i]):
+            const[i] = True
+        elif bound > 0.0 or sparse:
+            sx, sy = float(scale[i][0]), float(scale[i][1])
+            lowerx, lowery = (corner[i][0] + 0.5) / sx, (corner[i][1] + 0.5) / sy
+            upperx, uppery = lowerx + width / sx, lowery + height / sy
+            if bound > 0.0:
+                upperx = min(node_kp[i][0] + bound / sx, upperx)
+                uppery = min(node_kp[i][1] + bound / sy, uppery)
+                lowerx = max(node_kp[i][0] - bound / sx, lowerx)
+                lowery = max(node_kp[i][1] - bound / sy, lowery)
+            bounds[i] = (lowerx, lowery, upperx, uppery)
+    return const, bounds

@@ -1,11 +1,9 @@
-"""Golden vectors for the dense-feature cache reader: small cache files in both storage formats
-(tests/h5_writer.py = the layout pixsfm/features/store_features.py writes through h5py) and, beside them, what the
-REFERENCE's own reader hands out for each file -- features/src/featuremanager.cc, featureset.cc, featuremap.cc,
-featurepatch.cc compiled in place (oracle/Makefile -> oracle/_ref/libpxo_ref_h5.so).  Run in the build container:
+"""Small dense-feature cache files in both storage formats for the reader tests: written by tests/h5_writer.py
+(the layout pixsfm/extract.py:98-127 and pixsfm/features/store_features.py write through h5py, issued here through ctypes on
+the image's libhdf5 because h5py is absent) from the seeded content of cases().  The tests regenerate that content from the
+seed and require the product's reader to hand it back (tests/test_h5_reader.py).
 
-    python tests/golden/make_golden_h5.py
-
-writes tests/golden/h5_cache_*.h5 and tests/golden/h5_cache_ref.npz."""
+    python tests/golden/make_golden_h5.py       # writes tests/golden/h5_cache_*.h5"""
 import os
 import sys
 
@@ -14,7 +12,6 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import h5_writer            # noqa: E402
-import ref_h5_reader        # noqa: E402
 
 DT = {"half": np.float16, "float": np.float32, "double": np.float64}
 
@@ -47,40 +44,13 @@ def cases():
     return out
 
 
-def dump_reference(path, dtype, level_prefix):
-    """everything the reference's FeatureManager holds after a filled load, keyed 'level/image/...'"""
-    out = {}
-    with ref_h5_reader.ReferenceCache(path, dtype, True, level_prefix) as ref:
-        out["channels_per_level"] = np.array([ref.channels(l) for l in range(ref.num_levels)], np.int32)
-        for l in range(ref.num_levels):
-            names = ref.image_names(l)
-            out["%d/images" % l] = np.array(names)
-            for im in names:
-                info = ref.map_info(l, im)
-                ids = ref.patch_ids(l, im)
-                ps = [ref.patch(l, im, k) for k in ids]
-                key = "%d/%s/" % (l, im)
-                out[key + "is_sparse"] = np.array(info["is_sparse"])
-                out[key + "channels"] = np.array(info["channels"])
-                out[key + "ids"] = ids
-                out[key + "corners"] = np.stack([p["corner"] for p in ps])
-                out[key + "scales"] = np.stack([p["scale"] for p in ps])
-                out[key + "patches"] = np.stack([p["data"] for p in ps])
-    return out
-
-
 def main():
-    store = {}
     for name, levels, kw in cases():
         path = os.path.join(HERE, "h5_cache_%s.h5" % name)
         if os.path.exists(path):
             os.remove(path)
         h5_writer.write_cache(path, levels, **kw)
-        for k, v in dump_reference(path, DT[kw["dtype_name"]], kw["level_prefix"]).items():
-            store[name + "|" + k] = v
-        store[name + "|level_prefix"] = np.array(kw["level_prefix"])
         print(name, os.path.getsize(path), "bytes")
-    np.savez_compressed(os.path.join(HERE, "h5_cache_ref.npz"), **store)
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 """Generates tests/golden/half_rules.npz: the two half-precision rules the cost-map extraction leans on, evaluated by
-the REFERENCE's vendored third-party/half.hpp (compiled in place into oracle/_ref/libpxo_ref.so, oracle/ref_shim.cc):
+the REFERENCE's vendored third-party/half.hpp (compiled from its own source into oracle/_ref/libpxo_ref_half.so, oracle/ref_half_shim.cc -- the one piece of /root/reference that builds here without stand-ins):
   sub[i]  = half(a[i]) - half(b[i])     (central differences of costmap_extractor.h:266-276 are taken in the storage type)
   cast[i] = half(v[i]) for double v     (FeaturePatch::SetEntry, featurepatch.h:246-248: through float, two roundings)
 Seeded inputs incl. exact cancellations, subnormal results and exact half-way points.

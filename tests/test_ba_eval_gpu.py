@@ -115,17 +115,18 @@ def test_unsupported_channels_raise(ctx):
 
 @pytest.mark.parametrize("name,dtype,fs", [("f16", np.float16, 0), ("f16", np.float16, 1), ("f32", np.float32, 0),
                                            ("f64", np.float64, 0)])
-def test_kernel_reproduces_reference_golden_vectors(ctx, name, dtype, fs):
-    """tests/golden/bicubic_ref.npz was produced by the REFERENCE's own spline/grid code
-    (tests/golden/make_golden.py).  Drive the fused kernel so that it evaluates exactly those
-    (r, c) positions: identity pose, SIMPLE_PINHOLE f = 1, c = 0, X = (c + .5, r + .5, 1), no
-    normalisation, zero reference => r = f, gx = dfdc, gy = dfdr."""
-    import os
+def test_kernel_reproduces_the_oracles_bare_bicubic(ctx, name, dtype, fs):
+    """The bare bicubic (no normalisation) at the positions of tests/cases/bicubic_cases.py (the shape of the reference's
+    TestBiCubicSimilarCeres, interpolation_test.cc:327-364: border, outside, on-texel).  Drive the fused kernel so that it
+    evaluates exactly those (r, c): identity pose, SIMPLE_PINHOLE f = 1, c = 0, X = (c + .5, r + .5, 1), zero reference =>
+    r = f, gx = dfdc, gy = dfdr; compare with the oracle (same fp32-horizontal / fp64-vertical split, same FMA order)."""
+    import pxo
+    from cases import bicubic_cases
     from pixsfm_amd.engine import BAProblem, PatchArena, interp_cfg
-    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "bicubic_ref.npz"))
-    pos = gold["positions_rc"]
+    pos = bicubic_cases.positions()
     n = len(pos)
-    grid = np.ascontiguousarray(gold["grid_" + name].astype(dtype))[None]
+    data = np.ascontiguousarray(bicubic_cases.grid(name).astype(dtype))
+    grid = data[None]
     prob = dict(obs_image=np.zeros(n, np.int32), obs_point=np.arange(n, dtype=np.int32),
                 obs_patch=np.zeros(n, np.int64), image_camera=np.zeros(1, np.int32),
                 qvec=np.array([[1.0, 0, 0, 0]]), tvec=np.zeros((1, 3)), cam_model=np.zeros(1, np.int32),
@@ -134,7 +135,8 @@ def test_kernel_reproduces_reference_golden_vectors(ctx, name, dtype, fs):
     arena = PatchArena.from_numpy(ctx, grid, np.zeros((1, 2), np.int32), np.ones((1, 2)))
     ba = BAProblem(ctx, arena, prob)
     _, r, gx, gy = ba.eval(interp_cfg(l2_normalize=False, use_float_simd=bool(fs)), with_jacobian=True, materialize=True)
-    want = gold["out_%s_fs%d" % (name, fs)]
+    p = pxo.make_patch(data)
+    want = np.stack([np.stack(pxo.bicubic(p, float(rr), float(cc), bool(fs))) for rr, cc in pos])
     tol = 1e-12 * np.abs(want).max()          # (c + .5) - .5 may differ from c by one ulp
     assert np.abs(r.download() - want[:, 0]).max() < tol
     assert np.abs(gy.download() - want[:, 1]).max() < tol

@@ -1,6 +1,7 @@
-"""GPU: match-graph labelling on the device (pxr_graph_labels_device) against the vectors produced by the
-reference's own graph.cc (tests/golden/graph_ref.npz) and, at size, against the native host implementation (which is
-itself pinned to those vectors): track labels, scores (bit-identical: same summation order), roots."""
+"""GPU: match-graph labelling on the device (pxr_graph_labels_device) against the oracle's pure-Python
+restatement of graph.cc (oracle/pxo_graph.py) on the seeded graphs and, at size, against the native host implementation
+(itself compared with the oracle in tests/test_graph_labelling.py): track labels, scores (bit-identical: same summation
+order), roots."""
 import ctypes as C
 import os
 import sys
@@ -9,22 +10,22 @@ import numpy as np
 import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from test_graph_golden import _build, _gen  # noqa: E402
+from test_graph_labelling import _build, _gen, oracle_labels  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_device_labelling_matches_the_reference_vectors(ctx):
+def test_device_labelling_matches_the_oracle(ctx):
     from pixsfm_amd.api import base
     gen = _gen()
-    gold = np.load(os.path.join(HERE, "golden", "graph_ref.npz"))
     for name, pairs, mm in gen.cases():
         g = _build(base, pairs, mm)
+        want_l, want_s, want_r = oracle_labels(g)
         labels, scores, roots = base.compute_labels_on_device(g, ctx)
-        assert labels == gold[name + "_labels"].tolist(), name
-        assert np.array_equal(scores, gold[name + "_scores"]), name
-        assert [int(r) for r in roots] == gold[name + "_roots"].tolist(), name
+        assert labels == want_l, name
+        assert np.array_equal(scores, want_s), name
+        assert [int(r) for r in roots] == want_r, name
 
 
 def _flat_random_graph(rng, n_groups, per, n_img, n_matches, n_cross):

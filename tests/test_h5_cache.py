@@ -1,7 +1,7 @@
 """CPU: the native reader of pixsfm's dense-feature cache (libpixsfm_h5.so) against files written the
 way the reference's Python writes them (tests/h5_writer.py restates extract.py:98-127 + store_features.py on the image's
 libhdf5; h5py itself is absent).  Reader and writer are independent implementations of the two sides of the documented
-layout; the reader is pinned against the REFERENCE's reader in tests/test_h5_reader_vs_reference.py."""
+layout; more reader cases (committed files, h5dump, subsets, malformed files) in tests/test_h5_reader.py."""
 import ctypes as C
 import os
 import re

@@ -2,7 +2,7 @@
 
 The reference has no test or golden vector for CostMapExtractor, so:
   * the two storage-type rounding rules the extraction leans on are pinned bit-exactly against the reference's
-    OWN vendored half.hpp compiled in place (oracle/_ref): half - half, and dtype(double) of SetEntry;
+    OWN vendored half.hpp compiled from its own source (oracle/ref_half_shim.cc -> oracle/_ref/libpxo_ref_half.so): half - half, and dtype(double) of SetEntry;
   * the vectorised restatement is checked against an independent per-texel loop that follows
     costmap_extractor.h:242-357 statement by statement;
   * the 3-channel, reference-free residual block (costmap_bundle_optimizer.h:104-119) is checked by finite differences.

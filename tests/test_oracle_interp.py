@@ -1,53 +1,18 @@
 """CPU: pins the oracle's interpolation against
- (1) golden vectors produced by the REFERENCE's own spline/grid code (tests/golden/bicubic_ref.npz,
-     generator tests/golden/make_golden.py; cases of interpolation_test.cc:327-364),
- (2) the reference's other interpolation test cases re-stated here
-     (pixsfm/base/src/interpolation_test.cc:21-185 polynomial reproduction, :187-207 unit norm,
-      :272-311 Jet chain rule, :327-364 agreement with ceres::BiCubicInterpolator at 1e-5),
- (3) finite differences of every analytic derivative (untested in the reference)."""
-import os
+ (1) the KNOWN-ANSWER cases of the reference's own interpolation tests, re-stated here
+     (pixsfm/base/src/interpolation_test.cc:21-185 polynomial reproduction at 1e-8, :187-207 unit norm at 1e-10,
+      :272-311 Jet chain rule, :327-364 agreement of the SIMD path with ceres::BiCubicInterpolator at 1e-5 -- the latter
+      against a restatement of Ceres' published cubic_interpolation.h, Ceres itself being absent),
+ (2) finite differences of every analytic derivative (untested in the reference).
+These are the only pins the bicubic has: the reference's spline / grid headers include Eigen and Ceres and cannot be compiled in
+this image.  In particular the SPLIT of the arithmetic (fp32 horizontal pass for fp16 / fp32 storage, fp64 vertical
+pass; cubic_hermite_spline_simd.h:123-175, interpolation.h:183-217) is read from the source and is NOT pinned by any output of
+the reference: the 1e-5 / 1e-8 bounds above do not see it."""
 
 import numpy as np
 import pytest
 
 import pxo
-
-GOLD = os.path.join(os.path.dirname(__file__), "golden", "bicubic_ref.npz")
-
-
-@pytest.fixture(scope="module")
-def gold():
-    return np.load(GOLD)
-
-
-@pytest.mark.parametrize("name,fs", [("f16", 0), ("f16", 1), ("f32", 0), ("f64", 0)])
-def test_restatement_is_bit_exact_vs_reference_golden(gold, name, fs):
-    data = gold["grid_" + name]
-    want = gold["out_%s_fs%d" % (name, fs)]
-    p = pxo.make_patch(np.ascontiguousarray(data))
-    for (r, c), w in zip(gold["positions_rc"], want):
-        got = np.stack(pxo.bicubic(p, float(r), float(c), bool(fs)))
-        assert np.array_equal(got, w), (name, fs, r, c, np.abs(got - w).max())
-
-
-@pytest.mark.skipif(pxo.ref() is None, reason="oracle/_ref not built (needs /root/reference at build time)")
-@pytest.mark.parametrize("dt", [np.float16, np.float32, np.float64])
-@pytest.mark.parametrize("ch", [8, 12, 19, 64, 128])
-def test_restatement_vs_reference_headers_live(dt, ch):
-    """SIMD bodies bit-exact; the scalar tails (C % 8 / C % 4 channels) within 1e-14 (the
-    reference compiles them with FMA contraction allowed)."""
-    rng = np.random.default_rng(ch)
-    data = rng.uniform(-1, 1, (10, 10, ch)).astype(dt)
-    p = pxo.make_patch(data)
-    for r in np.arange(0, 100, 9) / 10.0:
-        for c in np.arange(0, 100, 11) / 10.0:
-            for fs in (False, True):
-                a = np.stack(pxo.bicubic(p, r, c, fs))
-                b = np.stack(pxo.ref_bicubic(data, r, c, fs))
-                nb = ch - ch % 8
-                assert np.array_equal(a[:, :nb], b[:, :nb])
-                assert np.abs(a - b).max() < 1e-14
-
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64, np.float16])
 def test_similar_to_ceres_bicubic(dt):
@@ -148,3 +113,20 @@ def test_half_conversion_matches_numpy():
     x = np.concatenate([rng.normal(0, 1, 2000), rng.normal(0, 1e-5, 2000), [0.0, -0.0, 65504.0, 1e6, -1e6, 6e-8]]).astype(np.float32)
     got = np.array([pxo.lib().pxo_float_to_half(float(v)) for v in x], dtype=np.uint16)
     assert np.array_equal(got, x.astype(np.float16).view(np.uint16))
+
+
+def test_half_widening_matches_the_references_half_hpp():
+    """Every one of the 65536 binary16 patterns widened to float by the reference's vendored third-party/half.hpp (compiled
+    from its own source, oracle/ref_half_shim.cc) and by the oracle's pxo_half_to_float (what the interpolation reads fp16
+    texels through; the reference's SIMD path uses F16C's _mm256_cvtph_ps, cubic_hermite_spline_simd.h:51-54, which is the
+    same IEEE widening)."""
+    import ctypes as C
+    r = pxo.ref()
+    if r is None:
+        pytest.skip("oracle/_ref/libpxo_ref_half.so not built (needs /root/reference at build time)")
+    bits = np.arange(65536, dtype=np.uint16)
+    want = np.empty(65536, np.float32)
+    r.pxo_ref_half_to_float(bits.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p), C.c_int64(65536))
+    got = np.array([pxo.lib().pxo_half_to_float(int(b)) for b in bits], dtype=np.float32)
+    nan = np.isnan(want)
+    assert np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32)) and np.isnan(got[nan]).all()

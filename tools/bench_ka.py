@@ -87,14 +87,6 @@ def cpu_legs_on_sample(prob, patches, dev):
     solve["sample"] = what + "; oracle C restatement of the bounded LM, one single-threaded solve per task, tasks taken from a shared counter"
     solve["projected_full_solve_ms"] = 1e3 * n_prob / solve["value"]
     out["cpu_baseline"] = solve
-    try:
-        edge = pxo_cpubench.ka_edge_reference(sub)
-        if edge is not None:
-            edge["sample"] = what + ("; the reference's FeatureMetric2DCostFunctor compiled in place, evaluated on 4-wide dual "
-                                     "numbers like ceres::AutoDiffCostFunction (residual + 128 x 4 Jacobian per block)")
-            out["cpu_baseline_edge_eval"] = edge
-    except Exception as e:  # noqa: BLE001 -- oracle/_ref is optional
-        out["cpu_baseline_edge_eval"] = {"value": None, "kind": "reference", "sample": "unavailable: %r" % (e,)}
     return out
 
 

@@ -315,6 +315,13 @@ int pxr_comm_rank(pxr_ctx* ctx, int* rank, int* nranks);
 /* in-place sum over the ranks of `count` doubles at device pointer d_buf, ordered with the context's stream
  * (ncclAllReduce on that stream); a no-op on a context without communicator / with one rank. */
 int pxr_comm_allreduce_sum(pxr_ctx* ctx, double* d_buf, int64_t count);
+/* Diagnostics.  pxr_comm_force(ctx, 1) (or PXR_FORCE_COLLECTIVE=1 in the environment when the context is created): a context
+ * whose communicator has ONE rank still takes the multi-rank branch of the solvers -- pack, ncclAllReduce(ncclInt64 /
+ * ncclFloat64) on the context's stream, unpack -- so that the native collective path can be exercised and timed on a single
+ * GPU; results must be bit-identical to the plain one-rank solve (tests/test_zz_multi_rank_gpu.py).
+ * pxr_comm_stats: ncclAllReduce calls / payload bytes issued through the context so far (NULL pointers are skipped). */
+int pxr_comm_force(pxr_ctx* ctx, int on);
+int pxr_comm_stats(pxr_ctx* ctx, int64_t* calls, int64_t* bytes, int reset);
 
 /* Caller-supplied collective (same contract as pxr_comm_allreduce_sum), for hosts that bring their own
  * transport -- the CPU/gloo tests, MPI.  Passed to pxr_ba_solve it takes precedence over the context's

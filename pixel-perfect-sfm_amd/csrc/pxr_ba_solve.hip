@@ -320,7 +320,11 @@ __global__ __launch_bounds__(256) void k_img(const SolveDev d, const ImgChunk* _
 __global__ __launch_bounds__(256) void k_pinv(int64_t n_points, const int* __restrict__ pt_var,
                                               const double* __restrict__ V,
                                               const double* __restrict__ Vdiag0 /* clamped diag */,
-                                              double inv_radius, double* __restrict__ T) {
+                                              double inv_radius, double* __restrict__ T,
+                                              double* __restrict__ zero_ptr, int zero_n) {
+  // side job of the attempt's first kernel: clear the attempt's scalars / limbs / info word (one fill launch less per attempt;
+  // nothing before the Schur kernels of this attempt touches them)
+  if (blockIdx.x == 0) for (int e = threadIdx.x; e < zero_n; e += blockDim.x) zero_ptr[e] = 0.0;
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_points) return;
   double* To = T + 6 * p;
@@ -334,6 +338,15 @@ __global__ __launch_bounds__(256) void k_pinv(int64_t n_points, const int* __res
   To[0] = c00 * id; To[1] = c01 * id; To[2] = c02 * id;
   To[3] = (a00 * a22 - a02 * a02) * id; To[4] = (a01 * a02 - a00 * a12) * id;
   To[5] = (a00 * a11 - a01 * a01) * id;
+}
+
+// the accepted candidate becomes the current point: four arrays, ONE launch (four hipMemcpyAsync cost four dispatches)
+struct Copy4 { const double* src[4]; double* dst[4]; int64_t n[4]; };
+__global__ __launch_bounds__(256) void k_copy4(const Copy4 c) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+    for (int64_t e = t0; e < c.n[a]; e += stride) c.dst[a][e] = c.src[a][e];
 }
 
 // ---- K_schur: S -= Y_i W_j^T (upper), rhs -= Y_i g_p ----------------------------------------------
@@ -997,7 +1010,7 @@ struct DevBuf {
 
 // pxr_chol.hip: factor the n x n SPD system stored row-major (upper) in the n x (n + 1) buffer `a` whose last
 // column is the right-hand side (forward substitution is fused into the factorisation), then back-substitute.
-int chol_factor_solve(hipStream_t st, double* a, int n, int* d_info, double* linv_ws, double* x_out);
+int chol_factor_solve(hipStream_t st, double* a, int n, int* d_info, double* linv_ws, double* x_out, bool zero_info = true);
 size_t chol_workspace_doubles(int n);
 
 // pxr_ba_inner.hip
@@ -1216,7 +1229,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   RC(scale_c.alloc(nc1)); RC(scale_p.alloc((size_t)n_pts * 3)); RC(delta_c.alloc(nc1)); RC(delta_p.alloc((size_t)n_pts * 3));
   RC(rec_a.alloc((size_t)n_obs * PXR_OBS_REC)); RC(rec_b.alloc((size_t)n_obs * PXR_OBS_REC));
   RC(q1.alloc((size_t)n_img * 4)); RC(t1.alloc((size_t)n_img * 3)); RC(k1.alloc((size_t)n_cam * PXR_KPAD)); RC(X1.alloc((size_t)n_pts * 3));
-  RC(scal.alloc(16 + 16 * PXR_LIMBS + 4));   // [0..7] summed over ranks, [8..15] replicated; the limbs of those 16 scalars; the newest linearisation's diagonal statistics
+  RC(scal.alloc(16 + 16 * PXR_LIMBS + 1 + 4));   // ... + one slot whose first 4 bytes are the factorisation's info word (read back with the scalars)   // [0..7] summed over ranks, [8..15] replicated; the limbs of those 16 scalars; the newest linearisation's diagonal statistics
   double* scal_sum = scal.p; double* scal_rep = scal.p + 8;
   const int ldS = n_c + 1;
   double* rhs = S.p + n_c;          // column n_c of S, stride ldS
@@ -1264,11 +1277,9 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     PXR_HIP(hipStreamSynchronize(st));        // (the host vectors above leave scope)
   }
   double* diagU = gcd.p; double* gc = gcd.p + nc1;
-  DevBuf<int> info_buf;
-  RC(info_buf.alloc(1));
   DevBuf<double> cb_flags;          // iteration callbacks on several ranks: the ranks' answers, summed
   RC(cb_flags.alloc(2));
-  int* d_info = info_buf.p;
+  int* d_info = reinterpret_cast<int*>(scal.p + 16 + 16 * PXR_LIMBS);   // zeroed with the scalars (zero_scalars), read back with them
 
   setup_mark("work buffers allocated");
   double* cur_q = const_cast<double*>(view->d_qvec); double* cur_t = const_cast<double*>(view->d_tvec);
@@ -1284,7 +1295,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   cand_view.d_qvec = q1.p; cand_view.d_tvec = t1.p; cand_view.d_cam_params = k1.p; cand_view.d_xyz = X1.p;
 
   // the collective: the caller's callback if given, else the context's RCCL communicator (pxr_comm_init)
-  const bool multi = allreduce != nullptr || (ctx->comm != nullptr && ctx->nranks > 1);
+  const bool multi = allreduce != nullptr || (ctx->comm != nullptr && (ctx->nranks > 1 || ctx->force_collective));   // (forced: a one-rank communicator runs the whole multi-rank branch through RCCL -- tests / bench, pxr_comm_force)
   auto ar = [&](double* buf, int64_t count) -> int {
     if (allreduce) {
       if (allreduce(ar_user, buf, count) != 0) return set_error(PXR_EHIP, "pxr_ba_solve: all-reduce callback failed");
@@ -1347,14 +1358,21 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     return PXR_OK;
   };
   auto zero_scalars = [&]() -> int {
-    PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * (16 + 16 * PXR_LIMBS), st));   // (the statistics behind them stay)
+    PXR_HIP(hipMemsetAsync(scal.p, 0, sizeof(double) * (16 + 16 * PXR_LIMBS + 1), st));   // scalars, limbs, the info word (the statistics behind them stay)
     return PXR_OK;
   };
   struct { double* p; } lin_stats;    // {max, sum, min of diag(U), trace} of the newest linearisation (k_finish_and_stats), behind the 16 scalars
-  constexpr int kScalAll = 16 + 16 * PXR_LIMBS + 4;
+  constexpr int kScalAll = 16 + 16 * PXR_LIMBS + 1 + 4;
   lin_stats.p = scal.p + (kScalAll - 4);
-  double h_scal[kScalAll] = {0};
+  // read back into PINNED host memory: an asynchronous copy into pageable memory (a stack array) is staged by the runtime and
+  // blocks the host until it is done -- two such copies per attempt (scalars, factorisation info) left the GPU idle for ~25 us
+  // each (profiles/r6_lm_timeline.txt)
+  if (!ctx->h_readback) PXR_HIP(hipHostMalloc(&ctx->h_readback, 4096, hipHostMallocDefault));
+  static_assert(sizeof(double) * kScalAll <= 4096, "read-back buffer");
+  double* const h_scal = static_cast<double*>(ctx->h_readback);
+  std::memset(h_scal, 0, sizeof(double) * kScalAll);
   double* const h_lin_stats = h_scal + (kScalAll - 4);
+  const int* const h_info_word = reinterpret_cast<const int*>(h_scal + 16 + 16 * PXR_LIMBS);
   const bool spin_wait = std::getenv("PXR_BLOCKING_WAIT") == nullptr;
   auto read_scal = [&](double* h16) -> int {
     if (det) {
@@ -1653,8 +1671,8 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     if (!reuse_diag) RC(refresh_damping());
     const double inv_radius = 1.0 / radius;
     // point elimination + reduced camera system
-    hipLaunchKernelGGL(k_pinv, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, d_pt_var.p, V.p, Vd0.p, inv_radius, T.p);
-    RC(zero_scalars());
+    hipLaunchKernelGGL(k_pinv, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, d_pt_var.p, V.p, Vd0.p, inv_radius, T.p, scal.p, 16 + 16 * PXR_LIMBS + 1);   // (+ zero_scalars' job)
+    if (n_pts == 0) RC(zero_scalars());
     bool ok = true;
     double inexact_correction = 0.0;
     if (n_c > 0 && iterative) {
@@ -1667,7 +1685,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       // The camera step only approximately solves S x = b; the points are eliminated exactly for that x.  With
       // e = b - S x:  model cost change = delta.(D^2 delta - g) / 2 + x.e / 2
       inexact_correction = 0.5 * pr.x_dot_r;
-      PXR_HIP(hipMemsetAsync(d_info, 0, sizeof(int), st));
+      PXR_HIP(hipMemsetAsync(d_info, 0, sizeof(int), st));    // (the CG loop's failure flag lives in the info word: reported through pr.ok)
       hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, xsol.p, gc, damp_c.p, inv_radius, delta_c.p, scal_rep, limb_arg);
       RC(from_rank0(delta_c.p, n_c));
     } else if (n_c > 0) {
@@ -1696,7 +1714,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       hipLaunchKernelGGL(k_copy_upper_add_diag, dim3(nblk((int64_t)n_c * ldS)), dim3(256), 0, st, n_c, U.p, damp_c.p, inv_radius, gc, S.p, 0, schur_scale);
       // row-major upper == column-major lower; the pivot check is read back with the scalars of
       // this attempt (no extra host synchronisation): a failed factorisation = invalid step.
-      RC(chol_factor_solve(st, S.p, n_c, d_info, linv.p, xsol.p));
+      RC(chol_factor_solve(st, S.p, n_c, d_info, linv.p, xsol.p, /*zero_info=*/false));     // (zero_scalars cleared the info word)
       phase(2);
       hipLaunchKernelGGL(k_finish_camera_step, dim3(nblk(n_c)), dim3(256), 0, st, n_c, xsol.p, gc, damp_c.p, inv_radius, delta_c.p, scal_rep, limb_arg);
       RC(from_rank0(delta_c.p, n_c));
@@ -1731,9 +1749,8 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
       }
       phase(4);
       RC(evaluate(cand_view, rec_cand));
-      int h_info = 0;
-      PXR_HIP(hipMemcpyAsync(&h_info, d_info, sizeof(int), hipMemcpyDeviceToHost, st));
       RC(read_scal(hs));
+      const int h_info = *h_info_word;
       if (det_fixed && !lin_fits(h_lin_stats, lin_md)) {
         // the overflow guard: a slot of the linearisation this iteration was computed from did not fit its grid -- repeat the
         // linearisation on a grid from the measured trace and the iteration with it (state untouched: radius, damping, counts)
@@ -1784,10 +1801,11 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     if (std::fabs(cost_change) <= opt->function_tolerance * cost) { sum->termination = PXR_TERM_CONVERGENCE; break; }
     const double rel = cost_change / model_cost_change;
     if (inner_useful || rel > opt->min_relative_decrease) {   // IsStepSuccessful + HandleSuccessfulStep
-      PXR_HIP(hipMemcpyAsync(cur_q, q1.p, sizeof(double) * 4 * n_img, hipMemcpyDeviceToDevice, st));
-      PXR_HIP(hipMemcpyAsync(cur_t, t1.p, sizeof(double) * 3 * n_img, hipMemcpyDeviceToDevice, st));
-      PXR_HIP(hipMemcpyAsync(cur_k, k1.p, sizeof(double) * PXR_KPAD * n_cam, hipMemcpyDeviceToDevice, st));
-      PXR_HIP(hipMemcpyAsync(cur_X, X1.p, sizeof(double) * 3 * n_pts, hipMemcpyDeviceToDevice, st));
+      {
+        Copy4 c4{{q1.p, t1.p, k1.p, X1.p}, {cur_q, cur_t, cur_k, cur_X},
+                 {(int64_t)4 * n_img, (int64_t)3 * n_img, (int64_t)PXR_KPAD * n_cam, (int64_t)3 * n_pts}};
+        hipLaunchKernelGGL(k_copy4, dim3((unsigned)std::min<int64_t>(1024, nblk(3 * n_pts + 1))), dim3(256), 0, st, c4);
+      }
       std::swap(rec_cur, rec_cand);
       cost = cand_cost;
       cur_is_exact = false;

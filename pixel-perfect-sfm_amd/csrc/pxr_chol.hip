@@ -25,6 +25,8 @@
 //                      through flags; x_k = inv(L_kk)^T z_k, z_c -= L(k-block, c-block)^T x_k.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "pxr_chol_core.h"
 #include "pxr_internal.h"
 
@@ -127,14 +129,13 @@ __device__ __forceinline__ void rank64_update(cholcore::d4 (&acc)[4], const doub
 
 // block step s: n_rows = rows of the (augmented) matrix, n_cols = columns to factor.  Grid: n_panel panel workgroups, then
 // the update workgroups of the tiles (ti, tj), 1 <= tj <= ti, of the matrix from block row s on (s >= 1 only).
-__global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ a, int n_rows, int n_cols, int lda, int s, int n_panel,
-                                                   int* __restrict__ info, double* __restrict__ linv_out, double* __restrict__ ldiag_out) {
+__device__ __forceinline__ void chol_step_body(unsigned char* smem, double* __restrict__ a, int n_rows, int n_cols, int lda, int s, int n_panel,
+                                               int block, int* __restrict__ info, double* __restrict__ linv_out, double* __restrict__ ldiag_out) {
   using namespace cholcore;
-  extern __shared__ __align__(16) unsigned char smem[];
   const int k0 = s * CNB, nb = min(CNB, n_cols - k0);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if ((int)blockIdx.x >= n_panel) {                                   // ---- an update workgroup
-    int t = (int)blockIdx.x - n_panel, ti = 1;
+  if (block >= n_panel) {                                             // ---- an update workgroup
+    int t = block - n_panel, ti = 1;
     while (t >= ti) { t -= ti; ++ti; }                                 // tile t of row ti: (ti, 1 + t), at most ~25 rows
     update_tile(*reinterpret_cast<UpdateLds*>(smem), a, n_rows, lda, k0 - CNB, k0, ti, 1 + t);
     return;
@@ -144,13 +145,13 @@ __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ a, int n
   const int i = lane & 15, g = lane >> 4;
   // the 16-row block this wavefront carries through the sweep: blocks 0..3 are identity rows (-> inv(L_ss)), then the rows
   // below the tile
-  const int v = wave - ROW_WAVE0, vb = ROW_WAVES * (int)blockIdx.x + v;
+  const int v = wave - ROW_WAVE0, vb = ROW_WAVES * block + v;
   const int r0 = k0 + nb + 16 * (vb - 4);                              // first matrix row of a real row block
   const bool real_rows = wave >= ROW_WAVE0 && vb >= 4 && r0 < n_rows;
   RowSink sink;
   // L_ss goes to the workspace, NOT over the tile: the other panel workgroups read the tile when they start, and with more
   // panel workgroups than CUs (n > ~12000) the late ones start after workgroup 0 has finished
-  sink.l_diag = blockIdx.x == 0 ? ldiag_out + (size_t)s * CNB * CNB : nullptr;
+  sink.l_diag = block == 0 ? ldiag_out + (size_t)s * CNB * CNB : nullptr;
   sink.ld = lda; sink.nb = nb; sink.rows_valid = 16; sink.rows_out = nullptr; sink.mode = RowSink::kNone;
   d4 acc[4];
   if (wave < 4) {
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ a, int n
     // step s - 1's rank-64 update of this workgroup's part of block column s.  Stage L(tile rows, s-1) and
     // L(own rows, s-1) as U[k][row] (rows contiguous in memory: coalesced), then MFMA from LDS.
     const int kp = k0 - CNB;
-    const int first_real = k0 + nb + 16 * (ROW_WAVES * (int)blockIdx.x - 4);   // row of this workgroup's row block v = 0
+    const int first_real = k0 + nb + 16 * (ROW_WAVES * block - 4);   // row of this workgroup's row block v = 0
     // thread t: row t % 128 of the 112 staged rows (tile rows, then this workgroup's 48), columns t / 128 + 4 q -- all 16
     // loads are issued before the first LDS store (a load -> store loop pays the memory latency once per trip)
     {
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ a, int n
       int gr = -1;
       if (r < CNB) { if (r < nb) gr = k0 + r; }
       else if (r < CNB + 16 * ROW_WAVES) {
-        const int vbb = ROW_WAVES * (int)blockIdx.x + ((r - CNB) >> 4);
+        const int vbb = ROW_WAVES * block + ((r - CNB) >> 4);
         if (vbb >= 4) gr = first_real + (r - CNB);
       }
       const bool live = gr >= 0 && gr < n_rows;
@@ -222,7 +223,56 @@ __global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ a, int n
     }
   }
   const int bad = factor_tile(lds.f, acc, wave, lane, sink);
-  if (blockIdx.x == 0 && tid == 0 && bad && bad <= nb) atomicCAS(info, 0, k0 + bad);
+  if (block == 0 && tid == 0 && bad && bad <= nb) atomicCAS(info, 0, k0 + bad);
+}
+
+// one launch per block step (the form of rounds 3-5; PXR_CHOL_STEP_LAUNCHES=1 and the standalone pxr_chol C-ABI keep it)
+__global__ __launch_bounds__(512) void k_chol_step(double* __restrict__ a, int n_rows, int n_cols, int lda, int s, int n_panel,
+                                                   int* __restrict__ info, double* __restrict__ linv_out, double* __restrict__ ldiag_out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  chol_step_body(smem, a, n_rows, n_cols, lda, s, n_panel, (int)blockIdx.x, info, linv_out, ldiag_out);
+}
+
+// ALL block steps in ONE launch (round 6; an EXPERIMENT, off by default -- see chol_factor_solve).  The chain of rounds 3-5 -- 25 launches at n = 1593 -- paid ~5 us of dispatch + cache
+// maintenance between two dependent kernels, a third of a 17 us step (profiles/r6_lm_timeline.txt).  Here the grid is the
+// concatenation of every step's workgroups (panel workgroups first, then the update tiles, step after step); a workgroup of
+// step s > 0 waits until ALL workgroups of step s - 1 have counted themselves done (done[s - 1] == their number) -- exactly the
+// dependency the stream order expressed.  Dependencies only point to LOWER workgroup ids, which the dispatcher starts first, so
+// the spin-waits cannot deadlock even when the grid exceeds the machine (the argument of k_chol_backsolve).  Release: every
+// thread's stores, a workgroup barrier, then one thread's __threadfence + atomic add; acquire: one thread's atomic load at agent
+// scope (it invalidates the CU's L1), a barrier, then plain loads.
+constexpr int kDoneStride = 32;      // one 128-byte line per step counter
+__global__ __launch_bounds__(512) void k_chol_all(double* __restrict__ a, int n_rows, int n_cols, int lda, int* __restrict__ info,
+                                                  double* __restrict__ linv_out, double* __restrict__ ldiag_out, int* __restrict__ done) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int sh_step[3];
+  const int rows_per_wg = 16 * cholcore::ROW_WAVES;
+  if (threadIdx.x == 0) {
+    int first = 0, s = 0, prev_count = 0;
+    for (int k = 0; k < n_cols; ++s, k += CNB) {          // (at most n / 64 trips of integer arithmetic)
+      const int nb = min(CNB, n_cols - k), rem = n_rows - k - nb;
+      const int n_panel = (CNB + rem + rows_per_wg - 1) / rows_per_wg;
+      const int T = (n_rows - k + CNB - 1) / CNB;
+      const int count = n_panel + (s > 0 ? T * (T - 1) / 2 : 0);
+      if ((int)blockIdx.x < first + count) { sh_step[0] = s; sh_step[1] = (int)blockIdx.x - first; sh_step[2] = n_panel; break; }
+      first += count; prev_count = count;
+    }
+    if (sh_step[0] > 0) {
+      // poll RELAXED (an acquire per poll invalidates this XCD's caches every time: with ~200 waiting workgroups that made the
+      // whole factorisation 2x slower than the chain of launches), then ONE acquire fence before the data is read
+      const int* flag = done + kDoneStride * (sh_step[0] - 1);
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < prev_count) __builtin_amdgcn_s_sleep(2);
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+  }
+  __syncthreads();
+  const int s = sh_step[0];
+  chol_step_body(smem, a, n_rows, n_cols, lda, s, sh_step[2], sh_step[1], info, linv_out, ldiag_out);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    __hip_atomic_fetch_add(done + kDoneStride * s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // L^T x = y in ONE launch: workgroup b owns block column c = nblk - 1 - b (64 unknowns) and keeps its
@@ -286,24 +336,43 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
 // `a` the diagonal tiles keep their INPUT values, see k_chol_step)
 size_t chol_workspace_doubles(int n) { return (size_t)(2 * ((n + CNB - 1) / CNB) + 1) * CNB * CNB; }
 
-int chol_factor_solve(hipStream_t st, double* a, int n, int* d_info, double* linv_ws, double* x_out) {
+int chol_factor_solve(hipStream_t st, double* a, int n, int* d_info, double* linv_ws, double* x_out, bool zero_info) {
   const int lda = n + 1, n_rows = n + 1;
   const int nblk = (n + CNB - 1) / CNB;
   // > 64 KiB of dynamic LDS needs the opt-in, per device (one process may hold contexts on several devices)
   if (int rc = hip_check(hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStepLds), "LDS size")) return rc;
-  if (int rc = hip_check(hipMemsetAsync(d_info, 0, sizeof(int), st), "memset info")) return rc;
+  if (zero_info) if (int rc = hip_check(hipMemsetAsync(d_info, 0, sizeof(int), st), "memset info")) return rc;
   const int rows_per_wg = 16 * cholcore::ROW_WAVES;
+  // the spare 64 x 64 block of the workspace: [0, nblk) the back-substitution's flags, [nblk, 2 nblk) the steps' completion counters
+  int* flags = reinterpret_cast<int*>(linv_ws + (size_t)nblk * CNB * CNB);
+  const size_t spare_ints = sizeof(double) * CNB * CNB / sizeof(int);
+  if ((size_t)nblk > spare_ints) return set_error(PXR_EINVAL, "chol_factor_solve: n = %d too large", n);
+  // one launch for all steps needs a 128-byte line per step counter behind the flags: n <= ~15800; beyond, the chain of launches
+  const bool one_launch_fits = (size_t)nblk * (1 + kDoneStride) <= spare_ints;
+  // MEASURED AND NOT ADOPTED (round 6, n = 1593, profiles/r6_chol_one_launch.txt): one launch for all steps 2.10 ms per LM iteration
+  // against 2.00 ms for the chain of 25 launches -- a release at agent scope writes the XCD's L2 back and an acquire invalidates
+  // it, per WORKGROUP here (3000 of them) instead of once per kernel boundary; with an acquire per poll it was 2.54 ms.  The
+  // chain stays the default; PXR_CHOL_ONE_LAUNCH=1 selects the single launch (tests/test_chol_gpu.py runs both).
+  const bool step_launches = std::getenv("PXR_CHOL_ONE_LAUNCH") == nullptr || !one_launch_fits;
+  if (int rc = hip_check(hipMemsetAsync(flags, 0, sizeof(int) * (step_launches ? (size_t)nblk : (size_t)nblk * (1 + kDoneStride)), st), "memset flags")) return rc;
+  long long total_wgs = 0;
   for (int s = 0, k = 0; k < n; ++s, k += CNB) {
     const int nb = (n - k < CNB) ? n - k : CNB;
     const int rem = n_rows - k - nb;                      // rows below the diagonal tile (>= 1: the rhs row)
     const int n_panel = (CNB + rem + rows_per_wg - 1) / rows_per_wg;   // 64 identity rows + the rows below
     const int T = (n_rows - k + CNB - 1) / CNB;           // row tiles from block row s on; tiles (ti, tj), 1 <= tj <= ti < T
     const int n_update = s > 0 ? T * (T - 1) / 2 : 0;
-    hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_update), dim3(512), kStepLds, st, a, n_rows, n, lda, s, n_panel, d_info, linv_ws,
-                       linv_ws + (size_t)(nblk + 1) * CNB * CNB);
+    total_wgs += n_panel + n_update;
+    if (step_launches)
+      hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_update), dim3(512), kStepLds, st, a, n_rows, n, lda, s, n_panel, d_info, linv_ws,
+                         linv_ws + (size_t)(nblk + 1) * CNB * CNB);
   }
-  int* flags = reinterpret_cast<int*>(linv_ws + (size_t)nblk * CNB * CNB);   // spare block of the workspace
-  if (int rc = hip_check(hipMemsetAsync(flags, 0, sizeof(int) * nblk, st), "memset flags")) return rc;
+  if (!step_launches) {
+    if (total_wgs > 0x7fffffffll) return set_error(PXR_EINVAL, "chol_factor_solve: n = %d too large for one launch", n);
+    if (int rc = hip_check(hipFuncSetAttribute((const void*)k_chol_all, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStepLds), "LDS size")) return rc;
+    hipLaunchKernelGGL(k_chol_all, dim3((unsigned)total_wgs), dim3(512), kStepLds, st, a, n_rows, n, lda, d_info, linv_ws,
+                       linv_ws + (size_t)(nblk + 1) * CNB * CNB, flags + nblk);
+  }
   hipLaunchKernelGGL(k_chol_backsolve, dim3(nblk), dim3(256), 0, st, a, n, lda, linv_ws, x_out, flags, nblk);
   return hip_check(hipGetLastError(), "cholesky launch");
 }
@@ -344,7 +413,7 @@ extern "C" int pxr_dense_spd_solve(pxr_ctx* ctx, double* d_a, int n, double* d_b
   }
   int* d_info = reinterpret_cast<int*>(ctx->d_scratch);
   hipLaunchKernelGGL(k_aug_pack, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, st, n, d_a, d_b, aug);
-  int rc = chol_factor_solve(st, aug, n, d_info, linv, d_b);
+  int rc = chol_factor_solve(st, aug, n, d_info, linv, d_b, true);
   if (!rc) {
     hipLaunchKernelGGL(k_aug_unpack, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, n, aug,
                        linv + (size_t)((n + CNB - 1) / CNB + 1) * CNB * CNB, d_a);

@@ -63,8 +63,9 @@ int nccl_check(int rc, const char* what) {
 }  // namespace
 
 int comm_allreduce_sum(pxr_ctx* ctx, double* d_buf, int64_t count, bool even_single_rank) {
-  if (!ctx->comm || count <= 0 || (ctx->nranks <= 1 && !even_single_rank)) return PXR_OK;
+  if (!ctx->comm || count <= 0 || (ctx->nranks <= 1 && !even_single_rank && !ctx->force_collective)) return PXR_OK;
   Rccl* r = rccl();
+  ++ctx->collective_calls; ctx->collective_bytes += count * 8;
   return nccl_check(r->AllReduce(d_buf, d_buf, (size_t)count, kNcclFloat64, kNcclSum, (NcclComm)ctx->comm, ctx->stream),
                     "ncclAllReduce");
 }
@@ -72,8 +73,9 @@ int comm_allreduce_sum(pxr_ctx* ctx, double* d_buf, int64_t count, bool even_sin
 // the same for 64-bit integers: the deterministic solvers' fixed-point slots and scalar limbs (integer sums are associative, so
 // an N-rank solve accumulates the very integers of the one-rank solve)
 int comm_allreduce_sum_i64(pxr_ctx* ctx, long long* d_buf, int64_t count) {
-  if (!ctx->comm || count <= 0 || ctx->nranks <= 1) return PXR_OK;
+  if (!ctx->comm || count <= 0 || (ctx->nranks <= 1 && !ctx->force_collective)) return PXR_OK;
   Rccl* r = rccl();
+  ++ctx->collective_calls; ctx->collective_bytes += count * 8;
   return nccl_check(r->AllReduce(d_buf, d_buf, (size_t)count, kNcclInt64, kNcclSum, (NcclComm)ctx->comm, ctx->stream),
                     "ncclAllReduce(int64)");
 }
@@ -136,6 +138,20 @@ int pxr_comm_rank(pxr_ctx* ctx, int* rank, int* nranks) {
   PXR_REQUIRE(ctx, "pxr_comm_rank: ctx is NULL");
   if (rank) *rank = ctx->rank;
   if (nranks) *nranks = ctx->nranks;
+  return PXR_OK;
+}
+
+int pxr_comm_force(pxr_ctx* ctx, int on) {
+  PXR_REQUIRE(ctx, "pxr_comm_force: ctx is NULL");
+  ctx->force_collective = on != 0;
+  return PXR_OK;
+}
+
+int pxr_comm_stats(pxr_ctx* ctx, int64_t* calls, int64_t* bytes, int reset) {
+  PXR_REQUIRE(ctx, "pxr_comm_stats: ctx is NULL");
+  if (calls) *calls = ctx->collective_calls;
+  if (bytes) *bytes = ctx->collective_bytes;
+  if (reset) { ctx->collective_calls = 0; ctx->collective_bytes = 0; }
   return PXR_OK;
 }
 

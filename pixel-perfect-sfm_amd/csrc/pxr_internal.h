@@ -13,6 +13,7 @@ struct pxr_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   hipEvent_t ev_sync = nullptr;  // the LM loop's polled host synchronisation (pxr_ba_solve)
+  void* h_readback = nullptr;    // 4 KiB of pinned host memory: the LM loop's per-attempt read-back (an async copy into pageable memory blocks the host)
   double* d_scratch = nullptr;   // small reduction scratch (device)
   size_t scratch_bytes = 0;
   int num_cus = 256;
@@ -22,6 +23,9 @@ struct pxr_ctx {
   size_t workspace_mat_bytes = 0;
   void* comm = nullptr;          // ncclComm_t of this rank (pxr_comm.cpp), NULL on a single GPU
   int rank = 0, nranks = 1;
+  bool force_collective = false; // pxr_comm_force / PXR_FORCE_COLLECTIVE=1: a ONE-rank communicator still runs every collective of the solvers through RCCL
+  int64_t collective_calls = 0;  // ncclAllReduce calls issued through this context (diagnostics: pxr_comm_stats)
+  int64_t collective_bytes = 0;
   pxr_iteration_callback iter_cb = nullptr;   // pxr_set_iteration_callback
   void* iter_user = nullptr;
   void* h_stage[2] = {nullptr, nullptr};      // pinned staging buffers of the patch uploads (pxr_arena_upload*), lazily allocated

@@ -54,6 +54,7 @@ int pxr_ctx_create(int device, void* stream, pxr_ctx** out) {
   PXR_HIP(hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming));
   if (const char* e = std::getenv("PXR_DETERMINISTIC")) c->deterministic = e[0] != '\0' && e[0] != '0';
   if (const char* e = std::getenv("PXR_GRAM_CACHE")) c->gram_cache = e[0] != '\0' && e[0] != '0';
+  if (const char* e = std::getenv("PXR_FORCE_COLLECTIVE")) c->force_collective = e[0] != '\0' && e[0] != '0';
   c->scratch_bytes = 1 << 20;
   PXR_HIP(hipMalloc((void**)&c->d_scratch, c->scratch_bytes));
   *out = c;
@@ -65,6 +66,7 @@ int pxr_ctx_destroy(pxr_ctx* ctx) {
   // teardown: nothing useful can be done with an error here
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->h_readback) { (void)hipHostFree(ctx->h_readback); ctx->h_readback = nullptr; }
   if (ctx->comm) (void)pxr_comm_destroy(ctx);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->d_workspace) (void)hipFree(ctx->d_workspace);

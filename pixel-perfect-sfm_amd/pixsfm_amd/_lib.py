@@ -149,6 +149,8 @@ _SIGNATURES = {
     "pxr_comm_set_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pxr_comm_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pxr_comm_allreduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pxr_comm_force": (C.c_int, [C.c_void_p, C.c_int]),
+    "pxr_comm_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]),
 }
 LINEAR_AUTO, LINEAR_DIRECT, LINEAR_ITERATIVE = 0, 1, 2
 COMM_ID_BYTES = 128

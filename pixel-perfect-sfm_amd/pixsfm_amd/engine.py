@@ -116,6 +116,17 @@ class Context:
         self._iter_cb = _lib.ITERATION_CALLBACK(hook)            # kept alive as long as it is installed
         check(self.lib.pxr_set_iteration_callback(self.handle, C.cast(self._iter_cb, C.c_void_p), None), "pxr_set_iteration_callback")
 
+    def comm_force(self, on=True):
+        """Diagnostics: with a ONE-rank communicator the solvers still take their multi-rank branch (pack, ncclAllReduce on the
+        context's stream, unpack); results must equal the plain solve bit for bit (pxr_comm_force)."""
+        check(self.lib.pxr_comm_force(self.handle, int(bool(on))), "pxr_comm_force")
+
+    def comm_stats(self, reset=False):
+        """(ncclAllReduce calls, payload bytes) issued through this context so far."""
+        calls, nbytes = C.c_int64(), C.c_int64()
+        check(self.lib.pxr_comm_stats(self.handle, C.byref(calls), C.byref(nbytes), int(bool(reset))), "pxr_comm_stats")
+        return calls.value, nbytes.value
+
     def comm_destroy(self):
         check(self.lib.pxr_comm_destroy(self.handle), "pxr_comm_destroy")
 

@@ -16,6 +16,8 @@ The collective of the BA path is native: an RCCL communicator owned by the engin
 channel that carries the 128-byte communicator id and the host-side gathers -- and, in the CPU
 tests (backend "gloo"), the transport behind the callback form of the collective.
 """
+import os
+
 import numpy as np
 
 
@@ -193,8 +195,8 @@ def allreduce_host(array, group=None, op="sum"):
     import torch
     import torch.distributed as dist
     rank, n = world(group)
-    if n == 1:
-        return array
+    if n == 1 and not (os.environ.get("PXR_FORCE_COLLECTIVE", "0") not in ("", "0") and dist.is_available() and dist.is_initialized()):
+        return array          # (PXR_FORCE_COLLECTIVE=1: a one-rank group still goes through the backend -- tests)
     rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX}[op]
     t = torch.from_numpy(array)
     if dist.get_backend(group) == "nccl":

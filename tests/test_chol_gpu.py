@@ -63,3 +63,22 @@ def test_more_panel_workgroups_than_compute_units(ctx):
     L = np.triu(dA.download()).T                      # the returned factor, diagonal tiles included
     rows = rng.integers(0, n, 40)
     assert np.allclose((L[rows] @ L.T), A[rows], rtol=0, atol=1e-9 * np.abs(A).max())
+
+
+@pytest.mark.parametrize("n", [64, 130, 1593])
+def test_single_launch_variant_gives_the_same_factor(ctx, n, monkeypatch):
+    """PXR_CHOL_ONE_LAUNCH=1: all block steps in one launch with step counters instead of kernel boundaries (an experiment that
+    measured slower than the chain of launches and is off by default; it must still be right)."""
+    rng = np.random.default_rng(100 + n)
+    M = rng.normal(size=(n, n + 5))
+    A = M @ M.T + np.eye(n) * 1e-3 * n
+    b = rng.normal(size=n)
+    out = []
+    for one in (False, True):
+        if one:
+            monkeypatch.setenv("PXR_CHOL_ONE_LAUNCH", "1")
+        dA, db = ctx.to_device(np.triu(A)), ctx.to_device(b)
+        info = C.c_int(-1)
+        assert ctx.lib.pxr_dense_spd_solve(ctx.handle, dA.ptr, n, db.ptr, C.byref(info)) == 0 and info.value == 0
+        out.append((db.download(), dA.download()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(np.triu(out[0][1]), np.triu(out[1][1]))

@@ -147,6 +147,78 @@ def test_native_rccl_communicator_single_rank():
     c.close()
 
 
+@pytest.mark.parametrize("mode", ["direct", "direct_inner", "iterative", "direct_fp_atomics"])
+def test_forced_native_collective_equals_the_plain_solve_bit_for_bit(mode):
+    """the multi-rank branch of pxr_ba_solve -- k_pack_upper -> ncclAllReduce(ncclInt64 / ncclFloat64) on the
+    context's stream -> k_unpack_upper, the scalar limbs, diag(U) | g_c -- really RUNS on RCCL: a one-rank communicator with
+    pxr_comm_force(ctx, 1).  A sum over one rank is the identity, so every parameter and both costs must equal the plain
+    solve's bit for bit (deterministic default; with floating-point atomics: to rounding), and the context must have issued
+    collectives."""
+    from pixsfm_amd.engine import BAProblem, Context, PatchArena, interp_cfg, lm_options, make_loss
+    prob = worker.ba_problem()
+    gauge = worker.ba_gauge(prob)
+    opts = dict(max_iterations=6, use_inner_iterations=(mode == "direct_inner"))
+    if mode == "iterative":
+        opts.update(linear_solver="iterative", eta=0.0, linear_r_tolerance=1e-13, max_linear_solver_iterations=1000)
+    out = []
+    for forced in (False, True):
+        c = Context(0)
+        if mode == "direct_fp_atomics":
+            c.deterministic = False
+        if forced:
+            c.comm_init(Context.comm_unique_id(), 0, 1)
+            c.comm_force(True)
+        arena = PatchArena.from_numpy(c, prob["patches"], prob["corners"], prob["scales"])
+        ba = BAProblem(c, arena, prob)
+        s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *gauge, options=lm_options(**opts))
+        calls, nbytes = c.comm_stats()
+        out.append((s, ba.params(), calls, nbytes))
+        arena.close()
+        if forced:
+            c.comm_destroy()
+        c.close()
+    (s0, p0, calls0, _), (s1, p1, calls1, bytes1) = out
+    assert calls0 == 0 and calls1 >= 2 * s1["iterations"] and bytes1 > 0        # at least [S | rhs] (or CG vectors) + scalars per iteration
+    assert s1["iterations"] == s0["iterations"] and s1["num_successful"] == s0["num_successful"]
+    if mode != "iterative":
+        n_c = s1["num_camera_unknowns"]
+        assert s1["collective_kib"] == (n_c * (n_c + 3) // 2 * 8 + 1023) // 1024 and s0["collective_kib"] == 0
+    if mode == "direct_fp_atomics":
+        assert abs(s1["final_cost"] - s0["final_cost"]) < 1e-9 * s0["initial_cost"]
+        for a, b in zip(p0, p1):
+            assert np.abs(a - b).max() < 1e-7
+    else:
+        assert s1["initial_cost"] == s0["initial_cost"] and s1["final_cost"] == s0["final_cost"]
+        for a, b in zip(p0, p1):
+            assert np.array_equal(a, b)
+
+
+def test_gathers_of_the_sharded_paths_run_on_rccl_with_one_rank(tmp_path):
+    """KA keypoint gather and reference gather (parallel.gather_rows / allreduce_host) through torch.distributed's nccl backend
+    (= RCCL) with a ONE-rank group in a fresh process: identity on the data."""
+    import subprocess
+    code = (
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from pixsfm_amd import parallel\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29577')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))\n"
+        "rows = np.arange(40, dtype=np.float64).reshape(20, 2) * 0.25 - 1\n"
+        "ids = np.arange(20)[::-1].copy()\n"
+        "full = parallel.gather_rows(rows, ids, 20)\n"
+        "assert np.array_equal(full[ids], rows)\n"
+        "refs = np.random.default_rng(0).normal(size=(7, 128))\n"
+        "assert np.array_equal(parallel.gather_rows(refs, np.arange(7), 7), refs)\n"
+        "assert np.array_equal(parallel.allreduce_host(np.array([3.0, 4.0])), [3.0, 4.0])\n"
+        "dist.destroy_process_group()\n"
+        "print('ok')\n") % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pixel-perfect-sfm_amd")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["PXR_FORCE_COLLECTIVE"] = "1"
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "ok" in p.stdout.split(), p.stderr[-3000:]           # (RCCL prints its banner after it)
+
+
 def test_pixsfm_api_on_two_ranks(ctx, tmp_path, monkeypatch):
     """KeypointAdjuster / BundleAdjuster through the pixsfm-shaped API with torch.distributed initialised: two ranks
     (sharing the one GPU of this box, gloo) give what one process gives -- refined keypoints, references of all points,

@@ -797,6 +797,8 @@ def compact_line(full):
                                           "successful_steps", "initial_cost", "final_cost")),
                      "roofline": _pick(rf, ("bound", "achieved", "peak", "frac", "kernel", "kernel_ms", "algorithmic_bytes", "traffic")),
                      "accuracy_px": {k: _r(v, 3) for k, v in ka.get("accuracy_px", {}).items()}}
+        if ka.get("operating_points"):
+            out["ka"]["operating_points_kernel_ms"] = {k: _r(v.get("kernel_ms")) for k, v in ka["operating_points"].items()}
         t = ka.get("telemetry")
         if t:
             out["ka"]["telemetry"] = {"sclk_mhz_mean": _mean(t.get("sclk_mhz")), "power_w_mean": _mean(t.get("power_w")),
@@ -940,6 +942,25 @@ def secondary_legs(job, total_points):
         ka_result = bench_ka.run(device_index=job.local_rank, ctx=job.ctx, rank=rank, world=world,
                                  cpu_legs=(rank == 0 and world == 1 and not args.no_cpu_baseline),
                                  telemetry=None if args.no_telemetry else GpuTelemetry(job.local_rank))
+        # the reference's OTHER shipped operating points of this path (VERDICT r5 missing-3): configs/low_memory.yaml:13-24 -- label
+        # groups of 1000 keypoints, 8 x 8 patches, bound 2, topological_reference (examples/sfm+loc_aachen.py:124-125) -- and ONE
+        # problem (split_in_subproblems = false, keypoint_adjustment/main.py:197-202).  A large label group runs on as many
+        # workgroups as it has chunks of whole tracks, with the decisions of one Ceres problem (pxr_ka_view.d_prob_group).
+        if rank == 0 and world == 1 and ka_result is not None:
+            pts = {}
+            for name, kw in (("max_kps_1000", dict(max_kps_per_problem=1000)),
+                             ("one_problem", dict(max_kps_per_problem=0)),
+                             ("low_memory_yaml", dict(max_kps_per_problem=1000, patch_size=8, bound=2.0, strategy="topological_reference")),
+                             ("low_memory_yaml_50_per_problem", dict(max_kps_per_problem=50, patch_size=8, bound=2.0, strategy="topological_reference"))):
+                try:
+                    torch.cuda.empty_cache()
+                    r = bench_ka.run(steps=2, device_index=job.local_rank, ctx=job.ctx, solves=3, **kw)
+                    pts[name] = {"options": r["options"], "kernel_ms": r["solve"]["kernel_ms"], "kernel_ms_min": r["solve"]["kernel_ms_min"],
+                                 "lm_iterations_max": r["solve"]["lm_iterations_max"], "successful_steps": r["solve"]["successful_steps"],
+                                 "final_cost": r["solve"]["final_cost"], "median_error_px_after": r["accuracy_px"]["median_after"]}
+                except Exception as e:  # noqa: BLE001 -- a secondary figure never fails the bench
+                    pts[name] = {"error": repr(e)}
+            ka_result["operating_points"] = pts
     if rank == 0 and world == 1 and not args.no_api_e2e:
         torch.cuda.empty_cache()
         sys.path.insert(0, os.path.join(ROOT, "tools"))

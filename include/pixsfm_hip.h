@@ -450,6 +450,15 @@ typedef struct {
   const double* d_unary_w;        /* [n_unary] ScaledLoss weight; NULL = 1                */
   const int64_t* d_prob_unary_ptr;/* [n_problems + 1] into d_prob_unary                   */
   const int32_t* d_prob_unary;
+  /* Optional (NULL: every sub-problem is a Ceres problem of its own, as above).  d_prob_group[i] = id of the label group --
+   * the ceres::Problem of the reference, ONE trust region / line search / termination (keypoint_optimizer.h:77-104) -- that
+   * sub-problem i is a CHUNK of.  The chunks of a group are consecutive sub-problems and share no variable (whole tracks
+   * each); every chunk still gets its own workgroup, and the group's scalars -- cost, model cost change, probe costs, step
+   * norms -- are summed over its workgroups, so that a group of 1000 keypoints (configs/low_memory.yaml:
+   * max_kps_per_problem 1000) runs on 20 workgroups instead of one with the decisions of ONE problem.  Per-chunk summaries
+   * then carry the group's iteration counts and the chunk's part of the costs.  A group may have at most as many chunks as
+   * the launch keeps resident (~448 on an MI355X; larger groups: PXR_EUNSUPPORTED). */
+  const int32_t* d_prob_group;    /* [n_problems] non-decreasing group ids, or NULL          */
 } pxr_ka_view;
 
 /* Per-edge evaluation for parity checks: d_cost [n_edges] = 0.5 w rho(|r|^2); optional

@@ -66,7 +66,54 @@ struct KaArgs {
   int stream_slots;            // > 0: the line-search probes run as ka_probe_stream (every sub-problem has at most this many nodes, <= 64,
                                // all its residual blocks in the LDS cache, no unary terms); its LDS region follows the LM state
   int stream_off;              // doubles from sh_A to that region
+  // ---- label groups that span several workgroups (round 6) -----------------------------------------------------------------
+  // A label group of the caller (ONE ceres::Problem of the reference: one trust region, one line search, one termination) may
+  // be handed over as several CHUNKS -- consecutive sub-problems that share no variable (whole tracks each): pxr_ka_view.
+  // d_prob_group.  Each chunk keeps its workgroup, its LDS state and its block-diagonal normal matrix; only the scalars a
+  // Ceres problem decides on are summed over the group's workgroups (ka_group_sum4): cost, model cost change, the directional
+  // derivative, every line-search probe's cost, step and parameter norms, the feasibility / rescale / factorisation flags.
+  const int* grp_first = nullptr;   // [n_problems] first sub-problem of this sub-problem's group (NULL: every sub-problem is its own group)
+  const int* grp_size = nullptr;    // [n_problems] sub-problems in the group
+  double* grp_part = nullptr;       // [2][n_problems][4] the members' addends of the current / the previous sum
+  unsigned* grp_cnt = nullptr;      // [n_problems][32] arrival counter of a group at its first member (one 128-byte line each)
 };
+constexpr int KA_GRP_CNT_STRIDE = 32;
+
+// Sum of four block-uniform values over the workgroups of a label group; every member gets the SAME bits (partials are added in
+// member order: lane l of the first wavefront takes members l, l + 64, ..., then a fixed shuffle tree).  `gen` counts the sums of
+// this launch (the same in every member); two slots per member (gen & 1): a member can be at most one sum ahead of the slowest.
+// All members are resident at the same time -- the host checks the group size against the launch's resident capacity, and
+// sub-problems are dispatched in index order (the argument of k_chol_backsolve), so the spin-wait cannot deadlock.
+struct KaGroup { int first, size, member, stride; double* part; unsigned* cnt; };
+__device__ __noinline__ void ka_group_sum4(const KaGroup g, unsigned gen, double v0, double v1, double v2, double v3, double* sh_out) {
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    double* slot = g.part + ((size_t)(gen & 1u) * g.stride + g.first) * 4;
+    if (lane == 0) {
+      double* mine = slot + (size_t)g.member * 4;
+      mine[0] = v0; mine[1] = v1; mine[2] = v2; mine[3] = v3;
+      __threadfence();
+      unsigned* c = g.cnt + (size_t)g.first * KA_GRP_CNT_STRIDE;
+      __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned want = (gen + 1u) * (unsigned)g.size;
+      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    __builtin_amdgcn_wave_barrier();
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int m = lane; m < g.size; m += 64) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s[k] += __hip_atomic_load(slot + (size_t)m * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off);
+      if (lane == 0) sh_out[k] = s[k];
+    }
+  }
+  __syncthreads();
+}
 constexpr int KA_TERM_RESCALE = 100;   // internal termination code: the sub-problem's fixed-point grid did not fit, launch again
 
 // Channel layout of a node over lanes: 8 channels per lane (one 16-byte fp16 load) for the CNN feature sizes, and the
@@ -1061,6 +1108,17 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   const bool fsimd = a.float_simd != 0;
   KaProb p;
   if (DET && a.prob_done[prob]) return;                  // (a repeated launch after a grid change: this sub-problem had finished)
+  // a label group that spans several workgroups (KaArgs::grp_first): the Ceres-level scalars are summed over its members
+  __shared__ double sh_gs[4];
+  KaGroup grp{prob, 1, 0, 0, nullptr, nullptr};
+  if (a.grp_first) { grp.first = a.grp_first[prob]; grp.size = a.grp_size[prob]; grp.member = prob - grp.first; grp.stride = a.v.n_problems; grp.part = a.grp_part; grp.cnt = a.grp_cnt; }
+  const bool grouped = grp.size > 1;
+  unsigned grp_gen = 0;
+  auto gsum4 = [&](double& v0, double& v1, double& v2, double& v3) {       // in place; a no-op for a group of one
+    if (!grouped) return;
+    ka_group_sum4(grp, grp_gen++, v0, v1, v2, v3, sh_gs);
+    v0 = uniform_f64(sh_gs[0]); v1 = uniform_f64(sh_gs[1]); v2 = uniform_f64(sh_gs[2]); v3 = uniform_f64(sh_gs[3]);
+  };
   __shared__ double sh_grid, sh_resc;
   if (tid == 0) { sh_grid = DET ? a.prob_scale[prob] : 0.0; sh_resc = 0.0; }
 
@@ -1229,12 +1287,13 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     KA_T(7);
     ka_nodes<ST, C, false>(a, p, a.kp_cand, fsimd, true);
     KA_T(3);
-    const double c = ka_terms<C, false>(a, p, sh4);
+    double c = ka_terms<C, false>(a, p, sh4);
     KA_T(4);
+    if (grouped) { double z1 = 0.0, z2 = 0.0, z3 = 0.0; gsum4(c, z1, z2, z3); }      // the GROUP's cost at the candidate
     return c;
   };
 
-  if (n == 0 || (p.ne1 == p.ne0 && p.nu1 == p.nu0)) {
+  if (!grouped && (n == 0 || (p.ne1 == p.ne0 && p.nu1 == p.nu0))) {       // (a member of a group goes through the loop with its siblings)
     ka_nodes<ST, C, false>(a, p, a.v.d_kp, fsimd);
     const double c = ka_terms<C, false>(a, p, sh4);
     sm.initial_cost = sm.final_cost = c; sm.termination = PXR_TERM_CONVERGENCE;
@@ -1242,15 +1301,22 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     return;
   }
   double cost = linearize(std::true_type{});
-  sm.initial_cost = cost;
-  if (DET && sh_resc != 0.0) {         // the grid does not fit this sub-problem: nothing was changed, the host launches again
-    sm.final_cost = cost; sm.termination = KA_TERM_RESCALE; sm.linear_iterations = stencils;
-    if (tid == 0) { a.summaries[prob] = sm; a.prob_scale[prob] = sh_resc; }
+  double cost_loc = cost;              // this member's part of the group's cost (what its summary reports: the host adds them up)
+  sm.initial_cost = cost_loc;
+  bool resc = DET && sh_resc != 0.0, infeasible = !inf.feasible;
+  if (grouped) {                       // one Ceres problem: its cost, and its members' flags, are the group's
+    double f_resc = resc ? 1.0 : 0.0, f_inf = infeasible ? 1.0 : 0.0, z = 0.0;
+    gsum4(cost, f_resc, f_inf, z);
+    resc = DET && f_resc > 0.0; infeasible = f_inf > 0.0;
+  }
+  if (resc) {                          // the grid does not fit this sub-problem (or a sibling): nothing was changed, the host launches again
+    sm.final_cost = cost_loc; sm.termination = KA_TERM_RESCALE; sm.linear_iterations = stencils;
+    if (tid == 0) { a.summaries[prob] = sm; a.prob_scale[prob] = sh_resc != 0.0 ? sh_resc : sh_grid; }
     return;
   }
-  if (!inf.feasible || !isfinite(cost)) {   // [upstream] Program::IsFeasible fails / the initial evaluation fails
+  if (infeasible || !isfinite(cost)) {      // [upstream] Program::IsFeasible fails / the initial evaluation fails
                                             // (non-finite input): FAILURE, parameters untouched
-    sm.final_cost = cost; sm.termination = PXR_TERM_FAILURE;
+    sm.final_cost = cost_loc; sm.termination = PXR_TERM_FAILURE;
     if (tid == 0) { a.summaries[prob] = sm; if (DET) a.prob_done[prob] = 1; }
     return;
   }
@@ -1307,7 +1373,23 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       part += -p.step[i] * p.g[i] - 0.5 * p.step[i] * hr;
       if (!isfinite(p.step[i])) part = NAN;
     }
-    const double model_cost_change = block_sum(part, sh4);
+    double model_cost_change = block_sum(part, sh4);
+    double g0 = 0.0;
+    if (grouped) {
+      // the step of a group is valid / invalid as a whole: the directional derivative is formed before the verdict so that the
+      // three scalars travel in ONE sum (a member whose factorisation failed contributes NaN-free zeros and the flag)
+      double g0p = 0.0;
+      for (int e = tid; e < n; e += blockDim.x) {
+        const double dl = p.step[e] * p.scale[e];
+        p.delta[e] = dl;
+        g0p += p.gun[e] * dl;
+      }
+      g0 = block_sum(g0p, sh4);
+      double bad = ok ? 0.0 : 1.0, z = 0.0;
+      if (!ok) { model_cost_change = 0.0; g0 = 0.0; }
+      gsum4(model_cost_change, g0, bad, z);
+      ok = bad == 0.0;
+    }
     if (!(model_cost_change > 0.0)) ok = false;
     if (!ok) {
       if (++invalid >= opt.max_consecutive_invalid_steps) { sm.termination = PXR_TERM_FAILURE; break; }
@@ -1315,13 +1397,15 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       continue;
     }
     invalid = 0;
-    double g0p = 0.0;
-    for (int e = tid; e < n; e += blockDim.x) {
-      const double dl = p.step[e] * p.scale[e];
-      p.delta[e] = dl;
-      g0p += p.gun[e] * dl;
+    if (!grouped) {
+      double g0p = 0.0;
+      for (int e = tid; e < n; e += blockDim.x) {
+        const double dl = p.step[e] * p.scale[e];
+        p.delta[e] = dl;
+        g0p += p.gun[e] * dl;
+      }
+      g0 = block_sum(g0p, sh4);
     }
-    const double g0 = block_sum(g0p, sh4);
     KA_T(6);
     // DoLineSearch [upstream trust_region_minimizer.cc]: projected Armijo search along delta.  The
     // accepted probe IS the candidate point P(x + delta): its cost is reused instead of re-evaluated.
@@ -1380,7 +1464,9 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
         s2 += d * d; x2 += x0 * x0;
       }
     }
-    const double step_norm = sqrt(block_sum(s2, sh4)), x_norm = sqrt(block_sum(x2, sh4));
+    double s2g = block_sum(s2, sh4), x2g = block_sum(x2, sh4);
+    if (grouped) { double z2 = 0.0, z3 = 0.0; gsum4(s2g, x2g, z2, z3); }
+    const double step_norm = sqrt(s2g), x_norm = sqrt(x2g);
     KA_T(10);
     if (step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) { sm.termination = PXR_TERM_CONVERGENCE; break; }
     const double cost_change = cost - cand;
@@ -1398,8 +1484,11 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       }
       __syncthreads();
       cost = linearize(std::false_type{});
+      cost_loc = cost;
       ++sm.num_successful;
-      if (DET && sh_resc != 0.0) { sm.termination = KA_TERM_RESCALE; break; }     // (the accepted keypoints stay; the next launch goes on from them)
+      bool resc2 = DET && sh_resc != 0.0;
+      if (grouped) { double f = resc2 ? 1.0 : 0.0, z2 = 0.0, z3 = 0.0; gsum4(cost, f, z2, z3); resc2 = DET && f > 0.0; }
+      if (resc2) { sm.termination = KA_TERM_RESCALE; break; }     // (the accepted keypoints stay; the next launch goes on from them)
       const double tmp = 2.0 * rel - 1.0;
       radius = uniform_f64(fmin(opt.max_radius, radius / fmax(1.0 / 3.0, 1.0 - tmp * tmp * tmp)));
       decrease_factor = 2.0; reuse_diag = false;
@@ -1407,11 +1496,11 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
       radius = uniform_f64(radius / decrease_factor); decrease_factor = uniform_f64(decrease_factor * 2.0); reuse_diag = true;
     }
   }
-  sm.final_cost = cost; sm.final_radius = radius; sm.linear_iterations = stencils;
+  sm.final_cost = cost_loc; sm.final_radius = radius; sm.linear_iterations = stencils;
   if (tid == 0) {
     a.summaries[prob] = sm;
     if (DET) {
-      if (sm.termination == KA_TERM_RESCALE) a.prob_scale[prob] = sh_resc;
+      if (sm.termination == KA_TERM_RESCALE) a.prob_scale[prob] = sh_resc != 0.0 ? sh_resc : sh_grid;
       else a.prob_done[prob] = 1;
     }
   }
@@ -1576,6 +1665,25 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   const size_t o_hptr = carve(sizeof(int64_t) * (np + 1)), o_sum = carve(sizeof(pxr_lm_summary) * np);
   const size_t o_info = carve(sizeof(KaInfo) * np);
   const size_t o_pscale = carve(sizeof(double) * np), o_pdone = carve(np), o_slot = carve(sizeof(int) * nn);
+  // label groups spanning several workgroups (pxr_ka_view.d_prob_group)
+  std::vector<int> grp_first, grp_size;
+  int grp_max = 1;
+  if (view->d_prob_group) {
+    std::vector<int32_t> gid(np);
+    PXR_HIP(hipMemcpyAsync(gid.data(), view->d_prob_group, sizeof(int32_t) * np, hipMemcpyDeviceToHost, st));
+    PXR_HIP(hipStreamSynchronize(st));
+    grp_first.resize(np); grp_size.resize(np);
+    for (int i = 0; i < np;) {
+      int j = i;
+      while (j < np && gid[j] == gid[i]) ++j;
+      PXR_REQUIRE(j == np || gid[j] > gid[i], "pxr_ka_solve: d_prob_group must be non-decreasing (the chunks of a group are consecutive)");
+      for (int k = i; k < j; ++k) { grp_first[k] = i; grp_size[k] = j - i; }
+      grp_max = std::max(grp_max, j - i);
+      i = j;
+    }
+  }
+  const size_t o_gfirst = carve(sizeof(int) * np), o_gsize = carve(sizeof(int) * np);
+  const size_t o_gpart = carve(sizeof(double) * 2 * 4 * np), o_gcnt = carve(sizeof(unsigned) * KA_GRP_CNT_STRIDE * np);
   if (int rc = grow(&ctx->d_workspace, &ctx->workspace_bytes, off)) return rc;
   char* ws = static_cast<char*>(ctx->d_workspace);
   int64_t* d_hptr = (int64_t*)(ws + o_hptr);
@@ -1599,6 +1707,13 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   a.var_of_node = (int*)(ws + o_var); a.label = (int*)(ws + o_label); a.ipos = (int*)(ws + o_ipos);
   a.irow = (int*)(ws + o_irow); a.comp_v0 = (int*)(ws + o_comp); a.used = (uint8_t*)(ws + o_used);
   a.prob_h_ptr = d_hptr; a.summaries = d_sum; a.slot_of_node = (int*)(ws + o_slot);
+  if (grp_max > 1) {
+    a.grp_first = (const int*)(ws + o_gfirst); a.grp_size = (const int*)(ws + o_gsize);
+    a.grp_part = (double*)(ws + o_gpart); a.grp_cnt = (unsigned*)(ws + o_gcnt);
+    PXR_HIP(hipMemcpyAsync(ws + o_gfirst, grp_first.data(), sizeof(int) * np, hipMemcpyHostToDevice, st));
+    PXR_HIP(hipMemcpyAsync(ws + o_gsize, grp_size.data(), sizeof(int) * np, hipMemcpyHostToDevice, st));
+    PXR_HIP(hipStreamSynchronize(st));
+  }
   // 1. components, unknown layout, bounds; the block sizes come back to size the matrices exactly
   hipLaunchKernelGGL(ka_setup_kernel, dim3(np), dim3(KA_NT), 0, st, a, d_info);
   PXR_HIP(hipGetLastError());
@@ -1655,6 +1770,14 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
     void (*kfn)(const KaArgs, const KaInfo*) = a.det_scale != 0.0 ? KERNEL<ST, CC, true> : KERNEL<ST, CC, false>; \
     PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                                          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                    \
+    if (grp_max > 1) {   /* every member of a group must be resident at the same time (ka_group_sum4 spins) */ \
+      int per_cu = 0;                                                                                        \
+      PXR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kfn), KA_NT, shmem)); \
+      const int resident = per_cu * ctx->num_cus;                                                            \
+      if (grp_max > resident * 7 / 8)                                                                        \
+        return set_error(PXR_EUNSUPPORTED, "pxr_ka_solve: a label group of %d chunks exceeds what one launch keeps resident (%d workgroups): use smaller groups", grp_max, resident); \
+      PXR_HIP(hipMemsetAsync(a.grp_cnt, 0, sizeof(unsigned) * KA_GRP_CNT_STRIDE * np, st));                  \
+    }                                                                                                        \
     PXR_HIP(hipEventRecord(ctx->ev_start, st));                                                              \
     hipLaunchKernelGGL(kfn, dim3(np), dim3(KA_NT), shmem, st, a, d_info);                                    \
     PXR_HIP(hipEventRecord(ctx->ev_stop, st));                                                               \
@@ -1704,7 +1827,7 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   for (int i = 0; i < np; ++i) {   // AccumulateSummaries (util/src/statistics.h:131-160)
     total->initial_cost += sums[i].initial_cost; total->final_cost += sums[i].final_cost;
     total->iterations = std::max(total->iterations, sums[i].iterations);
-    total->num_successful += sums[i].num_successful;
+    if (grp_max <= 1 || grp_first[i] == i) total->num_successful += sums[i].num_successful;      // (a group's chunks all report the group's steps)
     total->num_point_unknowns += sums[i].num_camera_unknowns;
     total->linear_iterations += sums[i].linear_iterations;          // node stencils interpolated over the whole solve
     if (sums[i].termination == PXR_TERM_FAILURE) total->termination = PXR_TERM_FAILURE;

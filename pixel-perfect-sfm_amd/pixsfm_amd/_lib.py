@@ -72,7 +72,7 @@ class KaView(C.Structure):
                 ("d_prob_node_ptr", C.c_void_p), ("d_prob_nodes", C.c_void_p), ("d_prob_edge_ptr", C.c_void_p),
                 ("d_prob_edges", C.c_void_p), ("n_unary", C.c_int64), ("d_unary_node", C.c_void_p),
                 ("d_unary_ref", C.c_void_p), ("d_unary_w", C.c_void_p), ("d_prob_unary_ptr", C.c_void_p),
-                ("d_prob_unary", C.c_void_p)]
+                ("d_prob_unary", C.c_void_p), ("d_prob_group", C.c_void_p)]
 
 # every symbol include/pixsfm_hip.h declares (checked by tests/test_cabi.py)
 _SIGNATURES = {

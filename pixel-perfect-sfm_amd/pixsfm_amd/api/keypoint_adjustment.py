@@ -179,7 +179,11 @@ class FeatureMetricKeypointOptimizer:
             labels = np.where(in_solve, 0, -1).astype(np.int32)
         prob = dict(kp=kp, node_patch=np.arange(n, dtype=np.int64), node_const=node_const,
                     node_problem=labels, edge_src=np.array(src, np.int32), edge_dst=np.array(dst, np.int32),
-                    edge_w=np.array(w, np.float64))
+                    edge_w=np.array(w, np.float64),
+                    # a label group of many keypoints (max_kps_per_problem = 1000 of configs/low_memory.yaml, or ONE problem with
+                    # split_in_subproblems = false) is solved as chunks of whole tracks on several workgroups that share its trust
+                    # region (ka_engine.chunk_label_groups, pxr_ka_view.d_prob_group): the tracks say where it may be cut
+                    node_track=np.asarray(track_labels, dtype=np.int64))
         s = o['solver']
         lm = lm_options(max_iterations=s['max_num_iterations'], function_tolerance=s['function_tolerance'],
                         gradient_tolerance=s['gradient_tolerance'], parameter_tolerance=s['parameter_tolerance'],

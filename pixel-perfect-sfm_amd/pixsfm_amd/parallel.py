@@ -300,6 +300,8 @@ def shard_ka_problem(problem, rank, world):
                  edge_dst=new_node[edge_dst[edge_sel]].astype(np.int32),
                  edge_w=np.asarray(problem["edge_w"], dtype=np.float64)[edge_sel],
                  patch_ids=node_patch, edge_ids=edge_sel)
+    if problem.get("node_track") is not None:
+        shard["node_track"] = np.asarray(problem["node_track"], dtype=np.int64)[node_sel]
     if len(edge_sel) and (shard["edge_dst"] < 0).any():
         raise ValueError("an edge connects two different sub-problems")
     for k in ("patches", "corners", "scales"):

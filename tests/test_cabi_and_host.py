@@ -41,7 +41,7 @@ def test_struct_layouts_match_the_header_sizes():
     assert ctypes.sizeof(_lib.InterpCfg) == 12
     assert ctypes.sizeof(_lib.Loss) == 16
     assert ctypes.sizeof(_lib.BaView) == 8 * 14
-    assert ctypes.sizeof(_lib.KaView) == 8 * 19
+    assert ctypes.sizeof(_lib.KaView) == 8 * 20
     assert ctypes.sizeof(_lib.LMOptions) == 8 * 16
     assert ctypes.sizeof(_lib.LMSummary) == 8 * 10
 

@@ -252,3 +252,93 @@ def test_all_constant_sub_problem_reports_its_cost(ctx):
     assert per[frozen]["final_cost"] == per[frozen]["initial_cost"]
     assert np.array_equal(ka.keypoints()[prob["node_problem"] == frozen], prob["kp"][prob["node_problem"] == frozen])
     assert np.abs(ka.keypoints() - kpo).max() < 1e-6
+
+
+# ---- label groups that span several workgroups (pxr_ka_view.d_prob_group, round 6) ----------------------------------------------
+def _grouped(ctx, prob):
+    """the same problem twice: its label groups on ONE workgroup each, and chunked by tracks (node_track given)"""
+    from pixsfm_amd.engine import PatchArena
+    from pixsfm_amd.ka_engine import KAProblem
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    single = KAProblem(ctx, arena, prob)
+    chunked = KAProblem(ctx, arena, dict(prob, node_track=prob["track_of_node"]))
+    return arena, single, chunked
+
+
+@pytest.mark.parametrize("bound,sigma", [(4.0, 1.0), (1.5, 1.5)])
+def test_chunked_label_group_takes_the_decisions_of_one_problem(ctx, bound, sigma):
+    """One label group of 300 keypoints (60 tracks): as ONE sub-problem on one workgroup, and as 8 chunks of whole tracks on 8
+    workgroups that share the trust region.  Same iterations, accepted steps, termination and costs as the oracle's solve of
+    the one problem (one Ceres problem in the reference: keypoint_adjustment/main.py:197-202 with split_in_subproblems = false,
+    or a 1000-keypoint group of configs/low_memory.yaml); keypoints to 1e-6 px.  sigma 1.5 / bound 1.5: active bounds, twenty-probe
+    line searches -- every probe's cost is a sum over the chunks."""
+    import pxo
+    import pxo_ka
+    from pixsfm_amd import synthetic_ka
+    from pixsfm_amd.engine import interp_cfg, lm_options, make_loss
+    prob = synthetic_ka.make_ka_problem(n_tracks=60, track_len=5, seed=21, max_kps_per_problem=100000, sigma=sigma)
+    assert prob["n_problems"] == 1
+    arena, single, chunked = _grouped(ctx, prob)
+    assert chunked.problem_group is not None and len(chunked.problem_group) == 6 and single.problem_group is None
+    opts = lm_options(parameter_tolerance=1e-5)
+    t1, p1 = single.solve(interp_cfg(), make_loss("cauchy", [0.25]), bound=bound, options=opts, per_problem=True)
+    t2, p2 = chunked.solve(interp_cfg(), make_loss("cauchy", [0.25]), bound=bound, options=opts, per_problem=True)
+    kpo, sums = pxo_ka.ka_solve(prob, pxo.cfg(), pxo.loss("cauchy", 0.25), bound, pxo.lm_options(parameter_tolerance=1e-5))
+    assert len(p2) == 1 == len(sums)
+    for got in (p1[0], p2[0]):
+        assert got["iterations"] == sums[0]["iterations"] and got["num_successful"] == sums[0]["num_successful"]
+        assert got["termination"] == sums[0]["termination"]
+        assert abs(got["initial_cost"] - sums[0]["initial_cost"]) < 1e-10 * sums[0]["initial_cost"]
+        assert abs(got["final_cost"] - sums[0]["final_cost"]) < 1e-7 * max(sums[0]["final_cost"], 1e-6)
+    assert t2["iterations"] == t1["iterations"] and t2["num_successful"] == t1["num_successful"]
+    assert np.abs(chunked.keypoints() - kpo).max() < 1e-6 and np.abs(single.keypoints() - kpo).max() < 1e-6
+    assert np.abs(chunked.keypoints() - single.keypoints()).max() < 1e-8
+    arena.close()
+
+
+def test_chunked_groups_of_different_sizes_next_to_small_ones_and_twice_the_same_bits(ctx):
+    """Three label groups: 200 keypoints (4 chunks), 40 keypoints (stays one sub-problem), 130 keypoints (3 chunks).  Every group
+    ends like the oracle's solve of that group as one problem; the deterministic default gives the same bits on a second run."""
+    import pxo
+    import pxo_ka
+    from pixsfm_amd import synthetic_ka
+    from pixsfm_amd.engine import PatchArena, interp_cfg, lm_options, make_loss
+    from pixsfm_amd.ka_engine import KAProblem
+    prob = synthetic_ka.make_ka_problem(n_tracks=74, track_len=5, seed=33, max_kps_per_problem=100000)
+    track = prob["track_of_node"]
+    prob["node_problem"] = np.where(track < 40, 0, np.where(track < 48, 1, 2)).astype(np.int32)
+    prob["n_problems"] = 3
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    out = []
+    for _ in range(2):
+        ka = KAProblem(ctx, arena, dict(prob, node_track=track))
+        assert ka.problem_group.tolist() == [0, 0, 0, 0, 1, 2, 2, 2]
+        total, per = ka.solve(interp_cfg(), make_loss("cauchy", [0.25]), bound=4.0, options=lm_options(parameter_tolerance=1e-5), per_problem=True)
+        out.append((ka.keypoints(), total, per))
+    kpo, sums = pxo_ka.ka_solve(prob, pxo.cfg(), pxo.loss("cauchy", 0.25), 4.0, pxo.lm_options(parameter_tolerance=1e-5))
+    kp, total, per = out[0]
+    assert len(per) == 3
+    for g, o in zip(per, sums):
+        assert g["iterations"] == o["iterations"] and g["num_successful"] == o["num_successful"] and g["termination"] == o["termination"]
+        assert abs(g["final_cost"] - o["final_cost"]) < 1e-7 * max(o["final_cost"], 1e-6)
+    assert np.abs(kp - kpo).max() < 1e-6
+    assert total["num_successful"] == sum(o["num_successful"] for o in sums)
+    assert ctx.deterministic and np.array_equal(out[0][0], out[1][0]) and out[0][1]["final_cost"] == out[1][1]["final_cost"]
+    arena.close()
+
+
+def test_a_group_with_too_many_chunks_is_refused_through_the_c_abi(ctx):
+    """More chunks in one group than a launch keeps resident: the spin-waits of the group sums could deadlock, so the C-ABI
+    refuses (the Python layer never builds such a view: chunk_label_groups leaves such a group on one workgroup)."""
+    from pixsfm_amd import PixsfmHipError, synthetic_ka
+    from pixsfm_amd.engine import PatchArena, interp_cfg, make_loss
+    from pixsfm_amd.ka_engine import KAProblem
+    prob = synthetic_ka.make_ka_problem(n_tracks=600, track_len=2, seed=3, max_kps_per_problem=2, channels=64)
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    ka = KAProblem(ctx, arena, prob)
+    assert ka.n_problems == 600
+    ka.d["prob_group"] = ctx.to_device(np.zeros(600, np.int32), np.int32)
+    ka.view.d_prob_group = ka.d["prob_group"].ptr
+    with pytest.raises(PixsfmHipError, match="resident"):
+        ka.solve(interp_cfg(), make_loss("cauchy", [0.25]))
+    arena.close()

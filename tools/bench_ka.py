@@ -21,7 +21,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def make_problem_gpu(dev, n_tracks, track_len, C=128, PS=16, seed=1, sigma=1.0, chunk=16384):
+def make_problem_gpu(dev, n_tracks, track_len, C=128, PS=16, seed=1, sigma=1.0, chunk=16384, max_kps_per_problem=50,
+                     strategy="featuremetric"):
+    """max_kps_per_problem: pixsfm's KeypointAdjuster option (50 by default, 1000 in configs/low_memory.yaml; 0 = ONE problem,
+    split_in_subproblems = false, keypoint_adjustment/main.py:197-202).  strategy "topological_reference"
+    (topological_reference_keypoint_optimizer.h:8-15): edges to the track's root only, unit weights."""
     from pixsfm_amd import synthetic
     from pixsfm_amd.ka_engine import pack_tracks_into_problems
     rng = np.random.default_rng(seed)
@@ -54,9 +58,15 @@ def make_problem_gpu(dev, n_tracks, track_len, C=128, PS=16, seed=1, sigma=1.0, 
     score = np.zeros(n); np.add.at(score, edge_src, edge_w); np.add.at(score, edge_dst, edge_w)
     node_const = np.zeros(n, np.uint8)
     node_const[(np.arange(n_tracks) * track_len) + score.reshape(n_tracks, track_len).argmax(1)] = 1
-    labels, bins = pack_tracks_into_problems(track, 50)
+    if strategy == "topological_reference":       # root_edges_only, weight_by_sim = false
+        keep = (node_const[edge_src] | node_const[edge_dst]).astype(bool)
+        edge_src, edge_dst, edge_w = edge_src[keep], edge_dst[keep], np.ones(int(keep.sum()))
+    if max_kps_per_problem > 0:
+        labels, bins = pack_tracks_into_problems(track, max_kps_per_problem)
+    else:
+        labels, bins = np.zeros(n, np.int32), [0]
     return dict(kp=kp0, node_patch=np.arange(n, dtype=np.int64), node_const=node_const,
-                node_problem=np.array(labels, np.int32), edge_src=edge_src, edge_dst=edge_dst, edge_w=edge_w,
+                node_problem=np.array(labels, np.int32), node_track=track, edge_src=edge_src, edge_dst=edge_dst, edge_w=edge_w,
                 corners=corners, scales=np.ones((n, 2)), true_xy=true_xy, n_problems=len(bins)), patches
 
 
@@ -90,7 +100,8 @@ def cpu_legs_on_sample(prob, patches, dev):
     return out
 
 
-def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, world=1, cpu_legs=False, telemetry=None, solves=8):
+def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, world=1, cpu_legs=False, telemetry=None, solves=8,
+        max_kps_per_problem=50, patch_size=16, bound=4.0, strategy="featuremetric", chunk_groups=True):
     """Runs the KA benchmark and returns its result dict (bench.py attaches it as "ka").
     world > 1 (torch.distributed initialised by the caller): STRONG scaling of BASELINE configs[1] -- the sub-problems
     are dealt to the ranks (parallel.shard_ka_problem, SURVEY 8e: no collective during the solve), every rank times its
@@ -102,7 +113,9 @@ def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, 
     from pixsfm_amd.ka_engine import KAProblem
     dev = "cuda:%d" % device_index
     torch.cuda.set_device(device_index)
-    prob, patches = make_problem_gpu(dev, args.tracks, args.track_len)
+    prob, patches = make_problem_gpu(dev, args.tracks, args.track_len, PS=patch_size, max_kps_per_problem=max_kps_per_problem, strategy=strategy)
+    if not chunk_groups:
+        prob.pop("node_track")          # every label group on ONE workgroup (the form of rounds 1-5)
     ctx = ctx or Context(device_index, stream=torch.cuda.current_stream().cuda_stream)
     full, node_ids = prob, np.arange(len(prob["kp"]))
     if world > 1:
@@ -127,7 +140,7 @@ def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, 
         dist.all_reduce(t)
         return t.item()
     n = len(prob["kp"])
-    arena = PatchArena(ctx, n, 16, 16, 128, np.float16, device_ptr=patches.data_ptr())
+    arena = PatchArena(ctx, n, patch_size, patch_size, 128, np.float16, device_ptr=patches.data_ptr())
     arena.upload(0, None, prob["corners"], prob["scales"])
     ka = KAProblem(ctx, arena, prob)
     cfg, ls = interp_cfg(), make_loss("cauchy", [0.25])
@@ -139,7 +152,7 @@ def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, 
     ms = slowest(ctx.timer_stop() / args.steps)
     c0 = summed(float(cost.download().sum()))
     cpu = cpu_legs_on_sample(prob, patches, dev) if (cpu_legs and world == 1) else None
-    cold, _ = ka.solve(cfg, ls, bound=4.0)          # first call: grows the context workspace
+    cold, _ = ka.solve(cfg, ls, bound=bound)          # first call: grows the context workspace
     ka.d["kp"].upload(np.ascontiguousarray(prob["kp"], dtype=np.float64))
     ctx.sync()
     if world > 1:
@@ -154,7 +167,7 @@ def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, 
             ka.d["kp"].upload(kp_init)
             ctx.sync()
             t0 = time.perf_counter()
-            s, _ = ka.solve(cfg, ls, bound=4.0)
+            s, _ = ka.solve(cfg, ls, bound=bound)
             walls.append(time.perf_counter() - t0)
             runs.append(s)
     tel = telemetry.sample_while(loop, interval=0.002) if (telemetry is not None and rank == 0) else (loop() or None)
@@ -184,8 +197,11 @@ def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, 
     off = (prob["kp"][root] - prob["true_xy"][root]).repeat(tl, axis=0)
     err0 = np.linalg.norm(prob["kp"] - (prob["true_xy"] + off), axis=1)
     err1 = np.linalg.norm(kp - (prob["true_xy"] + off), axis=1)
-    out = {"workload": "BASELINE.json configs[1]: %d tracks x %d nodes, %d edges, %d sub-problems, 128-ch fp16 16x16"
-                       % (args.tracks, tl, n_edges_total, n_problems_total),
+    out = {"workload": "BASELINE.json configs[1]: %d tracks x %d nodes, %d edges, %d sub-problems, 128-ch fp16 %dx%d"
+                       % (args.tracks, tl, n_edges_total, n_problems_total, patch_size, patch_size),
+           "options": {"max_kps_per_problem": max_kps_per_problem, "patch_size": patch_size, "bound": bound, "strategy": strategy,
+                       "label_groups": int(ka.n_labels), "workgroups": int(ka.n_problems),
+                       "groups_chunked_over_workgroups": bool(ka.problem_group is not None)},
            "n_gpus": world, "partition": "sub-problems dealt to the ranks by edge count, no collective in the solve" if world > 1 else "none",
            "gather_ms": gather_ms,
            "edge_eval": {"edges_per_s": n_edges_total / (ms * 1e-3), "kernel_ms": ms,
@@ -203,7 +219,7 @@ def run(tracks=10000, track_len=10, steps=20, device_index=0, ctx=None, rank=0, 
     # counts them (summary.linear_iterations).  HBM peak from MI355X_MICROARCH.md.
     kernel_ms = out["solve"]["kernel_ms"]
     stencils = int(total["linear_iterations"])
-    bytes_solve = stencils * 16 * 128 * 2
+    bytes_solve = stencils * 16 * 128 * 2          # (a 4 x 4 stencil whatever the patch size)
     ach = bytes_solve / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                        "kernel": "ka_solve_kernel_occ2<f16,128>", "kernel_ms": kernel_ms, "algorithmic_bytes": bytes_solve,
@@ -225,8 +241,15 @@ def main():
     ap.add_argument("--tracks", type=int, default=10000)
     ap.add_argument("--track-len", type=int, default=10)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--solves", type=int, default=8)
+    ap.add_argument("--max-kps-per-problem", type=int, default=50, help="50: pixsfm's default; 1000: configs/low_memory.yaml; 0: one problem (split_in_subproblems = false)")
+    ap.add_argument("--patch-size", type=int, default=16, help="16: default; 8: configs/low_memory.yaml")
+    ap.add_argument("--bound", type=float, default=4.0, help="4.0: default; 2.0: configs/low_memory.yaml")
+    ap.add_argument("--strategy", choices=("featuremetric", "topological_reference"), default="featuremetric")
+    ap.add_argument("--no-chunk", action="store_true", help="keep every label group on one workgroup (rounds 1-5)")
     args = ap.parse_args()
-    print(json.dumps(run(args.tracks, args.track_len, args.steps)))
+    print(json.dumps(run(args.tracks, args.track_len, args.steps, solves=args.solves, max_kps_per_problem=args.max_kps_per_problem,
+                         patch_size=args.patch_size, bound=args.bound, strategy=args.strategy, chunk_groups=not args.no_chunk)))
 
 
 if __name__ == "__main__":

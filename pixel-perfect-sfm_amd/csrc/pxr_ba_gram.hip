@@ -273,7 +273,8 @@ int gram_eval_prepare(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, G
   if (ctx->gram_bytes < need) {          // grow-only, like the KA workspace: no hipMalloc per solve
     if (ctx->d_gram) PXR_HIP(hipFree(ctx->d_gram));
     ctx->d_gram = nullptr; ctx->gram_bytes = 0;
-    if (hipMalloc(&ctx->d_gram, need) != hipSuccess) { (void)hipGetLastError(); return set_error(PXR_ENOMEM, "Gram-matrix cache: %zu bytes", need); }
+    // (PXR_GRAM_FAIL_ALLOC=1: the tests' way of running out of memory here)
+    if (getenv("PXR_GRAM_FAIL_ALLOC") != nullptr || hipMalloc(&ctx->d_gram, need) != hipSuccess) { (void)hipGetLastError(); return set_error(PXR_ENOMEM, "Gram-matrix cache: %zu bytes", need); }
     ctx->gram_bytes = need;
   }
   gram_layout(ctx->d_gram, n, np, out, &need);

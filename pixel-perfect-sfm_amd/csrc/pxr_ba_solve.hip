@@ -1412,7 +1412,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   //  needs no care: with reference descriptors the functor ignores the bounds check, feature_reference.h:128-136.)
   // (InterpolationConfig.use_float_simd asks for the reference's ALL-fp32 splines: the Gram-matrix paths -- exact fp64 algebra -- would
   // silently compute something finer; a solve with that flag keeps the texel kernels, which have the fp32 arithmetic bit for bit)
-  const bool gram_cache = ctx->gram_cache && gram_eval_supported(arena, view) && cfg->use_float_simd == 0;
+  bool gram_cache = ctx->gram_cache && gram_eval_supported(arena, view) && cfg->use_float_simd == 0;
   // The Gram-matrix kernel of the inner iterations keeps its matrices in the same cache from call to call (it writes back what
   // it builds), whether or not the LM loop evaluates from them: the same numbers as without a cache, fewer builds.  (That kernel
   // is built without the six extended camera models -- their forward-mode duals cost ~100 registers: a problem that uses one
@@ -1422,10 +1422,12 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   for (int c = 0; c < n_cam; ++c) gram_inner = gram_inner && cam_model[c] <= PXR_OPENCV;
   bool inner_cache = gram_inner && gram_eval_supported(arena, view) && !getenv("PXR_INNER_NO_CACHE");
   GramCache gram;
-  if (gram_cache) RC(gram_eval_prepare(ctx, arena, view, &gram));
-  else if (inner_cache && gram_eval_prepare(ctx, arena, view, &gram) != PXR_OK) {
-    inner_cache = false;            // no memory for it: the kernel builds at every call -- not an error of this solve,
-    (void)set_error(PXR_OK, "");    // so pxr_last_error() must not keep the allocation's message
+  if ((gram_cache || inner_cache) && gram_eval_prepare(ctx, arena, view, &gram) != PXR_OK) {
+    // no memory for the cache (1.4 KB per observation, next to the solver's own buffers): not an error of this solve -- a problem
+    // that fitted before the cache became the default must still run.  The LM loop evaluates from the texels (the exact-order
+    // kernel), the inner iterations build their matrices at every call.
+    gram_cache = false; inner_cache = false;
+    (void)set_error(PXR_OK, "");    // pxr_last_error() must not keep the allocation's message
   }
   bool gram_warm = false;               // the cache holds every observation's matrices (after the first evaluation / inner call)
   int n_evaluations = 0;

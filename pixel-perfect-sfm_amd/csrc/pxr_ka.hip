@@ -66,6 +66,7 @@ struct KaArgs {
   int stream_slots;            // > 0: the line-search probes run as ka_probe_stream (every sub-problem has at most this many nodes, <= 64,
                                // all its residual blocks in the LDS cache, no unary terms); its LDS region follows the LM state
   int stream_off;              // doubles from sh_A to that region
+  double* prob_state = nullptr;     // deterministic mode, [n_problems][KA_STATE]: LM state parked by a sub-problem that stopped with KA_TERM_RESCALE after an accepted step
   // ---- label groups that span several workgroups (round 6) -----------------------------------------------------------------
   // A label group of the caller (ONE ceres::Problem of the reference: one trust region, one line search, one termination) may
   // be handed over as several CHUNKS -- consecutive sub-problems that share no variable (whole tracks each): pxr_ka_view.
@@ -114,6 +115,7 @@ __device__ __noinline__ void ka_group_sum4(const KaGroup g, unsigned gen, double
   }
   __syncthreads();
 }
+constexpr int KA_STATE = 8;            // has_state, radius, iterations, accepted steps, initial cost, stencils
 constexpr int KA_TERM_RESCALE = 100;   // internal termination code: the sub-problem's fixed-point grid did not fit, launch again
 
 // Channel layout of a node over lanes: 8 channels per lane (one 16-byte fp16 load) for the CNN feature sizes, and the
@@ -1223,8 +1225,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   // the algorithmic traffic of the solve is 16 texels x C x sizeof(storage) each, reported as summary.linear_iterations
   int64_t stencils = 0;
   const int64_t nodes_all = p.np1 - p.np0, nodes_var = n / 2;
-  auto linearize = [&](auto first_tag) -> double {
-    constexpr bool compute_scale = decltype(first_tag)::value;      // the FIRST linearisation of the solve
+  auto linearize = [&](const bool compute_scale) -> double {        // compute_scale: the FIRST linearisation of the solve
     stencils += nodes_all;
     for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = 0.0;
     for (int e = tid; e < n; e += blockDim.x) p.g[e] = 0.0;
@@ -1300,7 +1301,17 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     if (tid == 0) { a.summaries[prob] = sm; if (DET) a.prob_done[prob] = 1; }
     return;
   }
-  double cost = linearize(std::true_type{});
+  // A sub-problem that an earlier launch of this solve left with KA_TERM_RESCALE after an ACCEPTED step goes on where it stopped:
+  // its Jacobi scaling (fixed at the first linearisation of the solve, [upstream]), radius, decrease factor and counts were
+  // parked in prob_state / the global scale vector (it used to start over with a fresh trust region).
+  const double* const pst = a.prob_state + (size_t)prob * KA_STATE;
+  const bool resumed = DET && pst[0] != 0.0;
+  if (resumed) {
+    const double* scale_g = a.vec + 2 * vstride + vb;
+    for (int e = tid; e < n; e += blockDim.x) p.scale[e] = scale_g[e];
+    __syncthreads();
+  }
+  double cost = linearize(!resumed);
   double cost_loc = cost;              // this member's part of the group's cost (what its summary reports: the host adds them up)
   sm.initial_cost = cost_loc;
   bool resc = DET && sh_resc != 0.0, infeasible = !inf.feasible;
@@ -1323,6 +1334,9 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   double radius = opt.initial_radius, decrease_factor = 2.0;
   int invalid = 0;
   bool reuse_diag = false;
+  if (resumed) {
+    radius = uniform_f64(pst[1]); sm.iterations = (int)pst[2]; sm.num_successful = (int)pst[3]; sm.initial_cost = pst[4]; stencils += (int64_t)pst[5];
+  }
   while (true) {
     if (sm.iterations >= opt.max_iterations) { sm.termination = PXR_TERM_NO_CONVERGENCE; break; }
     if (radius < opt.min_radius) { sm.termination = PXR_TERM_CONVERGENCE; break; }
@@ -1483,15 +1497,24 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
 #endif
       }
       __syncthreads();
-      cost = linearize(std::false_type{});
+      cost = linearize(false);
       cost_loc = cost;
       ++sm.num_successful;
-      bool resc2 = DET && sh_resc != 0.0;
-      if (grouped) { double f = resc2 ? 1.0 : 0.0, z2 = 0.0, z3 = 0.0; gsum4(cost, f, z2, z3); resc2 = DET && f > 0.0; }
-      if (resc2) { sm.termination = KA_TERM_RESCALE; break; }     // (the accepted keypoints stay; the next launch goes on from them)
       const double tmp = 2.0 * rel - 1.0;
       radius = uniform_f64(fmin(opt.max_radius, radius / fmax(1.0 / 3.0, 1.0 - tmp * tmp * tmp)));
       decrease_factor = 2.0; reuse_diag = false;
+      bool resc2 = DET && sh_resc != 0.0;
+      if (grouped) { double f = resc2 ? 1.0 : 0.0, z2 = 0.0, z3 = 0.0; gsum4(cost, f, z2, z3); resc2 = DET && f > 0.0; }
+      if (resc2) {       // the accepted keypoints stay; the LM state is parked and the next launch goes on from here
+        sm.termination = KA_TERM_RESCALE;
+        double* scale_g = a.vec + 2 * vstride + vb;
+        for (int e = tid; e < n; e += blockDim.x) scale_g[e] = p.scale[e];
+        if (tid == 0) {
+          double* st = a.prob_state + (size_t)prob * KA_STATE;
+          st[0] = 1.0; st[1] = radius; st[2] = (double)sm.iterations; st[3] = (double)sm.num_successful; st[4] = sm.initial_cost; st[5] = (double)stencils;
+        }
+        break;
+      }
     } else {
       radius = uniform_f64(radius / decrease_factor); decrease_factor = uniform_f64(decrease_factor * 2.0); reuse_diag = true;
     }
@@ -1651,7 +1674,13 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
     if (want <= *have) return PXR_OK;
     PXR_HIP(hipStreamSynchronize(st));
     if (*buf) { PXR_HIP(hipFree(*buf)); *buf = nullptr; *have = 0; }
-    PXR_HIP(hipMalloc(buf, want));
+    if (hipMalloc(buf, want) != hipSuccess) {
+      // the BA solver's Gram-matrix cache stays on the context between solves (grow-only, 1.4 GB at 1M observations): give it
+      // back before giving up
+      (void)hipGetLastError();
+      if (ctx->d_gram) { (void)hipFree(ctx->d_gram); ctx->d_gram = nullptr; ctx->gram_bytes = 0; }
+      PXR_HIP(hipMalloc(buf, want));
+    }
     *have = want;
     return PXR_OK;
   };
@@ -1682,6 +1711,7 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
       i = j;
     }
   }
+  const size_t o_pstate = carve(sizeof(double) * KA_STATE * np);
   const size_t o_gfirst = carve(sizeof(int) * np), o_gsize = carve(sizeof(int) * np);
   const size_t o_gpart = carve(sizeof(double) * 2 * 4 * np), o_gcnt = carve(sizeof(unsigned) * KA_GRP_CNT_STRIDE * np);
   if (int rc = grow(&ctx->d_workspace, &ctx->workspace_bytes, off)) return rc;
@@ -1697,6 +1727,8 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   // (bound = max(trace, sqrt(2 trace cost)) ~ 1e4 .. 1e5 at configs[1]), the kernel adapts it per sub-problem and linearisation
   a.det_scale = ctx->deterministic ? 274877906944.0 : 0.0;      // 2^38 (see the grid rule in ka_solve_body)
   a.prob_scale = (double*)(ws + o_pscale); a.prob_done = (uint8_t*)(ws + o_pdone);
+  a.prob_state = (double*)(ws + o_pstate);
+  PXR_HIP(hipMemsetAsync(a.prob_state, 0, sizeof(double) * KA_STATE * np, st));
   if (a.det_scale != 0.0) {
     std::vector<double> init((size_t)np, a.det_scale);
     PXR_HIP(hipMemcpyAsync(a.prob_scale, init.data(), sizeof(double) * np, hipMemcpyHostToDevice, st));
@@ -1808,12 +1840,12 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
     bool again = false;
     for (int i = 0; i < np; ++i) {
       if (launch == 0) { sums[i] = pass[i]; }
-      else if (sums[i].termination == KA_TERM_RESCALE) {        // this launch continued sub-problem i: merge
+      else if (sums[i].termination == KA_TERM_RESCALE) {        // this launch continued sub-problem i
         const pxr_lm_summary before = sums[i];
         sums[i] = pass[i];
-        sums[i].initial_cost = before.initial_cost;
-        sums[i].iterations += before.iterations; sums[i].num_successful += before.num_successful;
-        sums[i].linear_iterations += before.linear_iterations;
+        // (a sub-problem that had accepted steps resumed from its parked state and reports the running totals itself; one
+        //  that stopped at its very first linearisation had done nothing but count its stencils)
+        if (before.num_successful == 0) sums[i].linear_iterations += before.linear_iterations;
       }
       again = again || sums[i].termination == KA_TERM_RESCALE;
     }

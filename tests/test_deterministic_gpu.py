@@ -253,6 +253,8 @@ def test_ka_fixed_point_grid_follows_the_data(fast_ctx, det_ctx, scale):
     assert np.isfinite(t0["final_cost"]) and t0["final_cost"] < t0["initial_cost"]
     assert abs(t0["initial_cost"] - tf["initial_cost"]) <= 1e-12 * tf["initial_cost"]
     assert abs(t0["final_cost"] - tf["final_cost"]) < 1e-6 * tf["initial_cost"]
-    same = np.array([a["iterations"] == b["iterations"] for a, b in zip(perf, per0)])
-    assert same.mean() >= 0.9
-    assert np.abs(kpf - kp0)[same[prob["node_problem"]]].max() < 1e-4
+    # (round 6: a sub-problem that asks for a coarser grid after an accepted step parks its LM state -- Jacobi scaling, radius,
+    #  counts -- and the next launch resumes it: the same trajectory as the uninterrupted floating-point solve, everywhere)
+    same = np.array([a["iterations"] == b["iterations"] and a["num_successful"] == b["num_successful"] for a, b in zip(perf, per0)])
+    assert same.all()
+    assert np.abs(kpf - kp0).max() < 1e-9

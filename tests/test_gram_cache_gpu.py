@@ -241,3 +241,33 @@ def test_gram_records_match_the_oracles_functor(ctx, storage):
         arena.close()
     assert n_checked == len(gen.ba_cases()) and models == {0, 1, 2, 3, 4}
     assert worst < GRAM_VS_REFERENCE_SEEN, worst
+
+
+def test_solve_survives_a_failed_cache_allocation(monkeypatch):
+    """the cache is on by default and costs 1.4 KB per observation; when its allocation fails the solve must fall back to
+    the texel evaluation (what PXR_GRAM_CACHE=0 runs) instead of returning PXR_ENOMEM -- same bits as a context with the cache
+    switched off, and no stale error message."""
+    from pixsfm_amd import _lib, synthetic
+    from pixsfm_amd.engine import BAProblem, Context, PatchArena, interp_cfg, lm_options, make_loss
+    from test_ba_solve_gpu import _gauge
+    prob = synthetic.make_ba_problem(n_cams=6, n_points=80, obs_per_point=4, seed=42)
+    out = []
+    for fail in (False, True):
+        c = Context(0)
+        if fail:
+            monkeypatch.setenv("PXR_GRAM_FAIL_ALLOC", "1")
+            assert c.gram_cache
+        else:
+            c.gram_cache = False
+        arena = PatchArena.from_numpy(c, prob["patches"], prob["corners"], prob["scales"])
+        ba = BAProblem(c, arena, prob)
+        s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *_gauge(prob), options=lm_options(max_iterations=6, use_inner_iterations=True))
+        out.append((s, ba.params()))
+        if fail:
+            assert _lib.load().pxr_last_error() in (b"", None)
+        arena.close(); c.close()
+    monkeypatch.delenv("PXR_GRAM_FAIL_ALLOC")
+    (s0, p0), (s1, p1) = out
+    assert s1["final_cost"] == s0["final_cost"] and s1["iterations"] == s0["iterations"]
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b)

@@ -9,7 +9,10 @@ coalesced reads, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE (KB) is taken
 import csv
 import glob
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def mean_counter(root, pattern, counter):
@@ -23,8 +26,16 @@ def mean_counter(root, pattern, counter):
     return sum(vals) / len(vals), len(vals)
 
 
+def blob_hash(path):
+    """what `git hash-object` prints (the box that collects the counters has no .git)"""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 fetch_dir, write_dir, pattern, out, cmd = sys.argv[1:6]
 commit = sys.argv[6] if len(sys.argv) > 6 else "unrecorded"
+sources = sys.argv[7:]            # the kernel's source files (paths relative to the repository root): their hashes gate staleness
 f, nf = mean_counter(fetch_dir, pattern, "FETCH_SIZE")
 w, nw = mean_counter(write_dir, pattern, "WRITE_SIZE")
 rd, wr = 2.0 * f * 1024.0, w * 1024.0
@@ -32,6 +43,7 @@ res = {"kernel": pattern, "FETCH_SIZE_KB_per_launch_raw": f, "n_fetch_samples": 
        "n_write_samples": nw,
        "correction": "gfx950: read bytes = 2 x FETCH_SIZE x 1024 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported",
        "measured_at_commit": commit,
+       "source_hashes": {os.path.relpath(s, ROOT): blob_hash(s) for s in sources},
        "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
        "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- " + cmd,
                     "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- " + cmd]}

@@ -1564,7 +1564,8 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   // LDS-privatised Schur contraction: column tile so that DC x CT doubles fit in 128 KiB of LDS
   const bool use_lds_schur = std::getenv("PXR_SCHUR_GLOBAL_ATOMICS") == nullptr;
   int CT = n_c > 0 ? std::min(n_c, (int)((128 * 1024 / 8 - DC) / DC)) : 1;
-  const int n_ctiles = n_c > 0 ? (n_c + CT - 1) / CT : 1;
+  int n_ctiles = n_c > 0 ? (n_c + CT - 1) / CT : 1;
+  if (const char* e = std::getenv("PXR_SCHUR_CTILES")) n_ctiles = std::max(n_ctiles, std::min(std::max(1, n_c), std::atoi(e)));   // A/B knob (profiles/r6_schur_tiles.txt)
   CT = n_c > 0 ? (n_c + n_ctiles - 1) / n_ctiles : 1;       // balance the tiles
   const size_t schur_shmem = sizeof(double) * ((size_t)DC * CT + DC + 3 * 1024);   // tile, right-hand side, the lane groups' Y rows
   if (use_lds_schur && n_c > 0)

@@ -227,6 +227,12 @@ typedef struct {
   int64_t linear_iterations; /* pxr_ba_solve: conjugate-gradient iterations summed over the LM attempts (iterative solver);
                                 pxr_ka_solve: node stencils (4 x 4 texels x C) interpolated over the solve -- its
                                 algorithmic traffic is that count x 16 x C x sizeof(storage type)                 */
+  int32_t accumulation;      /* how the sums over observations / points / ranks were formed in THIS solve: 1 = fixed-point integers
+                                (the deterministic default: same bits for every run, launch shape and rank count), 2 = ordered
+                                partial sums (the iterative solver's deterministic form: same bits per rank count), 0 = floating-
+                                point atomics (pxr_set_deterministic(ctx, 0), or a direct solve WITHOUT Jacobi scaling, whose
+                                columns no single grid can serve -- pxr_get_deterministic() alone does not tell)        */
+  int32_t reserved;
 } pxr_lm_summary;
 
 /* ceres::IterationCallback of the BA solve (the `solver.callbacks` of pixsfm's option dicts, base/src/callbacks.h; the

@@ -1337,6 +1337,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   // ranks (the ranks' parts are all-reduced as doubles: the result depends on how the points are dealt to ranks, not on the run).
   const bool det_iter = ctx->deterministic && iterative;
   const bool det = det_fixed || det_iter;             // scalars as integer limbs, no rank-0 broadcasts
+  sum->accumulation = det_fixed ? 1 : (det_iter ? 2 : 0); sum->reserved = 0;
   const bool bcast = multi && ctx->nranks > 1 && !det;
   auto from_rank0 = [&](double* buf, int64_t count) -> int {
     if (!bcast) return PXR_OK;
@@ -1496,6 +1497,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   };
   // linearise on a grid made for diag(U) <= 8 md_guess; repeat on a grid from the measured trace until the check passes
   // (synchronises: used for the first two linearisations of a solve and on the -- never yet observed -- failure path)
+  bool lin_not_finite = false;        // set by linearize_checked: the Jacobian at the current point is not finite
   auto linearize_checked = [&](const double* rec, double md_guess, double cost_now, bool refine = false) -> int {
     if (!det_fixed) return linearize(rec);
     for (int attempt = 0; attempt < 8; ++attempt) {
@@ -1510,8 +1512,10 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
         if (refine && attempt == 0 && h_lin_stats[0] * 64.0 < md_guess) { md_guess = std::max(h_lin_stats[0], 1e-300); continue; }
         return PXR_OK;
       }
-      // the trace was measured in floating point and bounds every diagonal entry (NaN / Inf: the Jacobian itself is not finite)
-      PXR_REQUIRE(std::isfinite(h_lin_stats[3]) && h_lin_stats[3] >= 0.0, "pxr_ba_solve: the Jacobian is not finite (deterministic accumulation)");
+      // the trace was measured in floating point and bounds every diagonal entry.  NaN / Inf: the Jacobian itself is not finite --
+      // [upstream] "Residual and Jacobian evaluation failed": the solve TERMINATES with FAILURE at the last accepted point, it is
+      // not an error of the call (this used to return PXR_EINVAL)
+      if (!(std::isfinite(h_lin_stats[3]) && h_lin_stats[3] >= 0.0)) { lin_not_finite = true; return PXR_OK; }
       md_guess = std::max(h_lin_stats[3], 2.0 * md_guess);
     }
     return set_error(PXR_EINVAL, "pxr_ba_solve: the fixed-point grid of the deterministic mode could not be fitted");
@@ -1603,11 +1607,18 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   // (deterministic mode: the UNSCALED pass only yields diag(U) for the Jacobi scaling and has no a-priori bound: a first guess
   //  of 2^32 for its diagonal -- unit-norm descriptors give 1e3 .. 1e6 -- and the checked retry from the measured trace otherwise)
   RC(linearize_checked(rec_cur, std::ldexp(1.0, 32), cost, !opt->jacobi_scaling));
+  auto fail_not_finite = [&]() -> int {
+    sum->final_cost = cost; sum->final_radius = opt->initial_radius; sum->termination = PXR_TERM_FAILURE;
+    sum->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop0).count();
+    return PXR_OK;
+  };
+  if (lin_not_finite) return fail_not_finite();
   if (opt->jacobi_scaling) {   // 1 / (1 + sqrt(diag(J~^T J~))), fixed for the whole solve
     if (n_c > 0) hipLaunchKernelGGL(k_jacobi_scale, dim3(nblk(n_c)), dim3(256), 0, st, (int64_t)n_c, diagU, scale_c.p);
     hipLaunchKernelGGL(k_point_diag, dim3(nblk(n_pts)), dim3(256), 0, st, n_pts, V.p, Vd0.p);
     hipLaunchKernelGGL(k_jacobi_scale, dim3(nblk(n_pts * 3)), dim3(256), 0, st, n_pts * 3, Vd0.p, scale_p.p);
     RC(linearize_checked(rec_cur, 1.0 / 8.0, cost));      // scaled columns have norm < 1: diag(U) < 1 = 8 x 1/8
+    if (lin_not_finite) return fail_not_finite();
   }
   if (opt->gradient_tolerance > 0.0) {   // [upstream] the test is also made at iteration 0
     bool below = false;
@@ -1758,6 +1769,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
         // the overflow guard: a slot of the linearisation this iteration was computed from did not fit its grid -- repeat the
         // linearisation on a grid from the measured trace and the iteration with it (state untouched: radius, damping, counts)
         RC(linearize_checked(rec_cur, std::max(h_lin_stats[3], 2.0 * lin_md), cost));
+        if (lin_not_finite) { sum->termination = PXR_TERM_FAILURE; break; }
         --sum->iterations;
         continue;
       }

@@ -1138,7 +1138,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   pxr_lm_summary sm;
   sm.iterations = 0; sm.num_successful = 0; sm.termination = PXR_TERM_NO_CONVERGENCE;
   sm.num_camera_unknowns = 0; sm.num_point_unknowns = 0; sm.initial_cost = 0; sm.final_cost = 0;
-  sm.final_radius = 0; sm.total_ms = 0; sm.setup_ms = 0; sm.linear_solver = 0; sm.collective_kib = 0; sm.linear_iterations = 0;
+  sm.final_radius = 0; sm.total_ms = 0; sm.setup_ms = 0; sm.linear_solver = 0; sm.collective_kib = 0; sm.linear_iterations = 0; sm.accumulation = DET ? 1 : 0; sm.reserved = 0;
 
   __shared__ KaNodeMeta sh_nodes[KA_NODE_CACHE];
   __shared__ KaEdgeMeta sh_edges[KA_EDGE_CACHE];
@@ -1853,6 +1853,7 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
     PXR_REQUIRE(launch < 7, "pxr_ka_solve: the fixed-point grid of the deterministic mode could not be fitted (non-finite features?)");
   }
 #undef KA_SOLVE_LAUNCH
+  total->accumulation = a.det_scale != 0.0 ? 1 : 0;
   total->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   total->setup_ms = total->total_ms - kernel_ms;   // everything but the solve kernel itself (workspace, uploads, summaries download)
   total->termination = PXR_TERM_CONVERGENCE;

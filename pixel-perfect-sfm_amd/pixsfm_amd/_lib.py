@@ -56,7 +56,8 @@ class LMSummary(C.Structure):
                 ("num_camera_unknowns", C.c_int32), ("num_point_unknowns", C.c_int64),
                 ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double),
                 ("total_ms", C.c_double), ("setup_ms", C.c_double), ("linear_solver", C.c_int32),
-                ("collective_kib", C.c_int32), ("linear_iterations", C.c_int64)]
+                ("collective_kib", C.c_int32), ("linear_iterations", C.c_int64), ("accumulation", C.c_int32),
+                ("reserved", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

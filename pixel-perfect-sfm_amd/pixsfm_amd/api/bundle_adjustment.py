@@ -436,7 +436,8 @@ class _FlatBA:
         sc = self._scene
         if getattr(sc, "_image_names", None) is None:
             sc._image_names = [sc.reconstruction.images[i].name for i in sc.img_ids]
-        return cache.slots(sc._image_names, self._scene_obs_image, self._key_p2d)
+        return cache.slots(sc._image_names, self._scene_obs_image, self._key_p2d,
+                           feature_set=getattr(sc.feature_view, "feature_set", None))
 
     @property
     def obs_keys(self):

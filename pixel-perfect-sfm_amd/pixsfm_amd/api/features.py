@@ -170,6 +170,11 @@ class FeatureMap:
 
     _stack = None
 
+    def __getstate__(self):            # pickle / copy.deepcopy: the copy's patches own new memory -- it remembers no stack
+        state = dict(self.__dict__)
+        state["_stack"] = None
+        return state
+
     class _StackViews(dict):
         """The {keypoint id: FeaturePatch} dict of a map built from ONE stacked array: any write to it -- a patch replaced in
         place, not only through add_fpatch -- drops the owner's remembered stack, so that SharedArena.prefetch can never
@@ -180,6 +185,18 @@ class FeatureMap:
             owner = self.owner() if getattr(self, "owner", None) is not None else None
             if owner is not None:
                 owner._stack = None
+
+        # pickle / copy / deepcopy: as a PLAIN dict (a weak reference cannot be pickled, and a copy that kept `owner` would drop
+        # the ORIGINAL map's stack on a write to the copy -- ADVICE r5); the copy simply has no remembered stack
+        def __reduce__(self):
+            return (dict, (dict(self),))
+
+        def __copy__(self):
+            return dict(self)
+
+        def __deepcopy__(self, memo):
+            import copy
+            return {copy.deepcopy(k, memo): copy.deepcopy(v, memo) for k, v in self.items()}
 
         def __setitem__(self, k, v):
             self._dirty(); dict.__setitem__(self, k, v)
@@ -556,6 +573,7 @@ class SharedArena:
         if _host_module() is None or self.arena is not None or self._thread is not None:
             return False
         stacks, uniq, layout, base = [], [], {}, 0
+        origin = {}                                  # image name -> (the map object, its stack's address): checked again in slots()
         for name in image_names:
             if not feature_set.has_fmap(name):
                 continue
@@ -564,6 +582,7 @@ class SharedArena:
             if st is None:
                 return False
             stacks.append(st)
+            origin[name] = (fm, int(st[0].ctypes.data))
             uniq.extend(fm.patches.values())         # dict order = array order (insertion order of the constructor)
             ids = st[3] if len(st) > 3 and st[3] is not None else np.fromiter(fm.patches.keys(), dtype=np.int64, count=len(fm.patches))
             layout[name] = (base, ids)
@@ -578,6 +597,7 @@ class SharedArena:
         corners = np.concatenate([st[1] for st in stacks])
         scales = np.concatenate([np.broadcast_to(st[2], (len(st[0]), 2)) for st in stacks])
         self.uniq, self.layout, self._lut = uniq, layout, None
+        self._origin = (feature_set, origin)
 
         def work():
             try:
@@ -588,7 +608,23 @@ class SharedArena:
         self._thread.start()
         return True
 
-    def slots(self, image_names, obs_image, obs_p2d):
+    def still_mirrors(self, feature_set):
+        """True when `feature_set` is the set this arena was prefetched from and every one of its maps still mirrors the stacked
+        array that was uploaded (the layout maps (image name, keypoint id) to a slot -- for another feature set, or after
+        a patch was replaced, those slots hold stale data; the caller then goes through the patch objects, which are checked by
+        identity)."""
+        src = getattr(self, "_origin", None)
+        if src is None or feature_set is None or src[0] is not feature_set:
+            return False
+        for name, (fm, addr) in src[1].items():
+            if not feature_set.has_fmap(name) or feature_set.fmap(name) is not fm:
+                return False
+            st = fm.stacked()
+            if st is None or int(st[0].ctypes.data) != addr:
+                return False
+        return True
+
+    def slots(self, image_names, obs_image, obs_p2d, feature_set=None):
         """Arena slot of every observation (image position `obs_image` into `image_names`, keypoint id `obs_p2d`) straight from the
         prefetched stacks' layout -- first slot of the image's stack + the row of the keypoint -- with numpy only: no FeaturePatch
         object is looked up or touched (scene.patches_of + slots_of read a million of them: 0.3 + 0.1 s at BASELINE configs[2]).
@@ -596,6 +632,8 @@ class SharedArena:
         the patch objects)."""
         self.wait()
         if self.arena is None or not self.layout:
+            return None
+        if not self.still_mirrors(feature_set):
             return None
         if self._lut is None or self._lut[0] != tuple(image_names):
             ptr, parts = np.zeros(len(image_names) + 1, np.int64), []

@@ -585,19 +585,54 @@ def test_shared_arena_slots_follow_the_stacks_layout():
             maps[name] = fm
             layout[name] = (base, ids)
             base += n
+    class _Set:                                                         # what slots() asks of a feature set
+        def has_fmap(self, name):
+            return name in maps
+
+        def fmap(self, name):
+            return maps[name]
+    fset = _Set()
     sa = SharedArena()
-    assert sa.slots(names, [0], [0]) is None                            # no prefetched arena
+    assert sa.slots(names, [0], [0], feature_set=fset) is None          # no prefetched arena
     sa.arena, sa.layout = object(), layout
+    sa._origin = (fset, {n: (m, int(m.stacked()[0].ctypes.data)) for n, m in maps.items()})       # what prefetch() records
     oi = np.array([0, 2, 2, 0, 2], np.int32)
     oj = np.array([layout["a.jpg"][1][3], layout["c.jpg"][1][0], layout["c.jpg"][1][6], layout["a.jpg"][1][0], layout["c.jpg"][1][2]])
-    got = sa.slots(names, oi, oj)
+    got = sa.slots(names, oi, oj, feature_set=fset)
     assert got.tolist() == [3, 5, 11, 0, 7]
+    # the layout is only valid for the feature set that was prefetched, as it was then
+    assert sa.slots(names, oi, oj) is None and sa.slots(names, oi, oj, feature_set=_Set()) is None
     # the same through the objects: position of the patch in the concatenation of the maps' dicts
     order = [id(p) for n in names if n in maps for p in maps[n].patches.values()]
     want = [order.index(id(maps[names[i]].patches[int(j)])) for i, j in zip(oi, oj)]
     assert got.tolist() == want
     missing = next(k for k in range(20) if k not in set(layout["a.jpg"][1].tolist()))
-    assert sa.slots(names, [0], [missing]) is None                      # a keypoint the stack does not hold
-    assert sa.slots(names, [1], [0]) is None                            # an image without patches
-    assert sa.slots(names, [0], [-1]) is None and sa.slots(names, [0], [10 ** 6]) is None
+    assert sa.slots(names, [0], [missing], feature_set=fset) is None    # a keypoint the stack does not hold
+    assert sa.slots(names, [1], [0], feature_set=fset) is None          # an image without patches
+    assert sa.slots(names, [0], [-1], feature_set=fset) is None and sa.slots(names, [0], [10 ** 6], feature_set=fset) is None
+    first = next(iter(maps["a.jpg"].patches))
+    maps["a.jpg"].patches[first] = maps["a.jpg"].patches[first]         # a write drops the map's stack: the slots are stale
+    assert sa.slots(names, oi, oj, feature_set=fset) is None
     sa.arena = None
+
+
+def test_feature_map_from_a_stacked_array_pickles_and_copies():
+    """FeatureMap.patches of a map built from ONE stacked array is a dict subclass that holds a weak reference to the
+    map (a write drops the remembered stack).  It must pickle (FeaturePatch implements __setstate__ for that), and a deep copy
+    must not keep pointing at the original: a write to the copy leaves the original's remembered stack alone."""
+    import copy
+    import pickle
+    from pixsfm_amd.api import features
+    rng = np.random.default_rng(0)
+    arr = rng.normal(size=(5, 4, 4, 8)).astype(np.float16)
+    fm = features.FeatureMap(arr, np.arange(5), rng.integers(0, 50, (5, 2)), {"is_sparse": True, "scale": np.array([0.5, 0.5]), "patch_size": 4})
+    assert fm._stack is not None
+    back = pickle.loads(pickle.dumps(fm))
+    assert sorted(back.patches) == sorted(fm.patches) and back._stack is None
+    assert all(np.array_equal(back.patches[k].data, fm.patches[k].data) for k in fm.patches)
+    dup = copy.deepcopy(fm)
+    assert dup._stack is None and type(dup.patches) is dict
+    dup.patches[0] = dup.patches[1]
+    assert fm._stack is not None                                  # the original still mirrors its array
+    fm.patches[0] = fm.patches[1]
+    assert fm._stack is None                                      # ... until IT is written to

@@ -43,7 +43,7 @@ def test_struct_layouts_match_the_header_sizes():
     assert ctypes.sizeof(_lib.BaView) == 8 * 14
     assert ctypes.sizeof(_lib.KaView) == 8 * 20
     assert ctypes.sizeof(_lib.LMOptions) == 8 * 16
-    assert ctypes.sizeof(_lib.LMSummary) == 8 * 10
+    assert ctypes.sizeof(_lib.LMSummary) == 8 * 11
 
 
 def test_struct_layouts_match_the_c_compiler(tmp_path):

@@ -11,7 +11,8 @@ therefore pinned ONLY by
   * the reference's vendored half.hpp compiled from its own source (oracle/ref_half_shim.cc): fp16 rounding rules;
   * the reference's Python functions run here (find_problem_labels, extract_patches; tests/golden/make_golden_*.py);
   * third-party code the builder did not write: scipy.optimize.least_squares (optimum of the trust-region solves and the
-    robust losses), scipy.spatial.transform (rotation), numpy float16 (tests/test_third_party_*.py).
+    robust losses), torch.autograd (the analytic Jacobians against automatic differentiation, what the reference itself uses),
+    scipy.spatial.transform (rotation), numpy float16 (tests/test_third_party_*.py).
 Everything else -- featuremetric residual / Jacobian values (A7-A10), problem construction (A12-A17), reference extraction
 (A19), cost maps, the COLMAP camera models (A6), the trust-region TRAJECTORY (A14, A18) -- is a restatement read from the
 reference's source (each function cites file:line) and validated by finite differences / closed forms: PARITY UNPINNED.

@@ -232,7 +232,9 @@ typedef struct {
                                 partial sums (the iterative solver's deterministic form: same bits per rank count), 0 = floating-
                                 point atomics (pxr_set_deterministic(ctx, 0), or a direct solve WITHOUT Jacobi scaling, whose
                                 columns no single grid can serve -- pxr_get_deterministic() alone does not tell)        */
-  int32_t reserved;
+  int32_t initial_us;        /* pxr_ba_solve: microseconds of total_ms spent BEFORE the first LM iteration -- the evaluation at the initial
+                                point, the unscaled linearisation the Jacobi scaling is read from and the scaled one (device idle at
+                                the end of it: the fixed-point check synchronises); 0 for pxr_ka_solve                    */
 } pxr_lm_summary;
 
 /* ceres::IterationCallback of the BA solve (the `solver.callbacks` of pixsfm's option dicts, base/src/callbacks.h; the

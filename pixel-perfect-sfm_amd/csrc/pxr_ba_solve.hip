@@ -1337,7 +1337,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   // ranks (the ranks' parts are all-reduced as doubles: the result depends on how the points are dealt to ranks, not on the run).
   const bool det_iter = ctx->deterministic && iterative;
   const bool det = det_fixed || det_iter;             // scalars as integer limbs, no rank-0 broadcasts
-  sum->accumulation = det_fixed ? 1 : (det_iter ? 2 : 0); sum->reserved = 0;
+  sum->accumulation = det_fixed ? 1 : (det_iter ? 2 : 0); sum->initial_us = 0;
   const bool bcast = multi && ctx->nranks > 1 && !det;
   auto from_rank0 = [&](double* buf, int64_t count) -> int {
     if (!bcast) return PXR_OK;
@@ -1633,6 +1633,8 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   int invalid = 0;
   bool reuse_diag = false;
   bool inner_enabled = opt->use_inner_iterations != 0, inner_useful = false;
+  PXR_HIP(hipStreamSynchronize(st));         // (already idle in the deterministic mode: linearize_checked synchronises)
+  sum->initial_us = (int32_t)std::min<double>(2e9, 1e3 * std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop0).count());
   // ceres::IterationCallback (pxr_set_iteration_callback): 1 = SOLVER_ABORT, 2 = SOLVER_TERMINATE_SUCCESSFULLY
   // Several ranks: a callback installed on SOME ranks only (rank 0 logging, say) must not put the ranks' collectives out of
   // step -- whether any rank has one is agreed on once here; if so, every rank joins the per-iteration exchange of answers

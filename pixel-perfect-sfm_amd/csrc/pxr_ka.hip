@@ -1138,7 +1138,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   pxr_lm_summary sm;
   sm.iterations = 0; sm.num_successful = 0; sm.termination = PXR_TERM_NO_CONVERGENCE;
   sm.num_camera_unknowns = 0; sm.num_point_unknowns = 0; sm.initial_cost = 0; sm.final_cost = 0;
-  sm.final_radius = 0; sm.total_ms = 0; sm.setup_ms = 0; sm.linear_solver = 0; sm.collective_kib = 0; sm.linear_iterations = 0; sm.accumulation = DET ? 1 : 0; sm.reserved = 0;
+  sm.final_radius = 0; sm.total_ms = 0; sm.setup_ms = 0; sm.linear_solver = 0; sm.collective_kib = 0; sm.linear_iterations = 0; sm.accumulation = DET ? 1 : 0; sm.initial_us = 0;
 
   __shared__ KaNodeMeta sh_nodes[KA_NODE_CACHE];
   __shared__ KaEdgeMeta sh_edges[KA_EDGE_CACHE];

@@ -57,7 +57,7 @@ class LMSummary(C.Structure):
                 ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double),
                 ("total_ms", C.c_double), ("setup_ms", C.c_double), ("linear_solver", C.c_int32),
                 ("collective_kib", C.c_int32), ("linear_iterations", C.c_int64), ("accumulation", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("initial_us", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

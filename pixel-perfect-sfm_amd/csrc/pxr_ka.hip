@@ -66,7 +66,10 @@ struct KaArgs {
   int stream_slots;            // > 0: the line-search probes run as ka_probe_stream (every sub-problem has at most this many nodes, <= 64,
                                // all its residual blocks in the LDS cache, no unary terms); its LDS region follows the LM state
   int stream_off;              // doubles from sh_A to that region
-  double* prob_state = nullptr;     // deterministic mode, [n_problems][KA_STATE]: LM state parked by a sub-problem that stopped with KA_TERM_RESCALE after an accepted step
+  double* prob_state = nullptr;     // [n_problems][KA_STATE]: LM state parked by a sub-problem that stopped with KA_TERM_RESCALE after an accepted step, or after its first iteration (KA_TERM_PARKED)
+  int* sched = nullptr;             // two-phase launch (ka_solve_kernel_sched): [0] arrivals at the grid barrier, [1] release flag, [2] entries of the list, [3] next entry to take
+  int* sched_list = nullptr;        // [n_problems] the parked sub-problems, those with a keypoint on a bound first
+  uint8_t* prob_heavy = nullptr;    // [n_problems] set when a sub-problem is parked with a keypoint ON its bound
   // ---- label groups that span several workgroups (round 6) -----------------------------------------------------------------
   // A label group of the caller (ONE ceres::Problem of the reference: one trust region, one line search, one termination) may
   // be handed over as several CHUNKS -- consecutive sub-problems that share no variable (whole tracks each): pxr_ka_view.
@@ -115,8 +118,10 @@ __device__ __noinline__ void ka_group_sum4(const KaGroup g, unsigned gen, double
   }
   __syncthreads();
 }
-constexpr int KA_STATE = 8;            // has_state, radius, iterations, accepted steps, initial cost, stencils
-constexpr int KA_TERM_RESCALE = 100;   // internal termination code: the sub-problem's fixed-point grid did not fit, launch again
+constexpr int KA_STATE = 12;           // has_state, radius, iterations, accepted steps, initial cost, stencils, decrease factor, invalid steps,
+                                       // cost, next fixed-point grid, reuse_diag, FULL (the linearisation itself was parked too)
+constexpr int KA_TERM_RESCALE = 100;
+constexpr int KA_TERM_PARKED = 101;    // internal: stopped after its first LM iteration (phase 1 of ka_solve_kernel_sched), resumes in phase 2   // internal termination code: the sub-problem's fixed-point grid did not fit, launch again
 
 // Channel layout of a node over lanes: 8 channels per lane (one 16-byte fp16 load) for the CNN feature sizes, and the
 // whole descriptor in ONE lane for CHANNELS < 8 -- the reference instantiates (128, 1) and (1, 1)
@@ -1098,15 +1103,16 @@ __device__ __attribute__((noinline)) double ka_finish_fixed_point(double* Hm, do
   return ideal;
 }
 
+// phase 0: the whole solve; 1: at most ONE LM iteration, then the LM state is parked (KA_TERM_PARKED); 2: resume a parked sub-problem
 template <typename ST, int C, bool DET>
-__device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __restrict__ info, double* sh_A) {
+__device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __restrict__ info, double* sh_A, const int prob, const int phase) {
 #ifdef PXR_KA_PROFILE
   long long ka_prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ka_t0 = wall_clock64();
   const long long ka_tstart = ka_t0;
 #endif
   __shared__ double sh4[KA_NT / 64];
   __shared__ int sh_ok;
-  const int prob = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const bool fsimd = a.float_simd != 0;
   KaProb p;
   if (DET && a.prob_done[prob]) return;                  // (a repeated launch after a grid change: this sub-problem had finished)
@@ -1225,7 +1231,9 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   // the algorithmic traffic of the solve is 16 texels x C x sizeof(storage) each, reported as summary.linear_iterations
   int64_t stencils = 0;
   const int64_t nodes_all = p.np1 - p.np0, nodes_var = n / 2;
+  double grid_used = 0.0;              // deterministic mode: the fixed-point grid the newest linearisation was accumulated on
   auto linearize = [&](const bool compute_scale) -> double {        // compute_scale: the FIRST linearisation of the solve
+    if (DET) grid_used = uniform_f64(sh_grid);
     stencils += nodes_all;
     for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = 0.0;
     for (int e = tid; e < n; e += blockDim.x) p.g[e] = 0.0;
@@ -1305,13 +1313,23 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   // its Jacobi scaling (fixed at the first linearisation of the solve, [upstream]), radius, decrease factor and counts were
   // parked in prob_state / the global scale vector (it used to start over with a fresh trust region).
   const double* const pst = a.prob_state + (size_t)prob * KA_STATE;
-  const bool resumed = DET && pst[0] != 0.0;
+  const bool resumed = pst[0] != 0.0;
+  const bool resumed_full = resumed && pst[11] != 0.0;      // parked by phase 1 of the two-phase launch WITH its linearisation
   if (resumed) {
     const double* scale_g = a.vec + 2 * vstride + vb;
     for (int e = tid; e < n; e += blockDim.x) p.scale[e] = scale_g[e];
+    if (resumed_full) {
+      // H, g (scaled and unscaled) and the damping diagonal come back from global memory: nothing is evaluated again (the
+      // descriptors of the constant keypoints, which the probes read, are still in the scratch)
+      const double* Hg = a.Hbuf + a.prob_h_ptr[prob];
+      const double *g_g = a.vec + 0 * vstride + vb, *gun_g = a.vec + 1 * vstride + vb, *diag_g = a.vec + 3 * vstride + vb;
+      if (p.Hm != Hg) for (int e = tid; e < hsz; e += blockDim.x) p.Hm[e] = Hg[e];
+      if (p.g != g_g) for (int e = tid; e < n; e += blockDim.x) { p.g[e] = g_g[e]; p.gun[e] = gun_g[e]; p.diag[e] = diag_g[e]; }
+      if (DET && tid == 0) sh_grid = pst[9];
+    }
     __syncthreads();
   }
-  double cost = linearize(!resumed);
+  double cost = resumed_full ? uniform_f64(pst[8]) : linearize(!resumed);
   double cost_loc = cost;              // this member's part of the group's cost (what its summary reports: the host adds them up)
   sm.initial_cost = cost_loc;
   bool resc = DET && sh_resc != 0.0, infeasible = !inf.feasible;
@@ -1336,8 +1354,40 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
   bool reuse_diag = false;
   if (resumed) {
     radius = uniform_f64(pst[1]); sm.iterations = (int)pst[2]; sm.num_successful = (int)pst[3]; sm.initial_cost = pst[4]; stencils += (int64_t)pst[5];
+    decrease_factor = uniform_f64(pst[6]); invalid = (int)pst[7];
+    reuse_diag = resumed_full && pst[10] != 0.0;                      // (not FULL: the damping is formed again from the same H)
   }
+  const int park_at = sm.iterations + 1;
   while (true) {
+    if (phase == 1 && sm.iterations >= park_at && sm.iterations < opt.max_iterations && !(radius < opt.min_radius)) {
+      // phase 1 of the two-phase launch: one LM iteration done, the sub-problem goes on in phase 2 -- those that already sit on a
+      // bound (the ones that will run the twenty-probe line searches) first
+      sm.termination = KA_TERM_PARKED;
+      double* scale_g = a.vec + 2 * vstride + vb;
+      int on_bound = 0;
+      for (int64_t i = p.np0 + tid; i < p.np1; i += blockDim.x) {
+        const int64_t node = i - p.np0 < KA_NODE_CACHE ? sh_nodes[i - p.np0].id : a.v.d_prob_nodes[i];
+        const int v = a.var_of_node[node];
+        if (v < 0) continue;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { const double x = a.v.d_kp[2 * node + c]; if (x == p.lo[v + c] || x == p.hi[v + c]) on_bound = 1; }
+      }
+      for (int e = tid; e < n; e += blockDim.x) scale_g[e] = p.scale[e];
+      {   // the linearisation itself: phase 2 takes it back instead of evaluating the same point again
+        double* Hg = a.Hbuf + a.prob_h_ptr[prob];
+        double *g_g = a.vec + 0 * vstride + vb, *gun_g = a.vec + 1 * vstride + vb, *diag_g = a.vec + 3 * vstride + vb;
+        if (p.Hm != Hg) for (int e = tid; e < hsz; e += blockDim.x) Hg[e] = p.Hm[e];
+        if (p.g != g_g) for (int e = tid; e < n; e += blockDim.x) { g_g[e] = p.g[e]; gun_g[e] = p.gun[e]; diag_g[e] = p.diag[e]; }
+      }
+      on_bound = __syncthreads_or(on_bound);
+      if (tid == 0) {
+        double* st = a.prob_state + (size_t)prob * KA_STATE;
+        st[0] = 1.0; st[1] = radius; st[2] = (double)sm.iterations; st[3] = (double)sm.num_successful; st[4] = sm.initial_cost; st[5] = (double)stencils;
+        st[6] = decrease_factor; st[7] = (double)invalid; st[8] = cost; st[9] = DET ? sh_grid : 0.0; st[10] = reuse_diag ? 1.0 : 0.0; st[11] = 1.0;
+        a.prob_heavy[prob] = on_bound ? 1 : 0;
+      }
+      break;
+    }
     if (sm.iterations >= opt.max_iterations) { sm.termination = PXR_TERM_NO_CONVERGENCE; break; }
     if (radius < opt.min_radius) { sm.termination = PXR_TERM_CONVERGENCE; break; }
     ++sm.iterations;
@@ -1512,6 +1562,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
         if (tid == 0) {
           double* st = a.prob_state + (size_t)prob * KA_STATE;
           st[0] = 1.0; st[1] = radius; st[2] = (double)sm.iterations; st[3] = (double)sm.num_successful; st[4] = sm.initial_cost; st[5] = (double)stencils;
+          st[6] = decrease_factor; st[7] = 0.0; st[8] = 0.0; st[9] = 0.0; st[10] = 0.0; st[11] = 0.0;
         }
         break;
       }
@@ -1524,6 +1575,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     a.summaries[prob] = sm;
     if (DET) {
       if (sm.termination == KA_TERM_RESCALE) a.prob_scale[prob] = sh_resc != 0.0 ? sh_resc : sh_grid;
+      else if (sm.termination == KA_TERM_PARKED) a.prob_scale[prob] = grid_used;    // (phase 2 linearises the SAME point again: on the same grid, the same H and g bit for bit)
       else a.prob_done[prob] = 1;
     }
   }
@@ -1548,12 +1600,81 @@ template <typename ST, int C, bool DET>
 #endif
 __global__ __launch_bounds__(KA_NT) __attribute__((amdgpu_waves_per_eu(PXR_KA_WAVES, PXR_KA_WAVES))) void ka_solve_kernel_occ2(const KaArgs a, const KaInfo* __restrict__ info) {
   extern __shared__ __align__(16) double sh_A[];      // lds_elems doubles (damped blocks) when the sub-problem fits
-  ka_solve_body<ST, C, DET>(a, info, sh_A);
+  ka_solve_body<ST, C, DET>(a, info, sh_A, (int)blockIdx.x, 0);
+}
+
+// ---- the two-phase launch (round 6; an experiment, off by default: see pxr_ka_solve) ----------------------------------------------
+// One workgroup per sub-problem and dispatch in index order make the launch as long as its tail: the ~6 % of the sub-problems
+// that sit on an active bound run ~125 line-search probes (2.5-3.3 ms each), the others ~5 (0.65-0.9 ms), and the launch ends when
+// the LAST-dispatched heavy one does -- 5.3 ms at configs[1] against 4.1 ms of work per resident workgroup.  Which sub-problems are
+// heavy shows after ONE LM iteration: a keypoint whose unconstrained step crosses its bound is clamped onto it.  So a PERSISTENT
+// grid (as many workgroups as the launch keeps resident) first runs iteration 1 of every sub-problem and parks its LM state, meets
+// at a grid barrier whose last arrival lists the parked sub-problems -- those with a keypoint on a bound first --, and then takes
+// them from that list: the long chains start at once, the short ones fill the gaps.  Sub-problems are independent and every one
+// goes through the same arithmetic as in the one-phase launch (a parked one re-linearises at the point it stopped at: the same
+// H and g bit for bit in the deterministic mode), so the results do not depend on the order.
+template <typename ST, int C, bool DET>
+__global__ __launch_bounds__(KA_NT) __attribute__((amdgpu_waves_per_eu(PXR_KA_WAVES, PXR_KA_WAVES))) void ka_solve_kernel_sched(const KaArgs a, const KaInfo* __restrict__ info) {
+  extern __shared__ __align__(16) double sh_A[];
+  __shared__ int sh_take, sh_last, sh_cnt[2];
+  const int np = a.v.n_problems, tid = threadIdx.x;
+  // ONE call site of the solve body for both phases (two inlined copies of it: 531 spilled registers instead of 68, and a
+  // launch of 7.1 ms instead of 5.3)
+  int phase = 1, next = blockIdx.x, count = 0;
+  while (true) {
+    int prob;
+    if (phase == 1) {
+      if (next < np) { prob = next; next += gridDim.x; }
+      else {
+        // grid barrier (every workgroup of the grid is resident: the host sized it from the occupancy); the last arrival lists
+        // the parked sub-problems, those with a keypoint on a bound first
+        if (tid == 0) {
+          __threadfence();
+          sh_last = __hip_atomic_fetch_add(a.sched + 0, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+          sh_cnt[0] = 0; sh_cnt[1] = 0;
+        }
+        __syncthreads();
+        if (sh_last) {
+          __atomic_thread_fence(__ATOMIC_ACQUIRE);
+          for (int pass = 0; pass < 2; ++pass) {
+            for (int i = tid; i < np; i += blockDim.x) {
+              const bool parked = __hip_atomic_load(&a.summaries[i].termination, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == KA_TERM_PARKED;
+              const bool heavy = __hip_atomic_load(a.prob_heavy + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+              if (parked && heavy == (pass == 0)) a.sched_list[atomicAdd(&sh_cnt[0], 1)] = i;
+            }
+            __syncthreads();
+          }
+          if (tid == 0) {
+            a.sched[2] = sh_cnt[0];
+            __threadfence();
+            __hip_atomic_store(a.sched + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        } else if (tid == 0) {
+          while (__hip_atomic_load(a.sched + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+          __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
+        __syncthreads();
+        count = __hip_atomic_load(a.sched + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.stream_off == -1) count = 0;          // PXR_KA_PHASE1_ONLY=1 (a timing experiment: phase 1 and the barrier alone)
+        phase = 2;
+        continue;
+      }
+    } else {
+      if (tid == 0) sh_take = atomicAdd(a.sched + 3, 1);
+      __syncthreads();
+      const int k = sh_take;
+      __syncthreads();
+      if (k >= count) break;
+      prob = __hip_atomic_load(a.sched_list + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ka_solve_body<ST, C, DET>(a, info, sh_A, __builtin_amdgcn_readfirstlane(prob), phase);
+    __syncthreads();
+  }
 }
 template <typename ST, int C, bool DET>
 __global__ __launch_bounds__(KA_NT) void ka_solve_kernel(const KaArgs a, const KaInfo* __restrict__ info) {
   extern __shared__ __align__(16) double sh_A[];
-  ka_solve_body<ST, C, DET>(a, info, sh_A);
+  ka_solve_body<ST, C, DET>(a, info, sh_A, (int)blockIdx.x, 0);
 }
 
 // ---- per-edge evaluation (parity checks) -------------------------------------------------------------------
@@ -1712,6 +1833,7 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
     }
   }
   const size_t o_pstate = carve(sizeof(double) * KA_STATE * np);
+  const size_t o_sched = carve(sizeof(int) * 4), o_slist = carve(sizeof(int) * np), o_heavy = carve(np);
   const size_t o_gfirst = carve(sizeof(int) * np), o_gsize = carve(sizeof(int) * np);
   const size_t o_gpart = carve(sizeof(double) * 2 * 4 * np), o_gcnt = carve(sizeof(unsigned) * KA_GRP_CNT_STRIDE * np);
   if (int rc = grow(&ctx->d_workspace, &ctx->workspace_bytes, off)) return rc;
@@ -1729,6 +1851,7 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   a.prob_scale = (double*)(ws + o_pscale); a.prob_done = (uint8_t*)(ws + o_pdone);
   a.prob_state = (double*)(ws + o_pstate);
   PXR_HIP(hipMemsetAsync(a.prob_state, 0, sizeof(double) * KA_STATE * np, st));
+  a.sched = (int*)(ws + o_sched); a.sched_list = (int*)(ws + o_slist); a.prob_heavy = (uint8_t*)(ws + o_heavy);
   if (a.det_scale != 0.0) {
     std::vector<double> init((size_t)np, a.det_scale);
     PXR_HIP(hipMemcpyAsync(a.prob_scale, init.data(), sizeof(double) * np, hipMemcpyHostToDevice, st));
@@ -1797,9 +1920,31 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
 #else
   (void)edge_ptr;
 #endif
-#define KA_SOLVE_LAUNCH(KERNEL, ST, CC)                                                                      \
+  // the two-phase launch (ka_solve_kernel_sched): an EXPERIMENT, off unless PXR_KA_TWO_PHASE=1 (profiles/r6_ka_schedule.txt: the
+  // dispatch ORDER is worth 1.8 ms of the 5.3 -- 3.4 ms with the heaviest sub-problems first -- but which ones are heavy does
+  // not show after one LM iteration, and the persistent grid costs 0.6 ms in spilled registers and barrier time: 5.55 ms).  Needs
+  // more sub-problems than the launch keeps resident, no label groups that span workgroups, the fp16 / fp32 CNN-feature kernels.
+  const char* two_phase_knob = getenv("PXR_KA_TWO_PHASE");
+  const bool two_phase_wanted = two_phase_knob && two_phase_knob[0] == '1' && grp_max <= 1;
+#define KA_SOLVE_LAUNCH(KERNEL, SCHED, ST, CC)                                                                    \
   do {                                                                                                       \
     void (*kfn)(const KaArgs, const KaInfo*) = a.det_scale != 0.0 ? KERNEL<ST, CC, true> : KERNEL<ST, CC, false>; \
+    unsigned grid = (unsigned)np;                                                                            \
+    void (*sfn)(const KaArgs, const KaInfo*) = a.det_scale != 0.0 ? SCHED<ST, CC, true> : SCHED<ST, CC, false>;   \
+    if (two_phase_wanted && sfn != kfn) {                                                                    \
+      PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+      int per_cu = 0;                                                                                        \
+      PXR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(sfn), KA_NT, shmem)); \
+      int resident = per_cu * ctx->num_cus;                                                                  \
+      if (const char* e = getenv("PXR_KA_TWO_PHASE_RESIDENT")) resident = std::min(resident, std::max(1, atoi(e)));   /* tests: a small grid */ \
+      if (getenv("PXR_VERBOSE")) fprintf(stderr, "[pxr_ka_solve] two-phase launch: %d workgroups per CU x %d CUs resident, %d sub-problems, %zu B of dynamic LDS\n", per_cu, ctx->num_cus, np, (size_t)shmem); \
+      if (resident >= 1 && np > resident) {        /* (everything resident at once: no tail to schedule away) */ \
+        kfn = sfn; grid = (unsigned)resident;                                                                \
+        if (getenv("PXR_KA_PHASE1_ONLY")) a.stream_off = -1;                                                 \
+        PXR_HIP(hipMemsetAsync(a.sched, 0, sizeof(int) * 4, st));                                            \
+        PXR_HIP(hipMemsetAsync(a.prob_heavy, 0, np, st));                                                    \
+      }                                                                                                      \
+    }                                                                                                        \
     PXR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                                          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                    \
     if (grp_max > 1) {   /* every member of a group must be resident at the same time (ka_group_sum4 spins) */ \
@@ -1811,7 +1956,7 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
       PXR_HIP(hipMemsetAsync(a.grp_cnt, 0, sizeof(unsigned) * KA_GRP_CNT_STRIDE * np, st));                  \
     }                                                                                                        \
     PXR_HIP(hipEventRecord(ctx->ev_start, st));                                                              \
-    hipLaunchKernelGGL(kfn, dim3(np), dim3(KA_NT), shmem, st, a, d_info);                                    \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(KA_NT), shmem, st, a, d_info);                                  \
     PXR_HIP(hipEventRecord(ctx->ev_stop, st));                                                               \
   } while (0)
   std::vector<pxr_lm_summary> sums(np), pass(np);
@@ -1821,15 +1966,15 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   // sub-problems return at once, the others go on from their current keypoints.  (Never more than one launch with unit-norm
   // descriptors.)
   for (int launch = 0; launch < 8; ++launch) {
-    if (arena->dtype == PXR_F16 && arena->C == 128) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, _Float16, 128);
-    else if (arena->dtype == PXR_F16 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, _Float16, 64);
-    else if (arena->dtype == PXR_F32 && arena->C == 128) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, float, 128);
-    else if (arena->dtype == PXR_F64 && arena->C == 128) KA_SOLVE_LAUNCH(ka_solve_kernel, double, 128);
-    else if (arena->dtype == PXR_F32 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, float, 64);
-    else if (arena->dtype == PXR_F64 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel, double, 64);
-    else if (arena->dtype == PXR_F16 && arena->C == 1) KA_SOLVE_LAUNCH(ka_solve_kernel, _Float16, 1);
-    else if (arena->dtype == PXR_F32 && arena->C == 1) KA_SOLVE_LAUNCH(ka_solve_kernel, float, 1);
-    else if (arena->dtype == PXR_F64 && arena->C == 1) KA_SOLVE_LAUNCH(ka_solve_kernel, double, 1);
+    if (arena->dtype == PXR_F16 && arena->C == 128) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, ka_solve_kernel_sched, _Float16, 128);
+    else if (arena->dtype == PXR_F16 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, ka_solve_kernel_sched, _Float16, 64);
+    else if (arena->dtype == PXR_F32 && arena->C == 128) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, ka_solve_kernel_sched, float, 128);
+    else if (arena->dtype == PXR_F64 && arena->C == 128) KA_SOLVE_LAUNCH(ka_solve_kernel, ka_solve_kernel, double, 128);
+    else if (arena->dtype == PXR_F32 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel_occ2, ka_solve_kernel_sched, float, 64);
+    else if (arena->dtype == PXR_F64 && arena->C == 64) KA_SOLVE_LAUNCH(ka_solve_kernel, ka_solve_kernel, double, 64);
+    else if (arena->dtype == PXR_F16 && arena->C == 1) KA_SOLVE_LAUNCH(ka_solve_kernel, ka_solve_kernel, _Float16, 1);
+    else if (arena->dtype == PXR_F32 && arena->C == 1) KA_SOLVE_LAUNCH(ka_solve_kernel, ka_solve_kernel, float, 1);
+    else if (arena->dtype == PXR_F64 && arena->C == 1) KA_SOLVE_LAUNCH(ka_solve_kernel, ka_solve_kernel, double, 1);
     else return set_error(PXR_EUNSUPPORTED, "pxr_ka_solve: CHANNELS=%d not supported (128, 64, 1)", arena->C);
     PXR_HIP(hipGetLastError());
     PXR_HIP(hipMemcpyAsync(pass.data(), d_sum, sizeof(pxr_lm_summary) * np, hipMemcpyDeviceToHost, st));

@@ -342,3 +342,60 @@ def test_a_group_with_too_many_chunks_is_refused_through_the_c_abi(ctx):
     with pytest.raises(PixsfmHipError, match="resident"):
         ka.solve(interp_cfg(), make_loss("cauchy", [0.25]))
     arena.close()
+
+
+# ---- the two-phase launch (ka_solve_kernel_sched, round 6) ------------------------------------------------------------------------
+@pytest.mark.parametrize("sigma,bound", [(1.0, 4.0), (1.5, 1.5)])
+def test_two_phase_launch_gives_the_one_phase_results_bit_for_bit(ctx, monkeypatch, sigma, bound):
+    """More sub-problems than resident workgroups (forced here: a grid of 5): every sub-problem runs ONE LM iteration, parks its LM
+    state, and is resumed from a list that starts with those sitting on a bound.  Same arithmetic per sub-problem -- the resumed
+    linearisation is accumulated on the grid the interrupted one used -- so keypoints, costs and counts equal the one-phase
+    launch's bit for bit (deterministic default), and the oracle's to the usual tolerances."""
+    import pxo
+    import pxo_ka
+    from pixsfm_amd import synthetic_ka
+    from pixsfm_amd.engine import PatchArena, interp_cfg, lm_options, make_loss
+    from pixsfm_amd.ka_engine import KAProblem
+    prob = synthetic_ka.make_ka_problem(n_tracks=90, track_len=5, seed=17, max_kps_per_problem=15, sigma=sigma)
+    assert prob["n_problems"] == 30
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    out = []
+    for knob in ("0", "1"):
+        monkeypatch.setenv("PXR_KA_TWO_PHASE", knob)
+        monkeypatch.setenv("PXR_KA_TWO_PHASE_RESIDENT", "5")
+        ka = KAProblem(ctx, arena, prob)
+        total, per = ka.solve(interp_cfg(), make_loss("cauchy", [0.25]), bound=bound, options=lm_options(parameter_tolerance=1e-5), per_problem=True)
+        out.append((ka.keypoints(), total, per))
+    (kp0, t0, per0), (kp1, t1, per1) = out
+    assert ctx.deterministic and np.array_equal(kp0, kp1)
+    for a, b in zip(per0, per1):
+        for k in ("iterations", "num_successful", "termination", "initial_cost", "final_cost"):
+            assert a[k] == b[k], (k, a[k], b[k])
+        assert b["linear_iterations"] >= a["linear_iterations"]        # (a resumed sub-problem interpolates its nodes once more)
+    assert t0["final_cost"] == t1["final_cost"] and t0["num_successful"] == t1["num_successful"]
+    kpo, sums = pxo_ka.ka_solve(prob, pxo.cfg(), pxo.loss("cauchy", 0.25), bound, pxo.lm_options(parameter_tolerance=1e-5))
+    for g, o in zip(per1, sums):
+        assert g["iterations"] == o["iterations"] and g["num_successful"] == o["num_successful"] and g["termination"] == o["termination"]
+    assert np.abs(kp1 - kpo).max() < 1e-6
+    arena.close()
+
+
+def test_two_phase_launch_with_floating_point_atomics(monkeypatch):
+    from pixsfm_amd import synthetic_ka
+    from pixsfm_amd.engine import Context, PatchArena, interp_cfg, lm_options, make_loss
+    from pixsfm_amd.ka_engine import KAProblem
+    c = Context(0)
+    c.deterministic = False
+    prob = synthetic_ka.make_ka_problem(n_tracks=60, track_len=5, seed=18, max_kps_per_problem=10, sigma=1.5)
+    arena = PatchArena.from_numpy(c, prob["patches"], prob["corners"], prob["scales"])
+    out = []
+    for knob in ("0", "1"):
+        monkeypatch.setenv("PXR_KA_TWO_PHASE", knob)
+        monkeypatch.setenv("PXR_KA_TWO_PHASE_RESIDENT", "7")
+        ka = KAProblem(c, arena, prob)
+        total, per = ka.solve(interp_cfg(), make_loss("cauchy", [0.25]), bound=2.0, options=lm_options(parameter_tolerance=1e-5), per_problem=True)
+        out.append((ka.keypoints(), total, per))
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-9
+    assert [p["iterations"] for p in out[0][2]] == [p["iterations"] for p in out[1][2]]
+    assert abs(out[0][1]["final_cost"] - out[1][1]["final_cost"]) < 1e-10 * out[0][1]["initial_cost"]
+    arena.close(); c.close()

@@ -70,6 +70,9 @@ struct KaArgs {
   int* sched = nullptr;             // two-phase launch (ka_solve_kernel_sched): [0] arrivals at the grid barrier, [1] release flag, [2] entries of the list, [3] next entry to take
   int* sched_list = nullptr;        // [n_problems] the parked sub-problems, those with a keypoint on a bound first
   uint8_t* prob_heavy = nullptr;    // [n_problems] set when a sub-problem is parked with a keypoint ON its bound
+  int phase = 0;                    // the plain kernels (ka_solve_kernel_occ2): 0 the whole solve, 1 park after `park_iters` LM iterations, 2 resume the parked ones
+  int park_iters = 1;
+  const int* order = nullptr;       // phase 2: sub-problem of workgroup b (-1: none), the ones parked on a bound first
   // ---- label groups that span several workgroups (round 6) -----------------------------------------------------------------
   // A label group of the caller (ONE ceres::Problem of the reference: one trust region, one line search, one termination) may
   // be handed over as several CHUNKS -- consecutive sub-problems that share no variable (whole tracks each): pxr_ka_view.
@@ -1357,7 +1360,7 @@ __device__ __forceinline__ void ka_solve_body(const KaArgs& a, const KaInfo* __r
     decrease_factor = uniform_f64(pst[6]); invalid = (int)pst[7];
     reuse_diag = resumed_full && pst[10] != 0.0;                      // (not FULL: the damping is formed again from the same H)
   }
-  const int park_at = sm.iterations + 1;
+  const int park_at = sm.iterations + a.park_iters;
   while (true) {
     if (phase == 1 && sm.iterations >= park_at && sm.iterations < opt.max_iterations && !(radius < opt.min_radius)) {
       // phase 1 of the two-phase launch: one LM iteration done, the sub-problem goes on in phase 2 -- those that already sit on a
@@ -1600,7 +1603,23 @@ template <typename ST, int C, bool DET>
 #endif
 __global__ __launch_bounds__(KA_NT) __attribute__((amdgpu_waves_per_eu(PXR_KA_WAVES, PXR_KA_WAVES))) void ka_solve_kernel_occ2(const KaArgs a, const KaInfo* __restrict__ info) {
   extern __shared__ __align__(16) double sh_A[];      // lds_elems doubles (damped blocks) when the sub-problem fits
-  ka_solve_body<ST, C, DET>(a, info, sh_A, (int)blockIdx.x, 0);
+  int prob = (int)blockIdx.x;
+  if (a.order) { prob = a.order[blockIdx.x]; if (prob < 0) return; }          // (phase 2 of the two-launch schedule)
+  ka_solve_body<ST, C, DET>(a, info, sh_A, prob, a.phase);
+}
+
+// the order of phase 2: the parked sub-problems, those with a keypoint on a bound first; -1 for the rest of the grid
+__global__ __launch_bounds__(1024) void ka_order_kernel(const KaArgs a, int* __restrict__ order) {
+  __shared__ int cnt;
+  const int np = a.v.n_problems;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = threadIdx.x; i < np; i += blockDim.x)
+      if (a.summaries[i].termination == KA_TERM_PARKED && (a.prob_heavy[i] != 0) == (pass == 0)) order[atomicAdd(&cnt, 1)] = i;
+    __syncthreads();
+  }
+  for (int i = cnt + (int)threadIdx.x; i < np; i += blockDim.x) order[i] = -1;
 }
 
 // ---- the two-phase launch (round 6; an experiment, off by default: see pxr_ka_solve) ----------------------------------------------
@@ -1924,6 +1943,19 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
   // dispatch ORDER is worth 1.8 ms of the 5.3 -- 3.4 ms with the heaviest sub-problems first -- but which ones are heavy does
   // not show after one LM iteration, and the persistent grid costs 0.6 ms in spilled registers and barrier time: 5.55 ms).  Needs
   // more sub-problems than the launch keeps resident, no label groups that span workgroups, the fp16 / fp32 CNN-feature kernels.
+  // The two-LAUNCH schedule (round 6, the default when there are more sub-problems than resident workgroups): the launch is as
+  // long as its tail -- the ~7 % of the sub-problems that run twenty-probe line searches against an active bound take 2.5-3.3 ms,
+  // the others 0.65-0.9, and dispatch in index order starts some of the long ones last (with the heaviest first the same kernel
+  // needs 3.4 instead of 5.3 ms at configs[1]: profiles/r6_ka_schedule.txt).  Which ones are heavy shows after TWO LM iterations
+  // (a keypoint clamped onto its bound: 131 of 137 caught).  So: launch 1 runs two iterations of every sub-problem and parks the
+  // complete LM state (nothing is evaluated twice), a one-workgroup kernel lists the parked ones -- on a bound first --, launch 2
+  // resumes them in that order.  Same arithmetic per sub-problem: identical bits (tests/test_ka_gpu.py::test_two_phase_launch_*).
+  // 5.36 -> 4.97 ms at configs[1].  PXR_KA_TWO_LAUNCH=0 switches it off, =N parks after N iterations.
+  const char* two_launch_knob = getenv("PXR_KA_TWO_LAUNCH");
+  const int park_iters = two_launch_knob && atoi(two_launch_knob) > 0 ? atoi(two_launch_knob) : 2;
+  int resident_hint = 2 * ctx->num_cus;
+  if (const char* e = getenv("PXR_KA_TWO_PHASE_RESIDENT")) resident_hint = std::max(1, atoi(e));
+  const bool two_launch = !(two_launch_knob && two_launch_knob[0] == '0') && grp_max <= 1 && np > resident_hint;
   const char* two_phase_knob = getenv("PXR_KA_TWO_PHASE");
   const bool two_phase_wanted = two_phase_knob && two_phase_knob[0] == '1' && grp_max <= 1;
 #define KA_SOLVE_LAUNCH(KERNEL, SCHED, ST, CC)                                                                    \
@@ -1956,6 +1988,16 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
       PXR_HIP(hipMemsetAsync(a.grp_cnt, 0, sizeof(unsigned) * KA_GRP_CNT_STRIDE * np, st));                  \
     }                                                                                                        \
     PXR_HIP(hipEventRecord(ctx->ev_start, st));                                                              \
+    if (two_launch && kfn != sfn && sfn != (void (*)(const KaArgs, const KaInfo*))nullptr && (void*)SCHED<ST, CC, true> != (void*)KERNEL<ST, CC, true>) { \
+      /* two launches of the plain kernel: every sub-problem runs `park_iters` LM iterations and parks its complete LM state, */ \
+      /* a one-workgroup kernel lists the parked ones (those on a bound first), the second launch resumes them in that order  */ \
+      PXR_HIP(hipMemsetAsync(a.prob_heavy, 0, np, st));                                                      \
+      KaArgs a1 = a; a1.phase = 1; a1.park_iters = park_iters;                                               \
+      hipLaunchKernelGGL(kfn, dim3(grid), dim3(KA_NT), shmem, st, a1, d_info);                               \
+      hipLaunchKernelGGL(ka_order_kernel, dim3(1), dim3(1024), 0, st, a, a.sched_list);                      \
+      KaArgs a2 = a; a2.phase = 2; a2.order = a.sched_list;                                                  \
+      hipLaunchKernelGGL(kfn, dim3(grid), dim3(KA_NT), shmem, st, a2, d_info);                               \
+    } else                                                                                                   \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(KA_NT), shmem, st, a, d_info);                                  \
     PXR_HIP(hipEventRecord(ctx->ev_stop, st));                                                               \
   } while (0)

@@ -345,8 +345,9 @@ def test_a_group_with_too_many_chunks_is_refused_through_the_c_abi(ctx):
 
 
 # ---- the two-phase launch (ka_solve_kernel_sched, round 6) ------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["persistent", "two_launches_1", "two_launches_2"])
 @pytest.mark.parametrize("sigma,bound", [(1.0, 4.0), (1.5, 1.5)])
-def test_two_phase_launch_gives_the_one_phase_results_bit_for_bit(ctx, monkeypatch, sigma, bound):
+def test_two_phase_launch_gives_the_one_phase_results_bit_for_bit(ctx, monkeypatch, sigma, bound, variant):
     """More sub-problems than resident workgroups (forced here: a grid of 5): every sub-problem runs ONE LM iteration, parks its LM
     state, and is resumed from a list that starts with those sitting on a bound.  Same arithmetic per sub-problem -- the resumed
     linearisation is accumulated on the grid the interrupted one used -- so keypoints, costs and counts equal the one-phase
@@ -361,7 +362,9 @@ def test_two_phase_launch_gives_the_one_phase_results_bit_for_bit(ctx, monkeypat
     arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
     out = []
     for knob in ("0", "1"):
-        monkeypatch.setenv("PXR_KA_TWO_PHASE", knob)
+        # (the persistent grid, or two launches of the plain kernel that park after 1 / 2 LM iterations: PXR_KA_TWO_LAUNCH)
+        monkeypatch.setenv("PXR_KA_TWO_PHASE", knob if variant == "persistent" else "0")
+        monkeypatch.setenv("PXR_KA_TWO_LAUNCH", "0" if (variant == "persistent" or knob == "0") else variant[-1])
         monkeypatch.setenv("PXR_KA_TWO_PHASE_RESIDENT", "5")
         ka = KAProblem(ctx, arena, prob)
         total, per = ka.solve(interp_cfg(), make_loss("cauchy", [0.25]), bound=bound, options=lm_options(parameter_tolerance=1e-5), per_problem=True)
@@ -389,13 +392,15 @@ def test_two_phase_launch_with_floating_point_atomics(monkeypatch):
     prob = synthetic_ka.make_ka_problem(n_tracks=60, track_len=5, seed=18, max_kps_per_problem=10, sigma=1.5)
     arena = PatchArena.from_numpy(c, prob["patches"], prob["corners"], prob["scales"])
     out = []
-    for knob in ("0", "1"):
-        monkeypatch.setenv("PXR_KA_TWO_PHASE", knob)
+    for knob in ("0", "1", "launches"):
+        monkeypatch.setenv("PXR_KA_TWO_PHASE", "1" if knob == "1" else "0")
+        monkeypatch.setenv("PXR_KA_TWO_LAUNCH", "2" if knob == "launches" else "0")
         monkeypatch.setenv("PXR_KA_TWO_PHASE_RESIDENT", "7")
         ka = KAProblem(c, arena, prob)
         total, per = ka.solve(interp_cfg(), make_loss("cauchy", [0.25]), bound=2.0, options=lm_options(parameter_tolerance=1e-5), per_problem=True)
         out.append((ka.keypoints(), total, per))
-    assert np.abs(out[0][0] - out[1][0]).max() < 1e-9
-    assert [p["iterations"] for p in out[0][2]] == [p["iterations"] for p in out[1][2]]
-    assert abs(out[0][1]["final_cost"] - out[1][1]["final_cost"]) < 1e-10 * out[0][1]["initial_cost"]
+    for other in out[1:]:
+        assert np.abs(out[0][0] - other[0]).max() < 1e-9
+        assert [p["iterations"] for p in out[0][2]] == [p["iterations"] for p in other[2]]
+        assert abs(out[0][1]["final_cost"] - other[1]["final_cost"]) < 1e-10 * out[0][1]["initial_cost"]
     arena.close(); c.close()

@@ -27,7 +27,7 @@ pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ
 # roofline.traffic of the dominant kernel (with-Jacobian instantiation), stamped with the commit it was measured at
 python "$ROOT/tools/pmc_traffic.py" /tmp/pmc_fetch /tmp/pmc_write ba_eval_kernelIDF16_Li128ELb1ELb0 "$ROOT/$OUT/ba_eval_pmc.json" "$CMD" "$COMMIT" \
   $CS/pxr_ba_eval.hip $CS/pxr_interp.h $CS/pxr_device.h > /dev/null 2>> "$ROOT/$OUT/passes.log" || true
-python "$ROOT/tools/pmc_traffic.py" /tmp/pmc_fetch /tmp/pmc_write ka_solve_kernel "$ROOT/$OUT/ka_solve_kernel_traffic.json" "$CMD" "$COMMIT" \
+PMC_PER_KERNEL=ka_order_kernel python "$ROOT/tools/pmc_traffic.py" /tmp/pmc_fetch /tmp/pmc_write ka_solve_kernel "$ROOT/$OUT/ka_solve_kernel_traffic.json" "$CMD" "$COMMIT" \
   $CS/pxr_ka.hip $CS/pxr_interp.h $CS/pxr_device.h > /dev/null 2>> "$ROOT/$OUT/passes.log" || true
 for k in k_schur_lds k_inner_gram k_gram_build k_gram_eval; do
   python "$ROOT/tools/pmc_traffic.py" /tmp/pmc_fetch /tmp/pmc_write $k "$ROOT/$OUT/${k}_traffic.json" "$CMD" "$COMMIT" > /dev/null 2>> "$ROOT/$OUT/passes.log" || true

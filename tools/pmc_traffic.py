@@ -15,14 +15,26 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+PER = os.environ.get("PMC_PER_KERNEL")   # a kernel launched ONCE per unit of work: bytes are then per launch of THAT kernel
+                                         # (pxr_ka_solve runs ka_solve_kernel twice per solve since round 6 and ka_order_kernel once)
+
+
 def mean_counter(root, pattern, counter):
-    vals = []
+    vals, units = [], 0
     for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if pattern in r.get("Kernel_Name", "") and r["Counter_Name"] == counter:
+            if r["Counter_Name"] != counter:
+                continue
+            if pattern in r.get("Kernel_Name", ""):
                 vals.append(float(r["Counter_Value"]))
+            if PER and PER in r.get("Kernel_Name", ""):
+                units += 1
     if not vals:
         raise SystemExit("no %s samples for %s under %s" % (counter, pattern, root))
+    if PER:
+        if not units:
+            raise SystemExit("no launches of %s under %s" % (PER, root))
+        return sum(vals) / units, units
     return sum(vals) / len(vals), len(vals)
 
 
@@ -42,7 +54,7 @@ rd, wr = 2.0 * f * 1024.0, w * 1024.0
 res = {"kernel": pattern, "FETCH_SIZE_KB_per_launch_raw": f, "n_fetch_samples": nf, "WRITE_SIZE_KB_per_launch_raw": w,
        "n_write_samples": nw,
        "correction": "gfx950: read bytes = 2 x FETCH_SIZE x 1024 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported",
-       "measured_at_commit": commit,
+       "measured_at_commit": commit, "per": ("one launch of %s (all launches of the kernel summed)" % PER) if PER else "one launch of the kernel",
        "source_hashes": {os.path.relpath(s, ROOT): blob_hash(s) for s in sources},
        "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
        "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- " + cmd,

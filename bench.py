@@ -541,6 +541,16 @@ def run_lm(job, ba, prob, cfg):
         return lm, extra
     n_img = args.cams
     pose_const, tmask, cmask, ptc = default_gauge(n_img, len(prob["xyz"]))
+    # untimed warm-up, like the W steps of the headline: the FIRST pxr_ba_solve of a process pays for loading ~40 kernels' code
+    # objects, the 1.4 GB Gram-matrix cache and the pinned staging buffers (measured: 9.4 ms of set-up against 2.0 ms for every
+    # later solve, tools/_lm_setup_probe.py) -- a two-iteration solve takes that, its own time is reported as `first_solve_ms`
+    reset_parameters(ba, prob)
+    job.barrier()
+    first = ba.solve(cfg, make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,
+                     options=lm_options(max_iterations=2, use_inner_iterations=True, linear_solver=args.linear_solver),
+                     allreduce=job.solve_allreduce())
+    extra["first_solve_of_the_process"] = {"iterations": first["iterations"], "total_ms": first["total_ms"], "setup_ms": first["setup_ms"],
+                                           "note": "untimed warm-up before the lm / lm_no_inner solves"}
     for key, inner in (("lm", True), ("lm_no_inner", False)):
         reset_parameters(ba, prob)
         job.barrier()
@@ -851,7 +861,7 @@ def compact_line(full):
         o["mode"] = "defaults: deterministic (integer sums), evaluation from cached Gram matrices"
         o["initial_cost"], o["final_cost"] = _r(v.get("initial_cost"), 10), _r(v.get("final_cost"), 10)
         o["linear_solver"] = "direct: Schur + dense Cholesky" if str(v.get("linear_solver", "")).startswith("point") else "iterative: implicit Schur PCG"
-        for sub in ("texel_evaluation", "nondeterministic", "deterministic"):
+        for sub in ("texel_evaluation", "nondeterministic", "deterministic", "first_solve_of_the_process"):
             if isinstance(v.get(sub), dict):
                 o[sub] = {a: _r(b) for a, b in v[sub].items() if not isinstance(b, (dict, list))}
         for sub in ("allreduce_ms", "allreduce_bytes"):

@@ -921,17 +921,88 @@ __global__ __launch_bounds__(256) void k_build_descriptors(int64_t n_obs, const 
 // ---- observation lists on the device (set-up) -------------------------------------------------------------------------
 // counts per image / per point, index range check, and whether the observations are ordered by point (then the
 // point-ordered list is the identity); flags[0] = out-of-range index seen, flags[1] = a point index decreases
+// (the image counts are histogrammed in LDS per chunk of COUNT_CHUNK observations: a million global atomics on the ~13 cache
+//  lines of 200 image counters took 0.5 ms of every solve, profiles/r6_lm_setup.txt)
+constexpr int COUNT_CHUNK = 4096;
 __global__ __launch_bounds__(256) void k_count_indices(int64_t n_obs, const int32_t* __restrict__ obs_image,
                                                        const int32_t* __restrict__ obs_point, int n_img, int64_t n_pts,
                                                        unsigned long long* __restrict__ img_cnt, unsigned long long* __restrict__ pt_cnt,
                                                        int* __restrict__ flags) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_obs) return;
-  const int im = obs_image[i], pt = obs_point[i];
-  if (im < 0 || im >= n_img || pt < 0 || pt >= n_pts) { atomicOr(&flags[0], 1); return; }
-  atomicAdd(&img_cnt[im + 1], 1ull);
-  atomicAdd(&pt_cnt[pt + 1], 1ull);
-  if (i > 0 && obs_point[i - 1] > pt) atomicOr(&flags[1], 1);
+  extern __shared__ unsigned int sh_img[];                 // n_img counters (n_img <= SORT_MAX_IMAGES)
+  for (int k = threadIdx.x; k < n_img; k += 256) sh_img[k] = 0u;
+  __syncthreads();
+  const int64_t i0 = (int64_t)blockIdx.x * COUNT_CHUNK, i1 = min(n_obs, i0 + COUNT_CHUNK);
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    const int im = obs_image[i], pt = obs_point[i];
+    if (im < 0 || im >= n_img || pt < 0 || pt >= n_pts) { atomicOr(&flags[0], 1); continue; }
+    atomicAdd(&sh_img[im], 1u);
+    atomicAdd(&pt_cnt[pt + 1], 1ull);
+    if (i > 0 && obs_point[i - 1] > pt) atomicOr(&flags[1], 1);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < n_img; k += 256)
+    if (sh_img[k]) atomicAdd(&img_cnt[k + 1], (unsigned long long)sh_img[k]);
+}
+// the per-point side of the structure without a trip to the host (200k points: 1.6 MB each way through pageable memory were
+// 0.5 ms of every solve): pt_ptr = prefix sums of the counts k_count_indices left in cnt[p + 1] (cnt[0] = 0), pt_var[p] = the point
+// is not constant and has an observation, *n_var = how many.  Two launches: the sums of chunks of PT_SCAN_CHUNK points, then
+// every workgroup adds up the chunks before its own and scans its chunk.
+constexpr int PT_SCAN_CHUNK = 2048;
+__device__ __forceinline__ unsigned long long block_sum_256(unsigned long long v, unsigned long long* sh) {
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) sh[t] += sh[t + o]; __syncthreads(); }
+  const unsigned long long r = sh[0];
+  __syncthreads();
+  return r;
+}
+__global__ __launch_bounds__(256) void k_pt_scan_partials(int64_t n_pts, const unsigned long long* __restrict__ cnt, unsigned long long* __restrict__ part) {
+  __shared__ unsigned long long sh[256];
+  const int64_t p0 = (int64_t)blockIdx.x * PT_SCAN_CHUNK;
+  unsigned long long s = 0;
+  for (int j = threadIdx.x; j < PT_SCAN_CHUNK; j += 256) if (p0 + j < n_pts) s += cnt[p0 + j + 1];
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_pt_scan_apply(int64_t n_pts, const unsigned long long* __restrict__ cnt, const unsigned long long* __restrict__ part,
+                                                       const uint8_t* __restrict__ pt_const, int64_t* __restrict__ pt_ptr, int* __restrict__ pt_var,
+                                                       unsigned long long* __restrict__ n_var) {
+  __shared__ unsigned long long sh[256];
+  constexpr int PER = PT_SCAN_CHUNK / 256;
+  const int t = threadIdx.x;
+  unsigned long long base = 0;
+  for (int g = t; g < (int)blockIdx.x; g += 256) base += part[g];
+  base = block_sum_256(base, sh);
+  const int64_t p0 = (int64_t)blockIdx.x * PT_SCAN_CHUNK + (int64_t)t * PER;
+  unsigned long long c[PER], mine = 0;
+  int nv = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    c[j] = p0 + j < n_pts ? cnt[p0 + j + 1] : 0ull;
+    mine += c[j];
+  }
+  sh[t] = mine;                                             // inclusive scan of the threads' sums (Hillis-Steele, 8 rounds)
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const unsigned long long add = t >= o ? sh[t - o] : 0ull;
+    __syncthreads();
+    sh[t] += add;
+    __syncthreads();
+  }
+  unsigned long long run = base + sh[t] - mine;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    if (p0 + j >= n_pts) break;
+    run += c[j];
+    pt_ptr[p0 + j + 1] = (int64_t)run;
+    const int v = (!pt_const[p0 + j] && c[j] > 0) ? 1 : 0;
+    pt_var[p0 + j] = v; nv += v;
+  }
+  if (blockIdx.x == 0 && t == 0) pt_ptr[0] = 0;
+  __syncthreads();
+  const unsigned long long tot = block_sum_256((unsigned long long)nv, sh);
+  if (t == 0 && tot) atomicAdd(n_var, tot);
 }
 __global__ void k_iota(int64_t n, int64_t* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1012,13 +1083,14 @@ struct DevBuf {
 // column is the right-hand side (forward substitution is fused into the factorisation), then back-substitute.
 int chol_factor_solve(hipStream_t st, double* a, int n, int* d_info, double* linv_ws, double* x_out, bool zero_info = true);
 size_t chol_workspace_doubles(int n);
+size_t inner_wave_stage_bytes(int64_t n_pts);        // pxr_ba_inner.hip: host room for the packed table of n_pts points, worst case
 
 // pxr_ba_inner.hip
 int launch_inner_iterations(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* view, const pxr_interp_cfg* cfg,
                             const pxr_loss* loss, const int64_t* d_pt_ptr, const int64_t* d_pt_obs,
                             const int* d_pt_var, double* d_cost_before, const InnerLists* lists, double* d_cost_per_point,
                             const GramCache* gram, bool gram_warm);
-int make_inner_lists(hipStream_t st, const std::vector<int64_t>& pt_ptr, const pxr_ba_view* view, const int64_t* d_pt_ptr, const int64_t* d_pt_obs,
+int make_inner_lists(pxr_ctx* ctx, const int64_t* h_pt_ptr, int64_t n_pts, void* h_wave_stage, size_t wave_stage_bytes, const pxr_ba_view* view, const int64_t* d_pt_ptr, const int64_t* d_pt_obs,
                      InnerLists* out);
 void free_inner_lists(InnerLists* l);
 
@@ -1057,31 +1129,33 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   // to the host, the lists are built by a stable counting sort on the device.  Otherwise (and with PXR_BA_SETUP_HOST=1,
   // for the equivalence test) the lists are built on the host from a copy of the index arrays.
   std::vector<int32_t> obs_image, obs_point, image_camera(n_img), cam_model(n_cam);
-  std::vector<int64_t> img_cnt(n_img + 1, 0), pt_cnt(n_pts + 1, 0);
+  std::vector<int64_t> img_cnt(n_img + 1, 0), pt_cnt;      // (pt_cnt: the general host path only -- the fast path keeps the per-point side on the device)
   DevBuf<unsigned long long> d_cnt;
   DevBuf<int> d_flags;
   bool device_lists = n_img <= SORT_MAX_IMAGES && std::getenv("PXR_BA_SETUP_HOST") == nullptr;
   PXR_HIP(hipMemcpyAsync(image_camera.data(), view->d_image_camera, 4 * n_img, hipMemcpyDeviceToHost, st));
   PXR_HIP(hipMemcpyAsync(cam_model.data(), view->d_cam_model, 4 * n_cam, hipMemcpyDeviceToHost, st));
+  setup_mark("camera tables read");
   if (device_lists) {
     int h_flags[2] = {0, 0};
-    RC(d_cnt.alloc((size_t)n_img + 1 + (size_t)n_pts + 1)); RC(d_flags.alloc(2));
+    RC(d_cnt.alloc((size_t)n_img + 1 + (size_t)n_pts + 1 + 1)); RC(d_flags.alloc(2));     // ... + the number of variable points
+    setup_mark("counter buffers");
     PXR_HIP(hipMemsetAsync(d_cnt.p, 0, sizeof(unsigned long long) * d_cnt.n, st));
     PXR_HIP(hipMemsetAsync(d_flags.p, 0, sizeof(int) * 2, st));
-    hipLaunchKernelGGL(k_count_indices, dim3((unsigned)((n_obs + 255) / 256)), dim3(256), 0, st, n_obs, view->d_obs_image,
+    hipLaunchKernelGGL(k_count_indices, dim3((unsigned)((n_obs + COUNT_CHUNK - 1) / COUNT_CHUNK)), dim3(256), sizeof(unsigned int) * n_img, st, n_obs, view->d_obs_image,
                        view->d_obs_point, n_img, n_pts, d_cnt.p, d_cnt.p + n_img + 1, d_flags.p);
     static_assert(sizeof(unsigned long long) == sizeof(int64_t), "counter width");
     PXR_HIP(hipMemcpyAsync(img_cnt.data(), d_cnt.p, sizeof(int64_t) * (n_img + 1), hipMemcpyDeviceToHost, st));
-    PXR_HIP(hipMemcpyAsync(pt_cnt.data(), d_cnt.p + n_img + 1, sizeof(int64_t) * (n_pts + 1), hipMemcpyDeviceToHost, st));
     PXR_HIP(hipMemcpyAsync(h_flags, d_flags.p, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
     PXR_HIP(hipStreamSynchronize(st));
     PXR_REQUIRE(h_flags[0] == 0, "pxr_ba_solve: an observation references an image / point out of range");
     if (h_flags[1]) {                       // not ordered by point: the general host path
       device_lists = false;
-      std::fill(img_cnt.begin(), img_cnt.end(), 0); std::fill(pt_cnt.begin(), pt_cnt.end(), 0);
+      std::fill(img_cnt.begin(), img_cnt.end(), 0);
     }
   }
   if (!device_lists) {
+    pt_cnt.assign(n_pts + 1, 0);
     obs_image.resize(n_obs); obs_point.resize(n_obs);
     PXR_HIP(hipMemcpyAsync(obs_image.data(), view->d_obs_image, 4 * n_obs, hipMemcpyDeviceToHost, st));
     PXR_HIP(hipMemcpyAsync(obs_point.data(), view->d_obs_point, 4 * n_obs, hipMemcpyDeviceToHost, st));
@@ -1101,7 +1175,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   }
   // With several ranks a camera-side block may have no local observation but still be part of the
   // (global) program: the caller marks unused blocks constant, we keep every non-constant block.
-  std::vector<int> pose_off(n_img), pose_dim(n_img), tmask(n_img), intr_off(n_cam), intr_dim(n_cam), cmask(n_cam), pt_var(n_pts);
+  std::vector<int> pose_off(n_img), pose_dim(n_img), tmask(n_img), intr_off(n_cam), intr_dim(n_cam), cmask(n_cam), pt_var;
   int off = 0, dpose_max = 0, dintr_max = 0;
   for (int i = 0; i < n_img; ++i) {
     int d = 0;
@@ -1128,10 +1202,13 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   sum->linear_solver = iterative ? PXR_LINEAR_ITERATIVE : PXR_LINEAR_DIRECT;
   sum->linear_iterations = 0; sum->collective_kib = 0;
   int64_t n_pvar = 0;
-  for (int64_t p = 0; p < n_pts; ++p) { pt_var[p] = (!h_point_const[p] && pt_cnt[p + 1] > 0) ? 1 : 0; n_pvar += pt_var[p]; }
-  PXR_REQUIRE(n_c > 0 || n_pvar > 0, "pxr_ba_solve: every parameter block is constant");
+  if (!device_lists) {
+    pt_var.resize(n_pts);
+    for (int64_t p = 0; p < n_pts; ++p) { pt_var[p] = (!h_point_const[p] && pt_cnt[p + 1] > 0) ? 1 : 0; n_pvar += pt_var[p]; }
+    PXR_REQUIRE(n_c > 0 || n_pvar > 0, "pxr_ba_solve: every parameter block is constant");
+    for (int64_t p = 0; p < n_pts; ++p) pt_cnt[p + 1] += pt_cnt[p];
+  }
   for (int i = 0; i < n_img; ++i) img_cnt[i + 1] += img_cnt[i];
-  for (int64_t p = 0; p < n_pts; ++p) pt_cnt[p + 1] += pt_cnt[p];
   std::vector<int64_t> img_obs, pt_obs;
   if (!device_lists) {
     img_obs.resize(n_obs); pt_obs.resize(n_obs);
@@ -1192,8 +1269,21 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   DevBuf<int> d_part_obs;
   RC(d_pose_off.upload(pose_off, st)); RC(d_pose_dim.upload(pose_dim, st)); RC(d_tmask.upload(tmask, st));
   RC(d_intr_off.upload(intr_off, st)); RC(d_intr_dim.upload(intr_dim, st)); RC(d_cmask.upload(cmask, st));
-  RC(d_pt_var.upload(pt_var, st)); RC(d_pt_ptr.upload(pt_cnt, st)); RC(d_chunks.upload(chunks, st));
+  RC(d_chunks.upload(chunks, st));
+  DevBuf<uint8_t> d_pt_const;
+  DevBuf<unsigned long long> d_pt_part;
+  unsigned long long h_n_pvar = 0;
+  if (!device_lists) { RC(d_pt_var.upload(pt_var, st)); RC(d_pt_ptr.upload(pt_cnt, st)); }
   if (device_lists) {
+    // offsets, variable flags and their number from the counts that never left the device (k_pt_scan_*)
+    const int n_parts = (int)((n_pts + PT_SCAN_CHUNK - 1) / PT_SCAN_CHUNK);
+    unsigned long long* const d_pt_cnt = d_cnt.p + n_img + 1;
+    RC(d_pt_var.alloc(n_pts)); RC(d_pt_ptr.alloc((size_t)n_pts + 1)); RC(d_pt_const.alloc(n_pts)); RC(d_pt_part.alloc(n_parts));
+    PXR_HIP(hipMemcpyAsync(d_pt_const.p, h_point_const, (size_t)n_pts, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_pt_scan_partials, dim3(n_parts), dim3(256), 0, st, n_pts, (const unsigned long long*)d_pt_cnt, d_pt_part.p);
+    hipLaunchKernelGGL(k_pt_scan_apply, dim3(n_parts), dim3(256), 0, st, n_pts, (const unsigned long long*)d_pt_cnt, (const unsigned long long*)d_pt_part.p,
+                       (const uint8_t*)d_pt_const.p, d_pt_ptr.p, d_pt_var.p, d_pt_cnt + n_pts + 1);
+    PXR_HIP(hipMemcpyAsync(&h_n_pvar, d_pt_cnt + n_pts + 1, sizeof(h_n_pvar), hipMemcpyDeviceToHost, st));
     RC(d_img_obs.alloc(n_obs)); RC(d_pt_obs.alloc(n_obs));
     hipLaunchKernelGGL(k_iota, dim3(nblk(n_obs)), dim3(256), 0, st, n_obs, d_pt_obs.p);     // ordered by point already
     DevBuf<int64_t> d_img_ptr;
@@ -1205,7 +1295,11 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     hipLaunchKernelGGL(k_sort_scatter, dim3(n_chunks), dim3(256), sizeof(int) * (n_img + 256), st, n_obs, view->d_obs_image, n_img,
                        d_hist.p, d_img_obs.p);
     LAUNCH_CHECK("observation-list kernels");
+    setup_mark("list kernels launched");
     PXR_HIP(hipStreamSynchronize(st));      // d_img_ptr / d_hist go out of scope
+    setup_mark("list kernels done");
+    n_pvar = (int64_t)h_n_pvar;
+    PXR_REQUIRE(n_c > 0 || n_pvar > 0, "pxr_ba_solve: every parameter block is constant");
   } else {
     RC(d_img_obs.upload(img_obs, st)); RC(d_pt_obs.upload(pt_obs, st));
   }
@@ -1430,6 +1524,7 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
     gram_cache = false; inner_cache = false;
     (void)set_error(PXR_OK, "");    // pxr_last_error() must not keep the allocation's message
   }
+  setup_mark("Gram-matrix cache prepared");
   bool gram_warm = false;               // the cache holds every observation's matrices (after the first evaluation / inner call)
   int n_evaluations = 0;
   // The initial point is evaluated by the exact-order kernel (below), candidates from the cache: until a step is accepted the
@@ -1560,7 +1655,22 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
 
   // the inner iterations' tables (a pass over the points on the host, two small uploads): set-up, like the observation lists
   struct InnerListsOwner { InnerLists l; ~InnerListsOwner() { free_inner_lists(&l); } } inner_lists;
-  if (gram_inner) RC(make_inner_lists(st, pt_cnt, view, d_pt_ptr.p, d_pt_obs.p, &inner_lists.l));     // (pt_cnt holds the prefix sums by now)
+  if (gram_inner) {
+    const int64_t* h_pt_ptr = pt_cnt.data();                // (general path: pt_cnt holds the prefix sums by now)
+    std::vector<int64_t> pageable;
+    void* wave_stage = nullptr;                              // pinned room for the table the host packs (uploaded from where it is built)
+    const size_t ptr_bytes = (sizeof(int64_t) * ((size_t)n_pts + 1) + 255) & ~(size_t)255, wave_bytes = inner_wave_stage_bytes(n_pts);
+    if (device_lists) {                                      // fast path: the offsets come back once, through pinned memory
+      int64_t* stage = (ptr_bytes + wave_bytes) <= ((size_t)1 << 28) ? static_cast<int64_t*>(setup_staging(ctx, ptr_bytes + wave_bytes)) : nullptr;
+      if (stage) wave_stage = reinterpret_cast<char*>(stage) + ptr_bytes;
+      else { pageable.resize((size_t)n_pts + 1); stage = pageable.data(); }
+      PXR_HIP(hipMemcpyAsync(stage, d_pt_ptr.p, sizeof(int64_t) * ((size_t)n_pts + 1), hipMemcpyDeviceToHost, st));
+      PXR_HIP(hipStreamSynchronize(st));
+      h_pt_ptr = stage;
+    }
+    RC(make_inner_lists(ctx, h_pt_ptr, n_pts, wave_stage, wave_stage ? wave_bytes : 0, view, d_pt_ptr.p, d_pt_obs.p, &inner_lists.l));
+  }
+  setup_mark("inner-iteration tables");
   const auto t_loop0 = std::chrono::steady_clock::now();
   sum->setup_ms = std::chrono::duration<double, std::milli>(t_loop0 - t_setup0).count();
   sum->num_camera_unknowns = n_c; sum->num_point_unknowns = 3 * n_pvar;

@@ -14,6 +14,8 @@ struct pxr_ctx {
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   hipEvent_t ev_sync = nullptr;  // the LM loop's polled host synchronisation (pxr_ba_solve)
   void* h_readback = nullptr;    // 4 KiB of pinned host memory: the LM loop's per-attempt read-back (an async copy into pageable memory blocks the host)
+  void* h_setup = nullptr;       // grow-only pinned staging of the solvers' set-up (per-point offsets for the host's table building)
+  size_t h_setup_bytes = 0;
   double* d_scratch = nullptr;   // small reduction scratch (device)
   size_t scratch_bytes = 0;
   int num_cus = 256;
@@ -56,6 +58,8 @@ inline int hip_check(hipError_t e, const char* what) {
   if (e == hipSuccess) return PXR_OK;
   return set_error(PXR_EHIP, "%s: %s", what, hipGetErrorString(e));
 }
+// `bytes` of pinned host memory owned by the context (grow-only; NULL when it cannot be had: the caller takes its pageable path)
+void* setup_staging(pxr_ctx* ctx, size_t bytes);
 // in-place all-reduce(sum) on the context's stream through its RCCL communicator (no-op without one)
 int comm_allreduce_sum(pxr_ctx* ctx, double* d_buf, int64_t count, bool even_single_rank = false);
 int comm_allreduce_sum_i64(pxr_ctx* ctx, long long* d_buf, int64_t count);

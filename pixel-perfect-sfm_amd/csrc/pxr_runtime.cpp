@@ -26,6 +26,14 @@ int set_error(int code, const char* fmt, ...) {
   g_error = buf;
   return code;
 }
+void* setup_staging(pxr_ctx* ctx, size_t bytes) {
+  if (ctx->h_setup_bytes >= bytes) return ctx->h_setup;
+  if (ctx->h_setup) { (void)hipHostFree(ctx->h_setup); ctx->h_setup = nullptr; ctx->h_setup_bytes = 0; }
+  const size_t want = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+  if (hipHostMalloc(&ctx->h_setup, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->h_setup = nullptr; return nullptr; }
+  ctx->h_setup_bytes = want;
+  return ctx->h_setup;
+}
 }  // namespace pxr
 
 static void release_staging(pxr_ctx* ctx);
@@ -67,6 +75,7 @@ int pxr_ctx_destroy(pxr_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->h_readback) { (void)hipHostFree(ctx->h_readback); ctx->h_readback = nullptr; }
+  if (ctx->h_setup) { (void)hipHostFree(ctx->h_setup); ctx->h_setup = nullptr; ctx->h_setup_bytes = 0; }
   if (ctx->comm) (void)pxr_comm_destroy(ctx);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->d_workspace) (void)hipFree(ctx->d_workspace);

@@ -14,7 +14,6 @@ import torch
 
 from cases import residual_cases as gen
 
-torch.set_default_dtype(torch.float64)
 
 
 def _cr(p0, p1, p2, p3, x):

@@ -404,3 +404,34 @@ def test_two_phase_launch_with_floating_point_atomics(monkeypatch):
         assert [p["iterations"] for p in out[0][2]] == [p["iterations"] for p in other[2]]
         assert abs(out[0][1]["final_cost"] - other[1]["final_cost"]) < 1e-10 * out[0][1]["initial_cost"]
     arena.close(); c.close()
+
+
+@pytest.mark.parametrize("scale", [300.0, 3000.0])
+def test_two_launches_with_a_fixed_point_rescale_in_between(ctx, monkeypatch, scale):
+    """Raw features 300x / 3000x unit norm: sub-problems stop with the internal 'coarser grid' code in EITHER launch of the two-launch
+    schedule and the solve is launched again.  Parked state and rescale state share one record per sub-problem: the result must
+    still be the one-launch result bit for bit."""
+    from pixsfm_amd import synthetic_ka
+    from pixsfm_amd.engine import PatchArena, interp_cfg, lm_options, make_loss
+    from pixsfm_amd.ka_engine import KAProblem
+    prob = dict(synthetic_ka.make_ka_problem(n_tracks=90, track_len=5, seed=23, max_kps_per_problem=15, sigma=1.5))
+    prob["patches"] = (prob["patches"].astype(np.float32) * scale).astype(np.float16)
+    assert np.isfinite(prob["patches"].astype(np.float32)).all()
+    arena = PatchArena.from_numpy(ctx, prob["patches"], prob["corners"], prob["scales"])
+    out = []
+    for knob in ("0", "1", "2", "3"):
+        monkeypatch.setenv("PXR_KA_TWO_LAUNCH", knob)
+        monkeypatch.setenv("PXR_KA_TWO_PHASE_RESIDENT", "5")
+        ka = KAProblem(ctx, arena, prob)
+        total, per = ka.solve(interp_cfg(l2_normalize=False), make_loss("cauchy", [0.25 * scale]), bound=3.0,
+                              options=lm_options(parameter_tolerance=1e-5), per_problem=True)
+        out.append((ka.keypoints(), total, per))
+    assert ctx.deterministic
+    for kp, total, per in out[1:]:
+        assert np.array_equal(out[0][0], kp)
+        assert total["final_cost"] == out[0][1]["final_cost"] and total["num_successful"] == out[0][1]["num_successful"]
+        for a, b in zip(out[0][2], per):
+            for k in ("iterations", "num_successful", "termination", "initial_cost", "final_cost"):
+                assert a[k] == b[k], (k, a[k], b[k])
+    assert out[0][1]["final_cost"] < out[0][1]["initial_cost"]
+    arena.close()

@@ -74,3 +74,48 @@ def test_native_labelling_equals_the_oracle_and_has_the_defining_properties():
             assert reach == members, (name, t)
         n_conflicts += sum(1 for nd in g.nodes for m in nd.out_matches if tl[nd.node_idx] != tl[m.node_idx])
     assert n_conflicts > 100                                                       # the conflict rule is exercised
+
+
+def test_tracks_against_networkx_components():
+    """Third-party check (networkx, code the builder did not write): with matches that never put two features of one image into
+    one component, ComputeTrackLabels (graph.cc:126-206) is plain connected components -- the partition must equal
+    networkx.connected_components; with conflicts every track is a connected induced subgraph inside one component."""
+    import networkx as nx
+    from pixsfm_amd.api import base
+    rng = np.random.default_rng(2718)
+    # (a) conflict-free: ground-truth tracks, one feature per image, matches only inside a track
+    for trial in range(8):
+        n_img, n_tracks = int(rng.integers(3, 8)), int(rng.integers(5, 40))
+        feat = {}                                             # (track, image) -> feature index in that image
+        counters = [0] * n_img
+        for t in range(n_tracks):
+            for i in rng.permutation(n_img)[: int(rng.integers(2, n_img + 1))]:
+                feat[(t, int(i))] = counters[int(i)]; counters[int(i)] += 1
+        g = base.Graph()
+        for a in range(n_img):
+            for b in range(a + 1, n_img):
+                m = [(feat[(t, a)], feat[(t, b)]) for t in range(n_tracks) if (t, a) in feat and (t, b) in feat and rng.random() < 0.7]
+                if m:
+                    g.register_matches("im%d" % a, "im%d" % b, np.array(m, np.int64), rng.uniform(0.2, 1.0, len(m)))
+        tl = np.asarray(base.compute_track_labels(g))
+        G = nx.Graph()
+        G.add_nodes_from(range(len(g.nodes)))
+        G.add_edges_from((nd.node_idx, m.node_idx) for nd in g.nodes for m in nd.out_matches)
+        comps = {frozenset(c) for c in nx.connected_components(G)}
+        tracks = {frozenset(np.flatnonzero(tl == t).tolist()) for t in np.unique(tl)}
+        assert tracks == comps, trial
+    # (b) with conflicts: tracks are connected pieces of components
+    for name, pairs, mm in gen_mod.cases():
+        g = _build(base, pairs, mm)
+        tl = np.asarray(base.compute_track_labels(g))
+        G = nx.Graph()
+        G.add_nodes_from(range(len(g.nodes)))
+        G.add_edges_from((nd.node_idx, m.node_idx) for nd in g.nodes for m in nd.out_matches)
+        comp_of = {}
+        for k, c in enumerate(nx.connected_components(G)):
+            for v in c:
+                comp_of[v] = k
+        for t in np.unique(tl):
+            members = np.flatnonzero(tl == t).tolist()
+            assert len({comp_of[v] for v in members}) == 1, (name, t)
+            assert nx.is_connected(G.subgraph(members)), (name, t)

@@ -94,3 +94,41 @@ def test_hip_interpolation_equals_pillow(ctx):
         want = bigs[ch][rr.ravel(), cc.ravel()].astype(np.float64)
         assert np.abs(desc[:, ch] - want).max() < 5e-6, (ch, np.abs(desc[:, ch] - want).max())
     arena.close()
+
+
+def _scipy_bicubic(P, r, c):
+    """value, d/dr, d/dc at (r, c) of the Catmull-Rom surface over P (H, W) with clamped indices (grid2d.h:64-73), evaluated by
+    scipy.interpolate.CubicHermiteSpline: knots 0 and 1 of the cell, tangents = central differences of the neighbours."""
+    from scipy.interpolate import CubicHermiteSpline
+    H, W = P.shape
+    r0, c0 = int(np.floor(r)), int(np.floor(c))
+    rows = [min(max(r0 - 1 + j, 0), H - 1) for j in range(4)]
+    cols = [min(max(c0 - 1 + i, 0), W - 1) for i in range(4)]
+
+    def seg(p):       # p: four samples -> the spline of the middle interval
+        return CubicHermiteSpline([0.0, 1.0], [p[1], p[2]], [0.5 * (p[2] - p[0]), 0.5 * (p[3] - p[1])])
+    h, hc = [], []
+    for j in range(4):
+        s = seg([P[rows[j], cols[i]] for i in range(4)])
+        h.append(float(s(c - c0))); hc.append(float(s.derivative()(c - c0)))
+    sv = seg(h)
+    return float(sv(r - r0)), float(sv.derivative()(r - r0)), float(seg(hc)(r - r0))
+
+
+def test_oracle_bicubic_and_derivatives_equal_scipys_hermite_spline():
+    """Values AND both derivatives, border cells included, against scipy's CubicHermiteSpline (the scalar fp64 path of
+    interpolation.h:222-268 for C < 8: 1e-12; the SIMD contract for C >= 8 -- fp32 horizontal pass -- 2e-6)."""
+    import pxo
+    rng = np.random.default_rng(21)
+    H, W = 9, 11
+    for C, tol in ((1, 1e-12), (8, 2e-6)):
+        data = np.ascontiguousarray(rng.normal(size=(H, W, C)))
+        patch = pxo.make_patch(data)
+        pts = np.stack([rng.uniform(0.0, H - 1.001, 60), rng.uniform(0.0, W - 1.001, 60)], 1)
+        pts[:6] = [[0.3, 0.4], [0.2, W - 1.3], [H - 1.4, 0.6], [H - 1.2, W - 1.1], [0.5, 5.5], [4.5, 0.25]]     # border cells
+        for r, c in pts:
+            f, dr, dc = pxo.bicubic(patch, float(r), float(c))
+            for ch in range(C):
+                v, vr, vc = _scipy_bicubic(data[:, :, ch], r, c)
+                scale = max(1.0, abs(v), abs(vr), abs(vc))
+                assert abs(f[ch] - v) < tol * scale and abs(dr[ch] - vr) < tol * scale and abs(dc[ch] - vc) < tol * scale, (C, r, c, ch)

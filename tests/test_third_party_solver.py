@@ -175,3 +175,23 @@ def test_gpu_ka_ends_at_scipys_optimum(ctx, name):
     assert np.abs(ka.keypoints() - sp.keypoints(xs)).max() < 1e-5
     assert abs(total["final_cost"] - cs) < 1e-9 * cs
     arena.close()
+
+
+def test_loss_functions_equal_scipys_implementations():
+    """rho, rho', rho'' of the oracle's robustifiers (A20; ceres::CauchyLoss / HuberLoss / SoftLOneLoss as published:
+    rho(s) = a^2 rho0(s / a^2)) against the loss functions scipy.optimize.least_squares is built from
+    (scipy.optimize._lsq.least_squares.IMPLEMENTED_LOSSES: rho0(z), rho0'(z), rho0''(z) for z = s / a^2)."""
+    import pxo
+    from scipy.optimize._lsq.least_squares import IMPLEMENTED_LOSSES
+    rng = np.random.default_rng(4)
+    for name in ("cauchy", "huber", "soft_l1"):
+        for a in (0.25, 1.0, 3.0):
+            ls = pxo.loss(name, a)
+            s = np.concatenate([rng.uniform(0.0, 4.0 * a * a, 40), [0.0, 0.5 * a * a, 2.0 * a * a, 50.0 * a * a]])
+            z = s / (a * a)
+            rho0 = np.empty((3, len(z)))
+            IMPLEMENTED_LOSSES[name](z, rho0, False)
+            for k, sk in enumerate(s):
+                got = pxo.loss_eval(ls, float(sk))
+                want = np.array([a * a * rho0[0, k], rho0[1, k], rho0[2, k] / (a * a)])
+                assert np.allclose(got, want, rtol=1e-13, atol=1e-15), (name, a, sk, got, want)

@@ -543,7 +543,8 @@ def run_lm(job, ba, prob, cfg):
     pose_const, tmask, cmask, ptc = default_gauge(n_img, len(prob["xyz"]))
     # untimed warm-up, like the W steps of the headline: the FIRST pxr_ba_solve of a process pays for loading ~40 kernels' code
     # objects, the 1.4 GB Gram-matrix cache and the pinned staging buffers (measured: 9.4 ms of set-up against 2.0 ms for every
-    # later solve, tools/_lm_setup_probe.py) -- a two-iteration solve takes that, its own time is reported as `first_solve_ms`
+    # later solve -- outside total_ms -- and 1.7 ms more inside it, tools/_lm_setup_probe.py) -- a two-iteration solve takes that,
+    # its own time is reported as `first_solve_of_the_process`
     reset_parameters(ba, prob)
     job.barrier()
     first = ba.solve(cfg, make_loss("cauchy", [0.25]), pose_const, tmask, cmask, ptc,

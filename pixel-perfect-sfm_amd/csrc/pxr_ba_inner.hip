@@ -1583,9 +1583,11 @@ int make_inner_lists(pxr_ctx* ctx, const int64_t* pt_ptr, int64_t n, void* h_wav
   out->n_short = n_short; out->n_long = (int64_t)longs.size(); out->maxo_short = maxo;
   out->d_short = nullptr; out->d_long = nullptr; out->d_slots = nullptr;
   if (!shorts.empty()) {
-    if (int rc = hip_check(hipMalloc(&out->d_short, sizeof(GramPoint) * shorts.size()), "hipMalloc(inner lists)")) return rc;
+    out->d_short = solve_scratch(sizeof(GramPoint) * shorts.size(), &out->own_short);
+    if (!out->d_short) return set_error(PXR_ENOMEM, "hipMalloc(inner lists)");
     if (int rc = hip_check(hipMemcpyAsync(out->d_short, shorts.data(), sizeof(GramPoint) * shorts.size(), hipMemcpyHostToDevice, st), "H2D")) return rc;
-    if (int rc = hip_check(hipMalloc(&out->d_slots, gram_entry_bytes(maxo) * shorts.size()), "hipMalloc(inner table)")) return rc;
+    out->d_slots = solve_scratch(gram_entry_bytes(maxo) * shorts.size(), &out->own_slots);
+    if (!out->d_slots) return set_error(PXR_ENOMEM, "hipMalloc(inner table)");
     const int64_t n_thr = (int64_t)shorts.size() * (maxo + 1);
     hipLaunchKernelGGL(k_gram_table, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, st, (int64_t)shorts.size(), maxo,
                        static_cast<const GramPoint*>(out->d_short), d_pt_obs, view->d_obs_image, view->d_obs_patch, view->d_image_camera,
@@ -1593,8 +1595,8 @@ int make_inner_lists(pxr_ctx* ctx, const int64_t* pt_ptr, int64_t n, void* h_wav
   }
   if (n_wv > 0) {            // one allocation: the headers as the host packed them, then the table the kernel reads
     const size_t heads = (sizeof(GramWave) * (size_t)n_wv + 255) & ~(size_t)255;
-    char* d_all = nullptr;
-    if (int rc = hip_check(hipMalloc((void**)&d_all, heads + gram_wave_bytes() * (size_t)n_wv), "hipMalloc(inner wave table)")) return rc;
+    char* d_all = static_cast<char*>(solve_scratch(heads + gram_wave_bytes() * (size_t)n_wv, &out->own_heads));
+    if (!d_all) return set_error(PXR_ENOMEM, "hipMalloc(inner wave table)");
     out->d_wave_heads = d_all; out->d_waves = d_all + heads;
     if (int rc = hip_check(hipMemcpyAsync(d_all, waves, sizeof(GramWave) * (size_t)n_wv, hipMemcpyHostToDevice, st), "H2D")) return rc;
     const int64_t n_thr2 = n_wv * (GW_SLOTS + 1);
@@ -1603,16 +1605,17 @@ int make_inner_lists(pxr_ctx* ctx, const int64_t* pt_ptr, int64_t n, void* h_wav
                        static_cast<char*>(out->d_waves));
   }
   if (!longs.empty()) {
-    if (int rc = hip_check(hipMalloc((void**)&out->d_long, sizeof(int) * longs.size()), "hipMalloc(inner lists)")) return rc;
+    out->d_long = static_cast<int*>(solve_scratch(sizeof(int) * longs.size(), &out->own_long));
+    if (!out->d_long) return set_error(PXR_ENOMEM, "hipMalloc(inner lists)");
     if (int rc = hip_check(hipMemcpyAsync(out->d_long, longs.data(), sizeof(int) * longs.size(), hipMemcpyHostToDevice, st), "H2D")) return rc;
   }
   return hip_check(hipStreamSynchronize(st), "inner lists upload");    // the host vectors go out of scope
 }
 void free_inner_lists(InnerLists* l) {
-  if (l->d_short) (void)hipFree(l->d_short);
-  if (l->d_long) (void)hipFree(l->d_long);
-  if (l->d_slots) (void)hipFree(l->d_slots);
-  if (l->d_wave_heads) (void)hipFree(l->d_wave_heads);      // (d_waves lies inside it)
+  if (l->d_short && l->own_short) (void)hipFree(l->d_short);
+  if (l->d_long && l->own_long) (void)hipFree(l->d_long);
+  if (l->d_slots && l->own_slots) (void)hipFree(l->d_slots);
+  if (l->d_wave_heads && l->own_heads) (void)hipFree(l->d_wave_heads);      // (d_waves lies inside it)
   l->d_short = nullptr; l->d_long = nullptr; l->d_slots = nullptr; l->d_waves = nullptr; l->d_wave_heads = nullptr;
 }
 

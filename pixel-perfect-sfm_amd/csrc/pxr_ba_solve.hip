@@ -1062,13 +1062,32 @@ __global__ __launch_bounds__(256) void k_sort_scatter(int64_t n_obs, const int32
 }
 
 // ---- host orchestration -----------------------------------------------------------------------------------
+// The ~60 work buffers of a solve come out of ONE grow-only allocation of the context (round 6): the first solve of a size takes
+// them from hipMalloc and records what it needed, the next ones bump a pointer -- ~60 hipMalloc at the start and ~60 hipFree at the
+// end (each a device synchronisation) were 4 ms of a 24 ms call at 1M observations (profiles/r6_lm_setup.txt).  The arena of the
+// solve that is running on this thread; NULL outside pxr_ba_solve and with PXR_BA_ARENA=0.
+struct SolveArena { char* base = nullptr; size_t cap = 0, used = 0, wanted = 0; };
+static thread_local SolveArena* g_solve_arena = nullptr;
+void* solve_scratch(size_t bytes, bool* owned) {
+  const size_t b = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
+  if (SolveArena* a = g_solve_arena) {
+    a->wanted += b;
+    if (a->used + b <= a->cap) { void* p = a->base + a->used; a->used += b; *owned = false; return p; }
+  }
+  void* p = nullptr;
+  *owned = true;
+  if (hipMalloc(&p, b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  bool owned = true;
   int alloc(size_t count) {
     n = count;
-    return hip_check(hipMalloc((void**)&p, sizeof(T) * (count ? count : 1)), "hipMalloc(solver buffer)");
+    p = static_cast<T*>(solve_scratch(sizeof(T) * (count ? count : 1), &owned));
+    return p ? PXR_OK : set_error(PXR_ENOMEM, "hipMalloc(solver buffer): %zu bytes", sizeof(T) * count);
   }
   int upload(const std::vector<T>& h, hipStream_t s) {
     int rc = alloc(h.size());
@@ -1076,7 +1095,7 @@ struct DevBuf {
     if (!h.empty()) return hip_check(hipMemcpyAsync(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice, s), "H2D");
     return PXR_OK;
   }
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { if (p && owned) (void)hipFree(p); }
 };
 
 // pxr_chol.hip: factor the n x n SPD system stored row-major (upper) in the n x (n + 1) buffer `a` whose last
@@ -1114,6 +1133,26 @@ extern "C" int pxr_ba_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ba_view* v
   PXR_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const auto t_setup0 = std::chrono::steady_clock::now();
+  // (declared before every buffer: destroyed after all of them -- then the arena grows to what this solve asked for)
+  struct ArenaScope {
+    pxr_ctx* ctx; SolveArena a; bool on;
+    explicit ArenaScope(pxr_ctx* c) : ctx(c) {
+      const char* e = std::getenv("PXR_BA_ARENA");
+      on = !(e && e[0] == '0');
+      a.base = static_cast<char*>(c->d_solve_arena); a.cap = c->solve_arena_bytes;
+      if (on) g_solve_arena = &a;
+    }
+    ~ArenaScope() {
+      g_solve_arena = nullptr;
+      if (!on || a.wanted <= a.cap) return;
+      (void)hipDeviceSynchronize();                         // (an error return may leave kernels of this solve in flight)
+      if (ctx->d_solve_arena) (void)hipFree(ctx->d_solve_arena);
+      ctx->d_solve_arena = nullptr; ctx->solve_arena_bytes = 0;
+      const size_t want = a.wanted + a.wanted / 16 + (1u << 20);
+      if (hipMalloc(&ctx->d_solve_arena, want) == hipSuccess) ctx->solve_arena_bytes = want;
+      else { (void)hipGetLastError(); ctx->d_solve_arena = nullptr; }     // no room to keep it: the next solve allocates per buffer again
+    }
+  } arena_scope(ctx);
   const bool setup_verbose = std::getenv("PXR_VERBOSE") != nullptr;
   auto setup_mark = [&](const char* what) {
     if (setup_verbose)

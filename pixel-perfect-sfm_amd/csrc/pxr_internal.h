@@ -37,6 +37,8 @@ struct pxr_ctx {
   bool gram_cache = true;        // pxr_set_gram_cache / PXR_GRAM_CACHE=0 opts out: pxr_ba_solve evaluates from cached Gram matrices (pxr_ba_gram.hip)
   void* d_gram = nullptr;        // grow-only storage of that cache
   size_t gram_bytes = 0;
+  void* d_solve_arena = nullptr; // grow-only storage of pxr_ba_solve's ~60 work buffers (sized by the previous solve; PXR_BA_ARENA=0: hipMalloc / hipFree per buffer)
+  size_t solve_arena_bytes = 0;
 };
 
 struct pxr_arena {
@@ -74,7 +76,11 @@ struct InnerLists {
   void* d_slots = nullptr;                                            // the Gram-matrix kernel's table: per listed point {point, length, first slot} + {image, camera, patch, observation} x maxo_short
   void* d_waves = nullptr; int64_t n_waves = 0;                       // the packed Gram-matrix kernel's table: per wavefront {<= 4 points, first slots} + 16 observation slots
   void* d_wave_heads = nullptr;
+  bool own_short = true, own_long = true, own_slots = true, own_heads = true;   // false: carved out of the solve's arena (solve_scratch), not freed
 };
+// pxr_ba_solve.hip: `bytes` of device memory for the duration of the running pxr_ba_solve -- from the context's arena when it has
+// room (*owned = false), else from hipMalloc (*owned = true: the caller frees it)
+void* solve_scratch(size_t bytes, bool* owned);
 // pxr_ba_gram.hip: the per-observation Gram matrices of one solve (storage owned by the context)
 struct GramCache {
   double* G = nullptr;       // [n_obs][176]: ten 4 x 4 blocks of the upper triangle of G = T T^t, then D = T ref

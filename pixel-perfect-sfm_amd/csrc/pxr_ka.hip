@@ -1819,6 +1819,7 @@ extern "C" int pxr_ka_solve(pxr_ctx* ctx, pxr_arena* arena, const pxr_ka_view* v
       // back before giving up
       (void)hipGetLastError();
       if (ctx->d_gram) { (void)hipFree(ctx->d_gram); ctx->d_gram = nullptr; ctx->gram_bytes = 0; }
+      if (ctx->d_solve_arena) { (void)hipFree(ctx->d_solve_arena); ctx->d_solve_arena = nullptr; ctx->solve_arena_bytes = 0; }   // ... and the BA solver's buffers
       PXR_HIP(hipMalloc(buf, want));
     }
     *have = want;

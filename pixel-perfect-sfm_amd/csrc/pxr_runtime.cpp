@@ -81,6 +81,7 @@ int pxr_ctx_destroy(pxr_ctx* ctx) {
   if (ctx->d_workspace) (void)hipFree(ctx->d_workspace);
   if (ctx->d_workspace_mat) (void)hipFree(ctx->d_workspace_mat);
   if (ctx->d_gram) (void)hipFree(ctx->d_gram);
+  if (ctx->d_solve_arena) (void)hipFree(ctx->d_solve_arena);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   if (ctx->ev_sync) (void)hipEventDestroy(ctx->ev_sync);

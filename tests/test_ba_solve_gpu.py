@@ -223,3 +223,38 @@ def test_feature_reference_ba_on_image_intensities(ctx, channels, inner):
     s_cpu, qo, to, ko, Xo = pxo.ba_solve(prob, pxo.cfg(l2_normalize=False), pxo.loss("cauchy", 0.25), *gauge, pxo.lm_options(**kw))
     _assert_same(s_gpu, ba.params(), s_cpu, (qo, to, ko, Xo))
     assert s_gpu["final_cost"] < s_gpu["initial_cost"]
+
+
+@pytest.mark.parametrize("inner", [False, True])
+def test_work_buffer_arena_changes_nothing_and_follows_the_problem_size(monkeypatch, inner):
+    """Round 6: the solve's work buffers come out of one grow-only allocation of the context, sized by the PREVIOUS solve.  A small
+    problem, a larger one (the arena is too small: per-buffer allocation for what does not fit, then it grows), the small one again,
+    and the same three with PXR_BA_ARENA=0: identical bits everywhere (deterministic default)."""
+    from pixsfm_amd import synthetic
+    from pixsfm_amd.engine import BAProblem, Context, PatchArena, interp_cfg, lm_options, make_loss
+    probs = [synthetic.make_ba_problem(n_cams=4, n_points=40, obs_per_point=3, seed=3),
+             synthetic.make_ba_problem(n_cams=7, n_points=260, obs_per_point=4, seed=4),
+             synthetic.make_ba_problem(n_cams=4, n_points=40, obs_per_point=3, seed=3)]
+
+    def run(knob):
+        if knob is None:
+            monkeypatch.delenv("PXR_BA_ARENA", raising=False)
+        else:
+            monkeypatch.setenv("PXR_BA_ARENA", knob)
+        c = Context(0)
+        out = []
+        for prob in probs:
+            arena = PatchArena.from_numpy(c, prob["patches"], prob["corners"], prob["scales"])
+            ba = BAProblem(c, arena, prob)
+            s = ba.solve(interp_cfg(), make_loss("cauchy", [0.25]), *_gauge(prob),
+                         options=lm_options(max_iterations=8, use_inner_iterations=inner))
+            out.append((s["final_cost"], s["iterations"], s["num_successful"]) + ba.params())
+            arena.close()
+        c.close()
+        return out
+    with_arena, without = run(None), run("0")
+    for a, b in zip(with_arena, without):
+        assert a[:3] == b[:3]
+        for x, y in zip(a[3:], b[3:]):
+            assert np.array_equal(x, y)
+    assert with_arena[0][0] == with_arena[2][0] and np.array_equal(with_arena[0][6], with_arena[2][6])     # first == third solve

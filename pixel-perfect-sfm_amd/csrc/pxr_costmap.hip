@@ -423,7 +423,7 @@ __device__ __forceinline__ double swap_sum16(double A, double B) {   // even row
 //   widened halves: 54 instead of 88 vector instructions per lane and texel, the conversions half -> float -> double were 43 % of
 //   the kernel -- and everything across lanes (16 lanes x 4 wavefronts per texel) stays fp64.  A partial sum of eight products
 //   carries ~2e-7 relative; the texel's sum of 16 such partials ~5e-8: the fp16 result differs from the all-fp64 one only where
-//   the exact value lies that close to a rounding boundary (measured: tools/fuzz_costmap_vs_reference.py, tests/test_costmap_*).
+//   the exact value lies that close to a rounding boundary (measured: tests/test_costmap_*; rounds 4-5 also against a stand-in build of the reference that round 6 removed).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: an array of these is split into registers
 template <bool F32> struct TexelRef;

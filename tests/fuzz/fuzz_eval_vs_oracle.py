@@ -1,10 +1,10 @@
 """Randomised parity sweep, HIP kernels against the oracle (NOT part of the test suite; a bug hunt):
 pxr_ba_eval / pxr_ka_eval / pxr_interpolate on random patch shapes, storage types, channel counts, scales, corners, camera
 models 0-10, interpolation switches, keypoints inside / on the border / outside, points in front of and behind the camera.
-python tools/fuzz_eval_vs_oracle.py [n_trials] [seed]"""
+python tests/fuzz/fuzz_eval_vs_oracle.py [n_trials] [seed]"""
 import os
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'pixel-perfect-sfm_amd'))
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import numpy as np

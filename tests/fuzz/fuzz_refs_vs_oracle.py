@@ -1,10 +1,10 @@
 """Randomised sweep of the reference extraction (pxr_ba_compute_references: descriptors at the projections, robust-mean IRLS,
 closest observation) against the oracle -- random track lengths 1..14 (register and L2 paths), losses, iteration counts,
 normalisation, storage types, channel counts, noise levels incl. identical descriptors (the early return).  NOT part of the
-test suite.  python tools/fuzz_refs_vs_oracle.py [n_trials] [seed]"""
+test suite.  python tests/fuzz/fuzz_refs_vs_oracle.py [n_trials] [seed]"""
 import os
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for d in ("pixel-perfect-sfm_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, d))
 import numpy as np

@@ -9,7 +9,7 @@ inner-iteration kernel (PXR_INNER_PACKED=1): the fp32 horizontal pass everywhere
 solvers to the tolerances of rounds 1-3 (final cost / parameters 1e-7, initial cost 1e-9).  `--default-arithmetic` sweeps the
 shipped defaults instead (Gram-matrix algebra, exact fp64), at the one looser tolerance that difference is priced at (5e-6, the
 value of tests/conftest.py FP32_PASS_PARAM_RTOL rounded down).
-python tools/fuzz_solve_vs_oracle.py [n_trials] [seed] [--default-arithmetic]"""
+python tests/fuzz/fuzz_solve_vs_oracle.py [n_trials] [seed] [--default-arithmetic]"""
 import os
 import sys
 DEFAULT_ARITHMETIC = "--default-arithmetic" in sys.argv
@@ -17,7 +17,7 @@ sys.argv = [a for a in sys.argv if a != "--default-arithmetic"]
 if not DEFAULT_ARITHMETIC:
     os.environ["PXR_GRAM_CACHE"] = "0"
     os.environ["PXR_INNER_PACKED"] = "1"
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'pixel-perfect-sfm_amd'))
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import numpy as np

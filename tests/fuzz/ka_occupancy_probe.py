@@ -2,12 +2,12 @@
 runs the default-options KA test problem through the library named by PXR_HIP_LIB (e.g. a build of csrc/pxr_ka.hip with
 -DPXR_KA_WAVES=3) and lists, per sub-problem, where the in-kernel LM departs from the oracle.
 
-    PXR_HIP_LIB=tools/debug/libpixsfm_hip_occ3.so python tools/ka_occupancy_probe.py [max_iterations ...]
+    PXR_HIP_LIB=tools/debug/libpixsfm_hip_occ3.so python tests/fuzz/ka_occupancy_probe.py [max_iterations ...]
 """
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "pixel-perfect-sfm_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np  # noqa: E402

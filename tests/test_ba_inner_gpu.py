@@ -129,7 +129,7 @@ def test_inner_iterations_track_lengths_losses_and_unnormalised(arith, obs_per_p
 @pytest.mark.parametrize("dtype,channels", [(np.float32, 64), (np.float32, 128), (np.float16, 128)])
 def test_inner_iterations_every_camera_model_and_storage(arith, model, dtype, channels):
     """Regression: the packed kernel's fp32-storage instantiation returned garbage pixel coordinates for SIMPLE_PINHOLE
-    (found by tools/fuzz_solve_vs_oracle.py: the unused d(x,y)/dk outputs of the camera model survived as private-memory
+    (found by tests/fuzz/fuzz_solve_vs_oracle.py: the unused d(x,y)/dk outputs of the camera model survived as private-memory
     stores behind a pointer select); the camera model is now instantiated without them there."""
     import pxo
     ctx, cost_tol, _ = arith

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds csrc/pxr_ka.hip with the solve kernel capped at $1 (default 3) wavefronts per SIMD into
 # tools/debug/libpixsfm_hip_occ$1.so (the other objects are those of the regular build: run `make -C
-# pixel-perfect-sfm_amd/csrc` first) -- the input of tools/ka_occupancy_probe.py.
+# pixel-perfect-sfm_amd/csrc` first) -- the input of tests/fuzz/ka_occupancy_probe.py.
 set -e
 W=${1:-3}
 cd "$(dirname "$0")/../pixel-perfect-sfm_amd/csrc"

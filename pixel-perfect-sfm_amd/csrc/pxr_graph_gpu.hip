@@ -1,6 +1,7 @@
 // pxr_graph_gpu.hip -- match-graph labelling on the GPU: ComputeTrackLabels / ComputeScoreLabels /
 // ComputeRootLabels (pixsfm/base/src/graph.cc:126-256) for a flat graph that already lives in HBM, with exactly the
-// reference's results (tests/test_graph_golden.py runs it against vectors produced by graph.cc itself).
+// results of the native host version and of the oracle's restatement (tests/test_graph_gpu.py, tests/test_graph_labelling.py:
+// bit for bit; networkx' connected components on conflict-free graphs).  PARITY UNPINNED w.r.t. graph.cc itself.
 //
 // The reference walks ALL matches once in descending (similarity, src, dst) order, merging two tracks unless they share
 // an image.  A merge only involves the two tracks it touches and only nodes the match graph connects can ever merge, so

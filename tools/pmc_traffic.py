@@ -20,13 +20,14 @@ PER = os.environ.get("PMC_PER_KERNEL")   # a kernel launched ONCE per unit of wo
 
 
 def mean_counter(root, pattern, counter):
-    vals, units = [], 0
+    vals, grids, units = [], [], 0
     for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
             if pattern in r.get("Kernel_Name", ""):
                 vals.append(float(r["Counter_Value"]))
+                grids.append(int(r.get("Grid_Size") or 0))
             if PER and PER in r.get("Kernel_Name", ""):
                 units += 1
     if not vals:
@@ -35,6 +36,10 @@ def mean_counter(root, pattern, counter):
         if not units:
             raise SystemExit("no launches of %s under %s" % (PER, root))
         return sum(vals) / units, units
+    # only the launches of the bench's step: the LARGEST grid (the bench also launches the kernel on the 1/8 problem of its scaling
+    # model and inside the texel-evaluation solves; until round 6 those were averaged in, which read 0.84x instead of 0.93x)
+    top = max(grids)
+    vals = [v for v, g in zip(vals, grids) if g == top]
     return sum(vals) / len(vals), len(vals)
 
 

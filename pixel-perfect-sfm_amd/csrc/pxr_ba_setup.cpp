@@ -6,8 +6,8 @@
 // (feature_reference_bundle_optimizer.h:90-149), then ParameterizePoints / Images / Cameras (:335-453).  A binding dumps
 // the reconstruction into the arrays below (what pycolmap exposes per image / per point) and gets back the observation list
 // and the constancy masks pxr_ba_solve takes -- the walk itself stays native, like in the reference.
-// Checked against the oracle's Python restatement of that set-up code on seeded scenes (oracle/pxo_ba_setup.py,
-// tests/test_ba_setup.py); PARITY UNPINNED: bundle_optimizer.h needs COLMAP / Ceres and cannot be built here.
+// Checked against the Python restatement of that set-up code under oracle/ on seeded scenes
+// (tests/test_ba_setup.py); PARITY UNPINNED: bundle_optimizer.h needs COLMAP / Ceres and cannot be built here.
 #include <algorithm>
 #include <cstdint>
 #include <thread>

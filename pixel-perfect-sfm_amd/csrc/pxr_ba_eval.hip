@@ -25,6 +25,9 @@
 // operation order -> bit-identical h/f values; only the 16-lane reduction order differs.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "pxr_device.h"
 #include "pxr_interp.h"
 #include "pxr_internal.h"
@@ -46,6 +49,8 @@ struct BaEvalArgs {
   double* out_r;
   double* out_gx;
   double* out_gy;
+  int opr;            // observations a lane group walks (<= LPO): 4 from 200k observations on, LPO below (launch_eval) -- same arithmetic
+                      // per observation, only the number of wavefronts in flight changes
 };
 
 template <typename ST, int C, bool WITH_JAC, bool FLOAT_SIMD>
@@ -55,13 +60,14 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(const BaEvalArgs a) {
   const int lane = threadIdx.x & 63;
   const int sub = lane & (LPO - 1);
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int64_t obs0 = (wave * GPW + (lane / LPO)) * LPO;   // first observation of this lane group
+  const int opr = a.opr;                                    // observations per lane group (<= LPO)
+  const int64_t obs0 = (wave * GPW + (lane / LPO)) * opr;   // first observation of this lane group
   const int64_t n = a.v.n_obs;
-  if (wave * 64 >= n) return;                               // whole wave out of range (uniform)
+  if (wave * GPW * opr >= n) return;                        // whole wave out of range (uniform)
 
-  // ---- prologue: lane `sub` owns the geometry of observation obs0 + sub -----------------
+  // ---- prologue: lane `sub` (< opr) owns the geometry of observation obs0 + sub -----------------
   const int64_t mine = obs0 + sub;
-  const bool mine_valid = mine < n;
+  const bool mine_valid = sub < opr && mine < n;
   const int64_t oi = mine_valid ? mine : n - 1;
   const int img = a.v.d_obs_image[oi];
   const int pt = a.v.d_obs_point[oi];
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(const BaEvalArgs a) {
   const ST* arena = reinterpret_cast<const ST*>(a.arena);
   const int row_base = lane & ~(LPO - 1);
 
-  for (int it = 0; it < LPO; ++it) {
+  for (int it = 0; it < opr; ++it) {
     if (obs0 + it >= n) break;   // uniform within the lane group
     const int src = row_base | it;
     const double u = shfl_f64(my_u, src), v = shfl_f64(my_v, src);
@@ -284,11 +290,18 @@ __global__ __launch_bounds__(256) void ba_cost_kernel(const double* __restrict__
 }
 
 template <typename ST, int C>
-static int launch_eval(pxr_ctx* ctx, const BaEvalArgs& a, bool with_jac, bool float_simd) {
+static int launch_eval(pxr_ctx* ctx, const BaEvalArgs& a_in, bool with_jac, bool float_simd) {
   constexpr int LPO = C / 8;
-  const int64_t obs_per_block = 4 * 64;   // 4 waves x (64/LPO groups x LPO obs)
+  BaEvalArgs a = a_in;
+  // How many observations a lane group walks (round 6; until then always LPO = 16: lane s computes the projection of observation
+  // s, then the row walks its 16 observations).  With 4 the launch has four times the wavefronts -- each with sixteen 16-byte
+  // loads per lane in flight -- and a quarter of the projection lanes idle: measured on MI355X, alternating runs of the bench
+  // (ms per step, 16 / 4 observations per group): 1M observations 0.802-0.813 / 0.768-0.793, 500k 0.404 / 0.388, 250k 0.206 /
+  // 0.202, 125k 0.1046 / 0.1066 (6 and 8 per group: worse than both below 250k).  PXR_BA_EVAL_OPR=<n> forces a value.
+  static const int opr_knob = std::getenv("PXR_BA_EVAL_OPR") ? atoi(std::getenv("PXR_BA_EVAL_OPR")) : 0;
+  a.opr = opr_knob > 0 ? std::min(opr_knob, LPO) : (a.v.n_obs >= 200000 ? std::min(4, LPO) : LPO);
+  const int64_t obs_per_block = 4 * (64 / LPO) * a.opr;   // 4 waves x (64 / LPO groups x opr observations)
   const int64_t blocks = (a.v.n_obs + obs_per_block - 1) / obs_per_block;
-  (void)LPO;
   if (blocks == 0) return PXR_OK;
   dim3 grid((unsigned)blocks), block(256);
   if (with_jac) {

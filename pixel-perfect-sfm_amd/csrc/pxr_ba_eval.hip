@@ -53,10 +53,7 @@ struct BaEvalArgs {
                       // per observation, only the number of wavefronts in flight changes
 };
 
-// PIPE (round 6; the small launches: a 125k-observation shard of an 8-GPU run is 1953 wavefronts, under two per SIMD, so nothing
-// hides a wavefront's own load -> compute chain): the stencil of observation it + 1 is requested BEFORE observation it is computed,
-// a second set of sixteen texel registers (2 wavefronts per SIMD).  Same operations in the same order per observation.
-template <typename ST, int C, bool WITH_JAC, bool FLOAT_SIMD, bool PIPE = false>
+template <typename ST, int C, bool WITH_JAC, bool FLOAT_SIMD>
 __global__ __launch_bounds__(256) void ba_eval_kernel(const BaEvalArgs a) {
   constexpr int LPO = C / 8;            // lanes per observation (16 for C = 128)
   constexpr int GPW = 64 / LPO;         // observation groups per wave
@@ -99,15 +96,6 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(const BaEvalArgs a) {
   const ST* arena = reinterpret_cast<const ST*>(a.arena);
   const int row_base = lane & ~(LPO - 1);
 
-  // PIPE: the stencil of the observation the loop is ABOUT to compute (requested one iteration ahead)
-  StencilIndex si_n;
-  Texel8<ST> tx_n[4][4];
-  if constexpr (PIPE) {
-    const double u0 = shfl_f64(my_u, row_base), v0 = shfl_f64(my_v, row_base);
-    si_n = stencil_index(a.H, a.W, u0, v0);
-    interp8_load<ST>(arena + (size_t)shfl_i64(pidx, row_base) * patch_elems, C, sub * 8, si_n, tx_n);
-  }
-#pragma unroll 2
   for (int it = 0; it < opr; ++it) {
     if (obs0 + it >= n) break;   // uniform within the lane group
     const int src = row_base | it;
@@ -126,22 +114,8 @@ __global__ __launch_bounds__(256) void ba_eval_kernel(const BaEvalArgs a) {
     }
 
     double f[8], fr[8], fc[8];
-    if constexpr (PIPE) {
-      const StencilIndex si_c = si_n;
-      Texel8<ST> tx_c[4][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tx_c[j][i] = tx_n[j][i];
-      // the next observation's stencil goes out now (the last one asks for its own again: no branch around the loads)
-      const int nxt = row_base | min(it + 1, min(opr - 1, (int)(n - 1 - obs0)));
-      si_n = stencil_index(a.H, a.W, shfl_f64(my_u, nxt), shfl_f64(my_v, nxt));
-      interp8_load<ST>(arena + (size_t)shfl_i64(pidx, nxt) * patch_elems, C, sub * 8, si_n, tx_n);
-      interp8_from_texels<ST, LPO, WITH_JAC, FLOAT_SIMD>(tx_c, si_c, a.l2_normalize != 0, f, fr, fc);
-    } else {
-      interp8<ST, LPO, WITH_JAC, FLOAT_SIMD>(arena + (size_t)pi * patch_elems, a.H, a.W, C, sub, u, v,
-                                             a.l2_normalize != 0, f, fr, fc);
-    }
+    interp8<ST, LPO, WITH_JAC, FLOAT_SIMD>(arena + (size_t)pi * patch_elems, a.H, a.W, C, sub, u, v,
+                                           a.l2_normalize != 0, f, fr, fc);
     const double ref[8] = {rf0.x, rf0.y, rf1.x, rf1.y, rf2.x, rf2.y, rf3.x, rf3.y};
     double r[8];
     double s = 0, gcc = 0, gcr = 0, grr = 0, bc = 0, br = 0;
@@ -330,11 +304,8 @@ static int launch_eval(pxr_ctx* ctx, const BaEvalArgs& a_in, bool with_jac, bool
   const int64_t blocks = (a.v.n_obs + obs_per_block - 1) / obs_per_block;
   if (blocks == 0) return PXR_OK;
   dim3 grid((unsigned)blocks), block(256);
-  static const int pipe_knob = std::getenv("PXR_BA_EVAL_PIPE") ? atoi(std::getenv("PXR_BA_EVAL_PIPE")) : -1;   // A/B: 0 never, 1 always
-  const bool pipe = pipe_knob >= 0 ? pipe_knob != 0 : a.v.n_obs < 200000;
   if (with_jac) {
     if (float_simd) hipLaunchKernelGGL((ba_eval_kernel<ST, C, true, true>), grid, block, 0, ctx->stream, a);
-    else if (pipe && a.out_r == nullptr) hipLaunchKernelGGL((ba_eval_kernel<ST, C, true, false, true>), grid, block, 0, ctx->stream, a);
     else hipLaunchKernelGGL((ba_eval_kernel<ST, C, true, false>), grid, block, 0, ctx->stream, a);
   } else {
     if (float_simd) hipLaunchKernelGGL((ba_eval_kernel<ST, C, false, true>), grid, block, 0, ctx->stream, a);

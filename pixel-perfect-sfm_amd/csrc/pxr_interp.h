@@ -172,36 +172,13 @@ __device__ __forceinline__ void interp8_raw(const ST* __restrict__ patch, int H,
 
 // Normalised descriptor + gradients of 8 channels of one observation, all lanes of the
 // observation's lane group cooperating.  LPO = lanes per observation (C / 8).
-// L2 normalisation + chain rule of 8 channels per lane, the lane group cooperating (PixelInterpolator::Evaluate,
-// interpolation.h:648-666)
-template <int LPO, bool WITH_JAC>
-__device__ __forceinline__ void interp8_normalize(double f[8], double fr[8], double fc[8]);
-
-// the same from texels that are already in registers (a kernel that requested the NEXT observation's stencil before it
-// computes the current one: ba_eval_kernel<..., PIPE>): horizontal pass, vertical pass, normalisation -- the very operations of
-// interp8 below, in the same order
-template <typename ST, int LPO, bool WITH_JAC, bool FLOAT_SIMD>
-__device__ __forceinline__ void interp8_from_texels(const Texel8<ST> (&tx)[4][4], const StencilIndex& si, bool l2_normalize,
-                                                    double f[8], double fr[8], double fc[8]) {
-  typedef typename Texel8<ST>::work_t HT;
-  HT h[4][8], hd[4][8];
-  interp8_horizontal<ST, WITH_JAC, FLOAT_SIMD>(tx, si.dx, h, hd);
-  interp8_vertical<HT, WITH_JAC, FLOAT_SIMD>(h, hd, si.dy, f, fr, fc, nullptr);
-  if (l2_normalize) interp8_normalize<LPO, WITH_JAC>(f, fr, fc);
-}
-
 template <typename ST, int LPO, bool WITH_JAC, bool FLOAT_SIMD>
 __device__ __forceinline__ void interp8(const ST* __restrict__ patch, int H, int W, int C, int sub,
                                         double u, double v, bool l2_normalize, double f[8],
                                         double fr[8], double fc[8], double* frc = nullptr) {
   interp8_raw<ST, WITH_JAC, FLOAT_SIMD>(patch, H, W, C, sub * 8, u, v, f, fr, fc, frc);
-  if (l2_normalize) interp8_normalize<LPO, WITH_JAC>(f, fr, fc);
-}
-
-template <int LPO, bool WITH_JAC>
-__device__ __forceinline__ void interp8_normalize(double f[8], double fr[8], double fc[8]) {
   // PixelInterpolator::Evaluate L2 normalisation + chain rule, interpolation.h:648-666
-  {
+  if (l2_normalize) {
     double ss = 0.0;
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) ss = fma(f[ch], f[ch], ss);

@@ -75,7 +75,7 @@ class KaView(C.Structure):
                 ("d_unary_ref", C.c_void_p), ("d_unary_w", C.c_void_p), ("d_prob_unary_ptr", C.c_void_p),
                 ("d_prob_unary", C.c_void_p), ("d_prob_group", C.c_void_p)]
 
-# every symbol include/pixsfm_hip.h declares (checked by tests/test_cabi.py)
+# every symbol include/pixsfm_hip.h declares (checked by tests/test_cabi_and_host.py)
 _SIGNATURES = {
     "pxr_version": (C.c_int, []),
     "pxr_last_error": (C.c_char_p, []),
